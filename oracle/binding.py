@@ -1,0 +1,258 @@
+"""ctypes binding of the CPU oracle (oracle/lantern_oracle.h).
+
+TEST INFRASTRUCTURE.  Importable only from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under lantern_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "liblantern_oracle.so")
+
+METRIC_COS, METRIC_L2SQ, METRIC_HAMMING = 1, 3, 8
+SUM_SEQ, SUM_WAVE64, SUM_FAST = 0, 1, 2
+EMPTY = 0xFFFFFFFF
+
+METRICS = {"cos": METRIC_COS, "l2sq": METRIC_L2SQ, "hamming": METRIC_HAMMING}
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with its Makefile (gcc only)."""
+    if force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB_PATH)
+        for f in ("hnsw.c", "metrics.c", "metrics_fast.c", "lantern_oracle.h", "Makefile")
+    ):
+        subprocess.check_call(["make", "-s", "-C", HERE])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int
+    L.lo_distance.restype = C.c_float
+    L.lo_distance.argtypes = [vp, vp, sz, i32, i32]
+    L.lo_wave_group_lanes.restype = i32
+    L.lo_wave_group_lanes.argtypes = [sz]
+    L.lo_level_for.restype = i32
+    L.lo_level_for.argtypes = [u64, u64, u32]
+    L.lo_bruteforce.restype = None
+    L.lo_bruteforce.argtypes = [vp, sz, sz, i32, i32, vp, sz, sz, vp, vp, i32]
+    L.lo_create.restype = vp
+    L.lo_create.argtypes = [i32, sz, u32, u32, u32, u64, i32]
+    L.lo_free.argtypes = [vp]
+    L.lo_reserve.argtypes = [vp, sz]
+    L.lo_size.restype = sz
+    L.lo_size.argtypes = [vp]
+    L.lo_capacity.restype = sz
+    L.lo_capacity.argtypes = [vp]
+    L.lo_max_level.argtypes = [vp]
+    L.lo_entry_slot.restype = u32
+    L.lo_entry_slot.argtypes = [vp]
+    L.lo_add.argtypes = [vp, u64, vp]
+    L.lo_add_with_level.argtypes = [vp, u64, vp, i32]
+    L.lo_add_batch.argtypes = [vp, vp, vp, sz]
+    L.lo_plan_batch.restype = sz
+    L.lo_plan_batch.argtypes = [sz, i32, vp, sz, sz, sz]
+    L.lo_search.restype = sz
+    L.lo_search.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp]
+    L.lo_search_batch.restype = None
+    L.lo_search_batch.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp, vp, i32]
+    L.lo_last_distance_evals.restype = u64
+    L.lo_last_distance_evals.argtypes = [vp]
+    L.lo_last_expansions.restype = u64
+    L.lo_last_expansions.argtypes = [vp]
+    L.lo_upper_blocks.restype = sz
+    L.lo_upper_blocks.argtypes = [vp]
+    L.lo_export_graph.restype = None
+    L.lo_export_graph.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.lo_import_graph.restype = vp
+    L.lo_import_graph.argtypes = [i32, sz, u32, u32, u32, u64, i32, sz, vp, vp, vp, vp, vp, vp, u32, i32, i32]
+    L.lo_estimate_visited_tuples.restype = u64
+    L.lo_estimate_visited_tuples.argtypes = [C.c_double, u32, u32]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _rows(x, metric):
+    """f32 rows for cos/l2sq, u32 words for hamming; C-contiguous 2-D."""
+    dt = np.uint32 if metric == METRIC_HAMMING else np.float32
+    a = np.ascontiguousarray(x, dtype=dt)
+    return a.reshape(1, -1) if a.ndim == 1 else a
+
+
+def distance(a, b, metric: str | int, sum_mode: int = SUM_SEQ) -> float:
+    m = METRICS.get(metric, metric)
+    A, B = _rows(a, m)[0], _rows(b, m)[0]
+    if A.shape != B.shape:
+        raise ValueError("expected equally sized arrays")
+    dims = A.size * 32 if m == METRIC_HAMMING else A.size
+    return float(lib().lo_distance(_ptr(A), _ptr(B), dims, m, sum_mode))
+
+
+def level_for(seed: int, slot: int, M: int) -> int:
+    return int(lib().lo_level_for(seed, slot, M))
+
+
+def plan_batch(size, max_level, pending_levels, max_batch, min_ratio) -> int:
+    lv = np.ascontiguousarray(pending_levels, dtype=np.int32)
+    return int(lib().lo_plan_batch(size, max_level, _ptr(lv), lv.size, max_batch, min_ratio))
+
+
+def bruteforce(rows, queries, k, metric, sum_mode=SUM_SEQ, nthreads=1):
+    m = METRICS.get(metric, metric)
+    R, Q = _rows(rows, m), _rows(queries, m)
+    dims = R.shape[1] * 32 if m == METRIC_HAMMING else R.shape[1]
+    ids = np.empty((Q.shape[0], k), dtype=np.uint32)
+    dists = np.empty((Q.shape[0], k), dtype=np.float32)
+    lib().lo_bruteforce(_ptr(R), R.shape[0], dims, m, sum_mode, _ptr(Q), Q.shape[0], k, _ptr(ids), _ptr(dists), nthreads)
+    return ids, dists
+
+
+class OracleIndex:
+    """The oracle's HNSW index (usearch semantics; see oracle/hnsw.c)."""
+
+    def __init__(self, metric, dims, M=16, ef_construction=128, ef=64, seed=42, sum_mode=SUM_SEQ, _handle=None,
+                 _keep=None):
+        self.metric = METRICS.get(metric, metric)
+        self.dims = dims  # f32 scalars, or u32 WORDS for hamming (bits = 32*dims, scan.c:84-88)
+        self.M, self.efc, self.ef, self.seed, self.sum_mode = M, ef_construction, ef, seed, sum_mode
+        self._keep = _keep
+        bits_or_dims = dims * 32 if self.metric == METRIC_HAMMING else dims
+        self.h = _handle or lib().lo_create(self.metric, bits_or_dims, M, ef_construction, ef, seed, sum_mode)
+        if not self.h:
+            raise ValueError("lo_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lo_free(self.h)
+            self.h = None
+
+    def __len__(self):
+        return int(lib().lo_size(self.h))
+
+    @property
+    def max_level(self):
+        return int(lib().lo_max_level(self.h))
+
+    @property
+    def entry_slot(self):
+        return int(lib().lo_entry_slot(self.h))
+
+    def reserve(self, n):
+        lib().lo_reserve(self.h, n)
+
+    def add(self, label, vec, level=None):
+        v = _rows(vec, self.metric)[0]
+        assert v.size == self.dims, "dimension mismatch"
+        if level is None:
+            rc = lib().lo_add(self.h, int(label), _ptr(v))
+        else:
+            rc = lib().lo_add_with_level(self.h, int(label), _ptr(v), int(level))
+        assert rc == 0
+
+    def add_many(self, labels, vecs):
+        for l, v in zip(labels, _rows(vecs, self.metric)):
+            self.add(l, v)
+
+    def add_batch(self, labels, vecs):
+        V = _rows(vecs, self.metric)
+        lab = np.ascontiguousarray(labels, dtype=np.uint64)
+        rc = lib().lo_add_batch(self.h, _ptr(lab), _ptr(V), V.shape[0])
+        assert rc == 0, rc
+
+    def add_planned(self, labels, vecs, max_batch=4096, min_ratio=16):
+        """Insert with the device builder's batch plan (lo_plan_batch)."""
+        V = _rows(vecs, self.metric)
+        lab = np.ascontiguousarray(labels, dtype=np.uint64)
+        i, n = 0, V.shape[0]
+        while i < n:
+            size = len(self)
+            look = min(n - i, max_batch)
+            lv = [level_for(self.seed, size + j, self.M) for j in range(look)]
+            b = plan_batch(size, self.max_level, lv, max_batch, min_ratio)
+            self.add_batch(lab[i:i + b], V[i:i + b])
+            i += b
+
+    def search(self, query, k, ef=0, skip=0):
+        q = _rows(query, self.metric)[0]
+        labels = np.zeros(k, dtype=np.uint64)
+        dists = np.zeros(k, dtype=np.float32)
+        slots = np.zeros(k, dtype=np.uint32)
+        n = lib().lo_search(self.h, _ptr(q), k, ef, skip, _ptr(labels), _ptr(dists), _ptr(slots))
+        return labels[:n], dists[:n], slots[:n]
+
+    def last_counters(self):
+        return int(lib().lo_last_distance_evals(self.h)), int(lib().lo_last_expansions(self.h))
+
+    def search_batch(self, queries, k, ef=0, nthreads=1):
+        Q = _rows(queries, self.metric)
+        nq = Q.shape[0]
+        labels = np.zeros((nq, k), dtype=np.uint64)
+        dists = np.zeros((nq, k), dtype=np.float32)
+        slots = np.zeros((nq, k), dtype=np.uint32)
+        D = np.zeros(nq, dtype=np.uint64)
+        E = np.zeros(nq, dtype=np.uint64)
+        lib().lo_search_batch(self.h, _ptr(Q), nq, k, ef, _ptr(labels), _ptr(dists), _ptr(slots), _ptr(D), _ptr(E),
+                              nthreads)
+        return labels, dists, slots, D, E
+
+    def export_graph(self):
+        n, M = len(self), self.M
+        blocks = int(lib().lo_upper_blocks(self.h))
+        g = {
+            "levels": np.zeros(n, dtype=np.uint8),
+            "nbr0": np.zeros((n, 2 * M), dtype=np.uint32),
+            "upper_off": np.zeros(n, dtype=np.uint32),
+            "upper_nbr": np.zeros((max(blocks, 1), M), dtype=np.uint32),
+            "labels": np.zeros(n, dtype=np.uint64),
+        }
+        lib().lo_export_graph(self.h, _ptr(g["levels"]), _ptr(g["nbr0"]), _ptr(g["upper_off"]), _ptr(g["upper_nbr"]),
+                              _ptr(g["labels"]))
+        g["upper_nbr"] = g["upper_nbr"][:blocks]
+        g["entry_slot"] = self.entry_slot
+        g["max_level"] = self.max_level
+        return g
+
+    @classmethod
+    def from_graph(cls, metric, vectors, graph, M, ef_construction=128, ef=64, seed=42, sum_mode=SUM_SEQ,
+                   borrow=True):
+        m = METRICS.get(metric, metric)
+        V = _rows(vectors, m)
+        n, dims = V.shape
+        bits_or_dims = dims * 32 if m == METRIC_HAMMING else dims
+        levels = np.ascontiguousarray(graph["levels"], dtype=np.uint8)
+        nbr0 = np.ascontiguousarray(graph["nbr0"], dtype=np.uint32)
+        upper_off = np.ascontiguousarray(graph["upper_off"], dtype=np.uint32)
+        upper_nbr = np.ascontiguousarray(graph["upper_nbr"], dtype=np.uint32)
+        labels = np.ascontiguousarray(graph["labels"], dtype=np.uint64) if graph.get("labels") is not None else None
+        h = lib().lo_import_graph(m, bits_or_dims, M, ef_construction, ef, seed, sum_mode, n, _ptr(V), _ptr(labels),
+                                  _ptr(levels), _ptr(nbr0), _ptr(upper_off), _ptr(upper_nbr),
+                                  int(graph["entry_slot"]), int(graph["max_level"]), 1 if borrow else 0)
+        return cls(metric, dims, M, ef_construction, ef, seed, sum_mode, _handle=h, _keep=V if borrow else None)
+
+
+def recall_at_k(found_ids, true_ids) -> float:
+    """|top-k_ann ∩ top-k_exact| / k averaged over queries (index_autotune/mod.rs:239-247,
+    test/sql/utils/calculate_recall.sql:9-24)."""
+    f, t = np.asarray(found_ids), np.asarray(true_ids)
+    hits = 0
+    for a, b in zip(f, t):
+        hits += len(set(int(x) for x in a if x != EMPTY) & set(int(x) for x in b if x != EMPTY))
+    return hits / float(t.shape[0] * t.shape[1])

@@ -1,0 +1,731 @@
+/*
+ * hnsw.c -- oracle HNSW (TEST INFRASTRUCTURE; see lantern_oracle.h for scope and pinning).
+ *
+ * Restates the usearch 2.x index_gt algorithm as Lantern drives it:
+ *   add      <- usearch_add              lantern_hnsw/src/hnsw/build.c:83-135 (AddTupleToUsearchIndex)
+ *               index.add_raw            lantern_cli/src/external_index/server.rs:333-356
+ *               usearch_add_external     lantern_hnsw/src/hnsw/insert.c:209
+ *   search   <- usearch_search_ef        lantern_hnsw/src/hnsw/scan.c:220-228, :273-281
+ * Function names in comments (search_for_one_, search_to_insert_, search_to_find_in_base_,
+ * refine_, connect_new_node_, reconnect_neighbor_nodes_) are the upstream usearch names of
+ * the steps being restated.
+ */
+#include "lantern_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+float lo_hamming_fast(const void *pa, const void *pb, size_t bits); /* metrics_fast.c */
+
+typedef struct
+{
+    float    d;
+    uint32_t id;
+} cand_t;
+
+/* total order (distance, slot): see header, "deliberate deviations" */
+static inline int cand_less(cand_t a, cand_t b) { return a.d < b.d || (a.d == b.d && a.id < b.id); }
+
+typedef struct
+{
+    uint32_t *visited; /* epoch stamps, one per slot */
+    size_t    visited_cap;
+    uint32_t  epoch;
+    cand_t   *next; /* binary min-heap ("next" in usearch) */
+    size_t    next_n, next_cap;
+    cand_t   *top; /* ascending sorted buffer, bounded ("top" in usearch) */
+    size_t    top_n, top_cap;
+    uint64_t  D, E; /* distance evaluations / expanded nodes */
+} lo_ctx;
+
+struct lo_index
+{
+    int       metric, sum_mode;
+    size_t    dims, vec_bytes;
+    uint32_t  M, M0, efc, ef;
+    uint64_t  seed;
+    size_t    n, cap;
+    uint8_t  *vecs;
+    int       vecs_borrowed;
+    uint64_t *labels;
+    uint8_t  *levels;
+    uint32_t *nbr0;
+    uint32_t *upper_off;
+    uint32_t *upper_nbr;
+    size_t    upper_blocks, upper_cap;
+    uint32_t  entry;
+    int       max_level;
+    lo_ctx    ctx;
+    uint64_t  last_D, last_E;
+};
+
+/* ---------------------------------------------------------------------------------------- */
+
+static void ctx_free(lo_ctx *c)
+{
+    free(c->visited);
+    free(c->next);
+    free(c->top);
+    memset(c, 0, sizeof(*c));
+}
+
+static void ctx_fit(lo_ctx *c, size_t slots, size_t top_cap)
+{
+    if(c->visited_cap < slots) {
+        free(c->visited);
+        c->visited = (uint32_t *)calloc(slots, sizeof(uint32_t));
+        c->visited_cap = slots;
+        c->epoch = 0;
+    }
+    if(c->top_cap < top_cap + 1) {
+        c->top_cap = top_cap + 1;
+        c->top = (cand_t *)realloc(c->top, c->top_cap * sizeof(cand_t));
+    }
+}
+
+static void visits_clear(lo_ctx *c)
+{
+    if(++c->epoch == 0) {
+        memset(c->visited, 0, c->visited_cap * sizeof(uint32_t));
+        c->epoch = 1;
+    }
+}
+/* returns 1 if it was already set (usearch visits.set semantics) */
+static inline int visits_set(lo_ctx *c, uint32_t slot)
+{
+    if(c->visited[ slot ] == c->epoch) return 1;
+    c->visited[ slot ] = c->epoch;
+    return 0;
+}
+
+static void next_push(lo_ctx *c, cand_t x)
+{
+    if(c->next_n == c->next_cap) {
+        c->next_cap = c->next_cap ? c->next_cap * 2 : 256;
+        c->next = (cand_t *)realloc(c->next, c->next_cap * sizeof(cand_t));
+    }
+    size_t i = c->next_n++;
+    while(i > 0) {
+        size_t p = (i - 1) / 2;
+        if(!cand_less(x, c->next[ p ])) break;
+        c->next[ i ] = c->next[ p ];
+        i = p;
+    }
+    c->next[ i ] = x;
+}
+
+static cand_t next_pop(lo_ctx *c)
+{
+    cand_t best = c->next[ 0 ];
+    cand_t x = c->next[ --c->next_n ];
+    size_t i = 0, n = c->next_n;
+    for(;;) {
+        size_t l = 2 * i + 1, r = l + 1, m;
+        if(l >= n) break;
+        m = (r < n && cand_less(c->next[ r ], c->next[ l ])) ? r : l;
+        if(!cand_less(c->next[ m ], x)) break;
+        c->next[ i ] = c->next[ m ];
+        i = m;
+    }
+    if(n) c->next[ i ] = x;
+    return best;
+}
+
+/* sorted_buffer_gt::insert(element, limit): keep the `limit` smallest; returns 1 if kept */
+static int top_insert(lo_ctx *c, cand_t x, size_t limit)
+{
+    size_t lo = 0, hi = c->top_n;
+    while(lo < hi) {
+        size_t mid = (lo + hi) / 2;
+        if(cand_less(c->top[ mid ], x))
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if(lo == limit) return 0;
+    size_t last = c->top_n < limit ? c->top_n : limit - 1;
+    for(size_t i = last; i > lo; --i) c->top[ i ] = c->top[ i - 1 ];
+    c->top[ lo ] = x;
+    if(c->top_n < limit) c->top_n++;
+    return 1;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+
+const void *lo_vector(const lo_index *ix, uint32_t slot) { return ix->vecs + (size_t)slot * ix->vec_bytes; }
+
+static inline float measure_raw(const lo_index *ix, const void *a, const void *b)
+{
+    if(ix->metric == LO_METRIC_HAMMING) {
+        if(ix->sum_mode == LO_SUM_FAST) return lo_hamming_fast(a, b, ix->dims);
+        return lo_distance(a, b, ix->dims, LO_METRIC_HAMMING, 0);
+    }
+    return lo_distance(a, b, ix->dims, ix->metric, ix->sum_mode);
+}
+
+static inline float measure(const lo_index *ix, lo_ctx *c, const void *q, uint32_t slot)
+{
+    c->D++;
+    return measure_raw(ix, q, lo_vector(ix, slot));
+}
+
+static inline uint32_t *neighbors(const lo_index *ix, uint32_t slot, int level, uint32_t *cap)
+{
+    if(level == 0) {
+        *cap = ix->M0;
+        return ix->nbr0 + (size_t)slot * ix->M0;
+    }
+    *cap = ix->M;
+    return ix->upper_nbr + ((size_t)ix->upper_off[ slot ] + (size_t)(level - 1)) * ix->M;
+}
+
+static inline uint32_t nbr_count(const uint32_t *list, uint32_t cap)
+{
+    uint32_t n = 0;
+    while(n < cap && list[ n ] != LO_EMPTY_SLOT) ++n;
+    return n;
+}
+
+/* usearch choose_random_level_: floor(-ln(U) / ln(M)); Lantern's copy: insert.c:32-46.
+ * U comes from a stateless splitmix64 hash of (seed, slot) so any builder reproduces it. */
+static uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+int lo_level_for(uint64_t seed, uint64_t slot, uint32_t connectivity)
+{
+    uint64_t h = splitmix64(seed ^ splitmix64(slot + 0x632BE59BD9B4E019ull));
+    double   u = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740992.0); /* (0,1] */
+    double   level = -log(u) * (1.0 / log((double)connectivity));
+    if(level > 255.0) level = 255.0; /* levels are stored in a byte here; usearch uses int16 */
+    return (int)level;
+}
+
+/* ---- search_for_one_: greedy descent over levels (begin, end] ---------------------------- */
+static uint32_t search_for_one(const lo_index *ix, lo_ctx *c, const void *q, uint32_t closest, int begin_level,
+                               int end_level)
+{
+    float closest_d = measure(ix, c, q, closest);
+    for(int level = begin_level; level > end_level; --level) {
+        int changed;
+        do {
+            changed = 0;
+            uint32_t        cap;
+            const uint32_t *list = neighbors(ix, closest, level, &cap);
+            for(uint32_t i = 0; i < cap && list[ i ] != LO_EMPTY_SLOT; ++i) {
+                float d = measure(ix, c, q, list[ i ]);
+                if(d < closest_d) {
+                    closest_d = d;
+                    closest = list[ i ];
+                    changed = 1;
+                }
+            }
+        } while(changed);
+    }
+    return closest;
+}
+
+/* ---- search_to_insert_ / search_to_find_in_base_ ---------------------------------------- */
+/* Leaves the result in c->top (ascending, <= top_limit). */
+static void search_level(const lo_index *ix, lo_ctx *c, const void *q, uint32_t start, int level, size_t top_limit)
+{
+    visits_clear(c);
+    c->next_n = 0;
+    c->top_n = 0;
+    cand_t s = { measure(ix, c, q, start), start };
+    next_push(c, s);
+    top_insert(c, s, top_limit);
+    visits_set(c, start);
+    while(c->next_n) {
+        cand_t cand = c->next[ 0 ];
+        cand_t worst = c->top[ c->top_n - 1 ];
+        if(cand_less(worst, cand) && c->top_n == top_limit) break;
+        next_pop(c);
+        c->E++;
+        uint32_t        cap;
+        const uint32_t *list = neighbors(ix, cand.id, level, &cap);
+        for(uint32_t i = 0; i < cap && list[ i ] != LO_EMPTY_SLOT; ++i) {
+            uint32_t succ = list[ i ];
+            if(visits_set(c, succ)) continue;
+            cand_t x = { measure(ix, c, q, succ), succ };
+            if(c->top_n < top_limit || cand_less(x, c->top[ c->top_n - 1 ])) {
+                next_push(c, x);
+                top_insert(c, x, top_limit);
+            }
+        }
+    }
+}
+
+/* ---- refine_: the HNSW neighbour-selection heuristic -------------------------------------- */
+/*
+ * usearch sorts refine_'s input by distance only (std::sort, ties in arbitrary order).  A fixed
+ * (distance, slot) order here would make every exact duplicate choose the same few lowest slots
+ * as neighbours and make re-pruning always drop the newest duplicate, which starves duplicates of
+ * in-links (the reference's pagination test inserts 1000 identical rows: test/sql/hnsw_select.sql
+ * :77-119).  Ties are therefore ordered by a per-centre pseudo-random permutation of the slots:
+ * deterministic, a total order, and different for every centre.
+ */
+static inline uint32_t tie_mix(uint32_t id, uint32_t centre) { return (id ^ (centre * 0x9E3779B1u)) * 0x85EBCA6Bu; }
+
+static uint32_t g_sort_centre; /* qsort context (oracle is single-threaded while building) */
+static int      refine_cmp(const void *a, const void *b)
+{
+    cand_t x = *(const cand_t *)a, y = *(const cand_t *)b;
+    if(x.d != y.d) return x.d < y.d ? -1 : 1;
+    uint32_t hx = tie_mix(x.id, g_sort_centre), hy = tie_mix(y.id, g_sort_centre);
+    return hx < hy ? -1 : (hx > hy ? 1 : 0);
+}
+
+/* list[0..n): candidates with their distance to `centre`; sorted here; keeps <= needed. */
+static size_t refine(const lo_index *ix, cand_t *list, size_t n, size_t needed, uint32_t centre)
+{
+    g_sort_centre = centre;
+    qsort(list, n, sizeof(cand_t), refine_cmp);
+    if(n < needed) return n;
+    size_t submitted = 1, consumed = 1;
+    while(submitted < needed && consumed < n) {
+        cand_t cand = list[ consumed ];
+        int    good = 1;
+        for(size_t i = 0; i < submitted; ++i) {
+            float inter = measure_raw(ix, lo_vector(ix, cand.id), lo_vector(ix, list[ i ].id));
+            if(inter < cand.d) {
+                good = 0;
+                break;
+            }
+        }
+        if(good) list[ submitted++ ] = list[ consumed ];
+        consumed++;
+    }
+    return submitted;
+}
+
+/* ---- reconnect_neighbor_nodes_ for one (close, level) and one incoming new node ----------- */
+static void reverse_link(lo_index *ix, uint32_t close, int level, uint32_t new_slot, float d_new_close)
+{
+    uint32_t  cap;
+    uint32_t *list = neighbors(ix, close, level, &cap);
+    uint32_t  cnt = nbr_count(list, cap);
+    if(cnt < cap) {
+        list[ cnt ] = new_slot;
+        return;
+    }
+    cand_t tmp[ 1 + 512 ];
+    size_t n = 0;
+    tmp[ n++ ] = (cand_t){ d_new_close, new_slot };
+    for(uint32_t i = 0; i < cnt; ++i)
+        tmp[ n++ ] = (cand_t){ measure_raw(ix, lo_vector(ix, close), lo_vector(ix, list[ i ])), list[ i ] };
+    size_t keep = refine(ix, tmp, n, cap, close);
+    for(uint32_t i = 0; i < cap; ++i) list[ i ] = i < keep ? tmp[ i ].id : LO_EMPTY_SLOT;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+
+lo_index *lo_create(int metric, size_t dims, uint32_t M, uint32_t efc, uint32_t ef, uint64_t seed, int sum_mode)
+{
+    if(M < 2 || M > 256) return NULL;
+    lo_index *ix = (lo_index *)calloc(1, sizeof(lo_index));
+    ix->metric = metric;
+    ix->sum_mode = sum_mode;
+    ix->dims = dims;
+    ix->vec_bytes = metric == LO_METRIC_HAMMING ? (dims + 7) / 8 : dims * sizeof(float);
+    ix->M = M;
+    ix->M0 = 2 * M; /* validate_index.c:140-151: level 0 holds 2M slots, upper levels M */
+    ix->efc = efc ? efc : 128;
+    ix->ef = ef ? ef : 64; /* options.h:18-24 defaults */
+    ix->seed = seed;
+    ix->entry = LO_EMPTY_SLOT;
+    ix->max_level = -1;
+    return ix;
+}
+
+void lo_free(lo_index *ix)
+{
+    if(!ix) return;
+    if(!ix->vecs_borrowed) free(ix->vecs);
+    free(ix->labels);
+    free(ix->levels);
+    free(ix->nbr0);
+    free(ix->upper_off);
+    free(ix->upper_nbr);
+    ctx_free(&ix->ctx);
+    free(ix);
+}
+
+int lo_reserve(lo_index *ix, size_t cap)
+{
+    if(cap <= ix->cap) return 0;
+    if(ix->vecs_borrowed) return -1;
+    ix->vecs = (uint8_t *)realloc(ix->vecs, cap * ix->vec_bytes);
+    ix->labels = (uint64_t *)realloc(ix->labels, cap * sizeof(uint64_t));
+    ix->levels = (uint8_t *)realloc(ix->levels, cap);
+    ix->nbr0 = (uint32_t *)realloc(ix->nbr0, cap * ix->M0 * sizeof(uint32_t));
+    ix->upper_off = (uint32_t *)realloc(ix->upper_off, cap * sizeof(uint32_t));
+    ix->cap = cap;
+    return 0;
+}
+
+size_t   lo_size(const lo_index *ix) { return ix->n; }
+size_t   lo_capacity(const lo_index *ix) { return ix->cap; }
+int      lo_max_level(const lo_index *ix) { return ix->max_level; }
+uint32_t lo_entry_slot(const lo_index *ix) { return ix->entry; }
+uint64_t lo_last_distance_evals(const lo_index *ix) { return ix->last_D; }
+uint64_t lo_last_expansions(const lo_index *ix) { return ix->last_E; }
+size_t   lo_upper_blocks(const lo_index *ix) { return ix->upper_blocks; }
+
+/* allocate the node (node_make_): blank lists */
+static uint32_t node_make(lo_index *ix, uint64_t label, const void *vec, int level)
+{
+    if(ix->n == ix->cap) lo_reserve(ix, ix->cap ? ix->cap * 2 : 64); /* build.c:116-126 doubles too */
+    uint32_t slot = (uint32_t)ix->n++;
+    memcpy(ix->vecs + (size_t)slot * ix->vec_bytes, vec, ix->vec_bytes);
+    ix->labels[ slot ] = label;
+    ix->levels[ slot ] = (uint8_t)level;
+    for(uint32_t i = 0; i < ix->M0; ++i) ix->nbr0[ (size_t)slot * ix->M0 + i ] = LO_EMPTY_SLOT;
+    if(level > 0) {
+        if(ix->upper_blocks + (size_t)level > ix->upper_cap) {
+            ix->upper_cap = (ix->upper_blocks + (size_t)level) * 2 + 64;
+            ix->upper_nbr = (uint32_t *)realloc(ix->upper_nbr, ix->upper_cap * ix->M * sizeof(uint32_t));
+        }
+        ix->upper_off[ slot ] = (uint32_t)ix->upper_blocks;
+        for(size_t i = 0; i < (size_t)level * ix->M; ++i) ix->upper_nbr[ ix->upper_blocks * ix->M + i ] = LO_EMPTY_SLOT;
+        ix->upper_blocks += (size_t)level;
+    } else {
+        ix->upper_off[ slot ] = LO_EMPTY_SLOT;
+    }
+    return slot;
+}
+
+/* selected links of one new node, one level (phase A result) */
+typedef struct
+{
+    uint32_t close;
+    int      level;
+    uint32_t new_slot;
+    float    d;
+} link_t;
+
+/* phase A for one new node against the graph as it stands (entry/max_level given):
+ * search_for_one_ + per level { search_to_insert_, refine_ (connect_new_node_) }.
+ * Writes the node's own lists; appends its reverse-link requests to links[]. */
+static size_t insert_search(lo_index *ix, uint32_t new_slot, uint32_t entry, int max_level, link_t *links)
+{
+    lo_ctx     *c = &ix->ctx;
+    const void *q = lo_vector(ix, new_slot);
+    int         target = ix->levels[ new_slot ];
+    size_t      nl = 0;
+    ctx_fit(c, ix->cap, ix->efc);
+    uint32_t closest = search_for_one(ix, c, q, entry, max_level, target);
+    for(int level = target < max_level ? target : max_level; level >= 0; --level) {
+        search_level(ix, c, q, closest, level, ix->efc);
+        size_t    keep = refine(ix, c->top, c->top_n, ix->M, new_slot); /* connect_new_node_: connectivity, NOT 2M */
+        uint32_t  cap;
+        uint32_t *own = neighbors(ix, new_slot, level, &cap);
+        for(size_t i = 0; i < keep; ++i) {
+            own[ i ] = c->top[ i ].id;
+            links[ nl++ ] = (link_t){ c->top[ i ].id, level, new_slot, c->top[ i ].d };
+        }
+        closest = own[ 0 ];
+    }
+    return nl;
+}
+
+int lo_add_with_level(lo_index *ix, uint64_t label, const void *vec, int level)
+{
+    uint32_t entry = ix->entry;
+    int      max_level = ix->max_level;
+    uint32_t slot = node_make(ix, label, vec, level);
+    if(slot == 0) { /* "Do nothing for the first element" */
+        ix->entry = 0;
+        ix->max_level = level;
+        return 0;
+    }
+    link_t *links = (link_t *)malloc(sizeof(link_t) * (size_t)ix->M * (size_t)(level + 1) + sizeof(link_t));
+    size_t  nl = insert_search(ix, slot, entry, max_level, links);
+    for(size_t i = 0; i < nl; ++i) reverse_link(ix, links[ i ].close, links[ i ].level, slot, links[ i ].d);
+    free(links);
+    if(level > max_level) {
+        ix->entry = slot;
+        ix->max_level = level;
+    }
+    return 0;
+}
+
+int lo_add(lo_index *ix, uint64_t label, const void *vec)
+{
+    return lo_add_with_level(ix, label, vec, lo_level_for(ix->seed, ix->n, ix->M));
+}
+
+static int link_cmp(const void *a, const void *b)
+{
+    const link_t *x = (const link_t *)a, *y = (const link_t *)b;
+    if(x->close != y->close) return x->close < y->close ? -1 : 1;
+    if(x->level != y->level) return x->level < y->level ? -1 : 1;
+    if(x->new_slot != y->new_slot) return x->new_slot < y->new_slot ? -1 : 1;
+    return 0;
+}
+
+size_t lo_plan_batch(size_t current_size, int max_level, const int *pending_levels, size_t pending, size_t max_batch,
+                     size_t min_ratio)
+{
+    if(pending == 0) return 0;
+    if(current_size == 0) return 1;
+    size_t b = current_size / (min_ratio ? min_ratio : 1);
+    if(b < 1) b = 1;
+    if(b > max_batch) b = max_batch;
+    if(b > pending) b = pending;
+    /* a node that raises the top level is inserted alone, so entry/max_level never change
+     * in the middle of a batch */
+    for(size_t i = 0; i < b; ++i)
+        if(pending_levels[ i ] > max_level) return i == 0 ? 1 : i;
+    return b;
+}
+
+int lo_add_batch(lo_index *ix, const uint64_t *labels, const void *vecs, size_t n)
+{
+    if(n == 0) return 0;
+    if(ix->n == 0 || n == 1) {
+        for(size_t i = 0; i < n; ++i)
+            if(lo_add(ix, labels[ i ], (const uint8_t *)vecs + i * ix->vec_bytes)) return -1;
+        return 0;
+    }
+    uint32_t entry = ix->entry;
+    int      max_level = ix->max_level;
+    size_t   first = ix->n, total_links = 0, cap_links = 0;
+    for(size_t i = 0; i < n; ++i)
+        if(lo_level_for(ix->seed, first + i, ix->M) > max_level) return -2; /* planner contract violated */
+    for(size_t i = 0; i < n; ++i) {
+        int lvl = lo_level_for(ix->seed, ix->n, ix->M);
+        node_make(ix, labels[ i ], (const uint8_t *)vecs + i * ix->vec_bytes, lvl);
+        cap_links += (size_t)ix->M * (size_t)(lvl + 1);
+    }
+    link_t *links = (link_t *)malloc(sizeof(link_t) * (cap_links + 1));
+    /* phase A: every new node sees only the pre-batch graph (new nodes have no in-links yet) */
+    for(size_t i = 0; i < n; ++i) total_links += insert_search(ix, (uint32_t)(first + i), entry, max_level, links + total_links);
+    /* phase B: reverse links, grouped by (close, level), applied in new-slot order */
+    qsort(links, total_links, sizeof(link_t), link_cmp);
+    for(size_t i = 0; i < total_links; ++i)
+        reverse_link(ix, links[ i ].close, links[ i ].level, links[ i ].new_slot, links[ i ].d);
+    free(links);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+
+static size_t search_with_ctx(const lo_index *ix, lo_ctx *c, const void *q, size_t k, size_t ef, size_t skip,
+                              uint64_t *out_labels, float *out_dists, uint32_t *out_slots)
+{
+    c->D = c->E = 0;
+    if(ix->n == 0 || k == 0) return 0;
+    size_t wanted = k + skip;
+    size_t expansion = ef ? ef : ix->ef;
+    if(expansion < wanted) expansion = wanted; /* usearch: expansion = max(expansion, wanted) */
+    ctx_fit(c, ix->cap ? ix->cap : ix->n, expansion);
+    uint32_t closest = search_for_one(ix, c, q, ix->entry, ix->max_level, 0);
+    search_level(ix, c, q, closest, 0, expansion);
+    size_t got = 0;
+    for(size_t i = skip; i < c->top_n && got < k; ++i, ++got) {
+        if(out_labels) out_labels[ got ] = ix->labels[ c->top[ i ].id ];
+        if(out_dists) out_dists[ got ] = c->top[ i ].d;
+        if(out_slots) out_slots[ got ] = c->top[ i ].id;
+    }
+    return got;
+}
+
+size_t lo_search(lo_index *ix, const void *q, size_t k, size_t ef, size_t skip, uint64_t *out_labels, float *out_dists,
+                 uint32_t *out_slots)
+{
+    size_t got = search_with_ctx(ix, &ix->ctx, q, k, ef, skip, out_labels, out_dists, out_slots);
+    ix->last_D = ix->ctx.D;
+    ix->last_E = ix->ctx.E;
+    return got;
+}
+
+typedef struct
+{
+    const lo_index *ix;
+    const uint8_t  *queries;
+    size_t          nq, k, ef, next;
+    uint64_t       *labels;
+    float          *dists;
+    uint32_t       *slots;
+    uint64_t       *D, *E;
+    pthread_mutex_t mu;
+} batch_job;
+
+static void *batch_worker(void *arg)
+{
+    batch_job *job = (batch_job *)arg;
+    lo_ctx     c;
+    memset(&c, 0, sizeof(c));
+    for(;;) {
+        pthread_mutex_lock(&job->mu);
+        size_t begin = job->next;
+        job->next += 16;
+        pthread_mutex_unlock(&job->mu);
+        if(begin >= job->nq) break;
+        size_t end = begin + 16 < job->nq ? begin + 16 : job->nq;
+        for(size_t i = begin; i < end; ++i) {
+            size_t got = search_with_ctx(job->ix, &c, job->queries + i * job->ix->vec_bytes, job->k, job->ef, 0,
+                                         job->labels ? job->labels + i * job->k : NULL,
+                                         job->dists ? job->dists + i * job->k : NULL,
+                                         job->slots ? job->slots + i * job->k : NULL);
+            for(size_t j = got; j < job->k; ++j) {
+                if(job->labels) job->labels[ i * job->k + j ] = 0;
+                if(job->dists) job->dists[ i * job->k + j ] = INFINITY;
+                if(job->slots) job->slots[ i * job->k + j ] = LO_EMPTY_SLOT;
+            }
+            if(job->D) job->D[ i ] = c.D;
+            if(job->E) job->E[ i ] = c.E;
+        }
+    }
+    ctx_free(&c);
+    return NULL;
+}
+
+void lo_search_batch(lo_index *ix, const void *queries, size_t nq, size_t k, size_t ef, uint64_t *out_labels,
+                     float *out_dists, uint32_t *out_slots, uint64_t *out_D, uint64_t *out_E, int nthreads)
+{
+    batch_job job = { ix, (const uint8_t *)queries, nq, k, ef, 0, out_labels, out_dists, out_slots, out_D, out_E,
+                      PTHREAD_MUTEX_INITIALIZER };
+    if(nthreads < 1) nthreads = 1;
+    if(nthreads == 1) {
+        batch_worker(&job);
+        return;
+    }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    for(int t = 0; t < nthreads; ++t) pthread_create(&th[ t ], NULL, batch_worker, &job);
+    for(int t = 0; t < nthreads; ++t) pthread_join(th[ t ], NULL);
+    free(th);
+}
+
+/* ---------------------------------------------------------------------------------------- */
+
+void lo_export_graph(const lo_index *ix, uint8_t *levels, uint32_t *nbr0, uint32_t *upper_off, uint32_t *upper_nbr,
+                     uint64_t *labels)
+{
+    if(levels) memcpy(levels, ix->levels, ix->n);
+    if(nbr0) memcpy(nbr0, ix->nbr0, ix->n * ix->M0 * sizeof(uint32_t));
+    if(upper_off) memcpy(upper_off, ix->upper_off, ix->n * sizeof(uint32_t));
+    if(upper_nbr) memcpy(upper_nbr, ix->upper_nbr, ix->upper_blocks * ix->M * sizeof(uint32_t));
+    if(labels) memcpy(labels, ix->labels, ix->n * sizeof(uint64_t));
+}
+
+lo_index *lo_import_graph(int metric, size_t dims, uint32_t M, uint32_t efc, uint32_t ef, uint64_t seed, int sum_mode,
+                          size_t n, const void *vectors, const uint64_t *labels, const uint8_t *levels,
+                          const uint32_t *nbr0, const uint32_t *upper_off, const uint32_t *upper_nbr,
+                          uint32_t entry_slot, int max_level, int borrow_vectors)
+{
+    lo_index *ix = lo_create(metric, dims, M, efc, ef, seed, sum_mode);
+    if(!ix) return NULL;
+    size_t blocks = 0;
+    for(size_t i = 0; i < n; ++i) blocks += levels[ i ];
+    ix->n = ix->cap = n;
+    if(borrow_vectors) {
+        ix->vecs = (uint8_t *)(uintptr_t)vectors;
+        ix->vecs_borrowed = 1;
+    } else {
+        ix->vecs = (uint8_t *)malloc(n * ix->vec_bytes + 1);
+        memcpy(ix->vecs, vectors, n * ix->vec_bytes);
+    }
+    ix->labels = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
+    for(size_t i = 0; i < n; ++i) ix->labels[ i ] = labels ? labels[ i ] : (uint64_t)i;
+    ix->levels = (uint8_t *)malloc(n + 1);
+    memcpy(ix->levels, levels, n);
+    ix->nbr0 = (uint32_t *)malloc((n * ix->M0 + 1) * sizeof(uint32_t));
+    memcpy(ix->nbr0, nbr0, n * ix->M0 * sizeof(uint32_t));
+    ix->upper_off = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));
+    memcpy(ix->upper_off, upper_off, n * sizeof(uint32_t));
+    ix->upper_blocks = ix->upper_cap = blocks;
+    ix->upper_nbr = (uint32_t *)malloc((blocks * ix->M + 1) * sizeof(uint32_t));
+    if(blocks) memcpy(ix->upper_nbr, upper_nbr, blocks * ix->M * sizeof(uint32_t));
+    ix->entry = entry_slot;
+    ix->max_level = max_level;
+    return ix;
+}
+
+/* ---- exact k-NN --------------------------------------------------------------------------- */
+
+typedef struct
+{
+    const uint8_t  *rows, *queries;
+    size_t          n, dims, nq, k, vec_bytes, next;
+    int             metric, sum_mode;
+    uint32_t       *ids;
+    float          *dists;
+    pthread_mutex_t mu;
+} bf_job;
+
+static void *bf_worker(void *arg)
+{
+    bf_job *job = (bf_job *)arg;
+    cand_t *best = (cand_t *)malloc(sizeof(cand_t) * (job->k + 1));
+    for(;;) {
+        pthread_mutex_lock(&job->mu);
+        size_t qi = job->next++;
+        pthread_mutex_unlock(&job->mu);
+        if(qi >= job->nq) break;
+        const void *q = job->queries + qi * job->vec_bytes;
+        size_t      cnt = 0;
+        for(size_t i = 0; i < job->n; ++i) {
+            const void *row = job->rows + i * job->vec_bytes;
+            float       d;
+            if(job->metric == LO_METRIC_HAMMING)
+                d = job->sum_mode == LO_SUM_FAST ? lo_hamming_fast(q, row, job->dims)
+                                                 : lo_distance(q, row, job->dims, LO_METRIC_HAMMING, 0);
+            else
+                d = lo_distance(q, row, job->dims, job->metric, job->sum_mode);
+            cand_t x = { d, (uint32_t)i };
+            if(cnt == job->k && !cand_less(x, best[ cnt - 1 ])) continue;
+            size_t p = cnt < job->k ? cnt++ : cnt - 1;
+            while(p > 0 && cand_less(x, best[ p - 1 ])) {
+                best[ p ] = best[ p - 1 ];
+                --p;
+            }
+            best[ p ] = x;
+        }
+        for(size_t j = 0; j < job->k; ++j) {
+            job->ids[ qi * job->k + j ] = j < cnt ? best[ j ].id : LO_EMPTY_SLOT;
+            job->dists[ qi * job->k + j ] = j < cnt ? best[ j ].d : INFINITY;
+        }
+    }
+    free(best);
+    return NULL;
+}
+
+void lo_bruteforce(const void *rows, size_t n, size_t dims, int metric, int sum_mode, const void *queries, size_t nq,
+                   size_t k, uint32_t *out_ids, float *out_dists, int nthreads)
+{
+    bf_job job = { (const uint8_t *)rows, (const uint8_t *)queries, n, dims, nq, k,
+                   metric == LO_METRIC_HAMMING ? (dims + 7) / 8 : dims * sizeof(float), 0, metric, sum_mode, out_ids,
+                   out_dists, PTHREAD_MUTEX_INITIALIZER };
+    if(k == 0 || nq == 0) return;
+    if(nthreads < 1) nthreads = 1;
+    if(nthreads == 1) {
+        bf_worker(&job);
+        return;
+    }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    for(int t = 0; t < nthreads; ++t) pthread_create(&th[ t ], NULL, bf_worker, &job);
+    for(int t = 0; t < nthreads; ++t) pthread_join(th[ t ], NULL);
+    free(th);
+}
+
+/* ---- planner bound (hnsw.c:89-132) --------------------------------------------------------- */
+uint64_t lo_estimate_visited_tuples(double num_tuples, uint32_t M, uint32_t ef)
+{
+    if(num_tuples <= 0) return 0;
+    const double   mL = 1.0 / log((double)M);
+    const double   S = 1.0 / (1.0 - exp(-1.0 * mL));
+    const uint64_t per_upper = (uint64_t)(S * M);
+    const uint64_t base = (uint64_t)(ef * S * M * 2);
+    const uint64_t levels = (uint64_t)ceil(log(1.0 + num_tuples) * mL);
+    uint64_t       total = per_upper * (levels - 1) + base;
+    double         cap = num_tuples / 3.0;
+    return (double)total < cap ? total : (uint64_t)cap;
+}

@@ -1,0 +1,139 @@
+/*
+ * metrics.c -- oracle pairwise metrics (TEST INFRASTRUCTURE; see lantern_oracle.h).
+ *
+ * Restates usearch's metric_l2sq_gt / metric_cos_gt / metric_hamming_gt as reached through
+ * usearch_distance from lantern_hnsw/src/hnsw.c:296-345 (array_dist, vector_dist) and
+ * product_quantization.c:102,185.  Compile this file with -ffp-contract=off so that the
+ * SEQ order really is "one multiply, one add per element" and the WAVE64 order really is
+ * the explicit fmaf() chain it spells out.
+ */
+#include "lantern_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+float lo_distance_fast(const void *a, const void *b, size_t dims, int metric); /* metrics_fast.c */
+
+/* ---- LO_SUM_SEQ: the textbook usearch loops ------------------------------------------- */
+
+static float l2sq_seq(const float *a, const float *b, size_t d)
+{
+    float s = 0.f;
+    for(size_t i = 0; i != d; ++i) {
+        float t = a[ i ] - b[ i ];
+        s += t * t;
+    }
+    return s;
+}
+
+/* cosine zero-norm rules are pinned by the reference's tests:
+ *   both zero -> 0   (expected/hnsw_vector.out:205-210)
+ *   one zero  -> 1   (expected/hnsw_dist_func.out:58-61,90; hnsw_operators.out:99-103) */
+static float cos_finish(float ab, float a2, float b2)
+{
+    if(a2 == 0.f && b2 == 0.f) return 0.f;
+    if(a2 == 0.f || b2 == 0.f) return 1.f;
+    return 1.f - ab / (sqrtf(a2) * sqrtf(b2));
+}
+
+static float cos_seq(const float *a, const float *b, size_t d)
+{
+    float ab = 0.f, a2 = 0.f, b2 = 0.f;
+    for(size_t i = 0; i != d; ++i) {
+        ab += a[ i ] * b[ i ];
+        a2 += a[ i ] * a[ i ];
+        b2 += b[ i ] * b[ i ];
+    }
+    return cos_finish(ab, a2, b2);
+}
+
+/* hamming over b1x8: dims is a BIT count (hnsw.c:317-319 passes a_dim*32); popcount of XOR */
+static float hamming_bits(const uint8_t *a, const uint8_t *b, size_t bits)
+{
+    size_t   bytes = (bits + 7) / 8;
+    uint64_t total = 0;
+    for(size_t i = 0; i != bytes; ++i) total += (uint64_t)__builtin_popcount((unsigned)(a[ i ] ^ b[ i ]));
+    return (float)total;
+}
+
+/* ---- LO_SUM_WAVE64: the device reduction tree ------------------- */
+/*
+ * A row of d f32 scalars is zero-padded to d4 = 4*ceil(d/4).  G lanes cooperate
+ * (G = lo_wave_group_lanes(d)).  Lane l owns the float4 chunks l, l+G, l+2G, ... and runs
+ * one fmaf chain per accumulator over its scalars in memory order.  The G partials are then
+ * combined by an xor butterfly: for off = G/2 .. 1: p[l] = p[l] + p[l ^ off].
+ */
+int lo_wave_group_lanes(size_t dims)
+{
+    size_t chunks = (dims + 3) / 4;
+    if(chunks >= 64) return 64;
+    if(chunks >= 32) return 32;
+    if(chunks >= 16) return 16;
+    return 8;
+}
+
+static void butterfly(float *p, int G)
+{
+    float t[ 64 ];
+    for(int off = G / 2; off >= 1; off >>= 1) {
+        for(int l = 0; l < G; ++l) t[ l ] = p[ l ] + p[ l ^ off ];
+        memcpy(p, t, sizeof(float) * (size_t)G);
+    }
+}
+
+static float l2sq_wave(const float *a, const float *b, size_t d)
+{
+    int    G = lo_wave_group_lanes(d);
+    size_t chunks = (d + 3) / 4;
+    float  p[ 64 ];
+    for(int l = 0; l < G; ++l) {
+        float acc = 0.f;
+        for(size_t ch = (size_t)l; ch < chunks; ch += (size_t)G) {
+            for(size_t c = 0; c < 4; ++c) {
+                size_t i = ch * 4 + c;
+                float  x = i < d ? a[ i ] : 0.f, y = i < d ? b[ i ] : 0.f;
+                float  t = x - y;
+                acc = fmaf(t, t, acc);
+            }
+        }
+        p[ l ] = acc;
+    }
+    butterfly(p, G);
+    return p[ 0 ];
+}
+
+static float cos_wave(const float *a, const float *b, size_t d)
+{
+    int    G = lo_wave_group_lanes(d);
+    size_t chunks = (d + 3) / 4;
+    float  pab[ 64 ], pa2[ 64 ], pb2[ 64 ];
+    for(int l = 0; l < G; ++l) {
+        float ab = 0.f, a2 = 0.f, b2 = 0.f;
+        for(size_t ch = (size_t)l; ch < chunks; ch += (size_t)G) {
+            for(size_t c = 0; c < 4; ++c) {
+                size_t i = ch * 4 + c;
+                float  x = i < d ? a[ i ] : 0.f, y = i < d ? b[ i ] : 0.f;
+                ab = fmaf(x, y, ab);
+                a2 = fmaf(x, x, a2);
+                b2 = fmaf(y, y, b2);
+            }
+        }
+        pab[ l ] = ab;
+        pa2[ l ] = a2;
+        pb2[ l ] = b2;
+    }
+    butterfly(pab, G);
+    butterfly(pa2, G);
+    butterfly(pb2, G);
+    return cos_finish(pab[ 0 ], pa2[ 0 ], pb2[ 0 ]);
+}
+
+float lo_distance(const void *a, const void *b, size_t dims, int metric, int sum_mode)
+{
+    if(metric == LO_METRIC_HAMMING) return hamming_bits((const uint8_t *)a, (const uint8_t *)b, dims);
+    if(sum_mode == LO_SUM_FAST) return lo_distance_fast(a, b, dims, metric);
+    const float *x = (const float *)a, *y = (const float *)b;
+    if(metric == LO_METRIC_L2SQ) return sum_mode == LO_SUM_WAVE64 ? l2sq_wave(x, y, dims) : l2sq_seq(x, y, dims);
+    if(metric == LO_METRIC_COS) return sum_mode == LO_SUM_WAVE64 ? cos_wave(x, y, dims) : cos_seq(x, y, dims);
+    return NAN;
+}
