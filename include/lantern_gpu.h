@@ -1,0 +1,251 @@
+/*
+ * lantern_gpu.h -- C ABI of the MI355X-native HNSW distance-evaluation path for Lantern.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) The usearch C API exactly as Lantern calls it (boundary B1 of SURVEY.md section 8b).
+ *      Lantern static-links usearch's c/lib.cpp into lantern.so (lantern_hnsw/CMakeLists.txt:89,
+ *      115-120); usearch.h itself is NOT in the reference tree (un-vendored submodule), so the
+ *      prototypes below are reconstructed from the call sites cited next to each one.  A
+ *      maintainer links liblantern_gpu.so instead of c/lib.cpp and recompiles.
+ *
+ *  (2) lantern_gpu_* / lantern_scan_* / lantern_*_dist: batched and device-resident forms the
+ *      reference lacks, the amgettuple paging shim (scan.c:167-338) and the SQL-callable
+ *      distance functions' semantics (hnsw.c:296-405).
+ *
+ * Conventions (same as the reference's): errors are a `const char*` out-parameter, NULL on
+ * success, pointing at a static or index-owned string on failure (hnsw.c:341-343, scan.c:100,
+ * build.c:545-551); result arrays are caller-allocated (scan.c:207-212); vectors are borrowed
+ * for the duration of the call.  There is NO CPU fallback: without a HIP device every compute
+ * entry point fails with an error string.
+ */
+#ifndef LANTERN_GPU_H
+#define LANTERN_GPU_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LANTERN_GPU_EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ */
+/* (1) usearch C API as used by Lantern                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef void       *usearch_index_t;
+typedef uint64_t    usearch_key_t;
+typedef uint64_t    usearch_label_t; /* 6-byte heap TID packed in u64: utils.c:69-75 */
+typedef float       usearch_distance_t;
+typedef const char *usearch_error_t;
+
+/* enum values pinned by lantern_cli/src/external_index/cli.rs:56-69 and server.rs:94-101 */
+typedef enum usearch_metric_kind_t {
+    usearch_metric_unknown_k = 0,
+    usearch_metric_cos_k = 1,
+    usearch_metric_l2sq_k = 3,
+    usearch_metric_hamming_k = 8
+} usearch_metric_kind_t;
+
+typedef enum usearch_scalar_kind_t {
+    usearch_scalar_unknown_k = 0,
+    usearch_scalar_f32_k = 1,
+    usearch_scalar_f64_k = 2,
+    usearch_scalar_f16_k = 3,
+    usearch_scalar_i8_k = 4,
+    usearch_scalar_b1_k = 5
+} usearch_scalar_kind_t;
+
+/* external_index.c:613-697: slot -> pointer to the node tape */
+typedef void *(*usearch_node_retriever_t)(void *ctx, uint64_t slot);
+
+/* Fields are the ones Lantern sets: utils.c:57-67, scan.c:60-96, build.c:495-515, insert.c:116-132 */
+typedef struct usearch_init_options_t
+{
+    usearch_metric_kind_t    metric_kind;
+    void                    *metric; /* custom metric; Lantern always passes NULL (utils.c:63) */
+    usearch_scalar_kind_t    quantization;
+    size_t                   dimensions; /* f32 scalars, or BITS for hamming (scan.c:84-88) */
+    size_t                   connectivity;
+    size_t                   expansion_add;
+    size_t                   expansion_search;
+    size_t                   num_threads;
+    bool                     pq;
+    size_t                   num_centroids;
+    size_t                   num_subvectors;
+    void                    *retriever_ctx;
+    usearch_node_retriever_t retriever;
+    usearch_node_retriever_t retriever_mut;
+} usearch_init_options_t;
+
+/* usearch_storage.cpp:19-32,63-81 read these */
+typedef struct metadata_t
+{
+    size_t                 neighbors_bytes;      /* 4 + M*6      (upper levels) */
+    size_t                 neighbors_base_bytes; /* 4 + 2M*6     (level 0)      */
+    double                 inverse_log_connectivity;
+    size_t                 connectivity;
+    size_t                 dimensions;
+    usearch_init_options_t init_options;
+} metadata_t;
+
+#define USEARCH_SEARCH_EF_INVALID_VALUE 0 /* options.c:341: 0 = "use the index's ef" */
+#define LANTERN_SLOT_SIZE 6               /* validate_index.c:39, hnsw.h:42-49 */
+#define USEARCH_HEADER_SIZE 136           /* external_index.h:29-30 */
+#define USEARCH_EMPTY_INDEX_SIZE USEARCH_HEADER_SIZE /* build.c:678 */
+
+/* scan.c:99, build.c:517,675, insert.c:142.  pq_codebook must be NULL (PQ is out of scope). */
+LANTERN_GPU_EXPORT usearch_index_t usearch_init(usearch_init_options_t *, float *pq_codebook, usearch_error_t *);
+/* scan.c:131, build.c:450,549,597,684, insert.c:237 */
+LANTERN_GPU_EXPORT void usearch_free(usearch_index_t, usearch_error_t *);
+/* build.c:124,543, insert.c:182 */
+LANTERN_GPU_EXPORT void usearch_reserve(usearch_index_t, size_t capacity, usearch_error_t *);
+/* scan.c:246, build.c:117,121,558,590, insert.c:148 */
+LANTERN_GPU_EXPORT size_t usearch_size(usearch_index_t, usearch_error_t *);
+/* build.c:116 */
+LANTERN_GPU_EXPORT size_t usearch_capacity(usearch_index_t, usearch_error_t *);
+/* server.rs:222-229 (Index::dimensions) */
+LANTERN_GPU_EXPORT size_t usearch_dimensions(usearch_index_t, usearch_error_t *);
+/* build.c:128; Rust add_raw server.rs:349.  Inserts are buffered and applied in batches on the
+ * device (see lantern_gpu_set_add_batch); any reader (search/size/save) flushes first. */
+LANTERN_GPU_EXPORT void usearch_add(usearch_index_t, usearch_label_t, const void *vector, usearch_scalar_kind_t,
+                                    usearch_error_t *);
+/* scan.c:220-228,273-281.  ef == 0 -> index default.  streaming == true returns the NEXT k
+ * results of the same query after the ones already returned since the last non-streaming call. */
+LANTERN_GPU_EXPORT size_t usearch_search_ef(usearch_index_t, const void *query, usearch_scalar_kind_t, size_t k,
+                                            size_t ef, bool streaming, usearch_label_t *labels, float *distances,
+                                            usearch_error_t *);
+/* hnsw.c:317,326,340; product_quantization.c:102,185.  One pair, evaluated on the device. */
+LANTERN_GPU_EXPORT float usearch_distance(const void *a, const void *b, usearch_scalar_kind_t, size_t dims,
+                                          usearch_metric_kind_t, usearch_error_t *);
+/* build.c:561, insert.c:160, utils.c:91 */
+LANTERN_GPU_EXPORT metadata_t usearch_index_metadata(usearch_index_t, usearch_error_t *);
+/* build.c:583: usearch-format file = 136-byte header + node tapes in slot order (App. B) */
+LANTERN_GPU_EXPORT void usearch_save(usearch_index_t, const char *path, usearch_error_t *);
+/* build.c:679 */
+LANTERN_GPU_EXPORT void usearch_save_buffer(usearch_index_t, char *buffer, size_t length, usearch_error_t *);
+/* Rust Index::load_from_buffer (external_index_server_test.rs:271-314) / usearch_load */
+LANTERN_GPU_EXPORT void usearch_load(usearch_index_t, const char *path, usearch_error_t *);
+LANTERN_GPU_EXPORT void usearch_load_buffer(usearch_index_t, const char *buffer, size_t length, usearch_error_t *);
+LANTERN_GPU_EXPORT size_t usearch_serialized_length(usearch_index_t, usearch_error_t *);
+/* external_index.c:411,417 */
+LANTERN_GPU_EXPORT uint64_t usearch_header_get_entry_slot(char *header136);
+LANTERN_GPU_EXPORT void     usearch_header_set_entry_slot(char *header136, uint64_t slot);
+
+/* ------------------------------------------------------------------------------------------ */
+/* (2) batched / device-resident forms                                                         */
+/* ------------------------------------------------------------------------------------------ */
+
+LANTERN_GPU_EXPORT const char *lantern_gpu_version(void);
+LANTERN_GPU_EXPORT int         lantern_gpu_device_count(void);
+
+/* seed of the level draw (insert.c:32-46 uses PG's global PRNG; here levels are a stateless
+ * hash of (seed, slot) so that builds are reproducible).  Call before the first add. */
+LANTERN_GPU_EXPORT void lantern_gpu_set_seed(usearch_index_t, uint64_t seed, usearch_error_t *);
+/* Insert batching: at most `max_batch` pending vectors are inserted per device pass and never
+ * more than size/min_ratio (so early inserts are near-sequential).  max_batch = 1 reproduces
+ * usearch_add's strictly sequential semantics.  Defaults: 8192, 16. */
+LANTERN_GPU_EXPORT void lantern_gpu_set_add_batch(usearch_index_t, size_t max_batch, size_t min_ratio,
+                                                  usearch_error_t *);
+/* many inserts in one call (the external indexer's row stream, server.rs:214-267) */
+LANTERN_GPU_EXPORT void lantern_gpu_add_many(usearch_index_t, const usearch_label_t *labels, const void *vectors,
+                                             size_t n, usearch_scalar_kind_t, usearch_error_t *);
+/* apply all buffered inserts now */
+LANTERN_GPU_EXPORT void lantern_gpu_flush(usearch_index_t, usearch_error_t *);
+/* usearch_add_external-style insert with a caller-drawn level (insert.c:32-46,209) */
+LANTERN_GPU_EXPORT void lantern_gpu_add_with_level(usearch_index_t, usearch_label_t, const void *vector,
+                                                   usearch_scalar_kind_t, int level, usearch_error_t *);
+
+/* nq independent usearch_search_ef calls in one launch; host buffers.
+ * labels/distances: nq x k (unused tail: label 0, +inf); counts: nq (may be NULL). */
+LANTERN_GPU_EXPORT void lantern_gpu_search_batch(usearch_index_t, const void *queries, size_t nq,
+                                                 usearch_scalar_kind_t, size_t k, size_t ef, usearch_label_t *labels,
+                                                 float *distances, uint32_t *counts, usearch_error_t *);
+/* Same, every buffer already in device memory, asynchronous on `stream` (a hipStream_t; NULL =
+ * the default stream).  slots (u32 internal ids), counts, dist_evals (D) and expansions (E) may
+ * be NULL.  `skip` drops that many leading results per query (streaming continuation). */
+LANTERN_GPU_EXPORT void lantern_gpu_search_batch_device(usearch_index_t, const void *d_queries, size_t nq, size_t k,
+                                                        size_t ef, size_t skip, uint64_t *d_labels, float *d_distances,
+                                                        uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_dist_evals,
+                                                        uint64_t *d_expansions, void *stream, usearch_error_t *);
+/* kernel shape of the search launch: waves per query (1..8) and resident workgroups (0 = auto) */
+LANTERN_GPU_EXPORT void lantern_gpu_set_search_shape(usearch_index_t, int waves_per_query, int max_workgroups,
+                                                     usearch_error_t *);
+
+/* Exact k-NN over the index's vectors (the seq-scan `ORDER BY v <op> q LIMIT k`; ground truth
+ * for recall, index_autotune/mod.rs:196-203).  Host buffers; slots: nq x k ascending by
+ * (distance, slot). */
+LANTERN_GPU_EXPORT void lantern_gpu_exact_search(usearch_index_t, const void *queries, size_t nq, size_t k,
+                                                 uint32_t *slots, float *distances, usearch_error_t *);
+
+/* Gathered distances: out[i] = metric(query, row(slots[i])) -- the kernel the graph walk is
+ * made of, exposed for tests and profiling.  Host buffers. */
+LANTERN_GPU_EXPORT void lantern_gpu_distance_gather(usearch_index_t, const void *query, const uint32_t *slots,
+                                                    size_t n, float *out, usearch_error_t *);
+/* Dense na x nb distance matrix between two host matrices (f32 rows of `dims` scalars, or u32
+ * words for hamming with dims = bits).  `exact_order` != 0 uses the per-pair reduction order of
+ * the graph walk (bit-identical to usearch_distance); 0 uses the fp32-MFMA contraction. */
+LANTERN_GPU_EXPORT void lantern_gpu_distance_matrix(const void *a, size_t na, const void *b, size_t nb,
+                                                    usearch_scalar_kind_t, size_t dims, usearch_metric_kind_t,
+                                                    int exact_order, float *out, usearch_error_t *);
+
+/* flat graph exchange (tests, CPU-baseline timing on the identical graph, sharded serving) */
+typedef struct lantern_gpu_graph_info
+{
+    size_t   size;
+    size_t   upper_blocks; /* sum of node levels */
+    uint32_t connectivity;
+    uint32_t entry_slot;
+    int32_t  max_level;
+    uint32_t vector_words; /* 4-byte words per stored vector */
+} lantern_gpu_graph_info;
+LANTERN_GPU_EXPORT lantern_gpu_graph_info lantern_gpu_graph_info_get(usearch_index_t, usearch_error_t *);
+/* any output pointer may be NULL.  levels[size] u8; nbr0[size][2M] u32 (0xFFFFFFFF = empty);
+ * upper_off[size] u32; upper_nbr[upper_blocks][M] u32; labels[size] u64; vectors[size][words] */
+LANTERN_GPU_EXPORT void lantern_gpu_export_graph(usearch_index_t, uint8_t *levels, uint32_t *nbr0, uint32_t *upper_off,
+                                                 uint32_t *upper_nbr, uint64_t *labels, void *vectors,
+                                                 usearch_error_t *);
+LANTERN_GPU_EXPORT void lantern_gpu_import_graph(usearch_index_t, size_t size, const void *vectors,
+                                                 const uint64_t *labels, const uint8_t *levels, const uint32_t *nbr0,
+                                                 const uint32_t *upper_off, const uint32_t *upper_nbr,
+                                                 uint32_t entry_slot, int32_t max_level, usearch_error_t *);
+/* cumulative counters since init: distance evaluations and expanded nodes of searches, and the
+ * same for the insert path */
+typedef struct lantern_gpu_counters
+{
+    uint64_t search_dist_evals, search_expansions, search_queries;
+    uint64_t add_dist_evals, add_expansions, add_vectors, add_batches;
+} lantern_gpu_counters;
+LANTERN_GPU_EXPORT lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t, usearch_error_t *);
+
+/* ------------------------------------------------------------------------------------------ */
+/* amgettuple paging shim: ldb_ambeginscan / ldb_amgettuple / ldb_amendscan (scan.c:24-338)     */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct lantern_scan lantern_scan_t;
+/* init_k = GUC lantern_hnsw.init_k (options.h:44, default 10); ef = GUC lantern_hnsw.ef or 0 */
+LANTERN_GPU_EXPORT lantern_scan_t *lantern_scan_begin(usearch_index_t, int init_k, int ef, usearch_error_t *);
+/* ldb_amrescan: (re)arm the scan with an ORDER BY key; the vector is copied */
+LANTERN_GPU_EXPORT void lantern_scan_rescan(lantern_scan_t *, const void *query, usearch_scalar_kind_t,
+                                            usearch_error_t *);
+/* ldb_amgettuple: true and *label set while tuples remain.  Skips label 0 (deleted, scan.c:296-300),
+ * doubles k through the streaming continuation (scan.c:240-292), stops at 1000 rows (:249-252). */
+LANTERN_GPU_EXPORT bool lantern_scan_gettuple(lantern_scan_t *, usearch_label_t *label, usearch_error_t *);
+LANTERN_GPU_EXPORT void lantern_scan_end(lantern_scan_t *);
+
+/* ------------------------------------------------------------------------------------------ */
+/* SQL-callable distance functions' semantics (hnsw.c:296-405): dimension checks + messages     */
+/* ------------------------------------------------------------------------------------------ */
+/* l2sq_dist(real[], real[]) -> float4; error text hnsw.c:301-303 */
+LANTERN_GPU_EXPORT float lantern_l2sq_dist(const float *a, int a_dim, const float *b, int b_dim, usearch_error_t *);
+LANTERN_GPU_EXPORT float lantern_cos_dist(const float *a, int a_dim, const float *b, int b_dim, usearch_error_t *);
+/* hamming_dist(integer[], integer[]) -> int32 (hnsw.c:308-319,370-376): bits = dim*32 */
+LANTERN_GPU_EXPORT int32_t lantern_hamming_dist(const int32_t *a, int a_dim, const int32_t *b, int b_dim,
+                                                usearch_error_t *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANTERN_GPU_H */

@@ -1,0 +1,70 @@
+"""Compile the HIP library in-tree: lantern_amd/lib/liblantern_gpu.so (gfx950 only).
+
+    python -m lantern_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with
+the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(OUT_DIR, "obj")
+LIB = os.path.join(OUT_DIR, "liblantern_gpu.so")
+
+SOURCES = ["kernels.hip", "bruteforce.hip", "index.cpp", "usearch_file.cpp", "scan_shim.cpp"]
+HEADERS = ["device_common.hpp", "walk.hpp", "kernels.hpp", "index.hpp", "host_util.hpp", "../../include/lantern_gpu.h"]
+# -ffp-contract=off: every fma in the kernels is explicit, so the reduction tree is exactly the
+# one the oracle models.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
+         "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.sep not in cand or os.path.exists(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+        path = os.path.join(CSRC, src)
+        if force or _stale(obj, [path] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,421 @@
+"""ctypes binding of include/lantern_gpu.h -- what a foreign-language host would write.
+
+Every compute call goes through the C ABI of lantern_amd/lib/liblantern_gpu.so (hand-written
+HIP for gfx950).  There is no Python or CPU implementation behind these wrappers: if the
+library is missing or no device is present they raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "liblantern_gpu.so")
+
+# usearch_metric_kind_t / usearch_scalar_kind_t (cli.rs:56-69, server.rs:94-101)
+METRIC_COS, METRIC_L2SQ, METRIC_HAMMING = 1, 3, 8
+SCALAR_F32, SCALAR_B1 = 1, 5
+METRICS = {"cos": METRIC_COS, "l2sq": METRIC_L2SQ, "hamming": METRIC_HAMMING}
+EMPTY = 0xFFFFFFFF
+USEARCH_HEADER_SIZE = 136
+
+
+class LanternGpuError(RuntimeError):
+    pass
+
+
+class InitOptions(C.Structure):
+    _fields_ = [
+        ("metric_kind", C.c_int),
+        ("metric", C.c_void_p),
+        ("quantization", C.c_int),
+        ("dimensions", C.c_size_t),
+        ("connectivity", C.c_size_t),
+        ("expansion_add", C.c_size_t),
+        ("expansion_search", C.c_size_t),
+        ("num_threads", C.c_size_t),
+        ("pq", C.c_bool),
+        ("num_centroids", C.c_size_t),
+        ("num_subvectors", C.c_size_t),
+        ("retriever_ctx", C.c_void_p),
+        ("retriever", C.c_void_p),
+        ("retriever_mut", C.c_void_p),
+    ]
+
+
+class Metadata(C.Structure):
+    _fields_ = [
+        ("neighbors_bytes", C.c_size_t),
+        ("neighbors_base_bytes", C.c_size_t),
+        ("inverse_log_connectivity", C.c_double),
+        ("connectivity", C.c_size_t),
+        ("dimensions", C.c_size_t),
+        ("init_options", InitOptions),
+    ]
+
+
+class GraphInfo(C.Structure):
+    _fields_ = [
+        ("size", C.c_size_t),
+        ("upper_blocks", C.c_size_t),
+        ("connectivity", C.c_uint32),
+        ("entry_slot", C.c_uint32),
+        ("max_level", C.c_int32),
+        ("vector_words", C.c_uint32),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("search_dist_evals", "search_expansions", "search_queries", "add_dist_evals",
+                                          "add_expansions", "add_vectors", "add_batches")]
+
+
+EXPORTS = [
+    "usearch_init", "usearch_free", "usearch_reserve", "usearch_size", "usearch_capacity", "usearch_dimensions",
+    "usearch_add", "usearch_search_ef", "usearch_distance", "usearch_index_metadata", "usearch_save",
+    "usearch_save_buffer", "usearch_load", "usearch_load_buffer", "usearch_serialized_length",
+    "usearch_header_get_entry_slot", "usearch_header_set_entry_slot", "lantern_gpu_version", "lantern_gpu_device_count",
+    "lantern_gpu_set_seed", "lantern_gpu_set_add_batch", "lantern_gpu_add_many", "lantern_gpu_flush",
+    "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device",
+    "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
+    "lantern_gpu_distance_matrix", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
+    "lantern_gpu_counters_get", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
+    "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist",
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LanternGpuError(f"{LIB_PATH} is missing: run `python -m lantern_amd.build` (needs hipcc); "
+                              "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32, u64, i32, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_float
+    err = C.POINTER(C.c_char_p)
+    sig = {
+        "usearch_init": (vp, [C.POINTER(InitOptions), vp, err]),
+        "usearch_free": (None, [vp, err]),
+        "usearch_reserve": (None, [vp, sz, err]),
+        "usearch_size": (sz, [vp, err]),
+        "usearch_capacity": (sz, [vp, err]),
+        "usearch_dimensions": (sz, [vp, err]),
+        "usearch_add": (None, [vp, u64, vp, i32, err]),
+        "usearch_search_ef": (sz, [vp, vp, i32, sz, sz, C.c_bool, vp, vp, err]),
+        "usearch_distance": (f32, [vp, vp, i32, sz, i32, err]),
+        "usearch_index_metadata": (Metadata, [vp, err]),
+        "usearch_save": (None, [vp, C.c_char_p, err]),
+        "usearch_save_buffer": (None, [vp, vp, sz, err]),
+        "usearch_load": (None, [vp, C.c_char_p, err]),
+        "usearch_load_buffer": (None, [vp, vp, sz, err]),
+        "usearch_serialized_length": (sz, [vp, err]),
+        "usearch_header_get_entry_slot": (u64, [vp]),
+        "usearch_header_set_entry_slot": (None, [vp, u64]),
+        "lantern_gpu_version": (C.c_char_p, []),
+        "lantern_gpu_device_count": (i32, []),
+        "lantern_gpu_set_seed": (None, [vp, u64, err]),
+        "lantern_gpu_set_add_batch": (None, [vp, sz, sz, err]),
+        "lantern_gpu_add_many": (None, [vp, vp, vp, sz, i32, err]),
+        "lantern_gpu_flush": (None, [vp, err]),
+        "lantern_gpu_add_with_level": (None, [vp, u64, vp, i32, i32, err]),
+        "lantern_gpu_search_batch": (None, [vp, vp, sz, i32, sz, sz, vp, vp, vp, err]),
+        "lantern_gpu_search_batch_device": (None, [vp, vp, sz, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp, err]),
+        "lantern_gpu_set_search_shape": (None, [vp, i32, i32, err]),
+        "lantern_gpu_exact_search": (None, [vp, vp, sz, sz, vp, vp, err]),
+        "lantern_gpu_distance_gather": (None, [vp, vp, vp, sz, vp, err]),
+        "lantern_gpu_distance_matrix": (None, [vp, sz, vp, sz, i32, sz, i32, i32, vp, err]),
+        "lantern_gpu_graph_info_get": (GraphInfo, [vp, err]),
+        "lantern_gpu_export_graph": (None, [vp, vp, vp, vp, vp, vp, vp, err]),
+        "lantern_gpu_import_graph": (None, [vp, sz, vp, vp, vp, vp, vp, vp, u32, C.c_int32, err]),
+        "lantern_gpu_counters_get": (Counters, [vp, err]),
+        "lantern_scan_begin": (vp, [vp, i32, i32, err]),
+        "lantern_scan_rescan": (None, [vp, vp, i32, err]),
+        "lantern_scan_gettuple": (C.c_bool, [vp, C.POINTER(u64), err]),
+        "lantern_scan_end": (None, [vp]),
+        "lantern_l2sq_dist": (f32, [vp, i32, vp, i32, err]),
+        "lantern_cos_dist": (f32, [vp, i32, vp, i32, err]),
+        "lantern_hamming_dist": (C.c_int32, [vp, i32, vp, i32, err]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError = the library does not export what the header declares
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check(err: C.c_char_p):
+    if err.value is not None:
+        raise LanternGpuError(err.value.decode())
+
+
+def _call(name, *args):
+    err = C.c_char_p()
+    out = getattr(lib(), name)(*args, C.byref(err))
+    _check(err)
+    return out
+
+
+def device_count() -> int:
+    return int(lib().lantern_gpu_device_count())
+
+
+def _rows(x, metric):
+    dt = np.uint32 if metric == METRIC_HAMMING else np.float32
+    a = np.ascontiguousarray(x, dtype=dt)
+    return a.reshape(1, -1) if a.ndim == 1 else a
+
+
+def _kind(metric):
+    return SCALAR_B1 if metric == METRIC_HAMMING else SCALAR_F32
+
+
+def distance(a, b, metric) -> float:
+    """usearch_distance: one pair, on the device."""
+    m = METRICS.get(metric, metric)
+    A, B = _rows(a, m)[0], _rows(b, m)[0]
+    dims = A.size * 32 if m == METRIC_HAMMING else A.size
+    return float(_call("usearch_distance", _ptr(A), _ptr(B), _kind(m), dims, m))
+
+
+def distance_matrix(a, b, metric, exact_order=True):
+    m = METRICS.get(metric, metric)
+    A, B = _rows(a, m), _rows(b, m)
+    dims = A.shape[1] * 32 if m == METRIC_HAMMING else A.shape[1]
+    out = np.empty((A.shape[0], B.shape[0]), dtype=np.float32)
+    _call("lantern_gpu_distance_matrix", _ptr(A), A.shape[0], _ptr(B), B.shape[0], _kind(m), dims, m,
+          1 if exact_order else 0, _ptr(out))
+    return out
+
+
+def l2sq_dist(a, b) -> float:
+    """SQL l2sq_dist(real[], real[]) (hnsw.c:354-360)."""
+    A, B = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    return float(_call("lantern_l2sq_dist", _ptr(A), A.size, _ptr(B), B.size))
+
+
+def cos_dist(a, b) -> float:
+    A, B = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    return float(_call("lantern_cos_dist", _ptr(A), A.size, _ptr(B), B.size))
+
+
+def hamming_dist(a, b) -> int:
+    A, B = np.ascontiguousarray(a, dtype=np.int32), np.ascontiguousarray(b, dtype=np.int32)
+    return int(_call("lantern_hamming_dist", _ptr(A), A.size, _ptr(B), B.size))
+
+
+class GpuIndex:
+    """usearch_index_t over the C ABI.  `dims` = f32 scalars, or u32 WORDS for hamming."""
+
+    def __init__(self, metric, dims, M=16, ef_construction=128, ef=64, seed=42):
+        self.metric = METRICS.get(metric, metric)
+        self.dims, self.M, self.efc, self.ef = dims, M, ef_construction, ef
+        o = InitOptions()
+        o.metric_kind = self.metric
+        o.metric = None
+        o.quantization = _kind(self.metric)
+        o.dimensions = dims * 32 if self.metric == METRIC_HAMMING else dims  # scan.c:84-88
+        o.connectivity, o.expansion_add, o.expansion_search, o.num_threads = M, ef_construction, ef, 1
+        o.pq = False
+        self.h = None
+        self.h = _call("usearch_init", C.byref(o), None)
+        _call("lantern_gpu_set_seed", self.h, seed)
+
+    def close(self):
+        if getattr(self, "h", None):
+            _call("usearch_free", self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(_call("usearch_size", self.h))
+
+    @property
+    def capacity(self):
+        return int(_call("usearch_capacity", self.h))
+
+    def reserve(self, n):
+        _call("usearch_reserve", self.h, n)
+
+    def set_add_batch(self, max_batch, min_ratio):
+        _call("lantern_gpu_set_add_batch", self.h, max_batch, min_ratio)
+
+    def set_search_shape(self, waves, max_workgroups=0):
+        _call("lantern_gpu_set_search_shape", self.h, waves, max_workgroups)
+
+    def add(self, label, vec, level=None):
+        v = _rows(vec, self.metric)[0]
+        if v.size != self.dims:
+            raise LanternGpuError(f"Wrong number of dimensions: {v.size} instead of {self.dims} expected")  # hnsw_insert.out
+        if level is None:
+            _call("usearch_add", self.h, int(label), _ptr(v), _kind(self.metric))
+        else:
+            _call("lantern_gpu_add_with_level", self.h, int(label), _ptr(v), _kind(self.metric), int(level))
+
+    def add_many(self, labels, vecs):
+        V = _rows(vecs, self.metric)
+        lab = np.ascontiguousarray(labels, dtype=np.uint64)
+        assert V.shape[1] == self.dims and lab.size == V.shape[0]
+        _call("lantern_gpu_add_many", self.h, _ptr(lab), _ptr(V), V.shape[0], _kind(self.metric))
+
+    def flush(self):
+        _call("lantern_gpu_flush", self.h)
+
+    def search(self, query, k, ef=0, streaming=False):
+        """usearch_search_ef: (labels, distances) of length <= k."""
+        q = _rows(query, self.metric)[0]
+        if q.size != self.dims:
+            kind = "int" if self.metric == METRIC_HAMMING else "real"
+            raise LanternGpuError(f"Expected {kind} array with dimension {self.dims}, got {q.size}")  # hnsw.c:474-476
+        labels = np.zeros(k, dtype=np.uint64)
+        dists = np.zeros(k, dtype=np.float32)
+        n = _call("usearch_search_ef", self.h, _ptr(q), _kind(self.metric), k, ef, bool(streaming), _ptr(labels), _ptr(dists))
+        return labels[:n], dists[:n]
+
+    def search_batch(self, queries, k, ef=0):
+        Q = _rows(queries, self.metric)
+        nq = Q.shape[0]
+        labels = np.zeros((nq, k), dtype=np.uint64)
+        dists = np.zeros((nq, k), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        _call("lantern_gpu_search_batch", self.h, _ptr(Q), nq, _kind(self.metric), k, ef, _ptr(labels), _ptr(dists), _ptr(counts))
+        return labels, dists, counts
+
+    def search_batch_device(self, d_queries, nq, k, ef=0, skip=0, d_labels=None, d_dists=None, d_slots=None, d_counts=None,
+                            d_D=None, d_E=None, stream=None):
+        """All pointers are raw device addresses (ints), e.g. torch.Tensor.data_ptr()."""
+        _call("lantern_gpu_search_batch_device", self.h, _ptr(d_queries), nq, k, ef, skip, _ptr(d_labels), _ptr(d_dists),
+              _ptr(d_slots), _ptr(d_counts), _ptr(d_D), _ptr(d_E), _ptr(stream))
+
+    def exact_search(self, queries, k):
+        Q = _rows(queries, self.metric)
+        slots = np.zeros((Q.shape[0], k), dtype=np.uint32)
+        dists = np.zeros((Q.shape[0], k), dtype=np.float32)
+        _call("lantern_gpu_exact_search", self.h, _ptr(Q), Q.shape[0], k, _ptr(slots), _ptr(dists))
+        return slots, dists
+
+    def distance_gather(self, query, slots):
+        q = _rows(query, self.metric)[0]
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        out = np.zeros(s.size, dtype=np.float32)
+        _call("lantern_gpu_distance_gather", self.h, _ptr(q), _ptr(s), s.size, _ptr(out))
+        return out
+
+    def graph_info(self):
+        return _call("lantern_gpu_graph_info_get", self.h)
+
+    def counters(self):
+        c = _call("lantern_gpu_counters_get", self.h)
+        return {n: int(getattr(c, n)) for n, _ in Counters._fields_}
+
+    def metadata(self):
+        return _call("usearch_index_metadata", self.h)
+
+    def export_graph(self, with_vectors=False):
+        gi = self.graph_info()
+        n, M = gi.size, self.M
+        g = {
+            "levels": np.zeros(n, dtype=np.uint8),
+            "nbr0": np.zeros((n, 2 * M), dtype=np.uint32),
+            "upper_off": np.zeros(n, dtype=np.uint32),
+            "upper_nbr": np.zeros((max(gi.upper_blocks, 1), M), dtype=np.uint32),
+            "labels": np.zeros(n, dtype=np.uint64),
+        }
+        vecs = None
+        if with_vectors:
+            vecs = np.zeros((n, gi.vector_words), dtype=np.uint32 if self.metric == METRIC_HAMMING else np.float32)
+        _call("lantern_gpu_export_graph", self.h, _ptr(g["levels"]), _ptr(g["nbr0"]), _ptr(g["upper_off"]),
+              _ptr(g["upper_nbr"]), _ptr(g["labels"]), _ptr(vecs))
+        g["upper_nbr"] = g["upper_nbr"][:gi.upper_blocks]
+        g["entry_slot"], g["max_level"] = int(gi.entry_slot), int(gi.max_level)
+        if with_vectors:
+            g["vectors"] = vecs
+        return g
+
+    def import_graph(self, vectors, graph):
+        V = _rows(vectors, self.metric)
+        levels = np.ascontiguousarray(graph["levels"], dtype=np.uint8)
+        nbr0 = np.ascontiguousarray(graph["nbr0"], dtype=np.uint32)
+        upper_off = np.ascontiguousarray(graph["upper_off"], dtype=np.uint32)
+        upper_nbr = np.ascontiguousarray(graph["upper_nbr"], dtype=np.uint32)
+        if upper_nbr.size == 0:
+            upper_nbr = np.full((1, self.M), EMPTY, dtype=np.uint32)
+        labels = np.ascontiguousarray(graph["labels"], dtype=np.uint64) if graph.get("labels") is not None else None
+        _call("lantern_gpu_import_graph", self.h, V.shape[0], _ptr(V), _ptr(labels), _ptr(levels), _ptr(nbr0),
+              _ptr(upper_off), _ptr(upper_nbr), int(graph["entry_slot"]), int(graph["max_level"]))
+
+    def save(self, path):
+        _call("usearch_save", self.h, path.encode())
+
+    def load(self, path):
+        _call("usearch_load", self.h, path.encode())
+
+    def save_buffer(self) -> bytes:
+        n = int(_call("usearch_serialized_length", self.h))
+        buf = (C.c_char * n)()
+        _call("usearch_save_buffer", self.h, C.cast(buf, C.c_void_p), n)
+        return bytes(buf)
+
+    def load_buffer(self, data: bytes):
+        buf = C.create_string_buffer(data, len(data))
+        _call("usearch_load_buffer", self.h, C.cast(buf, C.c_void_p), len(data))
+
+
+class Scan:
+    """lantern_scan_*: the amgettuple paging shim (scan.c:24-338)."""
+
+    def __init__(self, index: GpuIndex, init_k=10, ef=0):
+        self.index = index
+        self.s = _call("lantern_scan_begin", index.h, init_k, ef)
+
+    def rescan(self, query):
+        q = _rows(query, self.index.metric)[0]
+        if q.size != self.index.dims:
+            kind = "int" if self.index.metric == METRIC_HAMMING else "real"
+            raise LanternGpuError(f"Expected {kind} array with dimension {self.index.dims}, got {q.size}")
+        _call("lantern_scan_rescan", self.s, _ptr(q), _kind(self.index.metric))
+
+    def gettuple(self):
+        label = C.c_uint64()
+        err = C.c_char_p()
+        ok = lib().lantern_scan_gettuple(self.s, C.byref(label), C.byref(err))
+        _check(err)
+        return int(label.value) if ok else None
+
+    def fetch(self, limit):
+        out = []
+        while len(out) < limit:
+            l = self.gettuple()
+            if l is None:
+                break
+            out.append(l)
+        return out
+
+    def end(self):
+        if self.s:
+            lib().lantern_scan_end(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.end()
+        except Exception:
+            pass

@@ -1,0 +1,174 @@
+// device_common.hpp -- gfx950 device primitives shared by every kernel of the HNSW path.
+//
+// Numerics contract: a row of d f32 scalars is zero-padded to whole
+// 16-byte chunks; G lanes (8/16/32/64, chosen from the chunk count) cooperate on one row; lane l
+// owns chunks l, l+G, l+2G... and runs ONE fmaf chain per accumulator over its scalars in memory
+// order; the G partials are combined by an xor butterfly (off = G/2 .. 1).  The oracle models
+// exactly this tree (oracle/metrics.c, LO_SUM_WAVE64), so device results are compared
+// bit-for-bit.  Built with -ffp-contract=off: every fma below is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lgpu {
+
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+
+// values follow usearch_metric_kind_t (include/lantern_gpu.h)
+constexpr int M_COS = 1;
+constexpr int M_L2SQ = 3;
+constexpr int M_HAMMING = 8;
+
+// ---- order-preserving float <-> u32, and the (distance, slot) candidate key ---------------------
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o)
+{
+    uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(b);
+}
+// key = distance (ordered) : slot : expanded-flag.  Total order (distance, slot); the flag is the
+// lowest bit so it never changes the relative order of two different slots.
+__device__ __forceinline__ uint64_t make_key(float d, uint32_t slot) { return ((uint64_t)f2ord(d) << 32) | ((uint64_t)slot << 1); }
+__device__ __forceinline__ uint32_t key_slot(uint64_t k) { return (uint32_t)(k & 0xFFFFFFFFu) >> 1; }
+__device__ __forceinline__ float    key_dist(uint64_t k) { return ord2f((uint32_t)(k >> 32)); }
+__device__ __forceinline__ bool     key_expanded(uint64_t k) { return (k & 1u) != 0; }
+
+// per-centre pseudo-random tie order used by the neighbour-selection heuristic (oracle/hnsw.c tie_mix)
+__device__ __forceinline__ uint32_t tie_mix(uint32_t id, uint32_t centre) { return (id ^ (centre * 0x9E3779B1u)) * 0x85EBCA6Bu; }
+
+// ---- per-lane accumulation ----------------------------------------------------------------------
+template <int METRIC> struct Acc;
+
+template <> struct Acc<M_L2SQ>
+{
+    float s = 0.f;
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb)
+    {
+        float t;
+        t = __uint_as_float(xa.x) - __uint_as_float(yb.x); s = __builtin_fmaf(t, t, s);
+        t = __uint_as_float(xa.y) - __uint_as_float(yb.y); s = __builtin_fmaf(t, t, s);
+        t = __uint_as_float(xa.z) - __uint_as_float(yb.z); s = __builtin_fmaf(t, t, s);
+        t = __uint_as_float(xa.w) - __uint_as_float(yb.w); s = __builtin_fmaf(t, t, s);
+    }
+    template <int G> __device__ __forceinline__ float finish()
+    {
+#pragma unroll
+        for(int off = G / 2; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+        return s;
+    }
+};
+
+template <> struct Acc<M_COS>
+{
+    float ab = 0.f, a2 = 0.f, b2 = 0.f;
+    __device__ __forceinline__ void one(float x, float y)
+    {
+        ab = __builtin_fmaf(x, y, ab);
+        a2 = __builtin_fmaf(x, x, a2);
+        b2 = __builtin_fmaf(y, y, b2);
+    }
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb)
+    {
+        one(__uint_as_float(xa.x), __uint_as_float(yb.x));
+        one(__uint_as_float(xa.y), __uint_as_float(yb.y));
+        one(__uint_as_float(xa.z), __uint_as_float(yb.z));
+        one(__uint_as_float(xa.w), __uint_as_float(yb.w));
+    }
+    template <int G> __device__ __forceinline__ float finish()
+    {
+#pragma unroll
+        for(int off = G / 2; off >= 1; off >>= 1) {
+            ab = ab + __shfl_xor(ab, off, 64);
+            a2 = a2 + __shfl_xor(a2, off, 64);
+            b2 = b2 + __shfl_xor(b2, off, 64);
+        }
+        // zero-norm rules pinned by the reference's tests (hnsw_vector.out:205-210,
+        // hnsw_dist_func.out:58-61): both zero -> 0, one zero -> 1
+        if(a2 == 0.f && b2 == 0.f) return 0.f;
+        if(a2 == 0.f || b2 == 0.f) return 1.f;
+        return 1.f - __fdiv_rn(ab, __fsqrt_rn(a2) * __fsqrt_rn(b2));
+    }
+};
+
+template <> struct Acc<M_HAMMING>
+{
+    uint32_t s = 0;
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb)
+    {
+        s += __popc(xa.x ^ yb.x) + __popc(xa.y ^ yb.y) + __popc(xa.z ^ yb.z) + __popc(xa.w ^ yb.w);
+    }
+    template <int G> __device__ __forceinline__ float finish()
+    {
+#pragma unroll
+        for(int off = G / 2; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+        return (float)s;
+    }
+};
+
+// One distance by one G-lane group: a and b each `chunks` uint4 long; gl = lane index in group.
+// Every lane of the group returns the same value.
+template <int METRIC, int G, typename PA, typename PB>
+__device__ __forceinline__ float group_dist(PA a, PB b, int chunks, int gl)
+{
+    Acc<METRIC> acc;
+#pragma unroll 4
+    for(int ch = gl; ch < chunks; ch += G) {
+        uint4 x = a[ ch ];
+        uint4 y = b[ ch ];
+        acc.add(x, y);
+    }
+    return acc.template finish<G>();
+}
+
+// Two rows against the same `a` at once (twice the loads in flight per lane).
+template <int METRIC, int G, typename PA, typename PB>
+__device__ __forceinline__ void group_dist2(PA a, PB b0, PB b1, int chunks, int gl, float &d0, float &d1)
+{
+    Acc<METRIC> acc0, acc1;
+#pragma unroll 4
+    for(int ch = gl; ch < chunks; ch += G) {
+        uint4 x = a[ ch ];
+        uint4 y0 = b0[ ch ];
+        uint4 y1 = b1[ ch ];
+        acc0.add(x, y0);
+        acc1.add(x, y1);
+    }
+    d0 = acc0.template finish<G>();
+    d1 = acc1.template finish<G>();
+}
+
+// lanes per row for a row of `chunks` 16-byte chunks (oracle: lo_wave_group_lanes)
+__host__ __device__ inline int group_lanes_for(uint32_t chunks) { return chunks >= 64 ? 64 : chunks >= 32 ? 32 : chunks >= 16 ? 16 : 8; }
+
+// ---- read-only view of the index in HBM -----------------------------------------------------------
+struct View
+{
+    const uint4    *vec;       // [n][chunks] rows, zero padded
+    uint32_t        chunks;    // uint4 per row
+    uint32_t        M, M0;     // neighbours per upper level / level 0 (2M)
+    uint32_t       *nbr0;      // [cap][M0], EMPTY-terminated
+    const uint32_t *upper_off; // [cap] first upper block of the node (levels 1..L are consecutive)
+    uint32_t       *upper_nbr; // [blocks][M]
+    const uint8_t  *levels;    // [cap]
+    uint32_t        n;
+    uint32_t        entry;
+    int32_t         max_level;
+};
+
+__device__ __forceinline__ const uint4 *row_of(const View &v, uint32_t slot) { return v.vec + (size_t)slot * v.chunks; }
+
+__device__ __forceinline__ uint32_t *neighbors_of(const View &v, uint32_t slot, int level, uint32_t &cap)
+{
+    if(level == 0) {
+        cap = v.M0;
+        return v.nbr0 + (size_t)slot * v.M0;
+    }
+    cap = v.M;
+    return v.upper_nbr + ((size_t)v.upper_off[ slot ] + (size_t)(level - 1)) * v.M;
+}
+
+}  // namespace lgpu

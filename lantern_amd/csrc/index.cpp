@@ -1,0 +1,844 @@
+// index.cpp -- host side of the C ABI: index lifecycle, buffered/batched inserts, search launches.
+//
+// Mirrors the usearch C API as Lantern calls it (prototypes and reference
+// call sites are listed in include/lantern_gpu.h).  The graph and the vector block live in HBM for
+// the whole life of the index; the host keeps only labels/levels (for serialisation) and the
+// buffer of not-yet-inserted vectors.
+#include "index.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "host_util.hpp"
+
+namespace lgpu {
+
+static const char *kNoDevice = "lantern_gpu: no HIP device available (this library has no CPU fallback)";
+
+const char *set_err(Index *ix, const std::string &msg)
+{
+    ix->err = msg;
+    return ix->err.c_str();
+}
+
+#define HIPCHK(ix, expr)                                                                  \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if(e_ != hipSuccess) {                                                            \
+            set_err(ix, std::string("lantern_gpu: HIP error in " #expr ": ") + hipGetErrorString(e_)); \
+            return false;                                                                 \
+        }                                                                                 \
+    } while(0)
+
+static bool dev_grow(Index *ix, void **p, size_t old_bytes, size_t new_bytes, int fill_new_with)
+{
+    void *q = nullptr;
+    HIPCHK(ix, hipMalloc(&q, new_bytes ? new_bytes : 16));
+    if(*p && old_bytes) HIPCHK(ix, hipMemcpyAsync(q, *p, old_bytes, hipMemcpyDeviceToDevice, ix->stream));
+    if(fill_new_with >= 0 && new_bytes > old_bytes)
+        HIPCHK(ix, hipMemsetAsync((char *)q + old_bytes, fill_new_with, new_bytes - old_bytes, ix->stream));
+    HIPCHK(ix, hipStreamSynchronize(ix->stream));
+    if(*p) HIPCHK(ix, hipFree(*p));
+    *p = q;
+    return true;
+}
+
+void *scratch(Index *ix, int which, size_t bytes)
+{
+    if(ix->scratch_bytes[ which ] >= bytes && ix->d_scratch[ which ]) return ix->d_scratch[ which ];
+    if(ix->d_scratch[ which ]) (void)hipFree(ix->d_scratch[ which ]);
+    ix->d_scratch[ which ] = nullptr;
+    ix->scratch_bytes[ which ] = 0;
+    size_t want = bytes + bytes / 2 + 256;
+    if(hipMalloc(&ix->d_scratch[ which ], want) != hipSuccess) {
+        set_err(ix, "lantern_gpu: out of device memory (scratch)");
+        return nullptr;
+    }
+    ix->scratch_bytes[ which ] = want;
+    return ix->d_scratch[ which ];
+}
+
+View Index::view() const
+{
+    View v;
+    v.vec = d_vec;
+    v.chunks = chunks;
+    v.M = M;
+    v.M0 = M0;
+    v.nbr0 = d_nbr0;
+    v.upper_off = d_upper_off;
+    v.upper_nbr = d_upper_nbr;
+    v.levels = d_levels;
+    v.n = (uint32_t)n;
+    v.entry = entry;
+    v.max_level = max_level;
+    return v;
+}
+
+static bool reserve_locked(Index *ix, size_t newcap)
+{
+    if(newcap <= ix->cap) return true;
+    if(newcap >= 0x7FFFFFFFull) { set_err(ix, "lantern_gpu: capacity above 2^31-1 slots is not supported"); return false; }
+    const size_t oc = ix->cap, row = (size_t)ix->chunks * 16;
+    if(!dev_grow(ix, (void **)&ix->d_vec, oc * row, newcap * row, -1)) return false;
+    if(!dev_grow(ix, (void **)&ix->d_labels, oc * 8, newcap * 8, -1)) return false;
+    if(!dev_grow(ix, (void **)&ix->d_levels, oc, newcap, 0)) return false;
+    if(!dev_grow(ix, (void **)&ix->d_nbr0, oc * ix->M0 * 4, newcap * ix->M0 * 4, 0xFF)) return false;
+    if(!dev_grow(ix, (void **)&ix->d_upper_off, oc * 4, newcap * 4, 0xFF)) return false;
+    ix->cap = newcap;
+    // the visited bitmaps are sized by capacity
+    if(ix->d_bitmaps) { (void)hipFree(ix->d_bitmaps); ix->d_bitmaps = nullptr; }
+    ix->bitmap_slots = 0;
+    ix->bm_words = 0;
+    return true;
+}
+
+static bool reserve_upper(Index *ix, size_t need_blocks)
+{
+    if(need_blocks <= ix->upper_cap) return true;
+    size_t nc = std::max<size_t>(std::max<size_t>(ix->upper_cap * 2, need_blocks), 1024);
+    if(!dev_grow(ix, (void **)&ix->d_upper_nbr, ix->upper_cap * ix->M * 4, nc * ix->M * 4, 0xFF)) return false;
+    ix->upper_cap = nc;
+    return true;
+}
+
+bool ensure_bitmaps(Index *ix, size_t slots)
+{
+    const size_t words = ((std::max<size_t>(ix->cap, 1) + 31) / 32 + 3) / 4 * 4;
+    if(ix->d_bitmaps && ix->bitmap_slots >= slots && ix->bm_words == words) return true;
+    if(ix->d_bitmaps) { (void)hipFree(ix->d_bitmaps); ix->d_bitmaps = nullptr; }
+    slots = std::max(slots, ix->bitmap_slots);
+    HIPCHK(ix, hipMalloc((void **)&ix->d_bitmaps, slots * words * 4));
+    ix->bitmap_slots = slots;
+    ix->bm_words = words;
+    return true;
+}
+
+bool pad_row(const Index *ix, const void *vec, uint32_t *dst)
+{
+    const size_t row_words = (size_t)ix->chunks * 4;
+    if(ix->scalar == usearch_scalar_b1_k) {
+        const size_t bytes = (ix->opts.dimensions + 7) / 8;
+        std::memset(dst, 0, row_words * 4);
+        std::memcpy(dst, vec, bytes);
+    } else {
+        std::memcpy(dst, vec, (size_t)ix->words * 4);
+        for(size_t i = ix->words; i < row_words; ++i) dst[ i ] = 0;
+    }
+    return true;
+}
+
+int search_grid(const Index *ix, size_t nq, int waves)
+{
+    // the kernels run at 4 waves/SIMD = 16 waves/CU (VGPR-bound); one workgroup = `waves` waves
+    int per_cu = std::max(1, 16 / std::max(1, waves));
+    size_t g = (size_t)ix->num_cus * per_cu;
+    if(ix->search_max_wg > 0) g = (size_t)ix->search_max_wg;
+    if(g > nq) g = nq;
+    return (int)std::max<size_t>(g, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// inserts
+// ---------------------------------------------------------------------------------------------------
+
+static bool insert_first(Index *ix, size_t pi)
+{
+    int lvl = ix->pend_levels[ pi ] >= 0 ? ix->pend_levels[ pi ] : level_for(ix->seed, 0, ix->M);
+    if(!reserve_locked(ix, std::max<size_t>(ix->cap, 64))) return false;
+    if(!reserve_upper(ix, (size_t)lvl)) return false;
+    const size_t row_words = (size_t)ix->chunks * 4;
+    uint8_t      l8 = (uint8_t)lvl;
+    uint32_t     uo = lvl > 0 ? 0u : EMPTY;
+    HIPCHK(ix, hipMemcpyAsync(ix->d_vec, &ix->pend_rows[ pi * row_words ], row_words * 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipMemcpyAsync(ix->d_labels, &ix->pend_labels[ pi ], 8, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipMemcpyAsync(ix->d_levels, &l8, 1, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipMemcpyAsync(ix->d_upper_off, &uo, 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipStreamSynchronize(ix->stream));
+    ix->labels.push_back(ix->pend_labels[ pi ]);
+    ix->levels.push_back(l8);
+    ix->upper_off.push_back(uo);
+    ix->upper_blocks = (size_t)lvl;
+    ix->n = 1;
+    ix->entry = 0;
+    ix->max_level = lvl;
+    ix->c_add_vectors += 1;
+    return true;
+}
+
+static bool run_batch(Index *ix, size_t pi, size_t b, const int *lv)
+{
+    const size_t first = ix->n, row_words = (size_t)ix->chunks * 4;
+    if(first + b > ix->cap && !reserve_locked(ix, std::max(ix->cap * 2, first + b))) return false;
+    size_t up = 0;
+    for(size_t i = 0; i < b; ++i) up += (size_t)lv[ i ];
+    if(!reserve_upper(ix, ix->upper_blocks + up)) return false;
+
+    std::vector<uint8_t>  l8(b);
+    std::vector<uint32_t> uo(b), link_off(b);
+    size_t                blocks = ix->upper_blocks, total_links = 0;
+    for(size_t i = 0; i < b; ++i) {
+        l8[ i ] = (uint8_t)lv[ i ];
+        uo[ i ] = lv[ i ] > 0 ? (uint32_t)blocks : EMPTY;
+        blocks += (size_t)lv[ i ];
+        link_off[ i ] = (uint32_t)total_links;
+        total_links += (size_t)ix->M * (size_t)(lv[ i ] + 1);
+    }
+    HIPCHK(ix, hipMemcpyAsync((char *)ix->d_vec + first * row_words * 4, &ix->pend_rows[ pi * row_words ], b * row_words * 4,
+                              hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipMemcpyAsync(ix->d_labels + first, &ix->pend_labels[ pi ], b * 8, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipMemcpyAsync(ix->d_levels + first, l8.data(), b, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipMemcpyAsync(ix->d_upper_off + first, uo.data(), b * 4, hipMemcpyHostToDevice, ix->stream));
+
+    uint32_t *d_link_off = (uint32_t *)scratch(ix, 0, b * 4);
+    LinkReq  *d_links = (LinkReq *)scratch(ix, 1, total_links * sizeof(LinkReq));
+    if(!d_link_off || !d_links) return false;
+    HIPCHK(ix, hipMemcpyAsync(d_link_off, link_off.data(), b * 4, hipMemcpyHostToDevice, ix->stream));
+
+    const int grid = search_grid(ix, b, ix->insert_waves);
+    if(!ensure_bitmaps(ix, (size_t)grid)) return false;
+
+    InsertArgs ia;
+    ia.view = ix->view();  // size/entry/max_level as they were BEFORE the batch
+    ia.first_slot = (uint32_t)first;
+    ia.count = (uint32_t)b;
+    ia.efc = ix->efc;
+    ia.link_off = d_link_off;
+    ia.links = d_links;
+    ia.bitmaps = ix->d_bitmaps;
+    ia.bm_words = (uint32_t)ix->bm_words;
+    ia.totals = ix->d_totals + 2;
+    if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
+    HIPCHK(ix, launch_insert(ix->metric, ia, ix->insert_waves, grid, ix->stream));
+
+    std::vector<LinkReq> h(total_links);
+    HIPCHK(ix, hipMemcpyAsync(h.data(), d_links, total_links * sizeof(LinkReq), hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(ix, hipStreamSynchronize(ix->stream));
+
+    // reverse links: group by (close, level); within a group apply in new-slot order
+    size_t m = 0;
+    for(size_t i = 0; i < total_links; ++i)
+        if(h[ i ].close != EMPTY) h[ m++ ] = h[ i ];
+    h.resize(m);
+    std::sort(h.begin(), h.end(), [](const LinkReq &x, const LinkReq &y) {
+        if(x.close != y.close) return x.close < y.close;
+        if(x.level != y.level) return x.level < y.level;
+        return x.new_slot < y.new_slot;
+    });
+    std::vector<uint32_t> gb;
+    for(size_t i = 0; i < m; ++i)
+        if(i == 0 || h[ i ].close != h[ i - 1 ].close || h[ i ].level != h[ i - 1 ].level) gb.push_back((uint32_t)i);
+    const uint32_t ngroups = (uint32_t)gb.size();
+    gb.push_back((uint32_t)m);
+    if(ngroups) {
+        LinkReq  *d_reqs = (LinkReq *)scratch(ix, 2, m * sizeof(LinkReq));
+        uint32_t *d_gb = (uint32_t *)scratch(ix, 3, gb.size() * 4);
+        if(!d_reqs || !d_gb) return false;
+        HIPCHK(ix, hipMemcpyAsync(d_reqs, h.data(), m * sizeof(LinkReq), hipMemcpyHostToDevice, ix->stream));
+        HIPCHK(ix, hipMemcpyAsync(d_gb, gb.data(), gb.size() * 4, hipMemcpyHostToDevice, ix->stream));
+        RevlinkArgs ra;
+        ra.view = ix->view();
+        ra.ngroups = ngroups;
+        ra.group_begin = d_gb;
+        ra.reqs = d_reqs;
+        ra.totals = ix->d_totals + 5;
+        HIPCHK(ix, launch_revlink(ix->metric, ra, ix->stream));
+        HIPCHK(ix, hipStreamSynchronize(ix->stream));
+    }
+
+    for(size_t i = 0; i < b; ++i) {
+        ix->labels.push_back(ix->pend_labels[ pi + i ]);
+        ix->levels.push_back(l8[ i ]);
+        ix->upper_off.push_back(uo[ i ]);
+    }
+    ix->upper_blocks = blocks;
+    ix->n = first + b;
+    if(b == 1 && lv[ 0 ] > ix->max_level) {  // "Updating the entry point if needed"
+        ix->entry = (uint32_t)first;
+        ix->max_level = lv[ 0 ];
+    }
+    ix->c_add_vectors += b;
+    ix->c_add_batches += 1;
+    return true;
+}
+
+bool flush_locked(Index *ix)
+{
+    const size_t pending = ix->pend_labels.size();
+    size_t       pi = 0;
+    bool         ok = true;
+    std::vector<int> lv;
+    while(pi < pending) {
+        if(ix->n == 0) {
+            if(!(ok = insert_first(ix, pi))) break;
+            pi += 1;
+            continue;
+        }
+        const size_t look = std::min(pending - pi, ix->add_batch_max);
+        lv.resize(look);
+        for(size_t i = 0; i < look; ++i)
+            lv[ i ] = ix->pend_levels[ pi + i ] >= 0 ? ix->pend_levels[ pi + i ] : level_for(ix->seed, ix->n + i, ix->M);
+        const size_t b = plan_batch(ix->n, ix->max_level, lv.data(), look, ix->add_batch_max, ix->add_min_ratio);
+        if(!(ok = run_batch(ix, pi, b, lv.data()))) break;
+        pi += b;
+    }
+    // drop what was inserted (everything, unless a batch failed)
+    const size_t row_words = (size_t)ix->chunks * 4;
+    ix->pend_labels.erase(ix->pend_labels.begin(), ix->pend_labels.begin() + (ptrdiff_t)pi);
+    ix->pend_levels.erase(ix->pend_levels.begin(), ix->pend_levels.begin() + (ptrdiff_t)pi);
+    ix->pend_rows.erase(ix->pend_rows.begin(), ix->pend_rows.begin() + (ptrdiff_t)(pi * row_words));
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------------------------------
+
+bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, size_t ef, size_t skip, uint64_t *d_labels,
+                       float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D, uint64_t *d_E, hipStream_t stream,
+                       int waves)
+{
+    if(nq == 0 || k == 0) return true;
+    size_t expansion = ef ? ef : ix->ef;
+    if(expansion < k + skip) expansion = k + skip;  // usearch: expansion = max(expansion, wanted)
+    if(search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0) > 160 * 1024) {
+        set_err(ix, "lantern_gpu: ef/k exceed the 160 KiB LDS budget of the search kernel");
+        return false;
+    }
+    const int grid = search_grid(ix, nq, waves);
+    if(!ensure_bitmaps(ix, (size_t)grid)) return false;
+    SearchArgs a;
+    a.view = ix->view();
+    a.queries = d_queries;
+    a.nq = (uint32_t)nq;
+    a.k = (uint32_t)k;
+    a.ef = (uint32_t)expansion;
+    a.skip = (uint32_t)skip;
+    a.labels = ix->d_labels;
+    a.out_labels = d_labels;
+    a.out_dists = d_dists;
+    a.out_slots = d_slots;
+    a.out_counts = d_counts;
+    a.out_D = d_D;
+    a.out_E = d_E;
+    a.bitmaps = ix->d_bitmaps;
+    a.bm_words = (uint32_t)ix->bm_words;
+    a.totals = ix->d_totals;
+    HIPCHK(ix, launch_search(ix->metric, a, waves, grid, stream));
+    ix->c_search_queries += nq;
+    return true;
+}
+
+bool import_graph_locked(Index *ix, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,
+                         const uint32_t *nbr0, const uint32_t *upper_off, const uint32_t *upper_nbr, uint32_t entry_slot,
+                         int32_t max_level)
+{
+    if(ix->n || !ix->pend_labels.empty()) { set_err(ix, "lantern_gpu: import needs an empty index"); return false; }
+    if(size == 0) return true;
+    size_t blocks = 0;
+    for(size_t i = 0; i < size; ++i) blocks += levels[ i ];
+    if(!reserve_locked(ix, std::max(size, ix->cap)) || !reserve_upper(ix, blocks)) return false;
+    if(ix->chunks * 4 == ix->words) {
+        HIPCHK(ix, hipMemcpy(ix->d_vec, vectors, size * (size_t)ix->words * 4, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(ix, hipMemset(ix->d_vec, 0, size * (size_t)ix->chunks * 16));
+        HIPCHK(ix, hipMemcpy2D(ix->d_vec, (size_t)ix->chunks * 16, vectors, (size_t)ix->words * 4, (size_t)ix->words * 4, size,
+                               hipMemcpyHostToDevice));
+    }
+    ix->labels.resize(size);
+    for(size_t i = 0; i < size; ++i) ix->labels[ i ] = labels ? labels[ i ] : (uint64_t)i;
+    ix->levels.assign(levels, levels + size);
+    ix->upper_off.assign(upper_off, upper_off + size);
+    HIPCHK(ix, hipMemcpy(ix->d_labels, ix->labels.data(), size * 8, hipMemcpyHostToDevice));
+    HIPCHK(ix, hipMemcpy(ix->d_levels, levels, size, hipMemcpyHostToDevice));
+    HIPCHK(ix, hipMemcpy(ix->d_nbr0, nbr0, size * ix->M0 * 4, hipMemcpyHostToDevice));
+    HIPCHK(ix, hipMemcpy(ix->d_upper_off, upper_off, size * 4, hipMemcpyHostToDevice));
+    if(blocks) HIPCHK(ix, hipMemcpy(ix->d_upper_nbr, upper_nbr, blocks * ix->M * 4, hipMemcpyHostToDevice));
+    ix->n = size;
+    ix->upper_blocks = blocks;
+    ix->entry = entry_slot;
+    ix->max_level = max_level;
+    return true;
+}
+
+}  // namespace lgpu
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+using namespace lgpu;
+
+#define CLEAR(e) do { if(e) *(e) = nullptr; } while(0)
+#define FAIL(e, msg) do { if(e) *(e) = (msg); } while(0)
+
+static Index *H(usearch_index_t h, usearch_error_t *e)
+{
+    if(!h) { FAIL(e, "lantern_gpu: null index handle"); return nullptr; }
+    return (Index *)h;
+}
+
+extern "C" {
+
+const char *lantern_gpu_version(void) { return "lantern_gpu 0.1 (gfx950)"; }
+
+int lantern_gpu_device_count(void)
+{
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usearch_error_t *e)
+{
+    CLEAR(e);
+    if(!o) { FAIL(e, "lantern_gpu: null init options"); return nullptr; }
+    if(o->metric != nullptr) { FAIL(e, "lantern_gpu: custom metric functions are not supported"); return nullptr; }
+    if(o->pq || pq_codebook) { FAIL(e, "lantern_gpu: product quantization is not supported by the device index"); return nullptr; }
+    if(o->metric_kind != usearch_metric_cos_k && o->metric_kind != usearch_metric_l2sq_k &&
+       o->metric_kind != usearch_metric_hamming_k) {
+        FAIL(e, "lantern_gpu: unsupported metric kind (expected cos, l2sq or hamming)");  // options.c:119-127
+        return nullptr;
+    }
+    if(o->dimensions == 0) { FAIL(e, "lantern_gpu: dimensions must be positive"); return nullptr; }
+    if(o->connectivity < 2 || o->connectivity > 128) { FAIL(e, "lantern_gpu: connectivity (M) must be in [2, 128]"); return nullptr; }  // options.c:165-179
+    const bool ham = o->metric_kind == usearch_metric_hamming_k;
+    if(ham && o->quantization != usearch_scalar_b1_k) { FAIL(e, "lantern_gpu: hamming needs b1 scalars"); return nullptr; }
+    if(!ham && o->quantization != usearch_scalar_f32_k) { FAIL(e, "lantern_gpu: only f32 storage is supported for cos/l2sq (quant_bits=32)"); return nullptr; }
+    if(lantern_gpu_device_count() <= 0) { FAIL(e, kNoDevice); return nullptr; }
+
+    Index *ix = new Index();
+    ix->opts = *o;
+    ix->metric = (int)o->metric_kind;
+    ix->scalar = (int)o->quantization;
+    ix->words = ham ? (uint32_t)((o->dimensions + 31) / 32) : (uint32_t)o->dimensions;
+    ix->chunks = (ix->words + 3) / 4;
+    ix->M = (uint32_t)o->connectivity;
+    ix->M0 = 2 * ix->M;  // validate_index.c:140-151
+    ix->efc = o->expansion_add ? (uint32_t)o->expansion_add : 128;      // options.h:18-24
+    ix->ef = o->expansion_search ? (uint32_t)o->expansion_search : 64;
+    if(const char *dv = std::getenv("LANTERN_GPU_DEVICE")) (void)hipSetDevice(std::atoi(dv));
+    (void)hipGetDevice(&ix->device);
+    hipDeviceProp_t prop;
+    if(hipGetDeviceProperties(&prop, ix->device) == hipSuccess) ix->num_cus = prop.multiProcessorCount;
+    if(hipMalloc((void **)&ix->d_totals, 8 * sizeof(unsigned long long)) != hipSuccess ||
+       hipMemset(ix->d_totals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        delete ix;
+        FAIL(e, "lantern_gpu: device allocation failed");
+        return nullptr;
+    }
+    return ix;
+}
+
+void usearch_free(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    void *ptrs[] = { ix->d_vec, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals };
+    for(void *p : ptrs)
+        if(p) (void)hipFree(p);
+    for(void *p : ix->d_scratch)
+        if(p) (void)hipFree(p);
+    delete ix;
+}
+
+void usearch_reserve(usearch_index_t h, size_t capacity, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!reserve_locked(ix, capacity)) FAIL(e, ix->err.c_str());
+}
+
+size_t usearch_size(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return 0;
+    std::lock_guard<std::mutex> g(ix->mu);
+    return ix->n + ix->pend_labels.size();  // logical size; build.c:117 polls this per tuple
+}
+
+size_t usearch_capacity(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return 0;
+    std::lock_guard<std::mutex> g(ix->mu);
+    return std::max(ix->cap, ix->n + ix->pend_labels.size());
+}
+
+size_t usearch_dimensions(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    return ix ? ix->opts.dimensions : 0;
+}
+
+static void add_common(Index *ix, const usearch_label_t *labels, const void *vectors, size_t n, usearch_scalar_kind_t kind,
+                       int level, usearch_error_t *e)
+{
+    if((int)kind != ix->scalar) { FAIL(e, "lantern_gpu: scalar kind of the vector does not match the index"); return; }
+    if(!vectors || !labels) { FAIL(e, "lantern_gpu: null vector or label pointer"); return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    const size_t row_words = (size_t)ix->chunks * 4;
+    const size_t in_bytes = ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4;
+    const size_t base = ix->pend_labels.size();
+    ix->pend_labels.insert(ix->pend_labels.end(), labels, labels + n);
+    ix->pend_levels.insert(ix->pend_levels.end(), n, level);
+    ix->pend_rows.resize((base + n) * row_words);
+    for(size_t i = 0; i < n; ++i) pad_row(ix, (const char *)vectors + i * in_bytes, &ix->pend_rows[ (base + i) * row_words ]);
+    if(ix->pend_labels.size() >= ix->add_batch_max && !flush_locked(ix)) FAIL(e, ix->err.c_str());
+}
+
+void usearch_add(usearch_index_t h, usearch_label_t label, const void *vector, usearch_scalar_kind_t kind, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(ix) add_common(ix, &label, vector, 1, kind, -1, e);
+}
+
+void lantern_gpu_add_many(usearch_index_t h, const usearch_label_t *labels, const void *vectors, size_t n,
+                          usearch_scalar_kind_t kind, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(ix && n) add_common(ix, labels, vectors, n, kind, -1, e);
+}
+
+void lantern_gpu_add_with_level(usearch_index_t h, usearch_label_t label, const void *vector, usearch_scalar_kind_t kind,
+                                int level, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    if(level < 0 || level > 255) { FAIL(e, "lantern_gpu: level out of range"); return; }
+    add_common(ix, &label, vector, 1, kind, level, e);
+}
+
+void lantern_gpu_flush(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) FAIL(e, ix->err.c_str());
+}
+
+void lantern_gpu_set_seed(usearch_index_t h, uint64_t seed, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(ix) ix->seed = seed;
+}
+
+void lantern_gpu_set_add_batch(usearch_index_t h, size_t max_batch, size_t min_ratio, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    if(max_batch == 0 || min_ratio == 0) { FAIL(e, "lantern_gpu: batch parameters must be positive"); return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->add_batch_max = max_batch;
+    ix->add_min_ratio = min_ratio;
+}
+
+void lantern_gpu_set_search_shape(usearch_index_t h, int waves, int max_wg, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    if(waves < 1 || waves > 8) { FAIL(e, "lantern_gpu: waves_per_query must be in [1, 8]"); return; }
+    ix->search_waves = waves;
+    ix->insert_waves = waves;
+    ix->search_max_wg = max_wg;
+}
+
+size_t usearch_search_ef(usearch_index_t h, const void *query, usearch_scalar_kind_t kind, size_t k, size_t ef, bool streaming,
+                         usearch_label_t *labels, float *distances, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return 0;
+    if((int)kind != ix->scalar) { FAIL(e, "lantern_gpu: scalar kind of the query does not match the index"); return 0; }
+    if(k == 0) return 0;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return 0; }
+    const size_t skip = streaming ? ix->stream_returned : 0;
+    if(ix->n == 0) { ix->stream_returned = 0; return 0; }
+    const size_t row = (size_t)ix->chunks * 16;
+    char        *buf = (char *)scratch(ix, 4, row + k * (8 + 4) + 16);
+    if(!buf) { FAIL(e, ix->err.c_str()); return 0; }
+    std::vector<uint32_t> padded((size_t)ix->chunks * 4);
+    pad_row(ix, query, padded.data());
+    uint64_t *d_lab = (uint64_t *)(buf + row);
+    float    *d_dist = (float *)(buf + row + k * 8);
+    uint32_t *d_cnt = (uint32_t *)(buf + row + k * 12);
+    uint32_t  got = 0;
+    bool      ok = hipMemcpyAsync(buf, padded.data(), row, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    // one query: spend a whole 8-wave workgroup on it (latency-bound path)
+    ok = ok && run_search_device(ix, (const uint4 *)buf, 1, k, ef, skip, d_lab, d_dist, nullptr, d_cnt, nullptr, nullptr, ix->stream, 8);
+    ok = ok && hipMemcpyAsync(&got, d_cnt, 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(labels, d_lab, k * 8, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(distances, d_dist, k * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
+    if(!ok) {
+        if(ix->err.empty()) set_err(ix, "lantern_gpu: HIP failure during search");
+        FAIL(e, ix->err.c_str());
+        return 0;
+    }
+    ix->stream_returned = skip + got;
+    return got;
+}
+
+void lantern_gpu_search_batch_device(usearch_index_t h, const void *d_queries, size_t nq, size_t k, size_t ef, size_t skip,
+                                     uint64_t *d_labels, float *d_distances, uint32_t *d_slots, uint32_t *d_counts,
+                                     uint64_t *d_D, uint64_t *d_E, void *stream, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    if(!run_search_device(ix, (const uint4 *)d_queries, nq, k, ef, skip, d_labels, d_distances, d_slots, d_counts, d_D, d_E,
+                          (hipStream_t)stream, ix->search_waves))
+        FAIL(e, ix->err.c_str());
+}
+
+void lantern_gpu_search_batch(usearch_index_t h, const void *queries, size_t nq, usearch_scalar_kind_t kind, size_t k, size_t ef,
+                              usearch_label_t *labels, float *distances, uint32_t *counts, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    if((int)kind != ix->scalar) { FAIL(e, "lantern_gpu: scalar kind of the queries does not match the index"); return; }
+    if(nq == 0 || k == 0) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    const size_t row_words = (size_t)ix->chunks * 4;
+    const size_t in_bytes = ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4;
+    std::vector<uint32_t> padded(nq * row_words);
+    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, &padded[ i * row_words ]);
+    char *dq = (char *)scratch(ix, 5, nq * row_words * 4);
+    char *dout = (char *)scratch(ix, 6, nq * k * 12 + nq * 4 + 64);
+    if(!dq || !dout) { FAIL(e, ix->err.c_str()); return; }
+    uint64_t *d_lab = (uint64_t *)dout;
+    float    *d_dist = (float *)(dout + nq * k * 8);
+    uint32_t *d_cnt = (uint32_t *)(dout + nq * k * 12);
+    bool      ok = hipMemcpyAsync(dq, padded.data(), nq * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    ok = ok && run_search_device(ix, (const uint4 *)dq, nq, k, ef, 0, d_lab, d_dist, nullptr, d_cnt, nullptr, nullptr, ix->stream,
+                                 ix->search_waves);
+    ok = ok && hipMemcpyAsync(labels, d_lab, nq * k * 8, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(distances, d_dist, nq * k * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    if(counts) ok = ok && hipMemcpyAsync(counts, d_cnt, nq * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
+    if(!ok) {
+        if(ix->err.empty()) set_err(ix, "lantern_gpu: HIP failure during batched search");
+        FAIL(e, ix->err.c_str());
+    }
+}
+
+// ---- distances ------------------------------------------------------------------------------------
+
+static bool metric_ok(usearch_metric_kind_t m) { return m == usearch_metric_cos_k || m == usearch_metric_l2sq_k || m == usearch_metric_hamming_k; }
+
+void lantern_gpu_distance_matrix(const void *a, size_t na, const void *b, size_t nb, usearch_scalar_kind_t kind, size_t dims,
+                                 usearch_metric_kind_t metric, int exact_order, float *out, usearch_error_t *e)
+{
+    CLEAR(e);
+    if(!metric_ok(metric)) { FAIL(e, "lantern_gpu: unsupported metric kind (expected cos, l2sq or hamming)"); return; }
+    const bool ham = metric == usearch_metric_hamming_k;
+    if(ham != (kind == usearch_scalar_b1_k) || (!ham && kind != usearch_scalar_f32_k)) { FAIL(e, "lantern_gpu: scalar kind does not fit the metric"); return; }
+    if(!a || !b || !out || dims == 0) { FAIL(e, "lantern_gpu: bad arguments"); return; }
+    if(lantern_gpu_device_count() <= 0) { FAIL(e, kNoDevice); return; }
+    if(!exact_order) { FAIL(e, "lantern_gpu: the MFMA contraction path is not built yet"); return; }
+    if(na == 0 || nb == 0) return;
+    const size_t words = ham ? (dims + 31) / 32 : dims, in_bytes = ham ? (dims + 7) / 8 : dims * 4;
+    const size_t chunks = (words + 3) / 4, row = chunks * 16;
+    std::vector<char> ha(na * row, 0), hb(nb * row, 0);
+    for(size_t i = 0; i < na; ++i) std::memcpy(&ha[ i * row ], (const char *)a + i * in_bytes, in_bytes);
+    for(size_t i = 0; i < nb; ++i) std::memcpy(&hb[ i * row ], (const char *)b + i * in_bytes, in_bytes);
+    void *da = nullptr, *db = nullptr, *dout = nullptr;
+    bool  ok = hipMalloc(&da, na * row) == hipSuccess && hipMalloc(&db, nb * row) == hipSuccess &&
+              hipMalloc(&dout, na * nb * 4) == hipSuccess;
+    ok = ok && hipMemcpy(da, ha.data(), na * row, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(db, hb.data(), nb * row, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && launch_pairs((int)metric, (const uint4 *)da, (uint32_t)na, (const uint4 *)db, (uint32_t)nb, (uint32_t)chunks,
+                            (float *)dout, nullptr) == hipSuccess;
+    ok = ok && hipMemcpy(out, dout, na * nb * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(da) (void)hipFree(da);
+    if(db) (void)hipFree(db);
+    if(dout) (void)hipFree(dout);
+    if(!ok) FAIL(e, "lantern_gpu: HIP failure in distance_matrix");
+}
+
+float usearch_distance(const void *a, const void *b, usearch_scalar_kind_t kind, size_t dims, usearch_metric_kind_t metric,
+                       usearch_error_t *e)
+{
+    float out = 0.f;
+    lantern_gpu_distance_matrix(a, 1, b, 1, kind, dims, metric, 1, &out, e);
+    return out;
+}
+
+void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uint32_t *slots, size_t n, float *out,
+                                 usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix || n == 0) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    for(size_t i = 0; i < n; ++i)
+        if(slots[ i ] >= ix->n) { FAIL(e, "lantern_gpu: slot out of range"); return; }
+    const size_t row = (size_t)ix->chunks * 16;
+    char        *buf = (char *)scratch(ix, 5, row + n * 8 + 16);
+    if(!buf) { FAIL(e, ix->err.c_str()); return; }
+    std::vector<uint32_t> padded((size_t)ix->chunks * 4);
+    pad_row(ix, query, padded.data());
+    uint32_t *d_slots = (uint32_t *)(buf + row);
+    float    *d_out = (float *)(buf + row + n * 4);
+    bool      ok = hipMemcpyAsync(buf, padded.data(), row, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d_slots, slots, n * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    ok = ok && launch_gather(ix->metric, ix->view(), (const uint4 *)buf, d_slots, (uint32_t)n, d_out, ix->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
+    if(!ok) FAIL(e, "lantern_gpu: HIP failure in distance_gather");
+}
+
+void lantern_gpu_exact_search(usearch_index_t h, const void *, size_t, size_t, uint32_t *, float *, usearch_error_t *e)
+{
+    CLEAR(e);
+    if(H(h, e)) FAIL(e, "lantern_gpu: exact_search is not built yet");
+}
+
+// ---- SQL-callable semantics (hnsw.c:296-405) ---------------------------------------------------------
+
+static thread_local char g_dim_msg[ 160 ];
+
+static bool same_dims(int a_dim, int b_dim, usearch_error_t *e)
+{
+    if(a_dim == b_dim) return true;
+    // hnsw.c:301-303
+    std::snprintf(g_dim_msg, sizeof(g_dim_msg), "expected equally sized arrays but got arrays with dimensions %d and %d", a_dim, b_dim);
+    FAIL(e, g_dim_msg);
+    return false;
+}
+
+float lantern_l2sq_dist(const float *a, int a_dim, const float *b, int b_dim, usearch_error_t *e)
+{
+    CLEAR(e);
+    if(!same_dims(a_dim, b_dim, e)) return 0.f;
+    return usearch_distance(a, b, usearch_scalar_f32_k, (size_t)a_dim, usearch_metric_l2sq_k, e);
+}
+
+float lantern_cos_dist(const float *a, int a_dim, const float *b, int b_dim, usearch_error_t *e)
+{
+    CLEAR(e);
+    if(!same_dims(a_dim, b_dim, e)) return 0.f;
+    return usearch_distance(a, b, usearch_scalar_f32_k, (size_t)a_dim, usearch_metric_cos_k, e);
+}
+
+int32_t lantern_hamming_dist(const int32_t *a, int a_dim, const int32_t *b, int b_dim, usearch_error_t *e)
+{
+    CLEAR(e);
+    if(!same_dims(a_dim, b_dim, e)) return 0;
+    // hnsw.c:317-319: dims = a_dim * sizeof(int32) * CHAR_BIT bits; result cast to int32 (hnsw.c:375)
+    return (int32_t)usearch_distance(a, b, usearch_scalar_b1_k, (size_t)a_dim * 32, usearch_metric_hamming_k, e);
+}
+
+// ---- metadata / counters / graph exchange --------------------------------------------------------------
+
+metadata_t usearch_index_metadata(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    metadata_t m;
+    std::memset(&m, 0, sizeof(m));
+    Index *ix = H(h, e);
+    if(!ix) return m;
+    m.neighbors_bytes = 4 + (size_t)ix->M * LANTERN_SLOT_SIZE;        // [count u32][M x 6-byte slots]
+    m.neighbors_base_bytes = 4 + (size_t)ix->M0 * LANTERN_SLOT_SIZE;  // level 0: 2M slots
+    m.inverse_log_connectivity = 1.0 / std::log((double)ix->M);
+    m.connectivity = ix->M;
+    m.dimensions = ix->opts.dimensions;
+    m.init_options = ix->opts;
+    return m;
+}
+
+lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    lantern_gpu_counters c;
+    std::memset(&c, 0, sizeof(c));
+    Index *ix = H(h, e);
+    if(!ix) return c;
+    unsigned long long t[ 8 ] = {};
+    if(hipMemcpy(t, ix->d_totals, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) { FAIL(e, "lantern_gpu: HIP failure reading counters"); return c; }
+    c.search_dist_evals = t[ 0 ];
+    c.search_expansions = t[ 1 ];
+    c.search_queries = ix->c_search_queries;
+    c.add_dist_evals = t[ 2 ] + t[ 4 ] + t[ 5 ];
+    c.add_expansions = t[ 3 ];
+    c.add_vectors = ix->c_add_vectors;
+    c.add_batches = ix->c_add_batches;
+    return c;
+}
+
+lantern_gpu_graph_info lantern_gpu_graph_info_get(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    lantern_gpu_graph_info gi;
+    std::memset(&gi, 0, sizeof(gi));
+    Index *ix = H(h, e);
+    if(!ix) return gi;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return gi; }
+    gi.size = ix->n;
+    gi.upper_blocks = ix->upper_blocks;
+    gi.connectivity = ix->M;
+    gi.entry_slot = ix->entry;
+    gi.max_level = ix->max_level;
+    gi.vector_words = ix->words;
+    return gi;
+}
+
+void lantern_gpu_export_graph(usearch_index_t h, uint8_t *levels, uint32_t *nbr0, uint32_t *upper_off, uint32_t *upper_nbr,
+                              uint64_t *labels, void *vectors, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    const size_t n = ix->n;
+    bool         ok = true;
+    if(levels && n) std::memcpy(levels, ix->levels.data(), n);
+    if(upper_off && n) std::memcpy(upper_off, ix->upper_off.data(), n * 4);
+    if(labels && n) std::memcpy(labels, ix->labels.data(), n * 8);
+    if(nbr0 && n) ok = ok && hipMemcpy(nbr0, ix->d_nbr0, n * ix->M0 * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(upper_nbr && ix->upper_blocks)
+        ok = ok && hipMemcpy(upper_nbr, ix->d_upper_nbr, ix->upper_blocks * ix->M * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(vectors && n) {
+        if(ix->chunks * 4 == ix->words) {
+            ok = ok && hipMemcpy(vectors, ix->d_vec, n * (size_t)ix->words * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        } else {
+            ok = ok && hipMemcpy2D(vectors, (size_t)ix->words * 4, ix->d_vec, (size_t)ix->chunks * 16, (size_t)ix->words * 4, n,
+                                   hipMemcpyDeviceToHost) == hipSuccess;
+        }
+    }
+    if(!ok) FAIL(e, "lantern_gpu: HIP failure exporting the graph");
+}
+
+void lantern_gpu_import_graph(usearch_index_t h, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,
+                              const uint32_t *nbr0, const uint32_t *upper_off, const uint32_t *upper_nbr, uint32_t entry_slot,
+                              int32_t max_level, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!import_graph_locked(ix, size, vectors, labels, levels, nbr0, upper_off, upper_nbr, entry_slot, max_level)) FAIL(e, ix->err.c_str());
+}
+
+}  // extern "C"

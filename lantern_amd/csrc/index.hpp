@@ -1,0 +1,93 @@
+// index.hpp -- the device-resident HNSW index behind the usearch-shaped C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lantern_gpu.h"
+#include "kernels.hpp"
+
+namespace lgpu {
+
+struct Index
+{
+    // ---- configuration (usearch_init_options_t as Lantern fills it) -------------------------------
+    usearch_init_options_t opts{};
+    int      metric = 0;
+    int      scalar = 0;         // usearch_scalar_f32_k or usearch_scalar_b1_k
+    uint32_t words = 0;          // 4-byte words per vector as the caller supplies it
+    uint32_t chunks = 0;         // 16-byte chunks per stored row (zero padded)
+    uint32_t M = 16, M0 = 32, efc = 128, ef = 64;
+    uint64_t seed = 42;
+    size_t   add_batch_max = 8192, add_min_ratio = 16;
+    int      search_waves = 4, search_max_wg = 0, insert_waves = 4;
+
+    // ---- graph state ------------------------------------------------------------------------------
+    size_t   n = 0, cap = 0;
+    uint32_t entry = EMPTY;
+    int      max_level = -1;
+    size_t   upper_blocks = 0, upper_cap = 0;
+
+    // ---- HBM ---------------------------------------------------------------------------------------
+    uint4    *d_vec = nullptr;
+    uint64_t *d_labels = nullptr;
+    uint8_t  *d_levels = nullptr;
+    uint32_t *d_nbr0 = nullptr;
+    uint32_t *d_upper_off = nullptr;
+    uint32_t *d_upper_nbr = nullptr;
+    uint32_t *d_bitmaps = nullptr;
+    size_t    bitmap_slots = 0, bm_words = 0;
+    unsigned long long *d_totals = nullptr;  // [0..1] search D,E  [2..4] insert D,E,refine  [5] revlink pairs
+
+    // scratch (grown on demand)
+    void  *d_scratch[ 8 ] = {};
+    size_t scratch_bytes[ 8 ] = {};
+
+    // ---- host mirrors ------------------------------------------------------------------------------
+    std::vector<uint64_t> labels;
+    std::vector<uint8_t>  levels;
+    std::vector<uint32_t> upper_off;
+
+    // ---- buffered inserts --------------------------------------------------------------------------
+    std::mutex            mu;  // add_raw is called from N threads on one index (server.rs:333-356)
+    std::vector<uint64_t> pend_labels;
+    std::vector<uint32_t> pend_rows;    // chunks*4 words per pending vector, zero padded
+    std::vector<int>      pend_levels;  // -1 = draw with level_for()
+
+    // ---- streaming continuation of usearch_search_ef (scan.c:273-281) ----------------------------
+    size_t stream_returned = 0;
+
+    // ---- counters ----------------------------------------------------------------------------------
+    uint64_t c_search_queries = 0, c_add_vectors = 0, c_add_batches = 0;
+
+    hipStream_t stream = nullptr;
+    int         device = 0;
+    int         num_cus = 256;
+    std::string err;
+
+    View view() const;
+};
+
+// implemented in index.cpp
+const char *set_err(Index *ix, const std::string &msg);
+bool        flush_locked(Index *ix);            // false -> ix->err set
+bool        ensure_bitmaps(Index *ix, size_t slots);
+void       *scratch(Index *ix, int which, size_t bytes);
+bool        pad_row(const Index *ix, const void *vec, uint32_t *dst);
+int         search_grid(const Index *ix, size_t nq, int waves);
+bool        run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, size_t ef, size_t skip,
+                              uint64_t *d_labels, float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D,
+                              uint64_t *d_E, hipStream_t stream, int waves);
+
+bool        import_graph_locked(Index *ix, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,
+                                const uint32_t *nbr0, const uint32_t *upper_off, const uint32_t *upper_nbr, uint32_t entry_slot,
+                                int32_t max_level);
+
+// usearch-format serialisation (usearch_file.cpp)
+size_t serialized_length(Index *ix);
+bool   serialize(Index *ix, char *buf, size_t len);
+bool   deserialize(Index *ix, const char *buf, size_t len);
+
+}  // namespace lgpu

@@ -1,0 +1,298 @@
+// kernels.hip -- gfx950 kernels of the HNSW distance-evaluation path.
+//
+//   k_search   usearch_search_ef  (lantern_hnsw/src/hnsw/scan.c:220-228,273-281): one workgroup per
+//              query, persistent over the batch; greedy descent + ef-bounded base-layer walk.
+//   k_insert   the search half of usearch_add (build.c:128; server.rs:349 add_raw): per new vector,
+//              descent + per-level ef_construction walk + neighbour selection; emits reverse-link
+//              requests.
+//   k_revlink  the reverse-link half (usearch reconnect_neighbor_nodes_): one workgroup per
+//              (node, level) that received requests; append or re-prune with the heuristic.
+//   k_gather   metric(query, row[slots[i]]) -- the distance kernel on its own (tests, profiling).
+//   k_pairs    na x nb pairwise distances in the walk's exact reduction order (usearch_distance,
+//              hnsw.c:296-345; PQ k-means assign product_quantization.c:80-124).
+//
+// HBM-bound by design: every row is read with 16-byte-per-lane coalesced loads (1 KiB per wave
+// instruction at G = 64), neighbour ids are staged through LDS, reductions are wavefront shuffles.
+#include "kernels.hpp"
+#include "walk.hpp"
+
+namespace lgpu {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
+
+// ---------------------------------------------------------------------------------------------------
+template <int METRIC, int G>
+__global__ void __launch_bounds__(512) k_search(SearchArgs a)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    WalkLds   s;
+    carve_walk(lgpu_smem, s, a.view.chunks, a.ef, a.view.M0);
+    uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
+    const uint32_t chunks = a.view.chunks;
+    for(uint32_t q = blockIdx.x; q < a.nq; q += gridDim.x) {
+        for(uint32_t i = tid; i < chunks; i += T) s.q[ i ] = a.queries[ (size_t)q * chunks + i ];
+        __syncthreads();
+        uint32_t D = 0, E = 0;
+        int      cnt = 0;
+        if(a.view.n != 0) {
+            uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
+            cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E);
+        }
+        int got = cnt - (int)a.skip;
+        got = got < 0 ? 0 : (got > (int)a.k ? (int)a.k : got);
+        for(uint32_t i = tid; i < a.k; i += T) {
+            const size_t o = (size_t)q * a.k + i;
+            if((int)i < got) {
+                const uint64_t key = s.keys[ a.skip + i ];
+                const uint32_t slot = key_slot(key);
+                if(a.out_labels) a.out_labels[ o ] = a.labels[ slot ];
+                if(a.out_dists) a.out_dists[ o ] = key_dist(key);
+                if(a.out_slots) a.out_slots[ o ] = slot;
+            } else {
+                if(a.out_labels) a.out_labels[ o ] = 0;  // INVALID_ELEMENT_LABEL (hnsw.h:40)
+                if(a.out_dists) a.out_dists[ o ] = __builtin_inff();
+                if(a.out_slots) a.out_slots[ o ] = EMPTY;
+            }
+        }
+        if(tid == 0) {
+            if(a.out_counts) a.out_counts[ q ] = (uint32_t)got;
+            if(a.out_D) a.out_D[ q ] = D;
+            if(a.out_E) a.out_E[ q ] = E;
+            if(a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)D); atomicAdd(&a.totals[ 1 ], (unsigned long long)E); }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int METRIC, int G>
+__global__ void __launch_bounds__(512) k_insert(InsertArgs a)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    WalkLds   s;
+    RefineLds r;
+    unsigned char *p = carve_walk(lgpu_smem, s, a.view.chunks, a.efc, a.view.M0);
+    carve_refine(p, r, a.efc);
+    uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
+    const uint32_t chunks = a.view.chunks, M = a.view.M;
+    for(uint32_t b = blockIdx.x; b < a.count; b += gridDim.x) {
+        const uint32_t me = a.first_slot + b;
+        const int      target = a.view.levels[ me ];
+        LinkReq       *out = a.links + a.link_off[ b ];
+        {
+            const uint4 *own = row_of(a.view, me);
+            for(uint32_t i = tid; i < chunks; i += T) s.q[ i ] = own[ i ];
+            for(uint32_t i = tid; i < M * (uint32_t)(target + 1); i += T) out[ i ].close = EMPTY;
+        }
+        __syncthreads();
+        uint32_t D = 0, E = 0, Dr = 0;
+        uint32_t cur = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, target, D);
+        for(int level = target < a.view.max_level ? target : a.view.max_level; level >= 0; --level) {
+            const int cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, cur, level, (int)a.efc, D, E);
+            for(int i = tid; i < cnt; i += T) {
+                const uint64_t key = s.keys[ i ];
+                r.cd[ i ] = key_dist(key);
+                r.cid[ i ] = key_slot(key);
+            }
+            __syncthreads();
+            // connect_new_node_: refine to `connectivity` (M) on EVERY level, also level 0
+            const int keep = refine<METRIC, G>(a.view, r, s.scal, cnt, (int)M, me, Dr);
+            uint32_t  cap;
+            uint32_t *list = neighbors_of(a.view, me, level, cap);
+            for(uint32_t i = tid; i < M; i += T) {
+                if((int)i < keep) {
+                    list[ i ] = r.sid[ i ];
+                    LinkReq req;
+                    req.close = r.sid[ i ];
+                    req.level = (uint32_t)level;
+                    req.new_slot = me;
+                    req.d = r.sd[ i ];
+                    out[ (uint32_t)level * M + i ] = req;
+                }
+            }
+            cur = r.sid[ 0 ];
+            __syncthreads();
+        }
+        if(tid == 0 && a.totals) {
+            atomicAdd(&a.totals[ 0 ], (unsigned long long)D);
+            atomicAdd(&a.totals[ 1 ], (unsigned long long)E);
+            atomicAdd(&a.totals[ 2 ], (unsigned long long)Dr);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int METRIC, int G>
+__global__ void __launch_bounds__(256) k_revlink(RevlinkArgs a)
+{
+    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
+    RefineLds r;
+    unsigned char *p = carve_refine(lgpu_smem, r, a.view.M0 + 1);
+    int      *scal = (int *)p;
+    const uint32_t gi = blockIdx.x;
+    const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+    const uint32_t close = a.reqs[ begin ].close;
+    const int      level = (int)a.reqs[ begin ].level;
+    uint32_t       cap;
+    uint32_t      *list = neighbors_of(a.view, close, level, cap);
+    if(tid == 0) scal[ S_CNT ] = 0;
+    __syncthreads();
+    for(uint32_t i = tid; i < cap; i += T) {
+        const uint32_t nb = list[ i ];
+        r.cid[ i ] = nb;
+        if(nb != EMPTY) atomicMax(&scal[ S_CNT ], (int)i + 1);
+    }
+    __syncthreads();
+    int      c = scal[ S_CNT ];
+    const int c0 = c;
+    bool     have_d = false;
+    uint32_t pairs = 0;
+    for(uint32_t t = begin; t < end; ++t) {
+        const uint32_t vnew = a.reqs[ t ].new_slot;
+        const float    dv = a.reqs[ t ].d;
+        if(c < (int)cap) {  // room: close_header.push_back(new_slot)
+            if(tid == 0) { r.cid[ c ] = vnew; r.cd[ c ] = dv; list[ c ] = vnew; }
+            c++;
+            __syncthreads();
+            continue;
+        }
+        if(!have_d) {  // distances of the original entries to `close`, once
+            for(int i = g; i < c0; i += NG) {
+                float d = group_dist<METRIC, G>(row_of(a.view, close), row_of(a.view, r.cid[ i ]), (int)a.view.chunks, gl);
+                if(gl == 0) r.cd[ i ] = d;
+            }
+            pairs += (uint32_t)c0;
+            have_d = true;
+        }
+        if(tid == 0) { r.cid[ c ] = vnew; r.cd[ c ] = dv; }
+        __syncthreads();
+        const int keep = refine<METRIC, G>(a.view, r, scal, c + 1, (int)cap, close, pairs);
+        for(uint32_t i = tid; i < cap; i += T) {
+            if((int)i < keep) {
+                r.cid[ i ] = r.sid[ i ];
+                r.cd[ i ] = r.sd[ i ];
+                list[ i ] = r.sid[ i ];
+            } else {
+                list[ i ] = EMPTY;
+            }
+        }
+        c = keep;
+        __syncthreads();
+    }
+    if(tid == 0 && a.totals) atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs);
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int METRIC, int G>
+__global__ void __launch_bounds__(256) k_gather(View v, const uint4 *query, const uint32_t *slots, uint32_t n, float *out)
+{
+    const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) / G, gl = threadIdx.x % G;
+    const uint32_t ngroups = gridDim.x * blockDim.x / G;
+    for(uint32_t i = gid; i < n; i += ngroups) {
+        float d = group_dist<METRIC, G>(query, row_of(v, slots[ i ]), (int)v.chunks, (int)gl);
+        if(gl == 0) out[ i ] = d;
+    }
+}
+
+template <int METRIC, int G>
+__global__ void __launch_bounds__(256) k_pairs(const uint4 *a, uint32_t na, const uint4 *b, uint32_t nb, uint32_t chunks, float *out)
+{
+    const uint64_t gid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const uint32_t gl = threadIdx.x % G;
+    const uint64_t ngroups = (uint64_t)gridDim.x * blockDim.x / G, total = (uint64_t)na * nb;
+    for(uint64_t p = gid; p < total; p += ngroups) {
+        const uint32_t i = (uint32_t)(p / nb), j = (uint32_t)(p % nb);
+        float d = group_dist<METRIC, G>(a + (size_t)i * chunks, b + (size_t)j * chunks, (int)chunks, (int)gl);
+        if(gl == 0) out[ p ] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dispatch on (metric, lanes per row)
+#define LGPU_DISPATCH(metric, chunks, CALL)                                   \
+    do {                                                                      \
+        const int G_ = group_lanes_for(chunks);                               \
+        switch(metric) {                                                      \
+            case M_L2SQ:                                                      \
+                switch(G_) { case 64: CALL(M_L2SQ, 64); break; case 32: CALL(M_L2SQ, 32); break; \
+                             case 16: CALL(M_L2SQ, 16); break; default: CALL(M_L2SQ, 8); }       \
+                break;                                                        \
+            case M_COS:                                                       \
+                switch(G_) { case 64: CALL(M_COS, 64); break; case 32: CALL(M_COS, 32); break;   \
+                             case 16: CALL(M_COS, 16); break; default: CALL(M_COS, 8); }         \
+                break;                                                        \
+            case M_HAMMING:                                                   \
+                switch(G_) { case 64: CALL(M_HAMMING, 64); break; case 32: CALL(M_HAMMING, 32); break; \
+                             case 16: CALL(M_HAMMING, 16); break; default: CALL(M_HAMMING, 8); } \
+                break;                                                        \
+            default: return hipErrorInvalidValue;                             \
+        }                                                                     \
+    } while(0)
+
+size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0) { return walk_lds_bytes(chunks, ef_cap, M0); }
+size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0) { return walk_lds_bytes(chunks, efc, M0) + refine_lds_bytes(efc); }
+
+hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream)
+{
+    const size_t lds = search_lds_bytes(a.view.chunks, a.ef, a.view.M0);
+#define CALL(MM, GG)                                                                                          \
+    {                                                                                                         \
+        (void)hipFuncSetAttribute((const void *)k_search<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_search<MM, GG>), dim3(grid), dim3(64 * waves), lds, stream, a);                 \
+    }
+    LGPU_DISPATCH(metric, a.view.chunks, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream)
+{
+    const size_t lds = insert_lds_bytes(a.view.chunks, a.efc, a.view.M0);
+#define CALL(MM, GG)                                                                                          \
+    {                                                                                                         \
+        (void)hipFuncSetAttribute((const void *)k_insert<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_insert<MM, GG>), dim3(grid), dim3(64 * waves), lds, stream, a);                 \
+    }
+    LGPU_DISPATCH(metric, a.view.chunks, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_revlink(int metric, const RevlinkArgs &a, hipStream_t stream)
+{
+    if(a.ngroups == 0) return hipSuccess;
+    const size_t lds = refine_lds_bytes(a.view.M0 + 1) + S_SCALARS * 4;
+#define CALL(MM, GG) hipLaunchKernelGGL((k_revlink<MM, GG>), dim3(a.ngroups), dim3(256), lds, stream, a)
+    LGPU_DISPATCH(metric, a.view.chunks, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(int metric, const View &v, const uint4 *query, const uint32_t *slots, uint32_t n, float *out,
+                         hipStream_t stream)
+{
+    if(n == 0) return hipSuccess;
+    const int G_ = group_lanes_for(v.chunks);
+    uint32_t  blocks = (uint32_t)(((uint64_t)n * G_ + 255) / 256);
+    if(blocks > 8192) blocks = 8192;
+#define CALL(MM, GG) hipLaunchKernelGGL((k_gather<MM, GG>), dim3(blocks), dim3(256), 0, stream, v, query, slots, n, out)
+    LGPU_DISPATCH(metric, v.chunks, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_pairs(int metric, const uint4 *a, uint32_t na, const uint4 *b, uint32_t nb, uint32_t chunks, float *out,
+                        hipStream_t stream)
+{
+    if(na == 0 || nb == 0) return hipSuccess;
+    const int G_ = group_lanes_for(chunks);
+    uint64_t  want = ((uint64_t)na * nb * G_ + 255) / 256;
+    uint32_t  blocks = want > 8192 ? 8192u : (uint32_t)want;
+#define CALL(MM, GG) hipLaunchKernelGGL((k_pairs<MM, GG>), dim3(blocks), dim3(256), 0, stream, a, na, b, nb, chunks, out)
+    LGPU_DISPATCH(metric, chunks, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+}  // namespace lgpu

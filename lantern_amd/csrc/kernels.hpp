@@ -1,0 +1,73 @@
+// kernels.hpp -- host-callable launchers of the gfx950 kernels (definitions in kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "device_common.hpp"
+
+namespace lgpu {
+
+struct SearchArgs
+{
+    View            view;
+    const uint4    *queries;   // [nq][chunks], zero padded
+    uint32_t        nq, k, ef, skip;
+    const uint64_t *labels;    // [n]
+    uint64_t       *out_labels;  // [nq][k] or NULL
+    float          *out_dists;   // [nq][k] or NULL
+    uint32_t       *out_slots;   // [nq][k] or NULL
+    uint32_t       *out_counts;  // [nq] or NULL
+    uint64_t       *out_D;       // [nq] or NULL
+    uint64_t       *out_E;       // [nq] or NULL
+    uint32_t       *bitmaps;     // [grid][bm_words]
+    uint32_t        bm_words;    // multiple of 4
+    unsigned long long *totals;  // [2] cumulative D, E (atomicAdd) or NULL
+};
+
+// one reverse-link request produced by the insert pass: add `new_slot` to `close`'s list at `level`
+struct LinkReq
+{
+    uint32_t close;  // EMPTY = unused entry
+    uint32_t level;
+    uint32_t new_slot;
+    float    d;  // metric(new_slot, close)
+};
+
+struct InsertArgs
+{
+    View            view;       // n = size BEFORE the batch; entry/max_level frozen
+    uint32_t        first_slot; // the batch occupies slots [first_slot, first_slot + count)
+    uint32_t        count;
+    uint32_t        efc;
+    const uint32_t *link_off;   // [count] first LinkReq of each new node (M*(level+1) entries each)
+    LinkReq        *links;
+    uint32_t       *bitmaps;
+    uint32_t        bm_words;
+    unsigned long long *totals;  // [3] cumulative D, E, refine-D
+};
+
+struct RevlinkArgs
+{
+    View            view;
+    uint32_t        ngroups;
+    const uint32_t *group_begin;  // [ngroups+1] into reqs (sorted by close, level, new_slot)
+    const LinkReq  *reqs;
+    unsigned long long *totals;   // [1] cumulative pair evaluations
+};
+
+// All launchers return hipSuccess or the launch error.  `metric` is a usearch_metric_kind_t value.
+hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);
+hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);
+hipError_t launch_revlink(int metric, const RevlinkArgs &a, hipStream_t stream);
+// out[i] = metric(query, row(slots[i]))
+hipError_t launch_gather(int metric, const View &v, const uint4 *query, const uint32_t *slots, uint32_t n, float *out,
+                         hipStream_t stream);
+// out[i*nb + j] = metric(a[i], b[j]) in the graph walk's exact reduction order
+hipError_t launch_pairs(int metric, const uint4 *a, uint32_t na, const uint4 *b, uint32_t nb, uint32_t chunks, float *out,
+                        hipStream_t stream);
+
+size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0);
+size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0);
+
+}  // namespace lgpu

@@ -1,0 +1,246 @@
+// usearch_file.cpp -- usearch-format serialisation of the device index.
+//
+// What Lantern consumes (lantern_hnsw/src/hnsw/external_index.c:298-372, usearch_storage.cpp:19-118,
+// validate_index.c:105-226, external_index.h:29-66):
+//
+//   bytes [0, 136)   opaque usearch header = 80-byte file header + 56-byte graph header
+//   then             node tapes back to back, node i is the i-th tape (external_index.c:137,161-164)
+//   node tape        [label u64][level u16] { [count u32][cap x 6-byte slot] } x (level+1) [vector]
+//                    cap = 2M on level 0, M above (validate_index.c:140-151); unused slots zero;
+//                    a slot carries the neighbour's u32 sequential id in its low 4 bytes
+//                    (external_index.c:399-403 rewrites them to ItemPointers on import)
+//
+// The 136 header bytes are parsed only inside usearch (usearch_view_mem_lazy,
+// usearch_header_get/set_entry_slot), whose source is not in the reference tree.  The field layout
+// below follows upstream usearch 2.x (index_dense_head_t, index_serialized_header_t) with the fork's
+// extra 16 + 16 bytes zeroed; it is self-consistent with this library's own reader and with
+// usearch_header_{get,set}_entry_slot below, and UNVERIFIED against the pinned fork.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "index.hpp"
+
+namespace lgpu {
+
+namespace {
+constexpr size_t OFF_MAGIC = 0;        // "usearch" (7 bytes)
+constexpr size_t OFF_VERSION = 7;      // u16 x 3
+constexpr size_t OFF_KIND_METRIC = 13; // u8
+constexpr size_t OFF_KIND_SCALAR = 14; // u8
+constexpr size_t OFF_KIND_KEY = 15;    // u8
+constexpr size_t OFF_KIND_SLOT = 16;   // u8
+constexpr size_t OFF_COUNT_PRESENT = 17;  // u64
+constexpr size_t OFF_COUNT_DELETED = 25;  // u64
+constexpr size_t OFF_DIMENSIONS = 33;     // u64
+constexpr size_t OFF_MULTI = 41;          // u8
+// [42, 80): padding + the fork's PQ fields (zero)
+constexpr size_t OFF_G_SIZE = 80;               // u64
+constexpr size_t OFF_G_CONNECTIVITY = 88;       // u64
+constexpr size_t OFF_G_CONNECTIVITY_BASE = 96;  // u64
+constexpr size_t OFF_G_MAX_LEVEL = 104;         // u64
+constexpr size_t OFF_G_ENTRY_SLOT = 112;        // u64
+// [120, 136): reserved (zero)
+
+template <typename T> void put(char *p, size_t off, T v) { std::memcpy(p + off, &v, sizeof(T)); }
+template <typename T> T    get(const char *p, size_t off) { T v; std::memcpy(&v, p + off, sizeof(T)); return v; }
+
+size_t vector_bytes(const Index *ix) { return ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4; }
+size_t node_bytes(const Index *ix, int level)
+{
+    return 8 + 2 + (4 + (size_t)ix->M0 * LANTERN_SLOT_SIZE) + (size_t)level * (4 + (size_t)ix->M * LANTERN_SLOT_SIZE) + vector_bytes(ix);
+}
+}  // namespace
+
+size_t serialized_length(Index *ix)
+{
+    size_t total = USEARCH_HEADER_SIZE;
+    for(size_t i = 0; i < ix->n; ++i) total += node_bytes(ix, ix->levels[ i ]);
+    return total;
+}
+
+static void write_header(const Index *ix, char *h)
+{
+    std::memset(h, 0, USEARCH_HEADER_SIZE);
+    std::memcpy(h + OFF_MAGIC, "usearch", 7);
+    put<uint16_t>(h, OFF_VERSION, 2);
+    put<uint16_t>(h, OFF_VERSION + 2, 0);
+    put<uint16_t>(h, OFF_VERSION + 4, 0);
+    put<uint8_t>(h, OFF_KIND_METRIC, (uint8_t)ix->metric);
+    put<uint8_t>(h, OFF_KIND_SCALAR, (uint8_t)ix->scalar);
+    put<uint8_t>(h, OFF_KIND_KEY, 8);   // 8-byte keys (usearch_label_t)
+    put<uint8_t>(h, OFF_KIND_SLOT, 6);  // 6-byte slots (lantern_slot_t)
+    put<uint64_t>(h, OFF_COUNT_PRESENT, ix->n);
+    put<uint64_t>(h, OFF_COUNT_DELETED, 0);
+    put<uint64_t>(h, OFF_DIMENSIONS, ix->opts.dimensions);
+    put<uint8_t>(h, OFF_MULTI, 0);
+    put<uint64_t>(h, OFF_G_SIZE, ix->n);
+    put<uint64_t>(h, OFF_G_CONNECTIVITY, ix->M);
+    put<uint64_t>(h, OFF_G_CONNECTIVITY_BASE, ix->M0);
+    put<uint64_t>(h, OFF_G_MAX_LEVEL, ix->n ? (uint64_t)ix->max_level : 0);
+    put<uint64_t>(h, OFF_G_ENTRY_SLOT, ix->n ? (uint64_t)ix->entry : 0);
+}
+
+bool serialize(Index *ix, char *buf, size_t len)
+{
+    const size_t need = serialized_length(ix);
+    if(len < need) { set_err(ix, "lantern_gpu: serialisation buffer too small"); return false; }
+    write_header(ix, buf);
+    const size_t n = ix->n;
+    if(n == 0) return true;
+    const size_t row = (size_t)ix->chunks * 16, vb = vector_bytes(ix);
+    std::vector<uint32_t> nbr0(n * ix->M0), upper(ix->upper_blocks * ix->M + 1);
+    std::vector<char>     rows(n * row);
+    bool ok = hipMemcpy(nbr0.data(), ix->d_nbr0, nbr0.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(ix->upper_blocks) ok = ok && hipMemcpy(upper.data(), ix->d_upper_nbr, ix->upper_blocks * ix->M * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(rows.data(), ix->d_vec, rows.size(), hipMemcpyDeviceToHost) == hipSuccess;
+    if(!ok) { set_err(ix, "lantern_gpu: HIP failure while serialising"); return false; }
+    char *p = buf + USEARCH_HEADER_SIZE;
+    for(size_t i = 0; i < n; ++i) {
+        const int level = ix->levels[ i ];
+        std::memset(p, 0, node_bytes(ix, level));
+        put<uint64_t>(p, 0, ix->labels[ i ]);
+        put<uint16_t>(p, 8, (uint16_t)level);
+        char *q = p + 10;
+        for(int l = 0; l <= level; ++l) {
+            const uint32_t  cap = l == 0 ? ix->M0 : ix->M;
+            const uint32_t *list = l == 0 ? &nbr0[ i * ix->M0 ] : &upper[ ((size_t)ix->upper_off[ i ] + (size_t)(l - 1)) * ix->M ];
+            uint32_t        cnt = 0;
+            while(cnt < cap && list[ cnt ] != EMPTY) ++cnt;
+            put<uint32_t>(q, 0, cnt);
+            for(uint32_t j = 0; j < cnt; ++j) put<uint32_t>(q, 4 + (size_t)j * LANTERN_SLOT_SIZE, list[ j ]);  // low 4 of 6 bytes
+            q += 4 + (size_t)cap * LANTERN_SLOT_SIZE;
+        }
+        std::memcpy(q, &rows[ i * row ], vb);
+        p += node_bytes(ix, level);
+    }
+    return true;
+}
+
+bool deserialize(Index *ix, const char *buf, size_t len)
+{
+    if(len < USEARCH_HEADER_SIZE || std::memcmp(buf + OFF_MAGIC, "usearch", 7) != 0) { set_err(ix, "lantern_gpu: not a usearch index file"); return false; }
+    const uint64_t n = get<uint64_t>(buf, OFF_G_SIZE);
+    if(get<uint64_t>(buf, OFF_G_CONNECTIVITY) != ix->M || get<uint64_t>(buf, OFF_DIMENSIONS) != ix->opts.dimensions ||
+       get<uint8_t>(buf, OFF_KIND_METRIC) != (uint8_t)ix->metric || get<uint8_t>(buf, OFF_KIND_SCALAR) != (uint8_t)ix->scalar) {
+        set_err(ix, "lantern_gpu: index file does not match the index options (metric, scalar kind, dimensions or connectivity)");
+        return false;
+    }
+    if(n == 0) return true;
+    const size_t vb = vector_bytes(ix);
+    std::vector<uint64_t> labels(n);
+    std::vector<uint8_t>  levels(n);
+    std::vector<uint32_t> nbr0(n * ix->M0, EMPTY), upper_off(n, EMPTY), upper;
+    std::vector<char>     vecs(n * vb);
+    const char *p = buf + USEARCH_HEADER_SIZE, *end = buf + len;
+    for(size_t i = 0; i < n; ++i) {
+        if(p + 10 > end) { set_err(ix, "lantern_gpu: truncated index file"); return false; }
+        labels[ i ] = get<uint64_t>(p, 0);
+        const int level = get<uint16_t>(p, 8);
+        if(level > 255 || p + node_bytes(ix, level) > end) { set_err(ix, "lantern_gpu: corrupt node tape"); return false; }
+        levels[ i ] = (uint8_t)level;
+        if(level > 0) {
+            upper_off[ i ] = (uint32_t)(upper.size() / ix->M);
+            upper.resize(upper.size() + (size_t)level * ix->M, EMPTY);
+        }
+        const char *q = p + 10;
+        for(int l = 0; l <= level; ++l) {
+            const uint32_t cap = l == 0 ? ix->M0 : ix->M;
+            uint32_t      *list = l == 0 ? &nbr0[ i * ix->M0 ] : &upper[ ((size_t)upper_off[ i ] + (size_t)(l - 1)) * ix->M ];
+            const uint32_t cnt = get<uint32_t>(q, 0);
+            if(cnt > cap) { set_err(ix, "lantern_gpu: corrupt neighbour count"); return false; }
+            for(uint32_t j = 0; j < cnt; ++j) {
+                list[ j ] = get<uint32_t>(q, 4 + (size_t)j * LANTERN_SLOT_SIZE);
+                if(list[ j ] >= n) { set_err(ix, "lantern_gpu: neighbour slot out of range"); return false; }
+            }
+            q += 4 + (size_t)cap * LANTERN_SLOT_SIZE;
+        }
+        std::memcpy(&vecs[ i * vb ], q, vb);
+        p += node_bytes(ix, level);
+    }
+    if(upper.empty()) upper.push_back(EMPTY);
+    // hamming rows are stored as bytes in the file; the importer wants whole u32 words per row
+    if(ix->scalar == usearch_scalar_b1_k && vb != (size_t)ix->words * 4) {
+        std::vector<char> w(n * (size_t)ix->words * 4, 0);
+        for(size_t i = 0; i < n; ++i) std::memcpy(&w[ i * (size_t)ix->words * 4 ], &vecs[ i * vb ], vb);
+        vecs.swap(w);
+    }
+    if(!import_graph_locked(ix, n, vecs.data(), labels.data(), levels.data(), nbr0.data(), upper_off.data(), upper.data(),
+                            (uint32_t)get<uint64_t>(buf, OFF_G_ENTRY_SLOT), (int32_t)get<uint64_t>(buf, OFF_G_MAX_LEVEL)))
+        return false;
+    return true;
+}
+
+}  // namespace lgpu
+
+using namespace lgpu;
+
+extern "C" {
+
+uint64_t usearch_header_get_entry_slot(char *h) { return get<uint64_t>(h, OFF_G_ENTRY_SLOT); }
+void     usearch_header_set_entry_slot(char *h, uint64_t slot) { put<uint64_t>(h, OFF_G_ENTRY_SLOT, slot); }
+
+size_t usearch_serialized_length(usearch_index_t h, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    Index *ix = (Index *)h;
+    if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return 0; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { if(e) *e = ix->err.c_str(); return 0; }
+    return serialized_length(ix);
+}
+
+void usearch_save_buffer(usearch_index_t h, char *buffer, size_t length, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    Index *ix = (Index *)h;
+    if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix) || !serialize(ix, buffer, length)) { if(e) *e = ix->err.c_str(); }
+}
+
+void usearch_save(usearch_index_t h, const char *path, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    Index *ix = (Index *)h;
+    if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { if(e) *e = ix->err.c_str(); return; }
+    std::vector<char> buf(serialized_length(ix));
+    if(!serialize(ix, buf.data(), buf.size())) { if(e) *e = ix->err.c_str(); return; }
+    FILE *f = std::fopen(path, "wb");
+    if(!f || std::fwrite(buf.data(), 1, buf.size(), f) != buf.size()) {
+        if(f) std::fclose(f);
+        if(e) *e = set_err(ix, std::string("lantern_gpu: cannot write index file ") + path);
+        return;
+    }
+    std::fclose(f);
+}
+
+void usearch_load_buffer(usearch_index_t h, const char *buffer, size_t length, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    Index *ix = (Index *)h;
+    if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!deserialize(ix, buffer, length) && e) *e = ix->err.c_str();
+}
+
+void usearch_load(usearch_index_t h, const char *path, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    Index *ix = (Index *)h;
+    if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
+    FILE *f = std::fopen(path, "rb");
+    if(!f) { if(e) *e = set_err(ix, std::string("lantern_gpu: cannot open index file ") + path); return; }
+    std::fseek(f, 0, SEEK_END);
+    long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<char> buf((size_t)(sz > 0 ? sz : 0));
+    const bool rd = std::fread(buf.data(), 1, buf.size(), f) == buf.size();
+    std::fclose(f);
+    if(!rd) { if(e) *e = set_err(ix, std::string("lantern_gpu: short read on ") + path); return; }
+    usearch_load_buffer(h, buf.data(), buf.size(), e);
+}
+
+}  // extern "C"

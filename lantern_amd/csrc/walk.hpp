@@ -1,0 +1,291 @@
+// walk.hpp -- the HNSW graph walk as one workgroup's cooperative device functions.
+//
+// Follows usearch's search_for_one_ / search_to_find_in_base_ / search_to_insert_ / refine_ as
+// Lantern reaches them through usearch_search_ef (lantern_hnsw/src/hnsw/scan.c:220-228) and
+// usearch_add (lantern_hnsw/src/hnsw/build.c:128), re-shaped for a 64-lane machine:
+//
+//  * usearch keeps two structures per search: `next` (a heap of candidates) and `top` (the ef best
+//    so far).  Under the total order (distance, slot) an element evicted from `top` can never be
+//    expanded later, so a single sorted list with an "expanded" bit per entry is equivalent:
+//    "pop the best candidate" = "first unexpanded entry"; the walk ends when there is none.
+//  * all unvisited neighbours of the popped node are evaluated at once (one G-lane group per row,
+//    several rows in flight per wave), then merged into the list in one parallel rank-merge.  The
+//    result equals inserting them one by one: the list ends up holding the ef smallest of
+//    (old list U new), whatever the order of insertion.
+//  * the visited set is a bitmap in HBM owned by the workgroup (atomicOr gives test-and-set).
+//
+// All functions must be called by every thread of the workgroup (they contain barriers).
+#pragma once
+#include "device_common.hpp"
+
+namespace lgpu {
+
+// scalar slots in LDS
+enum { S_POS = 0, S_NNEW, S_CNT, S_ANY, S_BAD, S_CUR, S_CURD, S_CHANGED, S_SCALARS = 16 };
+
+struct WalkLds
+{
+    uint4    *q;        // the query row (chunks uint4)
+    uint64_t *keys;     // current list   (ef_cap)
+    uint64_t *keys2;    // merge target   (ef_cap)
+    uint64_t *newkeys;  // keys of this hop's new neighbours (cap_max)
+    uint64_t *sorted;   // the same, sorted                  (cap_max)
+    uint32_t *newids;   // unvisited neighbour slots         (cap_max)
+    int      *scal;     // S_* scalars
+};
+
+// Carve the workgroup's dynamic LDS.  Every offset stays 16-byte aligned.
+__device__ __forceinline__ unsigned char *carve_walk(unsigned char *p, WalkLds &s, uint32_t chunks, uint32_t ef_cap, uint32_t cap_max)
+{
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    s.q = (uint4 *)p;            p += (size_t)chunks * 16;
+    s.keys = (uint64_t *)p;      p += up16((size_t)ef_cap * 8);
+    s.keys2 = (uint64_t *)p;     p += up16((size_t)ef_cap * 8);
+    s.newkeys = (uint64_t *)p;   p += up16((size_t)cap_max * 8);
+    s.sorted = (uint64_t *)p;    p += up16((size_t)cap_max * 8);
+    s.newids = (uint32_t *)p;    p += up16((size_t)cap_max * 4);
+    s.scal = (int *)p;           p += S_SCALARS * 4;
+    return p;
+}
+__host__ inline size_t walk_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t cap_max)
+{
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    return (size_t)chunks * 16 + 2 * up16((size_t)ef_cap * 8) + 2 * up16((size_t)cap_max * 8) + up16((size_t)cap_max * 4) + S_SCALARS * 4;
+}
+
+__device__ __forceinline__ int lower_bound_keys(const uint64_t *a, int n, uint64_t k)
+{
+    int lo = 0, hi = n;
+    while(lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if(a[ mid ] < k) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- search_for_one_: greedy descent over levels (begin, end] ---------------------------------------
+// Returns the closest slot (same value in every thread).  D counts distance evaluations.
+template <int METRIC, int G>
+__device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, int begin_level, int end_level, uint32_t &D)
+{
+    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
+    float *newd = (float *)s.newkeys;  // reuse: one f32 per neighbour
+    if(g == 0) {
+        float d = group_dist<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl);
+        if(gl == 0) { s.scal[ S_CUR ] = (int)start; s.scal[ S_CURD ] = __float_as_int(d); }
+    }
+    D += 1;
+    __syncthreads();
+    for(int level = begin_level; level > end_level; --level) {
+        for(;;) {
+            uint32_t        cur = (uint32_t)s.scal[ S_CUR ];
+            uint32_t        cap;
+            const uint32_t *list = neighbors_of(v, cur, level, cap);
+            if(tid == 0) s.scal[ S_NNEW ] = 0;
+            __syncthreads();
+            // gather the (EMPTY-terminated) list
+            for(uint32_t i = tid; i < cap; i += T) {
+                uint32_t nb = list[ i ];
+                s.newids[ i ] = nb;
+                if(nb != EMPTY) atomicMax(&s.scal[ S_NNEW ], (int)i + 1);
+            }
+            __syncthreads();
+            const int nn = s.scal[ S_NNEW ];
+            for(int i = g; i < nn; i += NG) {
+                float d = group_dist<METRIC, G>(s.q, row_of(v, s.newids[ i ]), (int)v.chunks, gl);
+                if(gl == 0) newd[ i ] = d;
+            }
+            D += (uint32_t)nn;
+            __syncthreads();
+            if(tid == 0) {
+                // the sequential scan of search_for_one_: first strictly-closer wins, in list order
+                float    best = __int_as_float(s.scal[ S_CURD ]);
+                uint32_t bslot = cur;
+                int      changed = 0;
+                for(int i = 0; i < nn; ++i)
+                    if(newd[ i ] < best) { best = newd[ i ]; bslot = s.newids[ i ]; changed = 1; }
+                s.scal[ S_CUR ] = (int)bslot;
+                s.scal[ S_CURD ] = __float_as_int(best);
+                s.scal[ S_CHANGED ] = changed;
+            }
+            __syncthreads();
+            if(!s.scal[ S_CHANGED ]) break;
+        }
+    }
+    uint32_t r = (uint32_t)s.scal[ S_CUR ];
+    __syncthreads();
+    return r;
+}
+
+// ---- search_to_find_in_base_ / search_to_insert_ -----------------------------------------------------
+// On return s.keys[0..cnt) holds the result ascending by (distance, slot); returns cnt.
+template <int METRIC, int G>
+__device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int level, int ef,
+                            uint32_t &D, uint32_t &E)
+{
+    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
+    const int lane = tid & 63;
+    // visits.clear()
+    {
+        uint4 *b4 = (uint4 *)bitmap;
+        for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
+    }
+    if(g == 0) {
+        float d = group_dist<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl);
+        if(gl == 0) s.keys[ 0 ] = make_key(d, start);
+    }
+    D += 1;
+    __syncthreads();
+    if(tid == 0) atomicOr(&bitmap[ start >> 5 ], 1u << (start & 31));
+    int cnt = 1;
+    for(;;) {
+        // ---- pop: first unexpanded entry of the list
+        if(tid == 0) { s.scal[ S_POS ] = 0x7FFFFFFF; s.scal[ S_ANY ] = 0; }
+        __syncthreads();
+        for(int i = tid; i < cnt; i += T)
+            if(!key_expanded(s.keys[ i ])) { atomicMin(&s.scal[ S_POS ], i); break; }
+        __syncthreads();
+        const int pos = s.scal[ S_POS ];
+        if(pos == 0x7FFFFFFF) break;
+        const uint32_t node = key_slot(s.keys[ pos ]);
+        E += 1;
+        // ---- neighbour list + visited test-and-set, compacted in list order (wave 0)
+        if(tid < 64) {
+            uint32_t        cap;
+            const uint32_t *list = neighbors_of(v, node, level, cap);
+            int             base = 0;
+            for(uint32_t off = 0; off < cap; off += 64) {
+                uint32_t i = off + (uint32_t)lane;
+                uint32_t nb = i < cap ? list[ i ] : EMPTY;
+                bool     isnew = false;
+                if(nb != EMPTY) {
+                    uint32_t bit = 1u << (nb & 31);
+                    uint32_t old = atomicOr(&bitmap[ nb >> 5 ], bit);
+                    isnew = (old & bit) == 0;
+                }
+                unsigned long long m = __ballot(isnew);
+                if(isnew) s.newids[ base + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
+                base += __popcll(m);
+            }
+            if(lane == 0) { s.scal[ S_NNEW ] = base; s.keys[ pos ] |= 1ull; }
+        }
+        __syncthreads();
+        const int nnew = s.scal[ S_NNEW ];
+        if(nnew == 0) continue;
+        // ---- distances: one G-lane group per row, two rows in flight per group
+        const uint64_t worst = cnt == ef ? s.keys[ cnt - 1 ] : ~0ull;
+        for(int i = g; i < nnew; i += 2 * NG) {
+            const int      j = i + NG;
+            const uint32_t id0 = s.newids[ i ];
+            const uint32_t id1 = j < nnew ? s.newids[ j ] : id0;
+            float          d0, d1;
+            group_dist2<METRIC, G>(s.q, row_of(v, id0), row_of(v, id1), (int)v.chunks, gl, d0, d1);
+            if(gl == 0) {
+                uint64_t k0 = make_key(d0, id0);
+                s.newkeys[ i ] = k0;
+                bool any = k0 < worst;
+                if(j < nnew) {
+                    uint64_t k1 = make_key(d1, id1);
+                    s.newkeys[ j ] = k1;
+                    any |= k1 < worst;
+                }
+                if(any) s.scal[ S_ANY ] = 1;
+            }
+        }
+        D += (uint32_t)nnew;
+        __syncthreads();
+        if(!s.scal[ S_ANY ]) continue;  // nothing beats the current radius: list unchanged
+        // ---- merge: rank-sort the new keys, then rank-merge both lists into keys2
+        for(int t = tid; t < nnew; t += T) {
+            const uint64_t k = s.newkeys[ t ];
+            int            r = 0;
+            for(int j = 0; j < nnew; ++j) r += s.newkeys[ j ] < k;
+            s.sorted[ r ] = k;
+        }
+        __syncthreads();
+        for(int i = tid; i < cnt; i += T) {
+            const uint64_t k = s.keys[ i ];
+            const int      p = i + lower_bound_keys(s.sorted, nnew, k);
+            if(p < ef) s.keys2[ p ] = k;
+        }
+        for(int j = tid; j < nnew; j += T) {
+            const uint64_t k = s.sorted[ j ];
+            const int      p = j + lower_bound_keys(s.keys, cnt, k);
+            if(p < ef) s.keys2[ p ] = k;
+        }
+        cnt = cnt + nnew < ef ? cnt + nnew : ef;
+        uint64_t *tmp = s.keys; s.keys = s.keys2; s.keys2 = tmp;
+        __syncthreads();
+    }
+    return cnt;
+}
+
+// ---- refine_: the neighbour-selection heuristic --------------------------------------------------------
+struct RefineLds
+{
+    float    *cd;   // candidates in: distance to the centre
+    uint32_t *cid;  //                slot
+    float    *sd;   // sorted / selected out
+    uint32_t *sid;
+};
+__device__ __forceinline__ unsigned char *carve_refine(unsigned char *p, RefineLds &r, uint32_t n_max)
+{
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    r.cd = (float *)p;      p += up16((size_t)n_max * 4);
+    r.cid = (uint32_t *)p;  p += up16((size_t)n_max * 4);
+    r.sd = (float *)p;      p += up16((size_t)n_max * 4);
+    r.sid = (uint32_t *)p;  p += up16((size_t)n_max * 4);
+    return p;
+}
+__host__ inline size_t refine_lds_bytes(uint32_t n_max)
+{
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    return 4 * up16((size_t)n_max * 4);
+}
+
+// in: r.cd/r.cid[0..n) in any order.  Sorts by (distance, tie_mix(slot, centre)) into r.sd/r.sid,
+// then keeps an entry iff no already-kept entry is strictly closer to it than the centre is.
+// Returns the number kept (<= needed), left in r.sd/r.sid[0..keep).  `scal` = WalkLds-style scalars.
+template <int METRIC, int G>
+__device__ int refine(const View &v, RefineLds &r, int *scal, int n, int needed, uint32_t centre, uint32_t &Dr)
+{
+    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
+    for(int t = tid; t < n; t += T) {
+        const float    d = r.cd[ t ];
+        const uint32_t id = r.cid[ t ];
+        const uint64_t k = ((uint64_t)f2ord(d) << 32) | tie_mix(id, centre);
+        int            rank = 0;
+        for(int j = 0; j < n; ++j) {
+            const uint64_t kj = ((uint64_t)f2ord(r.cd[ j ]) << 32) | tie_mix(r.cid[ j ], centre);
+            rank += kj < k;
+        }
+        r.sd[ rank ] = d;
+        r.sid[ rank ] = id;
+    }
+    if(tid == 0) scal[ S_BAD ] = 0;
+    __syncthreads();
+    if(n < needed) return n;
+    int submitted = 1, consumed = 1;
+    while(submitted < needed && consumed < n) {
+        const uint32_t cid = r.sid[ consumed ];
+        const float    cdist = r.sd[ consumed ];
+        for(int i = g; i < submitted; i += NG) {
+            float inter = group_dist<METRIC, G>(row_of(v, cid), row_of(v, r.sid[ i ]), (int)v.chunks, gl);
+            if(gl == 0 && inter < cdist) scal[ S_BAD ] = 1;
+        }
+        Dr += (uint32_t)submitted;
+        __syncthreads();
+        const bool good = scal[ S_BAD ] == 0;
+        __syncthreads();
+        if(tid == 0) {
+            scal[ S_BAD ] = 0;
+            if(good) { r.sid[ submitted ] = cid; r.sd[ submitted ] = cdist; }
+        }
+        if(good) submitted++;
+        consumed++;
+        __syncthreads();
+    }
+    return submitted;
+}
+
+}  // namespace lgpu

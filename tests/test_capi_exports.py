@@ -1,0 +1,77 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/lantern_gpu.h
+declares, and refuses loudly to compute without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from lantern_amd import build, capi
+
+    build.build()
+    capi.lib()
+    return capi
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lantern_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"LANTERN_GPU_EXPORT[^;(]*?\b((?:usearch|lantern)_[a-z0-9_]+)\s*\(", text)
+    assert len(names) > 30
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    raw = C.CDLL(capi.LIB_PATH)
+    missing = [n for n in declared_symbols() if not hasattr(raw, n)]
+    assert not missing, f"declared in lantern_gpu.h but not exported: {missing}"
+
+
+def test_binding_covers_the_header(capi):
+    assert sorted(capi.EXPORTS) == declared_symbols()
+
+
+def test_no_oracle_in_product_path():
+    # the product must never import, load or link the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lantern_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("import oracle", "from oracle", "liblantern_oracle", "lantern_oracle.h", "lo_search", "lo_distance"):
+                    assert needle not in src, (f, needle)
+
+
+def test_header_helpers_work_without_a_device(capi):
+    buf = C.create_string_buffer(capi.USEARCH_HEADER_SIZE)
+    capi.lib().usearch_header_set_entry_slot(buf, 0x0000123456789ABC)
+    assert capi.lib().usearch_header_get_entry_slot(buf) == 0x0000123456789ABC
+
+
+def test_fails_loudly_without_device(capi):
+    if capi.device_count() > 0:
+        pytest.skip("a device is present")
+    with pytest.raises(capi.LanternGpuError, match="no HIP device"):
+        capi.GpuIndex("l2sq", 8)
+    with pytest.raises(capi.LanternGpuError, match="no HIP device"):
+        capi.distance([1, 2, 3], [3, 2, 1], "l2sq")
+
+
+def test_argument_validation_precedes_device_use(capi):
+    # dimension mismatch text is the reference's (hnsw.c:301-303; hnsw_dist_func.out:126-135)
+    with pytest.raises(capi.LanternGpuError, match="expected equally sized arrays but got arrays with dimensions 2 and 3"):
+        capi.l2sq_dist([1, 1], [0, 1, 0])
+    with pytest.raises(capi.LanternGpuError, match="expected equally sized arrays"):
+        capi.hamming_dist([1, 1], [0, 1, 0])
+    o = capi.InitOptions()
+    o.metric_kind, o.quantization, o.dimensions, o.connectivity = 2, 1, 8, 16  # ip: not a Lantern metric
+    err = C.c_char_p()
+    assert capi.lib().usearch_init(C.byref(o), None, C.byref(err)) is None
+    assert b"unsupported metric" in err.value
+    o.metric_kind, o.pq = 3, True
+    assert capi.lib().usearch_init(C.byref(o), None, C.byref(err)) is None
+    assert b"product quantization" in err.value

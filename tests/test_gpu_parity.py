@@ -1,0 +1,271 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Needs an MI355X.
+
+Bar: bit-exact against the oracle's LO_SUM_WAVE64 order (the device's own reduction tree) for
+every metric; within 1e-5 relative of the usearch-order (LO_SUM_SEQ) result for L2sq/cosine;
+identical top-k id lists, identical distance-evaluation and expansion counts on the same graph.
+"""
+import numpy as np
+import pytest
+
+from tests.scan_driver import scan as oracle_scan
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star: L2sq / cosine within 1e-5 relative
+LABEL0 = 1
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from lantern_amd import capi
+
+    capi.lib()
+    assert capi.device_count() > 0, "no HIP device: the gpu tests need a real MI355X"
+    return capi
+
+
+def rand_rows(rng, n, d, metric):
+    if metric == "hamming":
+        return rng.integers(0, 2**32, size=(n, d), dtype=np.uint32)
+    return rng.standard_normal((n, d), dtype=np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# distances
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric", ["l2sq", "cos", "hamming"])
+@pytest.mark.parametrize("d", [1, 3, 4, 17, 63, 64, 100, 128, 255, 256, 768, 1536, 2000])
+def test_pair_distance_bit_exact_and_within_tolerance(capi, oracle, metric, d):
+    rng = np.random.default_rng(d)
+    if metric == "hamming" and d > 256:
+        pytest.skip("hamming rows are at most 2000*32 bits in Lantern; 256 words covers the group sizes")
+    a, b = rand_rows(rng, 1, d, metric)[0], rand_rows(rng, 1, d, metric)[0]
+    got = capi.distance(a, b, metric)
+    assert got == oracle.distance(a, b, metric, oracle.SUM_WAVE64)
+    ref = oracle.distance(a, b, metric, oracle.SUM_SEQ)
+    if metric == "hamming":
+        assert got == ref
+    else:
+        assert abs(got - ref) <= TOL * max(1.0, abs(ref))
+
+
+def test_golden_operator_cases_on_device(capi, golden):
+    for c in golden["operators"]["cases"]:
+        fn = {"l2sq": capi.l2sq_dist, "cos": capi.cos_dist, "hamming": capi.hamming_dist}[c["op"]]
+        d = fn(c["a"], c["b"])
+        if "expect" in c:
+            assert d == c["expect"], c
+        else:
+            assert round(d, 2) == c["expect_2dp"], c
+    # cosine zero-vector rules (hnsw_vector.out:205-210, hnsw_dist_func.out:58-61)
+    assert capi.cos_dist([0, 0, 0], [0, 0, 0]) == 0.0
+    assert capi.cos_dist([0, 0, 0], [0, 0, 2]) == 1.0
+    assert capi.cos_dist([0, 0, 1], [0, 0, 0]) == 1.0
+    with pytest.raises(capi.LanternGpuError, match="expected equally sized arrays but got arrays with dimensions 2 and 3"):
+        capi.cos_dist([1, 1], [0, 1, 0])
+
+
+@pytest.mark.parametrize("metric", ["l2sq", "cos", "hamming"])
+def test_distance_matrix_exact_order(capi, oracle, metric):
+    rng = np.random.default_rng(5)
+    d = 24 if metric == "hamming" else 96
+    A, B = rand_rows(rng, 7, d, metric), rand_rows(rng, 33, d, metric)
+    got = capi.distance_matrix(A, B, metric, exact_order=True)
+    ref = np.array([[oracle.distance(a, b, metric, oracle.SUM_WAVE64) for b in B] for a in A], dtype=np.float32)
+    assert np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# search on an identical graph
+# ------------------------------------------------------------------------------------------------
+CASES = [
+    # metric, n, d, M, efc, ef, k
+    ("l2sq", 3000, 128, 16, 64, 64, 10),   # BASELINE config[1] shape, reduced n
+    ("cos", 2000, 768, 16, 64, 64, 10),    # config[2]/[3] row width
+    ("l2sq", 1500, 100, 8, 40, 32, 5),     # ragged width (G=32, padded chunk)
+    ("l2sq", 800, 3, 2, 10, 4, 1),         # README example parameters (M=2, efc=10, ef=4)
+    ("hamming", 3000, 24, 16, 64, 64, 10), # SURVEY 8(d) hamming check set shape
+    ("cos", 600, 1536, 16, 32, 128, 10),   # config[4] width, ef=128
+]
+
+
+@pytest.mark.parametrize("metric,n,d,M,efc,ef,k", CASES)
+def test_search_matches_oracle_on_same_graph(capi, oracle, metric, n, d, M, efc, ef, k):
+    rng = np.random.default_rng(n + d)
+    base, queries = rand_rows(rng, n, d, metric), rand_rows(rng, 64, d, metric)
+    ora = oracle.OracleIndex(metric, d, M=M, ef_construction=efc, ef=ef, seed=9, sum_mode=oracle.SUM_WAVE64)
+    ora.add_many(np.arange(n, dtype=np.uint64) + LABEL0, base)
+    g = ora.export_graph()
+    gpu = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=ef, seed=9)
+    gpu.import_graph(base, g)
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, k)
+    import torch
+
+    dq = torch.zeros((64, ((d + 3) // 4) * 4), dtype=torch.float32 if metric != "hamming" else torch.int32, device="cuda")
+    src = torch.from_numpy(queries.view(np.int32) if metric == "hamming" else queries).cuda()
+    dq[:, :d] = src
+    lab = torch.zeros((64, k), dtype=torch.int64, device="cuda")
+    dist = torch.zeros((64, k), dtype=torch.float32, device="cuda")
+    slot = torch.zeros((64, k), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(64, dtype=torch.int32, device="cuda")
+    D = torch.zeros(64, dtype=torch.int64, device="cuda")
+    E = torch.zeros(64, dtype=torch.int64, device="cuda")
+    for waves in (1, 4, 8):
+        gpu.set_search_shape(waves)
+        gpu.search_batch_device(dq.data_ptr(), 64, k, 0, 0, lab.data_ptr(), dist.data_ptr(), slot.data_ptr(), cnt.data_ptr(),
+                                D.data_ptr(), E.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(slot.cpu().numpy().view(np.uint32), o_slot), f"top-k slots differ (waves={waves})"
+        assert np.array_equal(lab.cpu().numpy().view(np.uint64), o_lab)
+        assert np.array_equal(dist.cpu().numpy(), o_dist)
+        assert np.array_equal(D.cpu().numpy().view(np.uint64), o_D), "distance-evaluation counts differ"
+        assert np.array_equal(E.cpu().numpy().view(np.uint64), o_E), "expansion counts differ"
+    # host-buffer entry points agree with the device-buffer one
+    h_lab, h_dist, h_cnt = gpu.search_batch(queries, k)
+    assert np.array_equal(h_lab, o_lab) and np.array_equal(h_dist, o_dist)
+    l1, d1 = gpu.search(queries[0], k)
+    assert np.array_equal(l1, o_lab[0][: len(l1)]) and np.array_equal(d1, o_dist[0][: len(d1)])
+    # usearch-order oracle on the same graph: same ids except across near-ties, distances within tolerance
+    seq = oracle.OracleIndex.from_graph(metric, base, g, M, efc, ef, 9, oracle.SUM_SEQ)
+    _, s_dist, s_slot, _, _ = seq.search_batch(queries, k)
+    if metric == "hamming":
+        assert np.array_equal(s_slot, o_slot)
+    else:
+        assert np.all(np.abs(s_dist - o_dist) <= TOL * np.maximum(1.0, np.abs(s_dist)))
+        assert oracle.recall_at_k(o_slot, s_slot) >= 0.995
+
+
+@pytest.mark.parametrize("metric,n,d,M,efc", [("l2sq", 1200, 64, 8, 40), ("cos", 700, 256, 16, 64), ("hamming", 900, 8, 6, 32),
+                                              ("l2sq", 300, 5, 2, 10)])
+@pytest.mark.parametrize("plan", [(1, 1), (64, 4), (512, 16)])
+def test_build_matches_oracle_edge_for_edge(capi, oracle, metric, n, d, M, efc, plan):
+    rng = np.random.default_rng(n * 7 + d)
+    base = rand_rows(rng, n, d, metric)
+    labels = np.arange(n, dtype=np.uint64) + LABEL0
+    ora = oracle.OracleIndex(metric, d, M=M, ef_construction=efc, ef=32, seed=21, sum_mode=oracle.SUM_WAVE64)
+    ora.add_planned(labels, base, max_batch=plan[0], min_ratio=plan[1])
+    gpu = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=32, seed=21)
+    gpu.set_add_batch(*plan)
+    gpu.add_many(labels, base)
+    gpu.flush()
+    assert len(gpu) == n
+    go, gg = ora.export_graph(), gpu.export_graph(with_vectors=True)
+    assert gg["entry_slot"] == go["entry_slot"] and gg["max_level"] == go["max_level"]
+    assert np.array_equal(gg["levels"], go["levels"])
+    assert np.array_equal(gg["labels"], go["labels"])
+    assert np.array_equal(gg["upper_off"], go["upper_off"])
+    assert np.array_equal(gg["nbr0"], go["nbr0"]), "level-0 adjacency differs"
+    assert np.array_equal(gg["upper_nbr"], go["upper_nbr"]), "upper-level adjacency differs"
+    assert np.array_equal(gg["vectors"], base)
+
+
+def test_sequential_plan_is_usearch_add(capi, oracle):
+    # max_batch = 1 must reproduce the strictly sequential usearch_add semantics (oracle lo_add)
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((400, 32), dtype=np.float32)
+    ora = oracle.OracleIndex("l2sq", 32, M=8, ef_construction=32, seed=4, sum_mode=oracle.SUM_WAVE64)
+    ora.add_many(np.arange(400) + 1, base)
+    gpu = capi.GpuIndex("l2sq", 32, M=8, ef_construction=32, seed=4)
+    gpu.set_add_batch(1, 1)
+    for i in range(400):
+        gpu.add(i + 1, base[i])
+    assert np.array_equal(gpu.export_graph()["nbr0"], ora.export_graph()["nbr0"])
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's golden cases through the device index and its scan shim
+# ------------------------------------------------------------------------------------------------
+def gpu_build(capi, metric, rows, M=16, efc=128, ef=64):
+    rows = np.asarray(rows)
+    ix = capi.GpuIndex(metric, rows.shape[1], M=M, ef_construction=efc, ef=ef, seed=7)
+    ix.add_many(np.arange(rows.shape[0], dtype=np.uint64) + LABEL0, rows)
+    return ix
+
+
+def ordered(capi, ix, q, n, init_k=10):
+    s = capi.Scan(ix, init_k=init_k)
+    s.rescan(q)
+    out = s.fetch(n)
+    s.end()
+    return out
+
+
+def test_golden_small_world_on_device(capi, golden):
+    g, sw = golden["dist_func"], golden["small_world"]
+    dist = {"l2sq": capi.l2sq_dist, "cos": capi.cos_dist, "hamming": capi.hamming_dist}
+    for metric, key in (("l2sq", "l2sq_sorted"), ("cos", "cos_sorted_2dp"), ("hamming", "hamming_sorted")):
+        ix = gpu_build(capi, metric, sw["v"])
+        order = ordered(capi, ix, g["query"], 8)
+        assert sorted(order) == list(range(LABEL0, LABEL0 + 8))
+        assert [round(dist[metric](sw["v"][l - LABEL0], g["query"]), 2) for l in order] == g[key]
+    g4 = golden["four_nn_of_each_corner"]
+    ix = gpu_build(capi, "l2sq", sw["v"])
+    for ident, v in zip(sw["ids"], sw["v"]):
+        labels, dists = ix.search(v, 4)
+        got = [sw["ids"][int(l) - LABEL0] for l in labels]
+        assert got[0] == ident and sorted(got) == sorted(g4["rows"][ident]) and list(dists) == g4["dists"]
+
+
+def test_golden_streaming_and_pagination_on_device(capi, golden):
+    g, sw = golden["streaming"], golden["small_world"]
+    ix = gpu_build(capi, "l2sq", sw["v"] + [[99, 99, 2]], M=5, efc=20, ef=20)
+    assert len(ordered(capi, ix, g["query"], 3, init_k=g["init_k"])) == g["limit_3_count"]
+    got = ordered(capi, ix, g["query"], 15, init_k=g["init_k"])
+    assert len(got) == g["limit_15_count"] and len(set(got)) == len(got)
+    p = golden["pagination_duplicates"]
+    rows = [[np.float32(i) / np.float32(10)] * p["dim"] for i in p["ramp_ids"]] + [[p["dup_value"]] * p["dim"]] * p["dup_count"]
+    ix = capi.GpuIndex("l2sq", p["dim"], seed=7)
+    ix.set_add_batch(1, 1)  # the reference inserts these rows one by one
+    ids = [i + 1 for i in p["ramp_ids"]] + [p["dup_first_id"] + j + 1 for j in range(p["dup_count"])]
+    ix.add_many(ids, np.asarray(rows, dtype=np.float32))
+    got = ordered(capi, ix, [p["dup_value"]] * p["dim"], p["limit"], init_k=p["init_k"])
+    assert len(got) == p["limit"] and len(set(got)) == len(got)
+
+
+def test_golden_insert_dimension_errors_and_misc(capi, golden):
+    sw = golden["small_world"]
+    ix = gpu_build(capi, "l2sq", sw["v"])
+    ix.add(100, golden["insert_then_search"]["inserted"])
+    order = ordered(capi, ix, [0, 0, 0], 9)
+    rows = sw["v"] + [golden["insert_then_search"]["inserted"]]
+    assert [capi.l2sq_dist(rows[8 if l == 100 else l - LABEL0], [0, 0, 0]) for l in order] == golden["insert_then_search"]["sorted"]
+    with pytest.raises(capi.LanternGpuError, match="Wrong number of dimensions: 4 instead of 3 expected"):
+        ix.add(101, [4, 4, 4, 4])
+    with pytest.raises(capi.LanternGpuError, match=golden["dimension_errors"]["sized_array"]):
+        ix.search([0, 1, 0, 1], 1)
+    # empty index, k larger than the index, label 0 (deleted) is skipped by the scan
+    e = capi.GpuIndex("l2sq", 3)
+    assert len(e.search([0, 0, 0], 5)[0]) == 0
+    d = capi.GpuIndex("l2sq", 3)
+    d.add_many([5, 0, 7], [[0, 0, 0], [0, 0, 1], [0, 0, 2]])
+    assert ordered(capi, d, [0, 0, 0], 10) == [5, 7]
+    m = ix.metadata()
+    assert m.neighbors_bytes == 4 + 16 * 6 and m.neighbors_base_bytes == 4 + 32 * 6 and m.connectivity == 16
+
+
+def test_file_round_trip(capi, oracle, tmp_path):
+    rng = np.random.default_rng(8)
+    for metric, d in (("l2sq", 24), ("hamming", 3)):
+        base = rand_rows(rng, 500, d, metric)
+        ix = capi.GpuIndex(metric, d, M=4, ef_construction=24, seed=2)
+        ix.add_many(np.arange(500) + 1, base)
+        blob = ix.save_buffer()
+        g = ix.export_graph()
+        # layout: 136-byte header + node tapes: 8+2+(4+2M*6)+level*(4+M*6)+vector (usearch_storage.cpp:19-32)
+        vb = d * 4
+        assert len(blob) == 136 + sum(10 + (4 + 8 * 6) + int(l) * (4 + 4 * 6) + vb for l in g["levels"])
+        assert blob[:7] == b"usearch"
+        other = capi.GpuIndex(metric, d, M=4, ef_construction=24, seed=2)
+        other.load_buffer(blob)
+        g2 = other.export_graph(with_vectors=True)
+        for key in ("levels", "nbr0", "upper_off", "upper_nbr", "labels"):
+            assert np.array_equal(g[key], g2[key]), key
+        assert np.array_equal(g2["vectors"], base) and g2["entry_slot"] == g["entry_slot"]
+        path = str(tmp_path / f"{metric}.usearch")
+        ix.save(path)
+        third = capi.GpuIndex(metric, d, M=4, ef_construction=24, seed=2)
+        third.load(path)
+        q = rand_rows(rng, 1, d, metric)[0]
+        assert np.array_equal(third.search(q, 5)[0], ix.search(q, 5)[0])
+        # first node tape: label, level
+        assert int.from_bytes(blob[136:144], "little") == 1 and int.from_bytes(blob[144:146], "little") == int(g["levels"][0])
