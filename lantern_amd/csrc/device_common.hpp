@@ -90,7 +90,7 @@ template <> struct Acc<M_COS>
         // hnsw_dist_func.out:58-61): both zero -> 0, one zero -> 1
         if(a2 == 0.f && b2 == 0.f) return 0.f;
         if(a2 == 0.f || b2 == 0.f) return 1.f;
-        return 1.f - __fdiv_rn(ab, __fsqrt_rn(a2) * __fsqrt_rn(b2));
+        return 1.f - ab / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));  // IEEE sqrt and divide (hipcc default: correctly rounded)
     }
 };
 
