@@ -96,14 +96,11 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise LanternGpuError(f"{LIB_PATH} is missing: run `python -m lantern_amd.build` (needs hipcc); "
                               "there is no CPU fallback")
-    # PyTorch-ROCm bundles its own libamdhip64.so (same SONAME).  Two HIP runtimes in one process
-    # cannot both own the GPU, so when torch is installed it must be loaded FIRST: the loader then
-    # resolves this library's libamdhip64.so.7 dependency to the runtime torch already mapped, and
-    # device pointers / streams are shared between the two.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # NOTE for hosts that also use PyTorch-ROCm: torch bundles its own libamdhip64.so with the same
+    # SONAME, and two HIP runtimes in one process cannot both own the GPU.  `import torch` BEFORE the
+    # first call into this module: the loader then resolves this library's libamdhip64.so.7 dependency
+    # to the runtime torch already mapped and device pointers / streams are shared.  Without torch the
+    # library binds ROCm's own runtime (lantern_amd/hip.py gives buffers, streams and events).
     L = C.CDLL(LIB_PATH)
     vp, sz, u32, u64, i32, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_float
     err = C.POINTER(C.c_char_p)

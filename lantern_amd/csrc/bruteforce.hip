@@ -1,0 +1,297 @@
+// bruteforce.hip -- the dense batched-query x candidate contraction (BASELINE config[2]) and the
+// exact k-NN built on it (the seq-scan `ORDER BY v <op> q LIMIT k`; ground truth for recall@k as
+// defined by lantern_cli/src/index_autotune/mod.rs:196-203,239-247).
+//
+//   k_row_norms    ||x||^2 per row (one G-lane group per row, same reduction as the walk)
+//   k_dense_f32    D[q][c] = metric(Q[q], B[c]) for a 128 x 128 tile per workgroup on fp32 MFMA
+//                  (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate -- bf16/fp16 would lose the 1e-5
+//                  tolerance).  l2sq = |q|^2 + |b|^2 - 2 q.b ; cos = 1 - q.b / (|q||b|) with the
+//                  reference's zero-norm rules.  This is the only place MFMA is used: it is the one
+//                  true dense contraction on the path.
+//   k_dense_ham    the same tile shape for hamming (popcount of XOR; integer, VALU)
+//   k_select       per query: merge a chunk of the distance matrix into a running top-k'
+//   k_rerank       recompute the k' survivors in the graph walk's exact reduction order and emit
+//                  the final top-k by (distance, slot)
+#include "kernels.hpp"
+#include "walk.hpp"
+
+namespace lgpu {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------
+template <int G>
+__global__ void __launch_bounds__(256) k_row_norms(const uint4 *rows, uint32_t n, uint32_t chunks, float *out)
+{
+    const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) / G, gl = threadIdx.x % G;
+    const uint32_t ngroups = gridDim.x * blockDim.x / G;
+    for(uint32_t i = gid; i < n; i += ngroups) {
+        const uint4 *r = rows + (size_t)i * chunks;
+        float        s = 0.f;
+        for(uint32_t ch = gl; ch < chunks; ch += G) {
+            uint4 x = r[ ch ];
+            s = __builtin_fmaf(__uint_as_float(x.x), __uint_as_float(x.x), s);
+            s = __builtin_fmaf(__uint_as_float(x.y), __uint_as_float(x.y), s);
+            s = __builtin_fmaf(__uint_as_float(x.z), __uint_as_float(x.z), s);
+            s = __builtin_fmaf(__uint_as_float(x.w), __uint_as_float(x.w), s);
+        }
+#pragma unroll
+        for(int off = G / 2; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+        if(gl == 0) out[ i ] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 128 x 128 output tile per 256-thread workgroup; 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles of
+// 32 x 32; K staged through LDS 32 floats at a time (row stride 33 words: the 32 lanes of a half
+// wave read 32 different rows at one k -> 32 different banks).
+constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 1;
+
+template <int METRIC>
+__global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, const float *B, uint32_t nb, uint32_t stride /* floats per row */,
+                                                   const float *qn, const float *bn, float *out, uint32_t ldo)
+{
+    __shared__ float As[ BM * LDK ];
+    __shared__ float Bs[ BN * LDK ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: consecutive workgroups (which land on different XCDs) walk the query
+    // dimension first, so the 8 XCDs stream 8 different Q tiles against the same B tile column
+    const uint32_t tiles_m = (nq + BM - 1) / BM;
+    const uint32_t tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+    const uint32_t q0 = tm * BM, c0 = tn * BN;
+    floatx16 acc[ 2 ][ 2 ];
+#pragma unroll
+    for(int i = 0; i < 2; ++i)
+#pragma unroll
+        for(int j = 0; j < 2; ++j)
+#pragma unroll
+            for(int r = 0; r < 16; ++r) acc[ i ][ j ][ r ] = 0.f;
+
+    for(uint32_t k0 = 0; k0 < stride; k0 += BK) {
+        // stage: 128 rows x 32 floats per operand = 1024 float4; 4 per thread
+#pragma unroll
+        for(int it = 0; it < 4; ++it) {
+            const int      f = tid + it * 256;  // float4 index in the tile
+            const int      row = f >> 3, kq = (f & 7) * 4;
+            const uint32_t k = k0 + (uint32_t)kq;
+            float4         a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if(q0 + row < nq && k < stride) a = *(const float4 *)(Q + (size_t)(q0 + row) * stride + k);
+            if(c0 + row < nb && k < stride) b = *(const float4 *)(B + (size_t)(c0 + row) * stride + k);
+            float *pa = As + row * LDK + kq, *pb = Bs + row * LDK + kq;
+            pa[ 0 ] = a.x; pa[ 1 ] = a.y; pa[ 2 ] = a.z; pa[ 3 ] = a.w;
+            pb[ 0 ] = b.x; pb[ 1 ] = b.y; pb[ 2 ] = b.z; pb[ 3 ] = b.w;
+        }
+        __syncthreads();
+        const float *a0 = As + (wm * 64 + (lane & 31)) * LDK + (lane >> 5);
+        const float *b0 = Bs + (wn * 64 + (lane & 31)) * LDK + (lane >> 5);
+#pragma unroll
+        for(int kk = 0; kk < BK; kk += 2) {
+            const float av0 = a0[ kk ], av1 = a0[ 32 * LDK + kk ];
+            const float bv0 = b0[ kk ], bv1 = b0[ 32 * LDK + kk ];
+            acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc[ 0 ][ 0 ], 0, 0, 0);
+            acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv1, acc[ 0 ][ 1 ], 0, 0, 0);
+            acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv0, acc[ 1 ][ 0 ], 0, 0, 0);
+            acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc[ 1 ][ 1 ], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for(int i = 0; i < 2; ++i)
+#pragma unroll
+        for(int j = 0; j < 2; ++j) {
+            const uint32_t c = c0 + wn * 64 + j * 32 + (lane & 31);
+            if(c >= nb) continue;
+            const float nb2 = bn[ c ];
+#pragma unroll
+            for(int r = 0; r < 16; ++r) {
+                const uint32_t q = q0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if(q >= nq) continue;
+                const float dot = acc[ i ][ j ][ r ], nq2 = qn[ q ];
+                float       d;
+                if(METRIC == M_L2SQ) {
+                    d = nq2 + nb2 - 2.f * dot;
+                    d = d < 0.f ? 0.f : d;
+                } else {
+                    if(nq2 == 0.f && nb2 == 0.f) d = 0.f;
+                    else if(nq2 == 0.f || nb2 == 0.f) d = 1.f;
+                    else d = 1.f - dot / (__builtin_sqrtf(nq2) * __builtin_sqrtf(nb2));
+                }
+                out[ (size_t)q * ldo + (c - 0) ] = d;
+            }
+        }
+}
+
+// hamming: 16 queries in LDS per workgroup, one base row per thread
+__global__ void __launch_bounds__(256) k_dense_ham(const uint32_t *Q, uint32_t nq, const uint32_t *B, uint32_t nb, uint32_t stride /* words */,
+                                                   float *out, uint32_t ldo)
+{
+    extern __shared__ uint32_t qs[];  // [16][stride]
+    const uint32_t q0 = blockIdx.y * 16;
+    for(uint32_t i = threadIdx.x; i < 16 * stride; i += blockDim.x) {
+        const uint32_t q = q0 + i / stride;
+        qs[ i ] = q < nq ? Q[ (size_t)q * stride + i % stride ] : 0u;
+    }
+    __syncthreads();
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if(c >= nb) return;
+    uint32_t acc[ 16 ];
+#pragma unroll
+    for(int j = 0; j < 16; ++j) acc[ j ] = 0;
+    const uint32_t *row = B + (size_t)c * stride;
+    for(uint32_t w = 0; w < stride; ++w) {
+        const uint32_t x = row[ w ];
+#pragma unroll
+        for(int j = 0; j < 16; ++j) acc[ j ] += __popc(x ^ qs[ j * stride + w ]);
+    }
+#pragma unroll
+    for(int j = 0; j < 16; ++j)
+        if(q0 + j < nq) out[ (size_t)(q0 + j) * ldo + c ] = (float)acc[ j ];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_select: one workgroup per query.  best[q][0..kk) holds the running candidates as keys
+// (ordered distance << 32 | slot); a chunk of `ncols` distances (columns = slots c_base..) is merged in.
+constexpr int SEL_BUF = 2048;
+
+__device__ void bitonic_sort_lds(uint64_t *a, int n /* power of two */)
+{
+    for(int size = 2; size <= n; size <<= 1)
+        for(int stride = size >> 1; stride > 0; stride >>= 1) {
+            for(int i = threadIdx.x; i < n / 2; i += blockDim.x) {
+                const int lo = (i / stride) * stride * 2 + (i % stride), hi = lo + stride;
+                const bool up = ((lo / size) & 1) == 0;
+                const uint64_t x = a[ lo ], y = a[ hi ];
+                if((x > y) == up) { a[ lo ] = y; a[ hi ] = x; }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ void __launch_bounds__(256) k_select(const float *dist, uint32_t ldo, uint32_t ncols, uint32_t c_base, uint64_t *best, uint32_t kk)
+{
+    __shared__ uint64_t buf[ SEL_BUF ];
+    __shared__ int      cnt;
+    __shared__ uint64_t tau;
+    const uint32_t q = blockIdx.x;
+    const float   *row = dist + (size_t)q * ldo;
+    uint64_t      *mine = best + (size_t)q * kk;
+    for(int i = threadIdx.x; i < SEL_BUF; i += blockDim.x) buf[ i ] = i < (int)kk ? mine[ i ] : ~0ull;
+    if(threadIdx.x == 0) { cnt = (int)kk; tau = mine[ kk - 1 ]; }
+    __syncthreads();
+    for(uint32_t base = 0; base < ncols; base += blockDim.x * 4) {
+        // 4 columns per thread per round; anything below the current k-th best goes to the buffer
+        for(int u = 0; u < 4; ++u) {
+            const uint32_t c = base + u * blockDim.x + threadIdx.x;
+            if(c < ncols) {
+                const uint64_t key = ((uint64_t)f2ord(row[ c ]) << 32) | (uint64_t)(c_base + c);
+                if(key < tau) {
+                    const int p = atomicAdd(&cnt, 1);
+                    if(p < SEL_BUF) buf[ p ] = key;
+                }
+            }
+        }
+        __syncthreads();
+        // at most 1024 new entries per round, so sorting whenever the buffer is more than half full
+        // guarantees the next round fits
+        if(cnt > SEL_BUF / 2 || base + blockDim.x * 4 >= ncols) {
+            bitonic_sort_lds(buf, SEL_BUF);
+            for(int i = (int)kk + threadIdx.x; i < SEL_BUF; i += blockDim.x) buf[ i ] = ~0ull;
+            if(threadIdx.x == 0) { cnt = (int)kk; tau = buf[ kk - 1 ]; }
+            __syncthreads();
+        }
+    }
+    for(int i = threadIdx.x; i < (int)kk; i += blockDim.x) mine[ i ] = buf[ i ];
+}
+
+// k_rerank: exact-order distances of the kk survivors, then the k smallest by (distance, slot)
+template <int METRIC, int G>
+__global__ void __launch_bounds__(256) k_rerank(const uint4 *Q, const uint4 *B, uint32_t chunks, const uint64_t *best, uint32_t kk, uint32_t k,
+                                                uint32_t *out_slots, float *out_dists)
+{
+    __shared__ uint64_t keys[ 256 ];
+    const uint32_t q = blockIdx.x;
+    const int      tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
+    for(int i = tid; i < 256; i += T) keys[ i ] = ~0ull;
+    __syncthreads();
+    for(uint32_t i = g; i < kk; i += NG) {
+        const uint64_t cand = best[ (size_t)q * kk + i ];
+        if(cand == ~0ull) continue;
+        const uint32_t slot = (uint32_t)(cand & 0xFFFFFFFFu);
+        float          d = group_dist<METRIC, G>(Q + (size_t)q * chunks, B + (size_t)slot * chunks, (int)chunks, gl);
+        if(gl == 0) keys[ i ] = ((uint64_t)f2ord(d) << 32) | slot;
+    }
+    __syncthreads();
+    bitonic_sort_lds(keys, 256);
+    for(uint32_t i = tid; i < k; i += T) {
+        const uint64_t key = keys[ i ];
+        out_slots[ (size_t)q * k + i ] = key == ~0ull ? EMPTY : (uint32_t)(key & 0xFFFFFFFFu);
+        out_dists[ (size_t)q * k + i ] = key == ~0ull ? __builtin_inff() : ord2f((uint32_t)(key >> 32));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+hipError_t launch_row_norms(const uint4 *rows, uint32_t n, uint32_t chunks, float *out, hipStream_t stream)
+{
+    if(n == 0) return hipSuccess;
+    const int G_ = group_lanes_for(chunks);
+    uint32_t  blocks = (uint32_t)(((uint64_t)n * G_ + 255) / 256);
+    if(blocks > 16384) blocks = 16384;
+    switch(G_) {
+        case 64: hipLaunchKernelGGL((k_row_norms<64>), dim3(blocks), dim3(256), 0, stream, rows, n, chunks, out); break;
+        case 32: hipLaunchKernelGGL((k_row_norms<32>), dim3(blocks), dim3(256), 0, stream, rows, n, chunks, out); break;
+        case 16: hipLaunchKernelGGL((k_row_norms<16>), dim3(blocks), dim3(256), 0, stream, rows, n, chunks, out); break;
+        default: hipLaunchKernelGGL((k_row_norms<8>), dim3(blocks), dim3(256), 0, stream, rows, n, chunks, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_dense(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t nb, uint32_t chunks, const float *qn,
+                        const float *bn, float *out, uint32_t ldo, hipStream_t stream)
+{
+    if(nq == 0 || nb == 0) return hipSuccess;
+    const uint32_t stride = chunks * 4;
+    if(metric == M_HAMMING) {
+        dim3 grid((nb + 255) / 256, (nq + 15) / 16);
+        hipLaunchKernelGGL(k_dense_ham, grid, dim3(256), 16 * stride * 4, stream, (const uint32_t *)Q, nq, (const uint32_t *)B, nb, stride, out,
+                           ldo);
+        return hipGetLastError();
+    }
+    const uint32_t tiles = ((nq + BM - 1) / BM) * ((nb + BN - 1) / BN);
+    if(metric == M_L2SQ)
+        hipLaunchKernelGGL((k_dense_f32<M_L2SQ>), dim3(tiles), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn, bn,
+                           out, ldo);
+    else
+        hipLaunchKernelGGL((k_dense_f32<M_COS>), dim3(tiles), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn, bn,
+                           out, ldo);
+    return hipGetLastError();
+}
+
+hipError_t launch_select(const float *dist, uint32_t ldo, uint32_t nq, uint32_t ncols, uint32_t c_base, uint64_t *best, uint32_t kk,
+                         hipStream_t stream)
+{
+    if(nq == 0 || ncols == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_select, dim3(nq), dim3(256), 0, stream, dist, ldo, ncols, c_base, best, kk);
+    return hipGetLastError();
+}
+
+hipError_t launch_rerank(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t chunks, const uint64_t *best, uint32_t kk,
+                         uint32_t k, uint32_t *out_slots, float *out_dists, hipStream_t stream)
+{
+    if(nq == 0) return hipSuccess;
+    const int G_ = group_lanes_for(chunks);
+#define RR(MM, GG) hipLaunchKernelGGL((k_rerank<MM, GG>), dim3(nq), dim3(256), 0, stream, Q, B, chunks, best, kk, k, out_slots, out_dists)
+#define RRG(MM) switch(G_) { case 64: RR(MM, 64); break; case 32: RR(MM, 32); break; case 16: RR(MM, 16); break; default: RR(MM, 8); }
+    switch(metric) {
+        case M_L2SQ: RRG(M_L2SQ); break;
+        case M_COS: RRG(M_COS); break;
+        case M_HAMMING: RRG(M_HAMMING); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef RRG
+#undef RR
+    return hipGetLastError();
+}
+
+}  // namespace lgpu

@@ -7,6 +7,7 @@
 #include "index.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -653,24 +654,34 @@ void lantern_gpu_distance_matrix(const void *a, size_t na, const void *b, size_t
     if(ham != (kind == usearch_scalar_b1_k) || (!ham && kind != usearch_scalar_f32_k)) { FAIL(e, "lantern_gpu: scalar kind does not fit the metric"); return; }
     if(!a || !b || !out || dims == 0) { FAIL(e, "lantern_gpu: bad arguments"); return; }
     if(lantern_gpu_device_count() <= 0) { FAIL(e, kNoDevice); return; }
-    if(!exact_order) { FAIL(e, "lantern_gpu: the MFMA contraction path is not built yet"); return; }
     if(na == 0 || nb == 0) return;
     const size_t words = ham ? (dims + 31) / 32 : dims, in_bytes = ham ? (dims + 7) / 8 : dims * 4;
     const size_t chunks = (words + 3) / 4, row = chunks * 16;
     std::vector<char> ha(na * row, 0), hb(nb * row, 0);
     for(size_t i = 0; i < na; ++i) std::memcpy(&ha[ i * row ], (const char *)a + i * in_bytes, in_bytes);
     for(size_t i = 0; i < nb; ++i) std::memcpy(&hb[ i * row ], (const char *)b + i * in_bytes, in_bytes);
-    void *da = nullptr, *db = nullptr, *dout = nullptr;
+    void *da = nullptr, *db = nullptr, *dout = nullptr, *dn = nullptr;
     bool  ok = hipMalloc(&da, na * row) == hipSuccess && hipMalloc(&db, nb * row) == hipSuccess &&
-              hipMalloc(&dout, na * nb * 4) == hipSuccess;
+              hipMalloc(&dout, na * nb * 4) == hipSuccess && hipMalloc(&dn, (na + nb) * 4) == hipSuccess;
     ok = ok && hipMemcpy(da, ha.data(), na * row, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(db, hb.data(), nb * row, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && launch_pairs((int)metric, (const uint4 *)da, (uint32_t)na, (const uint4 *)db, (uint32_t)nb, (uint32_t)chunks,
-                            (float *)dout, nullptr) == hipSuccess;
+    if(exact_order) {
+        ok = ok && launch_pairs((int)metric, (const uint4 *)da, (uint32_t)na, (const uint4 *)db, (uint32_t)nb, (uint32_t)chunks,
+                                (float *)dout, nullptr) == hipSuccess;
+    } else {  // the dense contraction: fp32 MFMA for l2sq / cos
+        float *an = (float *)dn, *bnn = an + na;
+        if(!ham) {
+            ok = ok && launch_row_norms((const uint4 *)da, (uint32_t)na, (uint32_t)chunks, an, nullptr) == hipSuccess;
+            ok = ok && launch_row_norms((const uint4 *)db, (uint32_t)nb, (uint32_t)chunks, bnn, nullptr) == hipSuccess;
+        }
+        ok = ok && launch_dense((int)metric, (const uint4 *)da, (uint32_t)na, (const uint4 *)db, (uint32_t)nb, (uint32_t)chunks, an, bnn,
+                                (float *)dout, (uint32_t)nb, nullptr) == hipSuccess;
+    }
     ok = ok && hipMemcpy(out, dout, na * nb * 4, hipMemcpyDeviceToHost) == hipSuccess;
     if(da) (void)hipFree(da);
     if(db) (void)hipFree(db);
     if(dout) (void)hipFree(dout);
+    if(dn) (void)hipFree(dn);
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in distance_matrix");
 }
 
@@ -707,10 +718,57 @@ void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uin
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in distance_gather");
 }
 
-void lantern_gpu_exact_search(usearch_index_t h, const void *, size_t, size_t, uint32_t *, float *, usearch_error_t *e)
+void lantern_gpu_exact_search(usearch_index_t h, const void *queries, size_t nq, size_t k, uint32_t *slots, float *distances,
+                              usearch_error_t *e)
 {
     CLEAR(e);
-    if(H(h, e)) FAIL(e, "lantern_gpu: exact_search is not built yet");
+    Index *ix = H(h, e);
+    if(!ix || nq == 0 || k == 0) return;
+    if(k > 240) { FAIL(e, "lantern_gpu: exact_search supports k <= 240"); return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    const size_t n = ix->n, row_words = (size_t)ix->chunks * 4;
+    if(n == 0) {
+        for(size_t i = 0; i < nq * k; ++i) { slots[ i ] = EMPTY; distances[ i ] = INFINITY; }
+        return;
+    }
+    const size_t in_bytes = ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4;
+    std::vector<uint32_t> padded(nq * row_words);
+    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, &padded[ i * row_words ]);
+    // kk = k plus a margin: the MFMA distances (|q|^2 + |b|^2 - 2 q.b) differ from the exact-order ones in
+    // the last bits, so the survivors are re-ranked exactly and only then cut to k
+    const uint32_t kk = (uint32_t)k + 16;
+    const size_t   QT = 1024, CH = std::min<size_t>(n, 65536);
+    uint4    *dq = (uint4 *)scratch(ix, 5, nq * row_words * 4);
+    char     *aux = (char *)scratch(ix, 6, nq * 4 + n * 4 + nq * kk * 8 + nq * k * 8 + 64);
+    float    *dd = (float *)scratch(ix, 7, std::min(nq, QT) * CH * 4);
+    if(!dq || !aux || !dd) { FAIL(e, ix->err.c_str()); return; }
+    float    *qn = (float *)aux;
+    float    *bn = qn + nq;
+    uint64_t *best = (uint64_t *)(aux + (nq + n) * 4 + ((nq + n) % 2) * 4);
+    uint32_t *d_slots = (uint32_t *)(best + nq * kk);
+    float    *d_dists = (float *)(d_slots + nq * k);
+    hipStream_t st = ix->stream;
+    bool ok = hipMemcpyAsync(dq, padded.data(), nq * row_words * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipMemsetAsync(best, 0xFF, nq * kk * 8, st) == hipSuccess;
+    if(ix->metric != M_HAMMING) {
+        ok = ok && launch_row_norms(dq, (uint32_t)nq, ix->chunks, qn, st) == hipSuccess;
+        ok = ok && launch_row_norms(ix->d_vec, (uint32_t)n, ix->chunks, bn, st) == hipSuccess;
+    }
+    for(size_t q0 = 0; ok && q0 < nq; q0 += QT) {
+        const size_t nqt = std::min(QT, nq - q0);
+        for(size_t c0 = 0; ok && c0 < n; c0 += CH) {
+            const size_t nc = std::min(CH, n - c0);
+            ok = ok && launch_dense(ix->metric, dq + q0 * ix->chunks, (uint32_t)nqt, ix->d_vec + c0 * ix->chunks, (uint32_t)nc, ix->chunks,
+                                    qn + q0, bn + c0, dd, (uint32_t)CH, st) == hipSuccess;
+            ok = ok && launch_select(dd, (uint32_t)CH, (uint32_t)nqt, (uint32_t)nc, (uint32_t)c0, best + q0 * kk, kk, st) == hipSuccess;
+        }
+    }
+    ok = ok && launch_rerank(ix->metric, dq, (uint32_t)nq, ix->d_vec, ix->chunks, best, kk, (uint32_t)k, d_slots, d_dists, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(slots, d_slots, nq * k * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(distances, d_dists, nq * k * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    if(!ok) FAIL(e, "lantern_gpu: HIP failure in exact_search");
 }
 
 // ---- SQL-callable semantics (hnsw.c:296-405) ---------------------------------------------------------

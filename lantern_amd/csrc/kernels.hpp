@@ -67,6 +67,15 @@ hipError_t launch_gather(int metric, const View &v, const uint4 *query, const ui
 hipError_t launch_pairs(int metric, const uint4 *a, uint32_t na, const uint4 *b, uint32_t nb, uint32_t chunks, float *out,
                         hipStream_t stream);
 
+// dense contraction + exact k-NN building blocks (bruteforce.hip)
+hipError_t launch_row_norms(const uint4 *rows, uint32_t n, uint32_t chunks, float *out, hipStream_t stream);
+hipError_t launch_dense(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t nb, uint32_t chunks, const float *qn,
+                        const float *bn, float *out, uint32_t ldo, hipStream_t stream);
+hipError_t launch_select(const float *dist, uint32_t ldo, uint32_t nq, uint32_t ncols, uint32_t c_base, uint64_t *best, uint32_t kk,
+                         hipStream_t stream);
+hipError_t launch_rerank(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t chunks, const uint64_t *best, uint32_t kk,
+                         uint32_t k, uint32_t *out_slots, float *out_dists, hipStream_t stream);
+
 size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0);
 size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0);
 

@@ -99,27 +99,20 @@ def test_search_matches_oracle_on_same_graph(capi, oracle, metric, n, d, M, efc,
     gpu = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=ef, seed=9)
     gpu.import_graph(base, g)
     o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, k)
-    import torch
+    from lantern_amd import hip
 
-    dq = torch.zeros((64, ((d + 3) // 4) * 4), dtype=torch.float32 if metric != "hamming" else torch.int32, device="cuda")
-    src = torch.from_numpy(queries.view(np.int32) if metric == "hamming" else queries).cuda()
-    dq[:, :d] = src
-    lab = torch.zeros((64, k), dtype=torch.int64, device="cuda")
-    dist = torch.zeros((64, k), dtype=torch.float32, device="cuda")
-    slot = torch.zeros((64, k), dtype=torch.int32, device="cuda")
-    cnt = torch.zeros(64, dtype=torch.int32, device="cuda")
-    D = torch.zeros(64, dtype=torch.int64, device="cuda")
-    E = torch.zeros(64, dtype=torch.int64, device="cuda")
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, metric == "hamming"))
+    lab, dist, slot = hip.Buffer(64 * k * 8), hip.Buffer(64 * k * 4), hip.Buffer(64 * k * 4)
+    cnt, D, E = hip.Buffer(64 * 4), hip.Buffer(64 * 8), hip.Buffer(64 * 8)
     for waves in (1, 4, 8):
         gpu.set_search_shape(waves)
-        gpu.search_batch_device(dq.data_ptr(), 64, k, 0, 0, lab.data_ptr(), dist.data_ptr(), slot.data_ptr(), cnt.data_ptr(),
-                                D.data_ptr(), E.data_ptr())
-        torch.cuda.synchronize()
-        assert np.array_equal(slot.cpu().numpy().view(np.uint32), o_slot), f"top-k slots differ (waves={waves})"
-        assert np.array_equal(lab.cpu().numpy().view(np.uint64), o_lab)
-        assert np.array_equal(dist.cpu().numpy(), o_dist)
-        assert np.array_equal(D.cpu().numpy().view(np.uint64), o_D), "distance-evaluation counts differ"
-        assert np.array_equal(E.cpu().numpy().view(np.uint64), o_E), "expansion counts differ"
+        gpu.search_batch_device(dq.ptr, 64, k, 0, 0, lab.ptr, dist.ptr, slot.ptr, cnt.ptr, D.ptr, E.ptr)
+        hip.synchronize()
+        assert np.array_equal(slot.download((64, k), np.uint32), o_slot), f"top-k slots differ (waves={waves})"
+        assert np.array_equal(lab.download((64, k), np.uint64), o_lab)
+        assert np.array_equal(dist.download((64, k), np.float32), o_dist)
+        assert np.array_equal(D.download(64, np.uint64), o_D), "distance-evaluation counts differ"
+        assert np.array_equal(E.download(64, np.uint64), o_E), "expansion counts differ"
     # host-buffer entry points agree with the device-buffer one
     h_lab, h_dist, h_cnt = gpu.search_batch(queries, k)
     assert np.array_equal(h_lab, o_lab) and np.array_equal(h_dist, o_dist)
@@ -269,3 +262,34 @@ def test_file_round_trip(capi, oracle, tmp_path):
         assert np.array_equal(third.search(q, 5)[0], ix.search(q, 5)[0])
         # first node tape: label, level
         assert int.from_bytes(blob[136:144], "little") == 1 and int.from_bytes(blob[144:146], "little") == int(g["levels"][0])
+
+
+# ------------------------------------------------------------------------------------------------
+# the dense contraction (fp32 MFMA) and the exact k-NN built on it
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric,n,d", [("l2sq", 5000, 96), ("cos", 3000, 768), ("l2sq", 70000, 20), ("hamming", 4000, 24),
+                                        ("cos", 300, 130)])
+def test_exact_search_matches_bruteforce(capi, oracle, metric, n, d):
+    rng = np.random.default_rng(n + d)
+    base, queries = rand_rows(rng, n, d, metric), rand_rows(rng, 70, d, metric)
+    ix = capi.GpuIndex(metric, d, M=4, ef_construction=8, seed=1)
+    g = {"levels": np.zeros(n, np.uint8), "nbr0": np.full((n, 8), 0xFFFFFFFF, np.uint32), "upper_off": np.full(n, 0xFFFFFFFF, np.uint32),
+         "upper_nbr": np.zeros((0, 4), np.uint32), "labels": None, "entry_slot": 0, "max_level": 0}
+    ix.import_graph(base, g)  # vectors only: exact search never touches the graph
+    slots, dists = ix.exact_search(queries, 10)
+    t_ids, t_d = oracle.bruteforce(base, queries, 10, metric, oracle.SUM_WAVE64, 8)
+    assert np.array_equal(slots, t_ids)
+    assert np.array_equal(dists, t_d)
+
+
+@pytest.mark.parametrize("metric,d", [("l2sq", 768), ("cos", 768), ("l2sq", 50), ("cos", 1536)])
+def test_mfma_distance_matrix_within_tolerance(capi, oracle, metric, d):
+    rng = np.random.default_rng(d)
+    A, B = rng.standard_normal((130, d), dtype=np.float32), rng.standard_normal((257, d), dtype=np.float32)
+    A[3] = 0  # zero-norm rows exercise the cosine rules in the epilogue
+    B[5] = 0
+    got = capi.distance_matrix(A, B, metric, exact_order=False)
+    ref = capi.distance_matrix(A, B, metric, exact_order=True)
+    assert np.all(np.abs(got - ref) <= TOL * np.maximum(1.0, np.abs(ref)))
+    if metric == "cos":
+        assert got[3, 5] == 0.0 and got[3, 0] == 1.0 and got[0, 5] == 1.0
