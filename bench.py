@@ -129,9 +129,9 @@ def main():
     if world > 1:
         import torch
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from lantern_amd import sharded
+
+        elapsed = sharded.max_over_ranks(elapsed, device=torch.device("cuda", local_rank))
 
     # ---- algorithmic bytes of one launch --------------------------------------------
     D = d_D.download(nq, np.uint64).astype(np.float64)
