@@ -201,11 +201,29 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores() -> int:
+    """Threads this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(a, ix, base, queries, gpu_found):
     """The oracle (CPU port of the usearch path) on the identical graph, on this host's cores."""
     from oracle import binding as oracle
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     g = ix.export_graph()
     ora = oracle.OracleIndex.from_graph(a.metric, base, g, a.M, a.efc, a.ef, 42, oracle.SUM_FAST)
     # size the samples from a short probe so the whole leg stays near the budget (about 30 % of it
@@ -220,7 +238,12 @@ def cpu_baseline(a, ix, base, queries, gpu_found):
     t0 = time.perf_counter()
     ora.search_batch(queries[:n1], a.k, a.ef, 1)
     qps_1t = n1 / (time.perf_counter() - t0)
-    want = int((a.cpu_seconds * 0.7) * qps_1t * cores * 0.35)  # assume ~35 % parallel efficiency (memory-bound)
+    # a short all-cores probe sizes the timed all-cores sample (parallel efficiency is host-dependent)
+    pq = np.ascontiguousarray(np.tile(queries, (max(1, (cores * 32) // queries.shape[0] + 1), 1))[: cores * 32])
+    t0 = time.perf_counter()
+    ora.search_batch(pq, a.k, a.ef, cores)
+    qps_probe = pq.shape[0] / (time.perf_counter() - t0)
+    want = int(a.cpu_seconds * 0.6 * qps_probe)
     reps = int(max(1, min(64, -(-want // queries.shape[0]))))
     tiled = np.ascontiguousarray(np.tile(queries, (reps, 1)))
     nall = tiled.shape[0]

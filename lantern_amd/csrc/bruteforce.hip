@@ -35,9 +35,8 @@ __global__ void __launch_bounds__(256) k_row_norms(const uint4 *rows, uint32_t n
             s = __builtin_fmaf(__uint_as_float(x.z), __uint_as_float(x.z), s);
             s = __builtin_fmaf(__uint_as_float(x.w), __uint_as_float(x.w), s);
         }
-#pragma unroll
-        for(int off = G / 2; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
-        if(gl == 0) out[ i ] = s;
+        s = group_sum<G>(s);
+        if(gl == G - 1) out[ i ] = s;
     }
 }
 
@@ -220,7 +219,7 @@ __global__ void __launch_bounds__(256) k_rerank(const uint4 *Q, const uint4 *B, 
         if(cand == ~0ull) continue;
         const uint32_t slot = (uint32_t)(cand & 0xFFFFFFFFu);
         float          d = group_dist<METRIC, G>(Q + (size_t)q * chunks, B + (size_t)slot * chunks, (int)chunks, gl);
-        if(gl == 0) keys[ i ] = ((uint64_t)f2ord(d) << 32) | slot;
+        if(gl == G - 1) keys[ i ] = ((uint64_t)f2ord(d) << 32) | slot;
     }
     __syncthreads();
     bitonic_sort_lds(keys, 256);

@@ -3,9 +3,12 @@
 // Numerics contract: a row of d f32 scalars is zero-padded to whole
 // 16-byte chunks; G lanes (8/16/32/64, chosen from the chunk count) cooperate on one row; lane l
 // owns chunks l, l+G, l+2G... and runs ONE fmaf chain per accumulator over its scalars in memory
-// order; the G partials are combined by an xor butterfly (off = G/2 .. 1).  The oracle models
-// exactly this tree (oracle/metrics.c, LO_SUM_WAVE64), so device results are compared
-// bit-for-bit.  Built with -ffp-contract=off: every fma below is explicit.
+// order; the G partials are combined by a butterfly with offsets 1, 2, 4 .. G/2 (each step adds the
+// partner's running sum), executed as DPP adds (quad_perm, row_half_mirror, row_mirror, row_bcast15,
+// row_bcast31) -- one VALU op per step instead of a ds_bpermute round trip.  The complete sum is
+// guaranteed in the LAST lane of the group (lane G-1).  The oracle models exactly this tree
+// (oracle/metrics.c, LO_SUM_WAVE64), so device results are compared bit-for-bit.  Built with
+// -ffp-contract=off: every fma below is explicit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,6 +43,30 @@ __device__ __forceinline__ bool     key_expanded(uint64_t k) { return (k & 1u) !
 // per-centre pseudo-random tie order used by the neighbour-selection heuristic (oracle/hnsw.c tie_mix)
 __device__ __forceinline__ uint32_t tie_mix(uint32_t id, uint32_t centre) { return (id ^ (centre * 0x9E3779B1u)) * 0x85EBCA6Bu; }
 
+// ---- G-lane sum in DPP adds -------------------------------------------------------------------------
+// Step k adds the running sum of the lane 2^k away (butterfly, offsets ascending).  After the quad
+// steps every lane of a quad holds the quad's sum, so row_half_mirror / row_mirror deliver the same
+// values an xor-4 / xor-8 exchange would; row_bcast15 / row_bcast31 then carry a row's (half-wave's)
+// sum into the next one.  Only lane G-1 is guaranteed to hold the full sum.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_take(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_take(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int G, typename T> __device__ __forceinline__ T group_sum(T s)
+{
+    s = s + dpp_take<0xB1, 0xF>(s);                  // quad_perm [1,0,3,2]  : offset 1
+    s = s + dpp_take<0x4E, 0xF>(s);                  // quad_perm [2,3,0,1]  : offset 2
+    if(G >= 8) s = s + dpp_take<0x141, 0xF>(s);      // row_half_mirror      : offset 4
+    if(G >= 16) s = s + dpp_take<0x140, 0xF>(s);     // row_mirror           : offset 8
+    if(G >= 32) s = s + dpp_take<0x142, 0xA>(s);     // row_bcast15 -> rows 1,3 : offset 16
+    if(G >= 64) s = s + dpp_take<0x143, 0xC>(s);     // row_bcast31 -> rows 2,3 : offset 32
+    return s;
+}
+
 // ---- per-lane accumulation ----------------------------------------------------------------------
 template <int METRIC> struct Acc;
 
@@ -56,9 +83,7 @@ template <> struct Acc<M_L2SQ>
     }
     template <int G> __device__ __forceinline__ float finish()
     {
-#pragma unroll
-        for(int off = G / 2; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
-        return s;
+        return group_sum<G>(s);
     }
 };
 
@@ -80,12 +105,9 @@ template <> struct Acc<M_COS>
     }
     template <int G> __device__ __forceinline__ float finish()
     {
-#pragma unroll
-        for(int off = G / 2; off >= 1; off >>= 1) {
-            ab = ab + __shfl_xor(ab, off, 64);
-            a2 = a2 + __shfl_xor(a2, off, 64);
-            b2 = b2 + __shfl_xor(b2, off, 64);
-        }
+        ab = group_sum<G>(ab);
+        a2 = group_sum<G>(a2);
+        b2 = group_sum<G>(b2);
         // zero-norm rules pinned by the reference's tests (hnsw_vector.out:205-210,
         // hnsw_dist_func.out:58-61): both zero -> 0, one zero -> 1
         if(a2 == 0.f && b2 == 0.f) return 0.f;
@@ -103,14 +125,12 @@ template <> struct Acc<M_HAMMING>
     }
     template <int G> __device__ __forceinline__ float finish()
     {
-#pragma unroll
-        for(int off = G / 2; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
-        return (float)s;
+        return (float)group_sum<G>(s);
     }
 };
 
 // One distance by one G-lane group: a and b each `chunks` uint4 long; gl = lane index in group.
-// Every lane of the group returns the same value.
+// The value is complete in the LAST lane of the group (gl == G-1); other lanes hold partial sums.
 template <int METRIC, int G, typename PA, typename PB>
 __device__ __forceinline__ float group_dist(PA a, PB b, int chunks, int gl)
 {

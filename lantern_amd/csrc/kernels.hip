@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_revlink(RevlinkArgs a)
         if(!have_d) {  // distances of the original entries to `close`, once
             for(int i = g; i < c0; i += NG) {
                 float d = group_dist<METRIC, G>(row_of(a.view, close), row_of(a.view, r.cid[ i ]), (int)a.view.chunks, gl);
-                if(gl == 0) r.cd[ i ] = d;
+                if(gl == G - 1) r.cd[ i ] = d;
             }
             pairs += (uint32_t)c0;
             have_d = true;
@@ -184,6 +184,162 @@ __global__ void __launch_bounds__(256) k_revlink(RevlinkArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_revlink_staged: the same reverse-link step with the candidate rows staged in LDS.
+//
+// Re-pruning a full list evaluates up to cap*(cap+1)/2 candidate-candidate distances over only cap+2
+// distinct rows (33 list entries + the new node + `close` at M=16).  k_revlink re-reads both rows of
+// every pair from L2 (measured: the build's dominant cost, L2-bandwidth bound).  Here the rows are
+// loaded ONCE with coalesced 16-byte loads into LDS (34 x 3 KiB = 102 KiB at d=768), all pair
+// distances are evaluated from LDS in one parallel phase, and the heuristic itself runs on the small
+// distance matrix.  The metrics are bitwise symmetric and the pair set is a superset of what the
+// sequential heuristic evaluates, so the result is identical to k_revlink / the oracle.
+struct StagedLds
+{
+    uint4    *rows;   // [(cap + 2)][chunks]
+    float    *cd;     // [cap + 1] distance to `close`, candidate order
+    uint32_t *cid;    // [cap + 1]
+    float    *sd;     // sorted
+    uint32_t *sid;
+    uint16_t *sidx;   // sorted position -> candidate (= staged row) index
+    float    *pair;   // [(cap + 1)][(cap + 1)] by sorted positions, i > j
+    int      *scal;
+};
+__host__ __device__ inline size_t staged_lds_bytes(uint32_t chunks, uint32_t cap)
+{
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t n = cap + 1;
+    return (size_t)(cap + 2) * chunks * 16 + 4 * up16(n * 4) + up16(n * 2) + up16(n * n * 4) + S_SCALARS * 4;
+}
+
+template <int METRIC, int G>
+__global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a)
+{
+    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
+    const uint32_t gi = blockIdx.x;
+    const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+    const uint32_t close = a.reqs[ begin ].close;
+    const int      level = (int)a.reqs[ begin ].level;
+    uint32_t       cap;
+    uint32_t      *list = neighbors_of(a.view, close, level, cap);
+    const int      chunks = (int)a.view.chunks;
+    StagedLds s;
+    {
+        auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+        unsigned char *p = lgpu_smem;
+        const size_t   n = cap + 1;
+        s.rows = (uint4 *)p;     p += (size_t)(cap + 2) * chunks * 16;
+        s.cd = (float *)p;       p += up16(n * 4);
+        s.cid = (uint32_t *)p;   p += up16(n * 4);
+        s.sd = (float *)p;       p += up16(n * 4);
+        s.sid = (uint32_t *)p;   p += up16(n * 4);
+        s.sidx = (uint16_t *)p;  p += up16(n * 2);
+        s.pair = (float *)p;     p += up16(n * n * 4);
+        s.scal = (int *)p;
+    }
+    if(tid == 0) s.scal[ S_CNT ] = 0;
+    __syncthreads();
+    for(uint32_t i = tid; i < cap; i += T) {
+        const uint32_t nb = list[ i ];
+        s.cid[ i ] = nb;
+        if(nb != EMPTY) atomicMax(&s.scal[ S_CNT ], (int)i + 1);
+    }
+    __syncthreads();
+    int       c = s.scal[ S_CNT ];
+    const int c0 = c;
+    bool      have_d = false;
+    uint32_t  pairs = 0;
+    for(uint32_t t = begin; t < end; ++t) {
+        const uint32_t vnew = a.reqs[ t ].new_slot;
+        const float    dv = a.reqs[ t ].d;
+        if(c < (int)cap) {
+            if(tid == 0) { s.cid[ c ] = vnew; s.cd[ c ] = dv; list[ c ] = vnew; }
+            c++;
+            __syncthreads();
+            continue;
+        }
+        // ---- stage the c current entries, the new node (row c) and `close` (row c + 1)
+        if(tid == 0) { s.cid[ c ] = vnew; s.cd[ c ] = dv; }
+        __syncthreads();
+        const int n = c + 1;
+        for(int idx = tid; idx < (n + 1) * chunks; idx += T) {
+            const int      r = idx / chunks, ch = idx - r * chunks;
+            const uint32_t slot = r < n ? s.cid[ r ] : close;
+            s.rows[ idx ] = row_of(a.view, slot)[ ch ];
+        }
+        __syncthreads();
+        if(!have_d) {  // distances of the original entries to `close`, once (a = close, b = entry)
+            for(int i = g; i < c0; i += NG) {
+                float d = group_dist<METRIC, G>(s.rows + (size_t)n * chunks, s.rows + (size_t)i * chunks, chunks, gl);
+                if(gl == G - 1) s.cd[ i ] = d;
+            }
+            pairs += (uint32_t)c0;
+            have_d = true;
+            __syncthreads();
+        }
+        // ---- sort by (distance to close, tie_mix(slot, close))
+        for(int x = tid; x < n; x += T) {
+            const uint64_t k = ((uint64_t)f2ord(s.cd[ x ]) << 32) | tie_mix(s.cid[ x ], close);
+            int            rank = 0;
+            for(int j = 0; j < n; ++j) rank += (((uint64_t)f2ord(s.cd[ j ]) << 32) | tie_mix(s.cid[ j ], close)) < k;
+            s.sd[ rank ] = s.cd[ x ];
+            s.sid[ rank ] = s.cid[ x ];
+            s.sidx[ rank ] = (uint16_t)x;
+        }
+        __syncthreads();
+        // ---- all candidate-candidate distances (sorted positions i > j), from LDS
+        {
+            const int total = n * (n - 1) / 2;
+            int       i = 1, j = g;
+            while(j >= i) { j -= i; ++i; }
+            for(int p = g; p < total; p += NG) {
+                float d = group_dist<METRIC, G>(s.rows + (size_t)s.sidx[ i ] * chunks, s.rows + (size_t)s.sidx[ j ] * chunks, chunks, gl);
+                if(gl == G - 1) s.pair[ i * n + j ] = d;
+                j += NG;
+                while(j >= i) { j -= i; ++i; }
+            }
+            pairs += (uint32_t)total;
+        }
+        __syncthreads();
+        // ---- the heuristic on the distance matrix: wave 0, one lane per already-kept entry
+        // (lane x holds the sorted positions of kept entries x, x+64, x+128, x+192; cap <= 256)
+        if(tid < 64) {
+            const int lane = tid;
+            int       kpos[ 4 ] = { 0, 0, 0, 0 };  // kept[0] = sorted position 0
+            int       submitted = 1, consumed = 1;
+            while(submitted < (int)cap && consumed < n) {
+                const float cdist = s.sd[ consumed ];
+                bool        bad = false;
+#pragma unroll
+                for(int j = 0; j < 4; ++j) {
+                    const int x = lane + 64 * j;
+                    if(x < submitted) bad |= s.pair[ consumed * n + kpos[ j ] ] < cdist;
+                }
+                if(!__any(bad)) {
+                    if((submitted & 63) == lane) {
+#pragma unroll
+                        for(int j = 0; j < 4; ++j)
+                            if((submitted >> 6) == j) kpos[ j ] = consumed;
+                    }
+                    submitted++;
+                }
+                consumed++;
+            }
+#pragma unroll
+            for(int j = 0; j < 4; ++j) {
+                const int x = lane + 64 * j;
+                if(x < submitted) { s.cd[ x ] = s.sd[ kpos[ j ] ]; s.cid[ x ] = s.sid[ kpos[ j ] ]; }
+            }
+            if(lane == 0) s.scal[ S_CNT ] = submitted;
+        }
+        __syncthreads();
+        c = s.scal[ S_CNT ];
+        for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? s.cid[ i ] : EMPTY;
+        __syncthreads();
+    }
+    if(tid == 0 && a.totals) atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs);
+}
+
+// ---------------------------------------------------------------------------------------------------
 template <int METRIC, int G>
 __global__ void __launch_bounds__(256) k_gather(View v, const uint4 *query, const uint32_t *slots, uint32_t n, float *out)
 {
@@ -191,7 +347,7 @@ __global__ void __launch_bounds__(256) k_gather(View v, const uint4 *query, cons
     const uint32_t ngroups = gridDim.x * blockDim.x / G;
     for(uint32_t i = gid; i < n; i += ngroups) {
         float d = group_dist<METRIC, G>(query, row_of(v, slots[ i ]), (int)v.chunks, (int)gl);
-        if(gl == 0) out[ i ] = d;
+        if(gl == G - 1) out[ i ] = d;
     }
 }
 
@@ -204,7 +360,7 @@ __global__ void __launch_bounds__(256) k_pairs(const uint4 *a, uint32_t na, cons
     for(uint64_t p = gid; p < total; p += ngroups) {
         const uint32_t i = (uint32_t)(p / nb), j = (uint32_t)(p % nb);
         float d = group_dist<METRIC, G>(a + (size_t)i * chunks, b + (size_t)j * chunks, (int)chunks, (int)gl);
-        if(gl == 0) out[ p ] = d;
+        if(gl == G - 1) out[ p ] = d;
     }
 }
 
@@ -262,6 +418,18 @@ hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, h
 hipError_t launch_revlink(int metric, const RevlinkArgs &a, hipStream_t stream)
 {
     if(a.ngroups == 0) return hipSuccess;
+    // staged variant whenever the 2M+2 rows of a level-0 re-prune fit in LDS (d <= 1024 at M = 16)
+    const size_t staged = staged_lds_bytes(a.view.chunks, a.view.M0);
+    if(staged <= 150 * 1024 && a.view.M0 <= 256) {
+#define CALL(MM, GG)                                                                                                    \
+    {                                                                                                                   \
+        (void)hipFuncSetAttribute((const void *)k_revlink_staged<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged); \
+        hipLaunchKernelGGL((k_revlink_staged<MM, GG>), dim3(a.ngroups), dim3(512), staged, stream, a);                  \
+    }
+        LGPU_DISPATCH(metric, a.view.chunks, CALL);
+#undef CALL
+        return hipGetLastError();
+    }
     const size_t lds = refine_lds_bytes(a.view.M0 + 1) + S_SCALARS * 4;
 #define CALL(MM, GG) hipLaunchKernelGGL((k_revlink<MM, GG>), dim3(a.ngroups), dim3(256), lds, stream, a)
     LGPU_DISPATCH(metric, a.view.chunks, CALL);

@@ -72,7 +72,7 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
     float *newd = (float *)s.newkeys;  // reuse: one f32 per neighbour
     if(g == 0) {
         float d = group_dist<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl);
-        if(gl == 0) { s.scal[ S_CUR ] = (int)start; s.scal[ S_CURD ] = __float_as_int(d); }
+        if(gl == G - 1) { s.scal[ S_CUR ] = (int)start; s.scal[ S_CURD ] = __float_as_int(d); }
     }
     D += 1;
     __syncthreads();
@@ -93,7 +93,7 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
             const int nn = s.scal[ S_NNEW ];
             for(int i = g; i < nn; i += NG) {
                 float d = group_dist<METRIC, G>(s.q, row_of(v, s.newids[ i ]), (int)v.chunks, gl);
-                if(gl == 0) newd[ i ] = d;
+                if(gl == G - 1) newd[ i ] = d;
             }
             D += (uint32_t)nn;
             __syncthreads();
@@ -132,7 +132,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
     }
     if(g == 0) {
         float d = group_dist<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl);
-        if(gl == 0) s.keys[ 0 ] = make_key(d, start);
+        if(gl == G - 1) s.keys[ 0 ] = make_key(d, start);
     }
     D += 1;
     __syncthreads();
@@ -180,7 +180,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
             const uint32_t id1 = j < nnew ? s.newids[ j ] : id0;
             float          d0, d1;
             group_dist2<METRIC, G>(s.q, row_of(v, id0), row_of(v, id1), (int)v.chunks, gl, d0, d1);
-            if(gl == 0) {
+            if(gl == G - 1) {
                 uint64_t k0 = make_key(d0, id0);
                 s.newkeys[ i ] = k0;
                 bool any = k0 < worst;
@@ -271,7 +271,7 @@ __device__ int refine(const View &v, RefineLds &r, int *scal, int n, int needed,
         const float    cdist = r.sd[ consumed ];
         for(int i = g; i < submitted; i += NG) {
             float inter = group_dist<METRIC, G>(row_of(v, cid), row_of(v, r.sid[ i ]), (int)v.chunks, gl);
-            if(gl == 0 && inter < cdist) scal[ S_BAD ] = 1;
+            if(gl == G - 1 && inter < cdist) scal[ S_BAD ] = 1;
         }
         Dr += (uint32_t)submitted;
         __syncthreads();

@@ -61,7 +61,9 @@ static float hamming_bits(const uint8_t *a, const uint8_t *b, size_t bits)
  * A row of d f32 scalars is zero-padded to d4 = 4*ceil(d/4).  G lanes cooperate
  * (G = lo_wave_group_lanes(d)).  Lane l owns the float4 chunks l, l+G, l+2G, ... and runs
  * one fmaf chain per accumulator over its scalars in memory order.  The G partials are then
- * combined by an xor butterfly: for off = G/2 .. 1: p[l] = p[l] + p[l ^ off].
+ * combined by a butterfly with ascending offsets: for off = 1, 2, .. G/2: p[l] = p[l] + p[l ^ off]
+ * (the device executes it as DPP adds and reads the sum from lane G-1; every lane of a true xor
+ * butterfly holds the same bits, so p[0] below is that value).
  */
 int lo_wave_group_lanes(size_t dims)
 {
@@ -75,7 +77,7 @@ int lo_wave_group_lanes(size_t dims)
 static void butterfly(float *p, int G)
 {
     float t[ 64 ];
-    for(int off = G / 2; off >= 1; off >>= 1) {
+    for(int off = 1; off < G; off <<= 1) {
         for(int l = 0; l < G; ++l) t[ l ] = p[ l ] + p[ l ^ off ];
         memcpy(p, t, sizeof(float) * (size_t)G);
     }
