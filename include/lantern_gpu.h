@@ -236,6 +236,24 @@ LANTERN_GPU_EXPORT bool lantern_scan_gettuple(lantern_scan_t *, usearch_label_t 
 LANTERN_GPU_EXPORT void lantern_scan_end(lantern_scan_t *);
 
 /* ------------------------------------------------------------------------------------------ */
+/* External indexing server (boundary B3): drop-in for `lantern-cli start-indexing-server`        */
+/* (lantern_cli/src/external_index/server.rs:176-435,526-584); PostgreSQL side untouched           */
+/* (lantern_hnsw/src/hnsw/external_index_socket.c:322-536).                                        */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct lantern_index_server lantern_index_server_t;
+/* Bind host:port (port 0 = ephemeral; default of the reference is 0.0.0.0:8998, cli.rs:126-151), start the
+ * accept thread.  status_port: HTTP status endpoint {"status":0..3} (server.rs:586-597), -1 = none.
+ * One connection is served at a time, as in the reference.  TLS is not offered. */
+LANTERN_GPU_EXPORT lantern_index_server_t *lantern_index_server_start(const char *host, int port, int status_port,
+                                                                      const char *tmp_dir, usearch_error_t *);
+LANTERN_GPU_EXPORT int      lantern_index_server_port(lantern_index_server_t *);
+LANTERN_GPU_EXPORT int      lantern_index_server_status_port(lantern_index_server_t *);
+/* 0 idle, 1 in progress, 2 failed, 3 succeeded (server.rs:44-49) */
+LANTERN_GPU_EXPORT int      lantern_index_server_status(lantern_index_server_t *);
+LANTERN_GPU_EXPORT uint64_t lantern_index_server_served(lantern_index_server_t *);
+LANTERN_GPU_EXPORT void     lantern_index_server_stop(lantern_index_server_t *);
+
+/* ------------------------------------------------------------------------------------------ */
 /* SQL-callable distance functions' semantics (hnsw.c:296-405): dimension checks + messages     */
 /* ------------------------------------------------------------------------------------------ */
 /* l2sq_dist(real[], real[]) -> float4; error text hnsw.c:301-303 */

@@ -18,7 +18,7 @@ OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "liblantern_gpu.so")
 
-SOURCES = ["kernels.hip", "bruteforce.hip", "index.cpp", "usearch_file.cpp", "scan_shim.cpp"]
+SOURCES = ["kernels.hip", "bruteforce.hip", "index.cpp", "usearch_file.cpp", "scan_shim.cpp", "index_server.cpp"]
 HEADERS = ["device_common.hpp", "walk.hpp", "kernels.hpp", "index.hpp", "host_util.hpp", "../../include/lantern_gpu.h"]
 # -ffp-contract=off: every fma in the kernels is explicit, so the reduction tree is exactly the
 # one the oracle models.
@@ -59,7 +59,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, srcs))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    # the standalone server binary: `lantern_amd/lib/lantern-index-server --host H --port P --tmp-dir D`
+    tool_src = os.path.join(HERE, "tools", "lantern_index_server.cpp")
+    tool = os.path.join(OUT_DIR, "lantern-index-server")
+    if os.path.exists(tool_src) and (force or _stale(tool, [tool_src, LIB])):
+        cmd = [hipcc, "-O2", "-std=c++17", tool_src, "-o", tool, "-L" + OUT_DIR, "-llantern_gpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -82,7 +82,9 @@ EXPORTS = [
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
     "lantern_gpu_distance_matrix", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_counters_get", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
-    "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist",
+    "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist", "lantern_index_server_start",
+    "lantern_index_server_port", "lantern_index_server_status_port", "lantern_index_server_status",
+    "lantern_index_server_served", "lantern_index_server_stop",
 ]
 
 _lib = None
@@ -146,6 +148,12 @@ def lib() -> C.CDLL:
         "lantern_l2sq_dist": (f32, [vp, i32, vp, i32, err]),
         "lantern_cos_dist": (f32, [vp, i32, vp, i32, err]),
         "lantern_hamming_dist": (C.c_int32, [vp, i32, vp, i32, err]),
+        "lantern_index_server_start": (vp, [C.c_char_p, i32, i32, C.c_char_p, err]),
+        "lantern_index_server_port": (i32, [vp]),
+        "lantern_index_server_status_port": (i32, [vp]),
+        "lantern_index_server_status": (i32, [vp]),
+        "lantern_index_server_served": (u64, [vp]),
+        "lantern_index_server_stop": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what the header declares
@@ -422,5 +430,34 @@ class Scan:
     def __del__(self):
         try:
             self.end()
+        except Exception:
+            pass
+
+
+class IndexServer:
+    """lantern_index_server_*: the external indexing server (B3) on 127.0.0.1 by default."""
+
+    def __init__(self, host="127.0.0.1", port=0, status_port=0, tmp_dir="/tmp"):
+        self.s = _call("lantern_index_server_start", host.encode(), port, status_port, tmp_dir.encode())
+        self.host = host
+        self.port = int(lib().lantern_index_server_port(self.s))
+        self.status_port = int(lib().lantern_index_server_status_port(self.s))
+
+    @property
+    def status(self):
+        return int(lib().lantern_index_server_status(self.s))
+
+    @property
+    def served(self):
+        return int(lib().lantern_index_server_served(self.s))
+
+    def stop(self):
+        if self.s:
+            lib().lantern_index_server_stop(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.stop()
         except Exception:
             pass

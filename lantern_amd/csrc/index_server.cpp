@@ -1,0 +1,288 @@
+// index_server.cpp -- the external indexing server (boundary B3): a drop-in for
+// `lantern-cli start-indexing-server` (lantern_cli/src/external_index/server.rs) whose worker pool is
+// replaced by the device builder.  PostgreSQL connects to it from `CREATE INDEX ... WITH (external=true)`
+// (lantern_hnsw/src/hnsw/external_index_socket.c:322-536) and is not changed at all.
+//
+// Wire protocol, little-endian only (external_index_socket.c:337-339):
+//   server -> u32 PROTOCOL_VERSION (1), u32 SERVER_TYPE (1 = indexing server)          server.rs:183-184
+//   client -> u32 INIT_MSG 0x13333337 + external_index_params_t (11 x u32)             external_index_socket.h:24-38
+//   [pq: codebook frames + END_MSG -- refused here, PQ is out of scope]
+//   server -> u8 0                                                                      server.rs:206
+//   client -> rows [u64 label][dim * element_bits/8 bytes | ceil(dim/8) bytes if bits<8] server.rs:226-230, :169-174
+//   client -> u32 END_MSG 0x31333337
+//   server -> u64 rows added, u64 index file size, usearch-format file bytes            server.rs:388-422
+//   on any error: u32 ERR_MSG 0x37333337, u32 length, message                           server.rs:561-573
+// One connection is served at a time, as in the reference (server.rs:537-583).
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/lantern_gpu.h"
+
+namespace {
+
+constexpr uint32_t PROTOCOL_VERSION = 1, SERVER_TYPE = 1;
+constexpr uint32_t INIT_MSG = 0x13333337u, END_MSG = 0x31333337u, ERR_MSG = 0x37333337u;
+constexpr size_t   INDEX_HEADER_LENGTH = 4 * 12;  // magic + 11 params (server.rs:33-35)
+constexpr int      SOCKET_TIMEOUT_S = 10;         // server.rs:26, external_index_socket.h:17
+constexpr size_t   ADD_CHUNK = 8192;              // rows handed to the device builder at a time
+
+struct Fail { std::string msg; };
+
+enum Status { IDLE = 0, IN_PROGRESS = 1, FAILED = 2, SUCCEEDED = 3 };  // server.rs:44-49
+
+}  // namespace
+
+struct lantern_index_server
+{
+    int                 listen_fd = -1, status_fd = -1;
+    int                 port = 0, status_port = 0;
+    std::atomic<bool>   stop{ false };
+    std::atomic<int>    status{ IDLE };
+    std::atomic<long long> status_updated_at{ 0 };
+    std::atomic<uint64_t>  served{ 0 };
+    std::thread         accept_thread, status_thread;
+    std::string         tmp_dir;
+};
+
+namespace {
+
+long long now_ms() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count(); }
+void set_status(lantern_index_server *s, int st) { s->status = st; s->status_updated_at = now_ms(); }
+
+void write_all(int fd, const void *buf, size_t n)
+{
+    const char *p = (const char *)buf;
+    while(n) {
+        ssize_t w = ::send(fd, p, n, MSG_NOSIGNAL);
+        if(w <= 0) throw Fail{ "socket write failed" };
+        p += w;
+        n -= (size_t)w;
+    }
+}
+void read_exact(int fd, void *buf, size_t n)
+{
+    char *p = (char *)buf;
+    while(n) {
+        ssize_t r = ::recv(fd, p, n, 0);
+        if(r <= 0) throw Fail{ "failed to fill whole buffer" };
+        p += r;
+        n -= (size_t)r;
+    }
+}
+
+enum Frame { FRAME_INIT, FRAME_DATA, FRAME_EXIT };
+
+// read_frame (server.rs:275-309): one read, then fill up to expected_size
+Frame read_frame(int fd, std::vector<uint8_t> &buf, size_t expected_size, bool want_init)
+{
+    buf.assign(expected_size, 0);
+    ssize_t got = ::recv(fd, buf.data(), expected_size, 0);
+    if(got < 4) throw Fail{ "Invalid frame received" };
+    uint32_t hdr;
+    std::memcpy(&hdr, buf.data(), 4);
+    if(hdr == END_MSG) return FRAME_EXIT;
+    if(want_init && hdr != INIT_MSG) throw Fail{ "Invalid message header" };
+    if(expected_size > (size_t)got) read_exact(fd, buf.data() + got, expected_size - (size_t)got);
+    return hdr == INIT_MSG ? FRAME_INIT : FRAME_DATA;
+}
+
+void serve(lantern_index_server *srv, int fd)
+{
+    usearch_index_t index = nullptr;
+    usearch_error_t err = nullptr;
+    try {
+        uint32_t hello[ 2 ] = { PROTOCOL_VERSION, SERVER_TYPE };
+        write_all(fd, hello, 8);
+        std::vector<uint8_t> buf;
+        if(read_frame(fd, buf, INDEX_HEADER_LENGTH, true) != FRAME_INIT) throw Fail{ "send init message first" };
+        uint32_t p[ 11 ];
+        std::memcpy(p, buf.data() + 4, sizeof(p));
+        const uint32_t pq = p[ 0 ], metric_kind = p[ 1 ], quant = p[ 2 ], dim = p[ 3 ], m = p[ 4 ], efc = p[ 5 ], ef = p[ 6 ],
+                       num_centroids = p[ 7 ], num_subvectors = p[ 8 ], estimated_capacity = p[ 9 ], element_bits = p[ 10 ];
+        if(quant > 5) throw Fail{ "Invalid scalar quantization" };                                        // server.rs:94-101
+        if(metric_kind != 1 && metric_kind != 3 && metric_kind != 8) throw Fail{ "Invalid metric " + std::to_string(metric_kind) };  // cli.rs:56-69
+        usearch_init_options_t o;
+        std::memset(&o, 0, sizeof(o));
+        o.metric_kind = (usearch_metric_kind_t)metric_kind;
+        o.quantization = quant <= 1 ? usearch_scalar_f32_k : (usearch_scalar_kind_t)quant;
+        o.dimensions = dim;
+        o.connectivity = m;
+        o.expansion_add = efc;
+        o.expansion_search = ef;
+        o.pq = pq == 1;
+        o.num_centroids = num_centroids;
+        o.num_subvectors = num_subvectors;
+        index = usearch_init(&o, nullptr, &err);
+        if(err) throw Fail{ err };
+        usearch_reserve(index, estimated_capacity, &err);
+        if(err) throw Fail{ err };
+        const uint8_t okb = 0;
+        write_all(fd, &okb, 1);
+
+        // receive_rows (server.rs:214-267)
+        const size_t dims = usearch_dimensions(index, &err);
+        const size_t vec_bytes = element_bits < 8 ? (dims + 7) / 8 : dims * (element_bits / 8);
+        const size_t payload = 8 + vec_bytes;
+        const usearch_scalar_kind_t kind = o.quantization;
+        std::vector<uint64_t> labels;
+        std::vector<uint8_t>  rows;
+        labels.reserve(ADD_CHUNK);
+        rows.reserve(ADD_CHUNK * vec_bytes);
+        auto flush = [&]() {
+            if(labels.empty()) return;
+            lantern_gpu_add_many(index, labels.data(), rows.data(), labels.size(), kind, &err);
+            if(err) throw Fail{ err };
+            labels.clear();
+            rows.clear();
+        };
+        for(;;) {
+            Frame f = read_frame(fd, buf, payload, false);
+            if(f == FRAME_EXIT) break;
+            if(f != FRAME_DATA) throw Fail{ "Invalid message received" };
+            uint64_t label;
+            std::memcpy(&label, buf.data(), 8);
+            labels.push_back(label);
+            rows.insert(rows.end(), buf.begin() + 8, buf.end());
+            if(labels.size() == ADD_CHUNK) flush();
+        }
+        flush();
+        lantern_gpu_flush(index, &err);
+        if(err) throw Fail{ err };
+
+        // the build may take longer than the socket timeout on the client side; the client disables its
+        // read timeout while it waits (external_index_socket.c:502)
+        const uint64_t count = usearch_size(index, &err);
+        write_all(fd, &count, 8);
+        const size_t len = usearch_serialized_length(index, &err);
+        if(err) throw Fail{ err };
+        std::vector<char> file(len);
+        usearch_save_buffer(index, file.data(), len, &err);
+        if(err) throw Fail{ err };
+        const uint64_t len64 = len;
+        write_all(fd, &len64, 8);
+        write_all(fd, file.data(), len);
+        set_status(srv, SUCCEEDED);
+    } catch(const Fail &f) {
+        set_status(srv, FAILED);
+        std::vector<uint8_t> out(8 + f.msg.size());
+        const uint32_t hdr = ERR_MSG, n = (uint32_t)f.msg.size();
+        std::memcpy(out.data(), &hdr, 4);
+        std::memcpy(out.data() + 4, &n, 4);
+        std::memcpy(out.data() + 8, f.msg.data(), f.msg.size());
+        (void)::send(fd, out.data(), out.size(), MSG_NOSIGNAL);
+    }
+    if(index) usearch_free(index, &err);
+    srv->served++;
+}
+
+int listen_on(const char *host, int port, int *bound_port)
+{
+    int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+    if(fd < 0) return -1;
+    int one = 1;
+    ::setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    sockaddr_in a;
+    std::memset(&a, 0, sizeof(a));
+    a.sin_family = AF_INET;
+    a.sin_port = htons((uint16_t)port);
+    if(::inet_pton(AF_INET, host && *host ? host : "0.0.0.0", &a.sin_addr) != 1 || ::bind(fd, (sockaddr *)&a, sizeof(a)) != 0 ||
+       ::listen(fd, 16) != 0) {
+        ::close(fd);
+        return -1;
+    }
+    socklen_t len = sizeof(a);
+    ::getsockname(fd, (sockaddr *)&a, &len);
+    *bound_port = ntohs(a.sin_port);
+    timeval tv{ 0, 200000 };  // so the accept loop can notice `stop`
+    ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    return fd;
+}
+
+void accept_loop(lantern_index_server *srv)
+{
+    while(!srv->stop) {
+        int fd = ::accept(srv->listen_fd, nullptr, nullptr);
+        if(fd < 0) continue;
+        timeval tv{ SOCKET_TIMEOUT_S, 0 };
+        ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+        ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+        int one = 1;
+        ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        set_status(srv, IN_PROGRESS);
+        serve(srv, fd);
+        ::shutdown(fd, SHUT_RDWR);
+        ::close(fd);
+    }
+}
+
+// the optional HTTP status endpoint: {"status":0..3,"status_updated_at":ms} (server.rs:586-597)
+void status_loop(lantern_index_server *srv)
+{
+    while(!srv->stop) {
+        int fd = ::accept(srv->status_fd, nullptr, nullptr);
+        if(fd < 0) continue;
+        char   req[ 1024 ];
+        timeval tv{ 1, 0 };
+        ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+        (void)::recv(fd, req, sizeof(req), 0);
+        std::string body = "{\"status\":" + std::to_string(srv->status.load()) + ",\"status_updated_at\":" +
+                           std::to_string(srv->status_updated_at.load()) + "}";
+        std::string resp = "HTTP/1.1 200 OK\r\nContent-Type: application/json\r\nContent-Length: " + std::to_string(body.size()) +
+                           "\r\nConnection: close\r\n\r\n" + body;
+        (void)::send(fd, resp.data(), resp.size(), MSG_NOSIGNAL);
+        ::close(fd);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+lantern_index_server_t *lantern_index_server_start(const char *host, int port, int status_port, const char *tmp_dir, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    lantern_index_server *s = new lantern_index_server();
+    s->tmp_dir = tmp_dir ? tmp_dir : "/tmp";
+    s->listen_fd = listen_on(host, port, &s->port);
+    if(s->listen_fd < 0) {
+        if(e) *e = "lantern_gpu: cannot bind the indexing server socket";
+        delete s;
+        return nullptr;
+    }
+    set_status(s, IDLE);
+    if(status_port >= 0) {
+        s->status_fd = listen_on(host, status_port, &s->status_port);
+        if(s->status_fd >= 0) s->status_thread = std::thread(status_loop, s);
+    }
+    s->accept_thread = std::thread(accept_loop, s);
+    return s;
+}
+
+int lantern_index_server_port(lantern_index_server_t *s) { return s ? s->port : -1; }
+int lantern_index_server_status_port(lantern_index_server_t *s) { return s ? s->status_port : -1; }
+int lantern_index_server_status(lantern_index_server_t *s) { return s ? s->status.load() : -1; }
+uint64_t lantern_index_server_served(lantern_index_server_t *s) { return s ? s->served.load() : 0; }
+
+void lantern_index_server_stop(lantern_index_server_t *s)
+{
+    if(!s) return;
+    s->stop = true;
+    if(s->accept_thread.joinable()) s->accept_thread.join();
+    if(s->status_thread.joinable()) s->status_thread.join();
+    if(s->listen_fd >= 0) ::close(s->listen_fd);
+    if(s->status_fd >= 0) ::close(s->status_fd);
+    delete s;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""The external indexing server (boundary B3): protocol framing on CPU, a full build round trip on GPU.
+Cases follow lantern_cli/tests/external_index_server_test.rs:141-326."""
+import json
+import struct
+import time
+import urllib.request
+
+import numpy as np
+import pytest
+
+from tests import index_client as ic
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from lantern_amd import build, capi
+
+    build.build()
+    capi.lib()
+    return capi
+
+
+@pytest.fixture()
+def server(capi):
+    srv = capi.IndexServer("127.0.0.1", 0, 0, "/tmp")
+    yield srv
+    srv.stop()
+
+
+def status_of(srv):
+    with urllib.request.urlopen(f"http://127.0.0.1:{srv.status_port}/", timeout=5) as r:
+        return json.loads(r.read())
+
+
+def test_hello_and_invalid_header(server):
+    # external_index_server_test.rs:141-167
+    s, version, server_type = ic.connect(server.host, server.port)
+    assert (version, server_type) == (1, 1)
+    s.sendall(bytes([0, 1, 1, 1, 1, 1]))
+    assert ic.read_error(s) == "Invalid message header"
+    s.close()
+
+
+def test_short_message(server):
+    # external_index_server_test.rs:169-195
+    s, _, _ = ic.connect(server.host, server.port)
+    s.sendall(bytes([0, 1]))
+    assert ic.read_error(s) == "Invalid frame received"
+    s.close()
+
+
+def test_bad_params_and_status_endpoint(server):
+    assert status_of(server)["status"] == 0  # idle
+    s, _, _ = ic.connect(server.host, server.port)
+    s.sendall(ic.init_frame(metric_kind=2, quantization=1, dim=3, m=12, efc=64, ef=32, capacity=4, element_bits=32))
+    assert ic.read_error(s) == "Invalid metric 2"  # cli.rs:56-69
+    s.close()
+    s, _, _ = ic.connect(server.host, server.port)
+    s.sendall(ic.init_frame(metric_kind=1, quantization=9, dim=3, m=12, efc=64, ef=32, capacity=4, element_bits=32))
+    assert ic.read_error(s) == "Invalid scalar quantization"  # server.rs:94-101
+    s.close()
+    s, _, _ = ic.connect(server.host, server.port)
+    s.sendall(struct.pack("<I", ic.END_MSG) + bytes(44))
+    assert ic.read_error(s) == "send init message first"  # server.rs:209
+    s.close()
+    time.sleep(0.1)
+    st = status_of(server)
+    assert st["status"] == 2 and st["status_updated_at"] > 0  # failed
+    assert server.served == 3
+
+
+def test_build_without_device_is_refused_loudly(capi, server):
+    if capi.device_count() > 0:
+        pytest.skip("a device is present")
+    with pytest.raises(ic.IndexServerError, match="no HIP device"):
+        ic.build_index(server.host, server.port, 3, 3, [np.zeros(3, np.float32).tobytes()], [1])
+
+
+@pytest.mark.gpu
+def test_full_build_round_trip(capi, server):
+    # external_index_server_test.rs:197-326 (f32 cosine, 14 rows, capacity = len/2 to force a resize)
+    tuples = [(i, v) for i, v in enumerate([[0, 0, 0], [0, 0, 1], [0, 0, 2], [0, 0, 3], [0, 1, 0], [0, 1, 1], [0, 1, 2], [0, 1, 3],
+                                            [1, 0, 0], [1, 0, 1], [1, 0, 2], [1, 0, 3], [1, 1, 0], [1, 1, 1]])]
+    rows = [np.asarray(v, np.float32).tobytes() for _, v in tuples]
+    n, data = ic.build_index(server.host, server.port, 1, 3, rows, [t[0] for t in tuples], m=12, efc=64, ef=32, capacity=len(tuples) // 2)
+    assert n == len(tuples) and len(data) > 136 and data[:7] == b"usearch"
+    received = capi.GpuIndex("cos", 3, M=12, ef_construction=64, ef=32)
+    received.load_buffer(data)
+    local = capi.GpuIndex("cos", 3, M=12, ef_construction=64, ef=32)
+    local.add_many([t[0] for t in tuples], np.asarray([t[1] for t in tuples], np.float32))
+    assert len(received) == len(local) == len(tuples)  # what the Rust test asserts (:316)
+    assert received.save_buffer() == local.save_buffer()  # and byte-for-byte the same index file
+    time.sleep(0.1)
+    assert status_of(server)["status"] == 3
+
+
+@pytest.mark.gpu
+def test_hamming_and_larger_build(capi, server):
+    rng = np.random.default_rng(2)
+    # hamming: element_bits = 1, dim = bits, payload ceil(dim/8) bytes (server.rs:226-230)
+    words = rng.integers(0, 2**32, size=(700, 3), dtype=np.uint32)
+    n, data = ic.build_index(server.host, server.port, 8, 96, [w.tobytes() for w in words], np.arange(700) + 1, m=8, efc=32, ef=16,
+                             element_bits=1, quantization=5)
+    assert n == 700
+    ix = capi.GpuIndex("hamming", 3, M=8, ef_construction=32, ef=16)
+    ix.load_buffer(data)
+    labels, dists = ix.search(words[5], 1)
+    assert labels[0] == 6 and dists[0] == 0
+    # f32 l2sq, 3000 rows
+    base = rng.standard_normal((3000, 32), dtype=np.float32)
+    n, data = ic.build_index(server.host, server.port, 3, 32, [r.tobytes() for r in base], np.arange(3000) + 1, m=16, efc=64, ef=64)
+    ix = capi.GpuIndex("l2sq", 32, M=16, ef_construction=64, ef=64)
+    ix.load_buffer(data)
+    hits = sum(int(ix.search(base[i], 1)[0][0]) == i + 1 for i in range(0, 3000, 30))
+    assert n == 3000 and hits >= 95
+    # quantised storage is refused with an error frame, not a hang
+    with pytest.raises(ic.IndexServerError, match="only f32 storage"):
+        ic.build_index(server.host, server.port, 3, 32, [], [], element_bits=16, quantization=3)
