@@ -131,6 +131,13 @@ LANTERN_GPU_EXPORT void usearch_save_buffer(usearch_index_t, char *buffer, size_
 LANTERN_GPU_EXPORT void usearch_load(usearch_index_t, const char *path, usearch_error_t *);
 LANTERN_GPU_EXPORT void usearch_load_buffer(usearch_index_t, const char *buffer, size_t length, usearch_error_t *);
 LANTERN_GPU_EXPORT size_t usearch_serialized_length(usearch_index_t, usearch_error_t *);
+/* scan.c:110, insert.c:151: attach to an index that lives in PostgreSQL pages.  The reachable graph is
+ * walked ONCE through init_options.retriever (slot -> node tape, external_index.c:613-671) from the
+ * header's entry slot and mirrored into HBM; neighbour slots are the 6-byte ItemPointers of
+ * external_index.c:380-409.  Searches then run on the mirror and return the nodes' labels. */
+LANTERN_GPU_EXPORT void usearch_view_mem_lazy(usearch_index_t, char *header136, usearch_error_t *);
+/* insert.c:214: refresh size / max_level in the header copy (the entry slot stays the caller's business) */
+LANTERN_GPU_EXPORT void usearch_update_header(usearch_index_t, char *header136, usearch_error_t *);
 /* external_index.c:411,417 */
 LANTERN_GPU_EXPORT uint64_t usearch_header_get_entry_slot(char *header136);
 LANTERN_GPU_EXPORT void     usearch_header_set_entry_slot(char *header136, uint64_t slot);

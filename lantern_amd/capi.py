@@ -76,7 +76,8 @@ EXPORTS = [
     "usearch_init", "usearch_free", "usearch_reserve", "usearch_size", "usearch_capacity", "usearch_dimensions",
     "usearch_add", "usearch_search_ef", "usearch_distance", "usearch_index_metadata", "usearch_save",
     "usearch_save_buffer", "usearch_load", "usearch_load_buffer", "usearch_serialized_length",
-    "usearch_header_get_entry_slot", "usearch_header_set_entry_slot", "lantern_gpu_version", "lantern_gpu_device_count",
+    "usearch_header_get_entry_slot", "usearch_header_set_entry_slot", "usearch_view_mem_lazy", "usearch_update_header",
+    "lantern_gpu_version", "lantern_gpu_device_count",
     "lantern_gpu_set_seed", "lantern_gpu_set_add_batch", "lantern_gpu_add_many", "lantern_gpu_flush",
     "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device",
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
@@ -124,6 +125,8 @@ def lib() -> C.CDLL:
         "usearch_serialized_length": (sz, [vp, err]),
         "usearch_header_get_entry_slot": (u64, [vp]),
         "usearch_header_set_entry_slot": (None, [vp, u64]),
+        "usearch_view_mem_lazy": (None, [vp, vp, err]),
+        "usearch_update_header": (None, [vp, vp, err]),
         "lantern_gpu_version": (C.c_char_p, []),
         "lantern_gpu_device_count": (i32, []),
         "lantern_gpu_set_seed": (None, [vp, u64, err]),
@@ -233,7 +236,9 @@ def hamming_dist(a, b) -> int:
 class GpuIndex:
     """usearch_index_t over the C ABI.  `dims` = f32 scalars, or u32 WORDS for hamming."""
 
-    def __init__(self, metric, dims, M=16, ef_construction=128, ef=64, seed=42):
+    def __init__(self, metric, dims, M=16, ef_construction=128, ef=64, seed=42, retriever=None):
+        """retriever: optional Python callable slot(int) -> address(int) of the node tape (the
+        ldb_wal_index_node_retriever contract, external_index.c:613-671), used by view_mem_lazy()."""
         self.metric = METRICS.get(metric, metric)
         self.dims, self.M, self.efc, self.ef = dims, M, ef_construction, ef
         o = InitOptions()
@@ -243,6 +248,11 @@ class GpuIndex:
         o.dimensions = dims * 32 if self.metric == METRIC_HAMMING else dims  # scan.c:84-88
         o.connectivity, o.expansion_add, o.expansion_search, o.num_threads = M, ef_construction, ef, 1
         o.pq = False
+        self._retriever_cb = None
+        if retriever is not None:
+            self._retriever_cb = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)(lambda ctx, slot: retriever(int(slot)))
+            o.retriever = C.cast(self._retriever_cb, C.c_void_p)
+            o.retriever_mut = o.retriever
         self.h = None
         self.h = _call("usearch_init", C.byref(o), None)
         _call("lantern_gpu_set_seed", self.h, seed)
@@ -374,6 +384,11 @@ class GpuIndex:
         labels = np.ascontiguousarray(graph["labels"], dtype=np.uint64) if graph.get("labels") is not None else None
         _call("lantern_gpu_import_graph", self.h, V.shape[0], _ptr(V), _ptr(labels), _ptr(levels), _ptr(nbr0),
               _ptr(upper_off), _ptr(upper_nbr), int(graph["entry_slot"]), int(graph["max_level"]))
+
+    def view_mem_lazy(self, header: bytes):
+        """usearch_view_mem_lazy (scan.c:110): mirror the page-resident graph through the retriever."""
+        buf = C.create_string_buffer(bytes(header), USEARCH_HEADER_SIZE)
+        _call("usearch_view_mem_lazy", self.h, C.cast(buf, C.c_void_p))
 
     def save(self, path):
         _call("usearch_save", self.h, path.encode())

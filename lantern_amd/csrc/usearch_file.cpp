@@ -17,6 +17,7 @@
 // usearch_header_{get,set}_entry_slot below, and UNVERIFIED against the pinned fork.
 #include <cstdio>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "index.hpp"
@@ -171,11 +172,103 @@ bool deserialize(Index *ix, const char *buf, size_t len)
     return true;
 }
 
+// ---- HBM mirror of an index that lives in PostgreSQL pages ---------------------------------------------
+// Lantern's scan and insert paths never load the index: they hand usearch the 136-byte header and two
+// callbacks, slot -> pointer to the node tape inside a pinned shared buffer
+// (lantern_hnsw/src/hnsw/external_index.c:613-697, scan.c:93-110, insert.c:130-151).  On the page every
+// neighbour slot is a 6-byte ItemPointer (external_index.c:380-409) and the header's entry slot is one too
+// (:411-418).  The device cannot chase host callbacks per hop, so the graph is walked ONCE from the entry
+// slot through the callback, breadth first over every level's lists, into dense device ids.  Nodes that are
+// unreachable from the entry point are unreachable for any search as well, so the mirror is search-equivalent.
+bool mirror_from_retriever(Index *ix, const char *header)
+{
+    if(ix->n || !ix->pend_labels.empty()) { set_err(ix, "lantern_gpu: the mirror needs an empty index"); return false; }
+    if(!ix->opts.retriever) { set_err(ix, "lantern_gpu: usearch_view_mem_lazy needs init_options.retriever"); return false; }
+    if(std::memcmp(header + OFF_MAGIC, "usearch", 7) != 0) { set_err(ix, "lantern_gpu: not a usearch header"); return false; }
+    const uint64_t declared = get<uint64_t>(header, OFF_G_SIZE);
+    if(get<uint64_t>(header, OFF_G_CONNECTIVITY) != ix->M) { set_err(ix, "lantern_gpu: header connectivity does not match the index options"); return false; }
+    if(declared == 0) return true;
+    const uint64_t mask48 = 0xFFFFFFFFFFFFull;
+    const uint64_t entry = get<uint64_t>(header, OFF_G_ENTRY_SLOT) & mask48;
+    const size_t   vb = vector_bytes(ix), wbytes = (size_t)ix->words * 4;
+    std::unordered_map<uint64_t, uint32_t> id_of;
+    std::vector<uint64_t> slot_of, labels;
+    std::vector<uint8_t>  levels;
+    std::vector<uint32_t> nbr0, upper_off, upper;
+    std::vector<char>     vecs;
+    id_of.reserve(declared * 2);
+    auto intern = [&](uint64_t slot) -> uint32_t {
+        auto it = id_of.find(slot);
+        if(it != id_of.end()) return it->second;
+        const uint32_t id = (uint32_t)slot_of.size();
+        id_of.emplace(slot, id);
+        slot_of.push_back(slot);
+        return id;
+    };
+    intern(entry);
+    for(size_t head = 0; head < slot_of.size(); ++head) {
+        if(slot_of.size() > declared) { set_err(ix, "lantern_gpu: the page graph has more nodes than its header declares"); return false; }
+        const char *tape = (const char *)ix->opts.retriever(ix->opts.retriever_ctx, slot_of[ head ]);
+        if(!tape) { set_err(ix, "lantern_gpu: retriever returned NULL"); return false; }
+        labels.push_back(get<uint64_t>(tape, 0));
+        const int level = get<uint16_t>(tape, 8);
+        if(level > 255) { set_err(ix, "lantern_gpu: corrupt node level"); return false; }
+        levels.push_back((uint8_t)level);
+        nbr0.resize(nbr0.size() + ix->M0, EMPTY);
+        upper_off.push_back(level > 0 ? (uint32_t)(upper.size() / ix->M) : EMPTY);
+        if(level > 0) upper.resize(upper.size() + (size_t)level * ix->M, EMPTY);
+        const char *q = tape + 10;
+        for(int l = 0; l <= level; ++l) {
+            const uint32_t cap = l == 0 ? ix->M0 : ix->M;
+            const uint32_t cnt = get<uint32_t>(q, 0);
+            if(cnt > cap) { set_err(ix, "lantern_gpu: corrupt neighbour count"); return false; }
+            for(uint32_t j = 0; j < cnt; ++j) {
+                uint64_t slot = 0;
+                std::memcpy(&slot, q + 4 + (size_t)j * LANTERN_SLOT_SIZE, LANTERN_SLOT_SIZE);
+                const uint32_t id = intern(slot);  // may grow the vectors below: index, do not keep pointers
+                if(l == 0) nbr0[ head * ix->M0 + j ] = id;
+                else upper[ ((size_t)upper_off[ head ] + (size_t)(l - 1)) * ix->M + j ] = id;
+            }
+            q += 4 + (size_t)cap * LANTERN_SLOT_SIZE;
+        }
+        vecs.resize(vecs.size() + wbytes, 0);
+        std::memcpy(&vecs[ head * wbytes ], q, vb);
+    }
+    if(upper.empty()) upper.push_back(EMPTY);
+    return import_graph_locked(ix, slot_of.size(), vecs.data(), labels.data(), levels.data(), nbr0.data(), upper_off.data(), upper.data(),
+                               0 /* the entry slot was interned first */, (int32_t)get<uint64_t>(header, OFF_G_MAX_LEVEL));
+}
+
 }  // namespace lgpu
 
 using namespace lgpu;
 
 extern "C" {
+
+// scan.c:110, insert.c:151.  "Lazy" in usearch (nodes are fetched per hop); here the whole reachable graph is
+// mirrored into HBM once.  A scan-side shim keeps the mirror alive across scans.
+void usearch_view_mem_lazy(usearch_index_t h, char *header136, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    Index *ix = (Index *)h;
+    if(!ix || !header136) { if(e) *e = "lantern_gpu: null index handle or header"; return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!mirror_from_retriever(ix, header136) && e) *e = ix->err.c_str();
+}
+
+// insert.c:214: write size / max level / entry slot back into the header page copy
+void usearch_update_header(usearch_index_t h, char *header136, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    Index *ix = (Index *)h;
+    if(!ix || !header136) { if(e) *e = "lantern_gpu: null index handle or header"; return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { if(e) *e = ix->err.c_str(); return; }
+    put<uint64_t>(header136, OFF_COUNT_PRESENT, ix->n);
+    put<uint64_t>(header136, OFF_G_SIZE, ix->n);
+    put<uint64_t>(header136, OFF_G_MAX_LEVEL, ix->n ? (uint64_t)ix->max_level : 0);
+}
+
 
 uint64_t usearch_header_get_entry_slot(char *h) { return get<uint64_t>(h, OFF_G_ENTRY_SLOT); }
 void     usearch_header_set_entry_slot(char *h, uint64_t slot) { put<uint64_t>(h, OFF_G_ENTRY_SLOT, slot); }

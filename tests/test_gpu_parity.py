@@ -293,3 +293,65 @@ def test_mfma_distance_matrix_within_tolerance(capi, oracle, metric, d):
     assert np.all(np.abs(got - ref) <= TOL * np.maximum(1.0, np.abs(ref)))
     if metric == "cos":
         assert got[3, 5] == 0.0 and got[3, 0] == 1.0 and got[0, 5] == 1.0
+
+
+# ------------------------------------------------------------------------------------------------
+# the PostgreSQL-page view: node tapes with 6-byte ItemPointer slots behind a retriever callback
+# ------------------------------------------------------------------------------------------------
+def test_mirror_through_retriever_matches_direct_index(capi):
+    import ctypes as C
+    import struct
+
+    rng = np.random.default_rng(12)
+    n, d, M = 1500, 48, 6
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    a = capi.GpuIndex("l2sq", d, M=M, ef_construction=40, ef=32, seed=3)
+    a.add_many(np.arange(n, dtype=np.uint64) + 1000, base)
+    blob = bytearray(a.save_buffer())
+    # StoreExternalIndex (external_index.c:298-418): node i goes to some (block, offset); every neighbour slot
+    # (u32 seq id in the low 4 of 6 bytes) and the header's entry slot are rewritten to that ItemPointer
+    def item_pointer(i):  # ItemPointerData{bi_hi u16, bi_lo u16, posid u16}, as the low 48 bits of a u64
+        block, pos = 1 + i // 40, 1 + i % 40
+        return struct.pack("<HHH", block >> 16, block & 0xFFFF, pos)
+
+    tapes, off = [], 136
+    for i in range(n):
+        level = struct.unpack_from("<H", blob, off + 8)[0]
+        size = 10 + (4 + 2 * M * 6) + level * (4 + M * 6) + d * 4
+        tapes.append(bytearray(blob[off:off + size]))
+        off += size
+    assert off == len(blob)
+    for t in tapes:
+        level = struct.unpack_from("<H", t, 8)[0]
+        q = 10
+        for l in range(level + 1):
+            cap = 2 * M if l == 0 else M
+            cnt = struct.unpack_from("<I", t, q)[0]
+            for j in range(cnt):
+                seq = struct.unpack_from("<I", t, q + 4 + j * 6)[0]
+                t[q + 4 + j * 6:q + 10 + j * 6] = item_pointer(seq)
+            q += 4 + cap * 6
+    header = bytearray(blob[:136])
+    hbuf = C.create_string_buffer(bytes(header), 136)
+    entry_seq = capi.lib().usearch_header_get_entry_slot(hbuf)
+    capi.lib().usearch_header_set_entry_slot(hbuf, int.from_bytes(item_pointer(entry_seq), "little"))
+    pages = {int.from_bytes(item_pointer(i), "little"): C.create_string_buffer(bytes(t), len(t)) for i, t in enumerate(tapes)}
+    calls = []
+
+    def retriever(slot):
+        calls.append(slot)
+        return C.addressof(pages[slot])
+
+    b = capi.GpuIndex("l2sq", d, M=M, ef_construction=40, ef=32, seed=3, retriever=retriever)
+    b.view_mem_lazy(hbuf.raw)
+    assert len(b) <= n and len(calls) == len(b)  # every reachable node fetched exactly once
+    queries = rng.standard_normal((40, d), dtype=np.float32)
+    la, da, _ = a.search_batch(queries, 10)
+    lb, db, _ = b.search_batch(queries, 10)
+    assert np.array_equal(la, lb) and np.array_equal(da, db)
+    # the scan shim works on the mirror too
+    sa = capi.Scan(a, init_k=4)
+    sa.rescan(queries[0])
+    sb = capi.Scan(b, init_k=4)
+    sb.rescan(queries[0])
+    assert sa.fetch(25) == sb.fetch(25)
