@@ -37,7 +37,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--n", type=int, default=1_000_000)
+    p.add_argument("--rows", dest="n", type=int, default=1_000_000, help="indexed vectors (not --n: torchrun's own parser trips over that prefix)")
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--metric", default="l2sq")
     p.add_argument("--M", type=int, default=16)
@@ -51,6 +51,9 @@ def parse():
     p.add_argument("--truth-queries", type=int, default=1024, help="queries used for recall@k")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only to debug the N>1 path on one GPU")
+    p.add_argument("--data", default="gaussian", choices=["gaussian", "lowrank"],
+                   help="gaussian = the prescribed i.i.d. N(0,1) set (SURVEY 8d); lowrank = 32 latent dims embedded in --dim (embedding-like)")
     return p.parse_args()
 
 
@@ -68,18 +71,31 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % ndev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist.init_process_group(backend=a.dist_backend)
 
     from lantern_amd import capi, hip
 
     assert capi.device_count() > 0, "no HIP device: bench.py measures the HIP path only"
-    hip.set_device(local_rank if world > 1 else 0)
+    dev_index = (local_rank % capi.device_count()) if world > 1 else 0
+    hip.set_device(dev_index)
 
     # ---- synthetic data (numpy default_rng, standard normal f32, seeds 3 / 4) -------
     t0 = time.time()
     rng = np.random.default_rng(3)
-    base = rng.standard_normal((a.n, a.dim), dtype=np.float32)
+    if a.data == "gaussian":
+        base = rng.standard_normal((a.n, a.dim), dtype=np.float32)
+        make_queries = lambda r, n: r.standard_normal((n, a.dim), dtype=np.float32)
+    else:  # 32 latent dimensions + 5 % isotropic noise: has neighbourhood structure, unlike i.i.d. N(0,1) in 768-d
+        proj = np.random.default_rng(33).standard_normal((32, a.dim), dtype=np.float32) / np.float32(np.sqrt(32))
+        def make_queries(r, n):
+            z = r.standard_normal((n, 32), dtype=np.float32)
+            return z @ proj + np.float32(0.05) * r.standard_normal((n, a.dim), dtype=np.float32)
+        base = make_queries(rng, a.n)
     labels = np.arange(a.n, dtype=np.uint64) + 1  # 0 is INVALID_ELEMENT_LABEL (hnsw.h:40)
     t_gen = time.time() - t0
 
@@ -99,7 +115,7 @@ def main():
     # ---- this rank's queries, resident in HBM ----------------------------------------------------
     qrng = np.random.default_rng(4 + 1000 * rank)
     nq = a.queries
-    queries = qrng.standard_normal((nq, a.dim), dtype=np.float32)
+    queries = make_queries(qrng, nq)
     dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False))
     d_lab, d_dist, d_slot = hip.Buffer(nq * a.k * 8), hip.Buffer(nq * a.k * 4), hip.Buffer(nq * a.k * 4)
     d_D, d_E = hip.Buffer(nq * 8), hip.Buffer(nq * 8)
@@ -131,7 +147,7 @@ def main():
 
         from lantern_amd import sharded
 
-        elapsed = sharded.max_over_ranks(elapsed, device=torch.device("cuda", local_rank))
+        elapsed = sharded.max_over_ranks(elapsed, device=torch.device("cuda", dev_index) if a.dist_backend == "nccl" else None)
 
     # ---- algorithmic bytes of one launch --------------------------------------------
     D = d_D.download(nq, np.uint64).astype(np.float64)
@@ -178,7 +194,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if a.data == "gaussian" else "synthetic (low-rank)",
             "config": {"workload": f"HNSW search {a.n}x{a.dim} f32 {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}",
                        "queries_per_step_per_gpu": nq, "global_queries_per_step": nq * world, "waves_per_query": a.waves,
                        "parallelism": f"replicated index, query batch sharded x{world}, no collective"},
