@@ -203,6 +203,8 @@ def main():
             "build_vectors_per_s": a.n / t_build,
             "build_seconds": t_build,
             "build_batches": build_counters["add_batches"],
+            "build_counters_per_vector": {k: build_counters[k] / a.n for k in ("add_walk_evals", "add_select_evals", "add_revlink_evals",
+                                                                                 "add_reprunes", "add_expansions")},
             "dist_evals_per_query": float(D.mean()),
             "expansions_per_query": float(E.mean()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -225,6 +225,8 @@ typedef struct lantern_gpu_counters
 {
     uint64_t search_dist_evals, search_expansions, search_queries;
     uint64_t add_dist_evals, add_expansions, add_vectors, add_batches;
+    /* breakdown of add_dist_evals: walk / neighbour selection of the new node / reverse-link re-pruning */
+    uint64_t add_walk_evals, add_select_evals, add_revlink_evals, add_reprunes;
 } lantern_gpu_counters;
 LANTERN_GPU_EXPORT lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t, usearch_error_t *);
 

@@ -144,54 +144,44 @@ int search_grid(const Index *ix, size_t nq, int waves)
 // inserts
 // ---------------------------------------------------------------------------------------------------
 
-static bool insert_first(Index *ix, size_t pi)
+// Stable LSD radix sort of the reverse-link requests by (close, level); requests arrive in new-slot
+// order and the sort is stable, so every group ends up in new-slot order (the order the sequential
+// algorithm applies them in).
+static void sort_requests(std::vector<LinkReq> &h, std::vector<LinkReq> &tmp)
 {
-    int lvl = ix->pend_levels[ pi ] >= 0 ? ix->pend_levels[ pi ] : level_for(ix->seed, 0, ix->M);
-    if(!reserve_locked(ix, std::max<size_t>(ix->cap, 64))) return false;
-    if(!reserve_upper(ix, (size_t)lvl)) return false;
-    const size_t row_words = (size_t)ix->chunks * 4;
-    uint8_t      l8 = (uint8_t)lvl;
-    uint32_t     uo = lvl > 0 ? 0u : EMPTY;
-    HIPCHK(ix, hipMemcpyAsync(ix->d_vec, &ix->pend_rows[ pi * row_words ], row_words * 4, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(ix, hipMemcpyAsync(ix->d_labels, &ix->pend_labels[ pi ], 8, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(ix, hipMemcpyAsync(ix->d_levels, &l8, 1, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(ix, hipMemcpyAsync(ix->d_upper_off, &uo, 4, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(ix, hipStreamSynchronize(ix->stream));
-    ix->labels.push_back(ix->pend_labels[ pi ]);
-    ix->levels.push_back(l8);
-    ix->upper_off.push_back(uo);
-    ix->upper_blocks = (size_t)lvl;
-    ix->n = 1;
-    ix->entry = 0;
-    ix->max_level = lvl;
-    ix->c_add_vectors += 1;
-    return true;
+    const size_t m = h.size();
+    tmp.resize(m);
+    LinkReq *src = h.data(), *dst = tmp.data();
+    auto key = [](const LinkReq &r) { return ((uint64_t)r.close << 8) | (uint64_t)(r.level & 0xFF); };  // 40 bits
+    uint64_t all = 0;
+    for(size_t i = 0; i < m; ++i) all |= key(h[ i ]);
+    int passes = 0;
+    while(passes < 4 && (all >> (passes * 10)) != 0) ++passes;
+    if(passes & 1) ++passes;  // an even number of passes leaves the result in h
+    for(int pass = 0; pass < passes; ++pass) {  // up to 4 x 10 bits
+        const int shift = pass * 10;
+        uint32_t  hist[ 1025 ] = { 0 };
+        for(size_t i = 0; i < m; ++i) hist[ ((key(src[ i ]) >> shift) & 1023) + 1 ]++;
+        for(int b = 0; b < 1024; ++b) hist[ b + 1 ] += hist[ b ];
+        for(size_t i = 0; i < m; ++i) dst[ hist[ (key(src[ i ]) >> shift) & 1023 ]++ ] = src[ i ];
+        std::swap(src, dst);
+    }
+    // an even number of passes: the result is back in h
 }
 
-static bool run_batch(Index *ix, size_t pi, size_t b, const int *lv)
+// One device pass over `b` new vectors whose rows / labels / levels / upper offsets are ALREADY in HBM at
+// slots [first, first + b) (flush_locked uploads everything pending up front: an unlinked node is
+// unreachable, so its row may sit in the table before its batch runs).
+static bool run_batch(Index *ix, size_t b, const int *lv)
 {
-    const size_t first = ix->n, row_words = (size_t)ix->chunks * 4;
-    if(first + b > ix->cap && !reserve_locked(ix, std::max(ix->cap * 2, first + b))) return false;
-    size_t up = 0;
-    for(size_t i = 0; i < b; ++i) up += (size_t)lv[ i ];
-    if(!reserve_upper(ix, ix->upper_blocks + up)) return false;
-
-    std::vector<uint8_t>  l8(b);
-    std::vector<uint32_t> uo(b), link_off(b);
-    size_t                blocks = ix->upper_blocks, total_links = 0;
+    const size_t first = ix->n;
+    std::vector<uint32_t> &link_off = ix->h_link_off;
+    link_off.resize(b);
+    size_t total_links = 0;
     for(size_t i = 0; i < b; ++i) {
-        l8[ i ] = (uint8_t)lv[ i ];
-        uo[ i ] = lv[ i ] > 0 ? (uint32_t)blocks : EMPTY;
-        blocks += (size_t)lv[ i ];
         link_off[ i ] = (uint32_t)total_links;
         total_links += (size_t)ix->M * (size_t)(lv[ i ] + 1);
     }
-    HIPCHK(ix, hipMemcpyAsync((char *)ix->d_vec + first * row_words * 4, &ix->pend_rows[ pi * row_words ], b * row_words * 4,
-                              hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(ix, hipMemcpyAsync(ix->d_labels + first, &ix->pend_labels[ pi ], b * 8, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(ix, hipMemcpyAsync(ix->d_levels + first, l8.data(), b, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(ix, hipMemcpyAsync(ix->d_upper_off + first, uo.data(), b * 4, hipMemcpyHostToDevice, ix->stream));
-
     uint32_t *d_link_off = (uint32_t *)scratch(ix, 0, b * 4);
     LinkReq  *d_links = (LinkReq *)scratch(ix, 1, total_links * sizeof(LinkReq));
     if(!d_link_off || !d_links) return false;
@@ -213,21 +203,30 @@ static bool run_batch(Index *ix, size_t pi, size_t b, const int *lv)
     if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
     HIPCHK(ix, launch_insert(ix->metric, ia, ix->insert_waves, grid, ix->stream));
 
-    std::vector<LinkReq> h(total_links);
-    HIPCHK(ix, hipMemcpyAsync(h.data(), d_links, total_links * sizeof(LinkReq), hipMemcpyDeviceToHost, ix->stream));
+    // pinned landing buffer for the requests
+    if(ix->h_links_cap < total_links) {
+        if(ix->h_links) (void)hipHostFree(ix->h_links);
+        ix->h_links = nullptr;
+        ix->h_links_cap = 0;
+        HIPCHK(ix, hipHostMalloc((void **)&ix->h_links, (total_links + total_links / 2 + 64) * sizeof(LinkReq), hipHostMallocDefault));
+        ix->h_links_cap = total_links + total_links / 2 + 64;
+    }
+    LinkReq *hl = (LinkReq *)ix->h_links;
+    HIPCHK(ix, hipMemcpyAsync(hl, d_links, total_links * sizeof(LinkReq), hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(ix, hipStreamSynchronize(ix->stream));
 
     // reverse links: group by (close, level); within a group apply in new-slot order
-    size_t m = 0;
+    std::vector<LinkReq> &h = ix->h_reqs;
+    h.clear();
+    h.reserve(total_links);
     for(size_t i = 0; i < total_links; ++i)
-        if(h[ i ].close != EMPTY) h[ m++ ] = h[ i ];
-    h.resize(m);
-    std::sort(h.begin(), h.end(), [](const LinkReq &x, const LinkReq &y) {
-        if(x.close != y.close) return x.close < y.close;
-        if(x.level != y.level) return x.level < y.level;
-        return x.new_slot < y.new_slot;
-    });
-    std::vector<uint32_t> gb;
+        if(hl[ i ].close != EMPTY) h.push_back(hl[ i ]);
+    // k_insert emits per node, per level; make the stream new-slot-major before the stable sort
+    // (it already is: nodes are laid out in slot order and a node's requests are contiguous)
+    sort_requests(h, ix->h_reqs_tmp);
+    const size_t m = h.size();
+    std::vector<uint32_t> &gb = ix->h_group_begin;
+    gb.clear();
     for(size_t i = 0; i < m; ++i)
         if(i == 0 || h[ i ].close != h[ i - 1 ].close || h[ i ].level != h[ i - 1 ].level) gb.push_back((uint32_t)i);
     const uint32_t ngroups = (uint32_t)gb.size();
@@ -244,16 +243,11 @@ static bool run_batch(Index *ix, size_t pi, size_t b, const int *lv)
         ra.group_begin = d_gb;
         ra.reqs = d_reqs;
         ra.totals = ix->d_totals + 5;
-        HIPCHK(ix, launch_revlink(ix->metric, ra, ix->stream));
-        HIPCHK(ix, hipStreamSynchronize(ix->stream));
+        void *d_work = scratch(ix, 4, (size_t)ngroups * 8 + 16);
+        if(!d_work) return false;
+        HIPCHK(ix, launch_revlink(ix->metric, ra, (char *)d_work + 16, (uint32_t *)d_work, ix->num_cus, ix->stream));
+        HIPCHK(ix, hipStreamSynchronize(ix->stream));  // h / gb are reused by the next batch
     }
-
-    for(size_t i = 0; i < b; ++i) {
-        ix->labels.push_back(ix->pend_labels[ pi + i ]);
-        ix->levels.push_back(l8[ i ]);
-        ix->upper_off.push_back(uo[ i ]);
-    }
-    ix->upper_blocks = blocks;
     ix->n = first + b;
     if(b == 1 && lv[ 0 ] > ix->max_level) {  // "Updating the entry point if needed"
         ix->entry = (uint32_t)first;
@@ -264,31 +258,71 @@ static bool run_batch(Index *ix, size_t pi, size_t b, const int *lv)
     return true;
 }
 
-bool flush_locked(Index *ix)
+// Insert `count` vectors whose padded rows start at `rows` (row_words 4-byte words each).  levels[i] < 0
+// means "draw with level_for()".  Returns how many were inserted (== count unless a batch failed).
+static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_in, const uint32_t *rows, size_t count, bool *ok_out)
 {
-    const size_t pending = ix->pend_labels.size();
-    size_t       pi = 0;
-    bool         ok = true;
-    std::vector<int> lv;
-    while(pi < pending) {
-        if(ix->n == 0) {
-            if(!(ok = insert_first(ix, pi))) break;
+    *ok_out = true;
+    if(count == 0) return 0;
+    auto fail = [&]() { *ok_out = false; return (size_t)0; };
+    const size_t first = ix->n, row_words = (size_t)ix->chunks * 4;
+    // ---- levels and upper-block offsets of everything, then ONE upload of rows and metadata: an unlinked
+    // node is unreachable, so its row may sit in the table before its batch runs
+    std::vector<int>      lv(count);
+    std::vector<uint8_t>  l8(count);
+    std::vector<uint32_t> uo(count);
+    size_t blocks = ix->upper_blocks;
+    for(size_t i = 0; i < count; ++i) {
+        lv[ i ] = (levels_in && levels_in[ i ] >= 0) ? levels_in[ i ] : level_for(ix->seed, first + i, ix->M);
+        l8[ i ] = (uint8_t)lv[ i ];
+        uo[ i ] = lv[ i ] > 0 ? (uint32_t)blocks : EMPTY;
+        blocks += (size_t)lv[ i ];
+    }
+    if(first + count > ix->cap && !reserve_locked(ix, std::max(ix->cap * 2, first + count))) return fail();
+    if(!reserve_upper(ix, blocks)) return fail();
+    bool up = hipMemcpyAsync((char *)ix->d_vec + first * row_words * 4, rows, count * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    up = up && hipMemcpyAsync(ix->d_labels + first, labels, count * 8, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    up = up && hipMemcpyAsync(ix->d_levels + first, l8.data(), count, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    up = up && hipMemcpyAsync(ix->d_upper_off + first, uo.data(), count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
+    if(!up) { set_err(ix, "lantern_gpu: HIP failure uploading vectors"); return fail(); }
+
+    size_t pi = 0;
+    bool   ok = true;
+    while(pi < count) {
+        if(ix->n == 0) {  // "Do nothing for the first element": it only becomes the entry point
+            ix->n = 1;
+            ix->entry = 0;
+            ix->max_level = lv[ 0 ];
+            ix->c_add_vectors += 1;
             pi += 1;
             continue;
         }
-        const size_t look = std::min(pending - pi, ix->add_batch_max);
-        lv.resize(look);
-        for(size_t i = 0; i < look; ++i)
-            lv[ i ] = ix->pend_levels[ pi + i ] >= 0 ? ix->pend_levels[ pi + i ] : level_for(ix->seed, ix->n + i, ix->M);
-        const size_t b = plan_batch(ix->n, ix->max_level, lv.data(), look, ix->add_batch_max, ix->add_min_ratio);
-        if(!(ok = run_batch(ix, pi, b, lv.data()))) break;
+        const size_t look = std::min(count - pi, ix->add_batch_max);
+        const size_t b = plan_batch(ix->n, ix->max_level, lv.data() + pi, look, ix->add_batch_max, ix->add_min_ratio);
+        if(!(ok = run_batch(ix, b, lv.data() + pi))) break;
         pi += b;
     }
-    // drop what was inserted (everything, unless a batch failed)
+    // host mirrors of what was inserted
+    ix->labels.insert(ix->labels.end(), labels, labels + pi);
+    ix->levels.insert(ix->levels.end(), l8.begin(), l8.begin() + (ptrdiff_t)pi);
+    ix->upper_off.insert(ix->upper_off.end(), uo.begin(), uo.begin() + (ptrdiff_t)pi);
+    for(size_t i = 0; i < pi; ++i) ix->upper_blocks += (size_t)lv[ i ];
+    *ok_out = ok;
+    return pi;
+}
+
+bool flush_locked(Index *ix)
+{
+    const size_t pending = ix->pend_labels.size();
+    if(pending == 0) return true;
     const size_t row_words = (size_t)ix->chunks * 4;
+    bool         ok = true;
+    const size_t pi = insert_rows(ix, ix->pend_labels.data(), ix->pend_levels.data(), ix->pend_rows.data(), pending, &ok);
     ix->pend_labels.erase(ix->pend_labels.begin(), ix->pend_labels.begin() + (ptrdiff_t)pi);
     ix->pend_levels.erase(ix->pend_levels.begin(), ix->pend_levels.begin() + (ptrdiff_t)pi);
     ix->pend_rows.erase(ix->pend_rows.begin(), ix->pend_rows.begin() + (ptrdiff_t)(pi * row_words));
+    if(ix->pend_labels.empty()) { std::vector<uint32_t>().swap(ix->pend_rows); }
     return ok;
 }
 
@@ -441,6 +475,7 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
         if(p) (void)hipFree(p);
     for(void *p : ix->d_scratch)
         if(p) (void)hipFree(p);
+    if(ix->h_links) (void)hipHostFree(ix->h_links);
     delete ix;
 }
 
@@ -486,6 +521,15 @@ static void add_common(Index *ix, const usearch_label_t *labels, const void *vec
     std::lock_guard<std::mutex> g(ix->mu);
     const size_t row_words = (size_t)ix->chunks * 4;
     const size_t in_bytes = ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4;
+    if(n >= ix->add_batch_max && in_bytes == row_words * 4 && level < 0) {
+        // bulk insert of rows that need no padding: upload straight from the caller's buffer (it is borrowed
+        // for the duration of this call) instead of staging a copy
+        if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+        bool ok = true;
+        insert_rows(ix, labels, nullptr, (const uint32_t *)vectors, n, &ok);
+        if(!ok) FAIL(e, ix->err.c_str());
+        return;
+    }
     const size_t base = ix->pend_labels.size();
     ix->pend_labels.insert(ix->pend_labels.end(), labels, labels + n);
     ix->pend_levels.insert(ix->pend_levels.end(), n, level);
@@ -840,6 +884,10 @@ lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t h, usearch_error_t
     c.add_expansions = t[ 3 ];
     c.add_vectors = ix->c_add_vectors;
     c.add_batches = ix->c_add_batches;
+    c.add_walk_evals = t[ 2 ];
+    c.add_select_evals = t[ 4 ];
+    c.add_revlink_evals = t[ 5 ];
+    c.add_reprunes = t[ 6 ];
     return c;
 }
 

@@ -56,6 +56,12 @@ struct Index
     std::vector<uint32_t> pend_rows;    // chunks*4 words per pending vector, zero padded
     std::vector<int>      pend_levels;  // -1 = draw with level_for()
 
+    // reusable host staging for the batch loop
+    std::vector<uint32_t> h_link_off, h_group_begin;
+    std::vector<LinkReq>  h_reqs, h_reqs_tmp;
+    void  *h_links = nullptr;  // pinned
+    size_t h_links_cap = 0;
+
     // ---- streaming continuation of usearch_search_ef (scan.c:273-281) ----------------------------
     size_t stream_returned = 0;
 

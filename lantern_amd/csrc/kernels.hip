@@ -211,12 +211,53 @@ __host__ __device__ inline size_t staged_lds_bytes(uint32_t chunks, uint32_t cap
     return (size_t)(cap + 2) * chunks * 16 + 4 * up16(n * 4) + up16(n * 2) + up16(n * n * 4) + S_SCALARS * 4;
 }
 
+// k_revlink_append: the cheap half of the reverse-link step, one WAVE per (close, level) group: append
+// requests while the list has room.  A group whose list fills up is handed to k_revlink_staged through a
+// worklist entry {group, first unprocessed request}.  Splitting the step keeps the trivial groups (the
+// majority) out of the 110 KiB-LDS kernel, which can only hold one workgroup per CU.
+struct RevWork
+{
+    uint32_t group;
+    uint32_t t_start;
+};
+
+__global__ void __launch_bounds__(256) k_revlink_append(RevlinkArgs a, RevWork *work, uint32_t *work_count)
+{
+    const uint32_t gi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int      lane = threadIdx.x & 63;
+    if(gi >= a.ngroups) return;
+    const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+    const uint32_t close = a.reqs[ begin ].close;
+    const int      level = (int)a.reqs[ begin ].level;
+    uint32_t       cap;
+    uint32_t      *list = neighbors_of(a.view, close, level, cap);
+    // count = position of the first EMPTY slot (lists have no holes)
+    uint32_t c = 0;
+    for(uint32_t off = 0; off < cap; off += 64) {
+        const uint32_t i = off + (uint32_t)lane;
+        const bool     used = i < cap && list[ i ] != EMPTY;
+        c += (uint32_t)__popcll(__ballot(used));
+    }
+    const uint32_t room = cap - c, nreq = end - begin;
+    const uint32_t take = room < nreq ? room : nreq;
+    for(uint32_t t = (uint32_t)lane; t < take; t += 64) list[ c + t ] = a.reqs[ begin + t ].new_slot;
+    if(take < nreq && lane == 0) {
+        const uint32_t w = atomicAdd(work_count, 1u);
+        work[ w ].group = gi;
+        work[ w ].t_start = begin + take;
+    }
+}
+
 template <int METRIC, int G>
-__global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a)
+__global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const RevWork *work, const uint32_t *work_count)
 {
     const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
-    const uint32_t gi = blockIdx.x;
+    const uint32_t nwork = *work_count;
+    uint32_t pairs = 0, reprunes = 0;
+    for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const uint32_t gi = work[ wi ].group;
     const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+    const uint32_t t_first = work[ wi ].t_start;
     const uint32_t close = a.reqs[ begin ].close;
     const int      level = (int)a.reqs[ begin ].level;
     uint32_t       cap;
@@ -236,19 +277,16 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a)
         s.pair = (float *)p;     p += up16(n * n * 4);
         s.scal = (int *)p;
     }
-    if(tid == 0) s.scal[ S_CNT ] = 0;
+    __syncthreads();  // the previous work item is done with the LDS
+    // the list is full at hand-off: entries [c0, cap) were appended by k_revlink_append from the requests
+    // [begin, t_first), whose distances to `close` are known; the older entries are evaluated on first use
+    for(uint32_t i = tid; i < cap; i += T) s.cid[ i ] = list[ i ];
+    int       c = (int)cap;
+    const int c0 = (int)cap - (int)(t_first - begin);
+    for(int i = c0 + tid; i < (int)cap; i += T) s.cd[ i ] = a.reqs[ begin + (uint32_t)(i - c0) ].d;
     __syncthreads();
-    for(uint32_t i = tid; i < cap; i += T) {
-        const uint32_t nb = list[ i ];
-        s.cid[ i ] = nb;
-        if(nb != EMPTY) atomicMax(&s.scal[ S_CNT ], (int)i + 1);
-    }
-    __syncthreads();
-    int       c = s.scal[ S_CNT ];
-    const int c0 = c;
-    bool      have_d = false;
-    uint32_t  pairs = 0;
-    for(uint32_t t = begin; t < end; ++t) {
+    bool have_d = false;
+    for(uint32_t t = t_first; t < end; ++t) {
         const uint32_t vnew = a.reqs[ t ].new_slot;
         const float    dv = a.reqs[ t ].d;
         if(c < (int)cap) {
@@ -257,14 +295,32 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a)
             __syncthreads();
             continue;
         }
+        reprunes++;
         // ---- stage the c current entries, the new node (row c) and `close` (row c + 1)
         if(tid == 0) { s.cid[ c ] = vnew; s.cd[ c ] = dv; }
         __syncthreads();
         const int n = c + 1;
-        for(int idx = tid; idx < (n + 1) * chunks; idx += T) {
-            const int      r = idx / chunks, ch = idx - r * chunks;
-            const uint32_t slot = r < n ? s.cid[ r ] : close;
-            s.rows[ idx ] = row_of(a.view, slot)[ ch ];
+        {
+            // eight independent 16-byte loads in flight per thread before the first LDS store (a plain
+            // load->store loop serialises one HBM round trip per iteration)
+            const int total = (n + 1) * chunks;
+            for(int base = tid; base < total; base += T * 8) {
+                uint4 v[ 8 ];
+#pragma unroll
+                for(int u = 0; u < 8; ++u) {
+                    const int idx = base + u * T;
+                    if(idx < total) {
+                        const int      r = idx / chunks, ch = idx - r * chunks;
+                        const uint32_t slot = r < n ? s.cid[ r ] : close;
+                        v[ u ] = row_of(a.view, slot)[ ch ];
+                    }
+                }
+#pragma unroll
+                for(int u = 0; u < 8; ++u) {
+                    const int idx = base + u * T;
+                    if(idx < total) s.rows[ idx ] = v[ u ];
+                }
+            }
         }
         __syncthreads();
         if(!have_d) {  // distances of the original entries to `close`, once (a = close, b = entry)
@@ -336,7 +392,292 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a)
         for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? s.cid[ i ] : EMPTY;
         __syncthreads();
     }
-    if(tid == 0 && a.totals) atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs);
+    }  // work items
+    if(tid == 0 && a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs); atomicAdd(&a.totals[ 1 ], (unsigned long long)reprunes); }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_revlink_slab: the re-prune for the common shape (rows of >= 64 chunks, i.e. d >= 256, and cap <= 32,
+// i.e. M <= 16), restructured so that several workgroups fit on a CU.
+//
+// A re-prune needs the distances between all <= 33 candidates (and from `close` to the old entries):
+// 561 pairs over 34 rows.  k_revlink_staged holds the 34 full rows in LDS (102 KiB at d=768: ONE
+// workgroup per CU, every phase latency-exposed).  Here the rows are swept in column slabs instead: a slab
+// is chunk range [64p, 64p+64) of every row (34 KiB), each wave owns a contiguous run of pairs and keeps
+// one accumulator per pair IN REGISTERS across the slabs.  Lane l's fma chain still runs over chunks
+// l, l+64, l+128 in that order, so every distance has the same bits as group_dist<METRIC, 64>; for
+// cosine the per-row sums (a2 / b2) are accumulated once per row instead of once per pair (the same
+// chain).  ~43 KiB of LDS and <= 128 VGPRs: two 8-wave workgroups per CU.
+constexpr int SLAB_NMAX = 33;                               // candidates of one re-prune (cap + 1)
+constexpr int SLAB_PAIRS = SLAB_NMAX * (SLAB_NMAX - 1) / 2 + SLAB_NMAX;  // + close-to-candidate
+constexpr int SLAB_WAVES = 8;
+constexpr int SLAB_PPW = (SLAB_PAIRS + SLAB_WAVES - 1) / SLAB_WAVES;     // pairs per wave (71)
+constexpr int SLAB_RPW = (SLAB_NMAX + 1 + SLAB_WAVES - 1) / SLAB_WAVES;  // rows per wave for the cosine norms (5)
+
+template <int METRIC> struct PairAcc;
+template <> struct PairAcc<M_L2SQ>
+{
+    float s = 0.f;
+    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y)
+    {
+        float t;
+        t = __uint_as_float(x.x) - __uint_as_float(y.x); s = __builtin_fmaf(t, t, s);
+        t = __uint_as_float(x.y) - __uint_as_float(y.y); s = __builtin_fmaf(t, t, s);
+        t = __uint_as_float(x.z) - __uint_as_float(y.z); s = __builtin_fmaf(t, t, s);
+        t = __uint_as_float(x.w) - __uint_as_float(y.w); s = __builtin_fmaf(t, t, s);
+    }
+    __device__ __forceinline__ float sum() { return group_sum<64>(s); }
+};
+template <> struct PairAcc<M_COS>
+{
+    float s = 0.f;  // ab only; a2 / b2 are per-row
+    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y)
+    {
+        s = __builtin_fmaf(__uint_as_float(x.x), __uint_as_float(y.x), s);
+        s = __builtin_fmaf(__uint_as_float(x.y), __uint_as_float(y.y), s);
+        s = __builtin_fmaf(__uint_as_float(x.z), __uint_as_float(y.z), s);
+        s = __builtin_fmaf(__uint_as_float(x.w), __uint_as_float(y.w), s);
+    }
+    __device__ __forceinline__ float sum() { return group_sum<64>(s); }
+};
+template <> struct PairAcc<M_HAMMING>
+{
+    uint32_t s = 0;
+    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y)
+    {
+        s += __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
+    }
+    __device__ __forceinline__ float sum() { return (float)group_sum<64>(s); }
+};
+
+__host__ __device__ inline size_t slab_lds_bytes()
+{
+    // slab + pair table + pair matrix + norms + cd/cid/sd/sid + sidx + scalars
+    return (size_t)(SLAB_NMAX + 1) * 64 * 16 + 1152 + (size_t)(SLAB_NMAX + 1) * (SLAB_NMAX + 1) * 4 + 144 + 4 * 144 + 80 + S_SCALARS * 4;
+}
+
+template <int METRIC>
+__global__ void __launch_bounds__(512, 4) k_revlink_slab(RevlinkArgs a, const RevWork *work, const uint32_t *work_count)
+{
+    constexpr int NR = SLAB_NMAX + 1;  // row NR-1 ... the row of `close` lives at index n (<= 33)
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char *p = lgpu_smem;
+    uint4    *slab = (uint4 *)p;       p += (size_t)NR * 64 * 16;
+    uint8_t  *tab = (uint8_t *)p;      p += 1152;                       // (i, j) per pair
+    float    *pair = (float *)p;       p += (size_t)NR * NR * 4;        // [i][j], candidate indices, i > j; row n = close
+    float    *norm = (float *)p;       p += 144;
+    float    *cd = (float *)p;         p += 144;
+    uint32_t *cid = (uint32_t *)p;     p += 144;
+    float    *sd = (float *)p;         p += 144;
+    uint32_t *sid = (uint32_t *)p;     p += 144;
+    uint16_t *sidx = (uint16_t *)p;    p += 80;
+    int      *scal = (int *)p;
+    const uint32_t nwork = *work_count;
+    const int      chunks = (int)a.view.chunks;
+    const int      nslabs = (chunks + 63) / 64;
+    uint32_t       pairs = 0, reprunes = 0;
+    for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint32_t gi = work[ wi ].group;
+        const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+        const uint32_t t_first = work[ wi ].t_start;
+        const uint32_t close = a.reqs[ begin ].close;
+        const int      level = (int)a.reqs[ begin ].level;
+        uint32_t       cap;
+        uint32_t      *list = neighbors_of(a.view, close, level, cap);
+        __syncthreads();  // the previous work item is done with the LDS
+        for(uint32_t i = tid; i < cap; i += T) cid[ i ] = list[ i ];
+        int       c = (int)cap;
+        const int c0 = (int)cap - (int)(t_first - begin);
+        for(int i = c0 + tid; i < (int)cap; i += T) cd[ i ] = a.reqs[ begin + (uint32_t)(i - c0) ].d;
+        __syncthreads();
+        bool have_d = false;
+        for(uint32_t t = t_first; t < end; ++t) {
+            const uint32_t vnew = a.reqs[ t ].new_slot;
+            const float    dv = a.reqs[ t ].d;
+            if(c < (int)cap) {
+                if(tid == 0) { cid[ c ] = vnew; cd[ c ] = dv; list[ c ] = vnew; }
+                c++;
+                __syncthreads();
+                continue;
+            }
+            reprunes++;
+            const int n = __builtin_amdgcn_readfirstlane(c + 1);  // candidates 0..n-1, `close` = row n
+            const int npairs = (n + 1) * n / 2;
+            if(tid == 0) { cid[ c ] = vnew; cd[ c ] = dv; }
+            // The pairs are the strict lower triangle of an (n+1) x (n+1) matrix whose last row is `close`:
+            // q = i (i - 1) / 2 + j, j < i <= n.  A wave walks its contiguous run with scalar (i, j).
+            __syncthreads();
+            // ---- sweep the rows slab by slab; this wave owns pairs [p0, p1)
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            const int p0 = wv * SLAB_PPW, p1 = (p0 + SLAB_PPW < npairs) ? p0 + SLAB_PPW : npairs;
+            int       i0 = (int)((1.f + __builtin_sqrtf(1.f + 8.f * (float)p0)) * 0.5f);
+            while(i0 * (i0 - 1) / 2 > p0) --i0;
+            while((i0 + 1) * i0 / 2 <= p0) ++i0;
+            const int j0 = p0 - i0 * (i0 - 1) / 2;
+            PairAcc<METRIC> acc[ SLAB_PPW ];
+            float           nrm[ SLAB_RPW ];
+#pragma unroll
+            for(int k = 0; k < SLAB_RPW; ++k) nrm[ k ] = 0.f;
+            for(int ph = 0; ph < nslabs; ++ph) {
+                {
+                    const int total = (n + 1) * 64;
+                    uint4     v[ 5 ];
+#pragma unroll
+                    for(int u = 0; u < 5; ++u) {
+                        const int idx = tid + u * T;
+                        v[ u ] = make_uint4(0, 0, 0, 0);
+                        if(idx < total) {
+                            const int      r = idx >> 6, ch = ph * 64 + (idx & 63);
+                            const uint32_t slot = r < n ? cid[ r ] : close;
+                            if(ch < chunks) v[ u ] = row_of(a.view, slot)[ ch ];
+                        }
+                    }
+#pragma unroll
+                    for(int u = 0; u < 5; ++u) {
+                        const int idx = tid + u * T;
+                        if(idx < total) slab[ idx ] = v[ u ];
+                    }
+                }
+                __syncthreads();
+                {
+                    // branch-free walk of this wave's run of pairs, four pairs (eight LDS reads) in flight at a
+                    // time; (i, j) are scalar.  Past the end of the triangle the walk parks on (n, 0): the
+                    // sums of those slots are never stored.
+                    int i = i0, j = j0;
+#pragma unroll
+                    for(int k = 0; k < SLAB_PPW; k += 4) {
+                        uint4 xs[ 4 ], ys[ 4 ];
+#pragma unroll
+                        for(int u = 0; u < 4; ++u) {
+                            if(k + u < SLAB_PPW) {
+                                xs[ u ] = slab[ i * 64 + lane ];
+                                ys[ u ] = slab[ j * 64 + lane ];
+                                if(++j >= i) { ++i; j = 0; }
+                                if(i > n) { i = n; j = 0; }
+                            }
+                        }
+#pragma unroll
+                        for(int u = 0; u < 4; ++u)
+                            if(k + u < SLAB_PPW) acc[ k + u ].add(xs[ u ], ys[ u ]);
+                        __builtin_amdgcn_sched_barrier(0);  // one batch of loads in flight, not all eighteen
+                    }
+                    if(METRIC == M_COS) {  // per-row sums of squares; rows past n are clamped (result unused)
+#pragma unroll
+                        for(int k = 0; k < SLAB_RPW; ++k) {
+                            const int   r = wv + SLAB_WAVES * k;
+                            const uint4 z = slab[ (r <= n ? r : n) * 64 + lane ];
+                            nrm[ k ] = __builtin_fmaf(__uint_as_float(z.x), __uint_as_float(z.x), nrm[ k ]);
+                            nrm[ k ] = __builtin_fmaf(__uint_as_float(z.y), __uint_as_float(z.y), nrm[ k ]);
+                            nrm[ k ] = __builtin_fmaf(__uint_as_float(z.z), __uint_as_float(z.z), nrm[ k ]);
+                            nrm[ k ] = __builtin_fmaf(__uint_as_float(z.w), __uint_as_float(z.w), nrm[ k ]);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- reduce: lane 63 holds the sums
+            if(METRIC == M_COS) {
+#pragma unroll
+                for(int k = 0; k < SLAB_RPW; ++k) {
+                    const int   r = wv + SLAB_WAVES * k;
+                    const float v = group_sum<64>(nrm[ k ]);
+                    if(lane == 63 && r <= n) norm[ r ] = v;
+                }
+            }
+            {
+                int i = i0, j = j0;
+#pragma unroll
+                for(int k = 0; k < SLAB_PPW; ++k) {
+                    const float v = acc[ k ].sum();
+                    if(lane == 63 && p0 + k < p1) pair[ i * NR + j ] = v;
+                    if(++j >= i) { ++i; j = 0; }
+                    if(i > n) { i = n; j = 0; }
+                }
+            }
+            __syncthreads();
+            if(METRIC == M_COS) {  // finish 1 - ab / (sqrt(a2) sqrt(b2)) with the zero-norm rules
+                for(int cell = tid; cell < NR * NR; cell += T) {
+                    const int i = cell / NR, j = cell - i * NR;
+                    if(j < i && i <= n) {
+                        const float ab = pair[ cell ], a2 = norm[ i ], b2 = norm[ j ];
+                        float       d;
+                        if(a2 == 0.f && b2 == 0.f) d = 0.f;
+                        else if(a2 == 0.f || b2 == 0.f) d = 1.f;
+                        else d = 1.f - ab / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));
+                        pair[ cell ] = d;
+                    }
+                }
+                __syncthreads();
+            }
+            pairs += (uint32_t)npairs;
+            if(!have_d) {  // distances of the original entries to `close` (row n of the pair matrix)
+                for(int i = tid; i < c0; i += T) cd[ i ] = pair[ n * NR + i ];
+                have_d = true;
+                __syncthreads();
+            }
+            // ---- sort by (distance to close, tie_mix(slot, close)): one thread per (x, j) comparison
+            int                *rank = (int *)norm;                 // reuse: NR ints (norms are consumed)
+            unsigned long long *blockers = (unsigned long long *)tab;  // NR x u64, 8-byte aligned (tab sits at a 16-byte offset)
+            for(int x = tid; x < NR; x += T) { rank[ x ] = 0; blockers[ x ] = 0ull; }
+            __syncthreads();
+            for(int cell = tid; cell < n * n; cell += T) {
+                const int      x = cell / n, j = cell - x * n;
+                const uint64_t kx = ((uint64_t)f2ord(cd[ x ]) << 32) | tie_mix(cid[ x ], close);
+                const uint64_t kj = ((uint64_t)f2ord(cd[ j ]) << 32) | tie_mix(cid[ j ], close);
+                if(kj < kx) atomicAdd(&rank[ x ], 1);
+            }
+            __syncthreads();
+            for(int x = tid; x < n; x += T) {
+                const int r = rank[ x ];
+                sd[ r ] = cd[ x ];
+                sid[ r ] = cid[ x ];
+                sidx[ r ] = (uint16_t)x;
+            }
+            __syncthreads();
+            // ---- the heuristic.  blockers[c] = set of sorted positions p < c that, if kept, reject c
+            // (dist(c, p) < dist(c, close)); built in parallel, then one wave resolves the sequential
+            // dependency with 64-bit masks: c is kept iff none of its blockers is kept.
+            for(int cell = tid; cell < n * n; cell += T) {
+                const int cpos = cell / n, ppos = cell - cpos * n;
+                if(ppos < cpos) {
+                    const int ci = sidx[ cpos ], pi = sidx[ ppos ];
+                    const int hi = ci > pi ? ci : pi, lo = ci > pi ? pi : ci;
+                    if(pair[ hi * NR + lo ] < sd[ cpos ]) atomicOr(&blockers[ cpos ], 1ull << ppos);
+                }
+            }
+            __syncthreads();
+            if(tid < 64) {
+                const unsigned long long mine = lane < n ? blockers[ lane ] : 0ull;
+                unsigned long long       kept = 1ull;  // sorted position 0 is always kept
+                int                      submitted = 1;
+                for(int cpos = 1; cpos < n && submitted < (int)cap; ++cpos) {
+                    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(mine & 0xFFFFFFFFull), cpos);
+                    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(mine >> 32), cpos);
+                    const unsigned long long b = ((unsigned long long)hi << 32) | lo;
+                    if((b & kept) == 0ull) { kept |= 1ull << cpos; submitted++; }
+                }
+                // lane x takes the x-th kept position
+                float    kd = 0.f;
+                uint32_t ks = 0;
+                bool     have = false;
+                if(lane < submitted) {
+                    unsigned long long m = kept;
+                    for(int s2 = 0; s2 < lane; ++s2) m &= m - 1ull;  // drop the lane lowest set bits
+                    const int kpos = __builtin_ctzll(m);
+                    kd = sd[ kpos ];
+                    ks = sid[ kpos ];
+                    have = true;
+                }
+                if(have) { cd[ lane ] = kd; cid[ lane ] = ks; }
+                if(lane == 0) scal[ S_CNT ] = submitted;
+            }
+            __syncthreads();
+            c = scal[ S_CNT ];
+            for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? cid[ i ] : EMPTY;
+            __syncthreads();
+        }
+    }
+    if(tid == 0 && a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs); atomicAdd(&a.totals[ 1 ], (unsigned long long)reprunes); }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -415,16 +756,34 @@ hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, h
     return hipGetLastError();
 }
 
-hipError_t launch_revlink(int metric, const RevlinkArgs &a, hipStream_t stream)
+hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream)
 {
     if(a.ngroups == 0) return hipSuccess;
     // staged variant whenever the 2M+2 rows of a level-0 re-prune fit in LDS (d <= 1024 at M = 16)
     const size_t staged = staged_lds_bytes(a.view.chunks, a.view.M0);
-    if(staged <= 150 * 1024 && a.view.M0 <= 256) {
+    if(a.view.chunks >= 64 && a.view.M0 <= 32 && work && work_count) {
+        // common shape (d >= 256, M <= 16): column-slab sweep, 2 x 8 waves per CU
+        hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
+        if(e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_revlink_append, dim3((a.ngroups + 3) / 4), dim3(256), 0, stream, a, (RevWork *)work, work_count);
+        const size_t lds = slab_lds_bytes();
+        const int    grid = num_cus * 2;
+        switch(metric) {
+            case M_L2SQ: hipLaunchKernelGGL((k_revlink_slab<M_L2SQ>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
+            case M_COS: hipLaunchKernelGGL((k_revlink_slab<M_COS>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
+            case M_HAMMING: hipLaunchKernelGGL((k_revlink_slab<M_HAMMING>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if(staged <= 150 * 1024 && a.view.M0 <= 256 && work && work_count) {
+        hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
+        if(e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_revlink_append, dim3((a.ngroups + 3) / 4), dim3(256), 0, stream, a, (RevWork *)work, work_count);
 #define CALL(MM, GG)                                                                                                    \
     {                                                                                                                   \
         (void)hipFuncSetAttribute((const void *)k_revlink_staged<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged); \
-        hipLaunchKernelGGL((k_revlink_staged<MM, GG>), dim3(a.ngroups), dim3(512), staged, stream, a);                  \
+        hipLaunchKernelGGL((k_revlink_staged<MM, GG>), dim3(num_cus), dim3(512), staged, stream, a, (const RevWork *)work, work_count); \
     }
         LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL

@@ -53,13 +53,14 @@ struct RevlinkArgs
     uint32_t        ngroups;
     const uint32_t *group_begin;  // [ngroups+1] into reqs (sorted by close, level, new_slot)
     const LinkReq  *reqs;
-    unsigned long long *totals;   // [1] cumulative pair evaluations
+    unsigned long long *totals;   // [2] cumulative pair evaluations, re-prunes
 };
 
 // All launchers return hipSuccess or the launch error.  `metric` is a usearch_metric_kind_t value.
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);
-hipError_t launch_revlink(int metric, const RevlinkArgs &a, hipStream_t stream);
+// work: scratch of ngroups x 8 bytes; work_count: one u32 (both device memory; NULL = unstaged kernel)
+hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream);
 // out[i] = metric(query, row(slots[i]))
 hipError_t launch_gather(int metric, const View &v, const uint4 *query, const uint32_t *slots, uint32_t n, float *out,
                          hipStream_t stream);
