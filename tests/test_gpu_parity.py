@@ -128,8 +128,11 @@ def test_search_matches_oracle_on_same_graph(capi, oracle, metric, n, d, M, efc,
         assert oracle.recall_at_k(o_slot, s_slot) >= 0.995
 
 
+# shapes chosen to hit every reverse-link kernel: LDS-staged rows (short rows), the column-slab sweep
+# (>= 64 chunks, M <= 16; all three metrics; 1 and 6 slabs), and the unstaged one (M = 40: 82 rows do not fit in LDS)
 @pytest.mark.parametrize("metric,n,d,M,efc", [("l2sq", 1200, 64, 8, 40), ("cos", 700, 256, 16, 64), ("hamming", 900, 8, 6, 32),
-                                              ("l2sq", 300, 5, 2, 10)])
+                                              ("l2sq", 300, 5, 2, 10), ("hamming", 600, 256, 8, 32), ("l2sq", 700, 1536, 16, 48),
+                                              ("cos", 500, 1000, 12, 40), ("l2sq", 400, 512, 40, 48)])
 @pytest.mark.parametrize("plan", [(1, 1), (64, 4), (512, 16)])
 def test_build_matches_oracle_edge_for_edge(capi, oracle, metric, n, d, M, efc, plan):
     rng = np.random.default_rng(n * 7 + d)
