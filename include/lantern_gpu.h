@@ -199,6 +199,15 @@ LANTERN_GPU_EXPORT void lantern_gpu_distance_matrix(const void *a, size_t na, co
                                                     usearch_scalar_kind_t, size_t dims, usearch_metric_kind_t,
                                                     int exact_order, float *out, usearch_error_t *);
 
+/* PQ k-means assignment, product_quantization.c:80-124 (assign_to_clusters): for every row i of `dataset`
+ * (n rows of row_dims f32) the nearest of k centroids under `metric` over the subvector
+ * [subvector_start, subvector_start + subvector_dim); the first minimum wins, as in the reference's
+ * strict-< loop.  centers: k x subvector_dim f32.  out_distance may be NULL.  cos / l2sq only. */
+LANTERN_GPU_EXPORT void lantern_gpu_assign_to_clusters(const float *dataset, size_t n, size_t row_dims, size_t subvector_start,
+                                                       size_t subvector_dim, const float *centers, size_t k,
+                                                       usearch_metric_kind_t metric, uint32_t *out_cluster,
+                                                       float *out_distance, usearch_error_t *);
+
 /* flat graph exchange (tests, CPU-baseline timing on the identical graph, sharded serving) */
 typedef struct lantern_gpu_graph_info
 {

@@ -82,7 +82,7 @@ EXPORTS = [
     "lantern_gpu_set_seed", "lantern_gpu_set_add_batch", "lantern_gpu_add_many", "lantern_gpu_flush",
     "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device",
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
-    "lantern_gpu_distance_matrix", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
+    "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_counters_get", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
     "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist", "lantern_index_server_start",
     "lantern_index_server_port", "lantern_index_server_status_port", "lantern_index_server_status",
@@ -141,6 +141,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_exact_search": (None, [vp, vp, sz, sz, vp, vp, err]),
         "lantern_gpu_distance_gather": (None, [vp, vp, vp, sz, vp, err]),
         "lantern_gpu_distance_matrix": (None, [vp, sz, vp, sz, i32, sz, i32, i32, vp, err]),
+        "lantern_gpu_assign_to_clusters": (None, [vp, sz, sz, sz, sz, vp, sz, i32, vp, vp, err]),
         "lantern_gpu_graph_info_get": (GraphInfo, [vp, err]),
         "lantern_gpu_export_graph": (None, [vp, vp, vp, vp, vp, vp, vp, err]),
         "lantern_gpu_import_graph": (None, [vp, sz, vp, vp, vp, vp, vp, vp, u32, C.c_int32, err]),
@@ -216,6 +217,19 @@ def distance_matrix(a, b, metric, exact_order=True):
     _call("lantern_gpu_distance_matrix", _ptr(A), A.shape[0], _ptr(B), B.shape[0], _kind(m), dims, m,
           1 if exact_order else 0, _ptr(out))
     return out
+
+
+def assign_to_clusters(dataset, centers, metric, subvector_start=0, subvector_dim=None):
+    """product_quantization.c:80-124: nearest centroid of every row's subvector; (cluster ids, distances)."""
+    m = METRICS.get(metric, metric)
+    X = np.ascontiguousarray(dataset, dtype=np.float32)
+    Cn = np.ascontiguousarray(centers, dtype=np.float32)
+    sd = Cn.shape[1] if subvector_dim is None else subvector_dim
+    idx = np.zeros(X.shape[0], dtype=np.uint32)
+    dist = np.zeros(X.shape[0], dtype=np.float32)
+    _call("lantern_gpu_assign_to_clusters", _ptr(X), X.shape[0], X.shape[1], subvector_start, sd, _ptr(Cn), Cn.shape[0], m, _ptr(idx),
+          _ptr(dist))
+    return idx, dist
 
 
 def l2sq_dist(a, b) -> float:

@@ -762,6 +762,45 @@ void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uin
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in distance_gather");
 }
 
+// Exact k-NN of nq device-resident query rows over nb device-resident base rows (both `chunks` uint4 per row):
+// fp32-MFMA contraction in chunks of 64k base rows + running top-(k+16) + exact-order re-rank.
+// Result (device): slots[nq][k] ascending by (distance, slot), dists[nq][k].
+static bool exact_knn_device(int metric, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
+                             uint32_t *d_slots, float *d_dists, hipStream_t st)
+{
+    // kk = k plus a margin: the MFMA distances (|q|^2 + |b|^2 - 2 q.b) differ from the exact-order ones in the
+    // last bits, so the survivors are re-ranked exactly and only then cut to k
+    const uint32_t kk = (uint32_t)k + 16;
+    const size_t   QT = 1024, CH = std::min<size_t>(nb, 65536);
+    char *aux = nullptr;
+    float *dd = nullptr;
+    bool ok = hipMalloc((void **)&aux, (nq + nb) * 4 + 8 + nq * kk * 8) == hipSuccess &&
+              hipMalloc((void **)&dd, std::min(nq, QT) * CH * 4) == hipSuccess;
+    if(ok) {
+        float    *qn = (float *)aux, *bn = qn + nq;
+        uint64_t *best = (uint64_t *)(aux + (nq + nb) * 4 + ((nq + nb) % 2) * 4);
+        ok = ok && hipMemsetAsync(best, 0xFF, nq * kk * 8, st) == hipSuccess;
+        if(metric != M_HAMMING) {
+            ok = ok && launch_row_norms(d_q, (uint32_t)nq, chunks, qn, st) == hipSuccess;
+            ok = ok && launch_row_norms(d_base, (uint32_t)nb, chunks, bn, st) == hipSuccess;
+        }
+        for(size_t q0 = 0; ok && q0 < nq; q0 += QT) {
+            const size_t nqt = std::min(QT, nq - q0);
+            for(size_t c0 = 0; ok && c0 < nb; c0 += CH) {
+                const size_t nc = std::min(CH, nb - c0);
+                ok = ok && launch_dense(metric, d_q + q0 * chunks, (uint32_t)nqt, d_base + c0 * chunks, (uint32_t)nc, chunks, qn + q0, bn + c0, dd,
+                                        (uint32_t)CH, st) == hipSuccess;
+                ok = ok && launch_select(dd, (uint32_t)CH, (uint32_t)nqt, (uint32_t)nc, (uint32_t)c0, best + q0 * kk, kk, st) == hipSuccess;
+            }
+        }
+        ok = ok && launch_rerank(metric, d_q, (uint32_t)nq, d_base, chunks, best, kk, (uint32_t)k, d_slots, d_dists, st) == hipSuccess;
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    }
+    if(aux) (void)hipFree(aux);
+    if(dd) (void)hipFree(dd);
+    return ok;
+}
+
 void lantern_gpu_exact_search(usearch_index_t h, const void *queries, size_t nq, size_t k, uint32_t *slots, float *distances,
                               usearch_error_t *e)
 {
@@ -779,40 +818,51 @@ void lantern_gpu_exact_search(usearch_index_t h, const void *queries, size_t nq,
     const size_t in_bytes = ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4;
     std::vector<uint32_t> padded(nq * row_words);
     for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, &padded[ i * row_words ]);
-    // kk = k plus a margin: the MFMA distances (|q|^2 + |b|^2 - 2 q.b) differ from the exact-order ones in
-    // the last bits, so the survivors are re-ranked exactly and only then cut to k
-    const uint32_t kk = (uint32_t)k + 16;
-    const size_t   QT = 1024, CH = std::min<size_t>(n, 65536);
-    uint4    *dq = (uint4 *)scratch(ix, 5, nq * row_words * 4);
-    char     *aux = (char *)scratch(ix, 6, nq * 4 + n * 4 + nq * kk * 8 + nq * k * 8 + 64);
-    float    *dd = (float *)scratch(ix, 7, std::min(nq, QT) * CH * 4);
-    if(!dq || !aux || !dd) { FAIL(e, ix->err.c_str()); return; }
-    float    *qn = (float *)aux;
-    float    *bn = qn + nq;
-    uint64_t *best = (uint64_t *)(aux + (nq + n) * 4 + ((nq + n) % 2) * 4);
-    uint32_t *d_slots = (uint32_t *)(best + nq * kk);
+    uint4 *dq = (uint4 *)scratch(ix, 5, nq * row_words * 4);
+    char  *dout = (char *)scratch(ix, 6, nq * k * 8 + 64);
+    if(!dq || !dout) { FAIL(e, ix->err.c_str()); return; }
+    uint32_t *d_slots = (uint32_t *)dout;
     float    *d_dists = (float *)(d_slots + nq * k);
     hipStream_t st = ix->stream;
     bool ok = hipMemcpyAsync(dq, padded.data(), nq * row_words * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-    ok = ok && hipMemsetAsync(best, 0xFF, nq * kk * 8, st) == hipSuccess;
-    if(ix->metric != M_HAMMING) {
-        ok = ok && launch_row_norms(dq, (uint32_t)nq, ix->chunks, qn, st) == hipSuccess;
-        ok = ok && launch_row_norms(ix->d_vec, (uint32_t)n, ix->chunks, bn, st) == hipSuccess;
-    }
-    for(size_t q0 = 0; ok && q0 < nq; q0 += QT) {
-        const size_t nqt = std::min(QT, nq - q0);
-        for(size_t c0 = 0; ok && c0 < n; c0 += CH) {
-            const size_t nc = std::min(CH, n - c0);
-            ok = ok && launch_dense(ix->metric, dq + q0 * ix->chunks, (uint32_t)nqt, ix->d_vec + c0 * ix->chunks, (uint32_t)nc, ix->chunks,
-                                    qn + q0, bn + c0, dd, (uint32_t)CH, st) == hipSuccess;
-            ok = ok && launch_select(dd, (uint32_t)CH, (uint32_t)nqt, (uint32_t)nc, (uint32_t)c0, best + q0 * kk, kk, st) == hipSuccess;
-        }
-    }
-    ok = ok && launch_rerank(ix->metric, dq, (uint32_t)nq, ix->d_vec, ix->chunks, best, kk, (uint32_t)k, d_slots, d_dists, st) == hipSuccess;
-    ok = ok && hipMemcpyAsync(slots, d_slots, nq * k * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-    ok = ok && hipMemcpyAsync(distances, d_dists, nq * k * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    ok = ok && exact_knn_device(ix->metric, ix->chunks, ix->d_vec, n, dq, nq, k, d_slots, d_dists, st);
+    ok = ok && hipMemcpy(slots, d_slots, nq * k * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy(distances, d_dists, nq * k * 4, hipMemcpyDeviceToHost) == hipSuccess;
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in exact_search");
+}
+
+// PQ k-means assignment (product_quantization.c:80-124 assign_to_clusters): the one dense N x k contraction in
+// Lantern's C code -- N x k usearch_distance calls there, one fp32-MFMA pass + exact re-rank here.
+void lantern_gpu_assign_to_clusters(const float *dataset, size_t n, size_t row_dims, size_t subvector_start, size_t subvector_dim,
+                                    const float *centers, size_t k, usearch_metric_kind_t metric, uint32_t *out_cluster,
+                                    float *out_distance, usearch_error_t *e)
+{
+    CLEAR(e);
+    if(metric != usearch_metric_cos_k && metric != usearch_metric_l2sq_k) { FAIL(e, "lantern_gpu: assign_to_clusters needs cos or l2sq"); return; }
+    if(!dataset || !centers || !out_cluster || subvector_dim == 0 || subvector_start + subvector_dim > row_dims || k == 0) {
+        FAIL(e, "lantern_gpu: bad arguments");
+        return;
+    }
+    if(lantern_gpu_device_count() <= 0) { FAIL(e, kNoDevice); return; }
+    if(n == 0) return;
+    const size_t chunks = (subvector_dim + 3) / 4, rw = chunks * 4;
+    std::vector<float> hp(n * rw, 0.f), hc(k * rw, 0.f);
+    for(size_t i = 0; i < n; ++i) std::memcpy(&hp[ i * rw ], dataset + i * row_dims + subvector_start, subvector_dim * 4);
+    for(size_t j = 0; j < k; ++j) std::memcpy(&hc[ j * rw ], centers + j * subvector_dim, subvector_dim * 4);
+    void *dp = nullptr, *dc = nullptr, *dout = nullptr;
+    bool  ok = hipMalloc(&dp, hp.size() * 4) == hipSuccess && hipMalloc(&dc, hc.size() * 4) == hipSuccess &&
+              hipMalloc(&dout, n * 8) == hipSuccess;
+    ok = ok && hipMemcpy(dp, hp.data(), hp.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(dc, hc.data(), hc.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    // first minimum wins (strict `<` in the reference loop) == smallest (distance, index)
+    ok = ok && exact_knn_device((int)metric, (uint32_t)chunks, (const uint4 *)dc, k, (const uint4 *)dp, n, 1, (uint32_t *)dout,
+                                (float *)((uint32_t *)dout + n), nullptr);
+    ok = ok && hipMemcpy(out_cluster, dout, n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(out_distance) ok = ok && hipMemcpy(out_distance, (uint32_t *)dout + n, n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(dp) (void)hipFree(dp);
+    if(dc) (void)hipFree(dc);
+    if(dout) (void)hipFree(dout);
+    if(!ok) FAIL(e, "lantern_gpu: HIP failure in assign_to_clusters");
 }
 
 // ---- SQL-callable semantics (hnsw.c:296-405) ---------------------------------------------------------

@@ -358,3 +358,19 @@ def test_mirror_through_retriever_matches_direct_index(capi):
     sb = capi.Scan(b, init_k=4)
     sb.rescan(queries[0])
     assert sa.fetch(25) == sb.fetch(25)
+
+
+@pytest.mark.parametrize("metric", ["l2sq", "cos"])
+def test_assign_to_clusters_matches_reference_loop(capi, oracle, metric):
+    # product_quantization.c:80-124: argmin_j usearch_distance(subvector, center_j), first minimum wins
+    rng = np.random.default_rng(21)
+    data = rng.standard_normal((5000, 48), dtype=np.float32)
+    start, sdim, k = 16, 12, 256
+    centers = data[rng.choice(5000, k, replace=False), start:start + sdim].copy()
+    centers[7] = centers[3]  # an exact tie: the lower index must win
+    idx, dist = capi.assign_to_clusters(data, centers, metric, start, sdim)
+    sub = np.ascontiguousarray(data[:, start:start + sdim])
+    for i in range(0, 5000, 97):
+        d = np.array([oracle.distance(sub[i], c, metric, oracle.SUM_WAVE64) for c in centers], dtype=np.float32)
+        assert idx[i] == int(np.argmin(d)) and dist[i] == d.min()
+    assert not np.any(idx == 7)
