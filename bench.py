@@ -51,6 +51,7 @@ def parse():
     p.add_argument("--truth-queries", type=int, default=1024, help="queries used for recall@k")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--quant", default="f32", choices=["f32", "f16"], help="storage kind (reloption quant_bits 32 / 16); the headline config is f32")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only to debug the N>1 path on one GPU")
     p.add_argument("--data", default="gaussian", choices=["gaussian", "lowrank"],
                    help="gaussian = the prescribed i.i.d. N(0,1) set (SURVEY 8d); lowrank = 32 latent dims embedded in --dim (embedding-like)")
@@ -100,7 +101,7 @@ def main():
     t_gen = time.time() - t0
 
     # ---- build the index on this rank's GPU (replica per GPU; deterministic, so all replicas match)
-    ix = capi.GpuIndex(a.metric, a.dim, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
+    ix = capi.GpuIndex(a.metric, a.dim, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, quantization=a.quant)
     ix.reserve(a.n)
     ix.set_add_batch(a.add_batch, 16)
     ix.set_search_shape(a.waves, a.max_wg)
@@ -116,7 +117,7 @@ def main():
     qrng = np.random.default_rng(4 + 1000 * rank)
     nq = a.queries
     queries = make_queries(qrng, nq)
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False))
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False, a.quant == "f16"))
     d_lab, d_dist, d_slot = hip.Buffer(nq * a.k * 8), hip.Buffer(nq * a.k * 4), hip.Buffer(nq * a.k * 4)
     d_D, d_E = hip.Buffer(nq * 8), hip.Buffer(nq * 8)
     stream = hip.Stream()  # the launch stream; the events below are recorded on it
@@ -152,7 +153,7 @@ def main():
     # ---- algorithmic bytes of one launch --------------------------------------------
     D = d_D.download(nq, np.uint64).astype(np.float64)
     E = d_E.download(nq, np.uint64).astype(np.float64)
-    row_bytes = a.dim * 4
+    row_bytes = a.dim * (2 if a.quant == "f16" else 4)
     bytes_per_launch = float((D * row_bytes + E * (2 * a.M * 4) + row_bytes).sum())
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved = bytes_per_launch / avg_kernel_s / 1e9
@@ -176,7 +177,7 @@ def main():
         if os.path.exists(prof):
             try:
                 rec = json.load(open(prof))
-                key = f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves}"
+                key = f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves}" + ("" if a.quant == "f32" else "_" + a.quant)
                 traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -193,9 +194,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if a.quant == "f32" else "f32 arithmetic on f16 storage",
             "data": "synthetic" if a.data == "gaussian" else "synthetic (low-rank)",
-            "config": {"workload": f"HNSW search {a.n}x{a.dim} f32 {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}",
+            "config": {"workload": f"HNSW search {a.n}x{a.dim} {a.quant} {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}",
                        "queries_per_step_per_gpu": nq, "global_queries_per_step": nq * world, "waves_per_query": a.waves,
                        "parallelism": f"replicated index, query batch sharded x{world}, no collective"},
             f"recall_at_{a.k}": recall,
@@ -243,6 +244,8 @@ def cpu_baseline(a, ix, base, queries, gpu_found):
 
     cores = usable_cores()
     g = ix.export_graph()
+    if a.quant == "f16":  # the CPU port works on the rounded values (f32 arithmetic, no conversion cost: favours the CPU)
+        base, queries = oracle.round_f16(base), oracle.round_f16(queries)
     ora = oracle.OracleIndex.from_graph(a.metric, base, g, a.M, a.efc, a.ef, 42, oracle.SUM_FAST)
     # size the samples from a short probe so the whole leg stays near the budget (about 30 % of it
     # for the 1-thread leg, 70 % for the all-cores leg).  The all-cores sample cycles through the

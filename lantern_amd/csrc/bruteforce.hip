@@ -230,6 +230,30 @@ __global__ void __launch_bounds__(256) k_rerank(const uint4 *Q, const uint4 *B, 
     }
 }
 
+// f16 rows (8 halves per chunk) -> f32 rows (4 floats per chunk) for the MFMA contraction
+__global__ void __launch_bounds__(256) k_dequant_f16(const uint4 *src, size_t nchunks, uint4 *dst)
+{
+    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = src[ i ];
+        float       f[ 8 ];
+        unpack_h2(v.x, f[ 0 ], f[ 1 ]);
+        unpack_h2(v.y, f[ 2 ], f[ 3 ]);
+        unpack_h2(v.z, f[ 4 ], f[ 5 ]);
+        unpack_h2(v.w, f[ 6 ], f[ 7 ]);
+        dst[ 2 * i ] = make_uint4(__float_as_uint(f[ 0 ]), __float_as_uint(f[ 1 ]), __float_as_uint(f[ 2 ]), __float_as_uint(f[ 3 ]));
+        dst[ 2 * i + 1 ] = make_uint4(__float_as_uint(f[ 4 ]), __float_as_uint(f[ 5 ]), __float_as_uint(f[ 6 ]), __float_as_uint(f[ 7 ]));
+    }
+}
+
+hipError_t launch_dequant_f16(const uint4 *src, size_t nchunks, uint4 *dst, hipStream_t stream)
+{
+    if(nchunks == 0) return hipSuccess;
+    size_t blocks = (nchunks + 255) / 256;
+    if(blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_dequant_f16, dim3((uint32_t)blocks), dim3(256), 0, stream, src, nchunks, dst);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 hipError_t launch_row_norms(const uint4 *rows, uint32_t n, uint32_t chunks, float *out, hipStream_t stream)
 {
@@ -286,6 +310,8 @@ hipError_t launch_rerank(int metric, const uint4 *Q, uint32_t nq, const uint4 *B
         case M_L2SQ: RRG(M_L2SQ); break;
         case M_COS: RRG(M_COS); break;
         case M_HAMMING: RRG(M_HAMMING); break;
+        case M_L2SQ_F16: RRG(M_L2SQ_F16); break;
+        case M_COS_F16: RRG(M_COS_F16); break;
         default: return hipErrorInvalidValue;
     }
 #undef RRG

@@ -1,7 +1,7 @@
 // device_common.hpp -- gfx950 device primitives shared by every kernel of the HNSW path.
 //
 // Numerics contract: a row of d f32 scalars is zero-padded to whole
-// 16-byte chunks; G lanes (8/16/32/64, chosen from the chunk count) cooperate on one row; lane l
+// 16-byte chunks; G lanes (8/16/32/64, chosen from the chunk count: group_lanes_for) cooperate on one row; lane l
 // owns chunks l, l+G, l+2G... and runs ONE fmaf chain per accumulator over its scalars in memory
 // order; the G partials are combined by a butterfly with offsets 1, 2, 4 .. G/2 (each step adds the
 // partner's running sum), executed as DPP adds (quad_perm, row_half_mirror, row_mirror, row_bcast15,
@@ -21,6 +21,14 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr int M_COS = 1;
 constexpr int M_L2SQ = 3;
 constexpr int M_HAMMING = 8;
+// the same metrics over f16 STORAGE (quant_bits = 16, lantern_hnsw/src/hnsw/options.c:137-158): rows hold 8
+// halves per 16-byte chunk; every element is converted to f32 (exactly) and the arithmetic is the f32
+// arithmetic above -- usearch's metric_*_gt<f16_t, f32>.  Internal codes = metric + 100.
+constexpr int M_F16 = 100;
+constexpr int M_COS_F16 = M_COS + M_F16;
+constexpr int M_L2SQ_F16 = M_L2SQ + M_F16;
+__host__ __device__ inline bool mcode_is_f16(int m) { return m >= M_F16; }
+__host__ __device__ inline int  mcode_base(int m) { return m >= M_F16 ? m - M_F16 : m; }
 
 // ---- order-preserving float <-> u32, and the (distance, slot) candidate key ---------------------
 __device__ __forceinline__ uint32_t f2ord(float f)
@@ -129,6 +137,51 @@ template <> struct Acc<M_HAMMING>
     }
 };
 
+// ---- f16 storage: two halves per 32-bit word, low half first ---------------------------------------------
+typedef _Float16 lgpu_half2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void unpack_h2(uint32_t w, float &lo, float &hi)
+{
+    const lgpu_half2 v = __builtin_bit_cast(lgpu_half2, w);
+    lo = (float)v[ 0 ];
+    hi = (float)v[ 1 ];
+}
+
+template <> struct Acc<M_L2SQ_F16>
+{
+    float s = 0.f;
+    __device__ __forceinline__ void word(uint32_t xw, uint32_t yw)
+    {
+        float x0, x1, y0, y1, t;
+        unpack_h2(xw, x0, x1);
+        unpack_h2(yw, y0, y1);
+        t = x0 - y0; s = __builtin_fmaf(t, t, s);
+        t = x1 - y1; s = __builtin_fmaf(t, t, s);
+    }
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb)
+    {
+        word(xa.x, yb.x); word(xa.y, yb.y); word(xa.z, yb.z); word(xa.w, yb.w);
+    }
+    template <int G> __device__ __forceinline__ float finish() { return group_sum<G>(s); }
+};
+
+template <> struct Acc<M_COS_F16>
+{
+    Acc<M_COS> f;
+    __device__ __forceinline__ void word(uint32_t xw, uint32_t yw)
+    {
+        float x0, x1, y0, y1;
+        unpack_h2(xw, x0, x1);
+        unpack_h2(yw, y0, y1);
+        f.one(x0, y0);
+        f.one(x1, y1);
+    }
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb)
+    {
+        word(xa.x, yb.x); word(xa.y, yb.y); word(xa.z, yb.z); word(xa.w, yb.w);
+    }
+    template <int G> __device__ __forceinline__ float finish() { return f.template finish<G>(); }
+};
+
 // One distance by one G-lane group: a and b each `chunks` uint4 long; gl = lane index in group.
 // The value is complete in the LAST lane of the group (gl == G-1); other lanes hold partial sums.
 template <int METRIC, int G, typename PA, typename PB>
@@ -162,7 +215,10 @@ __device__ __forceinline__ void group_dist2(PA a, PB b0, PB b1, int chunks, int 
 }
 
 // lanes per row for a row of `chunks` 16-byte chunks (oracle: lo_wave_group_lanes)
-__host__ __device__ inline int group_lanes_for(uint32_t chunks) { return chunks >= 64 ? 64 : chunks >= 32 ? 32 : chunks >= 16 ? 16 : 8; }
+// Every lane should own at least two chunks (two 16-byte loads in flight per row per lane), so short rows are
+// shared by fewer lanes and a wave works on several rows at once: G = 64 from 128 chunks (d >= 512 f32 /
+// 1024 f16), 32 from 64, 16 from 32, else 8.
+__host__ __device__ inline int group_lanes_for(uint32_t chunks) { return chunks >= 128 ? 64 : chunks >= 64 ? 32 : chunks >= 32 ? 16 : 8; }
 
 // ---- read-only view of the index in HBM -----------------------------------------------------------
 struct View

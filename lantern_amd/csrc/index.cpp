@@ -116,16 +116,33 @@ bool ensure_bitmaps(Index *ix, size_t slots)
     return true;
 }
 
-bool pad_row(const Index *ix, const void *vec, uint32_t *dst)
+// bytes of one caller-side vector of scalar kind `kind_in`
+size_t input_bytes(const Index *ix, int kind_in)
+{
+    if(kind_in == usearch_scalar_b1_k) return (ix->opts.dimensions + 7) / 8;
+    if(kind_in == usearch_scalar_f16_k) return ix->opts.dimensions * 2;
+    return ix->opts.dimensions * 4;
+}
+
+// which caller-side scalar kinds an index takes: its own storage kind, and f32 for an f16 index (Lantern
+// hands f32 arrays to usearch_add / usearch_search_ef whatever quant_bits says: build.c:128, scan.c:220)
+bool kind_accepted(const Index *ix, int kind_in)
+{
+    return kind_in == ix->scalar || (ix->scalar == usearch_scalar_f16_k && kind_in == usearch_scalar_f32_k);
+}
+
+// caller vector -> stored row (zero padded to whole 16-byte chunks).  f32 -> f16 is round-to-nearest-even,
+// the cast usearch applies at add and at search time for a quant_bits=16 index.
+bool pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst)
 {
     const size_t row_words = (size_t)ix->chunks * 4;
-    if(ix->scalar == usearch_scalar_b1_k) {
-        const size_t bytes = (ix->opts.dimensions + 7) / 8;
-        std::memset(dst, 0, row_words * 4);
-        std::memcpy(dst, vec, bytes);
+    std::memset(dst, 0, row_words * 4);
+    if(ix->scalar == usearch_scalar_f16_k && kind_in == usearch_scalar_f32_k) {
+        const float *f = (const float *)vec;
+        _Float16    *h = (_Float16 *)dst;
+        for(size_t i = 0; i < ix->opts.dimensions; ++i) h[ i ] = (_Float16)f[ i ];
     } else {
-        std::memcpy(dst, vec, (size_t)ix->words * 4);
-        for(size_t i = ix->words; i < row_words; ++i) dst[ i ] = 0;
+        std::memcpy(dst, vec, input_bytes(ix, kind_in));
     }
     return true;
 }
@@ -201,7 +218,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
     ia.bm_words = (uint32_t)ix->bm_words;
     ia.totals = ix->d_totals + 2;
     if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
-    HIPCHK(ix, launch_insert(ix->metric, ia, ix->insert_waves, grid, ix->stream));
+    HIPCHK(ix, launch_insert(ix->mcode, ia, ix->insert_waves, grid, ix->stream));
 
     // pinned landing buffer for the requests
     if(ix->h_links_cap < total_links) {
@@ -245,7 +262,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
         ra.totals = ix->d_totals + 5;
         void *d_work = scratch(ix, 4, (size_t)ngroups * 8 + 16);
         if(!d_work) return false;
-        HIPCHK(ix, launch_revlink(ix->metric, ra, (char *)d_work + 16, (uint32_t *)d_work, ix->num_cus, ix->stream));
+        HIPCHK(ix, launch_revlink(ix->mcode, ra, (char *)d_work + 16, (uint32_t *)d_work, ix->num_cus, ix->stream));
         HIPCHK(ix, hipStreamSynchronize(ix->stream));  // h / gb are reused by the next batch
     }
     ix->n = first + b;
@@ -360,7 +377,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.bitmaps = ix->d_bitmaps;
     a.bm_words = (uint32_t)ix->bm_words;
     a.totals = ix->d_totals;
-    HIPCHK(ix, launch_search(ix->metric, a, waves, grid, stream));
+    HIPCHK(ix, launch_search(ix->mcode, a, waves, grid, stream));
     ix->c_search_queries += nq;
     return true;
 }
@@ -439,14 +456,19 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     if(o->connectivity < 2 || o->connectivity > 128) { FAIL(e, "lantern_gpu: connectivity (M) must be in [2, 128]"); return nullptr; }  // options.c:165-179
     const bool ham = o->metric_kind == usearch_metric_hamming_k;
     if(ham && o->quantization != usearch_scalar_b1_k) { FAIL(e, "lantern_gpu: hamming needs b1 scalars"); return nullptr; }
-    if(!ham && o->quantization != usearch_scalar_f32_k) { FAIL(e, "lantern_gpu: only f32 storage is supported for cos/l2sq (quant_bits=32)"); return nullptr; }
+    if(!ham && o->quantization != usearch_scalar_f32_k && o->quantization != usearch_scalar_f16_k) {
+        FAIL(e, "lantern_gpu: only f32 storage and f16 storage are supported for cos/l2sq (quant_bits=32 or 16)");  // options.c:137-158
+        return nullptr;
+    }
     if(lantern_gpu_device_count() <= 0) { FAIL(e, kNoDevice); return nullptr; }
 
     Index *ix = new Index();
     ix->opts = *o;
     ix->metric = (int)o->metric_kind;
     ix->scalar = (int)o->quantization;
-    ix->words = ham ? (uint32_t)((o->dimensions + 31) / 32) : (uint32_t)o->dimensions;
+    const bool f16 = o->quantization == usearch_scalar_f16_k;
+    ix->mcode = ix->metric + (f16 ? M_F16 : 0);
+    ix->words = ham ? (uint32_t)((o->dimensions + 31) / 32) : f16 ? (uint32_t)((o->dimensions + 1) / 2) : (uint32_t)o->dimensions;
     ix->chunks = (ix->words + 3) / 4;
     ix->M = (uint32_t)o->connectivity;
     ix->M0 = 2 * ix->M;  // validate_index.c:140-151
@@ -516,12 +538,12 @@ size_t usearch_dimensions(usearch_index_t h, usearch_error_t *e)
 static void add_common(Index *ix, const usearch_label_t *labels, const void *vectors, size_t n, usearch_scalar_kind_t kind,
                        int level, usearch_error_t *e)
 {
-    if((int)kind != ix->scalar) { FAIL(e, "lantern_gpu: scalar kind of the vector does not match the index"); return; }
+    if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the vector does not match the index"); return; }
     if(!vectors || !labels) { FAIL(e, "lantern_gpu: null vector or label pointer"); return; }
     std::lock_guard<std::mutex> g(ix->mu);
     const size_t row_words = (size_t)ix->chunks * 4;
-    const size_t in_bytes = ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4;
-    if(n >= ix->add_batch_max && in_bytes == row_words * 4 && level < 0) {
+    const size_t in_bytes = input_bytes(ix, (int)kind);
+    if(n >= ix->add_batch_max && (int)kind == ix->scalar && in_bytes == row_words * 4 && level < 0) {
         // bulk insert of rows that need no padding: upload straight from the caller's buffer (it is borrowed
         // for the duration of this call) instead of staging a copy
         if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
@@ -534,7 +556,7 @@ static void add_common(Index *ix, const usearch_label_t *labels, const void *vec
     ix->pend_labels.insert(ix->pend_labels.end(), labels, labels + n);
     ix->pend_levels.insert(ix->pend_levels.end(), n, level);
     ix->pend_rows.resize((base + n) * row_words);
-    for(size_t i = 0; i < n; ++i) pad_row(ix, (const char *)vectors + i * in_bytes, &ix->pend_rows[ (base + i) * row_words ]);
+    for(size_t i = 0; i < n; ++i) pad_row(ix, (const char *)vectors + i * in_bytes, (int)kind, &ix->pend_rows[ (base + i) * row_words ]);
     if(ix->pend_labels.size() >= ix->add_batch_max && !flush_locked(ix)) FAIL(e, ix->err.c_str());
 }
 
@@ -607,7 +629,7 @@ size_t usearch_search_ef(usearch_index_t h, const void *query, usearch_scalar_ki
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return 0;
-    if((int)kind != ix->scalar) { FAIL(e, "lantern_gpu: scalar kind of the query does not match the index"); return 0; }
+    if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the query does not match the index"); return 0; }
     if(k == 0) return 0;
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return 0; }
@@ -617,7 +639,7 @@ size_t usearch_search_ef(usearch_index_t h, const void *query, usearch_scalar_ki
     char        *buf = (char *)scratch(ix, 4, row + k * (8 + 4) + 16);
     if(!buf) { FAIL(e, ix->err.c_str()); return 0; }
     std::vector<uint32_t> padded((size_t)ix->chunks * 4);
-    pad_row(ix, query, padded.data());
+    pad_row(ix, query, (int)kind, padded.data());
     uint64_t *d_lab = (uint64_t *)(buf + row);
     float    *d_dist = (float *)(buf + row + k * 8);
     uint32_t *d_cnt = (uint32_t *)(buf + row + k * 12);
@@ -658,14 +680,14 @@ void lantern_gpu_search_batch(usearch_index_t h, const void *queries, size_t nq,
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
-    if((int)kind != ix->scalar) { FAIL(e, "lantern_gpu: scalar kind of the queries does not match the index"); return; }
+    if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the queries does not match the index"); return; }
     if(nq == 0 || k == 0) return;
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
     const size_t row_words = (size_t)ix->chunks * 4;
-    const size_t in_bytes = ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4;
+    const size_t in_bytes = input_bytes(ix, (int)kind);
     std::vector<uint32_t> padded(nq * row_words);
-    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, &padded[ i * row_words ]);
+    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
     char *dq = (char *)scratch(ix, 5, nq * row_words * 4);
     char *dout = (char *)scratch(ix, 6, nq * k * 12 + nq * 4 + 64);
     if(!dq || !dout) { FAIL(e, ix->err.c_str()); return; }
@@ -751,12 +773,12 @@ void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uin
     char        *buf = (char *)scratch(ix, 5, row + n * 8 + 16);
     if(!buf) { FAIL(e, ix->err.c_str()); return; }
     std::vector<uint32_t> padded((size_t)ix->chunks * 4);
-    pad_row(ix, query, padded.data());
+    pad_row(ix, query, ix->scalar == usearch_scalar_b1_k ? usearch_scalar_b1_k : usearch_scalar_f32_k, padded.data());
     uint32_t *d_slots = (uint32_t *)(buf + row);
     float    *d_out = (float *)(buf + row + n * 4);
     bool      ok = hipMemcpyAsync(buf, padded.data(), row, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(d_slots, slots, n * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-    ok = ok && launch_gather(ix->metric, ix->view(), (const uint4 *)buf, d_slots, (uint32_t)n, d_out, ix->stream) == hipSuccess;
+    ok = ok && launch_gather(ix->mcode, ix->view(), (const uint4 *)buf, d_slots, (uint32_t)n, d_out, ix->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in distance_gather");
@@ -765,39 +787,53 @@ void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uin
 // Exact k-NN of nq device-resident query rows over nb device-resident base rows (both `chunks` uint4 per row):
 // fp32-MFMA contraction in chunks of 64k base rows + running top-(k+16) + exact-order re-rank.
 // Result (device): slots[nq][k] ascending by (distance, slot), dists[nq][k].
-static bool exact_knn_device(int metric, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
+static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
                              uint32_t *d_slots, float *d_dists, hipStream_t st)
 {
     // kk = k plus a margin: the MFMA distances (|q|^2 + |b|^2 - 2 q.b) differ from the exact-order ones in the
     // last bits, so the survivors are re-ranked exactly and only then cut to k
     const uint32_t kk = (uint32_t)k + 16;
     const size_t   QT = 1024, CH = std::min<size_t>(nb, 65536);
-    char *aux = nullptr;
+    const bool     f16 = mcode_is_f16(mcode);
+    const int      base_metric = mcode_base(mcode);
+    const uint32_t fchunks = f16 ? chunks * 2 : chunks;  // chunks of the f32 view fed to the contraction
+    char  *aux = nullptr;
     float *dd = nullptr;
+    uint4 *fq = nullptr, *fb = nullptr;  // f32 copies of f16 rows (queries; one chunk of base rows)
     bool ok = hipMalloc((void **)&aux, (nq + nb) * 4 + 8 + nq * kk * 8) == hipSuccess &&
               hipMalloc((void **)&dd, std::min(nq, QT) * CH * 4) == hipSuccess;
+    if(ok && f16)
+        ok = hipMalloc((void **)&fq, nq * (size_t)fchunks * 16) == hipSuccess && hipMalloc((void **)&fb, CH * (size_t)fchunks * 16) == hipSuccess &&
+             launch_dequant_f16(d_q, nq * (size_t)chunks, fq, st) == hipSuccess;
     if(ok) {
         float    *qn = (float *)aux, *bn = qn + nq;
         uint64_t *best = (uint64_t *)(aux + (nq + nb) * 4 + ((nq + nb) % 2) * 4);
+        const uint4 *qv = f16 ? fq : d_q;
         ok = ok && hipMemsetAsync(best, 0xFF, nq * kk * 8, st) == hipSuccess;
-        if(metric != M_HAMMING) {
-            ok = ok && launch_row_norms(d_q, (uint32_t)nq, chunks, qn, st) == hipSuccess;
-            ok = ok && launch_row_norms(d_base, (uint32_t)nb, chunks, bn, st) == hipSuccess;
-        }
-        for(size_t q0 = 0; ok && q0 < nq; q0 += QT) {
-            const size_t nqt = std::min(QT, nq - q0);
-            for(size_t c0 = 0; ok && c0 < nb; c0 += CH) {
-                const size_t nc = std::min(CH, nb - c0);
-                ok = ok && launch_dense(metric, d_q + q0 * chunks, (uint32_t)nqt, d_base + c0 * chunks, (uint32_t)nc, chunks, qn + q0, bn + c0, dd,
-                                        (uint32_t)CH, st) == hipSuccess;
+        if(base_metric != M_HAMMING) ok = ok && launch_row_norms(qv, (uint32_t)nq, fchunks, qn, st) == hipSuccess;
+        if(base_metric != M_HAMMING && !f16) ok = ok && launch_row_norms(d_base, (uint32_t)nb, fchunks, bn, st) == hipSuccess;
+        for(size_t c0 = 0; ok && c0 < nb; c0 += CH) {
+            const size_t nc = std::min(CH, nb - c0);
+            const uint4 *bv = d_base + c0 * chunks;
+            if(f16) {
+                ok = ok && launch_dequant_f16(d_base + c0 * chunks, nc * (size_t)chunks, fb, st) == hipSuccess;
+                ok = ok && launch_row_norms(fb, (uint32_t)nc, fchunks, bn + c0, st) == hipSuccess;
+                bv = fb;
+            }
+            for(size_t q0 = 0; ok && q0 < nq; q0 += QT) {
+                const size_t nqt = std::min(QT, nq - q0);
+                ok = ok && launch_dense(base_metric, qv + q0 * fchunks, (uint32_t)nqt, bv, (uint32_t)nc, fchunks, qn + q0, bn + c0, dd, (uint32_t)CH,
+                                        st) == hipSuccess;
                 ok = ok && launch_select(dd, (uint32_t)CH, (uint32_t)nqt, (uint32_t)nc, (uint32_t)c0, best + q0 * kk, kk, st) == hipSuccess;
             }
         }
-        ok = ok && launch_rerank(metric, d_q, (uint32_t)nq, d_base, chunks, best, kk, (uint32_t)k, d_slots, d_dists, st) == hipSuccess;
+        ok = ok && launch_rerank(mcode, d_q, (uint32_t)nq, d_base, chunks, best, kk, (uint32_t)k, d_slots, d_dists, st) == hipSuccess;
         ok = ok && hipStreamSynchronize(st) == hipSuccess;
     }
     if(aux) (void)hipFree(aux);
     if(dd) (void)hipFree(dd);
+    if(fq) (void)hipFree(fq);
+    if(fb) (void)hipFree(fb);
     return ok;
 }
 
@@ -815,9 +851,10 @@ void lantern_gpu_exact_search(usearch_index_t h, const void *queries, size_t nq,
         for(size_t i = 0; i < nq * k; ++i) { slots[ i ] = EMPTY; distances[ i ] = INFINITY; }
         return;
     }
-    const size_t in_bytes = ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4;
+    const int    qkind = ix->scalar == usearch_scalar_b1_k ? usearch_scalar_b1_k : usearch_scalar_f32_k;  // queries arrive as f32 / bits
+    const size_t in_bytes = input_bytes(ix, qkind);
     std::vector<uint32_t> padded(nq * row_words);
-    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, &padded[ i * row_words ]);
+    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, qkind, &padded[ i * row_words ]);
     uint4 *dq = (uint4 *)scratch(ix, 5, nq * row_words * 4);
     char  *dout = (char *)scratch(ix, 6, nq * k * 8 + 64);
     if(!dq || !dout) { FAIL(e, ix->err.c_str()); return; }
@@ -825,7 +862,7 @@ void lantern_gpu_exact_search(usearch_index_t h, const void *queries, size_t nq,
     float    *d_dists = (float *)(d_slots + nq * k);
     hipStream_t st = ix->stream;
     bool ok = hipMemcpyAsync(dq, padded.data(), nq * row_words * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-    ok = ok && exact_knn_device(ix->metric, ix->chunks, ix->d_vec, n, dq, nq, k, d_slots, d_dists, st);
+    ok = ok && exact_knn_device(ix->mcode, ix->chunks, ix->d_vec, n, dq, nq, k, d_slots, d_dists, st);
     ok = ok && hipMemcpy(slots, d_slots, nq * k * 4, hipMemcpyDeviceToHost) == hipSuccess;
     ok = ok && hipMemcpy(distances, d_dists, nq * k * 4, hipMemcpyDeviceToHost) == hipSuccess;
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in exact_search");

@@ -15,8 +15,9 @@ struct Index
 {
     // ---- configuration (usearch_init_options_t as Lantern fills it) -------------------------------
     usearch_init_options_t opts{};
-    int      metric = 0;
-    int      scalar = 0;         // usearch_scalar_f32_k or usearch_scalar_b1_k
+    int      metric = 0;         // usearch_metric_kind_t
+    int      mcode = 0;          // kernel metric code: metric, +100 for f16 storage (device_common.hpp)
+    int      scalar = 0;         // STORAGE kind: usearch_scalar_f32_k, _f16_k (quant_bits=16) or _b1_k
     uint32_t words = 0;          // 4-byte words per vector as the caller supplies it
     uint32_t chunks = 0;         // 16-byte chunks per stored row (zero padded)
     uint32_t M = 16, M0 = 32, efc = 128, ef = 64;
@@ -81,7 +82,9 @@ const char *set_err(Index *ix, const std::string &msg);
 bool        flush_locked(Index *ix);            // false -> ix->err set
 bool        ensure_bitmaps(Index *ix, size_t slots);
 void       *scratch(Index *ix, int which, size_t bytes);
-bool        pad_row(const Index *ix, const void *vec, uint32_t *dst);
+bool        pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst);
+size_t      input_bytes(const Index *ix, int kind_in);
+bool        kind_accepted(const Index *ix, int kind_in);
 int         search_grid(const Index *ix, size_t nq, int waves);
 bool        run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, size_t ef, size_t skip,
                               uint64_t *d_labels, float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D,

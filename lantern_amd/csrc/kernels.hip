@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_revlink_slab: the re-prune for the common shape (rows of >= 64 chunks, i.e. d >= 256, and cap <= 32,
+// k_revlink_slab: the re-prune for the common shape (rows of >= 128 chunks, i.e. G = 64: d >= 512 f32, and cap <= 32,
 // i.e. M <= 16), restructured so that several workgroups fit on a CU.
 //
 // A re-prune needs the distances between all <= 33 candidates (and from `close` to the old entries):
@@ -449,6 +449,46 @@ template <> struct PairAcc<M_HAMMING>
     }
     __device__ __forceinline__ float sum() { return (float)group_sum<64>(s); }
 };
+
+template <> struct PairAcc<M_L2SQ_F16>
+{
+    Acc<M_L2SQ_F16> a;
+    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y) { a.add(x, y); }
+    __device__ __forceinline__ float sum() { return group_sum<64>(a.s); }
+};
+template <> struct PairAcc<M_COS_F16>
+{
+    float s = 0.f;  // ab only
+    __device__ __forceinline__ void word(uint32_t xw, uint32_t yw)
+    {
+        float x0, x1, y0, y1;
+        unpack_h2(xw, x0, x1);
+        unpack_h2(yw, y0, y1);
+        s = __builtin_fmaf(x0, y0, s);
+        s = __builtin_fmaf(x1, y1, s);
+    }
+    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y) { word(x.x, y.x); word(x.y, y.y); word(x.z, y.z); word(x.w, y.w); }
+    __device__ __forceinline__ float sum() { return group_sum<64>(s); }
+};
+// per-row sum of squares for the cosine metrics: the a2 / b2 chain of Acc<M_COS>
+template <int METRIC> __device__ __forceinline__ void norm_add(const uint4 &z, float &acc)
+{
+    if(METRIC == M_COS_F16) {
+        const uint32_t w[ 4 ] = { z.x, z.y, z.z, z.w };
+#pragma unroll
+        for(int i = 0; i < 4; ++i) {
+            float lo, hi;
+            unpack_h2(w[ i ], lo, hi);
+            acc = __builtin_fmaf(lo, lo, acc);
+            acc = __builtin_fmaf(hi, hi, acc);
+        }
+    } else {
+        acc = __builtin_fmaf(__uint_as_float(z.x), __uint_as_float(z.x), acc);
+        acc = __builtin_fmaf(__uint_as_float(z.y), __uint_as_float(z.y), acc);
+        acc = __builtin_fmaf(__uint_as_float(z.z), __uint_as_float(z.z), acc);
+        acc = __builtin_fmaf(__uint_as_float(z.w), __uint_as_float(z.w), acc);
+    }
+}
 
 __host__ __device__ inline size_t slab_lds_bytes()
 {
@@ -561,22 +601,19 @@ __global__ void __launch_bounds__(512, 4) k_revlink_slab(RevlinkArgs a, const Re
                             if(k + u < SLAB_PPW) acc[ k + u ].add(xs[ u ], ys[ u ]);
                         __builtin_amdgcn_sched_barrier(0);  // one batch of loads in flight, not all eighteen
                     }
-                    if(METRIC == M_COS) {  // per-row sums of squares; rows past n are clamped (result unused)
+                    if(METRIC == M_COS || METRIC == M_COS_F16) {  // per-row sums of squares; rows past n are clamped (result unused)
 #pragma unroll
                         for(int k = 0; k < SLAB_RPW; ++k) {
                             const int   r = wv + SLAB_WAVES * k;
                             const uint4 z = slab[ (r <= n ? r : n) * 64 + lane ];
-                            nrm[ k ] = __builtin_fmaf(__uint_as_float(z.x), __uint_as_float(z.x), nrm[ k ]);
-                            nrm[ k ] = __builtin_fmaf(__uint_as_float(z.y), __uint_as_float(z.y), nrm[ k ]);
-                            nrm[ k ] = __builtin_fmaf(__uint_as_float(z.z), __uint_as_float(z.z), nrm[ k ]);
-                            nrm[ k ] = __builtin_fmaf(__uint_as_float(z.w), __uint_as_float(z.w), nrm[ k ]);
+                            norm_add<METRIC>(z, nrm[ k ]);
                         }
                     }
                 }
                 __syncthreads();
             }
             // ---- reduce: lane 63 holds the sums
-            if(METRIC == M_COS) {
+            if(METRIC == M_COS || METRIC == M_COS_F16) {
 #pragma unroll
                 for(int k = 0; k < SLAB_RPW; ++k) {
                     const int   r = wv + SLAB_WAVES * k;
@@ -595,7 +632,7 @@ __global__ void __launch_bounds__(512, 4) k_revlink_slab(RevlinkArgs a, const Re
                 }
             }
             __syncthreads();
-            if(METRIC == M_COS) {  // finish 1 - ab / (sqrt(a2) sqrt(b2)) with the zero-norm rules
+            if(METRIC == M_COS || METRIC == M_COS_F16) {  // finish 1 - ab / (sqrt(a2) sqrt(b2)) with the zero-norm rules
                 for(int cell = tid; cell < NR * NR; cell += T) {
                     const int i = cell / NR, j = cell - i * NR;
                     if(j < i && i <= n) {
@@ -723,6 +760,14 @@ __global__ void __launch_bounds__(256) k_pairs(const uint4 *a, uint32_t na, cons
                 switch(G_) { case 64: CALL(M_HAMMING, 64); break; case 32: CALL(M_HAMMING, 32); break; \
                              case 16: CALL(M_HAMMING, 16); break; default: CALL(M_HAMMING, 8); } \
                 break;                                                        \
+            case M_L2SQ_F16:                                                  \
+                switch(G_) { case 64: CALL(M_L2SQ_F16, 64); break; case 32: CALL(M_L2SQ_F16, 32); break; \
+                             case 16: CALL(M_L2SQ_F16, 16); break; default: CALL(M_L2SQ_F16, 8); } \
+                break;                                                        \
+            case M_COS_F16:                                                   \
+                switch(G_) { case 64: CALL(M_COS_F16, 64); break; case 32: CALL(M_COS_F16, 32); break; \
+                             case 16: CALL(M_COS_F16, 16); break; default: CALL(M_COS_F16, 8); } \
+                break;                                                        \
             default: return hipErrorInvalidValue;                             \
         }                                                                     \
     } while(0)
@@ -761,8 +806,8 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
     if(a.ngroups == 0) return hipSuccess;
     // staged variant whenever the 2M+2 rows of a level-0 re-prune fit in LDS (d <= 1024 at M = 16)
     const size_t staged = staged_lds_bytes(a.view.chunks, a.view.M0);
-    if(a.view.chunks >= 64 && a.view.M0 <= 32 && work && work_count) {
-        // common shape (d >= 256, M <= 16): column-slab sweep, 2 x 8 waves per CU
+    if(a.view.chunks >= 128 && a.view.M0 <= 32 && work && work_count) {
+        // common shape (G = 64: d >= 512 f32 / 1024 f16, and M <= 16): column-slab sweep, 2 x 8 waves per CU
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;
         hipLaunchKernelGGL(k_revlink_append, dim3((a.ngroups + 3) / 4), dim3(256), 0, stream, a, (RevWork *)work, work_count);
@@ -772,6 +817,8 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
             case M_L2SQ: hipLaunchKernelGGL((k_revlink_slab<M_L2SQ>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
             case M_COS: hipLaunchKernelGGL((k_revlink_slab<M_COS>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
             case M_HAMMING: hipLaunchKernelGGL((k_revlink_slab<M_HAMMING>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
+            case M_L2SQ_F16: hipLaunchKernelGGL((k_revlink_slab<M_L2SQ_F16>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
+            case M_COS_F16: hipLaunchKernelGGL((k_revlink_slab<M_COS_F16>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

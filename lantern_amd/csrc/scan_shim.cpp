@@ -50,7 +50,8 @@ void lantern_scan_rescan(lantern_scan_t *s, const void *query, usearch_scalar_ki
     if(e) *e = nullptr;
     if(!s || !query) { if(e) *e = "cannot scan hnsw index without order"; return; }  // scan.c:192
     lgpu::Index *ix = (lgpu::Index *)s->index;
-    const size_t bytes = ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4;
+    if(!lgpu::kind_accepted(ix, (int)kind)) { if(e) *e = "lantern_gpu: scalar kind of the query does not match the index"; return; }
+    const size_t bytes = lgpu::input_bytes(ix, (int)kind);
     s->query.assign((const char *)query, (const char *)query + bytes);
     s->scalar = kind;
     s->first = true;  // ldb_amrescan: scanstate->first = true (scan.c:150)

@@ -46,7 +46,8 @@ constexpr size_t OFF_G_ENTRY_SLOT = 112;        // u64
 template <typename T> void put(char *p, size_t off, T v) { std::memcpy(p + off, &v, sizeof(T)); }
 template <typename T> T    get(const char *p, size_t off) { T v; std::memcpy(&v, p + off, sizeof(T)); return v; }
 
-size_t vector_bytes(const Index *ix) { return ix->scalar == usearch_scalar_b1_k ? (ix->opts.dimensions + 7) / 8 : (size_t)ix->words * 4; }
+// bytes of one stored vector on the tape: dimensions * bits_per_scalar / 8 (usearch_storage.cpp:63-81)
+size_t vector_bytes(const Index *ix) { return input_bytes(ix, ix->scalar); }
 size_t node_bytes(const Index *ix, int level)
 {
     return 8 + 2 + (4 + (size_t)ix->M0 * LANTERN_SLOT_SIZE) + (size_t)level * (4 + (size_t)ix->M * LANTERN_SLOT_SIZE) + vector_bytes(ix);
@@ -160,8 +161,8 @@ bool deserialize(Index *ix, const char *buf, size_t len)
         p += node_bytes(ix, level);
     }
     if(upper.empty()) upper.push_back(EMPTY);
-    // hamming rows are stored as bytes in the file; the importer wants whole u32 words per row
-    if(ix->scalar == usearch_scalar_b1_k && vb != (size_t)ix->words * 4) {
+    // bit / f16 rows are stored as bytes in the file; the importer wants whole u32 words per row
+    if(vb != (size_t)ix->words * 4) {
         std::vector<char> w(n * (size_t)ix->words * 4, 0);
         for(size_t i = 0; i < n; ++i) std::memcpy(&w[ i * (size_t)ix->words * 4 ], &vecs[ i * vb ], vb);
         vecs.swap(w);

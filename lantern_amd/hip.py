@@ -122,8 +122,19 @@ class Event:
         return float(ms.value)
 
 
-def padded_rows(x: np.ndarray, metric_is_hamming: bool) -> np.ndarray:
-    """Rows zero-padded to whole 16-byte chunks: the layout the device entry points expect."""
+def padded_rows(x: np.ndarray, metric_is_hamming: bool, f16: bool = False) -> np.ndarray:
+    """Rows in STORAGE format, zero-padded to whole 16-byte chunks: the layout the device entry points expect
+    (u32 words for hamming, f32, or halves for an f16 index: the cast is round-to-nearest-even)."""
+    if f16:
+        a = np.ascontiguousarray(x, dtype=np.float32).astype(np.float16)
+        if a.ndim == 1:
+            a = a.reshape(1, -1)
+        w = (a.shape[1] + 7) // 8 * 8
+        if w == a.shape[1]:
+            return a
+        out = np.zeros((a.shape[0], w), dtype=np.float16)
+        out[:, : a.shape[1]] = a
+        return out
     a = np.ascontiguousarray(x, dtype=np.uint32 if metric_is_hamming else np.float32)
     if a.ndim == 1:
         a = a.reshape(1, -1)

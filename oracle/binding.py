@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liblantern_oracle.so")
 
 METRIC_COS, METRIC_L2SQ, METRIC_HAMMING = 1, 3, 8
-SUM_SEQ, SUM_WAVE64, SUM_FAST = 0, 1, 2
+SUM_SEQ, SUM_WAVE64, SUM_FAST, SUM_WAVE64_F16 = 0, 1, 2, 3
 EMPTY = 0xFFFFFFFF
 
 METRICS = {"cos": METRIC_COS, "l2sq": METRIC_L2SQ, "hamming": METRIC_HAMMING}
@@ -104,6 +104,11 @@ def distance(a, b, metric: str | int, sum_mode: int = SUM_SEQ) -> float:
         raise ValueError("expected equally sized arrays")
     dims = A.size * 32 if m == METRIC_HAMMING else A.size
     return float(lib().lo_distance(_ptr(A), _ptr(B), dims, m, sum_mode))
+
+
+def round_f16(x) -> np.ndarray:
+    """f32 -> f16 -> f32, round-to-nearest-even: what an f16 index stores and what it casts a query to."""
+    return np.ascontiguousarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
 
 
 def level_for(seed: int, slot: int, M: int) -> int:

@@ -65,14 +65,15 @@ static float hamming_bits(const uint8_t *a, const uint8_t *b, size_t bits)
  * (the device executes it as DPP adds and reads the sum from lane G-1; every lane of a true xor
  * butterfly holds the same bits, so p[0] below is that value).
  */
-int lo_wave_group_lanes(size_t dims)
+static int group_lanes(size_t dims, size_t epc)
 {
-    size_t chunks = (dims + 3) / 4;
-    if(chunks >= 64) return 64;
-    if(chunks >= 32) return 32;
-    if(chunks >= 16) return 16;
+    size_t chunks = (dims + epc - 1) / epc; /* device rule (device_common.hpp group_lanes_for): >= 2 chunks per lane */
+    if(chunks >= 128) return 64;
+    if(chunks >= 64) return 32;
+    if(chunks >= 32) return 16;
     return 8;
 }
+int lo_wave_group_lanes(size_t dims) { return group_lanes(dims, 4); }
 
 static void butterfly(float *p, int G)
 {
@@ -83,16 +84,19 @@ static void butterfly(float *p, int G)
     }
 }
 
-static float l2sq_wave(const float *a, const float *b, size_t d)
+/* epc = scalars per 16-byte chunk: 4 for f32 storage, 8 for f16 storage (LO_SUM_WAVE64_F16).  For f16
+ * storage the caller passes values already rounded to f16 (usearch casts f32 -> f16 at add and at search
+ * and its metric_*_gt<f16_t, f32> converts every element back to f32 before the arithmetic). */
+static float l2sq_wave(const float *a, const float *b, size_t d, size_t epc)
 {
-    int    G = lo_wave_group_lanes(d);
-    size_t chunks = (d + 3) / 4;
+    int    G = group_lanes(d, epc);
+    size_t chunks = (d + epc - 1) / epc;
     float  p[ 64 ];
     for(int l = 0; l < G; ++l) {
         float acc = 0.f;
         for(size_t ch = (size_t)l; ch < chunks; ch += (size_t)G) {
-            for(size_t c = 0; c < 4; ++c) {
-                size_t i = ch * 4 + c;
+            for(size_t c = 0; c < epc; ++c) {
+                size_t i = ch * epc + c;
                 float  x = i < d ? a[ i ] : 0.f, y = i < d ? b[ i ] : 0.f;
                 float  t = x - y;
                 acc = fmaf(t, t, acc);
@@ -104,16 +108,16 @@ static float l2sq_wave(const float *a, const float *b, size_t d)
     return p[ 0 ];
 }
 
-static float cos_wave(const float *a, const float *b, size_t d)
+static float cos_wave(const float *a, const float *b, size_t d, size_t epc)
 {
-    int    G = lo_wave_group_lanes(d);
-    size_t chunks = (d + 3) / 4;
+    int    G = group_lanes(d, epc);
+    size_t chunks = (d + epc - 1) / epc;
     float  pab[ 64 ], pa2[ 64 ], pb2[ 64 ];
     for(int l = 0; l < G; ++l) {
         float ab = 0.f, a2 = 0.f, b2 = 0.f;
         for(size_t ch = (size_t)l; ch < chunks; ch += (size_t)G) {
-            for(size_t c = 0; c < 4; ++c) {
-                size_t i = ch * 4 + c;
+            for(size_t c = 0; c < epc; ++c) {
+                size_t i = ch * epc + c;
                 float  x = i < d ? a[ i ] : 0.f, y = i < d ? b[ i ] : 0.f;
                 ab = fmaf(x, y, ab);
                 a2 = fmaf(x, x, a2);
@@ -135,7 +139,9 @@ float lo_distance(const void *a, const void *b, size_t dims, int metric, int sum
     if(metric == LO_METRIC_HAMMING) return hamming_bits((const uint8_t *)a, (const uint8_t *)b, dims);
     if(sum_mode == LO_SUM_FAST) return lo_distance_fast(a, b, dims, metric);
     const float *x = (const float *)a, *y = (const float *)b;
-    if(metric == LO_METRIC_L2SQ) return sum_mode == LO_SUM_WAVE64 ? l2sq_wave(x, y, dims) : l2sq_seq(x, y, dims);
-    if(metric == LO_METRIC_COS) return sum_mode == LO_SUM_WAVE64 ? cos_wave(x, y, dims) : cos_seq(x, y, dims);
+    const int wave = sum_mode == LO_SUM_WAVE64 || sum_mode == LO_SUM_WAVE64_F16;
+    const size_t epc = sum_mode == LO_SUM_WAVE64_F16 ? 8 : 4;
+    if(metric == LO_METRIC_L2SQ) return wave ? l2sq_wave(x, y, dims, epc) : l2sq_seq(x, y, dims);
+    if(metric == LO_METRIC_COS) return wave ? cos_wave(x, y, dims, epc) : cos_seq(x, y, dims);
     return NAN;
 }

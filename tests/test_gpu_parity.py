@@ -374,3 +374,47 @@ def test_assign_to_clusters_matches_reference_loop(capi, oracle, metric):
         d = np.array([oracle.distance(sub[i], c, metric, oracle.SUM_WAVE64) for c in centers], dtype=np.float32)
         assert idx[i] == int(np.argmin(d)) and dist[i] == d.min()
     assert not np.any(idx == 7)
+
+
+# ------------------------------------------------------------------------------------------------
+# f16 storage (reloption quant_bits = 16, options.c:137-158): vectors and queries arrive as f32, are cast to
+# f16 (round-to-nearest-even), and every distance is the f32 arithmetic on the rounded values
+# (usearch metric_*_gt<f16_t, f32>).  The oracle gets the rounded values and the 8-scalars-per-chunk order.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric,n,d,M,efc", [("l2sq", 1500, 768, 16, 64), ("cos", 900, 200, 8, 40), ("l2sq", 600, 33, 4, 24)])
+def test_f16_storage_matches_oracle(capi, oracle, metric, n, d, M, efc):
+    rng = np.random.default_rng(n + d)
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    queries = rng.standard_normal((48, d), dtype=np.float32)
+    rb, rq = oracle.round_f16(base), oracle.round_f16(queries)
+    labels = np.arange(n, dtype=np.uint64) + 1
+    # build: device (f32 in, cast on add) vs oracle on the rounded values, same batch plan
+    ora = oracle.OracleIndex(metric, d, M=M, ef_construction=efc, ef=48, seed=5, sum_mode=oracle.SUM_WAVE64_F16)
+    ora.add_planned(labels, rb, max_batch=256, min_ratio=8)
+    gpu = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=48, seed=5, quantization="f16")
+    gpu.set_add_batch(256, 8)
+    gpu.add_many(labels, base)
+    go, gg = ora.export_graph(), gpu.export_graph(with_vectors=True)
+    assert np.array_equal(gg["nbr0"], go["nbr0"]) and np.array_equal(gg["upper_nbr"], go["upper_nbr"])
+    assert np.array_equal(gg["vectors"], base.astype(np.float16))
+    # search: ids, distances and counters identical
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(rq, 10)
+    lab, dist, cnt = gpu.search_batch(queries, 10)
+    assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist)
+    # the distance kernel alone, and the exact k-NN (MFMA contraction on the dequantised rows + exact re-rank)
+    slots = rng.integers(0, n, 40).astype(np.uint32)
+    ref = np.array([oracle.distance(rq[0], rb[s], metric, oracle.SUM_WAVE64_F16) for s in slots], dtype=np.float32)
+    assert np.array_equal(gpu.distance_gather(queries[0], slots), ref)
+    e_slots, e_dists = gpu.exact_search(queries, 10)
+    t_ids, t_d = oracle.bruteforce(rb, rq, 10, metric, oracle.SUM_WAVE64_F16, 8)
+    assert np.array_equal(e_slots, t_ids) and np.array_equal(e_dists, t_d)
+    # against the f32 index the f16 one is a quantisation, not a different algorithm: distances agree to f16 precision
+    full = oracle.OracleIndex.from_graph(metric, base, go, M, efc, 48, 5, oracle.SUM_SEQ)
+    _, f_dist, _, _, _ = full.search_batch(queries, 10)
+    assert np.median(np.abs(f_dist - o_dist) / np.maximum(np.abs(f_dist), 1e-6)) < 5e-3
+    # file: the tape holds d * 2 vector bytes
+    blob = gpu.save_buffer()
+    assert len(blob) == 136 + sum(10 + (4 + 2 * M * 6) + int(l) * (4 + M * 6) + d * 2 for l in gg["levels"])
+    other = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=48, seed=5, quantization="f16")
+    other.load_buffer(blob)
+    assert np.array_equal(other.search_batch(queries, 10)[0], lab)

@@ -114,5 +114,23 @@ def test_hamming_and_larger_build(capi, server):
     hits = sum(int(ix.search(base[i], 1)[0][0]) == i + 1 for i in range(0, 3000, 30))
     assert n == 3000 and hits >= 95
     # quantised storage is refused with an error frame, not a hang
-    with pytest.raises(ic.IndexServerError, match="only f32 storage"):
-        ic.build_index(server.host, server.port, 3, 32, [], [], element_bits=16, quantization=3)
+    with pytest.raises(ic.IndexServerError, match="only f32 storage and f16 storage"):
+        ic.build_index(server.host, server.port, 3, 32, [], [], element_bits=8, quantization=4)
+    # quant_bits = 16: PostgreSQL still streams f32 rows (element_bits = 32); the index stores halves.
+    # The Rust tests also stream raw halves (element_bits = 16): both give the same index file.
+    n1, f1 = ic.build_index(server.host, server.port, 3, 32, [r.tobytes() for r in base[:600]], np.arange(600) + 1, m=8, efc=32, ef=16,
+                            element_bits=32, quantization=3)
+    n2, f2 = ic.build_index(server.host, server.port, 3, 32, [r.astype(np.float16).tobytes() for r in base[:600]], np.arange(600) + 1, m=8,
+                            efc=32, ef=16, element_bits=16, quantization=3)
+    assert n1 == n2 == 600 and f1 == f2
+    assert len(f1) == 136 + sum(10 + (4 + 16 * 6) + lv * (4 + 8 * 6) + 32 * 2 for lv in _levels_of(f1, 600, 8, 64))
+
+
+def _levels_of(blob, n, M, vec_bytes):
+    out, off = [], 136
+    for _ in range(n):
+        lv = struct.unpack_from("<H", blob, off + 8)[0]
+        out.append(lv)
+        off += 10 + (4 + 2 * M * 6) + lv * (4 + M * 6) + vec_bytes
+    assert off == len(blob)
+    return out
