@@ -242,6 +242,7 @@ def cpu_baseline(a, ix, base, queries, gpu_found):
     """The oracle (CPU port of the usearch path) on the identical graph, on this host's cores."""
     from oracle import binding as oracle
 
+    native = oracle.build_native() and oracle.use_native(True)  # best CPU code for the baseline: -march=native on this host
     cores = usable_cores()
     g = ix.export_graph()
     if a.quant == "f16":  # the CPU port works on the rounded values (f32 arithmetic, no conversion cost: favours the CPU)
@@ -278,6 +279,7 @@ def cpu_baseline(a, ix, base, queries, gpu_found):
             "sample": f"{nall} queries (the step's {queries.shape[0]} cycled x{reps}) on {cores} threads, one query per thread "
                       f"(server.rs:317-359 model); {n1} queries on 1 thread (a PostgreSQL backend, utils.c:66)",
             "value_1_thread": qps_1t, "topk_overlap_with_gpu": agree,
+            "build": "gcc -O3 -march=native + the reference's -fassociative-math flags" if native else "gcc -O3 -march=x86-64-v3 + the reference's -fassociative-math flags",
             "note": "oracle/hnsw.c restates the usearch algorithm; the reference binary itself cannot be built here"}
 
 

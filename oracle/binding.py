@@ -13,6 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liblantern_oracle.so")
+NATIVE_LIB_PATH = os.path.join(HERE, "_build_native", "liblantern_oracle.so")
 
 METRIC_COS, METRIC_L2SQ, METRIC_HAMMING = 1, 3, 8
 SUM_SEQ, SUM_WAVE64, SUM_FAST, SUM_WAVE64_F16 = 0, 1, 2, 3
@@ -31,7 +32,30 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def build_native() -> bool:
+    """Rebuild the oracle with -march=native INTO A SEPARATE DIRECTORY on the machine that will time it
+    (the reference's own build offers -march=native: lantern_hnsw/CMakeLists.txt:134-136).  Used by
+    bench.py's cpu_baseline leg so the CPU gets its best code; the portable x86-64-v3 build stays the
+    one the tests use.  Returns False when no compiler is available."""
+    try:
+        # -B: always recompile here -- objects built for another host's `native` must never be reused
+        subprocess.check_call(["make", "-s", "-B", "-C", HERE, "ORACLE_MARCH=native", "BUILD=_build_native"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return os.path.exists(NATIVE_LIB_PATH)
+    except Exception:
+        return False
+
+
 _lib = None
+_use_native = False
+
+
+def use_native(flag: bool = True):
+    """Select the -march=native build for subsequently loaded handles (call before lib())."""
+    global _use_native, _lib
+    _use_native = flag and os.path.exists(NATIVE_LIB_PATH)
+    _lib = None
+    return _use_native
 
 
 def lib() -> C.CDLL:
@@ -40,7 +64,7 @@ def lib() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(NATIVE_LIB_PATH if _use_native else LIB_PATH)
     vp, sz, u32, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int
     L.lo_distance.restype = C.c_float
     L.lo_distance.argtypes = [vp, vp, sz, i32, i32]
