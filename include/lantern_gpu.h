@@ -113,8 +113,9 @@ LANTERN_GPU_EXPORT size_t usearch_dimensions(usearch_index_t, usearch_error_t *)
  * device (see lantern_gpu_set_add_batch); any reader (search/size/save) flushes first. */
 LANTERN_GPU_EXPORT void usearch_add(usearch_index_t, usearch_label_t, const void *vector, usearch_scalar_kind_t,
                                     usearch_error_t *);
-/* scan.c:220-228,273-281.  ef == 0 -> index default.  streaming == true returns the NEXT k
- * results of the same query after the ones already returned since the last non-streaming call. */
+/* scan.c:220-228,273-281.  ef == 0 -> index default.  streaming == true returns the NEXT k results of
+ * the same query: the index remembers what it handed out since the last non-streaming call, searches for
+ * that many + k, and returns the first k that were not returned before (never a row twice). */
 LANTERN_GPU_EXPORT size_t usearch_search_ef(usearch_index_t, const void *query, usearch_scalar_kind_t, size_t k,
                                             size_t ef, bool streaming, usearch_label_t *labels, float *distances,
                                             usearch_error_t *);

@@ -633,31 +633,43 @@ size_t usearch_search_ef(usearch_index_t h, const void *query, usearch_scalar_ki
     if(k == 0) return 0;
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return 0; }
-    const size_t skip = streaming ? ix->stream_returned : 0;
-    if(ix->n == 0) { ix->stream_returned = 0; return 0; }
+    if(!streaming) ix->stream_seen.clear();
+    if(ix->n == 0) return 0;
+    const size_t want = std::min(ix->stream_seen.size() + k, ix->n);  // enough to find k unseen ones
     const size_t row = (size_t)ix->chunks * 16;
-    char        *buf = (char *)scratch(ix, 4, row + k * (8 + 4) + 16);
+    char        *buf = (char *)scratch(ix, 4, row + want * (8 + 4 + 4) + 16);
     if(!buf) { FAIL(e, ix->err.c_str()); return 0; }
     std::vector<uint32_t> padded((size_t)ix->chunks * 4);
     pad_row(ix, query, (int)kind, padded.data());
+    // one result block: labels | distances | slots | count  -> one D2H copy
     uint64_t *d_lab = (uint64_t *)(buf + row);
-    float    *d_dist = (float *)(buf + row + k * 8);
-    uint32_t *d_cnt = (uint32_t *)(buf + row + k * 12);
-    uint32_t  got = 0;
-    bool      ok = hipMemcpyAsync(buf, padded.data(), row, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    float    *d_dist = (float *)(buf + row + want * 8);
+    uint32_t *d_slot = (uint32_t *)(buf + row + want * 12);
+    uint32_t *d_cnt = (uint32_t *)(buf + row + want * 16);
+    std::vector<char> host(want * 16 + 4);
+    bool ok = hipMemcpyAsync(buf, padded.data(), row, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     // one query: spend a whole 8-wave workgroup on it (latency-bound path)
-    ok = ok && run_search_device(ix, (const uint4 *)buf, 1, k, ef, skip, d_lab, d_dist, nullptr, d_cnt, nullptr, nullptr, ix->stream, 8);
-    ok = ok && hipMemcpyAsync(&got, d_cnt, 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(labels, d_lab, k * 8, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(distances, d_dist, k * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    ok = ok && run_search_device(ix, (const uint4 *)buf, 1, want, ef, 0, d_lab, d_dist, d_slot, d_cnt, nullptr, nullptr, ix->stream, 8);
+    ok = ok && hipMemcpyAsync(host.data(), buf + row, want * 16 + 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
     if(!ok) {
         if(ix->err.empty()) set_err(ix, "lantern_gpu: HIP failure during search");
         FAIL(e, ix->err.c_str());
         return 0;
     }
-    ix->stream_returned = skip + got;
-    return got;
+    const uint64_t *h_lab = (const uint64_t *)host.data();
+    const float    *h_dist = (const float *)(host.data() + want * 8);
+    const uint32_t *h_slot = (const uint32_t *)(host.data() + want * 12);
+    uint32_t        got;
+    std::memcpy(&got, host.data() + want * 16, 4);
+    size_t out = 0;
+    for(uint32_t i = 0; i < got && out < k; ++i) {
+        if(!ix->stream_seen.insert(h_slot[ i ]).second) continue;  // returned by an earlier call of this scan
+        labels[ out ] = h_lab[ i ];
+        distances[ out ] = h_dist[ i ];
+        ++out;
+    }
+    return out;
 }
 
 void lantern_gpu_search_batch_device(usearch_index_t h, const void *d_queries, size_t nq, size_t k, size_t ef, size_t skip,

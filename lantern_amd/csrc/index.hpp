@@ -4,6 +4,7 @@
 
 #include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/lantern_gpu.h"
@@ -64,7 +65,10 @@ struct Index
     size_t h_links_cap = 0;
 
     // ---- streaming continuation of usearch_search_ef (scan.c:273-281) ----------------------------
-    size_t stream_returned = 0;
+    // slots already handed out for the current query: a continuation searches for |seen| + k results and
+    // returns the first k that were not returned before, so a scan never sees a row twice even though a wider
+    // search may rank the earlier rows differently
+    std::unordered_set<uint32_t> stream_seen;
 
     // ---- counters ----------------------------------------------------------------------------------
     uint64_t c_search_queries = 0, c_add_vectors = 0, c_add_batches = 0;

@@ -418,3 +418,79 @@ def test_f16_storage_matches_oracle(capi, oracle, metric, n, d, M, efc):
     other = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=48, seed=5, quantization="f16")
     other.load_buffer(blob)
     assert np.array_equal(other.search_batch(queries, 10)[0], lab)
+
+
+# ------------------------------------------------------------------------------------------------
+# limits of the reloptions / GUCs (options.c:165-179,324-348; build.c:394-401) and concurrency
+# ------------------------------------------------------------------------------------------------
+def test_maximum_dimension_connectivity_and_ef(capi, oracle):
+    rng = np.random.default_rng(77)
+    # dim = 2000 is the largest row Lantern accepts (one node per 8 KB page); M = 128, ef_construction = ef = 400 are the caps
+    base = rng.standard_normal((260, 2000), dtype=np.float32)
+    labels = np.arange(260, dtype=np.uint64) + 1
+    ora = oracle.OracleIndex("l2sq", 2000, M=128, ef_construction=400, ef=400, seed=2, sum_mode=oracle.SUM_WAVE64)
+    ora.add_planned(labels, base, max_batch=64, min_ratio=4)
+    gpu = capi.GpuIndex("l2sq", 2000, M=128, ef_construction=400, ef=400, seed=2)
+    gpu.set_add_batch(64, 4)
+    gpu.add_many(labels, base)
+    assert np.array_equal(gpu.export_graph()["nbr0"], ora.export_graph()["nbr0"])
+    q = rng.standard_normal((8, 2000), dtype=np.float32)
+    o_lab, o_dist, _, _, _ = ora.search_batch(q, 200)
+    lab, dist, cnt = gpu.search_batch(q, 200)
+    assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist) and np.all(cnt == 200)
+    m = gpu.metadata()
+    assert m.neighbors_bytes == 4 + 128 * 6 and m.neighbors_base_bytes == 4 + 256 * 6
+    # the node tape of such a row still fits an 8 KB page only at M small; here we only check the size formula
+    assert len(gpu.save_buffer()) == 136 + sum(10 + (4 + 256 * 6) + int(l) * (4 + 128 * 6) + 8000 for l in gpu.export_graph()["levels"])
+
+
+def test_scan_stops_at_1000_rows_and_never_repeats(capi):
+    rng = np.random.default_rng(78)
+    base = rng.standard_normal((1800, 16), dtype=np.float32)
+    ix = capi.GpuIndex("l2sq", 16, M=16, ef_construction=64, ef=64, seed=1)
+    ix.add_many(np.arange(1800, dtype=np.uint64) + 1, base)
+    q = rng.standard_normal(16, dtype=np.float32)
+    for init_k in (1000, 10, 3):
+        s = capi.Scan(ix, init_k=init_k)
+        s.rescan(q)
+        got = s.fetch(5000)
+        assert len(set(got)) == len(got)
+        first_page = np.array([capi.l2sq_dist(base[l - 1], q) for l in got[:init_k]])
+        assert np.all(np.diff(first_page) >= 0)  # within a page the order is the index order
+        if init_k == 1000:
+            assert len(got) == 1000  # scan.c:249-252: no continuation once 1000 rows were loaded
+        else:
+            assert 1000 <= len(got) <= 1800  # the doubling continuation passes 1000 and is then cut off
+    with pytest.raises(capi.LanternGpuError, match="init_k"):
+        capi.Scan(ix, init_k=1001)  # GUC range 1..1000 (options.c:324-336)
+
+
+def test_concurrent_add_raw_from_many_threads(capi):
+    # the external indexer calls add_raw on ONE index from N threads (server.rs:333-356)
+    import threading
+
+    rng = np.random.default_rng(79)
+    base = rng.standard_normal((4000, 24), dtype=np.float32)
+    ix = capi.GpuIndex("l2sq", 24, M=8, ef_construction=32, ef=32, seed=1)
+    ix.set_add_batch(512, 16)
+    errors = []
+
+    def worker(t):
+        try:
+            for i in range(t, 4000, 8):
+                ix.add(i + 1, base[i])
+        except Exception as e:  # noqa
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    assert len(ix) == 4000
+    g = ix.export_graph(with_vectors=True)
+    assert sorted(g["labels"].tolist()) == list(range(1, 4001))
+    assert np.array_equal(g["vectors"], base[g["labels"].astype(np.int64) - 1])  # every row kept its own label
+    hits = sum(int(ix.search(base[i], 1)[0][0]) == i + 1 for i in range(0, 4000, 40))
+    assert hits >= 90  # M=8, ef=32: an ANN index, not an exact one

@@ -25,7 +25,7 @@ def build(oracle, metric, rows, M=16, efc=128, ef=64, sum_mode=0, batch=False):
 
 def ordered(oracle, ix, q, n):
     """All rows in index order, driven like the executor does (init_k=10)."""
-    return scan(lambda k, skip: ix.search(q, k, 0, skip)[:2], len(ix), n)
+    return scan(lambda k: ix.search(q, k), len(ix), n)
 
 
 @pytest.mark.parametrize("sum_mode", SUMS)
@@ -122,7 +122,7 @@ def test_streaming_continuation_counts(oracle, golden):
     rows = sw["v"] + [[99, 99, 2]]
     assert len(rows) == g["indexed_rows"]
     ix = build(oracle, "l2sq", rows, M=5, efc=20, ef=20)
-    search = lambda k, skip: ix.search(g["query"], k, 0, skip)[:2]
+    search = lambda k: ix.search(g["query"], k)
     assert len(scan(search, len(ix), 3, init_k=g["init_k"])) == g["limit_3_count"]
     got = scan(search, len(ix), 15, init_k=g["init_k"])
     assert len(got) == g["limit_15_count"] and len(set(got)) == len(got)
@@ -163,7 +163,7 @@ def test_pagination_with_duplicates(oracle, golden):
     ix = oracle.OracleIndex("l2sq", g["dim"], seed=7)
     ix.add_many(ids, rows)
     q = [g["dup_value"]] * g["dim"]
-    got = scan(lambda k, skip: ix.search(q, k, 0, skip)[:2], len(ix), g["limit"], init_k=g["init_k"])
+    got = scan(lambda k: ix.search(q, k), len(ix), g["limit"], init_k=g["init_k"])
     assert len(got) == g["limit"]
     assert len(set(got)) == len(got), "an id was returned twice while paginating"
 
