@@ -51,7 +51,7 @@ enum { LO_METRIC_COS = 1, LO_METRIC_L2SQ = 3, LO_METRIC_HAMMING = 8 };
 /* summation order for f32 metrics */
 enum {
     LO_SUM_SEQ = 0,    /* usearch metric_l2sq_gt / metric_cos_gt: one running f32 sum, i = 0..d-1 */
-    LO_SUM_WAVE64 = 1, /* device order: G-lane fmaf chains + xor butterfly */
+    LO_SUM_WAVE64 = 1, /* device order: G-lane fmaf chains + butterfly with offsets 1..G/2 */
     LO_SUM_FAST = 2,   /* same maths as SEQ, compiled with the reference's -fassociative-math flags
                           (lantern_hnsw/CMakeLists.txt:122-136): what the CPU baseline times */
     LO_SUM_WAVE64_F16 = 3 /* device order for f16 STORAGE (quant_bits=16, options.c:137-158): 8 scalars per
