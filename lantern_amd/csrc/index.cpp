@@ -354,7 +354,14 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     if(nq == 0 || k == 0) return true;
     size_t expansion = ef ? ef : ix->ef;
     if(expansion < k + skip) expansion = k + skip;  // usearch: expansion = max(expansion, wanted)
-    if(search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0) > 160 * 1024) {
+    // LDS visited set: sized for ~3x the planner's estimate of visited nodes per query (hnsw.c:89-132 puts it at
+    // about 2 M ef S with S ~ 3), capped so that four workgroups still fit on a CU; it spills to the bitmap beyond
+    uint32_t vis_slots = 1024;
+    while(vis_slots < 8192 && vis_slots / 4 * 3 < expansion * ix->M0 * 2) vis_slots <<= 1;
+    if(ix->search_vis_slots >= 0) vis_slots = (uint32_t)ix->search_vis_slots;
+    while(vis_slots && search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 38 * 1024) vis_slots >>= 1;
+    if(vis_slots && vis_slots < 4 * ix->M0) vis_slots = 0;
+    if(search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 160 * 1024) {
         set_err(ix, "lantern_gpu: ef/k exceed the 160 KiB LDS budget of the search kernel");
         return false;
     }
@@ -376,6 +383,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.out_E = d_E;
     a.bitmaps = ix->d_bitmaps;
     a.bm_words = (uint32_t)ix->bm_words;
+    a.vis_slots = vis_slots;
     a.totals = ix->d_totals;
     HIPCHK(ix, launch_search(ix->mcode, a, waves, grid, stream));
     ix->c_search_queries += nq;
@@ -475,6 +483,7 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     ix->efc = o->expansion_add ? (uint32_t)o->expansion_add : 128;      // options.h:18-24
     ix->ef = o->expansion_search ? (uint32_t)o->expansion_search : 64;
     if(const char *dv = std::getenv("LANTERN_GPU_DEVICE")) (void)hipSetDevice(std::atoi(dv));
+    if(const char *vs = std::getenv("LANTERN_GPU_VIS_SLOTS")) ix->search_vis_slots = std::atoi(vs);  // tuning/debug: 0 = bitmap only
     (void)hipGetDevice(&ix->device);
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, ix->device) == hipSuccess) ix->num_cus = prop.multiProcessorCount;

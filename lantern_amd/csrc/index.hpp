@@ -25,6 +25,7 @@ struct Index
     uint64_t seed = 42;
     size_t   add_batch_max = 8192, add_min_ratio = 16;
     int      search_waves = 4, search_max_wg = 0, insert_waves = 4;
+    int      search_vis_slots = -1;  // -1 = automatic size of the LDS visited set, 0 = HBM bitmap only
 
     // ---- graph state ------------------------------------------------------------------------------
     size_t   n = 0, cap = 0;

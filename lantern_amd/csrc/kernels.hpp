@@ -22,6 +22,7 @@ struct SearchArgs
     uint64_t       *out_E;       // [nq] or NULL
     uint32_t       *bitmaps;     // [grid][bm_words]
     uint32_t        bm_words;    // multiple of 4
+    uint32_t        vis_slots;   // LDS visited-set slots (power of two; 0 = HBM bitmap only)
     unsigned long long *totals;  // [2] cumulative D, E (atomicAdd) or NULL
 };
 
@@ -78,7 +79,7 @@ hipError_t launch_select(const float *dist, uint32_t ldo, uint32_t nq, uint32_t 
 hipError_t launch_rerank(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t chunks, const uint64_t *best, uint32_t kk,
                          uint32_t k, uint32_t *out_slots, float *out_dists, hipStream_t stream);
 
-size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0);
+size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots);
 size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0);
 
 }  // namespace lgpu

@@ -21,7 +21,7 @@
 namespace lgpu {
 
 // scalar slots in LDS
-enum { S_POS = 0, S_NNEW, S_CNT, S_ANY, S_BAD, S_CUR, S_CURD, S_CHANGED, S_SCALARS = 16 };
+enum { S_POS = 0, S_NNEW, S_CNT, S_ANY, S_BAD, S_CUR, S_CURD, S_CHANGED, S_VISCNT, S_SPILL, S_SCALARS = 16 };
 
 struct WalkLds
 {
@@ -32,10 +32,13 @@ struct WalkLds
     uint64_t *sorted;   // the same, sorted                  (cap_max)
     uint32_t *newids;   // unvisited neighbour slots         (cap_max)
     int      *scal;     // S_* scalars
+    uint32_t *vis;      // visited hash set (vis_slots entries, power of two; 0 = the HBM bitmap only)
+    uint32_t  vis_slots;
 };
 
 // Carve the workgroup's dynamic LDS.  Every offset stays 16-byte aligned.
-__device__ __forceinline__ unsigned char *carve_walk(unsigned char *p, WalkLds &s, uint32_t chunks, uint32_t ef_cap, uint32_t cap_max)
+__device__ __forceinline__ unsigned char *carve_walk(unsigned char *p, WalkLds &s, uint32_t chunks, uint32_t ef_cap, uint32_t cap_max,
+                                                     uint32_t vis_slots = 0)
 {
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     s.q = (uint4 *)p;            p += (size_t)chunks * 16;
@@ -45,12 +48,41 @@ __device__ __forceinline__ unsigned char *carve_walk(unsigned char *p, WalkLds &
     s.sorted = (uint64_t *)p;    p += up16((size_t)cap_max * 8);
     s.newids = (uint32_t *)p;    p += up16((size_t)cap_max * 4);
     s.scal = (int *)p;           p += S_SCALARS * 4;
+    s.vis = (uint32_t *)p;       p += (size_t)vis_slots * 4;
+    s.vis_slots = vis_slots;
     return p;
 }
-__host__ inline size_t walk_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t cap_max)
+__host__ inline size_t walk_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t cap_max, uint32_t vis_slots = 0)
 {
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return (size_t)chunks * 16 + 2 * up16((size_t)ef_cap * 8) + 2 * up16((size_t)cap_max * 8) + up16((size_t)cap_max * 4) + S_SCALARS * 4;
+    return (size_t)chunks * 16 + 2 * up16((size_t)ef_cap * 8) + 2 * up16((size_t)cap_max * 8) + up16((size_t)cap_max * 4) + S_SCALARS * 4 +
+           (size_t)vis_slots * 4;
+}
+
+// ---- visited set ------------------------------------------------------------------------------------------
+// usearch keeps a growing hash set of visited slots per search.  Here: an open-addressing hash set in LDS
+// (no HBM round trip per hop, nothing to clear in HBM per query) that SPILLS to the workgroup's HBM bitmap once it
+// is three quarters full: from then on new slots are recorded in the bitmap (cleared at that moment) and a
+// lookup consults both.  With vis_slots == 0 only the bitmap is used.
+__device__ __forceinline__ uint32_t vis_hash(uint32_t x, uint32_t slots) { return (x * 0x9E3779B1u) & (slots - 1); }
+
+// true if `x` was already visited; otherwise records it.  Called by the lanes of wave 0 only.
+__device__ __forceinline__ bool visit_test_and_set(WalkLds &s, uint32_t *bitmap, uint32_t x, bool spilled)
+{
+    if(s.vis_slots) {
+        uint32_t h = vis_hash(x, s.vis_slots);
+        for(;;) {
+            const uint32_t cur = spilled ? s.vis[ h ] : atomicCAS(&s.vis[ h ], EMPTY, x);
+            if(cur == x) return true;
+            if(cur == EMPTY) {
+                if(!spilled) { atomicAdd(&s.scal[ S_VISCNT ], 1); return false; }
+                break;  // not in the LDS set: the bitmap decides
+            }
+            h = (h + 1) & (s.vis_slots - 1);
+        }
+    }
+    const uint32_t bit = 1u << (x & 31);
+    return (atomicOr(&bitmap[ x >> 5 ], bit) & bit) != 0;
 }
 
 __device__ __forceinline__ int lower_bound_keys(const uint64_t *a, int n, uint64_t k)
@@ -126,7 +158,10 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
     const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
     const int lane = tid & 63;
     // visits.clear()
-    {
+    if(s.vis_slots) {
+        for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
+        if(tid == 0) { s.scal[ S_VISCNT ] = 0; s.scal[ S_SPILL ] = 0; }
+    } else {
         uint4 *b4 = (uint4 *)bitmap;
         for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
     }
@@ -136,8 +171,9 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
     }
     D += 1;
     __syncthreads();
-    if(tid == 0) atomicOr(&bitmap[ start >> 5 ], 1u << (start & 31));
-    int cnt = 1;
+    if(tid == 0) (void)visit_test_and_set(s, bitmap, start, false);
+    int  cnt = 1;
+    bool spilled = false;
     for(;;) {
         // ---- pop: first unexpanded entry of the list
         if(tid == 0) { s.scal[ S_POS ] = 0x7FFFFFFF; s.scal[ S_ANY ] = 0; }
@@ -149,6 +185,14 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         if(pos == 0x7FFFFFFF) break;
         const uint32_t node = key_slot(s.keys[ pos ]);
         E += 1;
+        // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (rare:
+        // the set holds 3/4 * vis_slots slots, a search visits D of them)
+        if(s.vis_slots && !spilled && (uint32_t)s.scal[ S_VISCNT ] + v.M0 > s.vis_slots / 4 * 3) {
+            uint4 *b4 = (uint4 *)bitmap;
+            for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
+            spilled = true;
+            __syncthreads();
+        }
         // ---- neighbour list + visited test-and-set, compacted in list order (wave 0)
         if(tid < 64) {
             uint32_t        cap;
@@ -158,11 +202,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                 uint32_t i = off + (uint32_t)lane;
                 uint32_t nb = i < cap ? list[ i ] : EMPTY;
                 bool     isnew = false;
-                if(nb != EMPTY) {
-                    uint32_t bit = 1u << (nb & 31);
-                    uint32_t old = atomicOr(&bitmap[ nb >> 5 ], bit);
-                    isnew = (old & bit) == 0;
-                }
+                if(nb != EMPTY) isnew = !visit_test_and_set(s, bitmap, nb, spilled);
                 unsigned long long m = __ballot(isnew);
                 if(isnew) s.newids[ base + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
                 base += __popcll(m);

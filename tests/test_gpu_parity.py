@@ -494,3 +494,26 @@ def test_concurrent_add_raw_from_many_threads(capi):
     assert np.array_equal(g["vectors"], base[g["labels"].astype(np.int64) - 1])  # every row kept its own label
     hits = sum(int(ix.search(base[i], 1)[0][0]) == i + 1 for i in range(0, 4000, 40))
     assert hits >= 90  # M=8, ef=32: an ANN index, not an exact one
+
+
+@pytest.mark.parametrize("vis_slots", ["0", "256", "1024"])
+def test_visited_set_variants_give_identical_walks(capi, oracle, vis_slots, monkeypatch):
+    # the LDS visited set spills to the HBM bitmap when it fills up: force "bitmap only" (0), "spills after a few hops"
+    # (256) and "spills late" (1024) and require the same ids, distances and counters every time
+    rng = np.random.default_rng(5)
+    base, queries = rng.standard_normal((4000, 64), dtype=np.float32), rng.standard_normal((64, 64), dtype=np.float32)
+    ora = oracle.OracleIndex("l2sq", 64, M=16, ef_construction=64, ef=128, seed=9, sum_mode=oracle.SUM_WAVE64)
+    ora.add_many(np.arange(4000, dtype=np.uint64) + 1, base)
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, 10)
+    monkeypatch.setenv("LANTERN_GPU_VIS_SLOTS", vis_slots)
+    gpu = capi.GpuIndex("l2sq", 64, M=16, ef_construction=64, ef=128, seed=9)
+    gpu.import_graph(base, ora.export_graph())
+    from lantern_amd import hip
+
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False))
+    lab, dist, D, E = hip.Buffer(64 * 10 * 8), hip.Buffer(64 * 10 * 4), hip.Buffer(64 * 8), hip.Buffer(64 * 8)
+    gpu.search_batch_device(dq.ptr, 64, 10, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr)
+    hip.synchronize()
+    assert np.array_equal(lab.download((64, 10), np.uint64), o_lab) and np.array_equal(dist.download((64, 10), np.float32), o_dist)
+    assert np.array_equal(D.download(64, np.uint64), o_D) and np.array_equal(E.download(64, np.uint64), o_E)
+    assert o_D.max() > 300  # more visits than 3/4 of 256 slots: the spill path really ran
