@@ -216,8 +216,14 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
     ia.links = d_links;
     ia.bitmaps = ix->d_bitmaps;
     ia.bm_words = (uint32_t)ix->bm_words;
+    // LDS visited set for the ef_construction-wide walk (spills to the bitmap when 3/4 full); env override for tuning
+    uint32_t ivis = 8192;
+    if(const char *vs = std::getenv("LANTERN_GPU_INSERT_VIS_SLOTS")) ivis = (uint32_t)std::atoi(vs);
+    while(ivis && insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 52 * 1024) ivis >>= 1;
+    if(ivis && ivis < 4 * ix->M0) ivis = 0;
+    ia.vis_slots = ivis;
     ia.totals = ix->d_totals + 2;
-    if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
+    if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
     HIPCHK(ix, launch_insert(ix->mcode, ia, ix->insert_waves, grid, ix->stream));
 
     // pinned landing buffer for the requests

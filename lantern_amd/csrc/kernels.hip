@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(512) k_insert(InsertArgs a)
     const int tid = threadIdx.x, T = blockDim.x;
     WalkLds   s;
     RefineLds r;
-    unsigned char *p = carve_walk(lgpu_smem, s, a.view.chunks, a.efc, a.view.M0);
+    unsigned char *p = carve_walk(lgpu_smem, s, a.view.chunks, a.efc, a.view.M0, a.vis_slots);
     carve_refine(p, r, a.efc);
     uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
     const uint32_t chunks = a.view.chunks, M = a.view.M;
@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(256) k_pairs(const uint4 *a, uint32_t na, cons
     } while(0)
 
 size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots) { return walk_lds_bytes(chunks, ef_cap, M0, vis_slots); }
-size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0) { return walk_lds_bytes(chunks, efc, M0) + refine_lds_bytes(efc); }
+size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0, uint32_t vis_slots) { return walk_lds_bytes(chunks, efc, M0, vis_slots) + refine_lds_bytes(efc); }
 
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream)
 {
@@ -790,7 +790,7 @@ hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, h
 
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream)
 {
-    const size_t lds = insert_lds_bytes(a.view.chunks, a.efc, a.view.M0);
+    const size_t lds = insert_lds_bytes(a.view.chunks, a.efc, a.view.M0, a.vis_slots);
 #define CALL(MM, GG)                                                                                          \
     {                                                                                                         \
         (void)hipFuncSetAttribute((const void *)k_insert<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -45,6 +45,7 @@ struct InsertArgs
     LinkReq        *links;
     uint32_t       *bitmaps;
     uint32_t        bm_words;
+    uint32_t        vis_slots;   // LDS visited-set slots (0 = HBM bitmap only)
     unsigned long long *totals;  // [3] cumulative D, E, refine-D
 };
 
@@ -80,6 +81,6 @@ hipError_t launch_rerank(int metric, const uint4 *Q, uint32_t nq, const uint4 *B
                          uint32_t k, uint32_t *out_slots, float *out_dists, hipStream_t stream);
 
 size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots);
-size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0);
+size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0, uint32_t vis_slots);
 
 }  // namespace lgpu
