@@ -199,10 +199,19 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
         link_off[ i ] = (uint32_t)total_links;
         total_links += (size_t)ix->M * (size_t)(lv[ i ] + 1);
     }
-    uint32_t *d_link_off = (uint32_t *)scratch(ix, 0, b * 4);
+    // one "item" per (new node, level): the walk result the selection kernel works on
+    const size_t items = total_links / ix->M;
+    std::vector<uint32_t> &item_node = ix->h_item_node;
+    item_node.resize(items);
+    for(size_t i = 0, it = 0; i < b; ++i)
+        for(int l = 0; l <= lv[ i ]; ++l) item_node[ it++ ] = (uint32_t)i;
+    uint32_t *d_link_off = (uint32_t *)scratch(ix, 0, b * 4 + items * 4 + items * 4);
     LinkReq  *d_links = (LinkReq *)scratch(ix, 1, total_links * sizeof(LinkReq));
-    if(!d_link_off || !d_links) return false;
+    uint64_t *d_tops = (uint64_t *)scratch(ix, 7, items * (size_t)ix->efc * 8);
+    if(!d_link_off || !d_links || !d_tops) return false;
+    uint32_t *d_item_node = d_link_off + b, *d_top_count = d_item_node + items;
     HIPCHK(ix, hipMemcpyAsync(d_link_off, link_off.data(), b * 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipMemcpyAsync(d_item_node, item_node.data(), items * 4, hipMemcpyHostToDevice, ix->stream));
 
     const int grid = search_grid(ix, b, ix->insert_waves);
     if(!ensure_bitmaps(ix, (size_t)grid)) return false;
@@ -213,7 +222,8 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
     ia.count = (uint32_t)b;
     ia.efc = ix->efc;
     ia.link_off = d_link_off;
-    ia.links = d_links;
+    ia.tops = d_tops;
+    ia.top_count = d_top_count;
     ia.bitmaps = ix->d_bitmaps;
     ia.bm_words = (uint32_t)ix->bm_words;
     // LDS visited set for the ef_construction-wide walk (spills to the bitmap when 3/4 full); env override for tuning
@@ -225,6 +235,19 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
     ia.totals = ix->d_totals + 2;
     if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
     HIPCHK(ix, launch_insert(ix->mcode, ia, ix->insert_waves, grid, ix->stream));
+
+    ConnectArgs ca;
+    ca.view = ia.view;
+    ca.first_slot = (uint32_t)first;
+    ca.items = (uint32_t)items;
+    ca.efc = ix->efc;
+    ca.link_off = d_link_off;
+    ca.item_node = d_item_node;
+    ca.tops = d_tops;
+    ca.top_count = d_top_count;
+    ca.links = d_links;
+    ca.totals = ix->d_totals + 4;
+    HIPCHK(ix, launch_connect(ix->mcode, ca, ix->stream));
 
     // pinned landing buffer for the requests
     if(ix->h_links_cap < total_links) {

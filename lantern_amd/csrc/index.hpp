@@ -60,7 +60,7 @@ struct Index
     std::vector<int>      pend_levels;  // -1 = draw with level_for()
 
     // reusable host staging for the batch loop
-    std::vector<uint32_t> h_link_off, h_group_begin;
+    std::vector<uint32_t> h_link_off, h_group_begin, h_item_node;
     std::vector<LinkReq>  h_reqs, h_reqs_tmp;
     void  *h_links = nullptr;  // pinned
     size_t h_links_cap = 0;

@@ -2,9 +2,10 @@
 //
 //   k_search   usearch_search_ef  (lantern_hnsw/src/hnsw/scan.c:220-228,273-281): one workgroup per
 //              query, persistent over the batch; greedy descent + ef-bounded base-layer walk.
-//   k_insert   the search half of usearch_add (build.c:128; server.rs:349 add_raw): per new vector,
-//              descent + per-level ef_construction walk + neighbour selection; emits reverse-link
-//              requests.
+//   k_insert   the walk of usearch_add (build.c:128; server.rs:349 add_raw): per new vector, descent +
+//              per-level ef_construction walk; the sorted results go to k_connect.
+//   k_connect  connect_new_node_: neighbour selection with the kept rows in registers; writes the new
+//              node's lists and emits the reverse-link requests.
 //   k_revlink  the reverse-link half (usearch reconnect_neighbor_nodes_): one workgroup per
 //              (node, level) that received requests; append or re-prune with the heuristic.
 //   k_gather   metric(query, row[slots[i]]) -- the distance kernel on its own (tests, profiling).
@@ -65,61 +66,189 @@ __global__ void __launch_bounds__(512) k_search(SearchArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_insert: the WALK half of an insertion.  Per new vector: descent to its level, then per level an
+// ef_construction-wide search_level whose sorted result (<= efc keys) goes to HBM for k_connect.  The start of
+// the next lower level is connect_new_node_'s first pick: the closest result under (distance, tie_mix).
 template <int METRIC, int G>
 __global__ void __launch_bounds__(512) k_insert(InsertArgs a)
 {
     const int tid = threadIdx.x, T = blockDim.x;
     WalkLds   s;
-    RefineLds r;
-    unsigned char *p = carve_walk(lgpu_smem, s, a.view.chunks, a.efc, a.view.M0, a.vis_slots);
-    carve_refine(p, r, a.efc);
+    carve_walk(lgpu_smem, s, a.view.chunks, a.efc, a.view.M0, a.vis_slots);
     uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
     const uint32_t chunks = a.view.chunks, M = a.view.M;
     for(uint32_t b = blockIdx.x; b < a.count; b += gridDim.x) {
         const uint32_t me = a.first_slot + b;
         const int      target = a.view.levels[ me ];
-        LinkReq       *out = a.links + a.link_off[ b ];
+        const uint32_t item0 = a.link_off[ b ] / M;  // one item per (node, level)
         {
             const uint4 *own = row_of(a.view, me);
             for(uint32_t i = tid; i < chunks; i += T) s.q[ i ] = own[ i ];
-            for(uint32_t i = tid; i < M * (uint32_t)(target + 1); i += T) out[ i ].close = EMPTY;
+            for(uint32_t i = tid; i <= (uint32_t)target; i += T) a.top_count[ item0 + i ] = 0;  // levels above max_level stay empty
         }
         __syncthreads();
-        uint32_t D = 0, E = 0, Dr = 0;
+        uint32_t D = 0, E = 0;
         uint32_t cur = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, target, D);
         for(int level = target < a.view.max_level ? target : a.view.max_level; level >= 0; --level) {
             const int cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, cur, level, (int)a.efc, D, E);
-            for(int i = tid; i < cnt; i += T) {
-                const uint64_t key = s.keys[ i ];
-                r.cd[ i ] = key_dist(key);
-                r.cid[ i ] = key_slot(key);
+            uint64_t *top = a.tops + (size_t)(item0 + (uint32_t)level) * a.efc;
+            for(int i = tid; i < cnt; i += T) top[ i ] = s.keys[ i ] & ~1ull;  // drop the "expanded" bit
+            if(tid == 0) {
+                a.top_count[ item0 + (uint32_t)level ] = (uint32_t)cnt;
+                // sel[0] of the heuristic = minimum by (distance, tie_mix(slot, me)): only an exact tie at the
+                // smallest distance can differ from keys[0]
+                const uint32_t d0 = (uint32_t)(s.keys[ 0 ] >> 32);
+                uint32_t       best = key_slot(s.keys[ 0 ]);
+                for(int i = 1; i < cnt && (uint32_t)(s.keys[ i ] >> 32) == d0; ++i) {
+                    const uint32_t id = key_slot(s.keys[ i ]);
+                    if(tie_mix(id, me) < tie_mix(best, me)) best = id;
+                }
+                s.scal[ S_CUR ] = (int)best;
             }
             __syncthreads();
-            // connect_new_node_: refine to `connectivity` (M) on EVERY level, also level 0
-            const int keep = refine<METRIC, G>(a.view, r, s.scal, cnt, (int)M, me, Dr);
-            uint32_t  cap;
-            uint32_t *list = neighbors_of(a.view, me, level, cap);
-            for(uint32_t i = tid; i < M; i += T) {
-                if((int)i < keep) {
-                    list[ i ] = r.sid[ i ];
-                    LinkReq req;
-                    req.close = r.sid[ i ];
-                    req.level = (uint32_t)level;
-                    req.new_slot = me;
-                    req.d = r.sd[ i ];
-                    out[ (uint32_t)level * M + i ] = req;
-                }
-            }
-            cur = r.sid[ 0 ];
+            cur = (uint32_t)s.scal[ S_CUR ];
             __syncthreads();
         }
         if(tid == 0 && a.totals) {
             atomicAdd(&a.totals[ 0 ], (unsigned long long)D);
             atomicAdd(&a.totals[ 1 ], (unsigned long long)E);
-            atomicAdd(&a.totals[ 2 ], (unsigned long long)Dr);
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_connect: connect_new_node_ -- the neighbour-selection heuristic over one walk result, one workgroup of four
+// waves per (new node, level).  It is its own kernel because its best shape differs from the walk's: the kept
+// rows live in REGISTERS (wave w owns kept entries w, w+4, w+8, w+12), every wave loads the candidate row once
+// (the next candidate's row is already in flight) and tests it against its own kept rows with no memory access,
+// so a candidate costs one barrier instead of a round of L2 reads.  Same lane/chunk ownership and reduction
+// tree as group_dist<METRIC, 64>, hence the same bits.  Rows that do not fit this shape (G < 64, more than 256
+// chunks, M > 16) take the generic refine().
+template <int METRIC, int G>
+__global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
+{
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    RefineLds r;
+    unsigned char *p = carve_refine(lgpu_smem, r, a.efc);
+    int      *scal = (int *)p;                  p += S_SCALARS * 4;
+    uint32_t *kid = (uint32_t *)p;              p += (size_t)((a.view.M + 3) & ~3u) * 4;  // selected slots (<= M)
+    float    *kd = (float *)p;
+    const uint32_t item = blockIdx.x;
+    const uint32_t b = a.item_node[ item ];
+    const uint32_t M = a.view.M;
+    const uint32_t me = a.first_slot + b;
+    const int      level = (int)(item - a.link_off[ b ] / M);
+    LinkReq       *out = a.links + a.link_off[ b ] + (uint32_t)level * M;
+    const int      n = (int)a.top_count[ item ];
+    const uint64_t *top = a.tops + (size_t)item * a.efc;
+    for(int i = tid; i < n; i += T) {
+        const uint64_t key = top[ i ];
+        r.cd[ i ] = key_dist(key);
+        r.cid[ i ] = key_slot(key);
+    }
+    __syncthreads();
+    uint32_t Dr = 0;
+    int      keep;
+    const int chunks = (int)a.view.chunks;
+    if(G == 64 && chunks <= 256 && M <= 16 && T == 256) {
+        // ---- sort by (distance, tie_mix(slot, me)) into sd / sid
+        for(int t = tid; t < n; t += T) {
+            const uint64_t k = ((uint64_t)f2ord(r.cd[ t ]) << 32) | tie_mix(r.cid[ t ], me);
+            int            rank = 0;
+            for(int j = 0; j < n; ++j) rank += (((uint64_t)f2ord(r.cd[ j ]) << 32) | tie_mix(r.cid[ j ], me)) < k;
+            r.sd[ rank ] = r.cd[ t ];
+            r.sid[ rank ] = r.cid[ t ];
+        }
+        if(tid < 3) scal[ tid ] = 0;  // three rotating "rejected" flags
+        __syncthreads();
+        if(n < (int)M) {  // refine_: fewer candidates than needed -> keep them all
+            keep = n;
+            for(int i = tid; i < n; i += T) { kid[ i ] = r.sid[ i ]; kd[ i ] = r.sd[ i ]; }
+        } else {
+            auto load_row = [&](uint32_t slot, uint4 (&v)[ 4 ]) {
+                const uint4 *row = row_of(a.view, slot);
+#pragma unroll
+                for(int c = 0; c < 4; ++c) {
+                    const int ch = lane + 64 * c;
+                    v[ c ] = ch < chunks ? row[ ch ] : make_uint4(0, 0, 0, 0);
+                }
+            };
+            uint4 kept[ 4 ][ 4 ], cur[ 4 ], nxt[ 4 ];
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+#pragma unroll
+                for(int c = 0; c < 4; ++c) kept[ j ][ c ] = make_uint4(0, 0, 0, 0);
+            load_row(r.sid[ 0 ], cur);
+            if(wave == 0) {
+#pragma unroll
+                for(int c = 0; c < 4; ++c) kept[ 0 ][ c ] = cur[ c ];
+            }
+            if(tid == 0) { kid[ 0 ] = r.sid[ 0 ]; kd[ 0 ] = r.sd[ 0 ]; }
+            int submitted = 1, consumed = 1;
+            if(n > 1) load_row(r.sid[ 1 ], nxt);
+            while(submitted < (int)M && consumed < n) {
+#pragma unroll
+                for(int c = 0; c < 4; ++c) cur[ c ] = nxt[ c ];
+                const float    cdist = r.sd[ consumed ];
+                const uint32_t cslot = r.sid[ consumed ];
+                if(consumed + 1 < n) load_row(r.sid[ consumed + 1 ], nxt);  // in flight while this one is tested
+                bool bad = false;
+#pragma unroll
+                for(int j = 0; j < 4; ++j) {
+                    if(wave + 4 * j < submitted) {  // wave-uniform
+                        Acc<METRIC> acc;
+#pragma unroll
+                        for(int c = 0; c < 4; ++c) acc.add(cur[ c ], kept[ j ][ c ]);
+                        const float d = acc.template finish<64>();
+                        bad |= d < cdist;  // meaningful in lane 63
+                    }
+                }
+                const int slot = consumed % 3;
+                if(lane == 63 && bad) scal[ slot ] = 1;
+                if(tid == 0) scal[ (consumed + 1) % 3 ] = 0;
+                Dr += (uint32_t)submitted;
+                __syncthreads();
+                if(scal[ slot ] == 0) {
+                    const int owner = submitted & 3, j = submitted >> 2;
+                    if(wave == owner) {
+#pragma unroll
+                        for(int jj = 0; jj < 4; ++jj)
+                            if(jj == j) {
+#pragma unroll
+                                for(int c = 0; c < 4; ++c) kept[ jj ][ c ] = cur[ c ];
+                            }
+                    }
+                    if(tid == 0) { kid[ submitted ] = cslot; kd[ submitted ] = cdist; }
+                    submitted++;
+                }
+                consumed++;
+            }
+            keep = submitted;
+        }
+        __syncthreads();
+    } else {
+        keep = refine<METRIC, G>(a.view, r, scal, n, (int)M, me, Dr);
+        for(int i = tid; i < keep; i += T) { kid[ i ] = r.sid[ i ]; kd[ i ] = r.sd[ i ]; }
+        __syncthreads();
+    }
+    // ---- the node's own list and one reverse-link request per pick
+    uint32_t  cap;
+    uint32_t *list = neighbors_of(a.view, me, level, cap);
+    for(uint32_t i = tid; i < M; i += T) {
+        LinkReq req;
+        req.close = EMPTY;
+        req.level = (uint32_t)level;
+        req.new_slot = me;
+        req.d = 0.f;
+        if((int)i < keep) {
+            list[ i ] = kid[ i ];
+            req.close = kid[ i ];
+            req.d = kd[ i ];
+        }
+        out[ i ] = req;
+    }
+    if(tid == 0 && a.totals) atomicAdd(&a.totals[ 0 ], (unsigned long long)Dr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -773,7 +902,7 @@ __global__ void __launch_bounds__(256) k_pairs(const uint4 *a, uint32_t na, cons
     } while(0)
 
 size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots) { return walk_lds_bytes(chunks, ef_cap, M0, vis_slots); }
-size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0, uint32_t vis_slots) { return walk_lds_bytes(chunks, efc, M0, vis_slots) + refine_lds_bytes(efc); }
+size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0, uint32_t vis_slots) { return walk_lds_bytes(chunks, efc, M0, vis_slots); }
 
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream)
 {
@@ -796,6 +925,18 @@ hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, h
         (void)hipFuncSetAttribute((const void *)k_insert<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_insert<MM, GG>), dim3(grid), dim3(64 * waves), lds, stream, a);                 \
     }
+    LGPU_DISPATCH(metric, a.view.chunks, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+size_t connect_lds_bytes(uint32_t efc, uint32_t M) { return refine_lds_bytes(efc) + S_SCALARS * 4 + (size_t)((M + 3) & ~3u) * 8; }
+
+hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream)
+{
+    if(a.items == 0) return hipSuccess;
+    const size_t lds = connect_lds_bytes(a.efc, a.view.M);
+#define CALL(MM, GG) hipLaunchKernelGGL((k_connect<MM, GG>), dim3(a.items), dim3(256), lds, stream, a)
     LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL
     return hipGetLastError();

@@ -41,12 +41,28 @@ struct InsertArgs
     uint32_t        first_slot; // the batch occupies slots [first_slot, first_slot + count)
     uint32_t        count;
     uint32_t        efc;
-    const uint32_t *link_off;   // [count] first LinkReq of each new node (M*(level+1) entries each)
-    LinkReq        *links;
+    const uint32_t *link_off;   // [count] first LinkReq of each new node (M*(level+1) entries each); /M = first item
+    uint64_t       *tops;       // [items][efc] walk results, ascending (distance, slot) keys
+    uint32_t       *top_count;  // [items]
     uint32_t       *bitmaps;
     uint32_t        bm_words;
     uint32_t        vis_slots;   // LDS visited-set slots (0 = HBM bitmap only)
-    unsigned long long *totals;  // [3] cumulative D, E, refine-D
+    unsigned long long *totals;  // [2] cumulative D, E
+};
+
+// neighbour selection of the new nodes: one item per (new node, level)
+struct ConnectArgs
+{
+    View            view;
+    uint32_t        first_slot;
+    uint32_t        items;
+    uint32_t        efc;
+    const uint32_t *link_off;    // [count]
+    const uint32_t *item_node;   // [items] index of the new node within the batch
+    const uint64_t *tops;
+    const uint32_t *top_count;
+    LinkReq        *links;       // [sum M*(level+1)]
+    unsigned long long *totals;  // [1] cumulative pair evaluations
 };
 
 struct RevlinkArgs
@@ -61,6 +77,7 @@ struct RevlinkArgs
 // All launchers return hipSuccess or the launch error.  `metric` is a usearch_metric_kind_t value.
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);
+hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream);
 // work: scratch of ngroups x 8 bytes; work_count: one u32 (both device memory; NULL = unstaged kernel)
 hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream);
 // out[i] = metric(query, row(slots[i]))
