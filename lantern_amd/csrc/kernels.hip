@@ -847,6 +847,150 @@ __global__ void __launch_bounds__(512, 4) k_revlink_slab(RevlinkArgs a, const Re
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_revlink_regs: the re-prune with the kept rows in REGISTERS (the k_connect scheme, eight waves: wave w owns
+// kept entries w, w+8, w+16, w+24).  For rows of 128..256 chunks (d = 512..1024 f32) and cap <= 32 it replaces the
+// column-slab sweep: a candidate costs one barrier and no LDS traffic; every wave streams the (sorted) candidate
+// rows through L1/L2 with the next one already in flight.  Same lane/chunk ownership and reduction tree as
+// group_dist<METRIC, 64>.
+template <int METRIC>
+__global__ void __launch_bounds__(512) k_revlink_regs(RevlinkArgs a, const RevWork *work, const uint32_t *work_count)
+{
+    constexpr int NMAX = 34;
+    __shared__ float    cd[ NMAX ], sd[ NMAX ], kd[ NMAX ];
+    __shared__ uint32_t cid[ NMAX ], sid[ NMAX ], kid[ NMAX ];
+    __shared__ int      flags[ 4 ];
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nwork = *work_count;
+    const int      chunks = (int)a.view.chunks;
+    uint32_t       pairs = 0, reprunes = 0;
+    auto load_row = [&](uint32_t slot, uint4 (&v)[ 4 ]) {
+        const uint4 *row = row_of(a.view, slot);
+#pragma unroll
+        for(int c = 0; c < 4; ++c) {
+            const int ch = lane + 64 * c;
+            v[ c ] = ch < chunks ? row[ ch ] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint32_t gi = work[ wi ].group;
+        const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+        const uint32_t t_first = work[ wi ].t_start;
+        const uint32_t close = a.reqs[ begin ].close;
+        const int      level = (int)a.reqs[ begin ].level;
+        uint32_t       cap;
+        uint32_t      *list = neighbors_of(a.view, close, level, cap);
+        __syncthreads();  // the previous work item is done with the LDS
+        for(uint32_t i = tid; i < cap; i += T) cid[ i ] = list[ i ];
+        int       c = (int)cap;
+        const int c0 = (int)cap - (int)(t_first - begin);
+        for(int i = c0 + tid; i < (int)cap; i += T) cd[ i ] = a.reqs[ begin + (uint32_t)(i - c0) ].d;
+        __syncthreads();
+        bool have_d = false;
+        for(uint32_t t = t_first; t < end; ++t) {
+            const uint32_t vnew = a.reqs[ t ].new_slot;
+            const float    dv = a.reqs[ t ].d;
+            if(c < (int)cap) {
+                if(tid == 0) { cid[ c ] = vnew; cd[ c ] = dv; list[ c ] = vnew; }
+                c++;
+                __syncthreads();
+                continue;
+            }
+            reprunes++;
+            const int n = c + 1;
+            if(tid == 0) { cid[ c ] = vnew; cd[ c ] = dv; }
+            if(tid < 3) flags[ tid ] = 0;
+            __syncthreads();
+            uint4 kept[ 4 ][ 4 ], cur[ 4 ], nxt[ 4 ];
+            if(!have_d) {  // distances of the original entries to `close`, once (a = close, b = entry)
+                // all (<= 4) rows of this wave in flight at once, parked in the not-yet-used kept registers
+                load_row(close, cur);
+#pragma unroll
+                for(int j = 0; j < 4; ++j)
+                    if(wave + 8 * j < c0) load_row(cid[ wave + 8 * j ], kept[ j ]);
+#pragma unroll
+                for(int j = 0; j < 4; ++j) {
+                    if(wave + 8 * j < c0) {
+                        Acc<METRIC> acc;
+#pragma unroll
+                        for(int cc = 0; cc < 4; ++cc) acc.add(cur[ cc ], kept[ j ][ cc ]);
+                        const float d = acc.template finish<64>();
+                        if(lane == 63) cd[ wave + 8 * j ] = d;
+                    }
+                }
+                pairs += (uint32_t)c0;
+                have_d = true;
+                __syncthreads();
+            }
+            // ---- sort by (distance to close, tie_mix(slot, close))
+            for(int x = tid; x < n; x += T) {
+                const uint64_t k = ((uint64_t)f2ord(cd[ x ]) << 32) | tie_mix(cid[ x ], close);
+                int            rank = 0;
+                for(int j = 0; j < n; ++j) rank += (((uint64_t)f2ord(cd[ j ]) << 32) | tie_mix(cid[ j ], close)) < k;
+                sd[ rank ] = cd[ x ];
+                sid[ rank ] = cid[ x ];
+            }
+            __syncthreads();
+            // ---- the heuristic: kept rows in registers, one barrier per candidate
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+#pragma unroll
+                for(int cc = 0; cc < 4; ++cc) kept[ j ][ cc ] = make_uint4(0, 0, 0, 0);
+            load_row(sid[ 0 ], cur);
+            if(wave == 0) {
+#pragma unroll
+                for(int cc = 0; cc < 4; ++cc) kept[ 0 ][ cc ] = cur[ cc ];
+            }
+            if(tid == 0) { kid[ 0 ] = sid[ 0 ]; kd[ 0 ] = sd[ 0 ]; }
+            int submitted = 1, consumed = 1;
+            load_row(sid[ 1 ], nxt);  // n >= 2 always (cap >= 1)
+            while(submitted < (int)cap && consumed < n) {
+#pragma unroll
+                for(int cc = 0; cc < 4; ++cc) cur[ cc ] = nxt[ cc ];
+                const float    cdist = sd[ consumed ];
+                const uint32_t cslot = sid[ consumed ];
+                if(consumed + 1 < n) load_row(sid[ consumed + 1 ], nxt);
+                bool bad = false;
+#pragma unroll
+                for(int j = 0; j < 4; ++j) {
+                    if(wave + 8 * j < submitted) {  // wave-uniform
+                        Acc<METRIC> acc;
+#pragma unroll
+                        for(int cc = 0; cc < 4; ++cc) acc.add(cur[ cc ], kept[ j ][ cc ]);
+                        const float d = acc.template finish<64>();
+                        bad |= d < cdist;  // meaningful in lane 63
+                    }
+                }
+                const int slot = consumed % 3;
+                if(lane == 63 && bad) flags[ slot ] = 1;
+                if(tid == 0) flags[ (consumed + 1) % 3 ] = 0;
+                pairs += (uint32_t)submitted;
+                __syncthreads();
+                if(flags[ slot ] == 0) {
+                    const int owner = submitted & 7, j = submitted >> 3;
+                    if(wave == owner) {
+#pragma unroll
+                        for(int jj = 0; jj < 4; ++jj)
+                            if(jj == j) {
+#pragma unroll
+                                for(int cc = 0; cc < 4; ++cc) kept[ jj ][ cc ] = cur[ cc ];
+                            }
+                    }
+                    if(tid == 0) { kid[ submitted ] = cslot; kd[ submitted ] = cdist; }
+                    submitted++;
+                }
+                consumed++;
+            }
+            __syncthreads();
+            c = submitted;
+            for(int i = tid; i < c; i += T) { cid[ i ] = kid[ i ]; cd[ i ] = kd[ i ]; }
+            for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? kid[ i ] : EMPTY;
+            __syncthreads();
+        }
+    }
+    if(tid == 0 && a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs); atomicAdd(&a.totals[ 1 ], (unsigned long long)reprunes); }
+}
+
+// ---------------------------------------------------------------------------------------------------
 template <int METRIC, int G>
 __global__ void __launch_bounds__(256) k_gather(View v, const uint4 *query, const uint32_t *slots, uint32_t n, float *out)
 {
@@ -947,6 +1091,22 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
     if(a.ngroups == 0) return hipSuccess;
     // staged variant whenever the 2M+2 rows of a level-0 re-prune fit in LDS (d <= 1024 at M = 16)
     const size_t staged = staged_lds_bytes(a.view.chunks, a.view.M0);
+    if(a.view.chunks >= 128 && a.view.chunks <= 256 && a.view.M0 <= 32 && work && work_count) {
+        // d = 512..1024 f32 rows, M <= 16: kept rows in registers (k_revlink_regs), 2 x 8 waves per CU
+        hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
+        if(e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_revlink_append, dim3((a.ngroups + 3) / 4), dim3(256), 0, stream, a, (RevWork *)work, work_count);
+        const int grid = num_cus * 2;
+        switch(metric) {
+            case M_L2SQ: hipLaunchKernelGGL((k_revlink_regs<M_L2SQ>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); break;
+            case M_COS: hipLaunchKernelGGL((k_revlink_regs<M_COS>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); break;
+            case M_HAMMING: hipLaunchKernelGGL((k_revlink_regs<M_HAMMING>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); break;
+            case M_L2SQ_F16: hipLaunchKernelGGL((k_revlink_regs<M_L2SQ_F16>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); break;
+            case M_COS_F16: hipLaunchKernelGGL((k_revlink_regs<M_COS_F16>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if(a.view.chunks >= 128 && a.view.M0 <= 32 && work && work_count) {
         // common shape (G = 64: d >= 512 f32 / 1024 f16, and M <= 16): column-slab sweep, 2 x 8 waves per CU
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
