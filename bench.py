@@ -55,6 +55,10 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only to debug the N>1 path on one GPU")
     p.add_argument("--data", default="gaussian", choices=["gaussian", "lowrank"],
                    help="gaussian = the prescribed i.i.d. N(0,1) set (SURVEY 8d); lowrank = 32 latent dims embedded in --dim (embedding-like)")
+    p.add_argument("--sharded-build", default="auto", choices=["auto", "on", "off"],
+                   help="after the search measurement, build the same index ONCE across all ranks (RCCL all-gathers, one child "
+                        "process per GPU: lantern_amd/sharded_build.py) and report its rate; auto = when --gpus > 1")
+    p.add_argument("--sharded-build-timeout", type=float, default=420.0)
     return p.parse_args()
 
 
@@ -86,17 +90,11 @@ def main():
     hip.set_device(dev_index)
 
     # ---- synthetic data (numpy default_rng, standard normal f32, seeds 3 / 4) -------
+    from lantern_amd import synth
+
     t0 = time.time()
-    rng = np.random.default_rng(3)
-    if a.data == "gaussian":
-        base = rng.standard_normal((a.n, a.dim), dtype=np.float32)
-        make_queries = lambda r, n: r.standard_normal((n, a.dim), dtype=np.float32)
-    else:  # 32 latent dimensions + 5 % isotropic noise: has neighbourhood structure, unlike i.i.d. N(0,1) in 768-d
-        proj = np.random.default_rng(33).standard_normal((32, a.dim), dtype=np.float32) / np.float32(np.sqrt(32))
-        def make_queries(r, n):
-            z = r.standard_normal((n, 32), dtype=np.float32)
-            return z @ proj + np.float32(0.05) * r.standard_normal((n, a.dim), dtype=np.float32)
-        base = make_queries(rng, a.n)
+    make_queries = synth.query_maker(a.data, a.dim)
+    base = synth.base_rows(a.data, a.n, a.dim)
     labels = np.arange(a.n, dtype=np.uint64) + 1  # 0 is INVALID_ELEMENT_LABEL (hnsw.h:40)
     t_gen = time.time() - t0
 
@@ -149,6 +147,11 @@ def main():
         from lantern_amd import sharded
 
         elapsed = sharded.max_over_ranks(elapsed, device=torch.device("cuda", dev_index) if a.dist_backend == "nccl" else None)
+
+    # ---- work-sharded build of the same index across all ranks, in child processes ----------
+    sharded_res = None
+    if a.sharded_build == "on" or (a.sharded_build == "auto" and world > 1):
+        sharded_res = sharded_build_leg(a, rank, world, dev_index, dist, ix if rank == 0 else None)
 
     # ---- algorithmic bytes of one launch --------------------------------------------
     D = d_D.download(nq, np.uint64).astype(np.float64)
@@ -212,12 +215,75 @@ def main():
                          "traffic": traffic, "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": avg_kernel_s * 1e3},
             "cpu_baseline": cpu,
+            "sharded_build": sharded_res,
             "setup_seconds": {"datagen": t_gen, "build": t_build, "exact_truth": t_truth},
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_build_leg(a, rank, world, dev_index, dist, ix0):
+    """One lantern_amd.sharded_build child per rank (own process: ROCm's HIP + RCCL, no torch), all building ONE index
+    together.  Returns rank 0's summary (None on the other ranks); a failure is reported, never raised: this leg runs
+    after the search measurement and must not cost the benchmark line."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    rdv = None
+    try:
+        if rank == 0:
+            rdv = tempfile.mkdtemp(prefix="lantern_rdv_")
+        if world > 1:
+            box = [rdv]
+            dist.broadcast_object_list(box, src=0)
+            rdv = box[0]
+        cmd = [sys.executable, "-m", "lantern_amd.sharded_build", "--rank", str(rank), "--world", str(world), "--rendezvous", rdv,
+               "--device", str(dev_index), "--rows", str(a.n), "--dim", str(a.dim), "--metric", a.metric, "--M", str(a.M),
+               "--efc", str(a.efc), "--ef", str(a.ef), "--add-batch", str(a.add_batch), "--quant", a.quant, "--data", a.data]
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("NCCL_SOCKET_IFNAME", "lo")  # all ranks are on this node; the container's hostname may not resolve
+        t0 = time.time()
+        try:
+            cp = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=a.sharded_build_timeout)
+            rc, text = cp.returncode, cp.stdout + cp.stderr
+        except subprocess.TimeoutExpired as e:
+            rc, text = -9, f"timed out after {a.sharded_build_timeout} s: " + str(e.stdout or "")[-400:]
+        wall = time.time() - t0
+        res = None
+        for line in text.splitlines():
+            if line.startswith("SHARDED_BUILD "):
+                res = json.loads(line[len("SHARDED_BUILD "):])
+        mine = res if (rc == 0 and res) else {"error": f"rank {rank}: exit {rc}: " + text[-600:]}
+        if world > 1:
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+        else:
+            every = [mine]
+        if rank != 0:
+            return None
+        bad = [r for r in every if "error" in r]
+        if bad:
+            return {"error": bad[0]["error"], "ranks_failed": len(bad), "world": world}
+        secs = max(r["seconds"] for r in every)
+        sums = sorted({r["checksum"] for r in every})
+        ref = f"{ix0.checksum():016x}"
+        return {
+            "world": world, "seconds": secs, "vectors_per_s": a.n / secs, "child_wall_seconds": wall,
+            "replicas_identical": len(sums) == 1, "identical_to_single_gpu_build": sums == [ref],
+            "checksum": sums[0], "single_gpu_checksum": ref,
+            "bytes_received_per_rank": [r["exchange"]["bytes_received"] for r in every],
+            "collectives": every[0]["exchange"]["collectives"],
+            "walk_evals_per_rank": [r["counters"]["add_walk_evals"] for r in every],
+            "transport": every[0]["transport"],
+        }
+    except Exception as e:  # noqa: BLE001 -- reported in the line
+        return {"error": repr(e)} if rank == 0 else None
+    finally:
+        if rank == 0 and rdv:
+            shutil.rmtree(rdv, ignore_errors=True)
 
 
 def usable_cores() -> int:

@@ -240,6 +240,55 @@ typedef struct lantern_gpu_counters
 } lantern_gpu_counters;
 LANTERN_GPU_EXPORT lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t, usearch_error_t *);
 
+/* order-independent-of-builder fingerprint of the graph (levels, labels, both adjacency arrays, entry point):
+ * equal on two indexes iff they hold the same graph; used to check that replicas agree without moving them */
+LANTERN_GPU_EXPORT uint64_t lantern_gpu_graph_checksum(usearch_index_t, usearch_error_t *);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Work-sharded index build over the GPUs of one node (the reference's     */
+/* own parallel build is a thread pool on one shared index, server.rs:328-359).  One process or  */
+/* thread per GPU, each with its own usearch_index_t replica.  lantern_gpu_add_sharded is a       */
+/* COLLECTIVE: rank r passes shard r of the rows (global slot order = rank order); the shards are */
+/* all-gathered into every replica's HBM, then every insertion batch is split across the ranks:   */
+/* each walks and connects its share of the new nodes, the ranks all-gather the resulting top-M   */
+/* neighbour lists, each applies the reverse links of the nodes it owns and the re-written        */
+/* adjacency rows are all-gathered.  All replicas end up bit-identical to the graph one GPU       */
+/* builds from the same rows with the same batch parameters.                                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct lantern_gpu_comm lantern_gpu_comm_t;
+#define LANTERN_GPU_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+/* RCCL transport (xGMI, data stays in HBM): rank 0 draws the id and ships it to its peers by any means,
+ * then every rank calls init_rccl with the HIP device it will build on current (hipSetDevice). */
+LANTERN_GPU_EXPORT void lantern_gpu_comm_unique_id(char *id128, usearch_error_t *);
+LANTERN_GPU_EXPORT lantern_gpu_comm_t *lantern_gpu_comm_init_rccl(int rank, int world, const char *id128, usearch_error_t *);
+/* Host transport: the caller supplies an in-place all-gather over a HOST buffer (MPI, gloo, sockets):
+ * on entry bytes [offsets[rank], +counts[rank]) are valid, on return (0 = success) every rank's segment is. */
+typedef int (*lantern_gpu_allgatherv_fn)(void *ctx, void *host_buf, const size_t *offsets, const size_t *counts, int world,
+                                         int rank);
+LANTERN_GPU_EXPORT lantern_gpu_comm_t *lantern_gpu_comm_init_host(int rank, int world, lantern_gpu_allgatherv_fn, void *ctx,
+                                                                  usearch_error_t *);
+/* In-process world: `world` communicators for `world` threads of this process (one thread per GPU of a node,
+ * or several ranks on one GPU in tests); out[world]. */
+LANTERN_GPU_EXPORT void lantern_gpu_comm_init_local(int world, lantern_gpu_comm_t **out, usearch_error_t *);
+LANTERN_GPU_EXPORT void lantern_gpu_comm_free(lantern_gpu_comm_t *);
+LANTERN_GPU_EXPORT int  lantern_gpu_comm_rank(lantern_gpu_comm_t *);
+LANTERN_GPU_EXPORT int  lantern_gpu_comm_world(lantern_gpu_comm_t *);
+/* a collective that does not complete within `seconds` (default 180) fails instead of hanging */
+LANTERN_GPU_EXPORT void lantern_gpu_comm_set_timeout(lantern_gpu_comm_t *, double seconds);
+/* bytes this rank received and number of exchanges so far */
+LANTERN_GPU_EXPORT void lantern_gpu_comm_stats(lantern_gpu_comm_t *, uint64_t *bytes_received, uint64_t *collectives);
+/* the exchange primitive itself (in-place all-gather with per-rank sizes), host and device buffers */
+LANTERN_GPU_EXPORT void lantern_gpu_comm_allgatherv_host(lantern_gpu_comm_t *, void *host_buf, const size_t *offsets,
+                                                         const size_t *counts, usearch_error_t *);
+LANTERN_GPU_EXPORT void lantern_gpu_comm_allgatherv_device(lantern_gpu_comm_t *, void *device_buf, const size_t *offsets,
+                                                           const size_t *counts, void *stream, usearch_error_t *);
+/* the balanced split used for batches and shards: rank r of `world` takes [n*r/world, n*(r+1)/world) */
+LANTERN_GPU_EXPORT void lantern_gpu_shard_range(size_t n, int world, int rank, size_t *begin, size_t *end);
+/* the collective insert described above; n_shard may be 0 */
+LANTERN_GPU_EXPORT void lantern_gpu_add_sharded(usearch_index_t, lantern_gpu_comm_t *, const usearch_label_t *labels_shard,
+                                                const void *vectors_shard, size_t n_shard, usearch_scalar_kind_t,
+                                                usearch_error_t *);
+
 /* ------------------------------------------------------------------------------------------ */
 /* amgettuple paging shim: ldb_ambeginscan / ldb_amgettuple / ldb_amendscan (scan.c:24-338)     */
 /* ------------------------------------------------------------------------------------------ */

@@ -18,8 +18,8 @@ OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "liblantern_gpu.so")
 
-SOURCES = ["kernels.hip", "bruteforce.hip", "index.cpp", "usearch_file.cpp", "scan_shim.cpp", "index_server.cpp"]
-HEADERS = ["device_common.hpp", "walk.hpp", "kernels.hpp", "index.hpp", "host_util.hpp", "../../include/lantern_gpu.h"]
+SOURCES = ["kernels.hip", "bruteforce.hip", "index.cpp", "comm.cpp", "usearch_file.cpp", "scan_shim.cpp", "index_server.cpp"]
+HEADERS = ["device_common.hpp", "walk.hpp", "kernels.hpp", "index.hpp", "comm.hpp", "host_util.hpp", "../../include/lantern_gpu.h"]
 # -ffp-contract=off: every fma in the kernels is explicit, so the reduction tree is exactly the
 # one the oracle models.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, srcs))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -87,7 +87,15 @@ EXPORTS = [
     "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist", "lantern_index_server_start",
     "lantern_index_server_port", "lantern_index_server_status_port", "lantern_index_server_status",
     "lantern_index_server_served", "lantern_index_server_stop",
+    "lantern_gpu_graph_checksum", "lantern_gpu_comm_unique_id", "lantern_gpu_comm_init_rccl", "lantern_gpu_comm_init_host",
+    "lantern_gpu_comm_init_local", "lantern_gpu_comm_free", "lantern_gpu_comm_rank", "lantern_gpu_comm_world",
+    "lantern_gpu_comm_set_timeout", "lantern_gpu_comm_stats", "lantern_gpu_comm_allgatherv_host",
+    "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded",
 ]
+
+# int fn(void *ctx, void *host_buf, const size_t *offsets, const size_t *counts, int world, int rank)
+ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int, C.c_int)
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -159,6 +167,20 @@ def lib() -> C.CDLL:
         "lantern_index_server_status": (i32, [vp]),
         "lantern_index_server_served": (u64, [vp]),
         "lantern_index_server_stop": (None, [vp]),
+        "lantern_gpu_graph_checksum": (u64, [vp, err]),
+        "lantern_gpu_comm_unique_id": (None, [vp, err]),
+        "lantern_gpu_comm_init_rccl": (vp, [i32, i32, vp, err]),
+        "lantern_gpu_comm_init_host": (vp, [i32, i32, ALLGATHERV_FN, vp, err]),
+        "lantern_gpu_comm_init_local": (None, [i32, C.POINTER(vp), err]),
+        "lantern_gpu_comm_free": (None, [vp]),
+        "lantern_gpu_comm_rank": (i32, [vp]),
+        "lantern_gpu_comm_world": (i32, [vp]),
+        "lantern_gpu_comm_set_timeout": (None, [vp, C.c_double]),
+        "lantern_gpu_comm_stats": (None, [vp, C.POINTER(u64), C.POINTER(u64)]),
+        "lantern_gpu_comm_allgatherv_host": (None, [vp, vp, C.POINTER(sz), C.POINTER(sz), err]),
+        "lantern_gpu_comm_allgatherv_device": (None, [vp, vp, C.POINTER(sz), C.POINTER(sz), vp, err]),
+        "lantern_gpu_shard_range": (None, [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]),
+        "lantern_gpu_add_sharded": (None, [vp, vp, vp, vp, sz, i32, err]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what the header declares
@@ -320,6 +342,16 @@ class GpuIndex:
     def flush(self):
         _call("lantern_gpu_flush", self.h)
 
+    def add_sharded(self, comm: "Comm", labels, vecs):
+        """COLLECTIVE: this rank's shard of the rows (global slot order = rank order); see lantern_gpu_add_sharded."""
+        V = _rows(vecs, self.metric) if len(labels) else np.zeros((0, self.dims), dtype=np.uint32 if self.metric == METRIC_HAMMING else np.float32)
+        lab = np.ascontiguousarray(labels, dtype=np.uint64)
+        assert V.shape[1] == self.dims and lab.size == V.shape[0]
+        _call("lantern_gpu_add_sharded", self.h, comm.h, _ptr(lab), _ptr(V), V.shape[0], _kind(self.metric))
+
+    def checksum(self) -> int:
+        return int(_call("lantern_gpu_graph_checksum", self.h))
+
     def search(self, query, k, ef=0, streaming=False):
         """usearch_search_ef: (labels, distances) of length <= k."""
         q = _rows(query, self.metric)[0]
@@ -427,6 +459,99 @@ class GpuIndex:
     def load_buffer(self, data: bytes):
         buf = C.create_string_buffer(data, len(data))
         _call("usearch_load_buffer", self.h, C.cast(buf, C.c_void_p), len(data))
+
+
+def shard_range(n: int, world: int, rank: int) -> tuple[int, int]:
+    b, e = C.c_size_t(), C.c_size_t()
+    lib().lantern_gpu_shard_range(n, world, rank, C.byref(b), C.byref(e))
+    return int(b.value), int(e.value)
+
+
+class Comm:
+    """lantern_gpu_comm_t: the exchange transport of the work-sharded build (RCCL, a caller-supplied host
+    all-gather, or the in-process hub)."""
+
+    def __init__(self, handle, keep=None):
+        self.h = handle
+        self._keep = keep  # the ctypes callback must outlive the communicator
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _call("lantern_gpu_comm_unique_id", C.cast(buf, C.c_void_p))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, rank: int, world: int, uid: bytes) -> "Comm":
+        assert len(uid) == COMM_ID_BYTES
+        buf = C.create_string_buffer(uid, COMM_ID_BYTES)
+        return cls(_call("lantern_gpu_comm_init_rccl", rank, world, C.cast(buf, C.c_void_p)))
+
+    @classmethod
+    def host(cls, rank: int, world: int, allgatherv) -> "Comm":
+        """allgatherv(buf: np.ndarray[u8] (whole extent, in place), offsets: list[int], counts: list[int]) -> None"""
+
+        def tramp(ctx, host_buf, offsets, counts, w, r):
+            try:
+                offs = [int(offsets[i]) for i in range(w)]
+                cnts = [int(counts[i]) for i in range(w)]
+                extent = max((o + c for o, c in zip(offs, cnts)), default=0)
+                view = np.ctypeslib.as_array(C.cast(host_buf, C.POINTER(C.c_uint8)), shape=(max(extent, 1),))
+                allgatherv(view, offs, cnts)
+                return 0
+            except Exception:  # the C side turns a non-zero return into an error string
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        cb = ALLGATHERV_FN(tramp)
+        return cls(_call("lantern_gpu_comm_init_host", rank, world, cb, None), keep=cb)
+
+    @classmethod
+    def local_world(cls, world: int) -> list["Comm"]:
+        arr = (C.c_void_p * world)()
+        _call("lantern_gpu_comm_init_local", world, arr)
+        return [cls(arr[i]) for i in range(world)]
+
+    @property
+    def rank(self):
+        return int(lib().lantern_gpu_comm_rank(self.h))
+
+    @property
+    def world(self):
+        return int(lib().lantern_gpu_comm_world(self.h))
+
+    def set_timeout(self, seconds: float):
+        lib().lantern_gpu_comm_set_timeout(self.h, float(seconds))
+
+    def stats(self):
+        b, c = C.c_uint64(), C.c_uint64()
+        lib().lantern_gpu_comm_stats(self.h, C.byref(b), C.byref(c))
+        return {"bytes_received": int(b.value), "collectives": int(c.value)}
+
+    def allgatherv_host(self, buf: np.ndarray, offsets, counts):
+        w = len(offsets)
+        off = (C.c_size_t * w)(*offsets)
+        cnt = (C.c_size_t * w)(*counts)
+        _call("lantern_gpu_comm_allgatherv_host", self.h, _ptr(buf), off, cnt)
+
+    def allgatherv_device(self, d_ptr: int, offsets, counts, stream=None):
+        w = len(offsets)
+        off = (C.c_size_t * w)(*offsets)
+        cnt = (C.c_size_t * w)(*counts)
+        _call("lantern_gpu_comm_allgatherv_device", self.h, _ptr(d_ptr), off, cnt, _ptr(stream))
+
+    def free(self):
+        if self.h:
+            lib().lantern_gpu_comm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Scan:

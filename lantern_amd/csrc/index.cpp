@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "comm.hpp"
 #include "host_util.hpp"
 
 namespace lgpu {
@@ -189,9 +190,32 @@ static void sort_requests(std::vector<LinkReq> &h, std::vector<LinkReq> &tmp)
 // One device pass over `b` new vectors whose rows / labels / levels / upper offsets are ALREADY in HBM at
 // slots [first, first + b) (flush_locked uploads everything pending up front: an unlinked node is
 // unreachable, so its row may sit in the table before its batch runs).
-static bool run_batch(Index *ix, size_t b, const int *lv)
+// Work-sharded build (comm != nullptr): the batch is the same as on one GPU, but every rank
+// walks and connects only its share [b_lo, b_hi) of the new nodes, the ranks all-gather the resulting top-M
+// neighbour lists (= the reverse-link requests: 16 bytes per pick), each rank applies the reverse links of the
+// nodes it owns (close % world), and the re-written adjacency rows are all-gathered.  Every step is
+// deterministic and independent of who executes it, so all replicas end up bit-identical to the graph one GPU
+// builds with the same batch plan.  Batches with fewer than kShardMinPerRank vectors per rank (the ramp at the
+// start of a build) are executed redundantly by every rank: no exchange, same result.
+static const size_t kShardMinPerRank = 8;
+
+static bool sync_stream(Index *ix, Comm *comm)
+{
+    if(comm) {
+        if(comm->wait(ix->stream)) return true;
+        set_err(ix, comm->err);
+        return false;
+    }
+    HIPCHK(ix, hipStreamSynchronize(ix->stream));
+    return true;
+}
+
+static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
 {
     const size_t first = ix->n;
+    const int    W = comm ? comm->world : 1, R = comm ? comm->rank : 0;
+    const bool   split = W > 1 && b >= (size_t)W * kShardMinPerRank;
+    const size_t b_lo = split ? b * (size_t)R / (size_t)W : 0, b_hi = split ? b * ((size_t)R + 1) / (size_t)W : b;
     std::vector<uint32_t> &link_off = ix->h_link_off;
     link_off.resize(b);
     size_t total_links = 0;
@@ -213,13 +237,15 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
     HIPCHK(ix, hipMemcpyAsync(d_link_off, link_off.data(), b * 4, hipMemcpyHostToDevice, ix->stream));
     HIPCHK(ix, hipMemcpyAsync(d_item_node, item_node.data(), items * 4, hipMemcpyHostToDevice, ix->stream));
 
-    const int grid = search_grid(ix, b, ix->insert_waves);
+    const int grid = search_grid(ix, b_hi - b_lo, ix->insert_waves);
     if(!ensure_bitmaps(ix, (size_t)grid)) return false;
+    auto link_at = [&](size_t i) { return i < b ? (size_t)link_off[ i ] : total_links; };
 
     InsertArgs ia;
     ia.view = ix->view();  // size/entry/max_level as they were BEFORE the batch
     ia.first_slot = (uint32_t)first;
-    ia.count = (uint32_t)b;
+    ia.b_begin = (uint32_t)b_lo;
+    ia.count = (uint32_t)b_hi;
     ia.efc = ix->efc;
     ia.link_off = d_link_off;
     ia.tops = d_tops;
@@ -239,7 +265,8 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
     ConnectArgs ca;
     ca.view = ia.view;
     ca.first_slot = (uint32_t)first;
-    ca.items = (uint32_t)items;
+    ca.item_begin = (uint32_t)(link_at(b_lo) / ix->M);
+    ca.items = (uint32_t)((link_at(b_hi) - link_at(b_lo)) / ix->M);
     ca.efc = ix->efc;
     ca.link_off = d_link_off;
     ca.item_node = d_item_node;
@@ -248,6 +275,19 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
     ca.links = d_links;
     ca.totals = ix->d_totals + 4;
     HIPCHK(ix, launch_connect(ix->mcode, ca, ix->stream));
+
+    if(split) {
+        // exchange 1: the ranks' top-M neighbour lists (one LinkReq per pick).  Afterwards every rank holds all
+        // requests of the batch; the own lists of the nodes a peer connected are rebuilt from them.
+        std::vector<size_t> off((size_t)W), cnt((size_t)W);
+        for(int r = 0; r < W; ++r) {
+            const size_t lo = b * (size_t)r / (size_t)W, hi = b * ((size_t)r + 1) / (size_t)W;
+            off[ (size_t)r ] = link_at(lo) * sizeof(LinkReq);
+            cnt[ (size_t)r ] = (link_at(hi) - link_at(lo)) * sizeof(LinkReq);
+        }
+        if(!comm->allgatherv_device(d_links, off.data(), cnt.data(), ix->stream)) { set_err(ix, comm->err); return false; }
+        HIPCHK(ix, launch_apply_own_links(ia.view, (uint32_t)first, d_link_off, d_links, (uint32_t)total_links, ix->stream));
+    }
 
     // pinned landing buffer for the requests
     if(ix->h_links_cap < total_links) {
@@ -259,14 +299,24 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
     }
     LinkReq *hl = (LinkReq *)ix->h_links;
     HIPCHK(ix, hipMemcpyAsync(hl, d_links, total_links * sizeof(LinkReq), hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(ix, hipStreamSynchronize(ix->stream));
+    if(!sync_stream(ix, comm)) return false;
 
-    // reverse links: group by (close, level); within a group apply in new-slot order
+    // reverse links: group by (close, level); within a group apply in new-slot order.  In a sharded batch a
+    // rank keeps only the groups of the nodes it owns (close % world) and counts the others' (the sizes of
+    // the second exchange's segments must be known to everybody without another round trip).
     std::vector<LinkReq> &h = ix->h_reqs;
     h.clear();
-    h.reserve(total_links);
-    for(size_t i = 0; i < total_links; ++i)
-        if(hl[ i ].close != EMPTY) h.push_back(hl[ i ]);
+    h.reserve(split ? total_links / (size_t)W + 64 : total_links);
+    std::vector<size_t> owner_reqs((size_t)W, 0);
+    for(size_t i = 0; i < total_links; ++i) {
+        if(hl[ i ].close == EMPTY) continue;
+        if(split) {
+            const size_t o = hl[ i ].close % (uint32_t)W;
+            owner_reqs[ o ]++;
+            if((int)o != R) continue;
+        }
+        h.push_back(hl[ i ]);
+    }
     // k_insert emits per node, per level; make the stream new-slot-major before the stable sort
     // (it already is: nodes are laid out in slot order and a node's requests are contiguous)
     sort_requests(h, ix->h_reqs_tmp);
@@ -277,22 +327,47 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
         if(i == 0 || h[ i ].close != h[ i - 1 ].close || h[ i ].level != h[ i - 1 ].level) gb.push_back((uint32_t)i);
     const uint32_t ngroups = (uint32_t)gb.size();
     gb.push_back((uint32_t)m);
+    RevlinkArgs ra;
+    ra.view = ix->view();
+    ra.ngroups = 0;
+    ra.group_begin = nullptr;
+    ra.reqs = nullptr;
+    ra.totals = ix->d_totals + 5;
     if(ngroups) {
         LinkReq  *d_reqs = (LinkReq *)scratch(ix, 2, m * sizeof(LinkReq));
         uint32_t *d_gb = (uint32_t *)scratch(ix, 3, gb.size() * 4);
         if(!d_reqs || !d_gb) return false;
         HIPCHK(ix, hipMemcpyAsync(d_reqs, h.data(), m * sizeof(LinkReq), hipMemcpyHostToDevice, ix->stream));
         HIPCHK(ix, hipMemcpyAsync(d_gb, gb.data(), gb.size() * 4, hipMemcpyHostToDevice, ix->stream));
-        RevlinkArgs ra;
-        ra.view = ix->view();
         ra.ngroups = ngroups;
         ra.group_begin = d_gb;
         ra.reqs = d_reqs;
-        ra.totals = ix->d_totals + 5;
         void *d_work = scratch(ix, 4, (size_t)ngroups * 8 + 16);
         if(!d_work) return false;
         HIPCHK(ix, launch_revlink(ix->mcode, ra, (char *)d_work + 16, (uint32_t *)d_work, ix->num_cus, ix->stream));
-        HIPCHK(ix, hipStreamSynchronize(ix->stream));  // h / gb are reused by the next batch
+        if(!split) HIPCHK(ix, hipStreamSynchronize(ix->stream));  // h / gb are reused by the next batch
+    }
+    if(split) {
+        // exchange 2: the adjacency rows the ranks re-wrote, one record [close, level, list[0..M0)] per group.
+        // A rank's segment is sized by the number of requests it owned (>= its number of groups; every rank can
+        // compute it from the request array) and padded with EMPTY records.
+        const size_t rec_bytes = ((size_t)ix->M0 + 2) * 4;
+        std::vector<size_t> off((size_t)W), cnt((size_t)W);
+        size_t total_recs = 0;
+        for(int r = 0; r < W; ++r) {
+            off[ (size_t)r ] = total_recs * rec_bytes;
+            cnt[ (size_t)r ] = owner_reqs[ (size_t)r ] * rec_bytes;
+            total_recs += owner_reqs[ (size_t)r ];
+        }
+        if(total_recs) {
+            char *d_rec = (char *)scratch(ix, 5, total_recs * rec_bytes);
+            if(!d_rec) return false;
+            if(cnt[ (size_t)R ]) HIPCHK(ix, hipMemsetAsync(d_rec + off[ (size_t)R ], 0xFF, cnt[ (size_t)R ], ix->stream));
+            HIPCHK(ix, launch_pack_lists(ra, (uint32_t *)(d_rec + off[ (size_t)R ]), ix->stream));
+            if(!comm->allgatherv_device(d_rec, off.data(), cnt.data(), ix->stream)) { set_err(ix, comm->err); return false; }
+            HIPCHK(ix, launch_apply_lists(ra.view, (const uint32_t *)d_rec, (uint32_t)total_recs, ix->stream));
+        }
+        if(!sync_stream(ix, comm)) return false;  // h / gb / the staging buffers are reused by the next batch
     }
     ix->n = first + b;
     if(b == 1 && lv[ 0 ] > ix->max_level) {  // "Updating the entry point if needed"
@@ -302,6 +377,59 @@ static bool run_batch(Index *ix, size_t b, const int *lv)
     ix->c_add_vectors += b;
     ix->c_add_batches += 1;
     return true;
+}
+
+// Levels and upper-block offsets of `count` new nodes at slots [ix->n, ix->n + count), capacity for them.
+struct StagedMeta
+{
+    std::vector<int>      lv;
+    std::vector<uint8_t>  l8;
+    std::vector<uint32_t> uo;
+};
+static bool stage_meta(Index *ix, const int *levels_in, size_t count, StagedMeta &s)
+{
+    const size_t first = ix->n;
+    s.lv.resize(count);
+    s.l8.resize(count);
+    s.uo.resize(count);
+    size_t blocks = ix->upper_blocks;
+    for(size_t i = 0; i < count; ++i) {
+        s.lv[ i ] = (levels_in && levels_in[ i ] >= 0) ? levels_in[ i ] : level_for(ix->seed, first + i, ix->M);
+        s.l8[ i ] = (uint8_t)s.lv[ i ];
+        s.uo[ i ] = s.lv[ i ] > 0 ? (uint32_t)blocks : EMPTY;
+        blocks += (size_t)s.lv[ i ];
+    }
+    if(first + count > ix->cap && !reserve_locked(ix, std::max(ix->cap * 2, first + count))) return false;
+    return reserve_upper(ix, blocks);
+}
+
+// The batch loop over `count` staged nodes whose rows / labels / levels / upper offsets are in HBM.  Returns how
+// many were inserted (== count unless a batch failed) and appends the host mirrors of those.
+static size_t run_batches(Index *ix, const uint64_t *labels, const StagedMeta &s, size_t count, Comm *comm, bool *ok_out)
+{
+    size_t pi = 0;
+    bool   ok = true;
+    while(pi < count) {
+        if(ix->n == 0) {  // "Do nothing for the first element": it only becomes the entry point
+            ix->n = 1;
+            ix->entry = 0;
+            ix->max_level = s.lv[ 0 ];
+            ix->c_add_vectors += 1;
+            pi += 1;
+            continue;
+        }
+        const size_t look = std::min(count - pi, ix->add_batch_max);
+        const size_t b = plan_batch(ix->n, ix->max_level, s.lv.data() + pi, look, ix->add_batch_max, ix->add_min_ratio);
+        if(!(ok = run_batch(ix, b, s.lv.data() + pi, comm))) break;
+        pi += b;
+    }
+    // host mirrors of what was inserted
+    ix->labels.insert(ix->labels.end(), labels, labels + pi);
+    ix->levels.insert(ix->levels.end(), s.l8.begin(), s.l8.begin() + (ptrdiff_t)pi);
+    ix->upper_off.insert(ix->upper_off.end(), s.uo.begin(), s.uo.begin() + (ptrdiff_t)pi);
+    for(size_t i = 0; i < pi; ++i) ix->upper_blocks += (size_t)s.lv[ i ];
+    *ok_out = ok;
+    return pi;
 }
 
 // Insert `count` vectors whose padded rows start at `rows` (row_words 4-byte words each).  levels[i] < 0
@@ -314,48 +442,70 @@ static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_i
     const size_t first = ix->n, row_words = (size_t)ix->chunks * 4;
     // ---- levels and upper-block offsets of everything, then ONE upload of rows and metadata: an unlinked
     // node is unreachable, so its row may sit in the table before its batch runs
-    std::vector<int>      lv(count);
-    std::vector<uint8_t>  l8(count);
-    std::vector<uint32_t> uo(count);
-    size_t blocks = ix->upper_blocks;
-    for(size_t i = 0; i < count; ++i) {
-        lv[ i ] = (levels_in && levels_in[ i ] >= 0) ? levels_in[ i ] : level_for(ix->seed, first + i, ix->M);
-        l8[ i ] = (uint8_t)lv[ i ];
-        uo[ i ] = lv[ i ] > 0 ? (uint32_t)blocks : EMPTY;
-        blocks += (size_t)lv[ i ];
-    }
-    if(first + count > ix->cap && !reserve_locked(ix, std::max(ix->cap * 2, first + count))) return fail();
-    if(!reserve_upper(ix, blocks)) return fail();
+    StagedMeta s;
+    if(!stage_meta(ix, levels_in, count, s)) return fail();
     bool up = hipMemcpyAsync((char *)ix->d_vec + first * row_words * 4, rows, count * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     up = up && hipMemcpyAsync(ix->d_labels + first, labels, count * 8, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-    up = up && hipMemcpyAsync(ix->d_levels + first, l8.data(), count, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-    up = up && hipMemcpyAsync(ix->d_upper_off + first, uo.data(), count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    up = up && hipMemcpyAsync(ix->d_levels + first, s.l8.data(), count, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    up = up && hipMemcpyAsync(ix->d_upper_off + first, s.uo.data(), count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
     if(!up) { set_err(ix, "lantern_gpu: HIP failure uploading vectors"); return fail(); }
+    return run_batches(ix, labels, s, count, nullptr, ok_out);
+}
 
-    size_t pi = 0;
-    bool   ok = true;
-    while(pi < count) {
-        if(ix->n == 0) {  // "Do nothing for the first element": it only becomes the entry point
-            ix->n = 1;
-            ix->entry = 0;
-            ix->max_level = lv[ 0 ];
-            ix->c_add_vectors += 1;
-            pi += 1;
-            continue;
-        }
-        const size_t look = std::min(count - pi, ix->add_batch_max);
-        const size_t b = plan_batch(ix->n, ix->max_level, lv.data() + pi, look, ix->add_batch_max, ix->add_min_ratio);
-        if(!(ok = run_batch(ix, b, lv.data() + pi))) break;
-        pi += b;
+// lantern_gpu_add_sharded: a COLLECTIVE insert.  Every rank contributes the rows [shard_off, shard_off + n_shard)
+// of the global slot order (rank order); the shards are all-gathered into every replica's HBM (the vector block
+// is replicated: 1M x 1536 f32 is 6.1 GB of 288), then the batches run work-sharded (run_batch).
+bool add_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const void *vectors, size_t n_shard, int kind_in)
+{
+    if(!flush_locked(ix)) return false;
+    const int    W = comm->world, R = comm->rank;
+    const size_t row = (size_t)ix->chunks * 16, first = ix->n;
+    // ---- shard sizes; all replicas must be in the same state
+    std::vector<uint64_t> meta((size_t)W * 2, 0);
+    std::vector<size_t>   off((size_t)W), cnt((size_t)W);
+    meta[ (size_t)R * 2 ] = n_shard;
+    meta[ (size_t)R * 2 + 1 ] = first;
+    for(int r = 0; r < W; ++r) { off[ (size_t)r ] = (size_t)r * 16; cnt[ (size_t)r ] = 16; }
+    if(!comm->allgatherv_host(meta.data(), off.data(), cnt.data())) { set_err(ix, comm->err); return false; }
+    size_t total = 0, my_off = 0;
+    for(int r = 0; r < W; ++r) {
+        if(meta[ (size_t)r * 2 + 1 ] != first) { set_err(ix, "lantern_gpu: the ranks' replicas differ in size; add_sharded needs identical replicas"); return false; }
+        if(r == R) my_off = total;
+        total += meta[ (size_t)r * 2 ];
     }
-    // host mirrors of what was inserted
-    ix->labels.insert(ix->labels.end(), labels, labels + pi);
-    ix->levels.insert(ix->levels.end(), l8.begin(), l8.begin() + (ptrdiff_t)pi);
-    ix->upper_off.insert(ix->upper_off.end(), uo.begin(), uo.begin() + (ptrdiff_t)pi);
-    for(size_t i = 0; i < pi; ++i) ix->upper_blocks += (size_t)lv[ i ];
-    *ok_out = ok;
-    return pi;
+    if(total == 0) return true;
+    StagedMeta s;
+    if(!stage_meta(ix, nullptr, total, s)) return false;
+    // ---- own shard -> HBM, then the all-gather of the shards (vectors, labels) over the transport
+    const size_t in_bytes = input_bytes(ix, kind_in);
+    std::vector<uint32_t> padded;
+    const void *src = vectors;
+    if(n_shard && !(kind_in == ix->scalar && in_bytes == row)) {
+        padded.resize(n_shard * (size_t)ix->chunks * 4);
+        for(size_t i = 0; i < n_shard; ++i) pad_row(ix, (const char *)vectors + i * in_bytes, kind_in, &padded[ i * (size_t)ix->chunks * 4 ]);
+        src = padded.data();
+    }
+    char     *vec_base = (char *)ix->d_vec + first * row;
+    uint64_t *lab_base = ix->d_labels + first;
+    if(n_shard) {
+        HIPCHK(ix, hipMemcpyAsync(vec_base + my_off * row, src, n_shard * row, hipMemcpyHostToDevice, ix->stream));
+        HIPCHK(ix, hipMemcpyAsync(lab_base + my_off, labels, n_shard * 8, hipMemcpyHostToDevice, ix->stream));
+    }
+    HIPCHK(ix, hipMemcpyAsync(ix->d_levels + first, s.l8.data(), total, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipMemcpyAsync(ix->d_upper_off + first, s.uo.data(), total * 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipStreamSynchronize(ix->stream));  // `padded` and the caller's buffers are free again
+    size_t at = 0;
+    for(int r = 0; r < W; ++r) { off[ (size_t)r ] = at * row; cnt[ (size_t)r ] = (size_t)meta[ (size_t)r * 2 ] * row; at += (size_t)meta[ (size_t)r * 2 ]; }
+    if(!comm->allgatherv_device(vec_base, off.data(), cnt.data(), ix->stream)) { set_err(ix, comm->err); return false; }
+    for(int r = 0; r < W; ++r) { off[ (size_t)r ] = off[ (size_t)r ] / row * 8; cnt[ (size_t)r ] = cnt[ (size_t)r ] / row * 8; }
+    if(!comm->allgatherv_device(lab_base, off.data(), cnt.data(), ix->stream)) { set_err(ix, comm->err); return false; }
+    std::vector<uint64_t> all_labels(total);
+    HIPCHK(ix, hipMemcpyAsync(all_labels.data(), lab_base, total * 8, hipMemcpyDeviceToHost, ix->stream));
+    if(!sync_stream(ix, comm)) return false;
+    bool ok = true;
+    run_batches(ix, all_labels.data(), s, total, comm, &ok);
+    return ok;
 }
 
 bool flush_locked(Index *ix)
@@ -621,6 +771,39 @@ void lantern_gpu_add_with_level(usearch_index_t h, usearch_label_t label, const 
     if(!ix) return;
     if(level < 0 || level > 255) { FAIL(e, "lantern_gpu: level out of range"); return; }
     add_common(ix, &label, vector, 1, kind, level, e);
+}
+
+void lantern_gpu_add_sharded(usearch_index_t h, lantern_gpu_comm_t *comm, const usearch_label_t *labels, const void *vectors,
+                             size_t n_shard, usearch_scalar_kind_t kind, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    if(!comm) { FAIL(e, "lantern_gpu: null communicator"); return; }
+    if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the vector does not match the index"); return; }
+    if(n_shard && (!vectors || !labels)) { FAIL(e, "lantern_gpu: null vector or label pointer"); return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!add_sharded_locked(ix, (Comm *)comm, labels, vectors, n_shard, (int)kind)) FAIL(e, ix->err.c_str());
+}
+
+uint64_t lantern_gpu_graph_checksum(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return 0;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return 0; }
+    const size_t n = ix->n;
+    std::vector<uint32_t> nbr0(n * ix->M0), upper(ix->upper_blocks * ix->M);
+    bool ok = true;
+    if(n) ok = ok && hipMemcpy(nbr0.data(), ix->d_nbr0, nbr0.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(!upper.empty()) ok = ok && hipMemcpy(upper.data(), ix->d_upper_nbr, upper.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(!ok) { FAIL(e, "lantern_gpu: HIP failure reading the graph"); return 0; }
+    uint64_t hsh = splitmix64((uint64_t)n ^ ((uint64_t)ix->entry << 32) ^ ((uint64_t)(uint32_t)ix->max_level << 24));
+    for(size_t i = 0; i < n; ++i) hsh = splitmix64(hsh ^ ix->levels[ i ] ^ (ix->labels[ i ] << 8));
+    for(uint32_t v : nbr0) hsh = splitmix64(hsh ^ v);
+    for(uint32_t v : upper) hsh = splitmix64(hsh ^ v);
+    return hsh;
 }
 
 void lantern_gpu_flush(usearch_index_t h, usearch_error_t *e)

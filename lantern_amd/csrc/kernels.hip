@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(512) k_insert(InsertArgs a)
     carve_walk(lgpu_smem, s, a.view.chunks, a.efc, a.view.M0, a.vis_slots);
     uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
     const uint32_t chunks = a.view.chunks, M = a.view.M;
-    for(uint32_t b = blockIdx.x; b < a.count; b += gridDim.x) {
+    for(uint32_t b = a.b_begin + blockIdx.x; b < a.count; b += gridDim.x) {
         const uint32_t me = a.first_slot + b;
         const int      target = a.view.levels[ me ];
         const uint32_t item0 = a.link_off[ b ] / M;  // one item per (node, level)
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
     int      *scal = (int *)p;                  p += S_SCALARS * 4;
     uint32_t *kid = (uint32_t *)p;              p += (size_t)((a.view.M + 3) & ~3u) * 4;  // selected slots (<= M)
     float    *kd = (float *)p;
-    const uint32_t item = blockIdx.x;
+    const uint32_t item = a.item_begin + blockIdx.x;
     const uint32_t b = a.item_node[ item ];
     const uint32_t M = a.view.M;
     const uint32_t me = a.first_slot + b;
@@ -991,6 +991,52 @@ __global__ void __launch_bounds__(512) k_revlink_regs(RevlinkArgs a, const RevWo
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// Work-sharded build: scatter kernels either side of the all-gathers (pure index traffic, no arithmetic).
+__global__ void __launch_bounds__(256) k_apply_own_links(View v, uint32_t first_slot, const uint32_t *link_off, const LinkReq *links,
+                                                         uint32_t total_links)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= total_links) return;
+    const LinkReq req = links[ j ];
+    if(req.close == EMPTY) return;  // lists are EMPTY-initialised beyond the kept entries
+    const uint32_t b = req.new_slot - first_slot;
+    const uint32_t i = j - link_off[ b ] - req.level * v.M;
+    uint32_t       cap;
+    uint32_t      *list = neighbors_of(v, req.new_slot, (int)req.level, cap);
+    list[ i ] = req.close;
+}
+
+__global__ void __launch_bounds__(256) k_pack_lists(RevlinkArgs a, uint32_t *records)
+{
+    const uint32_t rw = a.view.M0 + 2;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = t / rw, w = t - g * rw;
+    if(g >= a.ngroups) return;
+    const LinkReq  first = a.reqs[ a.group_begin[ g ] ];
+    uint32_t       cap;
+    const uint32_t *list = neighbors_of(a.view, first.close, (int)first.level, cap);
+    uint32_t       val;
+    if(w == 0) val = first.close;
+    else if(w == 1) val = first.level;
+    else val = (w - 2) < cap ? list[ w - 2 ] : EMPTY;
+    records[ (size_t)g * rw + w ] = val;
+}
+
+__global__ void __launch_bounds__(256) k_apply_lists(View v, const uint32_t *records, uint32_t nrecords)
+{
+    const uint32_t rw = v.M0 + 2;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = t / rw, w = t - g * rw;
+    if(g >= nrecords || w < 2) return;
+    const uint32_t close = records[ (size_t)g * rw ];
+    if(close == EMPTY) return;  // padding of a rank's segment
+    const int level = (int)records[ (size_t)g * rw + 1 ];
+    uint32_t  cap;
+    uint32_t *list = neighbors_of(v, close, level, cap);
+    if(w - 2 < cap) list[ w - 2 ] = records[ (size_t)g * rw + w ];
+}
+
 template <int METRIC, int G>
 __global__ void __launch_bounds__(256) k_gather(View v, const uint4 *query, const uint32_t *slots, uint32_t n, float *out)
 {
@@ -1141,6 +1187,30 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
 #define CALL(MM, GG) hipLaunchKernelGGL((k_revlink<MM, GG>), dim3(a.ngroups), dim3(256), lds, stream, a)
     LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_apply_own_links(const View &v, uint32_t first_slot, const uint32_t *link_off, const LinkReq *links,
+                                  uint32_t total_links, hipStream_t stream)
+{
+    if(total_links == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_apply_own_links, dim3((total_links + 255) / 256), dim3(256), 0, stream, v, first_slot, link_off, links, total_links);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_lists(const RevlinkArgs &a, uint32_t *records, hipStream_t stream)
+{
+    if(a.ngroups == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)a.ngroups * (a.view.M0 + 2);
+    hipLaunchKernelGGL(k_pack_lists, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, a, records);
+    return hipGetLastError();
+}
+
+hipError_t launch_apply_lists(const View &v, const uint32_t *records, uint32_t nrecords, hipStream_t stream)
+{
+    if(nrecords == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)nrecords * (v.M0 + 2);
+    hipLaunchKernelGGL(k_apply_lists, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, v, records, nrecords);
     return hipGetLastError();
 }
 

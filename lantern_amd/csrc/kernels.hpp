@@ -39,9 +39,10 @@ struct InsertArgs
 {
     View            view;       // n = size BEFORE the batch; entry/max_level frozen
     uint32_t        first_slot; // the batch occupies slots [first_slot, first_slot + count)
-    uint32_t        count;
+    uint32_t        b_begin;    // this launch walks the batch members [b_begin, count) -- a rank of a work-sharded
+    uint32_t        count;      // build (shard.cpp) walks only its own sub-range; 0 / batch size otherwise
     uint32_t        efc;
-    const uint32_t *link_off;   // [count] first LinkReq of each new node (M*(level+1) entries each); /M = first item
+    const uint32_t *link_off;   // [batch] first LinkReq of each new node (M*(level+1) entries each); /M = first item
     uint64_t       *tops;       // [items][efc] walk results, ascending (distance, slot) keys
     uint32_t       *top_count;  // [items]
     uint32_t       *bitmaps;
@@ -55,7 +56,8 @@ struct ConnectArgs
 {
     View            view;
     uint32_t        first_slot;
-    uint32_t        items;
+    uint32_t        item_begin;  // first item of this launch (a rank's sub-range of a work-sharded build; 0 otherwise)
+    uint32_t        items;       // items of this launch
     uint32_t        efc;
     const uint32_t *link_off;    // [count]
     const uint32_t *item_node;   // [items] index of the new node within the batch
@@ -80,6 +82,16 @@ hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, h
 hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream);
 // work: scratch of ngroups x 8 bytes; work_count: one u32 (both device memory; NULL = unstaged kernel)
 hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream);
+// ---- work-sharded build (shard.cpp): the exchange steps either side of the RCCL all-gathers -------------
+// Every rank holds the complete request array after the first all-gather; the own lists of the nodes another
+// rank connected are rebuilt from their requests: list(new_slot, level)[i] = links[link_off[b] + level*M + i].close
+hipError_t launch_apply_own_links(const View &v, uint32_t first_slot, const uint32_t *link_off, const LinkReq *links,
+                                  uint32_t total_links, hipStream_t stream);
+// One record per reverse-link group a rank owned: [close, level, list[0..M0)] (rec_words = M0 + 2 u32 words).
+// pack: records[g] for g in [0, ngroups); apply: every record with close != EMPTY is written into the local replica.
+hipError_t launch_pack_lists(const RevlinkArgs &a, uint32_t *records, hipStream_t stream);
+hipError_t launch_apply_lists(const View &v, const uint32_t *records, uint32_t nrecords, hipStream_t stream);
+
 // out[i] = metric(query, row(slots[i]))
 hipError_t launch_gather(int metric, const View &v, const uint4 *query, const uint32_t *slots, uint32_t n, float *out,
                          hipStream_t stream);

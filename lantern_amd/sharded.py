@@ -76,3 +76,49 @@ def sharded_search(search_fn, queries: np.ndarray, k: int, device=None):
     lab = gather_rows(np.ascontiguousarray(labels).view(np.int64), queries.shape[0], device).view(np.uint64)
     dst = gather_rows(np.ascontiguousarray(dists), queries.shape[0], device)
     return lab, dst
+
+
+# ---- work-sharded index build: communicators for lantern_gpu_add_sharded ------------------------
+
+
+def torch_allgatherv(group=None):
+    """An in-place host all-gather with per-rank sizes over torch.distributed (gloo on CPU tensors), in the shape
+    lantern_amd.capi.Comm.host expects.  Segments are padded to the largest one (gloo has no all-gather-v)."""
+    import torch
+
+    dist = _dist()
+
+    def allgatherv(buf: np.ndarray, offsets, counts):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        pad = max(max(counts), 1)
+        mine = torch.zeros(pad, dtype=torch.uint8)
+        if counts[rank]:
+            mine[: counts[rank]] = torch.from_numpy(buf[offsets[rank]: offsets[rank] + counts[rank]].copy())
+        outs = [torch.empty(pad, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(outs, mine, group=group)
+        for r in range(world):
+            if r != rank and counts[r]:
+                buf[offsets[r]: offsets[r] + counts[r]] = outs[r][: counts[r]].numpy()
+
+    return allgatherv
+
+
+def host_comm(group=None):
+    """A lantern_gpu communicator whose exchange runs over torch.distributed host tensors (gloo): the debug /
+    test transport.  Production multi-GPU builds use rccl_comm()."""
+    from lantern_amd import capi
+
+    dist = _dist()
+    return capi.Comm.host(dist.get_rank(group), dist.get_world_size(group), torch_allgatherv(group))
+
+
+def rccl_comm(group=None):
+    """A lantern_gpu communicator over RCCL (xGMI): rank 0 draws the unique id, torch.distributed carries it to
+    the peers (128 bytes, host side), every rank then joins with its current HIP device."""
+    from lantern_amd import capi
+
+    dist = _dist()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [capi.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return capi.Comm.rccl(rank, world, box[0])

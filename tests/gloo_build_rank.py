@@ -1,0 +1,45 @@
+"""One rank of tests/test_gpu_sharded_build.py::test_two_gloo_processes_share_one_build.
+
+    python tests/gloo_build_rank.py RANK WORLD OUT_DIR      (MASTER_ADDR / MASTER_PORT in the environment)
+
+Builds ONE index with lantern_gpu_add_sharded together with its peers; the exchange runs over torch.distributed's
+gloo backend through the library's host transport.  Every rank writes its replica's checksum; rank 0 also builds the
+same rows alone and writes that checksum.
+"""
+import os
+import sys
+
+import numpy as np
+
+
+def main():
+    rank, world, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    import torch  # noqa: F401  -- before the HIP library: one HIP runtime per process (lantern_amd/capi.py note)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lantern_amd import capi, sharded
+
+    n, d = 2400, 96
+    rng = np.random.default_rng(13)
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    labels = np.arange(n, dtype=np.uint64) + 1
+    comm = sharded.host_comm()
+    comm.set_timeout(120)
+    lo, hi = capi.shard_range(n, world, rank)
+    ix = capi.GpuIndex("l2sq", d, M=8, ef_construction=40, ef=32, seed=21)
+    ix.set_add_batch(256, 8)
+    ix.add_sharded(comm, labels[lo:hi], base[lo:hi])
+    np.save(os.path.join(out_dir, f"sum{rank}.npy"), np.array([ix.checksum()], dtype=np.uint64))
+    if rank == 0:
+        ref = capi.GpuIndex("l2sq", d, M=8, ef_construction=40, ef=32, seed=21)
+        ref.set_add_batch(256, 8)
+        ref.add_many(labels, base)
+        ref.flush()
+        np.save(os.path.join(out_dir, "ref.npy"), np.array([ref.checksum()], dtype=np.uint64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
