@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "lib", "liblantern_gpu.so")
 
 # usearch_metric_kind_t / usearch_scalar_kind_t (cli.rs:56-69, server.rs:94-101)
 METRIC_COS, METRIC_L2SQ, METRIC_HAMMING = 1, 3, 8
-SCALAR_F32, SCALAR_F16, SCALAR_B1 = 1, 3, 5
+SCALAR_F32, SCALAR_F16, SCALAR_I8, SCALAR_B1 = 1, 3, 4, 5
 METRICS = {"cos": METRIC_COS, "l2sq": METRIC_L2SQ, "hamming": METRIC_HAMMING}
 EMPTY = 0xFFFFFFFF
 USEARCH_HEADER_SIZE = 136
@@ -276,15 +276,16 @@ class GpuIndex:
     def __init__(self, metric, dims, M=16, ef_construction=128, ef=64, seed=42, retriever=None, quantization="f32"):
         """retriever: optional Python callable slot(int) -> address(int) of the node tape (the
         ldb_wal_index_node_retriever contract, external_index.c:613-671), used by view_mem_lazy().
-        quantization: "f32" or "f16" storage (reloption quant_bits 32 / 16, options.c:137-158); vectors and
-        queries are still handed over as f32, as Lantern does."""
+        quantization: "f32", "f16" or "i8" storage (reloption quant_bits 32 / 16 / 8, options.c:137-158); vectors
+        and queries are still handed over as f32, as Lantern does."""
         self.metric = METRICS.get(metric, metric)
         self.f16 = quantization == "f16"
+        self.i8 = quantization == "i8"
         self.dims, self.M, self.efc, self.ef = dims, M, ef_construction, ef
         o = InitOptions()
         o.metric_kind = self.metric
         o.metric = None
-        o.quantization = SCALAR_F16 if self.f16 else _kind(self.metric)
+        o.quantization = SCALAR_F16 if self.f16 else SCALAR_I8 if self.i8 else _kind(self.metric)
         o.dimensions = dims * 32 if self.metric == METRIC_HAMMING else dims  # scan.c:84-88
         o.connectivity, o.expansion_add, o.expansion_search, o.num_threads = M, ef_construction, ef, 1
         o.pq = False
@@ -414,13 +415,13 @@ class GpuIndex:
         }
         vecs = None
         if with_vectors:  # storage format: u32 words (hamming), f32, or f16 halves (two per word)
-            vecs = np.zeros((n, gi.vector_words), dtype=np.uint32 if (self.metric == METRIC_HAMMING or self.f16) else np.float32)
+            vecs = np.zeros((n, gi.vector_words), dtype=np.uint32 if (self.metric == METRIC_HAMMING or self.f16 or self.i8) else np.float32)
         _call("lantern_gpu_export_graph", self.h, _ptr(g["levels"]), _ptr(g["nbr0"]), _ptr(g["upper_off"]),
               _ptr(g["upper_nbr"]), _ptr(g["labels"]), _ptr(vecs))
         g["upper_nbr"] = g["upper_nbr"][:gi.upper_blocks]
         g["entry_slot"], g["max_level"] = int(gi.entry_slot), int(gi.max_level)
         if with_vectors:
-            g["vectors"] = vecs.view(np.float16)[:, :self.dims] if self.f16 else vecs
+            g["vectors"] = vecs.view(np.float16)[:, :self.dims] if self.f16 else vecs.view(np.int8)[:, :self.dims] if self.i8 else vecs
         return g
 
     def import_graph(self, vectors, graph):
@@ -429,6 +430,10 @@ class GpuIndex:
             h = np.zeros((V.shape[0], (self.dims + 1) // 2 * 2), dtype=np.float16)
             h[:, :self.dims] = V.astype(np.float16)
             V = h
+        if self.i8:  # storage format: the quantised bytes, padded to whole 4-byte words; V must already hold integers
+            q = np.zeros((V.shape[0], (self.dims + 3) // 4 * 4), dtype=np.int8)
+            q[:, :self.dims] = V.astype(np.int8)
+            V = q
         levels = np.ascontiguousarray(graph["levels"], dtype=np.uint8)
         nbr0 = np.ascontiguousarray(graph["nbr0"], dtype=np.uint32)
         upper_off = np.ascontiguousarray(graph["upper_off"], dtype=np.uint32)

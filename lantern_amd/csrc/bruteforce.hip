@@ -245,6 +245,30 @@ __global__ void __launch_bounds__(256) k_dequant_f16(const uint4 *src, size_t nc
     }
 }
 
+// i8 rows (16 bytes per chunk) -> f32 rows (four chunks) for the MFMA contraction; integers up to 100 are exact in f32
+__global__ void __launch_bounds__(256) k_dequant_i8(const uint4 *src, size_t nchunks, uint4 *dst)
+{
+    for(size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4    v = src[ i ];
+        const uint32_t w[ 4 ] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for(int j = 0; j < 4; ++j) {
+            const float f0 = (float)(int8_t)(w[ j ] & 0xFF), f1 = (float)(int8_t)((w[ j ] >> 8) & 0xFF);
+            const float f2 = (float)(int8_t)((w[ j ] >> 16) & 0xFF), f3 = (float)(int8_t)(w[ j ] >> 24);
+            dst[ 4 * i + j ] = make_uint4(__float_as_uint(f0), __float_as_uint(f1), __float_as_uint(f2), __float_as_uint(f3));
+        }
+    }
+}
+
+hipError_t launch_dequant_i8(const uint4 *src, size_t nchunks, uint4 *dst, hipStream_t stream)
+{
+    if(nchunks == 0) return hipSuccess;
+    size_t blocks = (nchunks + 255) / 256;
+    if(blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_dequant_i8, dim3((uint32_t)blocks), dim3(256), 0, stream, src, nchunks, dst);
+    return hipGetLastError();
+}
+
 hipError_t launch_dequant_f16(const uint4 *src, size_t nchunks, uint4 *dst, hipStream_t stream)
 {
     if(nchunks == 0) return hipSuccess;
@@ -312,6 +336,8 @@ hipError_t launch_rerank(int metric, const uint4 *Q, uint32_t nq, const uint4 *B
         case M_HAMMING: RRG(M_HAMMING); break;
         case M_L2SQ_F16: RRG(M_L2SQ_F16); break;
         case M_COS_F16: RRG(M_COS_F16); break;
+        case M_L2SQ_I8: RRG(M_L2SQ_I8); break;
+        case M_COS_I8: RRG(M_COS_I8); break;
         default: return hipErrorInvalidValue;
     }
 #undef RRG

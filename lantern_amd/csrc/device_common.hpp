@@ -27,8 +27,16 @@ constexpr int M_HAMMING = 8;
 constexpr int M_F16 = 100;
 constexpr int M_COS_F16 = M_COS + M_F16;
 constexpr int M_L2SQ_F16 = M_L2SQ + M_F16;
-__host__ __device__ inline bool mcode_is_f16(int m) { return m >= M_F16; }
-__host__ __device__ inline int  mcode_base(int m) { return m >= M_F16 ? m - M_F16 : m; }
+// i8 STORAGE (quant_bits = 8): 16 scalars per 16-byte chunk.  usearch quantises f32 -> i8 as trunc(x * 100) clamped
+// to [-100, 100] (lantern_hnsw/test/sql/hnsw_sq.sql:33-34: "i8 uniform [-1-1]=>[-100,100] quantization") and its
+// cos_i8_t / l2sq_i8_t metrics accumulate in int32 -- integer-exact, so the summation order is immaterial.
+// Internal codes = metric + 200.
+constexpr int M_I8 = 200;
+constexpr int M_COS_I8 = M_COS + M_I8;
+constexpr int M_L2SQ_I8 = M_L2SQ + M_I8;
+__host__ __device__ inline bool mcode_is_f16(int m) { return m >= M_F16 && m < M_I8; }
+__host__ __device__ inline bool mcode_is_i8(int m) { return m >= M_I8; }
+__host__ __device__ inline int  mcode_base(int m) { return m >= M_I8 ? m - M_I8 : m >= M_F16 ? m - M_F16 : m; }
 
 // ---- order-preserving float <-> u32, and the (distance, slot) candidate key ---------------------
 __device__ __forceinline__ uint32_t f2ord(float f)
@@ -180,6 +188,45 @@ template <> struct Acc<M_COS_F16>
         word(xa.x, yb.x); word(xa.y, yb.y); word(xa.z, yb.z); word(xa.w, yb.w);
     }
     template <int G> __device__ __forceinline__ float finish() { return f.template finish<G>(); }
+};
+
+// ---- i8 storage: four signed bytes per 32-bit word, V_DOT4_I32_I8 -----------------------------------------
+__device__ __forceinline__ int dot4_i8(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+
+template <> struct Acc<M_L2SQ_I8>
+{
+    // sum (a - b)^2 = sum a^2 + sum b^2 - 2 sum ab, every term an exact int32 (|.| <= 2000 * 100^2)
+    int ab = 0, a2 = 0, b2 = 0;
+    __device__ __forceinline__ void word(uint32_t x, uint32_t y)
+    {
+        ab = dot4_i8(x, y, ab);
+        a2 = dot4_i8(x, x, a2);
+        b2 = dot4_i8(y, y, b2);
+    }
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb)
+    {
+        word(xa.x, yb.x); word(xa.y, yb.y); word(xa.z, yb.z); word(xa.w, yb.w);
+    }
+    template <int G> __device__ __forceinline__ float finish()
+    {
+        const uint32_t s = group_sum<G>((uint32_t)(a2 + b2 - 2 * ab));
+        return (float)(int)s;
+    }
+};
+
+template <> struct Acc<M_COS_I8>
+{
+    Acc<M_L2SQ_I8> f;
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb) { f.add(xa, yb); }
+    template <int G> __device__ __forceinline__ float finish()
+    {
+        const float ab = (float)(int)group_sum<G>((uint32_t)f.ab);
+        const float a2 = (float)(int)group_sum<G>((uint32_t)f.a2);
+        const float b2 = (float)(int)group_sum<G>((uint32_t)f.b2);
+        if(a2 == 0.f && b2 == 0.f) return 0.f;  // the zero-norm rules of the f32 metric
+        if(a2 == 0.f || b2 == 0.f) return 1.f;
+        return 1.f - ab / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));
+    }
 };
 
 // One distance by one G-lane group: a and b each `chunks` uint4 long; gl = lane index in group.

@@ -122,14 +122,27 @@ size_t input_bytes(const Index *ix, int kind_in)
 {
     if(kind_in == usearch_scalar_b1_k) return (ix->opts.dimensions + 7) / 8;
     if(kind_in == usearch_scalar_f16_k) return ix->opts.dimensions * 2;
+    if(kind_in == usearch_scalar_i8_k) return ix->opts.dimensions;
     return ix->opts.dimensions * 4;
 }
 
-// which caller-side scalar kinds an index takes: its own storage kind, and f32 for an f16 index (Lantern
+// which caller-side scalar kinds an index takes: its own storage kind, and f32 for an f16 / i8 index (Lantern
 // hands f32 arrays to usearch_add / usearch_search_ef whatever quant_bits says: build.c:128, scan.c:220)
 bool kind_accepted(const Index *ix, int kind_in)
 {
-    return kind_in == ix->scalar || (ix->scalar == usearch_scalar_f16_k && kind_in == usearch_scalar_f32_k);
+    return kind_in == ix->scalar ||
+           ((ix->scalar == usearch_scalar_f16_k || ix->scalar == usearch_scalar_i8_k) && kind_in == usearch_scalar_f32_k);
+}
+
+// f32 -> i8 as usearch's i8 storage does it: x * 100, clamped to [-100, 100], truncated toward zero
+// (lantern_hnsw/test/sql/hnsw_sq.sql:33-34: "i8 uniform [-1-1]=>[-100,100] quantization"); NaN -> 0
+static inline int8_t quantize_i8(float x)
+{
+    float v = x * 100.0f;
+    if(!(v == v)) return 0;
+    if(v > 100.0f) v = 100.0f;
+    if(v < -100.0f) v = -100.0f;
+    return (int8_t)(int)v;
 }
 
 // caller vector -> stored row (zero padded to whole 16-byte chunks).  f32 -> f16 is round-to-nearest-even,
@@ -142,6 +155,10 @@ bool pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst)
         const float *f = (const float *)vec;
         _Float16    *h = (_Float16 *)dst;
         for(size_t i = 0; i < ix->opts.dimensions; ++i) h[ i ] = (_Float16)f[ i ];
+    } else if(ix->scalar == usearch_scalar_i8_k && kind_in == usearch_scalar_f32_k) {
+        const float *f = (const float *)vec;
+        int8_t      *q = (int8_t *)dst;
+        for(size_t i = 0; i < ix->opts.dimensions; ++i) q[ i ] = quantize_i8(f[ i ]);
     } else {
         std::memcpy(dst, vec, input_bytes(ix, kind_in));
     }
@@ -643,8 +660,8 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     if(o->connectivity < 2 || o->connectivity > 128) { FAIL(e, "lantern_gpu: connectivity (M) must be in [2, 128]"); return nullptr; }  // options.c:165-179
     const bool ham = o->metric_kind == usearch_metric_hamming_k;
     if(ham && o->quantization != usearch_scalar_b1_k) { FAIL(e, "lantern_gpu: hamming needs b1 scalars"); return nullptr; }
-    if(!ham && o->quantization != usearch_scalar_f32_k && o->quantization != usearch_scalar_f16_k) {
-        FAIL(e, "lantern_gpu: only f32 storage and f16 storage are supported for cos/l2sq (quant_bits=32 or 16)");  // options.c:137-158
+    if(!ham && o->quantization != usearch_scalar_f32_k && o->quantization != usearch_scalar_f16_k && o->quantization != usearch_scalar_i8_k) {
+        FAIL(e, "lantern_gpu: cos/l2sq indexes take f32, f16 or i8 storage (quant_bits=32, 16 or 8)");  // options.c:137-158
         return nullptr;
     }
     if(lantern_gpu_device_count() <= 0) { FAIL(e, kNoDevice); return nullptr; }
@@ -653,9 +670,12 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     ix->opts = *o;
     ix->metric = (int)o->metric_kind;
     ix->scalar = (int)o->quantization;
-    const bool f16 = o->quantization == usearch_scalar_f16_k;
-    ix->mcode = ix->metric + (f16 ? M_F16 : 0);
-    ix->words = ham ? (uint32_t)((o->dimensions + 31) / 32) : f16 ? (uint32_t)((o->dimensions + 1) / 2) : (uint32_t)o->dimensions;
+    const bool f16 = o->quantization == usearch_scalar_f16_k, i8 = o->quantization == usearch_scalar_i8_k;
+    ix->mcode = ix->metric + (f16 ? M_F16 : i8 ? M_I8 : 0);
+    ix->words = ham ? (uint32_t)((o->dimensions + 31) / 32)
+                : f16 ? (uint32_t)((o->dimensions + 1) / 2)
+                : i8 ? (uint32_t)((o->dimensions + 3) / 4)
+                     : (uint32_t)o->dimensions;
     ix->chunks = (ix->words + 3) / 4;
     ix->M = (uint32_t)o->connectivity;
     ix->M0 = 2 * ix->M;  // validate_index.c:140-151
@@ -1027,9 +1047,11 @@ static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, si
     // last bits, so the survivors are re-ranked exactly and only then cut to k
     const uint32_t kk = (uint32_t)k + 16;
     const size_t   QT = 1024, CH = std::min<size_t>(nb, 65536);
-    const bool     f16 = mcode_is_f16(mcode);
+    const bool     i8 = mcode_is_i8(mcode);
+    const bool     f16 = mcode_is_f16(mcode) || i8;  // "quantised storage": the contraction runs on an f32 copy
     const int      base_metric = mcode_base(mcode);
-    const uint32_t fchunks = f16 ? chunks * 2 : chunks;  // chunks of the f32 view fed to the contraction
+    const uint32_t fchunks = i8 ? chunks * 4 : f16 ? chunks * 2 : chunks;  // chunks of the f32 view fed to the contraction
+    auto dequant = [&](const uint4 *src, size_t nchunks, uint4 *dst) { return i8 ? launch_dequant_i8(src, nchunks, dst, st) : launch_dequant_f16(src, nchunks, dst, st); };
     char  *aux = nullptr;
     float *dd = nullptr;
     uint4 *fq = nullptr, *fb = nullptr;  // f32 copies of f16 rows (queries; one chunk of base rows)
@@ -1037,7 +1059,7 @@ static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, si
               hipMalloc((void **)&dd, std::min(nq, QT) * CH * 4) == hipSuccess;
     if(ok && f16)
         ok = hipMalloc((void **)&fq, nq * (size_t)fchunks * 16) == hipSuccess && hipMalloc((void **)&fb, CH * (size_t)fchunks * 16) == hipSuccess &&
-             launch_dequant_f16(d_q, nq * (size_t)chunks, fq, st) == hipSuccess;
+             dequant(d_q, nq * (size_t)chunks, fq) == hipSuccess;
     if(ok) {
         float    *qn = (float *)aux, *bn = qn + nq;
         uint64_t *best = (uint64_t *)(aux + (nq + nb) * 4 + ((nq + nb) % 2) * 4);
@@ -1049,7 +1071,7 @@ static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, si
             const size_t nc = std::min(CH, nb - c0);
             const uint4 *bv = d_base + c0 * chunks;
             if(f16) {
-                ok = ok && launch_dequant_f16(d_base + c0 * chunks, nc * (size_t)chunks, fb, st) == hipSuccess;
+                ok = ok && dequant(d_base + c0 * chunks, nc * (size_t)chunks, fb) == hipSuccess;
                 ok = ok && launch_row_norms(fb, (uint32_t)nc, fchunks, bn + c0, st) == hipSuccess;
                 bv = fb;
             }

@@ -1087,6 +1087,14 @@ __global__ void __launch_bounds__(256) k_pairs(const uint4 *a, uint32_t na, cons
                 switch(G_) { case 64: CALL(M_COS_F16, 64); break; case 32: CALL(M_COS_F16, 32); break; \
                              case 16: CALL(M_COS_F16, 16); break; default: CALL(M_COS_F16, 8); } \
                 break;                                                        \
+            case M_L2SQ_I8:                                                   \
+                switch(G_) { case 64: CALL(M_L2SQ_I8, 64); break; case 32: CALL(M_L2SQ_I8, 32); break; \
+                             case 16: CALL(M_L2SQ_I8, 16); break; default: CALL(M_L2SQ_I8, 8); } \
+                break;                                                        \
+            case M_COS_I8:                                                    \
+                switch(G_) { case 64: CALL(M_COS_I8, 64); break; case 32: CALL(M_COS_I8, 32); break; \
+                             case 16: CALL(M_COS_I8, 16); break; default: CALL(M_COS_I8, 8); } \
+                break;                                                        \
             default: return hipErrorInvalidValue;                             \
         }                                                                     \
     } while(0)
@@ -1137,7 +1145,8 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
     if(a.ngroups == 0) return hipSuccess;
     // staged variant whenever the 2M+2 rows of a level-0 re-prune fit in LDS (d <= 1024 at M = 16)
     const size_t staged = staged_lds_bytes(a.view.chunks, a.view.M0);
-    if(a.view.chunks >= 128 && a.view.chunks <= 256 && a.view.M0 <= 32 && work && work_count) {
+    const bool i8 = mcode_is_i8(metric);  // i8 rows take the LDS-staged / generic kernels (Lantern caps d at 2000: <= 125 chunks)
+    if(!i8 && a.view.chunks >= 128 && a.view.chunks <= 256 && a.view.M0 <= 32 && work && work_count) {
         // d = 512..1024 f32 rows, M <= 16: kept rows in registers (k_revlink_regs), 2 x 8 waves per CU
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;
@@ -1153,7 +1162,7 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
         }
         return hipGetLastError();
     }
-    if(a.view.chunks >= 128 && a.view.M0 <= 32 && work && work_count) {
+    if(!i8 && a.view.chunks >= 128 && a.view.M0 <= 32 && work && work_count) {
         // common shape (G = 64: d >= 512 f32 / 1024 f16, and M <= 16): column-slab sweep, 2 x 8 waves per CU
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;

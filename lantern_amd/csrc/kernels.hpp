@@ -102,6 +102,7 @@ hipError_t launch_pairs(int metric, const uint4 *a, uint32_t na, const uint4 *b,
 // dense contraction + exact k-NN building blocks (bruteforce.hip)
 hipError_t launch_row_norms(const uint4 *rows, uint32_t n, uint32_t chunks, float *out, hipStream_t stream);
 hipError_t launch_dequant_f16(const uint4 *src, size_t nchunks, uint4 *dst, hipStream_t stream);
+hipError_t launch_dequant_i8(const uint4 *src, size_t nchunks, uint4 *dst, hipStream_t stream);
 hipError_t launch_dense(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t nb, uint32_t chunks, const float *qn,
                         const float *bn, float *out, uint32_t ldo, hipStream_t stream);
 hipError_t launch_select(const float *dist, uint32_t ldo, uint32_t nq, uint32_t ncols, uint32_t c_base, uint64_t *best, uint32_t kk,

@@ -122,9 +122,20 @@ class Event:
         return float(ms.value)
 
 
-def padded_rows(x: np.ndarray, metric_is_hamming: bool, f16: bool = False) -> np.ndarray:
+def padded_rows(x: np.ndarray, metric_is_hamming: bool, f16: bool = False, i8: bool = False) -> np.ndarray:
     """Rows in STORAGE format, zero-padded to whole 16-byte chunks: the layout the device entry points expect
-    (u32 words for hamming, f32, or halves for an f16 index: the cast is round-to-nearest-even)."""
+    (u32 words for hamming, f32, halves for an f16 index: the cast is round-to-nearest-even, or bytes for an i8
+    index: trunc(clamp(x * 100, -100, 100)), the library's own rule for f32 input)."""
+    if i8:
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        if a.ndim == 1:
+            a = a.reshape(1, -1)
+        v = a * np.float32(100.0)
+        v = np.where(np.isnan(v), np.float32(0), v)
+        q = np.trunc(np.clip(v, np.float32(-100.0), np.float32(100.0))).astype(np.int8)
+        out = np.zeros((q.shape[0], (q.shape[1] + 15) // 16 * 16), dtype=np.int8)
+        out[:, : q.shape[1]] = q
+        return out
     if f16:
         a = np.ascontiguousarray(x, dtype=np.float32).astype(np.float16)
         if a.ndim == 1:

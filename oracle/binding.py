@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "_build", "liblantern_oracle.so")
 NATIVE_LIB_PATH = os.path.join(HERE, "_build_native", "liblantern_oracle.so")
 
 METRIC_COS, METRIC_L2SQ, METRIC_HAMMING = 1, 3, 8
-SUM_SEQ, SUM_WAVE64, SUM_FAST, SUM_WAVE64_F16 = 0, 1, 2, 3
+SUM_SEQ, SUM_WAVE64, SUM_FAST, SUM_WAVE64_F16, SUM_I8 = 0, 1, 2, 3, 4
 EMPTY = 0xFFFFFFFF
 
 METRICS = {"cos": METRIC_COS, "l2sq": METRIC_L2SQ, "hamming": METRIC_HAMMING}
@@ -133,6 +133,14 @@ def distance(a, b, metric: str | int, sum_mode: int = SUM_SEQ) -> float:
 def round_f16(x) -> np.ndarray:
     """f32 -> f16 -> f32, round-to-nearest-even: what an f16 index stores and what it casts a query to."""
     return np.ascontiguousarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def quantize_i8(x) -> np.ndarray:
+    """f32 -> the integers an i8 index stores, returned as f32: trunc(clamp(x * 100, -100, 100)) in f32 arithmetic
+    (usearch's i8 storage; lantern_hnsw/test/sql/hnsw_sq.sql:33-34), NaN -> 0.  Feed these to SUM_I8."""
+    v = np.ascontiguousarray(x, dtype=np.float32) * np.float32(100.0)
+    v = np.where(np.isnan(v), np.float32(0), v)
+    return np.trunc(np.clip(v, np.float32(-100.0), np.float32(100.0))).astype(np.float32)
 
 
 def level_for(seed: int, slot: int, M: int) -> int:

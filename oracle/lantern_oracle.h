@@ -54,10 +54,14 @@ enum {
     LO_SUM_WAVE64 = 1, /* device order: G-lane fmaf chains + butterfly with offsets 1..G/2 */
     LO_SUM_FAST = 2,   /* same maths as SEQ, compiled with the reference's -fassociative-math flags
                           (lantern_hnsw/CMakeLists.txt:122-136): what the CPU baseline times */
-    LO_SUM_WAVE64_F16 = 3 /* device order for f16 STORAGE (quant_bits=16, options.c:137-158): 8 scalars per
+    LO_SUM_WAVE64_F16 = 3, /* device order for f16 STORAGE (quant_bits=16, options.c:137-158): 8 scalars per
                           16-byte chunk.  The oracle always computes on f32 arrays; for an f16 index the caller
                           passes values already rounded to f16 (usearch casts at add/search and its
                           metric_*_gt<f16_t, f32> converts each element back to f32 before the arithmetic) */
+    LO_SUM_I8 = 4      /* i8 STORAGE (quant_bits=8): the caller passes f32 arrays that already hold the quantised
+                          integers trunc(clamp(x*100, -100, 100)) (lantern_hnsw/test/sql/hnsw_sq.sql:33-34); the
+                          arithmetic is usearch's l2sq_i8_t / cos_i8_t: int32 accumulation, integer-exact, so there
+                          is no summation order to model.  PARITY UNPINNED: the reference pins no i8 result offline */
 };
 
 #define LO_EMPTY_SLOT 0xFFFFFFFFu

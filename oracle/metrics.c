@@ -134,9 +134,37 @@ static float cos_wave(const float *a, const float *b, size_t d, size_t epc)
     return cos_finish(pab[ 0 ], pa2[ 0 ], pb2[ 0 ]);
 }
 
+/* ---- LO_SUM_I8: usearch l2sq_i8_t / cos_i8_t -- int32 accumulators over the quantised integers ------------- */
+static float l2sq_i8(const float *a, const float *b, size_t d)
+{
+    int32_t s = 0;
+    for(size_t i = 0; i != d; ++i) {
+        int32_t t = (int32_t)a[ i ] - (int32_t)b[ i ];
+        s += t * t;
+    }
+    return (float)s;
+}
+
+static float cos_i8(const float *a, const float *b, size_t d)
+{
+    int32_t ab = 0, a2 = 0, b2 = 0;
+    for(size_t i = 0; i != d; ++i) {
+        int32_t x = (int32_t)a[ i ], y = (int32_t)b[ i ];
+        ab += x * y;
+        a2 += x * x;
+        b2 += y * y;
+    }
+    return cos_finish((float)ab, (float)a2, (float)b2); /* same zero-norm rules as the f32 metric */
+}
+
 float lo_distance(const void *a, const void *b, size_t dims, int metric, int sum_mode)
 {
     if(metric == LO_METRIC_HAMMING) return hamming_bits((const uint8_t *)a, (const uint8_t *)b, dims);
+    if(sum_mode == LO_SUM_I8) {
+        if(metric == LO_METRIC_L2SQ) return l2sq_i8((const float *)a, (const float *)b, dims);
+        if(metric == LO_METRIC_COS) return cos_i8((const float *)a, (const float *)b, dims);
+        return NAN;
+    }
     if(sum_mode == LO_SUM_FAST) return lo_distance_fast(a, b, dims, metric);
     const float *x = (const float *)a, *y = (const float *)b;
     const int wave = sum_mode == LO_SUM_WAVE64 || sum_mode == LO_SUM_WAVE64_F16;

@@ -420,6 +420,55 @@ def test_f16_storage_matches_oracle(capi, oracle, metric, n, d, M, efc):
     assert np.array_equal(other.search_batch(queries, 10)[0], lab)
 
 
+# i8 storage (reloption quant_bits = 8, options.c:137-158): vectors and queries arrive as f32 and are quantised to
+# trunc(clamp(x * 100, -100, 100)) (hnsw_sq.sql:33-34); distances are usearch's l2sq_i8_t / cos_i8_t -- int32
+# accumulation, integer-exact.  The oracle gets the quantised integers (SUM_I8); everything must match bit for bit.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric,n,d,M,efc", [("l2sq", 1500, 768, 16, 64), ("cos", 900, 200, 8, 40), ("l2sq", 600, 33, 4, 24),
+                                              ("cos", 700, 2000, 16, 48)])
+def test_i8_storage_matches_oracle(capi, oracle, metric, n, d, M, efc):
+    rng = np.random.default_rng(n + d + 8)
+    base = (rng.standard_normal((n, d), dtype=np.float32) * np.float32(0.4)).astype(np.float32)  # some values clamp at +-1
+    queries = (rng.standard_normal((48, d), dtype=np.float32) * np.float32(0.4)).astype(np.float32)
+    base[0, :3] = [np.nan, 5.0, -7.0]  # NaN -> 0, out-of-range values clamp
+    qb, qq = oracle.quantize_i8(base), oracle.quantize_i8(queries)
+    assert qb[0, 0] == 0 and qb[0, 1] == 100 and qb[0, 2] == -100
+    labels = np.arange(n, dtype=np.uint64) + 1
+    ora = oracle.OracleIndex(metric, d, M=M, ef_construction=efc, ef=48, seed=5, sum_mode=oracle.SUM_I8)
+    ora.add_planned(labels, qb, max_batch=256, min_ratio=8)
+    gpu = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=48, seed=5, quantization="i8")
+    gpu.set_add_batch(256, 8)
+    gpu.add_many(labels, base)
+    go, gg = ora.export_graph(), gpu.export_graph(with_vectors=True)
+    assert np.array_equal(gg["vectors"], qb.astype(np.int8)), "the stored bytes are the quantisation rule's"
+    assert np.array_equal(gg["nbr0"], go["nbr0"]) and np.array_equal(gg["upper_nbr"], go["upper_nbr"])
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(qq, 10)
+    lab, dist, cnt = gpu.search_batch(queries, 10)
+    assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist)
+    slots = rng.integers(0, n, 40).astype(np.uint32)
+    ref = np.array([oracle.distance(qq[0], qb[s], metric, oracle.SUM_I8) for s in slots], dtype=np.float32)
+    assert np.array_equal(gpu.distance_gather(queries[0], slots), ref)
+    if metric == "l2sq":  # integer-valued distances
+        assert np.array_equal(dist, np.round(dist))
+    e_slots, e_dists = gpu.exact_search(queries, 10)
+    t_ids, t_d = oracle.bruteforce(qb, qq, 10, metric, oracle.SUM_I8, 8)
+    assert np.array_equal(e_slots, t_ids) and np.array_equal(e_dists, t_d)
+    # device-resident queries in storage format (what bench.py hands over) give the same answers
+    from lantern_amd import hip
+
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False, i8=True))
+    d_slot = hip.Buffer(48 * 10 * 4)
+    gpu.search_batch_device(dq.ptr, 48, 10, 0, 0, None, None, d_slot.ptr)
+    hip.synchronize()
+    assert np.array_equal(d_slot.download((48, 10), np.uint32), o_slot)
+    # file: the tape holds d vector bytes
+    blob = gpu.save_buffer()
+    assert len(blob) == 136 + sum(10 + (4 + 2 * M * 6) + int(l) * (4 + M * 6) + d for l in gg["levels"])
+    other = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=48, seed=5, quantization="i8")
+    other.load_buffer(blob)
+    assert np.array_equal(other.search_batch(queries, 10)[0], lab)
+
+
 # ------------------------------------------------------------------------------------------------
 # limits of the reloptions / GUCs (options.c:165-179,324-348; build.c:394-401) and concurrency
 # ------------------------------------------------------------------------------------------------

@@ -212,3 +212,29 @@ def test_recall_floor_on_random_data(oracle):
         _, _, slots, D, E = ix.search_batch(queries, 10)
         assert oracle.recall_at_k(slots, truth) >= 0.7
         assert D.min() > 0 and E.min() > 0
+
+
+def test_i8_quantisation_rule_and_integer_metrics(oracle):
+    """quant_bits=8: "i8 uniform [-1-1]=>[-100,100] quantization" (lantern_hnsw/test/sql/hnsw_sq.sql:33-34);
+    usearch's l2sq_i8_t / cos_i8_t accumulate in int32.  PARITY UNPINNED by the reference beyond that comment."""
+    import numpy as np
+
+    x = np.array([0.0, 1.0, -1.0, 0.505, -0.505, 0.019, 3.0, -3.0, float("nan"), 0.999], dtype=np.float32)
+    assert oracle.quantize_i8(x).tolist() == [0, 100, -100, 50, -50, 1, 100, -100, 0, 99]
+    a = oracle.quantize_i8(np.array([0.5, -0.25, 1.7, 0.009], dtype=np.float32))
+    b = oracle.quantize_i8(np.array([0.1, 0.1, -3.0, 0.5], dtype=np.float32))
+    assert oracle.distance(a, b, "l2sq", oracle.SUM_I8) == 40.0**2 + 35.0**2 + 200.0**2 + 50.0**2
+    ab, a2, b2 = 50 * 10 - 25 * 10 - 100 * 100, 50**2 + 25**2 + 100**2, 10**2 + 10**2 + 100**2 + 50**2
+    want = np.float32(1) - np.float32(ab) / (np.sqrt(np.float32(a2)) * np.sqrt(np.float32(b2)))
+    assert oracle.distance(a, b, "cos", oracle.SUM_I8) == want
+    z = np.zeros(4, dtype=np.float32)
+    assert oracle.distance(z, z, "cos", oracle.SUM_I8) == 0.0 and oracle.distance(z, a, "cos", oracle.SUM_I8) == 1.0
+    # an i8 HNSW walk on the oracle is self-consistent with its own brute force
+    rng = np.random.default_rng(1)
+    base = oracle.quantize_i8(rng.standard_normal((800, 24), dtype=np.float32) * np.float32(0.4))
+    ix = oracle.OracleIndex("l2sq", 24, M=8, ef_construction=64, ef=64, seed=3, sum_mode=oracle.SUM_I8)
+    ix.add_many(np.arange(800) + 1, base)
+    q = oracle.quantize_i8(rng.standard_normal((32, 24), dtype=np.float32) * np.float32(0.4))
+    _, _, slots, _, _ = ix.search_batch(q, 10)
+    truth, _ = oracle.bruteforce(base, q, 10, "l2sq", oracle.SUM_I8)
+    assert oracle.recall_at_k(slots, truth) > 0.9
