@@ -51,7 +51,7 @@ def parse():
     p.add_argument("--truth-queries", type=int, default=1024, help="queries used for recall@k")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     p.add_argument("--no-cpu", action="store_true")
-    p.add_argument("--quant", default="f32", choices=["f32", "f16"], help="storage kind (reloption quant_bits 32 / 16); the headline config is f32")
+    p.add_argument("--quant", default="f32", choices=["f32", "f16", "i8"], help="storage kind (reloption quant_bits 32 / 16 / 8); the headline config is f32")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only to debug the N>1 path on one GPU")
     p.add_argument("--data", default="gaussian", choices=["gaussian", "lowrank"],
                    help="gaussian = the prescribed i.i.d. N(0,1) set (SURVEY 8d); lowrank = 32 latent dims embedded in --dim (embedding-like)")
@@ -115,7 +115,7 @@ def main():
     qrng = np.random.default_rng(4 + 1000 * rank)
     nq = a.queries
     queries = make_queries(qrng, nq)
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False, a.quant == "f16"))
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False, a.quant == "f16", a.quant == "i8"))
     d_lab, d_dist, d_slot = hip.Buffer(nq * a.k * 8), hip.Buffer(nq * a.k * 4), hip.Buffer(nq * a.k * 4)
     d_D, d_E = hip.Buffer(nq * 8), hip.Buffer(nq * 8)
     stream = hip.Stream()  # the launch stream; the events below are recorded on it
@@ -156,7 +156,7 @@ def main():
     # ---- algorithmic bytes of one launch --------------------------------------------
     D = d_D.download(nq, np.uint64).astype(np.float64)
     E = d_E.download(nq, np.uint64).astype(np.float64)
-    row_bytes = a.dim * (2 if a.quant == "f16" else 4)
+    row_bytes = a.dim * {"f32": 4, "f16": 2, "i8": 1}[a.quant]
     bytes_per_launch = float((D * row_bytes + E * (2 * a.M * 4) + row_bytes).sum())
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved = bytes_per_launch / avg_kernel_s / 1e9
@@ -197,7 +197,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if a.quant == "f32" else "f32 arithmetic on f16 storage",
+            "dtype": {"f32": "f32", "f16": "f32 arithmetic on f16 storage", "i8": "int32 arithmetic on i8 storage"}[a.quant],
             "data": "synthetic" if a.data == "gaussian" else "synthetic (low-rank)",
             "config": {"workload": f"HNSW search {a.n}x{a.dim} {a.quant} {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}",
                        "queries_per_step_per_gpu": nq, "global_queries_per_step": nq * world, "waves_per_query": a.waves,
@@ -311,9 +311,12 @@ def cpu_baseline(a, ix, base, queries, gpu_found):
     native = oracle.build_native() and oracle.use_native(True)  # best CPU code for the baseline: -march=native on this host
     cores = usable_cores()
     g = ix.export_graph()
+    mode = oracle.SUM_FAST
     if a.quant == "f16":  # the CPU port works on the rounded values (f32 arithmetic, no conversion cost: favours the CPU)
         base, queries = oracle.round_f16(base), oracle.round_f16(queries)
-    ora = oracle.OracleIndex.from_graph(a.metric, base, g, a.M, a.efc, a.ef, 42, oracle.SUM_FAST)
+    if a.quant == "i8":  # the quantised integers held as f32 (int32 accumulation in the port)
+        base, queries, mode = oracle.quantize_i8(base), oracle.quantize_i8(queries), oracle.SUM_I8
+    ora = oracle.OracleIndex.from_graph(a.metric, base, g, a.M, a.efc, a.ef, 42, mode)
     # size the samples from a short probe so the whole leg stays near the budget (about 30 % of it
     # for the 1-thread leg, 70 % for the all-cores leg).  The all-cores sample cycles through the
     # step's query set: 256 threads need >10^5 queries to reach steady state (each thread first
@@ -339,12 +342,21 @@ def cpu_baseline(a, ix, base, queries, gpu_found):
     _, _, slots, _, _ = ora.search_batch(tiled, a.k, a.ef, cores)
     qps_all = nall / (time.perf_counter() - t0)
     del tiled
+    # index build on the CPU: the port's sequential usearch_add (a PostgreSQL backend builds with one thread,
+    # utils.c:66) on a bounded prefix of the same rows.  The rate falls as the graph grows, so this flatters the CPU.
+    nb = int(min(base.shape[0], 4096))
+    cb = oracle.OracleIndex(a.metric, a.dim, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, sum_mode=mode)
+    t0 = time.perf_counter()
+    cb.add_many(np.arange(nb, dtype=np.uint64) + 1, base[:nb])
+    cpu_build = nb / (time.perf_counter() - t0)
+    del cb
     m = min(nall, gpu_found.shape[0], queries.shape[0])
     agree = float(np.mean([len(set(x.tolist()) & set(y.tolist())) / a.k for x, y in zip(slots[:m], gpu_found[:m])]))
     return {"value": qps_all, "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": f"{nall} queries (the step's {queries.shape[0]} cycled x{reps}) on {cores} threads, one query per thread "
                       f"(server.rs:317-359 model); {n1} queries on 1 thread (a PostgreSQL backend, utils.c:66)",
             "value_1_thread": qps_1t, "topk_overlap_with_gpu": agree,
+            "build_vectors_per_s_1_thread": cpu_build, "build_sample": f"first {nb} rows, sequential usearch_add",
             "build": "gcc -O3 -march=native + the reference's -fassociative-math flags" if native else "gcc -O3 -march=x86-64-v3 + the reference's -fassociative-math flags",
             "note": "oracle/hnsw.c restates the usearch algorithm; the reference binary itself cannot be built here"}
 

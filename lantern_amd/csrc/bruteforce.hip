@@ -67,23 +67,40 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
 #pragma unroll
             for(int r = 0; r < 16; ++r) acc[ i ][ j ][ r ] = 0.f;
 
-    for(uint32_t k0 = 0; k0 < stride; k0 += BK) {
-        // stage: 128 rows x 32 floats per operand = 1024 float4; 4 per thread
+    // Software pipeline over K: the global loads of tile k0 + BK are issued BEFORE the MFMA loop of tile k0 and land
+    // in registers while the matrix cores work; they are written to LDS after the loop.  (Single-buffered LDS, two
+    // barriers per tile; 8 float4 = 32 VGPRs of prefetch per thread.)
+    float4 pa4[ 4 ], pb4[ 4 ];
+    auto fetch = [&](uint32_t k0) {
 #pragma unroll
         for(int it = 0; it < 4; ++it) {
-            const int      f = tid + it * 256;  // float4 index in the tile
+            const int      f = tid + it * 256;  // float4 index in the tile: 128 rows x 8 float4
             const int      row = f >> 3, kq = (f & 7) * 4;
             const uint32_t k = k0 + (uint32_t)kq;
             float4         a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
             if(q0 + row < nq && k < stride) a = *(const float4 *)(Q + (size_t)(q0 + row) * stride + k);
             if(c0 + row < nb && k < stride) b = *(const float4 *)(B + (size_t)(c0 + row) * stride + k);
-            float *pa = As + row * LDK + kq, *pb = Bs + row * LDK + kq;
-            pa[ 0 ] = a.x; pa[ 1 ] = a.y; pa[ 2 ] = a.z; pa[ 3 ] = a.w;
-            pb[ 0 ] = b.x; pb[ 1 ] = b.y; pb[ 2 ] = b.z; pb[ 3 ] = b.w;
+            pa4[ it ] = a;
+            pb4[ it ] = b;
         }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for(int it = 0; it < 4; ++it) {
+            const int f = tid + it * 256;
+            const int row = f >> 3, kq = (f & 7) * 4;
+            float    *pa = As + row * LDK + kq, *pb = Bs + row * LDK + kq;
+            pa[ 0 ] = pa4[ it ].x; pa[ 1 ] = pa4[ it ].y; pa[ 2 ] = pa4[ it ].z; pa[ 3 ] = pa4[ it ].w;
+            pb[ 0 ] = pb4[ it ].x; pb[ 1 ] = pb4[ it ].y; pb[ 2 ] = pb4[ it ].z; pb[ 3 ] = pb4[ it ].w;
+        }
+    };
+    const float *a0 = As + (wm * 64 + (lane & 31)) * LDK + (lane >> 5);
+    const float *b0 = Bs + (wn * 64 + (lane & 31)) * LDK + (lane >> 5);
+    fetch(0);
+    for(uint32_t k0 = 0; k0 < stride; k0 += BK) {
+        stash();
         __syncthreads();
-        const float *a0 = As + (wm * 64 + (lane & 31)) * LDK + (lane >> 5);
-        const float *b0 = Bs + (wn * 64 + (lane & 31)) * LDK + (lane >> 5);
+        if(k0 + BK < stride) fetch(k0 + BK);  // in flight during the MFMA loop below
 #pragma unroll
         for(int kk = 0; kk < BK; kk += 2) {
             const float av0 = a0[ kk ], av1 = a0[ 32 * LDK + kk ];
@@ -95,20 +112,25 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
         }
         __syncthreads();
     }
-    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // The tile's 128 + 128 squared norms go through LDS once (the K loop ended with a barrier, As / Bs are free)
+    // instead of 64 dependent global loads per thread.
+    if(tid < BM) As[ tid ] = q0 + tid < nq ? qn[ q0 + tid ] : 0.f;
+    else Bs[ tid - BM ] = c0 + (tid - BM) < nb ? bn[ c0 + (tid - BM) ] : 0.f;
+    __syncthreads();
 #pragma unroll
     for(int i = 0; i < 2; ++i)
 #pragma unroll
         for(int j = 0; j < 2; ++j) {
-            const uint32_t c = c0 + wn * 64 + j * 32 + (lane & 31);
-            if(c >= nb) continue;
-            const float nb2 = bn[ c ];
+            const int      cl = wn * 64 + j * 32 + (lane & 31);
+            const uint32_t c = c0 + (uint32_t)cl;
+            const float    nb2 = Bs[ cl ];
 #pragma unroll
             for(int r = 0; r < 16; ++r) {
-                const uint32_t q = q0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if(q >= nq) continue;
-                const float dot = acc[ i ][ j ][ r ], nq2 = qn[ q ];
-                float       d;
+                const int      ql = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const uint32_t q = q0 + (uint32_t)ql;
+                const float    dot = acc[ i ][ j ][ r ], nq2 = As[ ql ];
+                float          d;
                 if(METRIC == M_L2SQ) {
                     d = nq2 + nb2 - 2.f * dot;
                     d = d < 0.f ? 0.f : d;
@@ -117,7 +139,7 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
                     else if(nq2 == 0.f || nb2 == 0.f) d = 1.f;
                     else d = 1.f - dot / (__builtin_sqrtf(nq2) * __builtin_sqrtf(nb2));
                 }
-                out[ (size_t)q * ldo + (c - 0) ] = d;
+                if(q < nq && c < nb) out[ (size_t)q * ldo + c ] = d;
             }
         }
 }
