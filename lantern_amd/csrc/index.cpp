@@ -165,6 +165,16 @@ bool pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst)
     return true;
 }
 
+// a zeroed work ticket for one launch on `stream` (ring: concurrent launches on different streams get different slots)
+static const uint32_t kTicketRing = 64;
+static uint32_t *next_ticket(Index *ix, size_t work, int grid, hipStream_t stream)
+{
+    if(!ix->use_tickets || !ix->d_tickets || work <= (size_t)grid) return nullptr;
+    uint32_t *t = ix->d_tickets + (ix->ticket_next++ % kTicketRing);
+    if(hipMemsetAsync(t, 0, 4, stream) != hipSuccess) return nullptr;
+    return t;
+}
+
 int search_grid(const Index *ix, size_t nq, int waves)
 {
     // the kernels run at 4 waves/SIMD = 16 waves/CU (VGPR-bound); one workgroup = `waves` waves
@@ -276,6 +286,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     if(ivis && ivis < 4 * ix->M0) ivis = 0;
     ia.vis_slots = ivis;
     ia.totals = ix->d_totals + 2;
+    ia.ticket = next_ticket(ix, b_hi - b_lo, grid, ix->stream);
     if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
     HIPCHK(ix, launch_insert(ix->mcode, ia, ix->insert_waves, grid, ix->stream));
 
@@ -581,6 +592,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.bm_words = (uint32_t)ix->bm_words;
     a.vis_slots = vis_slots;
     a.totals = ix->d_totals;
+    a.ticket = next_ticket(ix, nq, grid, stream);
     HIPCHK(ix, launch_search(ix->mcode, a, waves, grid, stream));
     ix->c_search_queries += nq;
     return true;
@@ -631,6 +643,9 @@ using namespace lgpu;
 static Index *H(usearch_index_t h, usearch_error_t *e)
 {
     if(!h) { FAIL(e, "lantern_gpu: null index handle"); return nullptr; }
+    // HIP's current device is per host thread: an index lives on the device it was created on, whichever thread calls
+    // (one thread per GPU is how a single process drives a node: lantern_gpu_comm_init_local)
+    (void)hipSetDevice(((Index *)h)->device);
     return (Index *)h;
 }
 
@@ -686,7 +701,9 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     (void)hipGetDevice(&ix->device);
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, ix->device) == hipSuccess) ix->num_cus = prop.multiProcessorCount;
+    if(const char *tk = std::getenv("LANTERN_GPU_TICKETS")) ix->use_tickets = std::atoi(tk) != 0;
     if(hipMalloc((void **)&ix->d_totals, 8 * sizeof(unsigned long long)) != hipSuccess ||
+       hipMalloc((void **)&ix->d_tickets, kTicketRing * sizeof(uint32_t)) != hipSuccess ||
        hipMemset(ix->d_totals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         delete ix;
         FAIL(e, "lantern_gpu: device allocation failed");
@@ -700,7 +717,7 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
-    void *ptrs[] = { ix->d_vec, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals };
+    void *ptrs[] = { ix->d_vec, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals, ix->d_tickets };
     for(void *p : ptrs)
         if(p) (void)hipFree(p);
     for(void *p : ix->d_scratch)

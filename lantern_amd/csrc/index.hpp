@@ -42,6 +42,9 @@ struct Index
     uint32_t *d_upper_nbr = nullptr;
     uint32_t *d_bitmaps = nullptr;
     size_t    bitmap_slots = 0, bm_words = 0;
+    uint32_t *d_tickets = nullptr;  // ring of work tickets, one per launch in flight (kernels.hpp SearchArgs::ticket)
+    uint32_t  ticket_next = 0;
+    bool      use_tickets = true;   // LANTERN_GPU_TICKETS=0: static striding (tuning / debugging)
     unsigned long long *d_totals = nullptr;  // [0..1] search D,E  [2..4] insert D,E,refine  [5] revlink pairs
 
     // scratch (grown on demand)

@@ -135,7 +135,7 @@ void serve(lantern_index_server *srv, int fd)
         const size_t vec_bytes = element_bits < 8 ? (dims + 7) / 8 : dims * (element_bits / 8);
         const size_t payload = 8 + vec_bytes;
         // the rows' scalar kind follows element_bits (server.rs:226-230, add_raw(label, bytes, element_bits) :349)
-        const usearch_scalar_kind_t kind = element_bits < 8 ? usearch_scalar_b1_k : element_bits == 16 ? usearch_scalar_f16_k : usearch_scalar_f32_k;
+        const usearch_scalar_kind_t kind = element_bits < 8 ? usearch_scalar_b1_k : element_bits == 8 ? usearch_scalar_i8_k : element_bits == 16 ? usearch_scalar_f16_k : usearch_scalar_f32_k;
         std::vector<uint64_t> labels;
         std::vector<uint8_t>  rows;
         labels.reserve(ADD_CHUNK);

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(512) k_search(SearchArgs a)
     carve_walk(lgpu_smem, s, a.view.chunks, a.ef, a.view.M0, a.vis_slots);
     uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
     const uint32_t chunks = a.view.chunks;
-    for(uint32_t q = blockIdx.x; q < a.nq; q += gridDim.x) {
+    for(uint32_t q = blockIdx.x; q < a.nq;) {
         for(uint32_t i = tid; i < chunks; i += T) s.q[ i ] = a.queries[ (size_t)q * chunks + i ];
         __syncthreads();
         uint32_t D = 0, E = 0;
@@ -60,7 +60,11 @@ __global__ void __launch_bounds__(512) k_search(SearchArgs a)
             if(a.out_D) a.out_D[ q ] = D;
             if(a.out_E) a.out_E[ q ] = E;
             if(a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)D); atomicAdd(&a.totals[ 1 ], (unsigned long long)E); }
+            // next query: a ticket (walks differ in length by 2x; static striding leaves workgroups idle at the end)
+            s.scal[ S_POS ] = a.ticket ? (int)(gridDim.x + atomicAdd(a.ticket, 1u)) : (int)(q + gridDim.x);
         }
+        __syncthreads();
+        q = (uint32_t)s.scal[ S_POS ];
         __syncthreads();
     }
 }
@@ -77,7 +81,7 @@ __global__ void __launch_bounds__(512) k_insert(InsertArgs a)
     carve_walk(lgpu_smem, s, a.view.chunks, a.efc, a.view.M0, a.vis_slots);
     uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
     const uint32_t chunks = a.view.chunks, M = a.view.M;
-    for(uint32_t b = a.b_begin + blockIdx.x; b < a.count; b += gridDim.x) {
+    for(uint32_t b = a.b_begin + blockIdx.x; b < a.count;) {
         const uint32_t me = a.first_slot + b;
         const int      target = a.view.levels[ me ];
         const uint32_t item0 = a.link_off[ b ] / M;  // one item per (node, level)
@@ -109,10 +113,15 @@ __global__ void __launch_bounds__(512) k_insert(InsertArgs a)
             cur = (uint32_t)s.scal[ S_CUR ];
             __syncthreads();
         }
-        if(tid == 0 && a.totals) {
-            atomicAdd(&a.totals[ 0 ], (unsigned long long)D);
-            atomicAdd(&a.totals[ 1 ], (unsigned long long)E);
+        if(tid == 0) {
+            if(a.totals) {
+                atomicAdd(&a.totals[ 0 ], (unsigned long long)D);
+                atomicAdd(&a.totals[ 1 ], (unsigned long long)E);
+            }
+            s.scal[ S_POS ] = a.ticket ? (int)(a.b_begin + gridDim.x + atomicAdd(a.ticket, 1u)) : (int)(b + gridDim.x);
         }
+        __syncthreads();
+        b = (uint32_t)s.scal[ S_POS ];
         __syncthreads();
     }
 }

@@ -24,7 +24,8 @@ struct SearchArgs
     uint32_t        bm_words;    // multiple of 4
     uint32_t        vis_slots;   // LDS visited-set slots (power of two; 0 = HBM bitmap only)
     unsigned long long *totals;  // [2] cumulative D, E (atomicAdd) or NULL
-};
+    uint32_t       *ticket;      // zeroed before the launch: queries beyond the first gridDim.x are handed out dynamically
+};                               // (NULL = static striding); results do not depend on who runs a query
 
 // one reverse-link request produced by the insert pass: add `new_slot` to `close`'s list at `level`
 struct LinkReq
@@ -49,6 +50,7 @@ struct InsertArgs
     uint32_t        bm_words;
     uint32_t        vis_slots;   // LDS visited-set slots (0 = HBM bitmap only)
     unsigned long long *totals;  // [2] cumulative D, E
+    uint32_t       *ticket;      // as SearchArgs::ticket, over the batch members
 };
 
 // neighbour selection of the new nodes: one item per (new node, level)

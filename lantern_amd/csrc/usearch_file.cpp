@@ -252,6 +252,7 @@ void usearch_view_mem_lazy(usearch_index_t h, char *header136, usearch_error_t *
 {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
+    if(ix) (void)hipSetDevice(ix->device);
     if(!ix || !header136) { if(e) *e = "lantern_gpu: null index handle or header"; return; }
     std::lock_guard<std::mutex> g(ix->mu);
     if(!mirror_from_retriever(ix, header136) && e) *e = ix->err.c_str();
@@ -262,6 +263,7 @@ void usearch_update_header(usearch_index_t h, char *header136, usearch_error_t *
 {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
+    if(ix) (void)hipSetDevice(ix->device);
     if(!ix || !header136) { if(e) *e = "lantern_gpu: null index handle or header"; return; }
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) { if(e) *e = ix->err.c_str(); return; }
@@ -278,6 +280,7 @@ size_t usearch_serialized_length(usearch_index_t h, usearch_error_t *e)
 {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
+    if(ix) (void)hipSetDevice(ix->device);
     if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return 0; }
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) { if(e) *e = ix->err.c_str(); return 0; }
@@ -288,6 +291,7 @@ void usearch_save_buffer(usearch_index_t h, char *buffer, size_t length, usearch
 {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
+    if(ix) (void)hipSetDevice(ix->device);
     if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix) || !serialize(ix, buffer, length)) { if(e) *e = ix->err.c_str(); }
@@ -297,6 +301,7 @@ void usearch_save(usearch_index_t h, const char *path, usearch_error_t *e)
 {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
+    if(ix) (void)hipSetDevice(ix->device);
     if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) { if(e) *e = ix->err.c_str(); return; }
@@ -315,6 +320,7 @@ void usearch_load_buffer(usearch_index_t h, const char *buffer, size_t length, u
 {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
+    if(ix) (void)hipSetDevice(ix->device);
     if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
     std::lock_guard<std::mutex> g(ix->mu);
     if(!deserialize(ix, buffer, length) && e) *e = ix->err.c_str();
@@ -324,6 +330,7 @@ void usearch_load(usearch_index_t h, const char *path, usearch_error_t *e)
 {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
+    if(ix) (void)hipSetDevice(ix->device);
     if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
     FILE *f = std::fopen(path, "rb");
     if(!f) { if(e) *e = set_err(ix, std::string("lantern_gpu: cannot open index file ") + path); return; }

@@ -113,9 +113,18 @@ def test_hamming_and_larger_build(capi, server):
     ix.load_buffer(data)
     hits = sum(int(ix.search(base[i], 1)[0][0]) == i + 1 for i in range(0, 3000, 30))
     assert n == 3000 and hits >= 95
-    # quantised storage is refused with an error frame, not a hang
-    with pytest.raises(ic.IndexServerError, match="only f32 storage and f16 storage"):
-        ic.build_index(server.host, server.port, 3, 32, [], [], element_bits=8, quantization=4)
+    # an unsupported storage kind (f64) is refused with an error frame, not a hang
+    with pytest.raises(ic.IndexServerError, match="f32, f16 or i8 storage"):
+        ic.build_index(server.host, server.port, 3, 32, [], [], element_bits=32, quantization=2)
+    # quant_bits = 8: f32 rows in (element_bits = 32), i8 storage; raw i8 rows (element_bits = 8) give the same file
+    small = (base[:600] * np.float32(0.3)).astype(np.float32)
+    q8 = np.trunc(np.clip(small * np.float32(100.0), -100, 100)).astype(np.int8)
+    n3, f3 = ic.build_index(server.host, server.port, 3, 32, [r.tobytes() for r in small], np.arange(600) + 1, m=8, efc=32, ef=16,
+                            element_bits=32, quantization=4)
+    n4, f4 = ic.build_index(server.host, server.port, 3, 32, [r.tobytes() for r in q8], np.arange(600) + 1, m=8, efc=32, ef=16,
+                            element_bits=8, quantization=4)
+    assert n3 == n4 == 600 and f3 == f4
+    assert len(f3) == 136 + sum(10 + (4 + 16 * 6) + lv * (4 + 8 * 6) + 32 for lv in _levels_of(f3, 600, 8, 32))
     # quant_bits = 16: PostgreSQL still streams f32 rows (element_bits = 32); the index stores halves.
     # The Rust tests also stream raw halves (element_bits = 16): both give the same index file.
     n1, f1 = ic.build_index(server.host, server.port, 3, 32, [r.tobytes() for r in base[:600]], np.arange(600) + 1, m=8, efc=32, ef=16,
