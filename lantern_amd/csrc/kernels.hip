@@ -861,21 +861,25 @@ __global__ void __launch_bounds__(512, 4) k_revlink_slab(RevlinkArgs a, const Re
 // column-slab sweep: a candidate costs one barrier and no LDS traffic; every wave streams the (sorted) candidate
 // rows through L1/L2 with the next one already in flight.  Same lane/chunk ownership and reduction tree as
 // group_dist<METRIC, 64>.
-template <int METRIC>
-__global__ void __launch_bounds__(512) k_revlink_regs(RevlinkArgs a, const RevWork *work, const uint32_t *work_count)
+// CPL = 16-byte chunks per lane per row (rows of up to 64 * CPL chunks): 3 covers d <= 768 f32 and leaves room for FOUR waves
+// per SIMD (two re-prunes per CU in flight: the per-candidate chain is latency-bound, so throughput nearly doubles, at the
+// price of some spilled registers outside the candidate loop); 4 covers d <= 1024 at two waves per SIMD.
+template <int METRIC, int CPL>
+__global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_regs(RevlinkArgs a, const RevWork *work, const uint32_t *work_count)
 {
     constexpr int NMAX = 34;
     __shared__ float    cd[ NMAX ], sd[ NMAX ], kd[ NMAX ];
     __shared__ uint32_t cid[ NMAX ], sid[ NMAX ], kid[ NMAX ];
     __shared__ int      flags[ 4 ];
+    __shared__ uint4    ring[ 2 ][ 64 * CPL ];  // candidate rows on their way from the prefetching wave to all waves
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nwork = *work_count;
     const int      chunks = (int)a.view.chunks;
     uint32_t       pairs = 0, reprunes = 0;
-    auto load_row = [&](uint32_t slot, uint4 (&v)[ 4 ]) {
+    auto load_row = [&](uint32_t slot, uint4 (&v)[ CPL ]) {
         const uint4 *row = row_of(a.view, slot);
 #pragma unroll
-        for(int c = 0; c < 4; ++c) {
+        for(int c = 0; c < CPL; ++c) {
             const int ch = lane + 64 * c;
             v[ c ] = ch < chunks ? row[ ch ] : make_uint4(0, 0, 0, 0);
         }
@@ -909,7 +913,7 @@ __global__ void __launch_bounds__(512) k_revlink_regs(RevlinkArgs a, const RevWo
             if(tid == 0) { cid[ c ] = vnew; cd[ c ] = dv; }
             if(tid < 3) flags[ tid ] = 0;
             __syncthreads();
-            uint4 kept[ 4 ][ 4 ], cur[ 4 ], nxt[ 4 ];
+            uint4 kept[ 4 ][ CPL ], cur[ CPL ], nxt[ CPL ];
             if(!have_d) {  // distances of the original entries to `close`, once (a = close, b = entry)
                 // all (<= 4) rows of this wave in flight at once, parked in the not-yet-used kept registers
                 load_row(close, cur);
@@ -921,7 +925,7 @@ __global__ void __launch_bounds__(512) k_revlink_regs(RevlinkArgs a, const RevWo
                     if(wave + 8 * j < c0) {
                         Acc<METRIC> acc;
 #pragma unroll
-                        for(int cc = 0; cc < 4; ++cc) acc.add(cur[ cc ], kept[ j ][ cc ]);
+                        for(int cc = 0; cc < CPL; ++cc) acc.add(cur[ cc ], kept[ j ][ cc ]);
                         const float d = acc.template finish<64>();
                         if(lane == 63) cd[ wave + 8 * j ] = d;
                     }
@@ -939,32 +943,45 @@ __global__ void __launch_bounds__(512) k_revlink_regs(RevlinkArgs a, const RevWo
                 sid[ rank ] = cid[ x ];
             }
             __syncthreads();
-            // ---- the heuristic: kept rows in registers, one barrier per candidate
+            // ---- the heuristic: kept rows in registers, one barrier per candidate.  The candidate rows are cold (HBM
+            // latency >> the time a step computes), so EIGHT of them are in flight at any time: candidate r >= 1 is
+            // fetched by wave (r - 1) & 7 into its `nxt` registers eight steps ahead and published to the two-slot LDS
+            // ring during step r - 1; every wave then reads it from LDS.  Same rows, same accumulation order, same bits.
 #pragma unroll
             for(int j = 0; j < 4; ++j)
 #pragma unroll
-                for(int cc = 0; cc < 4; ++cc) kept[ j ][ cc ] = make_uint4(0, 0, 0, 0);
-            load_row(sid[ 0 ], cur);
-            if(wave == 0) {
+                for(int cc = 0; cc < CPL; ++cc) kept[ j ][ cc ] = make_uint4(0, 0, 0, 0);
+            if(wave == 0) {  // candidate 0 is always kept
+                load_row(sid[ 0 ], cur);
 #pragma unroll
-                for(int cc = 0; cc < 4; ++cc) kept[ 0 ][ cc ] = cur[ cc ];
+                for(int cc = 0; cc < CPL; ++cc) kept[ 0 ][ cc ] = cur[ cc ];
             }
             if(tid == 0) { kid[ 0 ] = sid[ 0 ]; kd[ 0 ] = sd[ 0 ]; }
+            if(1 + wave < n) load_row(sid[ 1 + wave ], nxt);  // candidates 1..8
+            if(wave == 0) {                                    // publish candidate 1 (n >= 2 always), refill with candidate 9
+#pragma unroll
+                for(int cc = 0; cc < CPL; ++cc) ring[ 1 ][ lane + 64 * cc ] = nxt[ cc ];
+                if(9 < n) load_row(sid[ 9 ], nxt);
+            }
+            __syncthreads();
             int submitted = 1, consumed = 1;
-            load_row(sid[ 1 ], nxt);  // n >= 2 always (cap >= 1)
             while(submitted < (int)cap && consumed < n) {
 #pragma unroll
-                for(int cc = 0; cc < 4; ++cc) cur[ cc ] = nxt[ cc ];
+                for(int cc = 0; cc < CPL; ++cc) cur[ cc ] = ring[ consumed & 1 ][ lane + 64 * cc ];
                 const float    cdist = sd[ consumed ];
                 const uint32_t cslot = sid[ consumed ];
-                if(consumed + 1 < n) load_row(sid[ consumed + 1 ], nxt);
+                if(consumed + 1 < n && wave == (consumed & 7)) {  // the owner of candidate consumed + 1 publishes it (the other slot
+#pragma unroll                                                      // was last read before the previous barrier) and refills
+                    for(int cc = 0; cc < CPL; ++cc) ring[ (consumed + 1) & 1 ][ lane + 64 * cc ] = nxt[ cc ];
+                    if(consumed + 9 < n) load_row(sid[ consumed + 9 ], nxt);
+                }
                 bool bad = false;
 #pragma unroll
                 for(int j = 0; j < 4; ++j) {
                     if(wave + 8 * j < submitted) {  // wave-uniform
                         Acc<METRIC> acc;
 #pragma unroll
-                        for(int cc = 0; cc < 4; ++cc) acc.add(cur[ cc ], kept[ j ][ cc ]);
+                        for(int cc = 0; cc < CPL; ++cc) acc.add(cur[ cc ], kept[ j ][ cc ]);
                         const float d = acc.template finish<64>();
                         bad |= d < cdist;  // meaningful in lane 63
                     }
@@ -981,7 +998,7 @@ __global__ void __launch_bounds__(512) k_revlink_regs(RevlinkArgs a, const RevWo
                         for(int jj = 0; jj < 4; ++jj)
                             if(jj == j) {
 #pragma unroll
-                                for(int cc = 0; cc < 4; ++cc) kept[ jj ][ cc ] = cur[ cc ];
+                                for(int cc = 0; cc < CPL; ++cc) kept[ jj ][ cc ] = cur[ cc ];
                             }
                     }
                     if(tid == 0) { kid[ submitted ] = cslot; kd[ submitted ] = cdist; }
@@ -1161,14 +1178,20 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
         if(e != hipSuccess) return e;
         hipLaunchKernelGGL(k_revlink_append, dim3((a.ngroups + 3) / 4), dim3(256), 0, stream, a, (RevWork *)work, work_count);
         const int grid = num_cus * 2;
+#define REGS(MM)                                                                                                                        \
+    {                                                                                                                                   \
+        if(a.view.chunks <= 192) hipLaunchKernelGGL((k_revlink_regs<MM, 3>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); \
+        else hipLaunchKernelGGL((k_revlink_regs<MM, 4>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count);       \
+    }
         switch(metric) {
-            case M_L2SQ: hipLaunchKernelGGL((k_revlink_regs<M_L2SQ>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); break;
-            case M_COS: hipLaunchKernelGGL((k_revlink_regs<M_COS>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); break;
-            case M_HAMMING: hipLaunchKernelGGL((k_revlink_regs<M_HAMMING>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); break;
-            case M_L2SQ_F16: hipLaunchKernelGGL((k_revlink_regs<M_L2SQ_F16>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); break;
-            case M_COS_F16: hipLaunchKernelGGL((k_revlink_regs<M_COS_F16>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); break;
+            case M_L2SQ: REGS(M_L2SQ); break;
+            case M_COS: REGS(M_COS); break;
+            case M_HAMMING: REGS(M_HAMMING); break;
+            case M_L2SQ_F16: REGS(M_L2SQ_F16); break;
+            case M_COS_F16: REGS(M_COS_F16); break;
             default: return hipErrorInvalidValue;
         }
+#undef REGS
         return hipGetLastError();
     }
     if(!i8 && a.view.chunks >= 128 && a.view.M0 <= 32 && work && work_count) {
