@@ -14,6 +14,8 @@
 //
 // HBM-bound by design: every row is read with 16-byte-per-lane coalesced loads (1 KiB per wave
 // instruction at G = 64), neighbour ids are staged through LDS, reductions are wavefront shuffles.
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "walk.hpp"
 
@@ -1178,9 +1180,10 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
         if(e != hipSuccess) return e;
         hipLaunchKernelGGL(k_revlink_append, dim3((a.ngroups + 3) / 4), dim3(256), 0, stream, a, (RevWork *)work, work_count);
         const int grid = num_cus * 2;
+        static const bool force4 = std::getenv("LANTERN_GPU_REGS_CPL4") != nullptr;  // tuning: always the four-chunks-per-lane variant
 #define REGS(MM)                                                                                                                        \
     {                                                                                                                                   \
-        if(a.view.chunks <= 192) hipLaunchKernelGGL((k_revlink_regs<MM, 3>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); \
+        if(a.view.chunks <= 192 && !force4) hipLaunchKernelGGL((k_revlink_regs<MM, 3>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); \
         else hipLaunchKernelGGL((k_revlink_regs<MM, 4>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count);       \
     }
         switch(metric) {
