@@ -261,6 +261,120 @@ __device__ __forceinline__ void group_dist2(PA a, PB b0, PB b1, int chunks, int 
     d1 = acc1.template finish<G>();
 }
 
+// ---- cached row norms for the cosine metrics ----------------------------------------------------------------
+// Acc<M_COS> runs three independent fma chains per lane (ab, a2, b2) and three G-lane sums.  a2 depends on the first
+// operand only and b2 on the second only, so for STORED rows both are properties of the row: they are computed once,
+// when the row enters the index, by the very chain and tree Acc<M_COS> would run (NormAcc + group_sum<G>, G fixed per
+// index), and kept in View::norm2.  A row evaluation is then ONE chain (ab) and ONE G-lane sum -- the bits of
+// 1 - ab / (sqrt(a2) * sqrt(b2)) are those of the one-pass accumulator (usearch metric_cos_gt), at the cost of the
+// l2sq walk.  The query's a2 is computed once per query the same way.
+template <int METRIC> constexpr bool kCachedNorms = (METRIC == M_COS || METRIC == M_COS_F16);
+
+__device__ __forceinline__ float cos_finish(float ab, float a2, float b2)
+{
+    // zero-norm rules pinned by the reference's tests (hnsw_vector.out:205-210, hnsw_dist_func.out:58-61)
+    if(a2 == 0.f && b2 == 0.f) return 0.f;
+    if(a2 == 0.f || b2 == 0.f) return 1.f;
+    return 1.f - ab / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));
+}
+
+// ||row||^2 of one operand: the a2 (= b2) chain of Acc<M_COS> / Acc<M_COS_F16>
+template <int METRIC> struct NormAcc
+{
+    float s = 0.f;
+    __device__ __forceinline__ void add(const uint4 &z)
+    {
+        if constexpr(METRIC == M_COS_F16) {
+            const uint32_t w[ 4 ] = { z.x, z.y, z.z, z.w };
+#pragma unroll
+            for(int i = 0; i < 4; ++i) {
+                float lo, hi;
+                unpack_h2(w[ i ], lo, hi);
+                s = __builtin_fmaf(lo, lo, s);
+                s = __builtin_fmaf(hi, hi, s);
+            }
+        } else {
+            s = __builtin_fmaf(__uint_as_float(z.x), __uint_as_float(z.x), s);
+            s = __builtin_fmaf(__uint_as_float(z.y), __uint_as_float(z.y), s);
+            s = __builtin_fmaf(__uint_as_float(z.z), __uint_as_float(z.z), s);
+            s = __builtin_fmaf(__uint_as_float(z.w), __uint_as_float(z.w), s);
+        }
+    }
+};
+// complete in the LAST lane of the group
+template <int METRIC, int G, typename PA> __device__ __forceinline__ float group_norm(PA a, int chunks, int gl)
+{
+    NormAcc<METRIC> acc;
+#pragma unroll 4
+    for(int ch = gl; ch < chunks; ch += G) {
+        uint4 x = a[ ch ];
+        acc.add(x);
+    }
+    return group_sum<G>(acc.s);
+}
+
+// The accumulator of one (row, row) evaluation when both norms are known: the ab chain only for the cosine metrics,
+// the full Acc otherwise (the norms are ignored).
+template <int METRIC> struct RowAcc : Acc<METRIC>
+{
+    template <int G> __device__ __forceinline__ float finish_n(float, float) { return this->template finish<G>(); }
+};
+template <> struct RowAcc<M_COS>
+{
+    float s = 0.f;
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb)
+    {
+        s = __builtin_fmaf(__uint_as_float(xa.x), __uint_as_float(yb.x), s);
+        s = __builtin_fmaf(__uint_as_float(xa.y), __uint_as_float(yb.y), s);
+        s = __builtin_fmaf(__uint_as_float(xa.z), __uint_as_float(yb.z), s);
+        s = __builtin_fmaf(__uint_as_float(xa.w), __uint_as_float(yb.w), s);
+    }
+    template <int G> __device__ __forceinline__ float finish_n(float a2, float b2) { return cos_finish(group_sum<G>(s), a2, b2); }
+};
+template <> struct RowAcc<M_COS_F16>
+{
+    float s = 0.f;
+    __device__ __forceinline__ void word(uint32_t xw, uint32_t yw)
+    {
+        float x0, x1, y0, y1;
+        unpack_h2(xw, x0, x1);
+        unpack_h2(yw, y0, y1);
+        s = __builtin_fmaf(x0, y0, s);
+        s = __builtin_fmaf(x1, y1, s);
+    }
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb) { word(xa.x, yb.x); word(xa.y, yb.y); word(xa.z, yb.z); word(xa.w, yb.w); }
+    template <int G> __device__ __forceinline__ float finish_n(float a2, float b2) { return cos_finish(group_sum<G>(s), a2, b2); }
+};
+
+// group_dist with known norms (a2 of `a`, b2 of `b`); complete in the LAST lane of the group
+template <int METRIC, int G, typename PA, typename PB>
+__device__ __forceinline__ float group_dist_n(PA a, PB b, int chunks, int gl, float a2, float b2)
+{
+    RowAcc<METRIC> acc;
+#pragma unroll 4
+    for(int ch = gl; ch < chunks; ch += G) {
+        uint4 x = a[ ch ];
+        uint4 y = b[ ch ];
+        acc.add(x, y);
+    }
+    return acc.template finish_n<G>(a2, b2);
+}
+template <int METRIC, int G, typename PA, typename PB>
+__device__ __forceinline__ void group_dist2_n(PA a, PB b0, PB b1, int chunks, int gl, float a2, float b2_0, float b2_1, float &d0, float &d1)
+{
+    RowAcc<METRIC> acc0, acc1;
+#pragma unroll 4
+    for(int ch = gl; ch < chunks; ch += G) {
+        uint4 x = a[ ch ];
+        uint4 y0 = b0[ ch ];
+        uint4 y1 = b1[ ch ];
+        acc0.add(x, y0);
+        acc1.add(x, y1);
+    }
+    d0 = acc0.template finish_n<G>(a2, b2_0);
+    d1 = acc1.template finish_n<G>(a2, b2_1);
+}
+
 // lanes per row for a row of `chunks` 16-byte chunks (oracle: lo_wave_group_lanes)
 // Every lane should own at least two chunks (two 16-byte loads in flight per row per lane), so short rows are
 // shared by fewer lanes and a wave works on several rows at once: G = 64 from 128 chunks (d >= 512 f32 /
@@ -277,12 +391,19 @@ struct View
     const uint32_t *upper_off; // [cap] first upper block of the node (levels 1..L are consecutive)
     uint32_t       *upper_nbr; // [blocks][M]
     const uint8_t  *levels;    // [cap]
+    const float    *norm2;     // [cap] ||row||^2 for the cosine metrics (exactly the a2 / b2 chain of Acc<M_COS>); else NULL
     uint32_t        n;
     uint32_t        entry;
     int32_t         max_level;
 };
 
 __device__ __forceinline__ const uint4 *row_of(const View &v, uint32_t slot) { return v.vec + (size_t)slot * v.chunks; }
+// cached ||row||^2 (cosine metrics); 0 and no memory access for the others
+template <int METRIC> __device__ __forceinline__ float row_norm(const View &v, uint32_t slot)
+{
+    if constexpr(kCachedNorms<METRIC>) return v.norm2[ slot ];
+    else return 0.f;
+}
 
 __device__ __forceinline__ uint32_t *neighbors_of(const View &v, uint32_t slot, int level, uint32_t &cap)
 {

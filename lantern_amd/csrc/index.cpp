@@ -72,6 +72,7 @@ View Index::view() const
     v.upper_off = d_upper_off;
     v.upper_nbr = d_upper_nbr;
     v.levels = d_levels;
+    v.norm2 = d_norm2;
     v.n = (uint32_t)n;
     v.entry = entry;
     v.max_level = max_level;
@@ -84,6 +85,7 @@ static bool reserve_locked(Index *ix, size_t newcap)
     if(newcap >= 0x7FFFFFFFull) { set_err(ix, "lantern_gpu: capacity above 2^31-1 slots is not supported"); return false; }
     const size_t oc = ix->cap, row = (size_t)ix->chunks * 16;
     if(!dev_grow(ix, (void **)&ix->d_vec, oc * row, newcap * row, -1)) return false;
+    if(mcode_base(ix->mcode) == M_COS && !mcode_is_i8(ix->mcode) && !dev_grow(ix, (void **)&ix->d_norm2, oc * 4, newcap * 4, -1)) return false;
     if(!dev_grow(ix, (void **)&ix->d_labels, oc * 8, newcap * 8, -1)) return false;
     if(!dev_grow(ix, (void **)&ix->d_levels, oc, newcap, 0)) return false;
     if(!dev_grow(ix, (void **)&ix->d_nbr0, oc * ix->M0 * 4, newcap * ix->M0 * 4, 0xFF)) return false;
@@ -102,6 +104,13 @@ static bool reserve_upper(Index *ix, size_t need_blocks)
     size_t nc = std::max<size_t>(std::max<size_t>(ix->upper_cap * 2, need_blocks), 1024);
     if(!dev_grow(ix, (void **)&ix->d_upper_nbr, ix->upper_cap * ix->M * 4, nc * ix->M * 4, 0xFF)) return false;
     ix->upper_cap = nc;
+    return true;
+}
+
+bool fill_norms(Index *ix, size_t first, size_t count)
+{
+    if(!ix->d_norm2 || count == 0) return true;
+    HIPCHK(ix, launch_fill_norms(ix->mcode, ix->view(), (uint32_t)first, (uint32_t)count, ix->d_norm2, ix->stream));
     return true;
 }
 
@@ -478,6 +487,7 @@ static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_i
     up = up && hipMemcpyAsync(ix->d_upper_off + first, s.uo.data(), count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
     if(!up) { set_err(ix, "lantern_gpu: HIP failure uploading vectors"); return fail(); }
+    if(!fill_norms(ix, first, count)) return fail();
     return run_batches(ix, labels, s, count, nullptr, ok_out);
 }
 
@@ -531,6 +541,7 @@ bool add_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const voi
     std::vector<uint64_t> all_labels(total);
     HIPCHK(ix, hipMemcpyAsync(all_labels.data(), lab_base, total * 8, hipMemcpyDeviceToHost, ix->stream));
     if(!sync_stream(ix, comm)) return false;
+    if(!fill_norms(ix, first, total)) return false;  // every rank over all rows: the replicas stay self-contained
     bool ok = true;
     run_batches(ix, all_labels.data(), s, total, comm, &ok);
     return ok;
@@ -614,6 +625,7 @@ bool import_graph_locked(Index *ix, size_t size, const void *vectors, const uint
         HIPCHK(ix, hipMemcpy2D(ix->d_vec, (size_t)ix->chunks * 16, vectors, (size_t)ix->words * 4, (size_t)ix->words * 4, size,
                                hipMemcpyHostToDevice));
     }
+    if(!fill_norms(ix, 0, size)) return false;
     ix->labels.resize(size);
     for(size_t i = 0; i < size; ++i) ix->labels[ i ] = labels ? labels[ i ] : (uint64_t)i;
     ix->levels.assign(levels, levels + size);
@@ -717,7 +729,7 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
-    void *ptrs[] = { ix->d_vec, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals, ix->d_tickets };
+    void *ptrs[] = { ix->d_vec, ix->d_norm2, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals, ix->d_tickets };
     for(void *p : ptrs)
         if(p) (void)hipFree(p);
     for(void *p : ix->d_scratch)

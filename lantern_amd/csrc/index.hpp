@@ -35,6 +35,7 @@ struct Index
 
     // ---- HBM ---------------------------------------------------------------------------------------
     uint4    *d_vec = nullptr;
+    float    *d_norm2 = nullptr;  // ||row||^2 per stored row, cosine metrics only (device_common.hpp "cached row norms")
     uint64_t *d_labels = nullptr;
     uint8_t  *d_levels = nullptr;
     uint32_t *d_nbr0 = nullptr;
@@ -89,6 +90,7 @@ struct Index
 const char *set_err(Index *ix, const std::string &msg);
 bool        flush_locked(Index *ix);            // false -> ix->err set
 bool        ensure_bitmaps(Index *ix, size_t slots);
+bool        fill_norms(Index *ix, size_t first, size_t count);  // after rows [first, first + count) are in d_vec
 void       *scratch(Index *ix, int which, size_t bytes);
 bool        pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst);
 size_t      input_bytes(const Index *ix, int kind_in);

@@ -35,6 +35,13 @@ __global__ void __launch_bounds__(512) k_search(SearchArgs a)
     for(uint32_t q = blockIdx.x; q < a.nq;) {
         for(uint32_t i = tid; i < chunks; i += T) s.q[ i ] = a.queries[ (size_t)q * chunks + i ];
         __syncthreads();
+        if(kCachedNorms<METRIC>) {  // ||query||^2 once per query, by the chain Acc<M_COS> would run for every row
+            if(tid < G) {
+                const float qn = group_norm<METRIC, G>(s.q, (int)chunks, tid);
+                if(tid == G - 1) s.scal[ S_QN2 ] = __float_as_int(qn);
+            }
+            __syncthreads();
+        }
         uint32_t D = 0, E = 0;
         int      cnt = 0;
         if(a.view.n != 0) {
@@ -91,6 +98,7 @@ __global__ void __launch_bounds__(512) k_insert(InsertArgs a)
             const uint4 *own = row_of(a.view, me);
             for(uint32_t i = tid; i < chunks; i += T) s.q[ i ] = own[ i ];
             for(uint32_t i = tid; i <= (uint32_t)target; i += T) a.top_count[ item0 + i ] = 0;  // levels above max_level stay empty
+            if(tid == 0) s.scal[ S_QN2 ] = __float_as_int(row_norm<METRIC>(a.view, me));     // the "query" is a stored row
         }
         __syncthreads();
         uint32_t D = 0, E = 0;
@@ -186,6 +194,7 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
                 }
             };
             uint4 kept[ 4 ][ 4 ], cur[ 4 ], nxt[ 4 ];
+            float keptn[ 4 ] = { 0.f, 0.f, 0.f, 0.f };  // cached norms of this wave's kept rows (cosine metrics)
 #pragma unroll
             for(int j = 0; j < 4; ++j)
 #pragma unroll
@@ -194,6 +203,7 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
             if(wave == 0) {
 #pragma unroll
                 for(int c = 0; c < 4; ++c) kept[ 0 ][ c ] = cur[ c ];
+                keptn[ 0 ] = row_norm<METRIC>(a.view, r.sid[ 0 ]);
             }
             if(tid == 0) { kid[ 0 ] = r.sid[ 0 ]; kd[ 0 ] = r.sd[ 0 ]; }
             int submitted = 1, consumed = 1;
@@ -203,15 +213,16 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
                 for(int c = 0; c < 4; ++c) cur[ c ] = nxt[ c ];
                 const float    cdist = r.sd[ consumed ];
                 const uint32_t cslot = r.sid[ consumed ];
+                const float    cn2 = row_norm<METRIC>(a.view, cslot);
                 if(consumed + 1 < n) load_row(r.sid[ consumed + 1 ], nxt);  // in flight while this one is tested
                 bool bad = false;
 #pragma unroll
                 for(int j = 0; j < 4; ++j) {
                     if(wave + 4 * j < submitted) {  // wave-uniform
-                        Acc<METRIC> acc;
+                        RowAcc<METRIC> acc;
 #pragma unroll
                         for(int c = 0; c < 4; ++c) acc.add(cur[ c ], kept[ j ][ c ]);
-                        const float d = acc.template finish<64>();
+                        const float d = acc.template finish_n<64>(cn2, keptn[ j ]);
                         bad |= d < cdist;  // meaningful in lane 63
                     }
                 }
@@ -228,6 +239,7 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
                             if(jj == j) {
 #pragma unroll
                                 for(int c = 0; c < 4; ++c) kept[ jj ][ c ] = cur[ c ];
+                                keptn[ jj ] = cn2;
                             }
                     }
                     if(tid == 0) { kid[ submitted ] = cslot; kd[ submitted ] = cdist; }
@@ -299,7 +311,8 @@ __global__ void __launch_bounds__(256) k_revlink(RevlinkArgs a)
         }
         if(!have_d) {  // distances of the original entries to `close`, once
             for(int i = g; i < c0; i += NG) {
-                float d = group_dist<METRIC, G>(row_of(a.view, close), row_of(a.view, r.cid[ i ]), (int)a.view.chunks, gl);
+                float d = group_dist_n<METRIC, G>(row_of(a.view, close), row_of(a.view, r.cid[ i ]), (int)a.view.chunks, gl,
+                                                  row_norm<METRIC>(a.view, close), row_norm<METRIC>(a.view, r.cid[ i ]));
                 if(gl == G - 1) r.cd[ i ] = d;
             }
             pairs += (uint32_t)c0;
@@ -465,7 +478,8 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
         __syncthreads();
         if(!have_d) {  // distances of the original entries to `close`, once (a = close, b = entry)
             for(int i = g; i < c0; i += NG) {
-                float d = group_dist<METRIC, G>(s.rows + (size_t)n * chunks, s.rows + (size_t)i * chunks, chunks, gl);
+                float d = group_dist_n<METRIC, G>(s.rows + (size_t)n * chunks, s.rows + (size_t)i * chunks, chunks, gl,
+                                                  row_norm<METRIC>(a.view, close), row_norm<METRIC>(a.view, s.cid[ i ]));
                 if(gl == G - 1) s.cd[ i ] = d;
             }
             pairs += (uint32_t)c0;
@@ -488,7 +502,8 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
             int       i = 1, j = g;
             while(j >= i) { j -= i; ++i; }
             for(int p = g; p < total; p += NG) {
-                float d = group_dist<METRIC, G>(s.rows + (size_t)s.sidx[ i ] * chunks, s.rows + (size_t)s.sidx[ j ] * chunks, chunks, gl);
+                float d = group_dist_n<METRIC, G>(s.rows + (size_t)s.sidx[ i ] * chunks, s.rows + (size_t)s.sidx[ j ] * chunks, chunks, gl,
+                                                  row_norm<METRIC>(a.view, s.sid[ i ]), row_norm<METRIC>(a.view, s.sid[ j ]));
                 if(gl == G - 1) s.pair[ i * n + j ] = d;
                 j += NG;
                 while(j >= i) { j -= i; ++i; }
@@ -925,10 +940,10 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_regs(RevlinkA
 #pragma unroll
                 for(int j = 0; j < 4; ++j) {
                     if(wave + 8 * j < c0) {
-                        Acc<METRIC> acc;
+                        RowAcc<METRIC> acc;
 #pragma unroll
                         for(int cc = 0; cc < CPL; ++cc) acc.add(cur[ cc ], kept[ j ][ cc ]);
-                        const float d = acc.template finish<64>();
+                        const float d = acc.template finish_n<64>(row_norm<METRIC>(a.view, close), row_norm<METRIC>(a.view, cid[ wave + 8 * j ]));
                         if(lane == 63) cd[ wave + 8 * j ] = d;
                     }
                 }
@@ -953,10 +968,12 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_regs(RevlinkA
             for(int j = 0; j < 4; ++j)
 #pragma unroll
                 for(int cc = 0; cc < CPL; ++cc) kept[ j ][ cc ] = make_uint4(0, 0, 0, 0);
+            float keptn[ 4 ] = { 0.f, 0.f, 0.f, 0.f };  // cached norms of this wave's kept rows (cosine metrics)
             if(wave == 0) {  // candidate 0 is always kept
                 load_row(sid[ 0 ], cur);
 #pragma unroll
                 for(int cc = 0; cc < CPL; ++cc) kept[ 0 ][ cc ] = cur[ cc ];
+                keptn[ 0 ] = row_norm<METRIC>(a.view, sid[ 0 ]);
             }
             if(tid == 0) { kid[ 0 ] = sid[ 0 ]; kd[ 0 ] = sd[ 0 ]; }
             if(1 + wave < n) load_row(sid[ 1 + wave ], nxt);  // candidates 1..8
@@ -972,6 +989,7 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_regs(RevlinkA
                 for(int cc = 0; cc < CPL; ++cc) cur[ cc ] = ring[ consumed & 1 ][ lane + 64 * cc ];
                 const float    cdist = sd[ consumed ];
                 const uint32_t cslot = sid[ consumed ];
+                const float    cn2 = row_norm<METRIC>(a.view, cslot);
                 if(consumed + 1 < n && wave == (consumed & 7)) {  // the owner of candidate consumed + 1 publishes it (the other slot
 #pragma unroll                                                      // was last read before the previous barrier) and refills
                     for(int cc = 0; cc < CPL; ++cc) ring[ (consumed + 1) & 1 ][ lane + 64 * cc ] = nxt[ cc ];
@@ -981,10 +999,10 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_regs(RevlinkA
 #pragma unroll
                 for(int j = 0; j < 4; ++j) {
                     if(wave + 8 * j < submitted) {  // wave-uniform
-                        Acc<METRIC> acc;
+                        RowAcc<METRIC> acc;
 #pragma unroll
                         for(int cc = 0; cc < CPL; ++cc) acc.add(cur[ cc ], kept[ j ][ cc ]);
-                        const float d = acc.template finish<64>();
+                        const float d = acc.template finish_n<64>(cn2, keptn[ j ]);
                         bad |= d < cdist;  // meaningful in lane 63
                     }
                 }
@@ -1001,6 +1019,7 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_regs(RevlinkA
                             if(jj == j) {
 #pragma unroll
                                 for(int cc = 0; cc < CPL; ++cc) kept[ jj ][ cc ] = cur[ cc ];
+                                keptn[ jj ] = cn2;
                             }
                     }
                     if(tid == 0) { kid[ submitted ] = cslot; kd[ submitted ] = cdist; }
@@ -1063,6 +1082,20 @@ __global__ void __launch_bounds__(256) k_apply_lists(View v, const uint32_t *rec
     uint32_t  cap;
     uint32_t *list = neighbors_of(v, close, level, cap);
     if(w - 2 < cap) list[ w - 2 ] = records[ (size_t)g * rw + w ];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_fill_norms: ||row||^2 of the rows [first, first + count) into View::norm2 -- once, when the rows enter the index
+// (cosine metrics; device_common.hpp "cached row norms").  One G-lane group per row, the a2 chain of Acc<M_COS>.
+template <int METRIC, int G>
+__global__ void __launch_bounds__(256) k_fill_norms(View v, uint32_t first, uint32_t count, float *norm2)
+{
+    const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) / G, gl = threadIdx.x % G;
+    const uint32_t ngroups = gridDim.x * blockDim.x / G;
+    for(uint32_t i = gid; i < count; i += ngroups) {
+        const float n2 = group_norm<METRIC, G>(row_of(v, first + i), (int)v.chunks, (int)gl);
+        if(gl == G - 1) norm2[ first + i ] = n2;
+    }
 }
 
 template <int METRIC, int G>
@@ -1255,6 +1288,20 @@ hipError_t launch_apply_lists(const View &v, const uint32_t *records, uint32_t n
     if(nrecords == 0) return hipSuccess;
     const uint64_t threads = (uint64_t)nrecords * (v.M0 + 2);
     hipLaunchKernelGGL(k_apply_lists, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, v, records, nrecords);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_norms(int metric, const View &v, uint32_t first, uint32_t count, float *norm2, hipStream_t stream)
+{
+    if(count == 0 || (metric != M_COS && metric != M_COS_F16)) return hipSuccess;
+    const int G_ = group_lanes_for(v.chunks);
+    uint32_t  blocks = (uint32_t)(((uint64_t)count * G_ + 255) / 256);
+    if(blocks > 16384) blocks = 16384;
+#define FN(MM, GG) hipLaunchKernelGGL((k_fill_norms<MM, GG>), dim3(blocks), dim3(256), 0, stream, v, first, count, norm2)
+#define FNG(MM) switch(G_) { case 64: FN(MM, 64); break; case 32: FN(MM, 32); break; case 16: FN(MM, 16); break; default: FN(MM, 8); }
+    if(metric == M_COS) FNG(M_COS) else FNG(M_COS_F16)
+#undef FNG
+#undef FN
     return hipGetLastError();
 }
 

@@ -94,6 +94,8 @@ hipError_t launch_apply_own_links(const View &v, uint32_t first_slot, const uint
 hipError_t launch_pack_lists(const RevlinkArgs &a, uint32_t *records, hipStream_t stream);
 hipError_t launch_apply_lists(const View &v, const uint32_t *records, uint32_t nrecords, hipStream_t stream);
 
+// ||row||^2 of rows [first, first + count) into norm2 (cosine metrics only; no-op otherwise)
+hipError_t launch_fill_norms(int metric, const View &v, uint32_t first, uint32_t count, float *norm2, hipStream_t stream);
 // out[i] = metric(query, row(slots[i]))
 hipError_t launch_gather(int metric, const View &v, const uint4 *query, const uint32_t *slots, uint32_t n, float *out,
                          hipStream_t stream);

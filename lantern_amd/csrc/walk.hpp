@@ -21,7 +21,8 @@
 namespace lgpu {
 
 // scalar slots in LDS
-enum { S_POS = 0, S_NNEW, S_CNT, S_ANY, S_BAD, S_CUR, S_CURD, S_CHANGED, S_VISCNT, S_SPILL, S_SCALARS = 16 };
+enum { S_POS = 0, S_NNEW, S_CNT, S_ANY, S_BAD, S_CUR, S_CURD, S_CHANGED, S_VISCNT, S_SPILL, S_QN2, S_SCALARS = 16 };
+// S_QN2: ||query||^2 as float bits (cosine metrics; set by the kernel before a walk: device_common.hpp "cached row norms")
 
 struct WalkLds
 {
@@ -102,8 +103,9 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
 {
     const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
     float *newd = (float *)s.newkeys;  // reuse: one f32 per neighbour
+    const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
-        float d = group_dist<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl);
+        float d = group_dist_n<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) { s.scal[ S_CUR ] = (int)start; s.scal[ S_CURD ] = __float_as_int(d); }
     }
     D += 1;
@@ -124,7 +126,8 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
             __syncthreads();
             const int nn = s.scal[ S_NNEW ];
             for(int i = g; i < nn; i += NG) {
-                float d = group_dist<METRIC, G>(s.q, row_of(v, s.newids[ i ]), (int)v.chunks, gl);
+                const uint32_t id = s.newids[ i ];
+                float d = group_dist_n<METRIC, G>(s.q, row_of(v, id), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id));
                 if(gl == G - 1) newd[ i ] = d;
             }
             D += (uint32_t)nn;
@@ -165,8 +168,9 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         uint4 *b4 = (uint4 *)bitmap;
         for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
     }
+    const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
-        float d = group_dist<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl);
+        float d = group_dist_n<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) s.keys[ 0 ] = make_key(d, start);
     }
     D += 1;
@@ -219,7 +223,8 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
             const uint32_t id0 = s.newids[ i ];
             const uint32_t id1 = j < nnew ? s.newids[ j ] : id0;
             float          d0, d1;
-            group_dist2<METRIC, G>(s.q, row_of(v, id0), row_of(v, id1), (int)v.chunks, gl, d0, d1);
+            group_dist2_n<METRIC, G>(s.q, row_of(v, id0), row_of(v, id1), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id0),
+                                     row_norm<METRIC>(v, id1), d0, d1);
             if(gl == G - 1) {
                 uint64_t k0 = make_key(d0, id0);
                 s.newkeys[ i ] = k0;
@@ -309,8 +314,10 @@ __device__ int refine(const View &v, RefineLds &r, int *scal, int n, int needed,
     while(submitted < needed && consumed < n) {
         const uint32_t cid = r.sid[ consumed ];
         const float    cdist = r.sd[ consumed ];
+        const float    cn2 = row_norm<METRIC>(v, cid);
         for(int i = g; i < submitted; i += NG) {
-            float inter = group_dist<METRIC, G>(row_of(v, cid), row_of(v, r.sid[ i ]), (int)v.chunks, gl);
+            const uint32_t kid = r.sid[ i ];
+            float inter = group_dist_n<METRIC, G>(row_of(v, cid), row_of(v, kid), (int)v.chunks, gl, cn2, row_norm<METRIC>(v, kid));
             if(gl == G - 1 && inter < cdist) scal[ S_BAD ] = 1;
         }
         Dr += (uint32_t)submitted;
