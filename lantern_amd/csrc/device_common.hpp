@@ -265,9 +265,10 @@ __device__ __forceinline__ void group_dist2(PA a, PB b0, PB b1, int chunks, int 
 // Acc<M_COS> runs three independent fma chains per lane (ab, a2, b2) and three G-lane sums.  a2 depends on the first
 // operand only and b2 on the second only, so for STORED rows both are properties of the row: they are computed once,
 // when the row enters the index, by the very chain and tree Acc<M_COS> would run (NormAcc + group_sum<G>, G fixed per
-// index), and kept in View::norm2.  A row evaluation is then ONE chain (ab) and ONE G-lane sum -- the bits of
-// 1 - ab / (sqrt(a2) * sqrt(b2)) are those of the one-pass accumulator (usearch metric_cos_gt), at the cost of the
-// l2sq walk.  The query's a2 is computed once per query the same way.
+// index), and kept -- already square-rooted: IEEE sqrt is a function of its argument -- in View::norm2.  A row
+// evaluation is then ONE chain (ab), ONE G-lane sum, one multiply and one divide: the bits of
+// 1 - ab / (sqrt(a2) * sqrt(b2)) are those of the one-pass accumulator (usearch metric_cos_gt).  The query's
+// sqrt(a2) is computed once per query the same way.
 template <int METRIC> constexpr bool kCachedNorms = (METRIC == M_COS || METRIC == M_COS_F16);
 
 __device__ __forceinline__ float cos_finish(float ab, float a2, float b2)
@@ -276,6 +277,14 @@ __device__ __forceinline__ float cos_finish(float ab, float a2, float b2)
     if(a2 == 0.f && b2 == 0.f) return 0.f;
     if(a2 == 0.f || b2 == 0.f) return 1.f;
     return 1.f - ab / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));
+}
+
+// the same with ra = sqrt(a2), rb = sqrt(b2) already taken (sqrt(x) == 0 iff x == 0)
+__device__ __forceinline__ float cos_finish_rooted(float ab, float ra, float rb)
+{
+    if(ra == 0.f && rb == 0.f) return 0.f;
+    if(ra == 0.f || rb == 0.f) return 1.f;
+    return 1.f - ab / (ra * rb);
 }
 
 // ||row||^2 of one operand: the a2 (= b2) chain of Acc<M_COS> / Acc<M_COS_F16>
@@ -301,7 +310,7 @@ template <int METRIC> struct NormAcc
         }
     }
 };
-// complete in the LAST lane of the group
+// sqrt(||row||^2), complete in the LAST lane of the group
 template <int METRIC, int G, typename PA> __device__ __forceinline__ float group_norm(PA a, int chunks, int gl)
 {
     NormAcc<METRIC> acc;
@@ -310,7 +319,7 @@ template <int METRIC, int G, typename PA> __device__ __forceinline__ float group
         uint4 x = a[ ch ];
         acc.add(x);
     }
-    return group_sum<G>(acc.s);
+    return __builtin_sqrtf(group_sum<G>(acc.s));
 }
 
 // The accumulator of one (row, row) evaluation when both norms are known: the ab chain only for the cosine metrics,
@@ -329,7 +338,7 @@ template <> struct RowAcc<M_COS>
         s = __builtin_fmaf(__uint_as_float(xa.z), __uint_as_float(yb.z), s);
         s = __builtin_fmaf(__uint_as_float(xa.w), __uint_as_float(yb.w), s);
     }
-    template <int G> __device__ __forceinline__ float finish_n(float a2, float b2) { return cos_finish(group_sum<G>(s), a2, b2); }
+    template <int G> __device__ __forceinline__ float finish_n(float ra, float rb) { return cos_finish_rooted(group_sum<G>(s), ra, rb); }
 };
 template <> struct RowAcc<M_COS_F16>
 {
@@ -343,10 +352,10 @@ template <> struct RowAcc<M_COS_F16>
         s = __builtin_fmaf(x1, y1, s);
     }
     __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb) { word(xa.x, yb.x); word(xa.y, yb.y); word(xa.z, yb.z); word(xa.w, yb.w); }
-    template <int G> __device__ __forceinline__ float finish_n(float a2, float b2) { return cos_finish(group_sum<G>(s), a2, b2); }
+    template <int G> __device__ __forceinline__ float finish_n(float ra, float rb) { return cos_finish_rooted(group_sum<G>(s), ra, rb); }
 };
 
-// group_dist with known norms (a2 of `a`, b2 of `b`); complete in the LAST lane of the group
+// group_dist with known (rooted) norms of `a` and `b`; complete in the LAST lane of the group
 template <int METRIC, int G, typename PA, typename PB>
 __device__ __forceinline__ float group_dist_n(PA a, PB b, int chunks, int gl, float a2, float b2)
 {
@@ -391,7 +400,7 @@ struct View
     const uint32_t *upper_off; // [cap] first upper block of the node (levels 1..L are consecutive)
     uint32_t       *upper_nbr; // [blocks][M]
     const uint8_t  *levels;    // [cap]
-    const float    *norm2;     // [cap] ||row||^2 for the cosine metrics (exactly the a2 / b2 chain of Acc<M_COS>); else NULL
+    const float    *norm2;     // [cap] sqrt(||row||^2) for the cosine metrics (the a2 / b2 chain of Acc<M_COS>, then IEEE sqrt); else NULL
     uint32_t        n;
     uint32_t        entry;
     int32_t         max_level;
