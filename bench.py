@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only to debug the N>1 path on one GPU")
     p.add_argument("--data", default="gaussian", choices=["gaussian", "lowrank"],
                    help="gaussian = the prescribed i.i.d. N(0,1) set (SURVEY 8d); lowrank = 32 latent dims embedded in --dim (embedding-like)")
+    p.add_argument("--data-scale", type=float, default=1.0, help="multiply the synthetic rows and queries (i8 storage quantises [-1, 1]: use 0.3)")
     p.add_argument("--sharded-build", default="auto", choices=["auto", "on", "off"],
                    help="after the search measurement, build the same index ONCE across all ranks (RCCL all-gathers, one child "
                         "process per GPU: lantern_amd/sharded_build.py) and report its rate; auto = when --gpus > 1")
@@ -95,6 +96,10 @@ def main():
     t0 = time.time()
     make_queries = synth.query_maker(a.data, a.dim)
     base = synth.base_rows(a.data, a.n, a.dim)
+    if a.data_scale != 1.0:
+        raw_queries = make_queries
+        make_queries = lambda r, n: raw_queries(r, n) * np.float32(a.data_scale)
+        base *= np.float32(a.data_scale)
     labels = np.arange(a.n, dtype=np.uint64) + 1  # 0 is INVALID_ELEMENT_LABEL (hnsw.h:40)
     t_gen = time.time() - t0
 
@@ -198,7 +203,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f16": "f32 arithmetic on f16 storage", "i8": "int32 arithmetic on i8 storage"}[a.quant],
-            "data": "synthetic" if a.data == "gaussian" else "synthetic (low-rank)",
+            "data": ("synthetic" if a.data == "gaussian" else "synthetic (low-rank)") + ("" if a.data_scale == 1.0 else f" x {a.data_scale}"),
             "config": {"workload": f"HNSW search {a.n}x{a.dim} {a.quant} {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}",
                        "queries_per_step_per_gpu": nq, "global_queries_per_step": nq * world, "waves_per_query": a.waves,
                        "parallelism": f"replicated index, query batch sharded x{world}, no collective"},
@@ -242,7 +247,7 @@ def sharded_build_leg(a, rank, world, dev_index, dist, ix0):
             rdv = box[0]
         cmd = [sys.executable, "-m", "lantern_amd.sharded_build", "--rank", str(rank), "--world", str(world), "--rendezvous", rdv,
                "--device", str(dev_index), "--rows", str(a.n), "--dim", str(a.dim), "--metric", a.metric, "--M", str(a.M),
-               "--efc", str(a.efc), "--ef", str(a.ef), "--add-batch", str(a.add_batch), "--quant", a.quant, "--data", a.data]
+               "--efc", str(a.efc), "--ef", str(a.ef), "--add-batch", str(a.add_batch), "--quant", a.quant, "--data", a.data, "--data-scale", str(a.data_scale)]
         env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.setdefault("NCCL_SOCKET_IFNAME", "lo")  # all ranks are on this node; the container's hostname may not resolve
         t0 = time.time()

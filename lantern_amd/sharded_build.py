@@ -56,6 +56,7 @@ def main():
     p.add_argument("--add-batch", type=int, default=8192)
     p.add_argument("--quant", default="f32")
     p.add_argument("--data", default="gaussian")
+    p.add_argument("--data-scale", type=float, default=1.0)
     p.add_argument("--timeout", type=float, default=120.0, help="deadline of every collective")
     a = p.parse_args()
 
@@ -68,6 +69,8 @@ def main():
 
     t0 = time.time()
     base = synth.base_rows(a.data, a.rows, a.dim)
+    if a.data_scale != 1.0:
+        base *= np.float32(a.data_scale)
     lo, hi = capi.shard_range(a.rows, a.world, a.rank)
     shard = np.ascontiguousarray(base[lo:hi])
     labels = np.arange(lo, hi, dtype=np.uint64) + 1
