@@ -210,6 +210,8 @@ extern "C" {
 void lantern_gpu_comm_unique_id(char *id128, usearch_error_t *e)
 {
     CLEAR(e);
+    int ndev = 0;
+    if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { FAIL(e, "lantern_gpu: no HIP device available (this library has no CPU fallback)"); return; }
     RcclApi *api = rccl_api();
     if(!api->so) { FAIL(e, keep_err(api->why)); return; }
     ncclUniqueId       id;
@@ -223,10 +225,12 @@ lantern_gpu_comm_t *lantern_gpu_comm_init_rccl(int rank, int world, const char *
 {
     CLEAR(e);
     if(world < 1 || rank < 0 || rank >= world || !id128) { FAIL(e, "lantern_gpu: bad rank / world / id"); return nullptr; }
-    RcclApi *api = rccl_api();
-    if(!api->so) { FAIL(e, keep_err(api->why)); return nullptr; }
+    // the device check comes first: a host without a GPU never maps librccl (573 MB, and a process that later imports
+    // PyTorch would otherwise end up with ROCm's RCCL under torch's bundled HIP stack)
     int ndev = 0;
     if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { FAIL(e, "lantern_gpu: no HIP device available (this library has no CPU fallback)"); return nullptr; }
+    RcclApi *api = rccl_api();
+    if(!api->so) { FAIL(e, keep_err(api->why)); return nullptr; }
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     ncclComm_t         nc = nullptr;
