@@ -86,17 +86,25 @@ template <int G, typename T> __device__ __forceinline__ T group_sum(T s)
 // ---- per-lane accumulation ----------------------------------------------------------------------
 template <int METRIC> struct Acc;
 
+// two f32 lanes of one VGPR pair: the differences of an l2sq chunk are independent of one another, so they are formed
+// with packed subtracts (v_pk_add_f32: two IEEE subtractions per instruction, same bits); the fma CHAIN stays scalar
+// and in memory order, which is what the reduction-order contract fixes.
+typedef float lgpu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void l2sq_chunk(const uint4 &xa, const uint4 &yb, float &s)
+{
+    const lgpu_f32x2 x01 = { __uint_as_float(xa.x), __uint_as_float(xa.y) }, x23 = { __uint_as_float(xa.z), __uint_as_float(xa.w) };
+    const lgpu_f32x2 y01 = { __uint_as_float(yb.x), __uint_as_float(yb.y) }, y23 = { __uint_as_float(yb.z), __uint_as_float(yb.w) };
+    const lgpu_f32x2 t01 = x01 - y01, t23 = x23 - y23;
+    s = __builtin_fmaf(t01[ 0 ], t01[ 0 ], s);
+    s = __builtin_fmaf(t01[ 1 ], t01[ 1 ], s);
+    s = __builtin_fmaf(t23[ 0 ], t23[ 0 ], s);
+    s = __builtin_fmaf(t23[ 1 ], t23[ 1 ], s);
+}
+
 template <> struct Acc<M_L2SQ>
 {
     float s = 0.f;
-    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb)
-    {
-        float t;
-        t = __uint_as_float(xa.x) - __uint_as_float(yb.x); s = __builtin_fmaf(t, t, s);
-        t = __uint_as_float(xa.y) - __uint_as_float(yb.y); s = __builtin_fmaf(t, t, s);
-        t = __uint_as_float(xa.z) - __uint_as_float(yb.z); s = __builtin_fmaf(t, t, s);
-        t = __uint_as_float(xa.w) - __uint_as_float(yb.w); s = __builtin_fmaf(t, t, s);
-    }
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb) { l2sq_chunk(xa, yb, s); }
     template <int G> __device__ __forceinline__ float finish()
     {
         return group_sum<G>(s);

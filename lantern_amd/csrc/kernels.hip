@@ -573,14 +573,7 @@ template <int METRIC> struct PairAcc;
 template <> struct PairAcc<M_L2SQ>
 {
     float s = 0.f;
-    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y)
-    {
-        float t;
-        t = __uint_as_float(x.x) - __uint_as_float(y.x); s = __builtin_fmaf(t, t, s);
-        t = __uint_as_float(x.y) - __uint_as_float(y.y); s = __builtin_fmaf(t, t, s);
-        t = __uint_as_float(x.z) - __uint_as_float(y.z); s = __builtin_fmaf(t, t, s);
-        t = __uint_as_float(x.w) - __uint_as_float(y.w); s = __builtin_fmaf(t, t, s);
-    }
+    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y) { l2sq_chunk(x, y, s); }
     __device__ __forceinline__ float sum() { return group_sum<64>(s); }
 };
 template <> struct PairAcc<M_COS>
