@@ -184,10 +184,14 @@ static uint32_t *next_ticket(Index *ix, size_t work, int grid, hipStream_t strea
     return t;
 }
 
-int search_grid(const Index *ix, size_t nq, int waves)
+// Resident workgroups of a walk kernel.  k_search is compiled for six waves per SIMD (<= 80 VGPRs:
+// __launch_bounds__(512, 6)) and its LDS is sized for six workgroups per CU, i.e. 24 waves per CU; k_insert (wider
+// lists, a larger visited set) runs at four waves per SIMD.  LANTERN_GPU_WAVES_PER_CU overrides (tuning).
+int search_grid(const Index *ix, size_t nq, int waves, int waves_per_cu)
 {
-    // the kernels run at 4 waves/SIMD = 16 waves/CU (VGPR-bound); one workgroup = `waves` waves
-    int per_cu = std::max(1, 16 / std::max(1, waves));
+    static const int forced = std::getenv("LANTERN_GPU_WAVES_PER_CU") ? std::atoi(std::getenv("LANTERN_GPU_WAVES_PER_CU")) : 0;
+    if(forced > 0) waves_per_cu = forced;
+    int per_cu = std::max(1, waves_per_cu / std::max(1, waves));
     size_t g = (size_t)ix->num_cus * per_cu;
     if(ix->search_max_wg > 0) g = (size_t)ix->search_max_wg;
     if(g > nq) g = nq;
@@ -273,7 +277,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     HIPCHK(ix, hipMemcpyAsync(d_link_off, link_off.data(), b * 4, hipMemcpyHostToDevice, ix->stream));
     HIPCHK(ix, hipMemcpyAsync(d_item_node, item_node.data(), items * 4, hipMemcpyHostToDevice, ix->stream));
 
-    const int grid = search_grid(ix, b_hi - b_lo, ix->insert_waves);
+    const int grid = search_grid(ix, b_hi - b_lo, ix->insert_waves, 16);
     if(!ensure_bitmaps(ix, (size_t)grid)) return false;
     auto link_at = [&](size_t i) { return i < b ? (size_t)link_off[ i ] : total_links; };
 
@@ -573,17 +577,18 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     size_t expansion = ef ? ef : ix->ef;
     if(expansion < k + skip) expansion = k + skip;  // usearch: expansion = max(expansion, wanted)
     // LDS visited set: sized for ~3x the planner's estimate of visited nodes per query (hnsw.c:89-132 puts it at
-    // about 2 M ef S with S ~ 3), capped so that four workgroups still fit on a CU; it spills to the bitmap beyond
+    // about 2 M ef S with S ~ 3), capped so that SIX workgroups fit on a CU (more walks in flight beat a roomier
+    // set: 1.106 -> 1.17 M QPS at 1M x 768); it spills to the bitmap beyond
     uint32_t vis_slots = 1024;
     while(vis_slots < 8192 && vis_slots / 4 * 3 < expansion * ix->M0 * 2) vis_slots <<= 1;
     if(ix->search_vis_slots >= 0) vis_slots = (uint32_t)ix->search_vis_slots;
-    while(vis_slots && search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 38 * 1024) vis_slots >>= 1;
+    while(vis_slots && search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 26 * 1024) vis_slots >>= 1;  // six workgroups per CU
     if(vis_slots && vis_slots < 4 * ix->M0) vis_slots = 0;
     if(search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 160 * 1024) {
         set_err(ix, "lantern_gpu: ef/k exceed the 160 KiB LDS budget of the search kernel");
         return false;
     }
-    const int grid = search_grid(ix, nq, waves);
+    const int grid = search_grid(ix, nq, waves, 24);
     if(!ensure_bitmaps(ix, (size_t)grid)) return false;
     SearchArgs a;
     a.view = ix->view();

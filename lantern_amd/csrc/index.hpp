@@ -95,7 +95,7 @@ void       *scratch(Index *ix, int which, size_t bytes);
 bool        pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst);
 size_t      input_bytes(const Index *ix, int kind_in);
 bool        kind_accepted(const Index *ix, int kind_in);
-int         search_grid(const Index *ix, size_t nq, int waves);
+int         search_grid(const Index *ix, size_t nq, int waves, int waves_per_cu);
 bool        run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, size_t ef, size_t skip,
                               uint64_t *d_labels, float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D,
                               uint64_t *d_E, hipStream_t stream, int waves);

@@ -25,7 +25,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
 
 // ---------------------------------------------------------------------------------------------------
 template <int METRIC, int G>
-__global__ void __launch_bounds__(512) k_search(SearchArgs a)
+__global__ void __launch_bounds__(512, 6) k_search(SearchArgs a)  // <= 80 VGPRs: six waves per SIMD, six 4-wave workgroups per CU
 {
     const int tid = threadIdx.x, T = blockDim.x;
     WalkLds   s;
