@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(512, 6) k_search(SearchArgs a)  // <= 80 VGPRs
 // ef_construction-wide search_level whose sorted result (<= efc keys) goes to HBM for k_connect.  The start of
 // the next lower level is connect_new_node_'s first pick: the closest result under (distance, tie_mix).
 template <int METRIC, int G>
-__global__ void __launch_bounds__(512) k_insert(InsertArgs a)
+__global__ void __launch_bounds__(512, 6) k_insert(InsertArgs a)
 {
     const int tid = threadIdx.x, T = blockDim.x;
     WalkLds   s;
