@@ -245,23 +245,30 @@ def sharded_build_leg(a, rank, world, dev_index, dist, ix0):
             box = [rdv]
             dist.broadcast_object_list(box, src=0)
             rdv = box[0]
-        cmd = [sys.executable, "-m", "lantern_amd.sharded_build", "--rank", str(rank), "--world", str(world), "--rendezvous", rdv,
-               "--device", str(dev_index), "--rows", str(a.n), "--dim", str(a.dim), "--metric", a.metric, "--M", str(a.M),
-               "--efc", str(a.efc), "--ef", str(a.ef), "--add-batch", str(a.add_batch), "--quant", a.quant, "--data", a.data, "--data-scale", str(a.data_scale)]
-        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        env.setdefault("NCCL_SOCKET_IFNAME", "lo")  # all ranks are on this node; the container's hostname may not resolve
-        t0 = time.time()
+        # whatever happens to this rank's child, the rank still takes part in the gather below (a rank that skipped it
+        # would leave its peers waiting in a collective)
+        wall = 0.0
         try:
-            cp = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=a.sharded_build_timeout)
-            rc, text = cp.returncode, cp.stdout + cp.stderr
-        except subprocess.TimeoutExpired as e:
-            rc, text = -9, f"timed out after {a.sharded_build_timeout} s: " + str(e.stdout or "")[-400:]
-        wall = time.time() - t0
-        res = None
-        for line in text.splitlines():
-            if line.startswith("SHARDED_BUILD "):
-                res = json.loads(line[len("SHARDED_BUILD "):])
-        mine = res if (rc == 0 and res) else {"error": f"rank {rank}: exit {rc}: " + text[-600:]}
+            cmd = [sys.executable, "-m", "lantern_amd.sharded_build", "--rank", str(rank), "--world", str(world), "--rendezvous", rdv,
+                   "--device", str(dev_index), "--rows", str(a.n), "--dim", str(a.dim), "--metric", a.metric, "--M", str(a.M),
+                   "--efc", str(a.efc), "--ef", str(a.ef), "--add-batch", str(a.add_batch), "--quant", a.quant, "--data", a.data,
+                   "--data-scale", str(a.data_scale)]
+            env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env.setdefault("NCCL_SOCKET_IFNAME", "lo")  # all ranks are on this node; the container's hostname may not resolve
+            t0 = time.time()
+            try:
+                cp = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=a.sharded_build_timeout)
+                rc, text = cp.returncode, cp.stdout + cp.stderr
+            except subprocess.TimeoutExpired as e:
+                rc, text = -9, f"timed out after {a.sharded_build_timeout} s: " + str(e.stdout or "")[-400:]
+            wall = time.time() - t0
+            res = None
+            for line in text.splitlines():
+                if line.startswith("SHARDED_BUILD "):
+                    res = json.loads(line[len("SHARDED_BUILD "):])
+            mine = res if (rc == 0 and res) else {"error": f"rank {rank}: exit {rc}: " + text[-600:]}
+        except Exception as e:  # noqa: BLE001
+            mine = {"error": f"rank {rank}: {e!r}"}
         if world > 1:
             every = [None] * world
             dist.all_gather_object(every, mine)
