@@ -186,7 +186,7 @@ static uint32_t *next_ticket(Index *ix, size_t work, int grid, hipStream_t strea
 
 // Resident workgroups of a walk kernel.  k_search is compiled for six waves per SIMD (<= 80 VGPRs:
 // __launch_bounds__(512, 6)) and its LDS is sized for six workgroups per CU, i.e. 24 waves per CU; k_insert (wider
-// lists, a larger visited set) runs at four waves per SIMD.  LANTERN_GPU_WAVES_PER_CU overrides (tuning).
+// lists, a larger visited set) runs at five.  LANTERN_GPU_WAVES_PER_CU overrides (tuning).
 int search_grid(const Index *ix, size_t nq, int waves, int waves_per_cu)
 {
     static const int forced = std::getenv("LANTERN_GPU_WAVES_PER_CU") ? std::atoi(std::getenv("LANTERN_GPU_WAVES_PER_CU")) : 0;
@@ -277,7 +277,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     HIPCHK(ix, hipMemcpyAsync(d_link_off, link_off.data(), b * 4, hipMemcpyHostToDevice, ix->stream));
     HIPCHK(ix, hipMemcpyAsync(d_item_node, item_node.data(), items * 4, hipMemcpyHostToDevice, ix->stream));
 
-    const int grid = search_grid(ix, b_hi - b_lo, ix->insert_waves, 16);
+    const int grid = search_grid(ix, b_hi - b_lo, ix->insert_waves, 20);
     if(!ensure_bitmaps(ix, (size_t)grid)) return false;
     auto link_at = [&](size_t i) { return i < b ? (size_t)link_off[ i ] : total_links; };
 
@@ -293,9 +293,11 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     ia.bitmaps = ix->d_bitmaps;
     ia.bm_words = (uint32_t)ix->bm_words;
     // LDS visited set for the ef_construction-wide walk (spills to the bitmap when 3/4 full); env override for tuning
+    // the largest table that still lets FIVE workgroups share a CU (160 KB / 5, minus the walk's lists): 6400 slots at
+    // 768-d / efc 128, enough for the ~3700 nodes such a walk visits at the 3/4 load limit
     uint32_t ivis = 8192;
-    if(const char *vs = std::getenv("LANTERN_GPU_INSERT_VIS_SLOTS")) ivis = (uint32_t)std::atoi(vs);
-    while(ivis && insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 52 * 1024) ivis >>= 1;
+    if(const char *vs = std::getenv("LANTERN_GPU_INSERT_VIS_SLOTS")) ivis = (uint32_t)std::atoi(vs) / 4 * 4;
+    while(ivis && insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 31 * 1024) ivis = ivis > 256 ? ivis - 256 : 0;
     if(ivis && ivis < 4 * ix->M0) ivis = 0;
     ia.vis_slots = ivis;
     ia.totals = ix->d_totals + 2;
@@ -581,8 +583,9 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     // set: 1.106 -> 1.17 M QPS at 1M x 768); it spills to the bitmap beyond
     uint32_t vis_slots = 1024;
     while(vis_slots < 8192 && vis_slots / 4 * 3 < expansion * ix->M0 * 2) vis_slots <<= 1;
-    if(ix->search_vis_slots >= 0) vis_slots = (uint32_t)ix->search_vis_slots;
-    while(vis_slots && search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 26 * 1024) vis_slots >>= 1;  // six workgroups per CU
+    if(ix->search_vis_slots >= 0) vis_slots = (uint32_t)ix->search_vis_slots / 4 * 4;
+    while(vis_slots && search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 26 * 1024)  // six workgroups per CU
+        vis_slots = vis_slots > 256 ? vis_slots - 256 : 0;
     if(vis_slots && vis_slots < 4 * ix->M0) vis_slots = 0;
     if(search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 160 * 1024) {
         set_err(ix, "lantern_gpu: ef/k exceed the 160 KiB LDS budget of the search kernel");

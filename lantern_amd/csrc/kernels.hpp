@@ -22,7 +22,7 @@ struct SearchArgs
     uint64_t       *out_E;       // [nq] or NULL
     uint32_t       *bitmaps;     // [grid][bm_words]
     uint32_t        bm_words;    // multiple of 4
-    uint32_t        vis_slots;   // LDS visited-set slots (power of two; 0 = HBM bitmap only)
+    uint32_t        vis_slots;   // LDS visited-set slots (a multiple of 4; 0 = HBM bitmap only)
     unsigned long long *totals;  // [2] cumulative D, E (atomicAdd) or NULL
     uint32_t       *ticket;      // zeroed before the launch: queries beyond the first gridDim.x are handed out dynamically
 };                               // (NULL = static striding); results do not depend on who runs a query

@@ -33,7 +33,7 @@ struct WalkLds
     uint64_t *sorted;   // the same, sorted                  (cap_max)
     uint32_t *newids;   // unvisited neighbour slots         (cap_max)
     int      *scal;     // S_* scalars
-    uint32_t *vis;      // visited hash set (vis_slots entries, power of two; 0 = the HBM bitmap only)
+    uint32_t *vis;      // visited hash set (vis_slots entries, any multiple of 4; 0 = the HBM bitmap only)
     uint32_t  vis_slots;
 };
 
@@ -65,7 +65,8 @@ __host__ inline size_t walk_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t
 // (no HBM round trip per hop, nothing to clear in HBM per query) that SPILLS to the workgroup's HBM bitmap once it
 // is three quarters full: from then on new slots are recorded in the bitmap (cleared at that moment) and a
 // lookup consults both.  With vis_slots == 0 only the bitmap is used.
-__device__ __forceinline__ uint32_t vis_hash(uint32_t x, uint32_t slots) { return (x * 0x9E3779B1u) & (slots - 1); }
+// multiply-shift onto [0, slots): any table size, so the set can be sized to the LDS a given occupancy leaves
+__device__ __forceinline__ uint32_t vis_hash(uint32_t x, uint32_t slots) { return __umulhi(x * 0x9E3779B1u, slots); }
 
 // true if `x` was already visited; otherwise records it.  Called by the lanes of wave 0 only.
 __device__ __forceinline__ bool visit_test_and_set(WalkLds &s, uint32_t *bitmap, uint32_t x, bool spilled)
@@ -79,7 +80,7 @@ __device__ __forceinline__ bool visit_test_and_set(WalkLds &s, uint32_t *bitmap,
                 if(!spilled) { atomicAdd(&s.scal[ S_VISCNT ], 1); return false; }
                 break;  // not in the LDS set: the bitmap decides
             }
-            h = (h + 1) & (s.vis_slots - 1);
+            h = h + 1 == s.vis_slots ? 0u : h + 1;
         }
     }
     const uint32_t bit = 1u << (x & 31);
