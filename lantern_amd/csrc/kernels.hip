@@ -1,19 +1,26 @@
 // kernels.hip -- gfx950 kernels of the HNSW distance-evaluation path.
 //
-//   k_search   usearch_search_ef  (lantern_hnsw/src/hnsw/scan.c:220-228,273-281): one workgroup per
-//              query, persistent over the batch; greedy descent + ef-bounded base-layer walk.
-//   k_insert   the walk of usearch_add (build.c:128; server.rs:349 add_raw): per new vector, descent +
-//              per-level ef_construction walk; the sorted results go to k_connect.
-//   k_connect  connect_new_node_: neighbour selection with the kept rows in registers; writes the new
-//              node's lists and emits the reverse-link requests.
-//   k_revlink  the reverse-link half (usearch reconnect_neighbor_nodes_): one workgroup per
-//              (node, level) that received requests; append or re-prune with the heuristic.
-//   k_gather   metric(query, row[slots[i]]) -- the distance kernel on its own (tests, profiling).
-//   k_pairs    na x nb pairwise distances in the walk's exact reduction order (usearch_distance,
-//              hnsw.c:296-345; PQ k-means assign product_quantization.c:80-124).
+//   k_search        usearch_search_ef  (lantern_hnsw/src/hnsw/scan.c:220-228,273-281): one workgroup per
+//                   query, persistent over the batch (six 4-wave workgroups per CU, work handed out by
+//                   ticket); greedy descent + ef-bounded base-layer walk.
+//   k_insert        the walk of usearch_add (build.c:128; server.rs:349 add_raw): per new vector, descent +
+//                   per-level ef_construction walk; the sorted results go to k_connect.
+//   k_connect       connect_new_node_: neighbour selection with the kept rows in registers; writes the new
+//                   node's lists and emits the reverse-link requests.
+//   k_revlink_*     the reverse-link half (usearch reconnect_neighbor_nodes_): k_revlink_append (one wave per
+//                   (node, level) group: append while there is room), then the re-prune of full lists by row
+//                   shape: k_revlink_regs (kept rows in registers, candidates through an LDS ring),
+//                   k_revlink_slab (column slabs through LDS), k_revlink_staged / k_revlink (rows staged whole
+//                   in LDS / read from L2).
+//   k_fill_norms    sqrt(||row||^2) of newly stored rows for the cosine metrics (device_common.hpp).
+//   k_apply_own_links / k_pack_lists / k_apply_lists
+//                   scatter kernels either side of the all-gathers of the work-sharded build (comm.cpp).
+//   k_gather        metric(query, row[slots[i]]) -- the distance kernel on its own (tests, profiling).
+//   k_pairs         na x nb pairwise distances in the walk's exact reduction order (usearch_distance,
+//                   hnsw.c:296-345; PQ k-means assign product_quantization.c:80-124).
 //
 // HBM-bound by design: every row is read with 16-byte-per-lane coalesced loads (1 KiB per wave
-// instruction at G = 64), neighbour ids are staged through LDS, reductions are wavefront shuffles.
+// instruction at G = 64), neighbour ids are staged through LDS, reductions are wavefront shuffles (DPP).
 #include <cstdlib>
 
 #include "kernels.hpp"

@@ -12,7 +12,8 @@
 //    several rows in flight per wave), then merged into the list in one parallel rank-merge.  The
 //    result equals inserting them one by one: the list ends up holding the ef smallest of
 //    (old list U new), whatever the order of insertion.
-//  * the visited set is a bitmap in HBM owned by the workgroup (atomicOr gives test-and-set).
+//  * the visited set is an open-addressing hash set in LDS that spills to a bitmap in HBM owned by the
+//    workgroup when three quarters full (visit_test_and_set below).
 //
 // All functions must be called by every thread of the workgroup (they contain barriers).
 #pragma once
