@@ -161,6 +161,13 @@ LANTERN_GPU_EXPORT void lantern_gpu_set_add_batch(usearch_index_t, size_t max_ba
 /* many inserts in one call (the external indexer's row stream, server.rs:214-267) */
 LANTERN_GPU_EXPORT void lantern_gpu_add_many(usearch_index_t, const usearch_label_t *labels, const void *vectors,
                                              size_t n, usearch_scalar_kind_t, usearch_error_t *);
+/* The two host-side rules that make a build reproducible by any builder (pure functions, no device):
+ * the level of the node at `slot` -- floor(-ln(U) / ln(M)) as insert.c:32-46, U a hash of (seed, slot) -- and the
+ * prefix of the pending vectors that forms the next device batch (<= max_batch, <= size / min_ratio, a vector that
+ * raises the top level goes alone). */
+LANTERN_GPU_EXPORT int    lantern_gpu_level_for(uint64_t seed, uint64_t slot, uint32_t connectivity);
+LANTERN_GPU_EXPORT size_t lantern_gpu_plan_batch(size_t current_size, int max_level, const int *pending_levels, size_t pending,
+                                                 size_t max_batch, size_t min_ratio);
 /* apply all buffered inserts now */
 LANTERN_GPU_EXPORT void lantern_gpu_flush(usearch_index_t, usearch_error_t *);
 /* usearch_add_external-style insert with a caller-drawn level (insert.c:32-46,209) */

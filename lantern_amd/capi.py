@@ -91,6 +91,7 @@ EXPORTS = [
     "lantern_gpu_comm_init_local", "lantern_gpu_comm_free", "lantern_gpu_comm_rank", "lantern_gpu_comm_world",
     "lantern_gpu_comm_set_timeout", "lantern_gpu_comm_stats", "lantern_gpu_comm_allgatherv_host",
     "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded",
+    "lantern_gpu_level_for", "lantern_gpu_plan_batch",
 ]
 
 # int fn(void *ctx, void *host_buf, const size_t *offsets, const size_t *counts, int world, int rank)
@@ -181,6 +182,8 @@ def lib() -> C.CDLL:
         "lantern_gpu_comm_allgatherv_device": (None, [vp, vp, C.POINTER(sz), C.POINTER(sz), vp, err]),
         "lantern_gpu_shard_range": (None, [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]),
         "lantern_gpu_add_sharded": (None, [vp, vp, vp, vp, sz, i32, err]),
+        "lantern_gpu_level_for": (i32, [u64, u64, u32]),
+        "lantern_gpu_plan_batch": (sz, [sz, i32, vp, sz, sz, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what the header declares
@@ -464,6 +467,15 @@ class GpuIndex:
     def load_buffer(self, data: bytes):
         buf = C.create_string_buffer(data, len(data))
         _call("usearch_load_buffer", self.h, C.cast(buf, C.c_void_p), len(data))
+
+
+def level_for(seed: int, slot: int, M: int) -> int:
+    return int(lib().lantern_gpu_level_for(seed, slot, M))
+
+
+def plan_batch(size: int, max_level: int, pending_levels, max_batch: int, min_ratio: int) -> int:
+    lv = np.ascontiguousarray(pending_levels, dtype=np.int32)
+    return int(lib().lantern_gpu_plan_batch(size, max_level, _ptr(lv), lv.size, max_batch, min_ratio))
 
 
 def shard_range(n: int, world: int, rank: int) -> tuple[int, int]:

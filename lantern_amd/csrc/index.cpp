@@ -863,6 +863,17 @@ uint64_t lantern_gpu_graph_checksum(usearch_index_t h, usearch_error_t *e)
     return hsh;
 }
 
+// the host-side rules a second builder (the test oracle, a CPU fallback on the reference side) must share to
+// reproduce a device build: the stateless level draw and the batch plan (host_util.hpp)
+int lantern_gpu_level_for(uint64_t seed, uint64_t slot, uint32_t connectivity) { return level_for(seed, slot, connectivity < 2 ? 2 : connectivity); }
+
+size_t lantern_gpu_plan_batch(size_t current_size, int max_level, const int *pending_levels, size_t pending, size_t max_batch,
+                              size_t min_ratio)
+{
+    if(!pending_levels) return 0;
+    return plan_batch(current_size, max_level, pending_levels, pending, max_batch ? max_batch : 1, min_ratio ? min_ratio : 1);
+}
+
 void lantern_gpu_flush(usearch_index_t h, usearch_error_t *e)
 {
     CLEAR(e);

@@ -75,3 +75,31 @@ def test_argument_validation_precedes_device_use(capi):
     o.metric_kind, o.pq = 3, True
     assert capi.lib().usearch_init(C.byref(o), None, C.byref(err)) is None
     assert b"product quantization" in err.value
+
+
+def test_level_draw_and_batch_plan_agree_with_the_oracle(capi):
+    """The builder's two host-side rules (host_util.hpp) against the oracle's restatement (oracle/hnsw.c: lo_level_for,
+    lo_plan_batch; level formula of lantern_hnsw/src/hnsw/insert.c:32-46): same level for every (seed, slot, M), same
+    batch boundaries for every state -- the precondition of the edge-for-edge build parity the GPU tests assert."""
+    import numpy as np
+
+    from oracle import binding as oracle
+
+    oracle.build()
+    rng = np.random.default_rng(0)
+    for M in (2, 3, 16, 48, 128):
+        seeds = rng.integers(0, 2**63, 40)
+        for seed in seeds[:4]:
+            lv = [capi.level_for(int(seed), s, M) for s in range(3000)]
+            assert lv == [oracle.level_for(int(seed), s, M) for s in range(3000)]
+        big = np.array([capi.level_for(42, s, M) for s in range(60000)])
+        assert abs((big >= 1).mean() - 1.0 / M) < 0.012  # P(level >= 1) = 1/M
+        assert big.max() < 40
+    for _ in range(300):
+        size = int(rng.integers(0, 200000))
+        max_level = int(rng.integers(0, 6))
+        pending = rng.integers(0, max_level + 2, int(rng.integers(1, 600))).astype(np.int32)
+        mb, mr = int(rng.integers(1, 9000)), int(rng.integers(1, 64))
+        got = capi.plan_batch(size, max_level, pending, mb, mr)
+        assert got == oracle.plan_batch(size, max_level, pending, mb, mr)
+        assert 1 <= got <= min(len(pending), mb)
