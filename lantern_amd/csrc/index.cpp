@@ -725,6 +725,8 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     if(hipMalloc((void **)&ix->d_totals, 8 * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&ix->d_tickets, kTicketRing * sizeof(uint32_t)) != hipSuccess ||
        hipMemset(ix->d_totals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        if(ix->d_totals) (void)hipFree(ix->d_totals);
+        if(ix->d_tickets) (void)hipFree(ix->d_tickets);
         delete ix;
         FAIL(e, "lantern_gpu: device allocation failed");
         return nullptr;
