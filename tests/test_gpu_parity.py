@@ -566,3 +566,44 @@ def test_visited_set_variants_give_identical_walks(capi, oracle, vis_slots, monk
     assert np.array_equal(lab.download((64, 10), np.uint64), o_lab) and np.array_equal(dist.download((64, 10), np.float32), o_dist)
     assert np.array_equal(D.download(64, np.uint64), o_D) and np.array_equal(E.download(64, np.uint64), o_E)
     assert o_D.max() > 300  # more visits than 3/4 of 256 slots: the spill path really ran
+
+
+# ------------------------------------------------------------------------------------------------
+# the committed fixture (tests/golden/oracle_regression.json): the device must reproduce, bit for bit, every case
+# whose summation order is the device's own (WAVE64 / WAVE64_F16 / integer metrics)
+# ------------------------------------------------------------------------------------------------
+def test_device_reproduces_the_committed_fixture(capi):
+    import hashlib
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import make_oracle_golden as gen
+
+    want = json.load(open(os.path.join(root, "tests", "golden", "oracle_regression.json")))["cases"]
+    ran = 0
+    for name, metric, n, d, M, efc, ef, k, mode, plan, storage in gen.CASES:
+        if mode == "SUM_SEQ" and metric != "hamming":
+            continue  # usearch's textbook order: compared within tolerance elsewhere, not bit for bit
+        rng = np.random.default_rng(int(hashlib.sha256(name.encode()).hexdigest()[:8], 16))
+        base, queries = gen.rows(rng, n, d, metric), gen.rows(rng, 16, d, metric)
+        if storage == "i8":  # the fixture quantised base * 0.4; the device quantises what it is given
+            base, queries = base * np.float32(0.4), queries * np.float32(0.4)
+        gpu = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=ef, seed=11, quantization=storage)
+        gpu.set_add_batch(*(plan if plan else (1, 1)))
+        gpu.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+        gpu.flush()
+        g = gpu.export_graph()
+        h = hashlib.sha256()
+        for key in ("levels", "nbr0", "upper_off", "upper_nbr"):
+            h.update(np.ascontiguousarray(g[key]).tobytes())
+        exp = want[name]["expect"]
+        assert h.hexdigest() == exp["graph_sha256"], name
+        assert (g["entry_slot"], g["max_level"]) == (exp["entry_slot"], exp["max_level"]), name
+        lab, dist, cnt = gpu.search_batch(queries, k)
+        assert (lab.astype(np.int64) - 1).tolist() == exp["slots"], name
+        assert [[f"{int(x):08x}" for x in row] for row in dist.view(np.uint32)] == exp["dist_bits"], name
+        ran += 1
+    assert ran == 6

@@ -238,3 +238,20 @@ def test_i8_quantisation_rule_and_integer_metrics(oracle):
     _, _, slots, _, _ = ix.search_batch(q, 10)
     truth, _ = oracle.bruteforce(base, q, 10, "l2sq", oracle.SUM_I8)
     assert oracle.recall_at_k(slots, truth) > 0.9
+
+
+def test_oracle_regression_fixture(oracle):
+    """The oracle itself is pinned: graphs, result lists, distance bits and D/E counters of seven seeded cases
+    (tests/golden/oracle_regression.json, made by scripts/make_oracle_golden.py) must not drift."""
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import make_oracle_golden as gen
+
+    want = json.load(open(os.path.join(root, "tests", "golden", "oracle_regression.json")))["cases"]
+    assert sorted(want) == sorted(c[0] for c in gen.CASES)
+    for c in gen.CASES:
+        assert gen.run_case(*c) == want[c[0]]["expect"], c[0]
