@@ -329,6 +329,38 @@ LANTERN_GPU_EXPORT uint64_t lantern_index_server_served(lantern_index_server_t *
 LANTERN_GPU_EXPORT void     lantern_index_server_stop(lantern_index_server_t *);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Scan-side service: ONE HBM-resident index serves the k-NN queries of    */
+/* many PostgreSQL backends, coalesced into batched launches.  A backend's ldb_amgettuple          */
+/* (scan.c:167-338) calls lantern_scan_client_search where it calls usearch_search_ef today; the   */
+/* server waits at most `max_wait_us` after the first queued query for company (at most            */
+/* `max_batch` queries per launch), runs one lantern_gpu_search_batch per distinct (k, ef) and     */
+/* routes the answers back.  Wire format: lantern_amd/csrc/scan_server.cpp.                         */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct lantern_scan_server lantern_scan_server_t;
+typedef struct lantern_scan_client lantern_scan_client_t;
+/* the batch search a server runs: nq queries of vec_bytes each -> labels/dists [nq][k], counts [nq]; 0 = ok,
+ * otherwise *err points at a message that outlives the call */
+typedef int (*lantern_batch_search_fn)(void *ctx, const void *queries, size_t nq, size_t vec_bytes, size_t k, size_t ef,
+                                       uint64_t *labels, float *distances, uint32_t *counts, const char **err);
+/* serve `index` (built, loaded or mirrored; it must outlive the server) on host:port (port 0 = ephemeral) */
+LANTERN_GPU_EXPORT lantern_scan_server_t *lantern_scan_server_start(usearch_index_t index, const char *host, int port,
+                                                                    size_t max_batch, unsigned max_wait_us, usearch_error_t *);
+/* the same front end over any batch search function (tests; a host that shards queries over several GPUs) */
+LANTERN_GPU_EXPORT lantern_scan_server_t *lantern_scan_server_start_fn(lantern_batch_search_fn, void *ctx, size_t vec_bytes,
+                                                                       const char *host, int port, size_t max_batch,
+                                                                       unsigned max_wait_us, usearch_error_t *);
+LANTERN_GPU_EXPORT int  lantern_scan_server_port(lantern_scan_server_t *);
+/* queries received, batches formed, search launches (one per distinct (k, ef) of a batch), largest batch so far */
+LANTERN_GPU_EXPORT void lantern_scan_server_stats(lantern_scan_server_t *, uint64_t *requests, uint64_t *batches,
+                                                  uint64_t *launches, uint64_t *largest_batch);
+LANTERN_GPU_EXPORT void lantern_scan_server_stop(lantern_scan_server_t *);
+/* client: one connection per backend, one query at a time; returns the number of results (<= k), ascending */
+LANTERN_GPU_EXPORT lantern_scan_client_t *lantern_scan_client_connect(const char *host, int port, usearch_error_t *);
+LANTERN_GPU_EXPORT size_t lantern_scan_client_search(lantern_scan_client_t *, const void *query, size_t query_bytes, size_t k,
+                                                     size_t ef, usearch_label_t *labels, float *distances, usearch_error_t *);
+LANTERN_GPU_EXPORT void   lantern_scan_client_close(lantern_scan_client_t *);
+
+/* ------------------------------------------------------------------------------------------ */
 /* SQL-callable distance functions' semantics (hnsw.c:296-405): dimension checks + messages     */
 /* ------------------------------------------------------------------------------------------ */
 /* l2sq_dist(real[], real[]) -> float4; error text hnsw.c:301-303 */

@@ -92,7 +92,13 @@ EXPORTS = [
     "lantern_gpu_comm_set_timeout", "lantern_gpu_comm_stats", "lantern_gpu_comm_allgatherv_host",
     "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded",
     "lantern_gpu_level_for", "lantern_gpu_plan_batch",
+    "lantern_scan_server_start", "lantern_scan_server_start_fn", "lantern_scan_server_port", "lantern_scan_server_stats",
+    "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_close",
 ]
+
+# int fn(void *ctx, const void *queries, size_t nq, size_t vec_bytes, size_t k, size_t ef, u64 *labels, f32 *dists, u32 *counts, const char **err)
+BATCH_SEARCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64),
+                              C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_char_p))
 
 # int fn(void *ctx, void *host_buf, const size_t *offsets, const size_t *counts, int world, int rank)
 ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int, C.c_int)
@@ -184,6 +190,14 @@ def lib() -> C.CDLL:
         "lantern_gpu_add_sharded": (None, [vp, vp, vp, vp, sz, i32, err]),
         "lantern_gpu_level_for": (i32, [u64, u64, u32]),
         "lantern_gpu_plan_batch": (sz, [sz, i32, vp, sz, sz, sz]),
+        "lantern_scan_server_start": (vp, [vp, C.c_char_p, i32, sz, C.c_uint, err]),
+        "lantern_scan_server_start_fn": (vp, [BATCH_SEARCH_FN, vp, sz, C.c_char_p, i32, sz, C.c_uint, err]),
+        "lantern_scan_server_port": (i32, [vp]),
+        "lantern_scan_server_stats": (None, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
+        "lantern_scan_server_stop": (None, [vp]),
+        "lantern_scan_client_connect": (vp, [C.c_char_p, i32, err]),
+        "lantern_scan_client_search": (sz, [vp, vp, sz, sz, sz, vp, vp, err]),
+        "lantern_scan_client_close": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what the header declares
@@ -609,6 +623,77 @@ class Scan:
     def __del__(self):
         try:
             self.end()
+        except Exception:
+            pass
+
+
+class ScanServer:
+    """lantern_scan_server_*: one HBM-resident index serving many backends' queries in batched launches."""
+
+    def __init__(self, index=None, host="127.0.0.1", port=0, max_batch=256, max_wait_us=200, batch_fn=None, vec_bytes=0):
+        """index: a GpuIndex (the server runs lantern_gpu_search_batch on it), or batch_fn(queries u8[nq, vec_bytes], k, ef)
+        -> (labels u64[nq, k], dists f32[nq, k], counts u32[nq]) for tests / custom back ends."""
+        self._keep = None
+        self.index = index
+        if batch_fn is not None:
+            def tramp(ctx, queries, nq, vb, k, ef, labels, dists, counts, errp):
+                try:
+                    q = np.ctypeslib.as_array(C.cast(queries, C.POINTER(C.c_uint8)), shape=(nq, vb))
+                    lab, dst, cnt = batch_fn(q, int(k), int(ef))
+                    np.ctypeslib.as_array(labels, shape=(nq, k))[:] = lab
+                    np.ctypeslib.as_array(dists, shape=(nq, k))[:] = dst
+                    np.ctypeslib.as_array(counts, shape=(nq,))[:] = cnt
+                    return 0
+                except Exception as ex:  # noqa: BLE001 -- becomes the error frame every query of the launch gets
+                    self._last_error = C.c_char_p(str(ex).encode())
+                    errp[0] = self._last_error
+                    return 1
+
+            self._keep = BATCH_SEARCH_FN(tramp)
+            self.s = _call("lantern_scan_server_start_fn", self._keep, None, vec_bytes, host.encode(), port, max_batch, max_wait_us)
+        else:
+            self.s = _call("lantern_scan_server_start", index.h, host.encode(), port, max_batch, max_wait_us)
+        self.host = host
+        self.port = int(lib().lantern_scan_server_port(self.s))
+
+    def stats(self):
+        v = [C.c_uint64() for _ in range(4)]
+        lib().lantern_scan_server_stats(self.s, *[C.byref(x) for x in v])
+        return dict(zip(("requests", "batches", "launches", "largest_batch"), (int(x.value) for x in v)))
+
+    def stop(self):
+        if self.s:
+            lib().lantern_scan_server_stop(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.stop()
+        except Exception:
+            pass
+
+
+class ScanClient:
+    """lantern_scan_client_*: what a backend's ldb_amgettuple calls where it calls usearch_search_ef today."""
+
+    def __init__(self, host, port):
+        self.c = _call("lantern_scan_client_connect", host.encode(), port)
+
+    def search(self, query: np.ndarray, k: int, ef: int = 0):
+        q = np.ascontiguousarray(query)
+        labels = np.zeros(k, dtype=np.uint64)
+        dists = np.zeros(k, dtype=np.float32)
+        n = _call("lantern_scan_client_search", self.c, _ptr(q), q.nbytes, k, ef, _ptr(labels), _ptr(dists))
+        return labels[:n], dists[:n]
+
+    def close(self):
+        if self.c:
+            lib().lantern_scan_client_close(self.c)
+            self.c = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -1,0 +1,176 @@
+"""The scan-side service (lantern_amd/csrc/scan_server.cpp): many clients, one query each at a time, coalesced into
+batched search launches.  CPU tests drive the REAL server, sockets, dispatcher and client code over an injected batch
+function (the server's pluggable back end), so batching, routing, grouping by (k, ef), error frames and shutdown are
+covered without a device; the -m gpu test puts a device index behind it and compares with direct batch search."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from lantern_amd import build, capi
+
+    build.build()
+    capi.lib()
+    return capi
+
+
+def fake_backend(calls):
+    """labels[i][j] = 1000 * (first float of query i) + j ; dists[i][j] = j + ef / 1000 ; records every launch."""
+    def fn(queries, k, ef):
+        nq = queries.shape[0]
+        first = queries.view(np.float32)[:, 0]
+        calls.append((nq, k, ef))
+        lab = (first[:, None] * 1000 + np.arange(k)[None, :]).astype(np.uint64)
+        dst = (np.arange(k, dtype=np.float32)[None, :] + np.float32(ef) / 1000).repeat(nq, 0)
+        return lab, dst, np.full(nq, k, dtype=np.uint32)
+    return fn
+
+
+def test_many_clients_are_batched_and_answers_routed(capi):
+    calls = []
+    srv = capi.ScanServer(batch_fn=fake_backend(calls), vec_bytes=16, max_batch=64, max_wait_us=20000)
+    nthreads, per = 24, 12
+    got, errs = {}, []
+    start = threading.Barrier(nthreads)
+
+    def backend_session(t):
+        try:
+            c = capi.ScanClient(srv.host, srv.port)
+            start.wait()
+            for i in range(per):
+                ident = t * 100 + i
+                q = np.array([ident, 0, 0, 0], dtype=np.float32)
+                k = 5 if t % 2 == 0 else 8  # two (k, ef) classes in flight at once
+                lab, dst = c.search(q, k, ef=40 if t % 2 == 0 else 0)
+                got[ident] = (lab.copy(), dst.copy(), k)
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=backend_session, args=(t,)) for t in range(nthreads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    st = srv.stats()
+    srv.stop()
+    assert not errs, errs
+    assert len(got) == nthreads * per
+    for ident, (lab, dst, k) in got.items():  # every client got ITS answer, in order, for ITS k and ef
+        assert lab.tolist() == [ident * 1000 + j for j in range(k)]
+        assert np.allclose(dst, np.arange(k) + (0.04 if k == 5 else 0.0))
+    assert st["requests"] == nthreads * per
+    assert st["batches"] < st["requests"] and st["largest_batch"] > 1, st  # coalescing happened
+    assert st["launches"] == len(calls) and sum(c[0] for c in calls) == st["requests"]
+    assert {(c[1], c[2]) for c in calls} == {(5, 40), (8, 0)}  # one launch per distinct (k, ef), never mixed
+
+
+def test_a_lone_query_is_not_held_longer_than_the_window(capi):
+    srv = capi.ScanServer(batch_fn=fake_backend([]), vec_bytes=8, max_batch=64, max_wait_us=3000)
+    c = capi.ScanClient(srv.host, srv.port)
+    c.search(np.array([1, 0], dtype=np.float32), 3)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        c.search(np.array([2, 0], dtype=np.float32), 3)
+    per = (time.perf_counter() - t0) / 20
+    c.close()
+    srv.stop()
+    assert per < 0.05, per  # the 3 ms window plus the round trip, not a stall
+
+
+def test_full_batch_leaves_before_the_window_closes(capi):
+    calls = []
+    srv = capi.ScanServer(batch_fn=fake_backend(calls), vec_bytes=8, max_batch=4, max_wait_us=2_000_000)  # a 2 s window
+    out, start = [], threading.Barrier(4)
+
+    def one(t):
+        c = capi.ScanClient(srv.host, srv.port)
+        start.wait()
+        out.append(c.search(np.array([t, 0], dtype=np.float32), 2)[0][0])
+        c.close()
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=one, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    took = time.perf_counter() - t0
+    srv.stop()
+    assert sorted(out) == [0, 1000, 2000, 3000] and took < 1.5, (out, took)  # max_batch reached: no need to wait 2 s
+
+
+def test_errors_come_back_as_messages_and_the_connection_survives(capi):
+    def failing(queries, k, ef):
+        if k == 7:
+            raise RuntimeError("lantern_gpu: ef/k exceed the LDS budget")
+        return fake_backend([])(queries, k, ef)
+
+    srv = capi.ScanServer(batch_fn=failing, vec_bytes=8, max_wait_us=100)
+    c = capi.ScanClient(srv.host, srv.port)
+    with pytest.raises(capi.LanternGpuError, match="exceed the LDS budget"):
+        c.search(np.array([1, 0], dtype=np.float32), 7)
+    with pytest.raises(capi.LanternGpuError, match="query of 12 bytes, the index takes 8"):
+        c.search(np.array([1, 0, 0], dtype=np.float32), 3)
+    lab, _ = c.search(np.array([5, 0], dtype=np.float32), 3)  # same connection, still in step
+    assert lab.tolist() == [5000, 5001, 5002]
+    with pytest.raises(capi.LanternGpuError, match="bad scan client arguments"):
+        c.search(np.array([5, 0], dtype=np.float32), 0)
+    c.close()
+    srv.stop()
+
+
+def test_stop_with_connected_clients_does_not_hang(capi):
+    srv = capi.ScanServer(batch_fn=fake_backend([]), vec_bytes=8, max_wait_us=100)
+    clients = [capi.ScanClient(srv.host, srv.port) for _ in range(5)]
+    clients[0].search(np.array([1, 0], dtype=np.float32), 2)
+    t0 = time.perf_counter()
+    srv.stop()
+    assert time.perf_counter() - t0 < 5
+    with pytest.raises(capi.LanternGpuError, match="went away|not connected"):
+        clients[1].search(np.array([1, 0], dtype=np.float32), 2)
+    [c.close() for c in clients]
+    with pytest.raises(capi.LanternGpuError, match="cannot connect"):
+        capi.ScanClient(srv.host, srv.port)
+
+
+def test_server_on_an_index_needs_a_device(capi):
+    if capi.device_count() > 0:
+        pytest.skip("a device is present")
+    err = __import__("ctypes").c_char_p()
+    assert capi.lib().lantern_scan_server_start(None, b"127.0.0.1", 0, 16, 100, __import__("ctypes").byref(err)) is None
+    assert b"null index handle" in err.value
+
+
+@pytest.mark.gpu
+def test_concurrent_backends_get_exactly_the_direct_search_results(capi):
+    n, d, k = 20000, 64, 10
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    ix = capi.GpuIndex("l2sq", d, M=16, ef_construction=64, ef=48, seed=3)
+    ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    ix.flush()
+    queries = rng.standard_normal((16 * 20, d), dtype=np.float32)
+    want_lab, want_dst, _ = ix.search_batch(queries, k)
+    srv = capi.ScanServer(index=ix, max_batch=64, max_wait_us=300)
+    got, errs = {}, []
+
+    def session(t):
+        try:
+            c = capi.ScanClient(srv.host, srv.port)
+            for i in range(20):
+                qi = t * 20 + i
+                got[qi] = c.search(queries[qi], k)
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=session, args=(t,)) for t in range(16)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    st = srv.stats()
+    srv.stop()
+    assert not errs, errs
+    for qi in range(queries.shape[0]):
+        assert np.array_equal(got[qi][0], want_lab[qi]) and np.array_equal(got[qi][1], want_dst[qi])
+    assert st["requests"] == 320 and st["batches"] < 320 and st["largest_batch"] > 1, st
