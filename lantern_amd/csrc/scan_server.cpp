@@ -268,6 +268,8 @@ void accept_loop(lantern_scan_server *s)
         if(fd < 0) continue;
         int one = 1;
         ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        timeval never{ 0, 0 };  // Linux hands the listener's receive timeout down to accepted sockets: a backend may idle for hours
+        ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &never, sizeof(never));
         std::lock_guard<std::mutex> g(s->mu);
         if(s->stop) { ::close(fd); break; }
         // reap the readers of connections that have ended (a backend connects once per session, but sessions come and go)

@@ -134,6 +134,18 @@ def test_stop_with_connected_clients_does_not_hang(capi):
         capi.ScanClient(srv.host, srv.port)
 
 
+def test_an_idle_connection_stays_open(capi):
+    # a backend connects once per session and may sit idle between queries (the listener's accept timeout must not leak
+    # into the connection)
+    srv = capi.ScanServer(batch_fn=fake_backend([]), vec_bytes=8, max_wait_us=100)
+    c = capi.ScanClient(srv.host, srv.port)
+    assert c.search(np.array([3, 0], dtype=np.float32), 2)[0].tolist() == [3000, 3001]
+    time.sleep(0.6)
+    assert c.search(np.array([4, 0], dtype=np.float32), 2)[0].tolist() == [4000, 4001]
+    c.close()
+    srv.stop()
+
+
 def test_server_on_an_index_needs_a_device(capi):
     if capi.device_count() > 0:
         pytest.skip("a device is present")
