@@ -63,14 +63,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    # the standalone server binary: `lantern_amd/lib/lantern-index-server --host H --port P --tmp-dir D`
-    tool_src = os.path.join(HERE, "tools", "lantern_index_server.cpp")
-    tool = os.path.join(OUT_DIR, "lantern-index-server")
-    if os.path.exists(tool_src) and (force or _stale(tool, [tool_src, LIB])):
-        cmd = [hipcc, "-O2", "-std=c++17", tool_src, "-o", tool, "-L" + OUT_DIR, "-llantern_gpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    # the standalone binaries: `lantern_amd/lib/lantern-index-server --host H --port P --tmp-dir D` (external indexing
+    # server) and `lantern_amd/lib/lantern-scan-server --index FILE --metric M --dim D --m M` (scan-side service)
+    for src_name, bin_name in (("lantern_index_server.cpp", "lantern-index-server"), ("lantern_scan_server.cpp", "lantern-scan-server")):
+        tool_src = os.path.join(HERE, "tools", src_name)
+        tool = os.path.join(OUT_DIR, bin_name)
+        if os.path.exists(tool_src) and (force or _stale(tool, [tool_src, LIB])):
+            cmd = [hipcc, "-O2", "-std=c++17", tool_src, "-o", tool, "-L" + OUT_DIR, "-llantern_gpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return LIB
 
 

@@ -186,3 +186,18 @@ def test_concurrent_backends_get_exactly_the_direct_search_results(capi):
     for qi in range(queries.shape[0]):
         assert np.array_equal(got[qi][0], want_lab[qi]) and np.array_equal(got[qi][1], want_dst[qi])
     assert st["requests"] == 320 and st["batches"] < 320 and st["largest_batch"] > 1, st
+
+
+def test_standalone_binary_fails_loudly_without_a_device_or_arguments(capi):
+    import os
+    import subprocess
+
+    from lantern_amd import build
+
+    exe = os.path.join(os.path.dirname(build.LIB), "lantern-scan-server")
+    assert os.path.exists(exe)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 2 and "--index and --dim are required" in p.stderr
+    if capi.device_count() == 0:
+        p = subprocess.run([exe, "--index", "/nonexistent", "--dim", "8"], capture_output=True, text=True, timeout=60)
+        assert p.returncode == 1 and "no HIP device" in p.stderr
