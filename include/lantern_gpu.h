@@ -113,12 +113,31 @@ LANTERN_GPU_EXPORT size_t usearch_dimensions(usearch_index_t, usearch_error_t *)
  * device (see lantern_gpu_set_add_batch); any reader (search/size/save) flushes first. */
 LANTERN_GPU_EXPORT void usearch_add(usearch_index_t, usearch_label_t, const void *vector, usearch_scalar_kind_t,
                                     usearch_error_t *);
+/* insert.c:209 (ldb_aminsert): one sequential insertion at the caller-drawn level (insert.c:32-46) of a node whose tape
+ * the caller allocated inside a PostgreSQL page (`node_tape`, headed by usearch_init_node, usearch_storage.cpp:34-44)
+ * at 48-bit page slot `slot`.  The node is linked into the HBM mirror; its own lists and stored vector are written into
+ * `node_tape`, the re-written lists of the nodes it linked to into their tapes through init_options.retriever_mut
+ * (external_index.c:673-697).  On an index that was not attached with usearch_view_mem_lazy the slots written are the
+ * sequential ids of the file format. */
+LANTERN_GPU_EXPORT void usearch_add_external(usearch_index_t, usearch_label_t, const void *vector, void *node_tape,
+                                             usearch_scalar_kind_t, int16_t level, uint64_t slot, usearch_error_t *);
 /* scan.c:220-228,273-281.  ef == 0 -> index default.  streaming == true returns the NEXT k results of
  * the same query: the index remembers what it handed out since the last non-streaming call, searches for
  * that many + k, and returns the first k that were not returned before (never a row twice). */
 LANTERN_GPU_EXPORT size_t usearch_search_ef(usearch_index_t, const void *query, usearch_scalar_kind_t, size_t k,
                                             size_t ef, bool streaming, usearch_label_t *labels, float *distances,
                                             usearch_error_t *);
+/* The per-scan half of the streaming contract.  In the reference every scan owns its own usearch handle (scan.c:99),
+ * so usearch_search_ef's "what was handed out since the last non-streaming call" is per scan there.  When ONE resident
+ * index serves many scans, each scan opens a cursor and searches through it; usearch_search_ef(h, ...) is the same call
+ * on the index's built-in cursor.  Cursors must be closed before usearch_free. */
+typedef struct lantern_gpu_cursor lantern_gpu_cursor_t;
+LANTERN_GPU_EXPORT lantern_gpu_cursor_t *lantern_gpu_cursor_open(usearch_index_t, usearch_error_t *);
+LANTERN_GPU_EXPORT size_t lantern_gpu_cursor_search(lantern_gpu_cursor_t *, const void *query, usearch_scalar_kind_t, size_t k,
+                                                    size_t ef, bool streaming, usearch_label_t *labels, float *distances,
+                                                    usearch_error_t *);
+LANTERN_GPU_EXPORT size_t lantern_gpu_cursor_seen(lantern_gpu_cursor_t *); /* rows handed out since the last non-streaming call */
+LANTERN_GPU_EXPORT void   lantern_gpu_cursor_close(lantern_gpu_cursor_t *);
 /* hnsw.c:317,326,340; product_quantization.c:102,185.  One pair, evaluated on the device. */
 LANTERN_GPU_EXPORT float usearch_distance(const void *a, const void *b, usearch_scalar_kind_t, size_t dims,
                                           usearch_metric_kind_t, usearch_error_t *);
@@ -137,7 +156,8 @@ LANTERN_GPU_EXPORT size_t usearch_serialized_length(usearch_index_t, usearch_err
  * header's entry slot and mirrored into HBM; neighbour slots are the 6-byte ItemPointers of
  * external_index.c:380-409.  Searches then run on the mirror and return the nodes' labels. */
 LANTERN_GPU_EXPORT void usearch_view_mem_lazy(usearch_index_t, char *header136, usearch_error_t *);
-/* insert.c:214: refresh size / max_level in the header copy (the entry slot stays the caller's business) */
+/* insert.c:214: refresh size / max_level / entry slot in the header copy (the entry slot in the form the index was
+ * attached in: a 48-bit page slot after usearch_view_mem_lazy, a sequential id otherwise) */
 LANTERN_GPU_EXPORT void usearch_update_header(usearch_index_t, char *header136, usearch_error_t *);
 /* external_index.c:411,417 */
 LANTERN_GPU_EXPORT uint64_t usearch_header_get_entry_slot(char *header136);
@@ -170,7 +190,7 @@ LANTERN_GPU_EXPORT size_t lantern_gpu_plan_batch(size_t current_size, int max_le
                                                  size_t max_batch, size_t min_ratio);
 /* apply all buffered inserts now */
 LANTERN_GPU_EXPORT void lantern_gpu_flush(usearch_index_t, usearch_error_t *);
-/* usearch_add_external-style insert with a caller-drawn level (insert.c:32-46,209) */
+/* usearch_add with a caller-drawn level (insert.c:32-46); usearch_add_external is this plus the write-back to the pages */
 LANTERN_GPU_EXPORT void lantern_gpu_add_with_level(usearch_index_t, usearch_label_t, const void *vector,
                                                    usearch_scalar_kind_t, int level, usearch_error_t *);
 
@@ -302,6 +322,11 @@ LANTERN_GPU_EXPORT void lantern_gpu_add_sharded(usearch_index_t, lantern_gpu_com
 typedef struct lantern_scan lantern_scan_t;
 /* init_k = GUC lantern_hnsw.init_k (options.h:44, default 10); ef = GUC lantern_hnsw.ef or 0 */
 LANTERN_GPU_EXPORT lantern_scan_t *lantern_scan_begin(usearch_index_t, int init_k, int ef, usearch_error_t *);
+/* the same scan driven through a scan-service connection (declared below) instead of a local index: what a PostgreSQL
+ * backend runs when the mirror lives in the service process.  query_bytes = the size of one query vector. */
+struct lantern_scan_client;
+LANTERN_GPU_EXPORT lantern_scan_t *lantern_scan_begin_client(struct lantern_scan_client *, size_t query_bytes, int init_k, int ef,
+                                                             usearch_error_t *);
 /* ldb_amrescan: (re)arm the scan with an ORDER BY key; the vector is copied */
 LANTERN_GPU_EXPORT void lantern_scan_rescan(lantern_scan_t *, const void *query, usearch_scalar_kind_t,
                                             usearch_error_t *);
@@ -358,6 +383,10 @@ LANTERN_GPU_EXPORT void lantern_scan_server_stop(lantern_scan_server_t *);
 LANTERN_GPU_EXPORT lantern_scan_client_t *lantern_scan_client_connect(const char *host, int port, usearch_error_t *);
 LANTERN_GPU_EXPORT size_t lantern_scan_client_search(lantern_scan_client_t *, const void *query, size_t query_bytes, size_t k,
                                                      size_t ef, usearch_label_t *labels, float *distances, usearch_error_t *);
+/* the streaming continuation (scan.c:273-281) through the service: the NEXT k rows of the scan this connection began with
+ * its last lantern_scan_client_search; the state is the connection's, so concurrent backends never disturb each other */
+LANTERN_GPU_EXPORT size_t lantern_scan_client_search_next(lantern_scan_client_t *, const void *query, size_t query_bytes, size_t k,
+                                                          size_t ef, usearch_label_t *labels, float *distances, usearch_error_t *);
 LANTERN_GPU_EXPORT void   lantern_scan_client_close(lantern_scan_client_t *);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -75,7 +75,8 @@ class Counters(C.Structure):
 
 EXPORTS = [
     "usearch_init", "usearch_free", "usearch_reserve", "usearch_size", "usearch_capacity", "usearch_dimensions",
-    "usearch_add", "usearch_search_ef", "usearch_distance", "usearch_index_metadata", "usearch_save",
+    "usearch_add", "usearch_add_external", "usearch_search_ef", "lantern_gpu_cursor_open", "lantern_gpu_cursor_search",
+    "lantern_gpu_cursor_seen", "lantern_gpu_cursor_close", "usearch_distance", "usearch_index_metadata", "usearch_save",
     "usearch_save_buffer", "usearch_load", "usearch_load_buffer", "usearch_serialized_length",
     "usearch_header_get_entry_slot", "usearch_header_set_entry_slot", "usearch_view_mem_lazy", "usearch_update_header",
     "lantern_gpu_version", "lantern_gpu_device_count",
@@ -93,7 +94,8 @@ EXPORTS = [
     "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded",
     "lantern_gpu_level_for", "lantern_gpu_plan_batch",
     "lantern_scan_server_start", "lantern_scan_server_start_fn", "lantern_scan_server_port", "lantern_scan_server_stats",
-    "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_close",
+    "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_search_next",
+    "lantern_scan_client_close", "lantern_scan_begin_client",
 ]
 
 # int fn(void *ctx, const void *queries, size_t nq, size_t vec_bytes, size_t k, size_t ef, u64 *labels, f32 *dists, u32 *counts, const char **err)
@@ -131,7 +133,12 @@ def lib() -> C.CDLL:
         "usearch_capacity": (sz, [vp, err]),
         "usearch_dimensions": (sz, [vp, err]),
         "usearch_add": (None, [vp, u64, vp, i32, err]),
+        "usearch_add_external": (None, [vp, u64, vp, vp, i32, C.c_int16, u64, err]),
         "usearch_search_ef": (sz, [vp, vp, i32, sz, sz, C.c_bool, vp, vp, err]),
+        "lantern_gpu_cursor_open": (vp, [vp, err]),
+        "lantern_gpu_cursor_search": (sz, [vp, vp, i32, sz, sz, C.c_bool, vp, vp, err]),
+        "lantern_gpu_cursor_seen": (sz, [vp]),
+        "lantern_gpu_cursor_close": (None, [vp]),
         "usearch_distance": (f32, [vp, vp, i32, sz, i32, err]),
         "usearch_index_metadata": (Metadata, [vp, err]),
         "usearch_save": (None, [vp, C.c_char_p, err]),
@@ -197,7 +204,9 @@ def lib() -> C.CDLL:
         "lantern_scan_server_stop": (None, [vp]),
         "lantern_scan_client_connect": (vp, [C.c_char_p, i32, err]),
         "lantern_scan_client_search": (sz, [vp, vp, sz, sz, sz, vp, vp, err]),
+        "lantern_scan_client_search_next": (sz, [vp, vp, sz, sz, sz, vp, vp, err]),
         "lantern_scan_client_close": (None, [vp]),
+        "lantern_scan_begin_client": (vp, [vp, sz, i32, i32, err]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what the header declares
@@ -290,7 +299,7 @@ def hamming_dist(a, b) -> int:
 class GpuIndex:
     """usearch_index_t over the C ABI.  `dims` = f32 scalars, or u32 WORDS for hamming."""
 
-    def __init__(self, metric, dims, M=16, ef_construction=128, ef=64, seed=42, retriever=None, quantization="f32"):
+    def __init__(self, metric, dims, M=16, ef_construction=128, ef=64, seed=42, retriever=None, quantization="f32", retriever_mut=None):
         """retriever: optional Python callable slot(int) -> address(int) of the node tape (the
         ldb_wal_index_node_retriever contract, external_index.c:613-671), used by view_mem_lazy().
         quantization: "f32", "f16" or "i8" storage (reloption quant_bits 32 / 16 / 8, options.c:137-158); vectors
@@ -311,6 +320,10 @@ class GpuIndex:
             self._retriever_cb = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)(lambda ctx, slot: retriever(int(slot)))
             o.retriever = C.cast(self._retriever_cb, C.c_void_p)
             o.retriever_mut = o.retriever
+        self._retriever_mut_cb = None
+        if retriever_mut is not None:  # external_index.c:673-697: the same lookup, marking the buffer dirty
+            self._retriever_mut_cb = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)(lambda ctx, slot: retriever_mut(int(slot)))
+            o.retriever_mut = C.cast(self._retriever_mut_cb, C.c_void_p)
         self.h = None
         self.h = _call("usearch_init", C.byref(o), None)
         _call("lantern_gpu_set_seed", self.h, seed)
@@ -380,6 +393,20 @@ class GpuIndex:
         dists = np.zeros(k, dtype=np.float32)
         n = _call("usearch_search_ef", self.h, _ptr(q), _kind(self.metric), k, ef, bool(streaming), _ptr(labels), _ptr(dists))
         return labels[:n], dists[:n]
+
+    def add_external(self, label, vec, node_tape, level, slot):
+        """usearch_add_external (insert.c:209): node_tape = address (int) of the new node's tape, slot = its 48-bit page slot."""
+        v = _rows(vec, self.metric)[0]
+        _call("usearch_add_external", self.h, int(label), _ptr(v), C.c_void_p(node_tape), _kind(self.metric), int(level), int(slot))
+
+    def update_header(self, header: bytes) -> bytes:
+        """usearch_update_header (insert.c:214): returns the refreshed 136 bytes."""
+        buf = C.create_string_buffer(bytes(header), USEARCH_HEADER_SIZE)
+        _call("usearch_update_header", self.h, C.cast(buf, C.c_void_p))
+        return buf.raw[:USEARCH_HEADER_SIZE]
+
+    def cursor(self) -> "Cursor":
+        return Cursor(self)
 
     def search_batch(self, queries, k, ef=0):
         Q = _rows(queries, self.metric)
@@ -481,6 +508,41 @@ class GpuIndex:
     def load_buffer(self, data: bytes):
         buf = C.create_string_buffer(data, len(data))
         _call("usearch_load_buffer", self.h, C.cast(buf, C.c_void_p), len(data))
+
+
+class Cursor:
+    """lantern_gpu_cursor_*: one scan's share of usearch_search_ef's streaming contract on a shared index."""
+
+    def __init__(self, index: GpuIndex):
+        self.index = index
+        self.c = _call("lantern_gpu_cursor_open", index.h)
+
+    def search(self, query, k, ef=0, streaming=False):
+        q = _rows(query, self.index.metric)[0]
+        labels = np.zeros(k, dtype=np.uint64)
+        dists = np.zeros(k, dtype=np.float32)
+        n = _call("lantern_gpu_cursor_search", self.c, _ptr(q), _kind(self.index.metric), k, ef, bool(streaming), _ptr(labels), _ptr(dists))
+        return labels[:n], dists[:n]
+
+    @property
+    def seen(self):
+        return int(lib().lantern_gpu_cursor_seen(self.c))
+
+    def close(self):
+        if self.c:
+            lib().lantern_gpu_cursor_close(self.c)
+            self.c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def header_entry_slot(header: bytes) -> int:
+    buf = C.create_string_buffer(bytes(header), USEARCH_HEADER_SIZE)
+    return int(lib().usearch_header_get_entry_slot(C.cast(buf, C.c_void_p)))
 
 
 def level_for(seed: int, slot: int, M: int) -> int:
@@ -588,16 +650,23 @@ class Comm:
 class Scan:
     """lantern_scan_*: the amgettuple paging shim (scan.c:24-338)."""
 
-    def __init__(self, index: GpuIndex, init_k=10, ef=0):
-        self.index = index
-        self.s = _call("lantern_scan_begin", index.h, init_k, ef)
+    def __init__(self, index: GpuIndex = None, init_k=10, ef=0, client: "ScanClient" = None, metric=None, dims=None):
+        """A scan on a local index, or -- client=ScanClient, metric=, dims= -- through the scan-side service."""
+        self.index, self.client = index, client
+        if client is not None:
+            self.metric, self.dims = METRICS.get(metric, metric), dims
+            qbytes = dims * 4  # f32 scalars, or u32 words for hamming
+            self.s = _call("lantern_scan_begin_client", client.c, qbytes, init_k, ef)
+        else:
+            self.metric, self.dims = index.metric, index.dims
+            self.s = _call("lantern_scan_begin", index.h, init_k, ef)
 
     def rescan(self, query):
-        q = _rows(query, self.index.metric)[0]
-        if q.size != self.index.dims:
-            kind = "int" if self.index.metric == METRIC_HAMMING else "real"
-            raise LanternGpuError(f"Expected {kind} array with dimension {self.index.dims}, got {q.size}")
-        _call("lantern_scan_rescan", self.s, _ptr(q), _kind(self.index.metric))
+        q = _rows(query, self.metric)[0]
+        if q.size != self.dims:
+            kind = "int" if self.metric == METRIC_HAMMING else "real"
+            raise LanternGpuError(f"Expected {kind} array with dimension {self.dims}, got {q.size}")
+        _call("lantern_scan_rescan", self.s, _ptr(q), _kind(self.metric))
 
     def gettuple(self):
         label = C.c_uint64()
@@ -684,6 +753,14 @@ class ScanClient:
         labels = np.zeros(k, dtype=np.uint64)
         dists = np.zeros(k, dtype=np.float32)
         n = _call("lantern_scan_client_search", self.c, _ptr(q), q.nbytes, k, ef, _ptr(labels), _ptr(dists))
+        return labels[:n], dists[:n]
+
+    def search_next(self, query: np.ndarray, k: int, ef: int = 0):
+        """The next k rows of the scan this connection began with search() (same query)."""
+        q = np.ascontiguousarray(query)
+        labels = np.zeros(k, dtype=np.uint64)
+        dists = np.zeros(k, dtype=np.float32)
+        n = _call("lantern_scan_client_search_next", self.c, _ptr(q), q.nbytes, k, ef, _ptr(labels), _ptr(dists))
         return labels[:n], dists[:n]
 
     def close(self):

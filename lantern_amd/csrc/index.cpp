@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 #include "comm.hpp"
 #include "host_util.hpp"
@@ -184,6 +185,24 @@ static uint32_t *next_ticket(Index *ix, size_t work, int grid, hipStream_t strea
     return t;
 }
 
+// Launches that use the index's shared scratch (the per-workgroup visited bitmaps, indexed by blockIdx only) are
+// serialised ACROSS streams: lantern_gpu_search_batch_device returns as soon as its kernel is queued on the caller's
+// stream, and the index mutex is released with the kernel still running, so a launch on a different stream could
+// otherwise overlap it and share its bitmaps.  Same-stream launches are ordered by the stream itself.
+bool order_launch(Index *ix, hipStream_t stream)
+{
+    if(ix->launch_pending && ix->launch_stream != stream) HIPCHK(ix, hipStreamWaitEvent(stream, ix->launch_done, 0));
+    return true;
+}
+bool record_launch(Index *ix, hipStream_t stream)
+{
+    if(!ix->launch_done) HIPCHK(ix, hipEventCreateWithFlags(&ix->launch_done, hipEventDisableTiming));
+    HIPCHK(ix, hipEventRecord(ix->launch_done, stream));
+    ix->launch_stream = stream;
+    ix->launch_pending = true;
+    return true;
+}
+
 // Resident workgroups of a walk kernel.  k_search is compiled for six waves per SIMD (<= 80 VGPRs:
 // __launch_bounds__(512, 6)) and its LDS is sized for six workgroups per CU, i.e. 24 waves per CU; k_insert (wider
 // lists, a larger visited set) runs at five.  LANTERN_GPU_WAVES_PER_CU overrides (tuning).
@@ -279,6 +298,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
 
     const int grid = search_grid(ix, b_hi - b_lo, ix->insert_waves, 20);
     if(!ensure_bitmaps(ix, (size_t)grid)) return false;
+    if(!order_launch(ix, ix->stream)) return false;  // a search may still be running on a caller's stream
     auto link_at = [&](size_t i) { return i < b ? (size_t)link_off[ i ] : total_links; };
 
     InsertArgs ia;
@@ -304,6 +324,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     ia.ticket = next_ticket(ix, b_hi - b_lo, grid, ix->stream);
     if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
     HIPCHK(ix, launch_insert(ix->mcode, ia, ix->insert_waves, grid, ix->stream));
+    if(!record_launch(ix, ix->stream)) return false;
 
     ConnectArgs ca;
     ca.view = ia.view;
@@ -612,9 +633,65 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.vis_slots = vis_slots;
     a.totals = ix->d_totals;
     a.ticket = next_ticket(ix, nq, grid, stream);
+    if(!order_launch(ix, stream)) return false;
     HIPCHK(ix, launch_search(ix->mcode, a, waves, grid, stream));
+    if(!record_launch(ix, stream)) return false;
     ix->c_search_queries += nq;
     return true;
+}
+
+// One usearch_search_ef (scan.c:220-228, :273-281) on behalf of one scan.  The query row and the answer live in ONE
+// pinned, device-mapped block: the kernel reads the row over the host link and writes labels | distances | slots |
+// count straight back, so the call is one launch + one stream synchronisation (no H2D / D2H copy commands, whose
+// queueing latency is of the order of the walk itself for a lone query).
+size_t search_one_locked(Index *ix, Cursor *cur, const void *query, int kind, size_t k, size_t ef, bool streaming, uint64_t *labels,
+                         float *distances)
+{
+    if(!streaming) cur->seen.clear();
+    if(ix->n == 0 || k == 0) return 0;
+    const size_t want = std::min(cur->seen.size() + k, ix->n);  // enough to find k unseen ones
+    const size_t row = (size_t)ix->chunks * 16;
+    const size_t need = row + want * 16 + 16;
+    if(ix->h_single_bytes < need) {
+        if(ix->h_single) (void)hipHostFree(ix->h_single);
+        ix->h_single = nullptr;
+        ix->h_single_bytes = 0;
+        const size_t cap = need * 2 + 4096;
+        if(hipHostMalloc((void **)&ix->h_single, cap, hipHostMallocMapped) != hipSuccess) {
+            set_err(ix, "lantern_gpu: cannot allocate the pinned single-query block");
+            return 0;
+        }
+        ix->h_single_bytes = cap;
+    }
+    char *dev = nullptr;
+    if(hipHostGetDevicePointer((void **)&dev, ix->h_single, 0) != hipSuccess) { set_err(ix, "lantern_gpu: the pinned block is not device-mapped"); return 0; }
+    pad_row(ix, query, kind, (uint32_t *)ix->h_single);
+    uint64_t *d_lab = (uint64_t *)(dev + row);
+    float    *d_dist = (float *)(dev + row + want * 8);
+    uint32_t *d_slot = (uint32_t *)(dev + row + want * 12);
+    uint32_t *d_cnt = (uint32_t *)(dev + row + want * 16);
+    // one query: spend a whole 8-wave workgroup on it (latency-bound path)
+    bool ok = run_search_device(ix, (const uint4 *)dev, 1, want, ef, 0, d_lab, d_dist, d_slot, d_cnt, nullptr, nullptr, ix->stream, 8);
+    ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
+    if(!ok) {
+        if(ix->err.empty()) set_err(ix, "lantern_gpu: HIP failure during search");
+        return 0;
+    }
+    ix->err.clear();
+    const char     *host = ix->h_single + row;
+    const uint64_t *h_lab = (const uint64_t *)host;
+    const float    *h_dist = (const float *)(host + want * 8);
+    const uint32_t *h_slot = (const uint32_t *)(host + want * 12);
+    uint32_t        got;
+    std::memcpy(&got, host + want * 16, 4);
+    size_t out = 0;
+    for(uint32_t i = 0; i < got && out < k; ++i) {
+        if(!cur->seen.insert(h_slot[ i ]).second) continue;  // returned by an earlier call of this scan
+        labels[ out ] = h_lab[ i ];
+        distances[ out ] = h_dist[ i ];
+        ++out;
+    }
+    return out;
 }
 
 bool import_graph_locked(Index *ix, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,
@@ -745,6 +822,8 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
     for(void *p : ix->d_scratch)
         if(p) (void)hipFree(p);
     if(ix->h_links) (void)hipHostFree(ix->h_links);
+    if(ix->h_single) (void)hipHostFree(ix->h_single);
+    if(ix->launch_done) (void)hipEventDestroy(ix->launch_done);
     delete ix;
 }
 
@@ -763,7 +842,7 @@ size_t usearch_size(usearch_index_t h, usearch_error_t *e)
     Index *ix = H(h, e);
     if(!ix) return 0;
     std::lock_guard<std::mutex> g(ix->mu);
-    return ix->n + ix->pend_labels.size();  // logical size; build.c:117 polls this per tuple
+    return logical_size(ix) + ix->pend_labels.size();  // logical size; build.c:117 polls this per tuple
 }
 
 size_t usearch_capacity(usearch_index_t h, usearch_error_t *e)
@@ -922,46 +1001,54 @@ size_t usearch_search_ef(usearch_index_t h, const void *query, usearch_scalar_ki
     if(!ix) return 0;
     if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the query does not match the index"); return 0; }
     if(k == 0) return 0;
+    if(!query || !labels || !distances) { FAIL(e, "lantern_gpu: null query or result pointer"); return 0; }
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return 0; }
-    if(!streaming) ix->stream_seen.clear();
-    if(ix->n == 0) return 0;
-    const size_t want = std::min(ix->stream_seen.size() + k, ix->n);  // enough to find k unseen ones
-    const size_t row = (size_t)ix->chunks * 16;
-    char        *buf = (char *)scratch(ix, 4, row + want * (8 + 4 + 4) + 16);
-    if(!buf) { FAIL(e, ix->err.c_str()); return 0; }
-    std::vector<uint32_t> padded((size_t)ix->chunks * 4);
-    pad_row(ix, query, (int)kind, padded.data());
-    // one result block: labels | distances | slots | count  -> one D2H copy
-    uint64_t *d_lab = (uint64_t *)(buf + row);
-    float    *d_dist = (float *)(buf + row + want * 8);
-    uint32_t *d_slot = (uint32_t *)(buf + row + want * 12);
-    uint32_t *d_cnt = (uint32_t *)(buf + row + want * 16);
-    std::vector<char> host(want * 16 + 4);
-    bool ok = hipMemcpyAsync(buf, padded.data(), row, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-    // one query: spend a whole 8-wave workgroup on it (latency-bound path)
-    ok = ok && run_search_device(ix, (const uint4 *)buf, 1, want, ef, 0, d_lab, d_dist, d_slot, d_cnt, nullptr, nullptr, ix->stream, 8);
-    ok = ok && hipMemcpyAsync(host.data(), buf + row, want * 16 + 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
-    ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
-    if(!ok) {
-        if(ix->err.empty()) set_err(ix, "lantern_gpu: HIP failure during search");
-        FAIL(e, ix->err.c_str());
-        return 0;
-    }
-    const uint64_t *h_lab = (const uint64_t *)host.data();
-    const float    *h_dist = (const float *)(host.data() + want * 8);
-    const uint32_t *h_slot = (const uint32_t *)(host.data() + want * 12);
-    uint32_t        got;
-    std::memcpy(&got, host.data() + want * 16, 4);
-    size_t out = 0;
-    for(uint32_t i = 0; i < got && out < k; ++i) {
-        if(!ix->stream_seen.insert(h_slot[ i ]).second) continue;  // returned by an earlier call of this scan
-        labels[ out ] = h_lab[ i ];
-        distances[ out ] = h_dist[ i ];
-        ++out;
-    }
+    ix->err.clear();
+    const size_t out = search_one_locked(ix, &ix->default_cursor, query, (int)kind, k, ef, streaming, labels, distances);
+    if(!ix->err.empty()) FAIL(e, ix->err.c_str());
     return out;
 }
+
+// ---- cursors: the per-scan half of usearch_search_ef's streaming contract ------------------------------------------
+struct lantern_gpu_cursor
+{
+    Index *ix;
+    Cursor cur;
+};
+
+lantern_gpu_cursor_t *lantern_gpu_cursor_open(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return nullptr;
+    lantern_gpu_cursor *c = new(std::nothrow) lantern_gpu_cursor();
+    if(!c) { FAIL(e, "lantern_gpu: out of host memory"); return nullptr; }
+    c->ix = ix;
+    return c;
+}
+
+size_t lantern_gpu_cursor_search(lantern_gpu_cursor_t *c, const void *query, usearch_scalar_kind_t kind, size_t k, size_t ef,
+                                 bool streaming, usearch_label_t *labels, float *distances, usearch_error_t *e)
+{
+    CLEAR(e);
+    if(!c) { FAIL(e, "lantern_gpu: null cursor"); return 0; }
+    Index *ix = H(c->ix, e);
+    if(!ix) return 0;
+    if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the query does not match the index"); return 0; }
+    if(k == 0) return 0;
+    if(!query || !labels || !distances) { FAIL(e, "lantern_gpu: null query or result pointer"); return 0; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return 0; }
+    ix->err.clear();
+    const size_t out = search_one_locked(ix, &c->cur, query, (int)kind, k, ef, streaming, labels, distances);
+    if(!ix->err.empty()) FAIL(e, ix->err.c_str());
+    return out;
+}
+
+size_t lantern_gpu_cursor_seen(lantern_gpu_cursor_t *c) { return c ? c->cur.seen.size() : 0; }
+
+void lantern_gpu_cursor_close(lantern_gpu_cursor_t *c) { delete c; }
 
 void lantern_gpu_search_batch_device(usearch_index_t h, const void *d_queries, size_t nq, size_t k, size_t ef, size_t skip,
                                      uint64_t *d_labels, float *d_distances, uint32_t *d_slots, uint32_t *d_counts,

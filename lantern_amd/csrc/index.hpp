@@ -4,6 +4,7 @@
 
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -11,6 +12,14 @@
 #include "kernels.hpp"
 
 namespace lgpu {
+
+// what one scan has been handed so far (device slots): a continuation searches for |seen| + k results and returns the
+// first k that were not returned before, so a scan never sees a row twice even though a wider search may rank the
+// earlier rows differently
+struct Cursor
+{
+    std::unordered_set<uint32_t> seen;
+};
 
 struct Index
 {
@@ -70,10 +79,34 @@ struct Index
     size_t h_links_cap = 0;
 
     // ---- streaming continuation of usearch_search_ef (scan.c:273-281) ----------------------------
-    // slots already handed out for the current query: a continuation searches for |seen| + k results and
-    // returns the first k that were not returned before, so a scan never sees a row twice even though a wider
-    // search may rank the earlier rows differently
-    std::unordered_set<uint32_t> stream_seen;
+    // In the reference every scan owns its own usearch handle (scan.c:99), so "what this scan has been handed so far"
+    // is per handle there.  Here ONE resident index serves many scans, so that state is a Cursor owned by the scan
+    // (lantern_scan, a scan-service connection, lantern_gpu_cursor_*); usearch_search_ef itself -- one handle, one
+    // scan, as in the reference -- uses the index's default cursor.
+    Cursor default_cursor;
+
+    // ---- page slots of a mirrored index (usearch_view_mem_lazy): device id -> the node's 48-bit slot in the PostgreSQL
+    // pages (an ItemPointer, external_index.c:380-409), and back.  usearch_add_external writes the lists it changes
+    // through retriever_mut in that form.
+    bool                                   page_mode = false;  // attached through usearch_view_mem_lazy
+    // the header's node count at attach time and the mirror's: they differ by the nodes no walk can reach (a re-prune
+    // may drop a node's last in-link; such nodes stay in the pages and in the header's count)
+    size_t                                 page_declared = 0, page_attach_n = 0;
+    std::vector<uint64_t>                  page_slots;
+    std::unordered_map<uint64_t, uint32_t> page_ids;
+
+    // ---- single-query path (usearch_search_ef): one pinned, device-mapped block [query row | labels | distances |
+    // slots | count] -- the kernel reads the query from it and writes the answer into it, so a lone query costs one
+    // launch and one stream synchronisation, no copy commands
+    char  *h_single = nullptr;
+    size_t h_single_bytes = 0;
+
+    // ---- launches on one index are serialised across streams: the walk kernels share per-index scratch (the
+    // per-workgroup visited bitmaps, indexed by blockIdx only), so a launch on another stream first waits for the event
+    // recorded behind the previous one
+    hipEvent_t  launch_done = nullptr;
+    hipStream_t launch_stream = nullptr;
+    bool        launch_pending = false;
 
     // ---- counters ----------------------------------------------------------------------------------
     uint64_t c_search_queries = 0, c_add_vectors = 0, c_add_batches = 0;
@@ -100,6 +133,13 @@ bool        run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size
                               uint64_t *d_labels, float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D,
                               uint64_t *d_E, hipStream_t stream, int waves);
 
+// one usearch_search_ef on behalf of `cur` (the caller holds ix->mu); returns the number of results
+size_t      search_one_locked(Index *ix, Cursor *cur, const void *query, int kind, size_t k, size_t ef, bool streaming,
+                              uint64_t *labels, float *distances);
+// usearch_size of the index: for a mirror, the header's count plus what was inserted since
+inline size_t logical_size(const Index *ix) { return ix->page_mode ? ix->page_declared + (ix->n - ix->page_attach_n) : ix->n; }
+bool        order_launch(Index *ix, hipStream_t stream);   // before a launch that uses the index's shared scratch
+bool        record_launch(Index *ix, hipStream_t stream);  // behind it
 bool        import_graph_locked(Index *ix, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,
                                 const uint32_t *nbr0, const uint32_t *upper_off, const uint32_t *upper_nbr, uint32_t entry_slot,
                                 int32_t max_level);

@@ -20,6 +20,7 @@
 #include <sys/time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -101,6 +102,8 @@ void serve(lantern_index_server *srv, int fd)
 {
     usearch_index_t index = nullptr;
     usearch_error_t err = nullptr;
+    std::string     failure;
+    bool            failed = false;
     try {
         uint32_t hello[ 2 ] = { PROTOCOL_VERSION, SERVER_TYPE };
         write_all(fd, hello, 8);
@@ -112,6 +115,10 @@ void serve(lantern_index_server *srv, int fd)
                        num_centroids = p[ 7 ], num_subvectors = p[ 8 ], estimated_capacity = p[ 9 ], element_bits = p[ 10 ];
         if(quant > 5) throw Fail{ "Invalid scalar quantization" };                                        // server.rs:94-101
         if(metric_kind != 1 && metric_kind != 3 && metric_kind != 8) throw Fail{ "Invalid metric " + std::to_string(metric_kind) };  // cli.rs:56-69
+        // every size below comes from the socket: bound it before anything is allocated from it (Lantern itself caps
+        // vectors at HNSW_MAX_DIM = 2000 scalars, options.h:14; bit vectors arrive as 32 x that many dimensions)
+        if(dim == 0 || dim > 2000u * 32u) throw Fail{ "Invalid dimensions " + std::to_string(dim) };
+        if(element_bits != 1 && element_bits != 8 && element_bits != 16 && element_bits != 32) throw Fail{ "Invalid element bits " + std::to_string(element_bits) };
         usearch_init_options_t o;
         std::memset(&o, 0, sizeof(o));
         o.metric_kind = (usearch_metric_kind_t)metric_kind;
@@ -138,8 +145,9 @@ void serve(lantern_index_server *srv, int fd)
         const usearch_scalar_kind_t kind = element_bits < 8 ? usearch_scalar_b1_k : element_bits == 8 ? usearch_scalar_i8_k : element_bits == 16 ? usearch_scalar_f16_k : usearch_scalar_f32_k;
         std::vector<uint64_t> labels;
         std::vector<uint8_t>  rows;
-        labels.reserve(ADD_CHUNK);
-        rows.reserve(ADD_CHUNK * vec_bytes);
+        const size_t chunk_rows = std::max<size_t>(64, std::min<size_t>(ADD_CHUNK, (64u << 20) / std::max<size_t>(vec_bytes, 1)));
+        labels.reserve(chunk_rows);
+        rows.reserve(chunk_rows * vec_bytes);
         auto flush = [&]() {
             if(labels.empty()) return;
             lantern_gpu_add_many(index, labels.data(), rows.data(), labels.size(), kind, &err);
@@ -155,7 +163,7 @@ void serve(lantern_index_server *srv, int fd)
             std::memcpy(&label, buf.data(), 8);
             labels.push_back(label);
             rows.insert(rows.end(), buf.begin() + 8, buf.end());
-            if(labels.size() == ADD_CHUNK) flush();
+            if(labels.size() == chunk_rows) flush();
         }
         flush();
         lantern_gpu_flush(index, &err);
@@ -175,13 +183,23 @@ void serve(lantern_index_server *srv, int fd)
         write_all(fd, file.data(), len);
         set_status(srv, SUCCEEDED);
     } catch(const Fail &f) {
+        failure = f.msg;
+        failed = true;
+    } catch(const std::exception &ex) {  // bad_alloc / length_error from a network-supplied size: an error frame, not an abort
+        failure = std::string("indexing server: ") + ex.what();
+        failed = true;
+    } catch(...) {
+        failure = "indexing server: unexpected failure";
+        failed = true;
+    }
+    if(failed) {
         set_status(srv, FAILED);
-        std::vector<uint8_t> out(8 + f.msg.size());
-        const uint32_t hdr = ERR_MSG, n = (uint32_t)f.msg.size();
-        std::memcpy(out.data(), &hdr, 4);
-        std::memcpy(out.data() + 4, &n, 4);
-        std::memcpy(out.data() + 8, f.msg.data(), f.msg.size());
-        (void)::send(fd, out.data(), out.size(), MSG_NOSIGNAL);
+        uint8_t        out[ 8 ];
+        const uint32_t hdr = ERR_MSG, n = (uint32_t)failure.size();
+        std::memcpy(out, &hdr, 4);
+        std::memcpy(out + 4, &n, 4);
+        (void)::send(fd, out, 8, MSG_NOSIGNAL);
+        (void)::send(fd, failure.data(), failure.size(), MSG_NOSIGNAL);
     }
     if(index) usearch_free(index, &err);
     srv->served++;

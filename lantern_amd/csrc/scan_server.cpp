@@ -11,9 +11,15 @@
 //
 // Wire protocol (ours; the reference has no such component), little-endian:
 //   client -> u32 0x5152534C ("LSRQ"), u32 k, u32 ef (0 = index default), u32 vector bytes, the vector
+//             or u32 0x4352534C ("LSRC"), same fields: the CONTINUATION of this connection's scan -- the next k rows of
+//             the same query (usearch_search_ef(streaming = true), scan.c:273-281)
 //   server -> u32 0x5052534C ("LSRP"), u32 status (0 = ok), u32 count, count x u64 labels, count x f32 distances
 //             status != 0: u32 length, message
 // A connection carries one request at a time (a backend runs one scan step at a time) and stays open across requests.
+// The continuation state -- which rows this scan has been handed since its last "LSRQ" -- belongs to the CONNECTION
+// (one backend, one scan at a time), never to the shared index: any number of backends paginate concurrently.  A
+// continuation is served as a search for |handed out| + k rows from which the rows already handed out are dropped
+// (by label: a heap TID is indexed once; rows with label 0 -- deleted, skipped by the scan -- are dropped by count).
 //
 // Threads: an acceptor; one reader per connection (blocking read -> enqueue -> wait for the answer -> write); one
 // dispatcher that takes up to `max_batch` queued requests -- waiting at most `max_wait_us` after the first one for
@@ -36,13 +42,14 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/lantern_gpu.h"
 
 namespace {
 
-constexpr uint32_t REQ_MAGIC = 0x5152534Cu, REP_MAGIC = 0x5052534Cu;
+constexpr uint32_t REQ_MAGIC = 0x5152534Cu, CONT_MAGIC = 0x4352534Cu, REP_MAGIC = 0x5052534Cu;
 constexpr uint32_t MAX_K = 4096, MAX_VEC_BYTES = 1u << 20;
 
 bool read_exact(int fd, void *buf, size_t n)
@@ -190,10 +197,14 @@ bool reply_error(int fd, const std::string &msg)
 void reader_loop(lantern_scan_server *s, lantern_scan_server::Conn *conn)
 {
     const int fd = conn->fd;
+    // this connection's scan: labels handed out since its last fresh request, and how many label-0 rows among them
+    std::unordered_set<uint64_t> seen;
+    size_t                       seen_zero = 0;
     for(;;) {
         uint32_t head[ 4 ];
         if(!read_exact(fd, head, sizeof(head))) break;  // peer closed, or the server is stopping (shutdown on the fd)
-        if(head[ 0 ] != REQ_MAGIC) { reply_error(fd, "lantern_scan_server: bad request magic"); break; }
+        if(head[ 0 ] != REQ_MAGIC && head[ 0 ] != CONT_MAGIC) { reply_error(fd, "lantern_scan_server: bad request magic"); break; }
+        const bool     cont = head[ 0 ] == CONT_MAGIC;
         const uint32_t k = head[ 1 ], ef = head[ 2 ], nbytes = head[ 3 ];
         if(nbytes > MAX_VEC_BYTES) { reply_error(fd, "lantern_scan_server: vector too large"); break; }
         auto p = std::make_shared<Pending>();
@@ -209,6 +220,13 @@ void reader_loop(lantern_scan_server *s, lantern_scan_server::Conn *conn)
             if(!reply_error(fd, "lantern_scan_server: k out of range")) break;
             continue;
         }
+        if(!cont) { seen.clear(); seen_zero = 0; }
+        const size_t handed = seen.size() + seen_zero;
+        if(handed + k > MAX_K) {
+            if(!reply_error(fd, "lantern_scan_server: the scan has paged past the service's row limit")) break;
+            continue;
+        }
+        p->k = (uint32_t)(handed + k);  // enough rows to find k that were not handed out yet
         s->n_requests += 1;
         {
             std::lock_guard<std::mutex> g(s->mu);
@@ -224,9 +242,24 @@ void reader_loop(lantern_scan_server *s, lantern_scan_server::Conn *conn)
             if(!reply_error(fd, p->error)) break;
             continue;
         }
-        const uint32_t c = (uint32_t)p->labels.size();
+        // drop what this scan already has; keep the first k of the rest
+        std::vector<uint64_t> out_l;
+        std::vector<float>    out_d;
+        size_t                zeros_to_skip = seen_zero;
+        for(size_t i = 0; i < p->labels.size() && out_l.size() < k; ++i) {
+            const uint64_t l = p->labels[ i ];
+            if(l == 0) {
+                if(zeros_to_skip) { --zeros_to_skip; continue; }
+                ++seen_zero;
+            } else if(!seen.insert(l).second) {
+                continue;
+            }
+            out_l.push_back(l);
+            out_d.push_back(p->dists[ i ]);
+        }
+        const uint32_t c = (uint32_t)out_l.size();
         uint32_t       rep[ 3 ] = { REP_MAGIC, 0u, c };
-        if(!write_all(fd, rep, sizeof(rep)) || (c && (!write_all(fd, p->labels.data(), c * 8) || !write_all(fd, p->dists.data(), c * 4)))) break;
+        if(!write_all(fd, rep, sizeof(rep)) || (c && (!write_all(fd, out_l.data(), c * 8) || !write_all(fd, out_d.data(), c * 4)))) break;
     }
     {
         // the descriptor leaves the server's books BEFORE it is closed: stop() must never shut down a recycled number
@@ -406,8 +439,8 @@ lantern_scan_client_t *lantern_scan_client_connect(const char *host, int port, u
     return c;
 }
 
-size_t lantern_scan_client_search(lantern_scan_client_t *c, const void *query, size_t query_bytes, size_t k, size_t ef, usearch_label_t *labels,
-                                  float *distances, usearch_error_t *e)
+static size_t client_request(lantern_scan_client_t *c, uint32_t magic, const void *query, size_t query_bytes, size_t k, size_t ef,
+                             usearch_label_t *labels, float *distances, usearch_error_t *e)
 {
     if(e) *e = nullptr;
     if(!c || c->fd < 0) { if(e) *e = "lantern_gpu: the scan client is not connected"; return 0; }
@@ -419,7 +452,7 @@ size_t lantern_scan_client_search(lantern_scan_client_t *c, const void *query, s
         if(e) *e = c->err.c_str();
         return (size_t)0;
     };
-    uint32_t head[ 4 ] = { REQ_MAGIC, (uint32_t)k, (uint32_t)ef, (uint32_t)query_bytes };
+    uint32_t head[ 4 ] = { magic, (uint32_t)k, (uint32_t)ef, (uint32_t)query_bytes };
     if(!write_all(c->fd, head, sizeof(head)) || !write_all(c->fd, query, query_bytes)) return fail("lantern_gpu: the scan server went away");
     uint32_t rep[ 3 ];
     if(!read_exact(c->fd, rep, sizeof(rep)) || rep[ 0 ] != REP_MAGIC) return fail("lantern_gpu: the scan server went away");
@@ -435,6 +468,19 @@ size_t lantern_scan_client_search(lantern_scan_client_t *c, const void *query, s
     if(count && (!read_exact(c->fd, labels, (size_t)count * 8) || !read_exact(c->fd, distances, (size_t)count * 4)))
         return fail("lantern_gpu: the scan server went away");
     return count;
+}
+
+size_t lantern_scan_client_search(lantern_scan_client_t *c, const void *query, size_t query_bytes, size_t k, size_t ef, usearch_label_t *labels,
+                                  float *distances, usearch_error_t *e)
+{
+    return client_request(c, REQ_MAGIC, query, query_bytes, k, ef, labels, distances, e);
+}
+
+// the next k rows of the scan this connection started with lantern_scan_client_search (same query)
+size_t lantern_scan_client_search_next(lantern_scan_client_t *c, const void *query, size_t query_bytes, size_t k, size_t ef,
+                                       usearch_label_t *labels, float *distances, usearch_error_t *e)
+{
+    return client_request(c, CONT_MAGIC, query, query_bytes, k, ef, labels, distances, e);
 }
 
 void lantern_scan_client_close(lantern_scan_client_t *c)

@@ -10,11 +10,33 @@
 //                    a slot carries the neighbour's u32 sequential id in its low 4 bytes
 //                    (external_index.c:399-403 rewrites them to ItemPointers on import)
 //
-// The 136 header bytes are parsed only inside usearch (usearch_view_mem_lazy,
-// usearch_header_get/set_entry_slot), whose source is not in the reference tree.  The field layout
-// below follows upstream usearch 2.x (index_dense_head_t, index_serialized_header_t) with the fork's
-// extra 16 + 16 bytes zeroed; it is self-consistent with this library's own reader and with
-// usearch_header_{get,set}_entry_slot below, and UNVERIFIED against the pinned fork.
+// The 136 header bytes are parsed only inside usearch (usearch_view_mem_lazy, usearch_update_header,
+// usearch_header_get/set_entry_slot), whose source is not in the reference tree.  Field OFFSETS and VALUES below
+// follow upstream usearch 2.x:
+//
+//   index_dense_head_t (index_dense.hpp), packed, no alignment:
+//     [ 0,  7)  magic "usearch"
+//     [ 7, 13)  version_major, version_minor, version_patch          u16 x 3   (load refuses another MAJOR)
+//     [13]      kind_metric           metric_kind_t  -- ASCII codes: cos 'c', l2sq 'e', hamming 'b', ip 'i' ...
+//     [14]      kind_scalar           scalar_kind_t  -- b1x8 1, u40 2, uuid 3, f64 10, f32 11, f16 12, f8 13,
+//                                                       u64 14, u32 15, u16 16, u8 17, i64 20, i32 21, i16 22, i8 23
+//     [15]      kind_key              scalar_kind_t of the key type      (u64 for usearch_label_t: 14)
+//     [16]      kind_compressed_slot  scalar_kind_t of the slot type     (load refuses a mismatch; see below)
+//     [17, 25)  count_present   u64
+//     [25, 33)  count_deleted   u64
+//     [33, 41)  dimensions      u64
+//     [41]      multi           bool
+//     upstream reserves 64 bytes for this block; Lantern's fork 80 (its PQ fields; zero here)
+//   index_serialized_header_t (index.hpp), five u64: size, connectivity, connectivity_base, max_level, entry_slot;
+//     upstream 40 bytes, the fork 56 (external_index.h:59-66) -- at [80, 136) here
+//
+// (The C-API numerals of include/lantern_gpu.h -- cos 1, l2sq 3, f32 1 ... -- are a different enum: the C layer
+// converts them, as usearch_storage.cpp:44-60 does for the scalar kind.)  kind_compressed_slot: the fork's slot type is
+// the 48-bit lantern_slot_t (usearch_storage.cpp:16); upstream's 40-bit slot is scalar_kind_t::u40_k and a type with
+// no scalar_kind<> specialisation reports unknown_k -- which of the two the fork stores cannot be read off the tree, so
+// u40_k ("the wide custom slot") is written and ANY value is accepted on read.
+// STATUS: UNVERIFIED against the pinned fork (rev aa4f91d); no fixture of a header produced by real usearch can be
+// made offline.  The reader accepts both upstream codes and this library's round-1 numerals.
 #include <cstdio>
 #include <cstring>
 #include <unordered_map>
@@ -43,6 +65,24 @@ constexpr size_t OFF_G_MAX_LEVEL = 104;         // u64
 constexpr size_t OFF_G_ENTRY_SLOT = 112;        // u64
 // [120, 136): reserved (zero)
 
+// upstream metric_kind_t / scalar_kind_t codes (index_plugins.hpp)
+constexpr uint8_t SK_B1X8 = 1, SK_U40 = 2, SK_F64 = 10, SK_F32 = 11, SK_F16 = 12, SK_U64 = 14, SK_I8 = 23;
+uint8_t metric_code(int metric) { return metric == usearch_metric_cos_k ? 'c' : metric == usearch_metric_l2sq_k ? 'e' : metric == usearch_metric_hamming_k ? 'b' : 0; }
+uint8_t scalar_code(int scalar)
+{
+    switch(scalar) {
+        case usearch_scalar_f32_k: return SK_F32;
+        case usearch_scalar_f64_k: return SK_F64;
+        case usearch_scalar_f16_k: return SK_F16;
+        case usearch_scalar_i8_k: return SK_I8;
+        case usearch_scalar_b1_k: return SK_B1X8;
+        default: return 0;
+    }
+}
+// a header written by upstream-coded usearch OR by round 1 of this library (C-API numerals)
+bool metric_matches(uint8_t stored, int metric) { return stored == metric_code(metric) || stored == (uint8_t)metric; }
+bool scalar_matches(uint8_t stored, int scalar) { return stored == scalar_code(scalar) || stored == (uint8_t)scalar; }
+
 template <typename T> void put(char *p, size_t off, T v) { std::memcpy(p + off, &v, sizeof(T)); }
 template <typename T> T    get(const char *p, size_t off) { T v; std::memcpy(&v, p + off, sizeof(T)); return v; }
 
@@ -65,13 +105,13 @@ static void write_header(const Index *ix, char *h)
 {
     std::memset(h, 0, USEARCH_HEADER_SIZE);
     std::memcpy(h + OFF_MAGIC, "usearch", 7);
-    put<uint16_t>(h, OFF_VERSION, 2);
-    put<uint16_t>(h, OFF_VERSION + 2, 0);
-    put<uint16_t>(h, OFF_VERSION + 4, 0);
-    put<uint8_t>(h, OFF_KIND_METRIC, (uint8_t)ix->metric);
-    put<uint8_t>(h, OFF_KIND_SCALAR, (uint8_t)ix->scalar);
-    put<uint8_t>(h, OFF_KIND_KEY, 8);   // 8-byte keys (usearch_label_t)
-    put<uint8_t>(h, OFF_KIND_SLOT, 6);  // 6-byte slots (lantern_slot_t)
+    put<uint16_t>(h, OFF_VERSION, 2);  // usearch 2.x: load refuses a different major
+    put<uint16_t>(h, OFF_VERSION + 2, 8);
+    put<uint16_t>(h, OFF_VERSION + 4, 15);
+    put<uint8_t>(h, OFF_KIND_METRIC, metric_code(ix->metric));
+    put<uint8_t>(h, OFF_KIND_SCALAR, scalar_code(ix->scalar));
+    put<uint8_t>(h, OFF_KIND_KEY, SK_U64);   // usearch_label_t = u64
+    put<uint8_t>(h, OFF_KIND_SLOT, SK_U40);  // the wide custom slot (see the file comment)
     put<uint64_t>(h, OFF_COUNT_PRESENT, ix->n);
     put<uint64_t>(h, OFF_COUNT_DELETED, 0);
     put<uint64_t>(h, OFF_DIMENSIONS, ix->opts.dimensions);
@@ -124,11 +164,17 @@ bool deserialize(Index *ix, const char *buf, size_t len)
     if(len < USEARCH_HEADER_SIZE || std::memcmp(buf + OFF_MAGIC, "usearch", 7) != 0) { set_err(ix, "lantern_gpu: not a usearch index file"); return false; }
     const uint64_t n = get<uint64_t>(buf, OFF_G_SIZE);
     if(get<uint64_t>(buf, OFF_G_CONNECTIVITY) != ix->M || get<uint64_t>(buf, OFF_DIMENSIONS) != ix->opts.dimensions ||
-       get<uint8_t>(buf, OFF_KIND_METRIC) != (uint8_t)ix->metric || get<uint8_t>(buf, OFF_KIND_SCALAR) != (uint8_t)ix->scalar) {
+       !metric_matches(get<uint8_t>(buf, OFF_KIND_METRIC), ix->metric) || !scalar_matches(get<uint8_t>(buf, OFF_KIND_SCALAR), ix->scalar)) {
         set_err(ix, "lantern_gpu: index file does not match the index options (metric, scalar kind, dimensions or connectivity)");
         return false;
     }
     if(n == 0) return true;
+    // the file is untrusted input (the index server hands back what a socket peer built; usearch_load takes any path):
+    // every count is bounded by what `len` can hold BEFORE anything is allocated from it
+    if(get<uint64_t>(buf, OFF_G_CONNECTIVITY_BASE) != ix->M0) { set_err(ix, "lantern_gpu: index file's level-0 connectivity is not 2 x connectivity"); return false; }
+    if(n > (len - USEARCH_HEADER_SIZE) / node_bytes(ix, 0) || n >= 0x7FFFFFFFull) { set_err(ix, "lantern_gpu: index file declares more nodes than it can hold"); return false; }
+    const uint64_t entry = get<uint64_t>(buf, OFF_G_ENTRY_SLOT), top = get<uint64_t>(buf, OFF_G_MAX_LEVEL);
+    if(entry >= n || top > 255) { set_err(ix, "lantern_gpu: index file's entry slot or top level is out of range"); return false; }
     const size_t vb = vector_bytes(ix);
     std::vector<uint64_t> labels(n);
     std::vector<uint8_t>  levels(n);
@@ -161,6 +207,16 @@ bool deserialize(Index *ix, const char *buf, size_t len)
         p += node_bytes(ix, level);
     }
     if(upper.empty()) upper.push_back(EMPTY);
+    if(levels[ entry ] != top) { set_err(ix, "lantern_gpu: the entry node's level is not the index's top level"); return false; }
+    for(size_t i = 0; i < n; ++i)
+        if(levels[ i ] > top) { set_err(ix, "lantern_gpu: a node's level exceeds the index's top level"); return false; }
+    // a neighbour listed on level l must itself reach level l (a walk reads its level-l list)
+    for(size_t i = 0; i < n; ++i)
+        for(int l = 1; l <= levels[ i ]; ++l) {
+            const uint32_t *list = &upper[ ((size_t)upper_off[ i ] + (size_t)(l - 1)) * ix->M ];
+            for(uint32_t j = 0; j < ix->M && list[ j ] != EMPTY; ++j)
+                if(levels[ list[ j ] ] < l) { set_err(ix, "lantern_gpu: an upper-level list names a node that does not reach that level"); return false; }
+        }
     // bit / f16 rows are stored as bytes in the file; the importer wants whole u32 words per row
     if(vb != (size_t)ix->words * 4) {
         std::vector<char> w(n * (size_t)ix->words * 4, 0);
@@ -188,7 +244,9 @@ bool mirror_from_retriever(Index *ix, const char *header)
     if(std::memcmp(header + OFF_MAGIC, "usearch", 7) != 0) { set_err(ix, "lantern_gpu: not a usearch header"); return false; }
     const uint64_t declared = get<uint64_t>(header, OFF_G_SIZE);
     if(get<uint64_t>(header, OFF_G_CONNECTIVITY) != ix->M) { set_err(ix, "lantern_gpu: header connectivity does not match the index options"); return false; }
+    ix->page_mode = true;
     if(declared == 0) return true;
+    if(declared >= 0x7FFFFFFFull) { set_err(ix, "lantern_gpu: the header declares more nodes than the device index supports"); return false; }
     const uint64_t mask48 = 0xFFFFFFFFFFFFull;
     const uint64_t entry = get<uint64_t>(header, OFF_G_ENTRY_SLOT) & mask48;
     const size_t   vb = vector_bytes(ix), wbytes = (size_t)ix->words * 4;
@@ -236,8 +294,82 @@ bool mirror_from_retriever(Index *ix, const char *header)
         std::memcpy(&vecs[ head * wbytes ], q, vb);
     }
     if(upper.empty()) upper.push_back(EMPTY);
-    return import_graph_locked(ix, slot_of.size(), vecs.data(), labels.data(), levels.data(), nbr0.data(), upper_off.data(), upper.data(),
-                               0 /* the entry slot was interned first */, (int32_t)get<uint64_t>(header, OFF_G_MAX_LEVEL));
+    // the pages are as untrusted as a file: the walk kernels start at (entry, max_level) and read the level-l list of
+    // every node a level-l list names
+    const uint64_t top = get<uint64_t>(header, OFF_G_MAX_LEVEL);
+    if(top > 255 || levels[ 0 ] != top) { set_err(ix, "lantern_gpu: the entry node's level is not the header's top level"); return false; }
+    for(size_t i = 0; i < levels.size(); ++i) {
+        if(levels[ i ] > top) { set_err(ix, "lantern_gpu: a node's level exceeds the header's top level"); return false; }
+        for(int l = 1; l <= levels[ i ]; ++l) {
+            const uint32_t *list = &upper[ ((size_t)upper_off[ i ] + (size_t)(l - 1)) * ix->M ];
+            for(uint32_t j = 0; j < ix->M && list[ j ] != EMPTY; ++j)
+                if(levels[ list[ j ] ] < l) { set_err(ix, "lantern_gpu: an upper-level list names a node that does not reach that level"); return false; }
+        }
+    }
+    if(!import_graph_locked(ix, slot_of.size(), vecs.data(), labels.data(), levels.data(), nbr0.data(), upper_off.data(), upper.data(),
+                            0 /* the entry slot was interned first */, (int32_t)top))
+        return false;
+    ix->page_slots.swap(slot_of);
+    ix->page_ids.swap(id_of);
+    ix->page_declared = (size_t)declared;
+    ix->page_attach_n = ix->n;
+    return true;
+}
+
+// ---- usearch_add_external: the aminsert path (insert.c:200-214) -----------------------------------------------------
+// Byte offset of level l's list inside a node tape (usearch_storage.cpp:19-32: [label u64][level u16] then one
+// [count u32][cap x 6-byte slot] block per level, cap = 2M on level 0 and M above).
+static size_t tape_list_offset(const Index *ix, int l)
+{
+    return 10 + (l == 0 ? 0 : (4 + (size_t)ix->M0 * LANTERN_SLOT_SIZE) + (size_t)(l - 1) * (4 + (size_t)ix->M * LANTERN_SLOT_SIZE));
+}
+
+// Write the device list of (id, level l) into a node tape, neighbour ids as the slots the pages use.
+static bool write_list_to_tape(Index *ix, uint32_t id, int l, char *tape)
+{
+    const uint32_t cap = l == 0 ? ix->M0 : ix->M;
+    std::vector<uint32_t> list(cap);
+    const uint32_t *src = l == 0 ? ix->d_nbr0 + (size_t)id * ix->M0 : ix->d_upper_nbr + ((size_t)ix->upper_off[ id ] + (size_t)(l - 1)) * ix->M;
+    if(hipMemcpy(list.data(), src, (size_t)cap * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err(ix, "lantern_gpu: HIP failure reading a neighbour list"); return false; }
+    char *q = tape + tape_list_offset(ix, l);
+    uint32_t cnt = 0;
+    while(cnt < cap && list[ cnt ] != EMPTY) ++cnt;
+    std::memset(q, 0, 4 + (size_t)cap * LANTERN_SLOT_SIZE);
+    put<uint32_t>(q, 0, cnt);
+    for(uint32_t j = 0; j < cnt; ++j) {
+        const uint64_t slot = ix->page_mode ? ix->page_slots[ list[ j ] ] : (uint64_t)list[ j ];
+        std::memcpy(q + 4 + (size_t)j * LANTERN_SLOT_SIZE, &slot, LANTERN_SLOT_SIZE);
+    }
+    return true;
+}
+
+// After the node `id` (the newest) has been linked on the device: its own tape gets label, level, lists and the stored
+// vector; every node it linked to gets its (possibly re-pruned) list of that level re-written through retriever_mut.
+bool write_back_insert(Index *ix, uint32_t id, char *node_tape)
+{
+    const int level = ix->levels[ id ];
+    put<uint64_t>(node_tape, 0, ix->labels[ id ]);
+    put<uint16_t>(node_tape, 8, (uint16_t)level);
+    std::vector<uint32_t> own((size_t)ix->M0);
+    for(int l = 0; l <= level; ++l) {
+        if(!write_list_to_tape(ix, id, l, node_tape)) return false;
+        const uint32_t cap = l == 0 ? ix->M0 : ix->M;
+        const uint32_t *src = l == 0 ? ix->d_nbr0 + (size_t)id * ix->M0 : ix->d_upper_nbr + ((size_t)ix->upper_off[ id ] + (size_t)(l - 1)) * ix->M;
+        if(hipMemcpy(own.data(), src, (size_t)cap * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err(ix, "lantern_gpu: HIP failure reading a neighbour list"); return false; }
+        for(uint32_t j = 0; j < cap && own[ j ] != EMPTY; ++j) {
+            if(!ix->page_mode) continue;  // no pages behind this index: the device lists are the only copy
+            if(!ix->opts.retriever_mut) { set_err(ix, "lantern_gpu: usearch_add_external needs init_options.retriever_mut"); return false; }
+            char *tape = (char *)ix->opts.retriever_mut(ix->opts.retriever_ctx, ix->page_slots[ own[ j ] ]);
+            if(!tape) { set_err(ix, "lantern_gpu: retriever_mut returned NULL"); return false; }
+            if(!write_list_to_tape(ix, own[ j ], l, tape)) return false;
+        }
+    }
+    // the stored vector sits behind the last list (usearch_init_node leaves it zeroed: usearch_storage.cpp:34-44)
+    const size_t row = (size_t)ix->chunks * 16;
+    std::vector<char> stored(row);
+    if(hipMemcpy(stored.data(), (const char *)ix->d_vec + (size_t)id * row, row, hipMemcpyDeviceToHost) != hipSuccess) { set_err(ix, "lantern_gpu: HIP failure reading a row"); return false; }
+    std::memcpy(node_tape + tape_list_offset(ix, level + 1), stored.data(), vector_bytes(ix));
+    return true;
 }
 
 }  // namespace lgpu
@@ -267,9 +399,54 @@ void usearch_update_header(usearch_index_t h, char *header136, usearch_error_t *
     if(!ix || !header136) { if(e) *e = "lantern_gpu: null index handle or header"; return; }
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) { if(e) *e = ix->err.c_str(); return; }
-    put<uint64_t>(header136, OFF_COUNT_PRESENT, ix->n);
-    put<uint64_t>(header136, OFF_G_SIZE, ix->n);
+    put<uint64_t>(header136, OFF_COUNT_PRESENT, logical_size(ix));
+    put<uint64_t>(header136, OFF_G_SIZE, logical_size(ix));
     put<uint64_t>(header136, OFF_G_MAX_LEVEL, ix->n ? (uint64_t)ix->max_level : 0);
+    // the entry point moves when an insert raises the top level; in the pages it is a 48-bit page slot
+    // (external_index.c:411-418), in a file a sequential id
+    if(ix->n) put<uint64_t>(header136, OFF_G_ENTRY_SLOT, ix->page_mode ? ix->page_slots[ ix->entry ] : (uint64_t)ix->entry);
+}
+
+// insert.c:209.  `node_tape` is the new node's tape inside a PostgreSQL page, already sized and headed by
+// usearch_init_node (usearch_storage.cpp:34-44); `slot` its 48-bit page slot.  The node is linked into the HBM mirror
+// exactly as usearch_add would (one sequential insertion at the caller's level), then everything the insertion changed
+// is written to where PostgreSQL keeps it: the node's own lists and vector into `node_tape`, the re-written lists of
+// the nodes it linked to through init_options.retriever_mut (external_index.c:673-697 marks those buffers dirty).
+void usearch_add_external(usearch_index_t h, usearch_label_t label, const void *vector, void *node_tape, usearch_scalar_kind_t kind,
+                          int16_t level, uint64_t slot, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    Index *ix = (Index *)h;
+    if(ix) (void)hipSetDevice(ix->device);
+    if(!ix || !vector || !node_tape) { if(e) *e = "lantern_gpu: null index handle, vector or node tape"; return; }
+    if(level < 0 || level > 255) { if(e) *e = "lantern_gpu: level out of range"; return; }
+    usearch_error_t err = nullptr;
+    lantern_gpu_flush(h, &err);
+    if(err) { if(e) *e = err; return; }
+    uint32_t id;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        id = (uint32_t)ix->n;
+        if(ix->page_mode) {
+            const uint64_t s48 = slot & 0xFFFFFFFFFFFFull;
+            if(ix->page_ids.count(s48)) { if(e) *e = set_err(ix, "lantern_gpu: usearch_add_external: the slot is already in the index"); return; }
+            if(ix->page_slots.size() != ix->n) { if(e) *e = set_err(ix, "lantern_gpu: the mirror and its page slots are out of step"); return; }
+            ix->page_slots.push_back(s48);
+            ix->page_ids.emplace(s48, id);
+        }
+    }
+    lantern_gpu_add_with_level(h, label, vector, kind, (int)level, &err);
+    if(!err) lantern_gpu_flush(h, &err);
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(err || ix->n != (size_t)id + 1) {
+        if(ix->page_mode && ix->page_slots.size() > ix->n) {  // the node did not make it in
+            ix->page_ids.erase(ix->page_slots.back());
+            ix->page_slots.pop_back();
+        }
+        if(e) *e = err ? err : set_err(ix, "lantern_gpu: usearch_add_external: the insertion did not complete");
+        return;
+    }
+    if(!write_back_insert(ix, id, (char *)node_tape) && e) *e = ix->err.c_str();
 }
 
 

@@ -167,6 +167,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
         if(tid == 0) { s.scal[ S_VISCNT ] = 0; s.scal[ S_SPILL ] = 0; }
     } else {
+        if(tid == 0) s.scal[ S_SPILL ] = 0;
         uint4 *b4 = (uint4 *)bitmap;
         for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
     }
@@ -182,7 +183,17 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
     bool spilled = false;
     for(;;) {
         // ---- pop: first unexpanded entry of the list
-        if(tid == 0) { s.scal[ S_POS ] = 0x7FFFFFFF; s.scal[ S_ANY ] = 0; }
+        // The spill decision is taken by ONE thread and published with the pop scalars: S_VISCNT is only ever changed
+        // by wave 0 (visit_test_and_set), between the barrier after the pop and the barrier that ends the neighbour
+        // pass, so thread 0 reads its final value here and every wave branches on the same flag two barriers later
+        // (each wave reading S_VISCNT for itself could see wave 0's increments of THIS hop and take a different branch).
+        if(tid == 0) {
+            s.scal[ S_POS ] = 0x7FFFFFFF;
+            s.scal[ S_ANY ] = 0;
+            // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (rare:
+            // the set holds 3/4 * vis_slots slots, a search visits D of them)
+            if(s.vis_slots && (uint32_t)s.scal[ S_VISCNT ] + v.M0 > s.vis_slots / 4 * 3) s.scal[ S_SPILL ] = 1;
+        }
         __syncthreads();
         for(int i = tid; i < cnt; i += T)
             if(!key_expanded(s.keys[ i ])) { atomicMin(&s.scal[ S_POS ], i); break; }
@@ -191,9 +202,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         if(pos == 0x7FFFFFFF) break;
         const uint32_t node = key_slot(s.keys[ pos ]);
         E += 1;
-        // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (rare:
-        // the set holds 3/4 * vis_slots slots, a search visits D of them)
-        if(s.vis_slots && !spilled && (uint32_t)s.scal[ S_VISCNT ] + v.M0 > s.vis_slots / 4 * 3) {
+        if(!spilled && s.scal[ S_SPILL ]) {  // uniform: S_SPILL was written before the two barriers above
             uint4 *b4 = (uint4 *)bitmap;
             for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
             spilled = true;

@@ -347,7 +347,7 @@ def test_mirror_through_retriever_matches_direct_index(capi):
 
     b = capi.GpuIndex("l2sq", d, M=M, ef_construction=40, ef=32, seed=3, retriever=retriever)
     b.view_mem_lazy(hbuf.raw)
-    assert len(b) <= n and len(calls) == len(b)  # every reachable node fetched exactly once
+    assert len(b) == n and len(calls) == b.graph_info().size <= n  # usearch_size = the header's count; every reachable node fetched once
     queries = rng.standard_normal((40, d), dtype=np.float32)
     la, da, _ = a.search_batch(queries, 10)
     lb, db, _ = b.search_batch(queries, 10)

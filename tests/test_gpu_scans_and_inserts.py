@@ -1,0 +1,287 @@
+"""Scans that share one resident index, launches on two streams, the aminsert path (usearch_add_external,
+usearch_update_header, lantern_gpu_add_with_level) and the usearch-format header.  Needs an MI355X."""
+import ctypes as C
+import math
+import struct
+
+import numpy as np
+import pytest
+
+from tests.pg_pages import PageStore, graph_by_label
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from lantern_amd import capi
+
+    capi.lib()
+    assert capi.device_count() > 0, "no HIP device: the gpu tests need a real MI355X"
+    return capi
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# per-scan continuation state (scan.c:99: one usearch handle per scan in the reference)
+# ------------------------------------------------------------------------------------------------------------------
+def test_interleaved_scans_on_one_index_do_not_disturb_each_other(capi):
+    rng = np.random.default_rng(21)
+    n, d = 4000, 32
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    ix = capi.GpuIndex("l2sq", d, M=8, ef_construction=48, ef=32, seed=5)
+    ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    qa, qb, qc = rng.standard_normal((3, d), dtype=np.float32)
+
+    def solo(q, init_k, limit):
+        s = capi.Scan(ix, init_k=init_k)
+        s.rescan(q)
+        rows = s.fetch(limit)
+        s.end()
+        return rows
+
+    want_a, want_b, want_c = solo(qa, 3, 120), solo(qb, 5, 90), solo(qc, 4, 40)
+    assert len(set(want_a)) == 120 and len(set(want_b)) == 90
+    # two cursors / the two sides of a nested loop: the scans advance in lock step, then one is re-armed half way
+    sa, sb = capi.Scan(ix, init_k=3), capi.Scan(ix, init_k=5)
+    sa.rescan(qa)
+    sb.rescan(qb)
+    got_a, got_b = [], []
+    for i in range(120):
+        got_a.append(sa.gettuple())
+        if i < 90:
+            got_b.append(sb.gettuple())
+        if i == 50:  # a third scan starts and finishes in the middle; plain usearch_search_ef calls happen too
+            assert solo(qc, 4, 40) == want_c
+            ix.search(qc, 7)
+            ix.search(qc, 7, streaming=True)
+    assert got_a == want_a and got_b == want_b
+    sb.rescan(qa)  # ldb_amrescan on an open scan: it starts over, the other scan is untouched
+    assert sb.fetch(30) == want_a[:30]
+    assert sa.gettuple() == solo(qa, 3, 121)[120]
+    # cursors expose the same contract without the paging shim
+    c1, c2 = ix.cursor(), ix.cursor()
+    l1, _ = c1.search(qa, 4)
+    l2, _ = c2.search(qb, 4)
+    n1, _ = c1.search(qa, 6, streaming=True)
+    n2, _ = c2.search(qb, 6, streaming=True)
+    ref_a, _ = ix.search(qa, 4)
+    more_a, _ = ix.search(qa, 6, streaming=True)
+    assert l1.tolist() == ref_a.tolist() and n1.tolist() == more_a.tolist()
+    assert not set(l1.tolist()) & set(n1.tolist()) and not set(l2.tolist()) & set(n2.tolist())
+    assert c1.seen == 10 and c2.seen == 10
+
+
+def test_searches_on_two_streams_share_the_index_safely(capi, monkeypatch):
+    """lantern_gpu_search_batch_device returns with its kernel still running; a launch on another stream must not share
+    the per-workgroup visited bitmaps with it.  LANTERN_GPU_VIS_SLOTS=0 puts EVERY visit in those bitmaps."""
+    from lantern_amd import hip
+
+    monkeypatch.setenv("LANTERN_GPU_VIS_SLOTS", "0")
+    rng = np.random.default_rng(22)
+    n, d, k, nq = 30000, 64, 10, 3000
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    ix = capi.GpuIndex("l2sq", d, M=16, ef_construction=64, ef=64, seed=6)
+    ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    ix.flush()
+    qs = [rng.standard_normal((nq, d), dtype=np.float32) for _ in range(2)]
+    want = [ix.search_batch(q, k) for q in qs]
+    streams = [hip.Stream(), hip.Stream()]
+    dq = [hip.Buffer.from_numpy(hip.padded_rows(q, False)) for q in qs]
+    out_l = [hip.Buffer(nq * k * 8) for _ in qs]
+    out_d = [hip.Buffer(nq * k * 4) for _ in qs]
+    for rounds in range(3):
+        for i in (0, 1):  # queued back to back on different streams: without ordering they would overlap
+            ix.search_batch_device(dq[i].ptr, nq, k, 0, 0, out_l[i].ptr, out_d[i].ptr, None, None, None, None, streams[i].handle)
+        hip.synchronize()
+        for i in (0, 1):
+            assert np.array_equal(out_l[i].download((nq, k), np.uint64), want[i][0])
+            assert np.array_equal(out_d[i].download((nq, k), np.float32), want[i][1])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the insert path: caller-drawn levels (insert.c:32-46), usearch_add_external (insert.c:209), usearch_update_header
+# ------------------------------------------------------------------------------------------------------------------
+def pg_level(rng, M):
+    """hnsw_generate_new_level (insert.c:32-46): floor(-ln(U) * 1/ln(M)) with U from the backend's PRNG."""
+    u = 1.0 - rng.random()  # (0, 1]
+    return int(-math.log(u) * (1.0 / math.log(M)))
+
+
+def test_add_with_level_is_usearch_add_at_that_level(capi, oracle):
+    rng = np.random.default_rng(23)
+    n, extra, d, M = 800, 60, 40, 6
+    base = rng.standard_normal((n + extra, d), dtype=np.float32)
+    labels = np.arange(n + extra, dtype=np.uint64) + 10
+    levels = [pg_level(rng, M) for _ in range(extra)]
+    levels[7] = 5  # one insert raises the top level: the entry point moves (insert.c:214 then refreshes the header)
+    gpu = capi.GpuIndex("l2sq", d, M=M, ef_construction=32, ef=32, seed=9)
+    gpu.set_add_batch(1, 1)  # a backend inserts one tuple at a time
+    gpu.add_many(labels[:n], base[:n])
+    ora = oracle.OracleIndex("l2sq", d, M=M, ef_construction=32, ef=32, seed=9, sum_mode=oracle.SUM_WAVE64)
+    ora.add_many(labels[:n], base[:n])
+    for i, lv in enumerate(levels):
+        gpu.add(labels[n + i], base[n + i], level=lv)
+        ora.add(labels[n + i], base[n + i], level=lv)
+    g, o = gpu.export_graph(), ora.export_graph()
+    for key in ("levels", "nbr0", "upper_off", "upper_nbr", "labels"):
+        assert np.array_equal(g[key], o[key]), key
+    assert g["entry_slot"] == o["entry_slot"] == n + 7 and g["max_level"] == o["max_level"] == 5
+    assert list(g["levels"][n:]) == levels
+    with pytest.raises(capi.LanternGpuError, match="level out of range"):
+        gpu.add(1, base[0], level=300)
+
+
+def test_add_external_links_the_mirror_and_writes_the_pages(capi):
+    rng = np.random.default_rng(24)
+    n, extra, d, M = 1200, 40, 24, 5
+    base = rng.standard_normal((n + extra, d), dtype=np.float32)
+    labels = np.arange(n + extra, dtype=np.uint64) + 500
+    levels = [pg_level(rng, M) for _ in range(extra)]
+    levels[11] = 6  # raises the top level
+    a = capi.GpuIndex("l2sq", d, M=M, ef_construction=40, ef=32, seed=4)
+    a.set_add_batch(1, 1)
+    a.add_many(labels[:n], base[:n])
+    store = PageStore(capi, a.save_buffer(), d * 4, M)
+    # --- the backend: attach (insert.c:142-151), insert tuple by tuple (insert.c:182-214)
+    b = capi.GpuIndex("l2sq", d, M=M, ef_construction=40, ef=32, seed=4, retriever=store.retriever, retriever_mut=store.retriever_mut)
+    b.view_mem_lazy(store.header)
+    # usearch_size is the header's count; the mirror holds the nodes a walk can reach (a few have lost their last in-link)
+    assert len(b) == n and n - 20 <= b.graph_info().size <= n
+    header = store.header
+    for i, lv in enumerate(levels):
+        addr, slot = store.new_tuple(int(labels[n + i]), lv)
+        store.mutated.clear()
+        b.add_external(labels[n + i], base[n + i], addr, lv, slot)
+        header = b.update_header(header)
+        # exactly the nodes the new node linked to were re-written (and only through retriever_mut)
+        _, _, lists, vec = store.node(slot)
+        assert sorted(store.mutated) == sorted(x for lst in lists for x in lst)
+        assert vec == base[n + i].tobytes() and len(lists) == lv + 1
+    # --- the reference state: the same inserts applied to the direct index
+    for i, lv in enumerate(levels):
+        a.add(labels[n + i], base[n + i], level=lv)
+    want = graph_by_label(a.export_graph(), base)
+    got = store.graph_by_label()
+    assert got.keys() == want.keys()
+    for lab in want:
+        assert got[lab] == want[lab], lab
+    # header: size, top level, entry slot (in page form)
+    assert struct.unpack_from("<Q", header, 80)[0] == n + extra and struct.unpack_from("<Q", header, 104)[0] == 6
+    assert capi.header_entry_slot(header) == store.order[n + 11]
+    # --- a fresh backend mirrors the updated pages and finds what the direct index finds
+    c = capi.GpuIndex("l2sq", d, M=M, ef_construction=40, ef=32, seed=4, retriever=store.retriever)
+    c.view_mem_lazy(header)
+    assert len(c) == n + extra and c.graph_info().size <= n + extra
+    queries = rng.standard_normal((50, d), dtype=np.float32)
+    la, da, _ = a.search_batch(queries, 10)
+    lc, dc, _ = c.search_batch(queries, 10)
+    lb, db, _ = b.search_batch(queries, 10)
+    assert np.array_equal(la, lc) and np.array_equal(da, dc) and np.array_equal(la, lb) and np.array_equal(da, db)
+    # the same slot twice is refused; an index without pages writes sequential ids into the tape
+    with pytest.raises(capi.LanternGpuError, match="already in the index"):
+        b.add_external(1, base[0], store.retriever(store.order[0]), 0, store.order[0])
+    e = capi.GpuIndex("l2sq", d, M=M, ef_construction=40, ef=32, seed=4)
+    e.set_add_batch(1, 1)
+    e.add_many(labels[:50], base[:50])
+    tape = C.create_string_buffer(store.tape_bytes(1))
+    e.add_external(777, base[60], C.addressof(tape), 1, 0)
+    g = e.export_graph()
+    cnt = struct.unpack_from("<I", tape.raw, 10)[0]
+    ids = [struct.unpack_from("<I", tape.raw, 14 + j * 6)[0] for j in range(cnt)]
+    assert ids == [int(x) for x in g["nbr0"][50] if x != 0xFFFFFFFF] and struct.unpack_from("<QH", tape.raw, 0) == (777, 1)
+
+
+def test_add_external_from_an_empty_page_index(capi):
+    """CREATE INDEX on an empty table, then INSERTs: the header declares zero nodes (build.c:675-684)."""
+    rng = np.random.default_rng(25)
+    d, M = 16, 4
+    empty = capi.GpuIndex("l2sq", d, M=M, ef_construction=16, ef=16, seed=1)
+    store = PageStore(capi, empty.save_buffer(), d * 4, M)
+    b = capi.GpuIndex("l2sq", d, M=M, ef_construction=16, ef=16, seed=1, retriever=store.retriever, retriever_mut=store.retriever_mut)
+    b.view_mem_lazy(store.header)
+    rows = rng.standard_normal((30, d), dtype=np.float32)
+    header = store.header
+    direct = capi.GpuIndex("l2sq", d, M=M, ef_construction=16, ef=16, seed=1)
+    direct.set_add_batch(1, 1)
+    for i, row in enumerate(rows):
+        lv = 2 if i == 0 else (1 if i % 7 == 0 else 0)
+        addr, slot = store.new_tuple(100 + i, lv)
+        b.add_external(100 + i, row, addr, lv, slot)
+        header = b.update_header(header)
+        direct.add(100 + i, row, level=lv)
+    assert store.graph_by_label() == graph_by_label(direct.export_graph(), rows)
+    assert capi.header_entry_slot(header) == store.order[0] and struct.unpack_from("<Q", header, 80)[0] == 30
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the 136-byte header (external_index.h:29-66) and untrusted files
+# ------------------------------------------------------------------------------------------------------------------
+def test_header_carries_upstream_codes_and_both_codings_load(capi):
+    rng = np.random.default_rng(26)
+    for metric, quant, mcode, scode, d in (("l2sq", "f32", b"e", 11, 12), ("cos", "f16", b"c", 12, 12), ("cos", "i8", b"c", 23, 12),
+                                           ("hamming", "f32", b"b", 1, 2)):
+        rows = rng.integers(0, 2**32, size=(60, d), dtype=np.uint32) if metric == "hamming" else rng.uniform(-1, 1, (60, d)).astype(np.float32)
+        ix = capi.GpuIndex(metric, d, M=4, ef_construction=16, seed=2, quantization=quant)
+        ix.add_many(np.arange(60) + 1, rows)
+        blob = bytearray(ix.save_buffer())
+        # index_dense_head_t: magic, version 2.x, metric_kind_t ASCII code, scalar_kind_t codes, u64 keys
+        assert blob[:7] == b"usearch" and struct.unpack_from("<H", blob, 7)[0] == 2
+        assert blob[13:14] == mcode and blob[14] == scode and blob[15] == 14 and blob[16] == 2
+        assert struct.unpack_from("<QQQ", blob, 17) == (60, 0, d * 32 if metric == "hamming" else d)
+        assert struct.unpack_from("<QQQ", blob, 80) == (60, 4, 8)
+        again = capi.GpuIndex(metric, d, M=4, ef_construction=16, seed=2, quantization=quant)
+        again.load_buffer(bytes(blob))
+        assert again.checksum() == ix.checksum()
+        # a file written by round 1 of this library (C-API numerals in the kind bytes) still loads
+        old = bytearray(blob)
+        old[13] = {"l2sq": 3, "cos": 1, "hamming": 8}[metric]
+        old[14] = {"f32": 5 if metric == "hamming" else 1, "f16": 3, "i8": 4}[quant]
+        old[15], old[16] = 8, 6
+        legacy = capi.GpuIndex(metric, d, M=4, ef_construction=16, seed=2, quantization=quant)
+        legacy.load_buffer(bytes(old))
+        assert legacy.checksum() == ix.checksum()
+        other = capi.GpuIndex("cos" if metric == "l2sq" else "l2sq", d * 32 if metric == "hamming" else d, M=4, ef_construction=16)
+        with pytest.raises(capi.LanternGpuError, match="does not match the index options"):
+            other.load_buffer(bytes(blob))
+
+
+def test_corrupt_files_are_refused_not_trusted(capi):
+    rng = np.random.default_rng(27)
+    d, M = 8, 4
+    ix = capi.GpuIndex("l2sq", d, M=M, ef_construction=16, seed=3)
+    ix.add_many(np.arange(200) + 1, rng.standard_normal((200, d), dtype=np.float32))
+    blob = ix.save_buffer()
+    g = ix.export_graph()
+
+    def load(b):
+        capi.GpuIndex("l2sq", d, M=M, ef_construction=16, seed=3).load_buffer(bytes(b))
+
+    load(blob)
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, 80, 1 << 40)  # a node count no file of this length can hold
+    with pytest.raises(capi.LanternGpuError, match="more nodes than it can hold"):
+        load(bad)
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, 112, 5000)  # entry slot beyond the nodes
+    with pytest.raises(capi.LanternGpuError, match="entry slot or top level"):
+        load(bad)
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, 104, int(g["max_level"]) + 1)  # the walk would start above the entry node's lists
+    with pytest.raises(capi.LanternGpuError, match="entry node's level"):
+        load(bad)
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, 96, 2 * M + 2)
+    with pytest.raises(capi.LanternGpuError, match="level-0 connectivity"):
+        load(bad)
+    with pytest.raises(capi.LanternGpuError, match="truncated|corrupt"):
+        load(blob[:len(blob) - 40])
+    # an upper-level list that names a level-0 node: a walk would read a list that does not exist
+    top = next(i for i in range(200) if g["levels"][i] >= 1 and g["upper_nbr"][g["upper_off"][i]][0] != 0xFFFFFFFF)
+    flat = next(i for i in range(200) if g["levels"][i] == 0)
+    off = 136
+    for i in range(top):
+        off += 10 + (4 + 2 * M * 6) + int(g["levels"][i]) * (4 + M * 6) + d * 4
+    bad = bytearray(blob)
+    struct.pack_into("<I", bad, off + 10 + (4 + 2 * M * 6) + 4, flat)
+    with pytest.raises(capi.LanternGpuError, match="does not reach that level"):
+        load(bad)

@@ -67,6 +67,80 @@ def test_many_clients_are_batched_and_answers_routed(capi):
     assert {(c[1], c[2]) for c in calls} == {(5, 40), (8, 0)}  # one launch per distinct (k, ef), never mixed
 
 
+def ranked_backend(table):
+    """A back end with a real ranking: rows of `table` (n x 4 f32) by squared distance to the query, labels = row + 1,
+    except row 3 whose label is 0 (a deleted row, skipped by the scan: scan.c:296-300)."""
+    def fn(queries, k, ef):
+        q = queries.view(np.float32).reshape(queries.shape[0], -1)
+        d = ((q[:, None, :] - table[None, :, :]) ** 2).sum(-1)
+        order = np.argsort(d, axis=1, kind="stable")[:, :k]
+        lab = (order + 1).astype(np.uint64)
+        lab[order == 3] = 0
+        cnt = np.full(q.shape[0], min(k, table.shape[0]), dtype=np.uint32)
+        out_l = np.zeros((q.shape[0], k), dtype=np.uint64)
+        out_d = np.full((q.shape[0], k), np.inf, dtype=np.float32)
+        out_l[:, :order.shape[1]] = lab
+        out_d[:, :order.shape[1]] = np.take_along_axis(d, order, axis=1)
+        return out_l, out_d, cnt
+    return fn
+
+
+def test_concurrent_scans_paginate_independently_through_the_service(capi):
+    """The continuation state is the CONNECTION's (the reference: one usearch handle per scan, scan.c:99): backends that
+    page through their results at the same time each see exactly what they see alone -- nothing twice, nothing lost."""
+    rng = np.random.default_rng(3)
+    table = rng.standard_normal((300, 4)).astype(np.float32)
+    srv = capi.ScanServer(batch_fn=ranked_backend(table), vec_bytes=16, max_batch=32, max_wait_us=2000)
+    queries = rng.standard_normal((12, 4)).astype(np.float32)
+
+    def page_through(c, q):
+        rows = []
+        lab, _ = c.search(q, 4)
+        rows += lab.tolist()
+        for k in (8, 16, 32):
+            lab, _ = c.search_next(q, k)
+            rows += lab.tolist()
+        return rows
+
+    solo = []
+    c = capi.ScanClient(srv.host, srv.port)
+    for q in queries:
+        solo.append(page_through(c, q))
+    c.close()
+    for q, rows in zip(queries, solo):  # the pages are consecutive stretches of the full ranking, label 0 included once
+        full = ranked_backend(table)(q.view(np.uint8).reshape(1, -1), 60, 0)[0][0].tolist()
+        assert rows == full and len([r for r in rows if r]) == len(set(r for r in rows if r))
+    got, errs = {}, []
+    start = threading.Barrier(len(queries))
+
+    def session(i):
+        try:
+            cc = capi.ScanClient(srv.host, srv.port)
+            start.wait()
+            got[i] = page_through(cc, queries[i])
+            cc.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=session, args=(i,)) for i in range(len(queries))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert [got[i] for i in range(len(queries))] == solo
+    # the amgettuple shim over a service connection: init_k = 3, then 6, 12, ... through the continuation; label 0 skipped
+    cc = capi.ScanClient(srv.host, srv.port)
+    sc = capi.Scan(client=cc, metric="l2sq", dims=4, init_k=3)
+    sc.rescan(queries[0])
+    rows = sc.fetch(40)
+    want = [r for r in ranked_backend(table)(queries[0].view(np.uint8).reshape(1, -1), 60, 0)[0][0].tolist() if r][:40]
+    assert rows == want
+    sc.rescan(queries[1])  # ldb_amrescan: a fresh scan on the same connection
+    assert sc.fetch(5) == [r for r in solo[1] if r][:5]
+    sc.end()
+    cc.close()
+    srv.stop()
+
+
 def test_a_lone_query_is_not_held_longer_than_the_window(capi):
     srv = capi.ScanServer(batch_fn=fake_backend([]), vec_bytes=8, max_batch=64, max_wait_us=3000)
     c = capi.ScanClient(srv.host, srv.port)
