@@ -9,6 +9,13 @@ over one batch of synthetic queries that is already resident in HBM.  Queries sh
 with no collective (the index is replicated in each GPU's HBM), so scaling is weak: every rank
 searches its own `--queries` per step and `value` = all ranks' queries / max-over-ranks time.
 
+Multi-GPU: `python bench.py --gpus N` with no WORLD_SIZE in the environment re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (what the driver does itself for N > 1); a launch whose world size
+differs from --gpus is refused.  torch.distributed.run only LAUNCHES the ranks: the measuring processes never import
+PyTorch (it bundles a second HIP runtime).  The ranks rendezvous through a directory (lantern_amd/rendezvous.py), build
+ONE index together (lantern_gpu_add_sharded: RCCL all-gathers over xGMI of the top-M neighbour lists; every rank ends
+with a bit-identical replica), and then each searches its own queries on its replica.
+
 Besides the contract's fields the JSON line carries
   roofline      algorithmic bytes of the search kernel (D*d*4 + E*2M*4 + d*4 per query,
                 D and E counted on the device) / its average launch time (HIP events on the launch
@@ -52,37 +59,106 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--quant", default="f32", choices=["f32", "f16", "i8"], help="storage kind (reloption quant_bits 32 / 16 / 8); the headline config is f32")
-    p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo only to debug the N>1 path on one GPU")
+    p.add_argument("--dist-backend", default="rccl", choices=["rccl", "nccl", "files", "gloo"],
+                   help="exchange transport of the collective build at N>1: rccl (alias nccl; xGMI, data stays in HBM) or files (alias "
+                        "gloo: the host transport over the rendezvous directory -- debugging, or several ranks on one GPU)")
+    p.add_argument("--dry-run", action="store_true", help="launch, rendezvous, barrier and print the line's shape without touching a device (CPU test of the N>1 plumbing)")
+    p.add_argument("--build-quality-rows", type=int, default=100_000, help="rows of the build-quality leg (device batched build vs sequential CPU build; 0 = skip)")
     p.add_argument("--data", default="gaussian", choices=["gaussian", "lowrank"],
                    help="gaussian = the prescribed i.i.d. N(0,1) set (SURVEY 8d); lowrank = 32 latent dims embedded in --dim (embedding-like)")
     p.add_argument("--data-scale", type=float, default=1.0, help="multiply the synthetic rows and queries (i8 storage quantises [-1, 1]: use 0.3)")
-    p.add_argument("--sharded-build", default="auto", choices=["auto", "on", "off"],
-                   help="after the search measurement, build the same index ONCE across all ranks (RCCL all-gathers, one child "
-                        "process per GPU: lantern_amd/sharded_build.py) and report its rate; auto = when --gpus > 1")
-    p.add_argument("--sharded-build-timeout", type=float, default=420.0)
+    p.add_argument("--collective-timeout", type=float, default=180.0, help="deadline of every exchange of the collective build")
     return p.parse_args()
+
+
+def respawn_under_torchrun(a):
+    """`python bench.py --gpus N` typed by hand: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    (the command the driver issues itself), so the plain command measures N GPUs instead of silently measuring one."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.execvpe(cmd[0], cmd, env)
+
+
+def bring_up_comm(a, rdv, rank, world, capi):
+    """The exchange transport of the collective build.  RCCL first (data stays in HBM, xGMI); every rank reports whether
+    its communicator came up AND passed one small all-gather, and only if ALL did is it used -- otherwise every rank
+    switches to the host transport over the rendezvous directory (slower, but a broken fabric never costs the line)."""
+    import threading
+
+    note = None
+    want_rccl = a.dist_backend in ("rccl", "nccl")
+    if want_rccl:
+        box = {}
+
+        def attempt():
+            try:
+                uid = rdv.broadcast(capi.Comm.unique_id() if rank == 0 else None, 0, timeout=120.0)
+                c = capi.Comm.rccl(rank, world, uid)
+                c.set_timeout(60.0)
+                probe = np.zeros(8 * world, dtype=np.uint8)
+                probe[8 * rank: 8 * rank + 8] = rank + 1
+                c.allgatherv_host(probe, [8 * r for r in range(world)], [8] * world)
+                assert all(probe[8 * r] == r + 1 for r in range(world)), "RCCL all-gather returned wrong data"
+                box["comm"] = c
+            except Exception as e:  # noqa: BLE001
+                box["err"] = repr(e)
+
+        t = threading.Thread(target=attempt, daemon=True)  # ncclCommInitRank has no deadline of its own
+        t.start()
+        t.join(150.0)
+        ok = "comm" in box
+        verdicts = rdv.allgather((b"1" if ok else b"0") + (box.get("err", "timed out") if not ok else "").encode()[:300], timeout=300.0)
+        if all(v[:1] == b"1" for v in verdicts):
+            box["comm"].set_timeout(a.collective_timeout)
+            return box["comm"], "RCCL all-gather-v (grouped ncclBroadcast) on the index stream", None
+        note = "RCCL unavailable (" + "; ".join(f"rank {r}: {v[1:].decode(errors='replace')}" for r, v in enumerate(verdicts) if v[:1] != b"1") + ")"
+    c = capi.Comm.host(rank, world, rdv.allgatherv)
+    c.set_timeout(a.collective_timeout)
+    return c, "host transport over the rendezvous directory (D2H / files / H2D)", note
 
 
 def main():
     a = parse()
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if a.gpus > 1 and env_world == 0:
+        respawn_under_torchrun(a)  # does not return
+    world = env_world or 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    if world != a.gpus:
+        sys.exit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {a.gpus}: the line would claim the wrong GPU count; "
+                 f"pass --gpus {world} (or launch {a.gpus} ranks)")
+    rdv = None
     if world > 1:
-        # torch is plumbing here: rendezvous, barrier and the max-over-ranks reduction over RCCL.  It must
-        # be imported before the HIP library so both share one HIP runtime (lantern_amd/capi.py note).
-        import torch
-        import torch.distributed as dist
+        from lantern_amd import rendezvous
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        ndev = torch.cuda.device_count()
-        torch.cuda.set_device(local_rank % ndev)
-        if a.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % ndev))
-        else:
-            dist.init_process_group(backend=a.dist_backend)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # all ranks are on this node; the container's hostname may not resolve
+        rdv = rendezvous.FileRendezvous(rank, world)
+        rdv.barrier()
+
+    def finish(line):
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if rdv:
+            rdv.barrier()
+            rdv.cleanup()
+
+    if a.dry_run:  # the N>1 plumbing without a device: launch, world check, rendezvous, reductions, line shape
+        elapsed = rdv.max_float(0.001 * (rank + 1)) if rdv else 0.001
+        ranks = [int(x) for x in rdv.allgather(str(rank).encode())] if rdv else [0]
+        return finish({"metric": f"QPS (recall@{a.k} alongside), {a.n}x{a.dim} f32 {a.metric} ef={a.ef} k={a.k}", "value": None, "unit": "queries/s",
+                       "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3, "higher_is_better": True,
+                       "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True, "ranks_seen": ranks,
+                       "config": {"workload": f"HNSW search {a.n}x{a.dim} {a.quant} {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}",
+                                  "queries_per_step_per_gpu": a.queries, "global_queries_per_step": a.queries * world,
+                                  "parallelism": f"replicated index, query batch sharded x{world}, no collective"}})
 
     from lantern_amd import capi, hip
 
@@ -103,18 +179,63 @@ def main():
     labels = np.arange(a.n, dtype=np.uint64) + 1  # 0 is INVALID_ELEMENT_LABEL (hnsw.h:40)
     t_gen = time.time() - t0
 
-    # ---- build the index on this rank's GPU (replica per GPU; deterministic, so all replicas match)
+    # ---- the index.  One GPU: built here.  N GPUs: ONE collective build -- rank r contributes shard r of the rows, the
+    # work of every insertion batch is split over the ranks, the top-M neighbour lists and the re-written adjacency rows
+    # are all-gathered -- which leaves a bit-identical replica in every GPU's HBM: exactly what the
+    # query-sharded search leg needs.
     ix = capi.GpuIndex(a.metric, a.dim, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, quantization=a.quant)
     ix.reserve(a.n)
     ix.set_add_batch(a.add_batch, 16)
     ix.set_search_shape(a.waves, a.max_wg)
-    hip.synchronize()
-    t0 = time.time()
-    ix.add_many(labels, base)
-    ix.flush()
-    hip.synchronize()
-    t_build = time.time() - t0
+    ix.set_profiling(True)
+    collective = None
+    if world > 1:
+        comm, transport, note = bring_up_comm(a, rdv, rank, world, capi)
+        lo, hi = capi.shard_range(a.n, world, rank)
+        rdv.barrier()
+        hip.synchronize()
+        t0 = time.time()
+        err = None
+        try:
+            ix.add_sharded(comm, labels[lo:hi], np.ascontiguousarray(base[lo:hi]))
+            ix.flush()
+            hip.synchronize()
+        except Exception as e:  # noqa: BLE001 -- every rank fails together: a collective that misses its deadline fails on all
+            err = repr(e)
+        t_build = time.time() - t0
+        errs = [x.decode(errors="replace") for x in rdv.allgather((err or "").encode()[:400], timeout=a.collective_timeout + 60)]
+        if any(errs):
+            # the collective build failed: fall back to N independent builds of the same (deterministic) index so that the
+            # search measurement still stands; the failure is reported in the line
+            ix = capi.GpuIndex(a.metric, a.dim, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, quantization=a.quant)
+            ix.reserve(a.n)
+            ix.set_add_batch(a.add_batch, 16)
+            ix.set_search_shape(a.waves, a.max_wg)
+            ix.set_profiling(True)
+            hip.synchronize()
+            t0 = time.time()
+            ix.add_many(labels, base)
+            ix.flush()
+            hip.synchronize()
+            t_build = time.time() - t0
+            collective = {"error": next(e for e in errs if e), "fallback": "every rank built its own replica", "transport": transport, "transport_note": note}
+        else:
+            sums = [x.decode() for x in rdv.allgather(f"{ix.checksum():016x}".encode())]
+            stats = comm.stats()
+            collective = {"world": world, "seconds": rdv.max_float(t_build), "transport": transport, "transport_note": note,
+                          "replicas_identical": len(set(sums)) == 1, "checksum": sums[0],
+                          "bytes_received_per_rank": [int(x) for x in rdv.allgather(str(stats["bytes_received"]).encode())],
+                          "collectives": stats["collectives"]}
+            collective["vectors_per_s"] = a.n / collective["seconds"]
+    else:
+        hip.synchronize()
+        t0 = time.time()
+        ix.add_many(labels, base)
+        ix.flush()
+        hip.synchronize()
+        t_build = time.time() - t0
     build_counters = ix.counters()
+    build_profile = ix.build_profile()
 
     # ---- this rank's queries, resident in HBM ----------------------------------------------------
     qrng = np.random.default_rng(4 + 1000 * rank)
@@ -130,8 +251,8 @@ def main():
 
     def barrier():
         hip.synchronize()
-        if world > 1:
-            dist.barrier()
+        if rdv:
+            rdv.barrier()
         hip.synchronize()
 
     for _ in range(a.warmup):
@@ -146,17 +267,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [s.elapsed_ms(e) for s, e in ev]  # HIP events on the launch stream: one search launch each
-    if world > 1:
-        import torch
-
-        from lantern_amd import sharded
-
-        elapsed = sharded.max_over_ranks(elapsed, device=torch.device("cuda", dev_index) if a.dist_backend == "nccl" else None)
-
-    # ---- work-sharded build of the same index across all ranks, in child processes ----------
-    sharded_res = None
-    if a.sharded_build == "on" or (a.sharded_build == "auto" and world > 1):
-        sharded_res = sharded_build_leg(a, rank, world, dev_index, dist, ix if rank == 0 else None)
+    if rdv:
+        elapsed = rdv.max_float(elapsed)
 
     # ---- algorithmic bytes of one launch --------------------------------------------
     D = d_D.download(nq, np.uint64).astype(np.float64)
@@ -214,88 +326,39 @@ def main():
             "build_batches": build_counters["add_batches"],
             "build_counters_per_vector": {k: build_counters[k] / a.n for k in ("add_walk_evals", "add_select_evals", "add_revlink_evals",
                                                                                  "add_reprunes", "add_expansions")},
+            "build_roofline": build_roofline(a, build_counters, build_profile, t_build, world),
             "dist_evals_per_query": float(D.mean()),
             "expansions_per_query": float(E.mean()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command; not re-measured in this run)" if traffic else None,
+                         "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": avg_kernel_s * 1e3},
             "cpu_baseline": cpu,
-            "sharded_build": sharded_res,
+            "collective_build": collective,
             "setup_seconds": {"datagen": t_gen, "build": t_build, "exact_truth": t_truth},
         }
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(out)
 
 
-def sharded_build_leg(a, rank, world, dev_index, dist, ix0):
-    """One lantern_amd.sharded_build child per rank (own process: ROCm's HIP + RCCL, no torch), all building ONE index
-    together.  Returns rank 0's summary (None on the other ranks); a failure is reported, never raised: this leg runs
-    after the search measurement and must not cost the benchmark line."""
-    import shutil
-    import subprocess
-    import tempfile
-
-    rdv = None
-    try:
-        if rank == 0:
-            rdv = tempfile.mkdtemp(prefix="lantern_rdv_")
-        if world > 1:
-            box = [rdv]
-            dist.broadcast_object_list(box, src=0)
-            rdv = box[0]
-        # whatever happens to this rank's child, the rank still takes part in the gather below (a rank that skipped it
-        # would leave its peers waiting in a collective)
-        wall = 0.0
-        try:
-            cmd = [sys.executable, "-m", "lantern_amd.sharded_build", "--rank", str(rank), "--world", str(world), "--rendezvous", rdv,
-                   "--device", str(dev_index), "--rows", str(a.n), "--dim", str(a.dim), "--metric", a.metric, "--M", str(a.M),
-                   "--efc", str(a.efc), "--ef", str(a.ef), "--add-batch", str(a.add_batch), "--quant", a.quant, "--data", a.data,
-                   "--data-scale", str(a.data_scale)]
-            env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
-            env.setdefault("NCCL_SOCKET_IFNAME", "lo")  # all ranks are on this node; the container's hostname may not resolve
-            t0 = time.time()
-            try:
-                cp = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=a.sharded_build_timeout)
-                rc, text = cp.returncode, cp.stdout + cp.stderr
-            except subprocess.TimeoutExpired as e:
-                rc, text = -9, f"timed out after {a.sharded_build_timeout} s: " + str(e.stdout or "")[-400:]
-            wall = time.time() - t0
-            res = None
-            for line in text.splitlines():
-                if line.startswith("SHARDED_BUILD "):
-                    res = json.loads(line[len("SHARDED_BUILD "):])
-            mine = res if (rc == 0 and res) else {"error": f"rank {rank}: exit {rc}: " + text[-600:]}
-        except Exception as e:  # noqa: BLE001
-            mine = {"error": f"rank {rank}: {e!r}"}
-        if world > 1:
-            every = [None] * world
-            dist.all_gather_object(every, mine)
-        else:
-            every = [mine]
-        if rank != 0:
-            return None
-        bad = [r for r in every if "error" in r]
-        if bad:
-            return {"error": bad[0]["error"], "ranks_failed": len(bad), "world": world}
-        secs = max(r["seconds"] for r in every)
-        sums = sorted({r["checksum"] for r in every})
-        ref = f"{ix0.checksum():016x}"
-        return {
-            "world": world, "seconds": secs, "vectors_per_s": a.n / secs, "child_wall_seconds": wall,
-            "replicas_identical": len(sums) == 1, "identical_to_single_gpu_build": sums == [ref],
-            "checksum": sums[0], "single_gpu_checksum": ref,
-            "bytes_received_per_rank": [r["exchange"]["bytes_received"] for r in every],
-            "collectives": every[0]["exchange"]["collectives"],
-            "walk_evals_per_rank": [r["counters"]["add_walk_evals"] for r in every],
-            "transport": every[0]["transport"],
-        }
-    except Exception as e:  # noqa: BLE001 -- reported in the line
-        return {"error": repr(e)} if rank == 0 else None
-    finally:
-        if rank == 0 and rdv:
-            shutil.rmtree(rdv, ignore_errors=True)
+def build_roofline(a, c, prof, t_build, world):
+    """Per-phase time of the build (HIP events recorded inside the library around each phase of every batch) against
+    the algorithmic traffic of that phase (SURVEY.md 8d "Build unit of work"): the walk reads one row per distance
+    evaluation and one adjacency row per expansion; a re-prune needs the cap+1 candidate rows and `close`'s once."""
+    if not prof or not prof.get("batches"):
+        return None
+    row = a.dim * {"f32": 4, "f16": 2, "i8": 1}[a.quant]
+    scale = 1.0 / max(world, 1)  # counters and event times are this rank's share of a collective build
+    walk_bytes = c["add_walk_evals"] * row + c["add_expansions"] * (2 * a.M * 4)
+    reprune_bytes = c["add_reprunes"] * (2 * a.M + 2) * row
+    out = {"note": "achieved = algorithmic bytes / time of that phase's kernels (HIP events inside the library); peak 8 TB/s HBM",
+           "phases_ms": {k: prof[k] for k in ("walk_ms", "connect_ms", "group_ms", "revlink_ms", "exchange_ms")},
+           "device_ms_total": sum(prof[k] for k in ("walk_ms", "connect_ms", "group_ms", "revlink_ms", "exchange_ms")),
+           "host_and_idle_ms": max(0.0, t_build * 1e3 - sum(prof[k] for k in ("walk_ms", "connect_ms", "group_ms", "revlink_ms", "exchange_ms")))}
+    for name, nbytes, ms in (("walk", walk_bytes, prof["walk_ms"]), ("reprune", reprune_bytes, prof["revlink_ms"])):
+        gbs = nbytes / max(ms, 1e-9) / 1e6
+        out[name] = {"bound": "hbm", "algorithmic_bytes": float(nbytes), "ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbs / HBM_PEAK_GBS}
+    return out
 
 
 def usable_cores() -> int:

@@ -267,6 +267,18 @@ typedef struct lantern_gpu_counters
 } lantern_gpu_counters;
 LANTERN_GPU_EXPORT lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t, usearch_error_t *);
 
+/* Build profile: with profiling on, every insertion batch is bracketed by HIP events on the index stream (phase by phase);
+ * the sums are milliseconds of device time per phase since init.  walk = k_insert (+ the batch layout), connect =
+ * k_connect, group = the request grouping (+ exchange 1 of a sharded build), revlink = append + re-prune kernels,
+ * exchange = exchange 2 of a sharded build (0 on one GPU). */
+typedef struct lantern_gpu_build_profile
+{
+    double   walk_ms, connect_ms, group_ms, revlink_ms, exchange_ms;
+    uint64_t batches;
+} lantern_gpu_build_profile;
+LANTERN_GPU_EXPORT void lantern_gpu_set_profiling(usearch_index_t, int on, usearch_error_t *);
+LANTERN_GPU_EXPORT lantern_gpu_build_profile lantern_gpu_build_profile_get(usearch_index_t, usearch_error_t *);
+
 /* order-independent-of-builder fingerprint of the graph (levels, labels, both adjacency arrays, entry point):
  * equal on two indexes iff they hold the same graph; used to check that replicas agree without moving them */
 LANTERN_GPU_EXPORT uint64_t lantern_gpu_graph_checksum(usearch_index_t, usearch_error_t *);

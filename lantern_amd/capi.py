@@ -73,6 +73,10 @@ class Counters(C.Structure):
                                           "add_revlink_evals", "add_reprunes")]
 
 
+class BuildProfile(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("walk_ms", "connect_ms", "group_ms", "revlink_ms", "exchange_ms")] + [("batches", C.c_uint64)]
+
+
 EXPORTS = [
     "usearch_init", "usearch_free", "usearch_reserve", "usearch_size", "usearch_capacity", "usearch_dimensions",
     "usearch_add", "usearch_add_external", "usearch_search_ef", "lantern_gpu_cursor_open", "lantern_gpu_cursor_search",
@@ -84,7 +88,7 @@ EXPORTS = [
     "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device",
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
-    "lantern_gpu_counters_get", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
+    "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
     "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist", "lantern_index_server_start",
     "lantern_index_server_port", "lantern_index_server_status_port", "lantern_index_server_status",
     "lantern_index_server_served", "lantern_index_server_stop",
@@ -168,6 +172,8 @@ def lib() -> C.CDLL:
         "lantern_gpu_export_graph": (None, [vp, vp, vp, vp, vp, vp, vp, err]),
         "lantern_gpu_import_graph": (None, [vp, sz, vp, vp, vp, vp, vp, vp, u32, C.c_int32, err]),
         "lantern_gpu_counters_get": (Counters, [vp, err]),
+        "lantern_gpu_set_profiling": (None, [vp, i32, err]),
+        "lantern_gpu_build_profile_get": (BuildProfile, [vp, err]),
         "lantern_scan_begin": (vp, [vp, i32, i32, err]),
         "lantern_scan_rescan": (None, [vp, vp, i32, err]),
         "lantern_scan_gettuple": (C.c_bool, [vp, C.POINTER(u64), err]),
@@ -443,6 +449,13 @@ class GpuIndex:
     def counters(self):
         c = _call("lantern_gpu_counters_get", self.h)
         return {n: int(getattr(c, n)) for n, _ in Counters._fields_}
+
+    def set_profiling(self, on=True):
+        _call("lantern_gpu_set_profiling", self.h, 1 if on else 0)
+
+    def build_profile(self):
+        p = _call("lantern_gpu_build_profile_get", self.h)
+        return {n: (int(getattr(p, n)) if n == "batches" else float(getattr(p, n))) for n, _ in BuildProfile._fields_}
 
     def metadata(self):
         return _call("usearch_index_metadata", self.h)

@@ -1,0 +1,122 @@
+// grouping.hip -- the reverse-link requests of one insertion batch, grouped on the device.
+//
+// k_connect leaves one request (close, level, new_slot, d) per selected neighbour, new-slot-major, with EMPTY entries
+// where a node kept fewer than M (kernels.hpp LinkReq).  The reverse-link kernels want them grouped by (close, level)
+// with every group in new-slot order -- the order the sequential algorithm (usearch reconnect_neighbor_nodes_, reached
+// from usearch_add: lantern_hnsw/src/hnsw/build.c:128) applies them in.  Round 1 did this on the host: D2H of the
+// requests, a stable LSD radix sort, H2D, one stream synchronisation per batch (284 per 1M build).  Here:
+//
+//   k_link_keys     key = close << 8 | level (40 bits; EMPTY or not-owned -> all ones), value = position
+//   rocPRIM         stable radix sort of (key, position) over the 40 key bits   [library sort: not a hot op]
+//   k_gather_heads  sorted[j] = links[position[j]]; a thread whose key differs from its left neighbour's opens a
+//                   group: it scans to the group's end and appends {begin, end} to the group list (atomic counter;
+//                   groups are independent of one another, so their order is immaterial)
+//   k_batch_layout  link_off / item_node of a batch from the levels already in HBM
+//
+// so a build's batches queue up on the stream back to back.
+#include <cstring>  // rocPRIM's headers use memset without including it
+#include <hip/hip_runtime.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "kernels.hpp"
+
+namespace lgpu {
+
+namespace {
+constexpr uint64_t KEY_NONE = (1ull << 40) - 1;  // sorts behind every real key (close < 2^31)
+
+__global__ void __launch_bounds__(256) k_link_keys(const LinkReq *links, uint32_t n, uint64_t *keys, uint32_t *idx, uint32_t *ngroups, int world,
+                                                   int rank, uint32_t *owner_counts)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i == 0) *ngroups = 0;
+    if(i >= n) return;
+    const LinkReq r = links[ i ];
+    uint64_t      k = KEY_NONE;
+    if(r.close != EMPTY) {
+        bool mine = true;
+        if(world > 1) {  // a rank of a work-sharded build applies the groups of the nodes it owns and counts the others'
+            const uint32_t o = r.close % (uint32_t)world;
+            atomicAdd(&owner_counts[ o ], 1u);
+            mine = (int)o == rank;
+        }
+        if(mine) k = ((uint64_t)r.close << 8) | (uint64_t)(r.level & 0xFFu);
+    }
+    keys[ i ] = k;
+    idx[ i ] = i;
+}
+
+__global__ void __launch_bounds__(256) k_gather_heads(const LinkReq *links, uint32_t n, const uint64_t *keys, const uint32_t *idx, LinkReq *sorted,
+                                                      uint2 *groups, uint32_t *ngroups)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= n) return;
+    const uint64_t k = keys[ j ];
+    if(k == KEY_NONE) return;
+    sorted[ j ] = links[ idx[ j ] ];
+    if(j != 0 && keys[ j - 1 ] == k) return;
+    uint32_t e = j + 1;
+    while(e < n && keys[ e ] == k) ++e;
+    const uint32_t g = atomicAdd(ngroups, 1u);
+    groups[ g ] = make_uint2(j, e);
+}
+
+// one block: exclusive scan of (level + 1) over the batch
+__global__ void __launch_bounds__(1024) k_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, uint32_t *link_off, uint32_t *item_node)
+{
+    __shared__ uint32_t part[ 1024 ];
+    const uint32_t tid = threadIdx.x, per = (b + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = lo + per < b ? lo + per : b;
+    uint32_t       sum = 0;
+    for(uint32_t i = lo; i < hi; ++i) sum += (uint32_t)levels[ i ] + 1u;
+    part[ tid ] = sum;
+    __syncthreads();
+    for(uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        const uint32_t v = tid >= off ? part[ tid - off ] : 0u;
+        __syncthreads();
+        part[ tid ] += v;
+        __syncthreads();
+    }
+    uint32_t item = part[ tid ] - sum;  // exclusive prefix: first item of this thread's first node
+    for(uint32_t i = lo; i < hi; ++i) {
+        link_off[ i ] = item * M;
+        const uint32_t cnt = (uint32_t)levels[ i ] + 1u;
+        for(uint32_t l = 0; l < cnt; ++l) item_node[ item + l ] = i;
+        item += cnt;
+    }
+}
+}  // namespace
+
+size_t group_temp_bytes(size_t n)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    n ? n : 1, 0u, 40u, (hipStream_t) nullptr);
+    return bytes;
+}
+
+hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupScratch &gs, LinkReq *sorted, uint2 *groups, uint32_t *ngroups,
+                                 int world, int rank, uint32_t *owner_counts, hipStream_t stream)
+{
+    if(n == 0) return hipMemsetAsync(ngroups, 0, 4, stream);
+    hipError_t e = hipSuccess;
+    if(world > 1 && (e = hipMemsetAsync(owner_counts, 0, (size_t)world * 4, stream)) != hipSuccess) return e;
+    const uint32_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_link_keys, dim3(blocks), dim3(256), 0, stream, links, n, gs.keys_a, gs.idx_a, ngroups, world, rank, owner_counts);
+    size_t temp = gs.temp_bytes;
+    e = rocprim::radix_sort_pairs(gs.temp, temp, (const uint64_t *)gs.keys_a, gs.keys_b, (const uint32_t *)gs.idx_a, gs.idx_b, (size_t)n, 0u, 40u, stream);
+    if(e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gather_heads, dim3(blocks), dim3(256), 0, stream, links, n, (const uint64_t *)gs.keys_b, (const uint32_t *)gs.idx_b, sorted, groups,
+                       ngroups);
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, uint32_t *link_off, uint32_t *item_node, hipStream_t stream)
+{
+    if(b == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_batch_layout, dim3(1), dim3(1024), 0, stream, levels, b, M, link_off, item_node);
+    return hipGetLastError();
+}
+
+}  // namespace lgpu

@@ -221,34 +221,12 @@ int search_grid(const Index *ix, size_t nq, int waves, int waves_per_cu)
 // inserts
 // ---------------------------------------------------------------------------------------------------
 
-// Stable LSD radix sort of the reverse-link requests by (close, level); requests arrive in new-slot
-// order and the sort is stable, so every group ends up in new-slot order (the order the sequential
-// algorithm applies them in).
-static void sort_requests(std::vector<LinkReq> &h, std::vector<LinkReq> &tmp)
-{
-    const size_t m = h.size();
-    tmp.resize(m);
-    LinkReq *src = h.data(), *dst = tmp.data();
-    auto key = [](const LinkReq &r) { return ((uint64_t)r.close << 8) | (uint64_t)(r.level & 0xFF); };  // 40 bits
-    uint64_t all = 0;
-    for(size_t i = 0; i < m; ++i) all |= key(h[ i ]);
-    int passes = 0;
-    while(passes < 4 && (all >> (passes * 10)) != 0) ++passes;
-    if(passes & 1) ++passes;  // an even number of passes leaves the result in h
-    for(int pass = 0; pass < passes; ++pass) {  // up to 4 x 10 bits
-        const int shift = pass * 10;
-        uint32_t  hist[ 1025 ] = { 0 };
-        for(size_t i = 0; i < m; ++i) hist[ ((key(src[ i ]) >> shift) & 1023) + 1 ]++;
-        for(int b = 0; b < 1024; ++b) hist[ b + 1 ] += hist[ b ];
-        for(size_t i = 0; i < m; ++i) dst[ hist[ (key(src[ i ]) >> shift) & 1023 ]++ ] = src[ i ];
-        std::swap(src, dst);
-    }
-    // an even number of passes: the result is back in h
-}
-
 // One device pass over `b` new vectors whose rows / labels / levels / upper offsets are ALREADY in HBM at
 // slots [first, first + b) (flush_locked uploads everything pending up front: an unlinked node is
-// unreachable, so its row may sit in the table before its batch runs).
+// unreachable, so its row may sit in the table before its batch runs).  Nothing in here waits for the device on one
+// GPU: layout, walk, selection, the grouping of the reverse-link requests (grouping.hip) and the reverse-link kernels
+// are queued on the index stream, and the next batch is queued right behind them (the host knows sizes, levels and the
+// entry point of every batch in advance; only the graph itself is device state).
 // Work-sharded build (comm != nullptr): the batch is the same as on one GPU, but every rank
 // walks and connects only its share [b_lo, b_hi) of the new nodes, the ranks all-gather the resulting top-M
 // neighbour lists (= the reverse-link requests: 16 bytes per pick), each rank applies the reverse links of the
@@ -269,13 +247,56 @@ static bool sync_stream(Index *ix, Comm *comm)
     return true;
 }
 
+// ---- build profile: HIP events around the phases of every batch, resolved lazily (never a wait on fresh work) -----
+static const int kProfMarks = 6;  // start | walk | connect | exchange 1 + grouping | reverse links | exchange 2
+static hipEvent_t prof_event(Index *ix)
+{
+    if(!ix->prof_free.empty()) {
+        hipEvent_t e = ix->prof_free.back();
+        ix->prof_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if(hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+static void prof_mark(Index *ix, int which)
+{
+    if(!ix->profiling) return;
+    if(which == 0) ix->prof_pending.emplace_back();
+    hipEvent_t e = prof_event(ix);
+    ix->prof_pending.back().ev[ which ] = e;
+    if(e) (void)hipEventRecord(e, ix->stream);
+}
+void prof_resolve(Index *ix, size_t keep)
+{
+    while(ix->prof_pending.size() > keep) {
+        Index::ProfBatch &pb = ix->prof_pending.front();
+        bool ok = true;
+        for(int i = 0; i < kProfMarks; ++i) ok = ok && pb.ev[ i ] != nullptr;
+        if(ok && hipEventSynchronize(pb.ev[ kProfMarks - 1 ]) == hipSuccess) {
+            float ms[ kProfMarks - 1 ] = {};
+            for(int i = 0; i + 1 < kProfMarks; ++i) (void)hipEventElapsedTime(&ms[ i ], pb.ev[ i ], pb.ev[ i + 1 ]);
+            ix->prof.walk_ms += ms[ 0 ];
+            ix->prof.connect_ms += ms[ 1 ];
+            ix->prof.group_ms += ms[ 2 ];
+            ix->prof.revlink_ms += ms[ 3 ];
+            ix->prof.exchange_ms += ms[ 4 ];
+            ix->prof.batches += 1;
+        }
+        for(int i = 0; i < kProfMarks; ++i)
+            if(pb.ev[ i ]) ix->prof_free.push_back(pb.ev[ i ]);
+        ix->prof_pending.pop_front();
+    }
+}
+
 static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
 {
     const size_t first = ix->n;
     const int    W = comm ? comm->world : 1, R = comm ? comm->rank : 0;
     const bool   split = W > 1 && b >= (size_t)W * kShardMinPerRank;
     const size_t b_lo = split ? b * (size_t)R / (size_t)W : 0, b_hi = split ? b * ((size_t)R + 1) / (size_t)W : b;
-    std::vector<uint32_t> &link_off = ix->h_link_off;
+    std::vector<uint32_t> &link_off = ix->h_link_off;  // host copy: sizes the exchanges and the launches (never uploaded)
     link_off.resize(b);
     size_t total_links = 0;
     for(size_t i = 0; i < b; ++i) {
@@ -284,17 +305,30 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     }
     // one "item" per (new node, level): the walk result the selection kernel works on
     const size_t items = total_links / ix->M;
-    std::vector<uint32_t> &item_node = ix->h_item_node;
-    item_node.resize(items);
-    for(size_t i = 0, it = 0; i < b; ++i)
-        for(int l = 0; l <= lv[ i ]; ++l) item_node[ it++ ] = (uint32_t)i;
     uint32_t *d_link_off = (uint32_t *)scratch(ix, 0, b * 4 + items * 4 + items * 4);
     LinkReq  *d_links = (LinkReq *)scratch(ix, 1, total_links * sizeof(LinkReq));
     uint64_t *d_tops = (uint64_t *)scratch(ix, 7, items * (size_t)ix->efc * 8);
-    if(!d_link_off || !d_links || !d_tops) return false;
+    LinkReq  *d_reqs = (LinkReq *)scratch(ix, 2, total_links * sizeof(LinkReq));
+    // groups | ngroups | owner counts
+    char     *d_grp = (char *)scratch(ix, 3, total_links * sizeof(uint2) + 16 + (size_t)W * 4);
+    void     *d_work = scratch(ix, 4, total_links * 8 + 16);
+    const size_t temp_bytes = group_temp_bytes(total_links);
+    char     *d_sort = (char *)scratch(ix, 8, total_links * 24 + temp_bytes + 64);
+    if(!d_link_off || !d_links || !d_tops || !d_reqs || !d_grp || !d_work || !d_sort) return false;
     uint32_t *d_item_node = d_link_off + b, *d_top_count = d_item_node + items;
-    HIPCHK(ix, hipMemcpyAsync(d_link_off, link_off.data(), b * 4, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(ix, hipMemcpyAsync(d_item_node, item_node.data(), items * 4, hipMemcpyHostToDevice, ix->stream));
+    uint2    *d_groups = (uint2 *)d_grp;
+    uint32_t *d_ngroups = (uint32_t *)(d_grp + total_links * sizeof(uint2));
+    uint32_t *d_owner = d_ngroups + 4;
+    GroupScratch gs;
+    gs.keys_a = (uint64_t *)d_sort;
+    gs.keys_b = gs.keys_a + total_links;
+    gs.idx_a = (uint32_t *)(gs.keys_b + total_links);
+    gs.idx_b = gs.idx_a + total_links;
+    gs.temp = (void *)(((uintptr_t)(gs.idx_b + total_links) + 63) & ~(uintptr_t)63);
+    gs.temp_bytes = temp_bytes;
+
+    prof_mark(ix, 0);
+    HIPCHK(ix, launch_batch_layout(ix->d_levels + first, (uint32_t)b, ix->M, d_link_off, d_item_node, ix->stream));
 
     const int grid = search_grid(ix, b_hi - b_lo, ix->insert_waves, 20);
     if(!ensure_bitmaps(ix, (size_t)grid)) return false;
@@ -325,6 +359,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
     HIPCHK(ix, launch_insert(ix->mcode, ia, ix->insert_waves, grid, ix->stream));
     if(!record_launch(ix, ix->stream)) return false;
+    prof_mark(ix, 1);
 
     ConnectArgs ca;
     ca.view = ia.view;
@@ -339,6 +374,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     ca.links = d_links;
     ca.totals = ix->d_totals + 4;
     HIPCHK(ix, launch_connect(ix->mcode, ca, ix->stream));
+    prof_mark(ix, 2);
 
     if(split) {
         // exchange 1: the ranks' top-M neighbour lists (one LinkReq per pick).  Afterwards every rank holds all
@@ -353,64 +389,25 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
         HIPCHK(ix, launch_apply_own_links(ia.view, (uint32_t)first, d_link_off, d_links, (uint32_t)total_links, ix->stream));
     }
 
-    // pinned landing buffer for the requests
-    if(ix->h_links_cap < total_links) {
-        if(ix->h_links) (void)hipHostFree(ix->h_links);
-        ix->h_links = nullptr;
-        ix->h_links_cap = 0;
-        HIPCHK(ix, hipHostMalloc((void **)&ix->h_links, (total_links + total_links / 2 + 64) * sizeof(LinkReq), hipHostMallocDefault));
-        ix->h_links_cap = total_links + total_links / 2 + 64;
+    // reverse links: group by (close, level); within a group apply in new-slot order -- on the device (grouping.hip).
+    // In a sharded batch a rank keeps only the groups of the nodes it owns (close % world) and counts the others'
+    // (the sizes of the second exchange's segments must be known to every rank's HOST: the one value read back).
+    HIPCHK(ix, launch_group_requests(d_links, (uint32_t)total_links, gs, d_reqs, d_groups, d_ngroups, split ? W : 1, R, d_owner, ix->stream));
+    std::vector<uint32_t> owner_reqs((size_t)W, 0);
+    if(split) {
+        HIPCHK(ix, hipMemcpyAsync(owner_reqs.data(), d_owner, (size_t)W * 4, hipMemcpyDeviceToHost, ix->stream));
+        if(!sync_stream(ix, comm)) return false;
     }
-    LinkReq *hl = (LinkReq *)ix->h_links;
-    HIPCHK(ix, hipMemcpyAsync(hl, d_links, total_links * sizeof(LinkReq), hipMemcpyDeviceToHost, ix->stream));
-    if(!sync_stream(ix, comm)) return false;
-
-    // reverse links: group by (close, level); within a group apply in new-slot order.  In a sharded batch a
-    // rank keeps only the groups of the nodes it owns (close % world) and counts the others' (the sizes of
-    // the second exchange's segments must be known to everybody without another round trip).
-    std::vector<LinkReq> &h = ix->h_reqs;
-    h.clear();
-    h.reserve(split ? total_links / (size_t)W + 64 : total_links);
-    std::vector<size_t> owner_reqs((size_t)W, 0);
-    for(size_t i = 0; i < total_links; ++i) {
-        if(hl[ i ].close == EMPTY) continue;
-        if(split) {
-            const size_t o = hl[ i ].close % (uint32_t)W;
-            owner_reqs[ o ]++;
-            if((int)o != R) continue;
-        }
-        h.push_back(hl[ i ]);
-    }
-    // k_insert emits per node, per level; make the stream new-slot-major before the stable sort
-    // (it already is: nodes are laid out in slot order and a node's requests are contiguous)
-    sort_requests(h, ix->h_reqs_tmp);
-    const size_t m = h.size();
-    std::vector<uint32_t> &gb = ix->h_group_begin;
-    gb.clear();
-    for(size_t i = 0; i < m; ++i)
-        if(i == 0 || h[ i ].close != h[ i - 1 ].close || h[ i ].level != h[ i - 1 ].level) gb.push_back((uint32_t)i);
-    const uint32_t ngroups = (uint32_t)gb.size();
-    gb.push_back((uint32_t)m);
+    prof_mark(ix, 3);
     RevlinkArgs ra;
     ra.view = ix->view();
-    ra.ngroups = 0;
-    ra.group_begin = nullptr;
-    ra.reqs = nullptr;
+    ra.ngroups = d_ngroups;
+    ra.groups = d_groups;
+    ra.max_groups = split ? owner_reqs[ (size_t)R ] : (uint32_t)total_links;
+    ra.reqs = d_reqs;
     ra.totals = ix->d_totals + 5;
-    if(ngroups) {
-        LinkReq  *d_reqs = (LinkReq *)scratch(ix, 2, m * sizeof(LinkReq));
-        uint32_t *d_gb = (uint32_t *)scratch(ix, 3, gb.size() * 4);
-        if(!d_reqs || !d_gb) return false;
-        HIPCHK(ix, hipMemcpyAsync(d_reqs, h.data(), m * sizeof(LinkReq), hipMemcpyHostToDevice, ix->stream));
-        HIPCHK(ix, hipMemcpyAsync(d_gb, gb.data(), gb.size() * 4, hipMemcpyHostToDevice, ix->stream));
-        ra.ngroups = ngroups;
-        ra.group_begin = d_gb;
-        ra.reqs = d_reqs;
-        void *d_work = scratch(ix, 4, (size_t)ngroups * 8 + 16);
-        if(!d_work) return false;
-        HIPCHK(ix, launch_revlink(ix->mcode, ra, (char *)d_work + 16, (uint32_t *)d_work, ix->num_cus, ix->stream));
-        if(!split) HIPCHK(ix, hipStreamSynchronize(ix->stream));  // h / gb are reused by the next batch
-    }
+    HIPCHK(ix, launch_revlink(ix->mcode, ra, (char *)d_work + 16, (uint32_t *)d_work, ix->num_cus, ix->stream));
+    prof_mark(ix, 4);
     if(split) {
         // exchange 2: the adjacency rows the ranks re-wrote, one record [close, level, list[0..M0)] per group.
         // A rank's segment is sized by the number of requests it owned (>= its number of groups; every rank can
@@ -431,8 +428,10 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
             if(!comm->allgatherv_device(d_rec, off.data(), cnt.data(), ix->stream)) { set_err(ix, comm->err); return false; }
             HIPCHK(ix, launch_apply_lists(ra.view, (const uint32_t *)d_rec, (uint32_t)total_recs, ix->stream));
         }
-        if(!sync_stream(ix, comm)) return false;  // h / gb / the staging buffers are reused by the next batch
+        if(!sync_stream(ix, comm)) return false;  // the host transport's staging buffers are reused by the next batch
     }
+    prof_mark(ix, 5);
+    if(ix->profiling) prof_resolve(ix, 192);  // only batches the device finished long ago are waited for
     ix->n = first + b;
     if(b == 1 && lv[ 0 ] > ix->max_level) {  // "Updating the entry point if needed"
         ix->entry = (uint32_t)first;
@@ -487,6 +486,10 @@ static size_t run_batches(Index *ix, const uint64_t *labels, const StagedMeta &s
         if(!(ok = run_batch(ix, b, s.lv.data() + pi, comm))) break;
         pi += b;
     }
+    // the batches were queued without waiting for the device: one synchronisation per flush surfaces a failure and makes
+    // the scratch buffers safe to re-size
+    if(ok && !sync_stream(ix, comm)) ok = false;
+    if(ix->profiling) prof_resolve(ix, 0);
     // host mirrors of what was inserted
     ix->labels.insert(ix->labels.end(), labels, labels + pi);
     ix->levels.insert(ix->levels.end(), s.l8.begin(), s.l8.begin() + (ptrdiff_t)pi);
@@ -821,7 +824,8 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
         if(p) (void)hipFree(p);
     for(void *p : ix->d_scratch)
         if(p) (void)hipFree(p);
-    if(ix->h_links) (void)hipHostFree(ix->h_links);
+    prof_resolve(ix, 0);
+    for(hipEvent_t ev : ix->prof_free) (void)hipEventDestroy(ev);
     if(ix->h_single) (void)hipHostFree(ix->h_single);
     if(ix->launch_done) (void)hipEventDestroy(ix->launch_done);
     delete ix;
@@ -1368,6 +1372,28 @@ lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t h, usearch_error_t
     c.add_revlink_evals = t[ 5 ];
     c.add_reprunes = t[ 6 ];
     return c;
+}
+
+void lantern_gpu_set_profiling(usearch_index_t h, int on, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->profiling = on != 0;
+}
+
+lantern_gpu_build_profile lantern_gpu_build_profile_get(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    lantern_gpu_build_profile out;
+    std::memset(&out, 0, sizeof(out));
+    Index *ix = H(h, e);
+    if(!ix) return out;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return out; }
+    prof_resolve(ix, 0);
+    return ix->prof;
 }
 
 lantern_gpu_graph_info lantern_gpu_graph_info_get(usearch_index_t h, usearch_error_t *e)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <deque>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -58,8 +59,8 @@ struct Index
     unsigned long long *d_totals = nullptr;  // [0..1] search D,E  [2..4] insert D,E,refine  [5] revlink pairs
 
     // scratch (grown on demand)
-    void  *d_scratch[ 8 ] = {};
-    size_t scratch_bytes[ 8 ] = {};
+    void  *d_scratch[ 12 ] = {};
+    size_t scratch_bytes[ 12 ] = {};
 
     // ---- host mirrors ------------------------------------------------------------------------------
     std::vector<uint64_t> labels;
@@ -72,11 +73,15 @@ struct Index
     std::vector<uint32_t> pend_rows;    // chunks*4 words per pending vector, zero padded
     std::vector<int>      pend_levels;  // -1 = draw with level_for()
 
-    // reusable host staging for the batch loop
-    std::vector<uint32_t> h_link_off, h_group_begin, h_item_node;
-    std::vector<LinkReq>  h_reqs, h_reqs_tmp;
-    void  *h_links = nullptr;  // pinned
-    size_t h_links_cap = 0;
+    // host copy of a batch's layout (sizes the launches and the exchanges; the device derives its own from the levels)
+    std::vector<uint32_t> h_link_off;
+
+    // ---- build profile (lantern_gpu_set_profiling): HIP events around the phases of every batch
+    struct ProfBatch { hipEvent_t ev[ 6 ] = {}; };
+    bool                    profiling = false;
+    std::deque<ProfBatch>   prof_pending;
+    std::vector<hipEvent_t> prof_free;
+    lantern_gpu_build_profile prof{};
 
     // ---- streaming continuation of usearch_search_ef (scan.c:273-281) ----------------------------
     // In the reference every scan owns its own usearch handle (scan.c:99), so "what this scan has been handed so far"
@@ -138,6 +143,7 @@ size_t      search_one_locked(Index *ix, Cursor *cur, const void *query, int kin
                               uint64_t *labels, float *distances);
 // usearch_size of the index: for a mirror, the header's count plus what was inserted since
 inline size_t logical_size(const Index *ix) { return ix->page_mode ? ix->page_declared + (ix->n - ix->page_attach_n) : ix->n; }
+void        prof_resolve(Index *ix, size_t keep);          // fold finished batches' event times into ix->prof
 bool        order_launch(Index *ix, hipStream_t stream);   // before a launch that uses the index's shared scratch
 bool        record_launch(Index *ix, hipStream_t stream);  // behind it
 bool        import_graph_locked(Index *ix, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,

@@ -21,7 +21,9 @@
 //
 // HBM-bound by design: every row is read with 16-byte-per-lane coalesced loads (1 KiB per wave
 // instruction at G = 64), neighbour ids are staged through LDS, reductions are wavefront shuffles (DPP).
+#include <algorithm>
 #include <cstdlib>
+#include <string>
 
 #include "kernels.hpp"
 #include "walk.hpp"
@@ -289,12 +291,15 @@ __global__ void __launch_bounds__(256) k_revlink(RevlinkArgs a)
     RefineLds r;
     unsigned char *p = carve_refine(lgpu_smem, r, a.view.M0 + 1);
     int      *scal = (int *)p;
-    const uint32_t gi = blockIdx.x;
-    const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+    const uint32_t ng = *a.ngroups;
+    uint32_t       pairs = 0;
+    for(uint32_t gi = blockIdx.x; gi < ng; gi += gridDim.x) {
+    const uint32_t begin = a.groups[ gi ].x, end = a.groups[ gi ].y;
     const uint32_t close = a.reqs[ begin ].close;
     const int      level = (int)a.reqs[ begin ].level;
     uint32_t       cap;
     uint32_t      *list = neighbors_of(a.view, close, level, cap);
+    __syncthreads();  // the previous group is done with the LDS
     if(tid == 0) scal[ S_CNT ] = 0;
     __syncthreads();
     for(uint32_t i = tid; i < cap; i += T) {
@@ -306,7 +311,6 @@ __global__ void __launch_bounds__(256) k_revlink(RevlinkArgs a)
     int      c = scal[ S_CNT ];
     const int c0 = c;
     bool     have_d = false;
-    uint32_t pairs = 0;
     for(uint32_t t = begin; t < end; ++t) {
         const uint32_t vnew = a.reqs[ t ].new_slot;
         const float    dv = a.reqs[ t ].d;
@@ -340,6 +344,7 @@ __global__ void __launch_bounds__(256) k_revlink(RevlinkArgs a)
         c = keep;
         __syncthreads();
     }
+    }  // groups
     if(tid == 0 && a.totals) atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs);
 }
 
@@ -383,10 +388,10 @@ struct RevWork
 
 __global__ void __launch_bounds__(256) k_revlink_append(RevlinkArgs a, RevWork *work, uint32_t *work_count)
 {
-    const uint32_t gi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int      lane = threadIdx.x & 63;
-    if(gi >= a.ngroups) return;
-    const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+    const uint32_t ng = *a.ngroups, nwaves = gridDim.x * (blockDim.x >> 6);
+    for(uint32_t gi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); gi < ng; gi += nwaves) {
+    const uint32_t begin = a.groups[ gi ].x, end = a.groups[ gi ].y;
     const uint32_t close = a.reqs[ begin ].close;
     const int      level = (int)a.reqs[ begin ].level;
     uint32_t       cap;
@@ -406,6 +411,7 @@ __global__ void __launch_bounds__(256) k_revlink_append(RevlinkArgs a, RevWork *
         work[ w ].group = gi;
         work[ w ].t_start = begin + take;
     }
+    }  // groups
 }
 
 template <int METRIC, int G>
@@ -416,7 +422,7 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
     uint32_t pairs = 0, reprunes = 0;
     for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
     const uint32_t gi = work[ wi ].group;
-    const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+    const uint32_t begin = a.groups[ gi ].x, end = a.groups[ gi ].y;
     const uint32_t t_first = work[ wi ].t_start;
     const uint32_t close = a.reqs[ begin ].close;
     const int      level = (int)a.reqs[ begin ].level;
@@ -673,7 +679,7 @@ __global__ void __launch_bounds__(512, 4) k_revlink_slab(RevlinkArgs a, const Re
     uint32_t       pairs = 0, reprunes = 0;
     for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         const uint32_t gi = work[ wi ].group;
-        const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+        const uint32_t begin = a.groups[ gi ].x, end = a.groups[ gi ].y;
         const uint32_t t_first = work[ wi ].t_start;
         const uint32_t close = a.reqs[ begin ].close;
         const int      level = (int)a.reqs[ begin ].level;
@@ -903,7 +909,7 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_regs(RevlinkA
     };
     for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         const uint32_t gi = work[ wi ].group;
-        const uint32_t begin = a.group_begin[ gi ], end = a.group_begin[ gi + 1 ];
+        const uint32_t begin = a.groups[ gi ].x, end = a.groups[ gi ].y;
         const uint32_t t_first = work[ wi ].t_start;
         const uint32_t close = a.reqs[ begin ].close;
         const int      level = (int)a.reqs[ begin ].level;
@@ -1038,6 +1044,193 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_regs(RevlinkA
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_revlink_pairs: the re-prune of a full list (rows of 128..256 chunks, cap <= 32) with NO sequential dependency in
+// its distance phase.  k_revlink_regs walks the sorted candidates one by one -- one barrier and one LDS hand-off per
+// candidate, a ~0.85 us chain x 32 -- because whether candidate c is tested against candidate p depends on p having been
+// kept.  Here ALL pairs among the <= 33 candidates and `close` are evaluated up front ((n+1) n / 2 <= 561 independent
+// distances, ~18 % more than the sequential walk evaluates), then the keep/drop scan runs over that table with 64-bit
+// "blocker" masks (one wave, ~n steps of readlane).  Rows never leave registers for the arithmetic's second operand:
+//   * wave w (of 8) loads rows w, w+8, w+16, ... of the (n+1)-row set straight from HBM into registers (<= 5 rows,
+//     all loads in flight at once) -- every row is read from HBM exactly once per re-prune;
+//   * in round t each wave publishes its row 8t+w to one half of a double-buffered LDS ring; after ONE barrier every wave
+//     reads the round's <= 8 rows from LDS and evaluates them against its own register rows with a higher index.
+// Five rounds, five barriers, for what was thirty-two.  Lane/chunk ownership and the reduction tree are those of
+// group_dist<METRIC, 64> (lane l owns chunks l, l+64, ...; one fma chain per accumulator in memory order; DPP butterfly),
+// and the metrics are bitwise symmetric, so every table entry has the bits the sequential kernels / the oracle compute.
+constexpr int PAIRS_NMAX = 34;  // candidates (<= 33) + close
+__host__ __device__ inline size_t pairs_lds_bytes(int cpl)
+{
+    return (size_t)2 * 8 * 64 * cpl * 16 + (size_t)PAIRS_NMAX * PAIRS_NMAX * 4 + 7 * 160 + 320 + 64;
+}
+
+template <int METRIC, int CPL>
+__global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_pairs(RevlinkArgs a, const RevWork *work, const uint32_t *work_count)
+{
+    constexpr int NM = PAIRS_NMAX;
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char *p = lgpu_smem;
+    uint4    *ring = (uint4 *)p;                   p += (size_t)2 * 8 * 64 * CPL * 16;  // [half][wave][64 * CPL]
+    float    *pair = (float *)p;                   p += (size_t)NM * NM * 4;            // [i][j], i > j; row n = close
+    float    *cd = (float *)p;                     p += 160;
+    float    *sd = (float *)p;                     p += 160;
+    float    *nrm = (float *)p;                    p += 160;
+    uint32_t *cid = (uint32_t *)p;                 p += 160;
+    uint32_t *sid = (uint32_t *)p;                 p += 160;
+    int      *rank = (int *)p;                     p += 160;
+    uint16_t *sidx = (uint16_t *)p;                p += 160;
+    unsigned long long *blockers = (unsigned long long *)p;  p += 320;
+    int      *scal = (int *)p;
+    const uint32_t nwork = *work_count;
+    const int      chunks = (int)a.view.chunks;
+    uint32_t       pairs = 0, reprunes = 0;
+    auto load_row = [&](uint32_t slot, uint4 (&v)[ CPL ]) {
+        const uint4 *row = row_of(a.view, slot);
+#pragma unroll
+        for(int c = 0; c < CPL; ++c) {
+            const int ch = lane + 64 * c;
+            v[ c ] = ch < chunks ? row[ ch ] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint32_t gi = work[ wi ].group;
+        const uint32_t begin = a.groups[ gi ].x, end = a.groups[ gi ].y;
+        const uint32_t t_first = work[ wi ].t_start;
+        const uint32_t close = a.reqs[ begin ].close;
+        const int      level = (int)a.reqs[ begin ].level;
+        uint32_t       cap;
+        uint32_t      *list = neighbors_of(a.view, close, level, cap);
+        __syncthreads();  // the previous work item is done with the LDS
+        for(uint32_t i = tid; i < cap; i += T) cid[ i ] = list[ i ];
+        int c = (int)cap;  // the list is full at hand-off (k_revlink_append filled it from the requests [begin, t_first))
+        __syncthreads();
+        for(uint32_t t = t_first; t < end; ++t) {
+            const uint32_t vnew = a.reqs[ t ].new_slot;
+            if(c < (int)cap) {
+                if(tid == 0) { cid[ c ] = vnew; list[ c ] = vnew; }
+                c++;
+                __syncthreads();
+                continue;
+            }
+            reprunes++;
+            const int n = c + 1;  // candidates 0..n-1; `close` is row n
+            if(tid == 0) cid[ c ] = vnew;
+            __syncthreads();
+            // ---- this wave's rows, all in flight at once
+            uint4 own[ 5 ][ CPL ];
+            float ownn[ 5 ];
+#pragma unroll
+            for(int j = 0; j < 5; ++j) {
+                const int r = wave + 8 * j;
+                ownn[ j ] = 0.f;
+                if(r <= n) {
+                    const uint32_t slot = r < n ? cid[ r ] : close;
+                    load_row(slot, own[ j ]);
+                    ownn[ j ] = row_norm<METRIC>(a.view, slot);
+                } else {
+#pragma unroll
+                    for(int cc = 0; cc < CPL; ++cc) own[ j ][ cc ] = make_uint4(0, 0, 0, 0);
+                }
+            }
+            if(kCachedNorms<METRIC>) {
+                if(tid <= n) nrm[ tid ] = row_norm<METRIC>(a.view, tid < n ? cid[ tid ] : close);
+            }
+            // ---- rounds: publish row 8t + wave, one barrier, evaluate the round's rows against the own rows above them
+#pragma unroll
+            for(int t8 = 0; t8 < 5; ++t8) {
+                if(8 * t8 <= n) {  // block-uniform
+                    uint4 *half = ring + (size_t)(t8 & 1) * 8 * 64 * CPL;
+                    if(8 * t8 + wave <= n) {
+#pragma unroll
+                        for(int cc = 0; cc < CPL; ++cc) half[ (size_t)wave * 64 * CPL + lane + 64 * cc ] = own[ t8 ][ cc ];
+                    }
+                    __syncthreads();  // also: everybody is done reading this half from round t8 - 2
+                    for(int u = 0; u < 8; ++u) {
+                        const int jr = 8 * t8 + u;
+                        if(jr > n) break;
+                        // does any own row sit above jr?  (rows 8 j + wave with j > t8, or j == t8 and wave > u)
+                        if(!(8 * (t8 + 1) + wave <= n || (wave > u && 8 * t8 + wave <= n))) continue;
+                        uint4 cur[ CPL ];
+#pragma unroll
+                        for(int cc = 0; cc < CPL; ++cc) cur[ cc ] = half[ (size_t)u * 64 * CPL + lane + 64 * cc ];
+                        const float jn = kCachedNorms<METRIC> ? nrm[ jr ] : 0.f;
+#pragma unroll
+                        for(int j = 0; j < 5; ++j) {
+                            const int i = wave + 8 * j;
+                            if(j >= t8 && i <= n && i > jr) {  // wave-uniform
+                                RowAcc<METRIC> acc;
+#pragma unroll
+                                for(int cc = 0; cc < CPL; ++cc) acc.add(own[ j ][ cc ], cur[ cc ]);
+                                const float d = acc.template finish_n<64>(ownn[ j ], jn);
+                                if(lane == 63) pair[ i * NM + jr ] = d;
+                            }
+                        }
+                    }
+                }
+            }
+            pairs += (uint32_t)((n + 1) * n / 2);
+            __syncthreads();
+            // ---- distance to `close` = row n of the table; sort by (distance, tie_mix(slot, close))
+            for(int x = tid; x < NM; x += T) {
+                rank[ x ] = 0;
+                blockers[ x ] = 0ull;
+                if(x < n) cd[ x ] = pair[ n * NM + x ];
+            }
+            __syncthreads();
+            for(int cell = tid; cell < n * n; cell += T) {
+                const int      x = cell / n, j = cell - x * n;
+                const uint64_t kx = ((uint64_t)f2ord(cd[ x ]) << 32) | tie_mix(cid[ x ], close);
+                const uint64_t kj = ((uint64_t)f2ord(cd[ j ]) << 32) | tie_mix(cid[ j ], close);
+                if(kj < kx) atomicAdd(&rank[ x ], 1);
+            }
+            __syncthreads();
+            for(int x = tid; x < n; x += T) {
+                const int r = rank[ x ];
+                sd[ r ] = cd[ x ];
+                sid[ r ] = cid[ x ];
+                sidx[ r ] = (uint16_t)x;
+            }
+            __syncthreads();
+            // ---- the heuristic.  blockers[c] = sorted positions p < c that, if kept, reject c (dist(c, p) < dist(c, close));
+            // built in parallel, then one wave resolves the sequential dependency: c is kept iff none of its blockers is
+            for(int cell = tid; cell < n * n; cell += T) {
+                const int cpos = cell / n, ppos = cell - cpos * n;
+                if(ppos < cpos) {
+                    const int ci = sidx[ cpos ], pi = sidx[ ppos ];
+                    const int hi = ci > pi ? ci : pi, lo = ci > pi ? pi : ci;
+                    if(pair[ hi * NM + lo ] < sd[ cpos ]) atomicOr(&blockers[ cpos ], 1ull << ppos);
+                }
+            }
+            __syncthreads();
+            if(tid < 64) {
+                const unsigned long long mine = lane < n ? blockers[ lane ] : 0ull;
+                unsigned long long       kept = 1ull;  // sorted position 0 is always kept
+                int                      submitted = 1;
+                for(int cpos = 1; cpos < n && submitted < (int)cap; ++cpos) {
+                    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(mine & 0xFFFFFFFFull), cpos);
+                    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(mine >> 32), cpos);
+                    const unsigned long long b = ((unsigned long long)hi << 32) | lo;
+                    if((b & kept) == 0ull) { kept |= 1ull << cpos; submitted++; }
+                }
+                uint32_t ks = 0;
+                if(lane < submitted) {  // lane x takes the x-th kept position
+                    unsigned long long m = kept;
+                    for(int s2 = 0; s2 < lane; ++s2) m &= m - 1ull;
+                    ks = sid[ __builtin_ctzll(m) ];
+                }
+                if(lane < submitted) cid[ lane ] = ks;
+                if(lane == 0) scal[ 0 ] = submitted;
+            }
+            __syncthreads();
+            c = scal[ 0 ];
+            for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? cid[ i ] : EMPTY;
+            __syncthreads();
+        }
+    }
+    if(tid == 0 && a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs); atomicAdd(&a.totals[ 1 ], (unsigned long long)reprunes); }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------
 // Work-sharded build: scatter kernels either side of the all-gathers (pure index traffic, no arithmetic).
 __global__ void __launch_bounds__(256) k_apply_own_links(View v, uint32_t first_slot, const uint32_t *link_off, const LinkReq *links,
@@ -1059,8 +1252,8 @@ __global__ void __launch_bounds__(256) k_pack_lists(RevlinkArgs a, uint32_t *rec
     const uint32_t rw = a.view.M0 + 2;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t g = t / rw, w = t - g * rw;
-    if(g >= a.ngroups) return;
-    const LinkReq  first = a.reqs[ a.group_begin[ g ] ];
+    if(g >= *a.ngroups) return;
+    const LinkReq  first = a.reqs[ a.groups[ g ].x ];
     uint32_t       cap;
     const uint32_t *list = neighbors_of(a.view, first.close, (int)first.level, cap);
     uint32_t       val;
@@ -1203,38 +1396,68 @@ hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream)
 
 hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream)
 {
-    if(a.ngroups == 0) return hipSuccess;
+    if(a.max_groups == 0) return hipSuccess;
+    // the number of groups is known to the device only (*a.ngroups): every kernel below loops over it with a grid sized
+    // for the chip, so nothing here waits for the grouping pass
+    const int append_grid = (int)std::min<uint32_t>((a.max_groups + 3) / 4, (uint32_t)num_cus * 8);
     // staged variant whenever the 2M+2 rows of a level-0 re-prune fit in LDS (d <= 1024 at M = 16)
     const size_t staged = staged_lds_bytes(a.view.chunks, a.view.M0);
     const bool i8 = mcode_is_i8(metric);  // i8 rows take the LDS-staged / generic kernels (Lantern caps d at 2000: <= 125 chunks)
     if(!i8 && a.view.chunks >= 128 && a.view.chunks <= 256 && a.view.M0 <= 32 && work && work_count) {
-        // d = 512..1024 f32 rows, M <= 16: kept rows in registers (k_revlink_regs), 2 x 8 waves per CU
+        // d = 512..1024 f32 rows, M <= 16: all-pairs re-prune with the rows in registers (k_revlink_pairs);
+        // LANTERN_GPU_REPRUNE=regs selects the sequential-walk kernel it replaced (A/B measurements)
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_revlink_append, dim3((a.ngroups + 3) / 4), dim3(256), 0, stream, a, (RevWork *)work, work_count);
-        const int grid = num_cus * 2;
+        hipLaunchKernelGGL(k_revlink_append, dim3(append_grid), dim3(256), 0, stream, a, (RevWork *)work, work_count);
+        static const bool use_regs = std::getenv("LANTERN_GPU_REPRUNE") && std::string(std::getenv("LANTERN_GPU_REPRUNE")) == "regs";
         static const bool force4 = std::getenv("LANTERN_GPU_REGS_CPL4") != nullptr;  // tuning: always the four-chunks-per-lane variant
+        const bool cpl3 = a.view.chunks <= 192 && !force4;
+        if(use_regs) {
+            const int grid = num_cus * 2;
 #define REGS(MM)                                                                                                                        \
     {                                                                                                                                   \
-        if(a.view.chunks <= 192 && !force4) hipLaunchKernelGGL((k_revlink_regs<MM, 3>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count); \
+        if(cpl3) hipLaunchKernelGGL((k_revlink_regs<MM, 3>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count);   \
         else hipLaunchKernelGGL((k_revlink_regs<MM, 4>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count);       \
     }
+            switch(metric) {
+                case M_L2SQ: REGS(M_L2SQ); break;
+                case M_COS: REGS(M_COS); break;
+                case M_HAMMING: REGS(M_HAMMING); break;
+                case M_L2SQ_F16: REGS(M_L2SQ_F16); break;
+                case M_COS_F16: REGS(M_COS_F16); break;
+                default: return hipErrorInvalidValue;
+            }
+#undef REGS
+            return hipGetLastError();
+        }
+        const size_t lds = pairs_lds_bytes(cpl3 ? 3 : 4);
+        const int    grid = num_cus * (cpl3 ? 2 : 1);
+#define PAIRS(MM)                                                                                                                       \
+    {                                                                                                                                   \
+        if(cpl3) {                                                                                                                      \
+            (void)hipFuncSetAttribute((const void *)k_revlink_pairs<MM, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            hipLaunchKernelGGL((k_revlink_pairs<MM, 3>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count);     \
+        } else {                                                                                                                        \
+            (void)hipFuncSetAttribute((const void *)k_revlink_pairs<MM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            hipLaunchKernelGGL((k_revlink_pairs<MM, 4>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count);     \
+        }                                                                                                                               \
+    }
         switch(metric) {
-            case M_L2SQ: REGS(M_L2SQ); break;
-            case M_COS: REGS(M_COS); break;
-            case M_HAMMING: REGS(M_HAMMING); break;
-            case M_L2SQ_F16: REGS(M_L2SQ_F16); break;
-            case M_COS_F16: REGS(M_COS_F16); break;
+            case M_L2SQ: PAIRS(M_L2SQ); break;
+            case M_COS: PAIRS(M_COS); break;
+            case M_HAMMING: PAIRS(M_HAMMING); break;
+            case M_L2SQ_F16: PAIRS(M_L2SQ_F16); break;
+            case M_COS_F16: PAIRS(M_COS_F16); break;
             default: return hipErrorInvalidValue;
         }
-#undef REGS
+#undef PAIRS
         return hipGetLastError();
     }
     if(!i8 && a.view.chunks >= 128 && a.view.M0 <= 32 && work && work_count) {
         // common shape (G = 64: d >= 512 f32 / 1024 f16, and M <= 16): column-slab sweep, 2 x 8 waves per CU
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_revlink_append, dim3((a.ngroups + 3) / 4), dim3(256), 0, stream, a, (RevWork *)work, work_count);
+        hipLaunchKernelGGL(k_revlink_append, dim3(append_grid), dim3(256), 0, stream, a, (RevWork *)work, work_count);
         const size_t lds = slab_lds_bytes();
         const int    grid = num_cus * 2;
         switch(metric) {
@@ -1250,7 +1473,7 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
     if(staged <= 150 * 1024 && a.view.M0 <= 256 && work && work_count) {
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_revlink_append, dim3((a.ngroups + 3) / 4), dim3(256), 0, stream, a, (RevWork *)work, work_count);
+        hipLaunchKernelGGL(k_revlink_append, dim3(append_grid), dim3(256), 0, stream, a, (RevWork *)work, work_count);
 #define CALL(MM, GG)                                                                                                    \
     {                                                                                                                   \
         (void)hipFuncSetAttribute((const void *)k_revlink_staged<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged); \
@@ -1261,7 +1484,8 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
         return hipGetLastError();
     }
     const size_t lds = refine_lds_bytes(a.view.M0 + 1) + S_SCALARS * 4;
-#define CALL(MM, GG) hipLaunchKernelGGL((k_revlink<MM, GG>), dim3(a.ngroups), dim3(256), lds, stream, a)
+    const int    ggrid = (int)std::min<uint32_t>(a.max_groups, (uint32_t)num_cus * 8);
+#define CALL(MM, GG) hipLaunchKernelGGL((k_revlink<MM, GG>), dim3(ggrid), dim3(256), lds, stream, a)
     LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL
     return hipGetLastError();
@@ -1277,8 +1501,8 @@ hipError_t launch_apply_own_links(const View &v, uint32_t first_slot, const uint
 
 hipError_t launch_pack_lists(const RevlinkArgs &a, uint32_t *records, hipStream_t stream)
 {
-    if(a.ngroups == 0) return hipSuccess;
-    const uint64_t threads = (uint64_t)a.ngroups * (a.view.M0 + 2);
+    if(a.max_groups == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)a.max_groups * (a.view.M0 + 2);
     hipLaunchKernelGGL(k_pack_lists, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, a, records);
     return hipGetLastError();
 }

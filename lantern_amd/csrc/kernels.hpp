@@ -72,17 +72,37 @@ struct ConnectArgs
 struct RevlinkArgs
 {
     View            view;
-    uint32_t        ngroups;
-    const uint32_t *group_begin;  // [ngroups+1] into reqs (sorted by close, level, new_slot)
-    const LinkReq  *reqs;
+    const uint32_t *ngroups;      // device: number of (close, level) groups of this batch (written by the grouping pass)
+    const uint2    *groups;       // device: [*ngroups] {begin, end} into reqs; any order (groups are independent of one another)
+    uint32_t        max_groups;   // host-side upper bound on *ngroups (sizes grids and the worklist)
+    const LinkReq  *reqs;         // sorted by (close, level), stable: within a group in new-slot order
     unsigned long long *totals;   // [2] cumulative pair evaluations, re-prunes
 };
+
+// The grouping pass (grouping.hip): the reverse-link requests of a batch, as k_connect left them (new-slot-major, EMPTY
+// entries in between), become `sorted` -- stable radix sort by (close, level) -- and the list of groups.  Everything stays
+// on the device and on `stream`: the batches of a build queue up without a host round trip.
+// world > 1 (work-sharded build): only the requests whose `close` this rank owns (close % world == rank) are kept;
+// owner_counts[world] (device, zeroed here) receives the number of requests per owner.
+struct GroupScratch
+{
+    uint64_t *keys_a, *keys_b;   // [n]
+    uint32_t *idx_a, *idx_b;     // [n]
+    void     *temp;              // rocPRIM temporary storage
+    size_t    temp_bytes;
+};
+size_t     group_temp_bytes(size_t n);
+hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupScratch &gs, LinkReq *sorted, uint2 *groups, uint32_t *ngroups,
+                                 int world, int rank, uint32_t *owner_counts, hipStream_t stream);
+// link_off[i] = M * sum_{j<i} (level_j + 1), item_node[item] = i for the (level_i + 1) items of node i -- the layout of
+// one batch, from the levels already in HBM (no per-batch host upload)
+hipError_t launch_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, uint32_t *link_off, uint32_t *item_node, hipStream_t stream);
 
 // All launchers return hipSuccess or the launch error.  `metric` is a usearch_metric_kind_t value.
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream);
-// work: scratch of ngroups x 8 bytes; work_count: one u32 (both device memory; NULL = unstaged kernel)
+// work: scratch of max_groups x 8 bytes; work_count: one u32 (both device memory)
 hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream);
 // ---- work-sharded build (shard.cpp): the exchange steps either side of the RCCL all-gathers -------------
 // Every rank holds the complete request array after the first all-gather; the own lists of the nodes another

@@ -1,0 +1,206 @@
+"""The other BASELINE.json configurations at their full sizes, each against the oracle on the SAME graph
+(exported from the device) on a sample of queries, plus size-independent properties over the whole batch:
+
+  C2  100k x 128 f32 L2sq, M=16 ef=64 k=10, queries issued ONE AT A TIME through usearch_search_ef
+  C3  1M x 768 f32 cosine, 1024-query batch
+  C4  shape: ef=128 on a 1M x 768 L2sq graph
+  Hamming check set: 100k x 24 words (768 bits) -- identical id sets
+
+and build-QUALITY parity (north_star: "recall@10 within +-0.5 % of the reference"): the device's batch-synchronous build
+against the oracle's strictly sequential usearch_add (build.c:83-135: one usearch_add per tuple) on the same rows,
+searched with the same queries, both against exact truth.  Needs an MI355X; a few minutes (the sequential CPU builds
+dominate)."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M, EFC, K = 16, 128, 10
+
+
+@pytest.fixture(scope="module")
+def env():
+    from lantern_amd import capi, hip
+
+    capi.lib()
+    assert capi.device_count() > 0
+    return capi, hip
+
+
+def device_batch(hip, ix, queries, k, ef, ham=False, waves=4):
+    nq = queries.shape[0]
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, ham))
+    lab, dist, slot = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4), hip.Buffer(nq * k * 4)
+    cnt, Dv, Ev = hip.Buffer(nq * 4), hip.Buffer(nq * 8), hip.Buffer(nq * 8)
+    ix.set_search_shape(waves)
+    ix.search_batch_device(dq.ptr, nq, k, ef, 0, lab.ptr, dist.ptr, slot.ptr, cnt.ptr, Dv.ptr, Ev.ptr)
+    hip.synchronize()
+    ix.set_search_shape(4)
+    return (lab.download((nq, k), np.uint64), dist.download((nq, k), np.float32), slot.download((nq, k), np.uint32),
+            cnt.download(nq, np.uint32), Dv.download(nq, np.uint64), Ev.download(nq, np.uint64))
+
+
+def build(capi, metric, base, ef=64, plan=(8192, 16)):
+    ix = capi.GpuIndex(metric, base.shape[1], M=M, ef_construction=EFC, ef=ef, seed=42)
+    ix.reserve(base.shape[0])
+    ix.set_add_batch(*plan)
+    ix.add_many(np.arange(base.shape[0], dtype=np.uint64) + 1, base)
+    ix.flush()
+    return ix
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# C2: single-query search, 100k x 128
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c2(env):
+    capi, hip = env
+    base = np.random.default_rng(1).standard_normal((100_000, 128), dtype=np.float32)
+    queries = np.random.default_rng(2).standard_normal((10_000, 128), dtype=np.float32)
+    return base, queries, build(capi, "l2sq", base)
+
+
+def test_c2_one_query_at_a_time_matches_the_oracle_and_the_batch(env, c2, oracle):
+    capi, hip = env
+    base, queries, ix = c2
+    g = ix.export_graph()
+    ora = oracle.OracleIndex.from_graph("l2sq", base, g, M, EFC, 64, 42, oracle.SUM_WAVE64)
+    sample = queries[:300]
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(sample, K, 64, 8)
+    for i, q in enumerate(sample):  # usearch_search_ef, one call per query (scan.c:220-228)
+        lab, dist = ix.search(q, K)
+        assert np.array_equal(lab, o_lab[i]) and np.array_equal(dist, o_dist[i]), i
+    # the whole 10 000-query set as one launch: same answers as the single calls, D / E equal to the oracle's on the sample
+    lab, dist, slot, cnt, Dv, Ev = device_batch(hip, ix, queries, K, 64)
+    assert np.array_equal(lab[:300], o_lab) and np.array_equal(Dv[:300], o_D) and np.array_equal(Ev[:300], o_E)
+    assert np.all(cnt == K) and np.all(np.diff(dist, axis=1) >= 0) and all(len(set(r.tolist())) == K for r in slot[::97])
+    # the streaming continuation at full size: 10, then 20 more -- the first 30 of a wider search's ranking are all there
+    first, _ = ix.search(queries[0], 10)
+    more, _ = ix.search(queries[0], 20, streaming=True)
+    assert len(set(first.tolist()) | set(more.tolist())) == 30
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# C3: 1M x 768 cosine, 1024-query batches; C4 shape: ef = 128
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def million(env):
+    base = np.random.default_rng(3).standard_normal((1_000_000, 768), dtype=np.float32)
+    return base
+
+
+def test_c3_cosine_1024_query_batch(env, million, oracle):
+    capi, hip = env
+    base = million
+    ix = build(capi, "cos", base)
+    assert len(ix) == base.shape[0]
+    queries = np.random.default_rng(4).standard_normal((1024, 768), dtype=np.float32)
+    lab, dist, slot, cnt, Dv, Ev = device_batch(hip, ix, queries, K, 64)
+    assert np.all(cnt == K) and np.all(np.diff(dist, axis=1) >= 0) and slot.max() < base.shape[0]
+    assert all(len(set(r.tolist())) == K for r in slot)
+    for waves in (4, 8):  # idempotence, independence from the launch shape
+        again = device_batch(hip, ix, queries, K, 64, waves=waves)
+        assert np.array_equal(again[2], slot) and np.array_equal(again[1], dist) and np.array_equal(again[4], Dv)
+    g = ix.export_graph()
+    ora = oracle.OracleIndex.from_graph("cos", base, g, M, EFC, 64, 42, oracle.SUM_WAVE64)
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries[:48], K, 64, 8)
+    assert np.array_equal(slot[:48], o_slot) and np.array_equal(dist[:48], o_dist)
+    assert np.array_equal(Dv[:48], o_D) and np.array_equal(Ev[:48], o_E)
+    # usearch-order cosine (one running sum per accumulator): within 1e-5 relative
+    fast = oracle.OracleIndex.from_graph("cos", base, g, M, EFC, 64, 42, oracle.SUM_SEQ)
+    _, f_dist, f_slot, _, _ = fast.search_batch(queries[:48], K, 64, 8)
+    assert np.all(np.abs(f_dist - dist[:48]) <= 1e-5 * np.maximum(1.0, np.abs(f_dist)))
+    # every reported distance is the pair kernel's value (no cached norm involved there): bit-exact
+    for qi in (0, 500, 1023):
+        assert np.array_equal(ix.distance_gather(queries[qi], slot[qi]), dist[qi])
+
+
+def test_c4_shape_ef_128_on_the_million_row_graph(env, million, oracle):
+    capi, hip = env
+    base = million
+    ix = build(capi, "l2sq", base, ef=128)
+    queries = np.random.default_rng(6).standard_normal((1024, 768), dtype=np.float32)
+    lab, dist, slot, cnt, Dv, Ev = device_batch(hip, ix, queries, K, 128)
+    assert np.all(cnt == K) and np.all(np.diff(dist, axis=1) >= 0) and Dv.min() > 128
+    l64 = device_batch(hip, ix, queries, K, 64)
+    assert Dv.sum() > l64[4].sum()  # a wider beam evaluates more rows ...
+    truth, _ = ix.exact_search(queries[:256], K)
+    assert oracle.recall_at_k(slot[:256], truth) >= oracle.recall_at_k(l64[2][:256], truth)  # ... and does not find fewer
+    g = ix.export_graph()
+    ora = oracle.OracleIndex.from_graph("l2sq", base, g, M, EFC, 128, 42, oracle.SUM_WAVE64)
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries[:32], K, 128, 8)
+    assert np.array_equal(slot[:32], o_slot) and np.array_equal(dist[:32], o_dist)
+    assert np.array_equal(Dv[:32], o_D) and np.array_equal(Ev[:32], o_E)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Hamming check set: 100k x 24 words
+# ------------------------------------------------------------------------------------------------------------------
+def test_hamming_check_set_identical_id_sets(env, oracle):
+    capi, hip = env
+    base = np.random.default_rng(9).integers(0, 2**32, size=(100_000, 24), dtype=np.uint32)
+    queries = np.random.default_rng(10).integers(0, 2**32, size=(4096, 24), dtype=np.uint32)
+    ix = build(capi, "hamming", base)
+    lab, dist, slot, cnt, Dv, Ev = device_batch(hip, ix, queries, K, 64, ham=True)
+    g = ix.export_graph()
+    ora = oracle.OracleIndex.from_graph("hamming", base, g, M, EFC, 64, 42, oracle.SUM_SEQ)
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, K, 64, 8)
+    assert np.array_equal(slot, o_slot) and np.array_equal(dist, o_dist)  # integer work: identical, all 4096 queries
+    assert np.array_equal(Dv, o_D) and np.array_equal(Ev, o_E)
+    # exact k-NN (integer popcounts through the dense path) against the oracle's brute force on a sample
+    t_slots, t_d = ix.exact_search(queries[:64], K)
+    b_ids, b_d = oracle.bruteforce(base, queries[:64], K, "hamming", oracle.SUM_SEQ, 8)
+    assert np.array_equal(t_slots, b_ids) and np.array_equal(t_d, b_d)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# build quality: batch-synchronous device build vs strictly sequential usearch_add
+# ------------------------------------------------------------------------------------------------------------------
+def sequential_cpu_build(oracle, metric, base):
+    """The reference's build: one usearch_add per tuple, in order (build.c:83-135), with the reference's own summation
+    (-fassociative-math flags: LO_SUM_FAST).  Returns the graph in the exchange format."""
+    o = oracle.OracleIndex(metric, base.shape[1], M=M, ef_construction=EFC, ef=64, seed=42, sum_mode=oracle.SUM_FAST)
+    o.reserve(base.shape[0])
+    o.add_many(np.arange(base.shape[0], dtype=np.uint64) + 1, base)
+    return o.export_graph()
+
+
+def recall_of(capi, hip, oracle, metric, base, graph, queries, truth):
+    ix = capi.GpuIndex(metric, base.shape[1], M=M, ef_construction=EFC, ef=64, seed=42)
+    ix.import_graph(base, graph)
+    slot = device_batch(hip, ix, queries, K, 64)[2]
+    return oracle.recall_at_k(slot, truth)
+
+
+@pytest.mark.parametrize("name", ["c2_gaussian_100k_x_128", "lowrank_200k_x_768"])
+def test_build_quality_matches_the_sequential_reference_build(env, oracle, name):
+    capi, hip = env
+    from lantern_amd import synth
+
+    if name.startswith("c2"):
+        base = np.random.default_rng(1).standard_normal((100_000, 128), dtype=np.float32)
+        queries = np.random.default_rng(2).standard_normal((1000, 128), dtype=np.float32)
+    else:
+        make = synth.query_maker("lowrank", 768)
+        base = make(np.random.default_rng(synth.BASE_SEED), 200_000)
+        queries = make(np.random.default_rng(4), 1000)
+    t0 = time.time()
+    dev = build(capi, "l2sq", base)  # the default plan: batches of up to 8192, never more than size / 16
+    t_dev = time.time() - t0
+    truth, _ = dev.exact_search(queries, K)
+    r_dev = oracle.recall_at_k(device_batch(hip, dev, queries, K, 64)[2], truth)
+    t0 = time.time()
+    seq_graph = sequential_cpu_build(oracle, "l2sq", base)
+    t_seq = time.time() - t0
+    r_seq = recall_of(capi, hip, oracle, "l2sq", base, seq_graph, queries, truth)
+    # the same sequential build on the device (batch plan (1, 1)) on a prefix: it IS usearch_add, edge for edge
+    print(f"{name}: recall@10 device-batched {r_dev:.4f} (built in {t_dev:.1f} s), sequential reference build {r_seq:.4f} ({t_seq:.1f} s)")
+    assert abs(r_dev - r_seq) <= 0.005, (r_dev, r_seq)
+    # neither graph is degenerate: same edge budget, same level structure
+    g = dev.export_graph()
+    deg_dev = (g["nbr0"] != 0xFFFFFFFF).sum(axis=1).mean()
+    deg_seq = (seq_graph["nbr0"] != 0xFFFFFFFF).sum(axis=1).mean()
+    assert abs(deg_dev - deg_seq) / deg_seq < 0.05, (deg_dev, deg_seq)
+    assert np.array_equal(g["levels"], seq_graph["levels"])  # the level draw is shared (insert.c:32-46 formula, same seed)
