@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -399,6 +400,27 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
         if(!sync_stream(ix, comm)) return false;
     }
     prof_mark(ix, 3);
+    if(std::getenv("LANTERN_GPU_DEBUG_GROUPS")) {  // debugging aid: the size distribution of this batch's groups
+        HIPCHK(ix, hipStreamSynchronize(ix->stream));
+        uint32_t ng = 0;
+        HIPCHK(ix, hipMemcpy(&ng, d_ngroups, 4, hipMemcpyDeviceToHost));
+        std::vector<uint2> hg(ng);
+        if(ng) HIPCHK(ix, hipMemcpy(hg.data(), d_groups, (size_t)ng * 8, hipMemcpyDeviceToHost));
+        uint32_t mx = 0, over[ 5 ] = {};
+        uint64_t sum = 0;
+        for(const uint2 &g2 : hg) {
+            const uint32_t sz = g2.y - g2.x;
+            mx = std::max(mx, sz);
+            sum += sz;
+            over[ 0 ] += sz > 8;
+            over[ 1 ] += sz > 32;
+            over[ 2 ] += sz > 128;
+            over[ 3 ] += sz > 512;
+            over[ 4 ] += sz > 2048;
+        }
+        std::fprintf(stderr, "batch first=%zu b=%zu groups=%u reqs=%llu max=%u >8:%u >32:%u >128:%u >512:%u >2048:%u\n", first, b, ng,
+                     (unsigned long long)sum, mx, over[ 0 ], over[ 1 ], over[ 2 ], over[ 3 ], over[ 4 ]);
+    }
     RevlinkArgs ra;
     ra.view = ix->view();
     ra.ngroups = d_ngroups;
