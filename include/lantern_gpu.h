@@ -97,7 +97,15 @@ typedef struct metadata_t
 #define USEARCH_HEADER_SIZE 136           /* external_index.h:29-30 */
 #define USEARCH_EMPTY_INDEX_SIZE USEARCH_HEADER_SIZE /* build.c:678 */
 
-/* scan.c:99, build.c:517,675, insert.c:142.  pq_codebook must be NULL (PQ is out of scope). */
+/* scan.c:99, build.c:517,675, insert.c:142.
+ * quantization: f32 / f16 / i8 storage of real[] input (quant_bits 32 / 16 / 8), or b1 -- for hamming (integer[] input:
+ *   bits) and for l2sq over real[] (quant_bits = 1, options.c:154-155: bit = (x > 0); the l2sq distance of {0,1} vectors
+ *   is their Hamming distance).
+ * pq = true (build.c:497-500, scan.c:75-81): pq_codebook = num_centroids rows of `dimensions` floats, row c = centroid c
+ *   of every subvector, concatenated (pqtable.c:194-240); copied.  Every stored vector is replaced by its quantisation
+ *   (per subvector the nearest centroid under the index metric, first minimum wins: product_quantization.c:80-124);
+ *   all distances are distances to / between the DECODED vectors; the file and the pages carry num_subvectors code bytes
+ *   per node (usearch_storage.cpp:29-31).  The device keeps the decodings resident in HBM next to the codes. */
 LANTERN_GPU_EXPORT usearch_index_t usearch_init(usearch_init_options_t *, float *pq_codebook, usearch_error_t *);
 /* scan.c:131, build.c:450,549,597,684, insert.c:237 */
 LANTERN_GPU_EXPORT void usearch_free(usearch_index_t, usearch_error_t *);
@@ -252,6 +260,8 @@ LANTERN_GPU_EXPORT lantern_gpu_graph_info lantern_gpu_graph_info_get(usearch_ind
 LANTERN_GPU_EXPORT void lantern_gpu_export_graph(usearch_index_t, uint8_t *levels, uint32_t *nbr0, uint32_t *upper_off,
                                                  uint32_t *upper_nbr, uint64_t *labels, void *vectors,
                                                  usearch_error_t *);
+/* pq indexes: the code bytes, codes[size][num_subvectors] (export_graph's `vectors` are the decoded f32 rows) */
+LANTERN_GPU_EXPORT void lantern_gpu_export_codes(usearch_index_t, uint8_t *codes, usearch_error_t *);
 LANTERN_GPU_EXPORT void lantern_gpu_import_graph(usearch_index_t, size_t size, const void *vectors,
                                                  const uint64_t *labels, const uint8_t *levels, const uint32_t *nbr0,
                                                  const uint32_t *upper_off, const uint32_t *upper_nbr,

@@ -88,6 +88,7 @@ EXPORTS = [
     "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device",
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
+    "lantern_gpu_export_codes",
     "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
     "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist", "lantern_index_server_start",
     "lantern_index_server_port", "lantern_index_server_status_port", "lantern_index_server_status",
@@ -171,6 +172,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_graph_info_get": (GraphInfo, [vp, err]),
         "lantern_gpu_export_graph": (None, [vp, vp, vp, vp, vp, vp, vp, err]),
         "lantern_gpu_import_graph": (None, [vp, sz, vp, vp, vp, vp, vp, vp, u32, C.c_int32, err]),
+        "lantern_gpu_export_codes": (None, [vp, vp, err]),
         "lantern_gpu_counters_get": (Counters, [vp, err]),
         "lantern_gpu_set_profiling": (None, [vp, i32, err]),
         "lantern_gpu_build_profile_get": (BuildProfile, [vp, err]),
@@ -305,7 +307,8 @@ def hamming_dist(a, b) -> int:
 class GpuIndex:
     """usearch_index_t over the C ABI.  `dims` = f32 scalars, or u32 WORDS for hamming."""
 
-    def __init__(self, metric, dims, M=16, ef_construction=128, ef=64, seed=42, retriever=None, quantization="f32", retriever_mut=None):
+    def __init__(self, metric, dims, M=16, ef_construction=128, ef=64, seed=42, retriever=None, quantization="f32", retriever_mut=None,
+                 pq_codebook=None, num_subvectors=0):
         """retriever: optional Python callable slot(int) -> address(int) of the node tape (the
         ldb_wal_index_node_retriever contract, external_index.c:613-671), used by view_mem_lazy().
         quantization: "f32", "f16" or "i8" storage (reloption quant_bits 32 / 16 / 8, options.c:137-158); vectors
@@ -313,11 +316,12 @@ class GpuIndex:
         self.metric = METRICS.get(metric, metric)
         self.f16 = quantization == "f16"
         self.i8 = quantization == "i8"
+        self.b1 = quantization == "b1" and self.metric != METRIC_HAMMING  # quant_bits = 1 on real[]: f32 in, one bit per dimension stored
         self.dims, self.M, self.efc, self.ef = dims, M, ef_construction, ef
         o = InitOptions()
         o.metric_kind = self.metric
         o.metric = None
-        o.quantization = SCALAR_F16 if self.f16 else SCALAR_I8 if self.i8 else _kind(self.metric)
+        o.quantization = SCALAR_F16 if self.f16 else SCALAR_I8 if self.i8 else SCALAR_B1 if self.b1 else _kind(self.metric)
         o.dimensions = dims * 32 if self.metric == METRIC_HAMMING else dims  # scan.c:84-88
         o.connectivity, o.expansion_add, o.expansion_search, o.num_threads = M, ef_construction, ef, 1
         o.pq = False
@@ -331,7 +335,13 @@ class GpuIndex:
             self._retriever_mut_cb = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)(lambda ctx, slot: retriever_mut(int(slot)))
             o.retriever_mut = C.cast(self._retriever_mut_cb, C.c_void_p)
         self.h = None
-        self.h = _call("usearch_init", C.byref(o), None)
+        cb = None
+        if pq_codebook is not None:  # pq = true: [num_centroids][dims] f32, row c = centroid c of every subvector (pqtable.c:194-240)
+            cb = np.ascontiguousarray(pq_codebook, dtype=np.float32)
+            assert cb.ndim == 2 and cb.shape[1] == dims
+            o.pq, o.num_centroids, o.num_subvectors = True, cb.shape[0], num_subvectors
+        self.pq_S = num_subvectors if pq_codebook is not None else 0
+        self.h = _call("usearch_init", C.byref(o), _ptr(cb))
         _call("lantern_gpu_set_seed", self.h, seed)
 
     def close(self):
@@ -472,7 +482,7 @@ class GpuIndex:
         }
         vecs = None
         if with_vectors:  # storage format: u32 words (hamming), f32, or f16 halves (two per word)
-            vecs = np.zeros((n, gi.vector_words), dtype=np.uint32 if (self.metric == METRIC_HAMMING or self.f16 or self.i8) else np.float32)
+            vecs = np.zeros((n, gi.vector_words), dtype=np.uint32 if (self.metric == METRIC_HAMMING or self.f16 or self.i8 or self.b1) else np.float32)
         _call("lantern_gpu_export_graph", self.h, _ptr(g["levels"]), _ptr(g["nbr0"]), _ptr(g["upper_off"]),
               _ptr(g["upper_nbr"]), _ptr(g["labels"]), _ptr(vecs))
         g["upper_nbr"] = g["upper_nbr"][:gi.upper_blocks]
@@ -480,6 +490,12 @@ class GpuIndex:
         if with_vectors:
             g["vectors"] = vecs.view(np.float16)[:, :self.dims] if self.f16 else vecs.view(np.int8)[:, :self.dims] if self.i8 else vecs
         return g
+
+    def export_codes(self):
+        """pq indexes: the code bytes [size][num_subvectors]."""
+        codes = np.zeros((self.graph_info().size, self.pq_S), dtype=np.uint8)
+        _call("lantern_gpu_export_codes", self.h, _ptr(codes))
+        return codes
 
     def import_graph(self, vectors, graph):
         V = _rows(vectors, self.metric)

@@ -86,7 +86,66 @@ __global__ void __launch_bounds__(1024) k_batch_layout(const uint8_t *levels, ui
         item += cnt;
     }
 }
+// ---- product quantisation (pq = true): per-subvector staging either side of the nearest-centroid search -----------
+// take: sub[i][0 .. subdim) = row(first + i)[s * subdim ..], zero padded to whole chunks
+__global__ void __launch_bounds__(256) k_pq_take(const float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t s, uint32_t subdim,
+                                                 uint32_t sub_floats, float *sub)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = (uint32_t)(t / sub_floats), j = (uint32_t)(t % sub_floats);
+    if(i >= count) return;
+    sub[ (size_t)i * sub_floats + j ] = j < subdim ? rows[ (size_t)(first + i) * row_floats + (size_t)s * subdim + j ] : 0.f;
+}
+// put: codes[first + i][s] = nearest[i]; row(first + i)[s * subdim ..] = the centroid's values (the row becomes its decoding)
+__global__ void __launch_bounds__(256) k_pq_put(float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t s, uint32_t subdim, uint32_t S,
+                                                const uint32_t *nearest, const float *codebook, uint32_t dims, uint8_t *codes)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = (uint32_t)(t / subdim), j = (uint32_t)(t % subdim);
+    if(i >= count) return;
+    const uint32_t c = nearest[ i ];
+    rows[ (size_t)(first + i) * row_floats + (size_t)s * subdim + j ] = codebook[ (size_t)c * dims + (size_t)s * subdim + j ];
+    if(j == 0) codes[ (size_t)(first + i) * S + s ] = (uint8_t)c;
+}
+// decode: row(first + i) = concatenation of the centroids its codes name
+__global__ void __launch_bounds__(256) k_pq_decode(float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t subdim, uint32_t S,
+                                                   const float *codebook, uint32_t dims, const uint8_t *codes)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = (uint32_t)(t / row_floats), j = (uint32_t)(t % row_floats);
+    if(i >= count) return;
+    float v = 0.f;
+    if(j < dims) v = codebook[ (size_t)codes[ (size_t)(first + i) * S + j / subdim ] * dims + j ];
+    rows[ (size_t)(first + i) * row_floats + j ] = v;
+}
 }  // namespace
+
+hipError_t launch_pq_take(const float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t s, uint32_t subdim, uint32_t sub_floats,
+                          float *sub, hipStream_t stream)
+{
+    if(count == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)count * sub_floats;
+    hipLaunchKernelGGL(k_pq_take, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, rows, row_floats, first, count, s, subdim, sub_floats, sub);
+    return hipGetLastError();
+}
+hipError_t launch_pq_put(float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t s, uint32_t subdim, uint32_t S, const uint32_t *nearest,
+                         const float *codebook, uint32_t dims, uint8_t *codes, hipStream_t stream)
+{
+    if(count == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)count * subdim;
+    hipLaunchKernelGGL(k_pq_put, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, rows, row_floats, first, count, s, subdim, S, nearest, codebook,
+                       dims, codes);
+    return hipGetLastError();
+}
+hipError_t launch_pq_decode(float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t subdim, uint32_t S, const float *codebook, uint32_t dims,
+                            const uint8_t *codes, hipStream_t stream)
+{
+    if(count == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)count * row_floats;
+    hipLaunchKernelGGL(k_pq_decode, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, rows, row_floats, first, count, subdim, S, codebook, dims,
+                       codes);
+    return hipGetLastError();
+}
 
 size_t group_temp_bytes(size_t n)
 {

@@ -16,6 +16,10 @@
 #include "comm.hpp"
 #include "host_util.hpp"
 
+// the exact k-NN building block (fp32-MFMA contraction + exact re-rank), defined with the C ABI below
+static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
+                             uint32_t *d_slots, float *d_dists, hipStream_t st);
+
 namespace lgpu {
 
 static const char *kNoDevice = "lantern_gpu: no HIP device available (this library has no CPU fallback)";
@@ -88,6 +92,7 @@ static bool reserve_locked(Index *ix, size_t newcap)
     const size_t oc = ix->cap, row = (size_t)ix->chunks * 16;
     if(!dev_grow(ix, (void **)&ix->d_vec, oc * row, newcap * row, -1)) return false;
     if(mcode_base(ix->mcode) == M_COS && !mcode_is_i8(ix->mcode) && !dev_grow(ix, (void **)&ix->d_norm2, oc * 4, newcap * 4, -1)) return false;
+    if(ix->pq && !dev_grow(ix, (void **)&ix->d_codes, oc * ix->pq_S, newcap * ix->pq_S, 0)) return false;
     if(!dev_grow(ix, (void **)&ix->d_labels, oc * 8, newcap * 8, -1)) return false;
     if(!dev_grow(ix, (void **)&ix->d_levels, oc, newcap, 0)) return false;
     if(!dev_grow(ix, (void **)&ix->d_nbr0, oc * ix->M0 * 4, newcap * ix->M0 * 4, 0xFF)) return false;
@@ -116,6 +121,40 @@ bool fill_norms(Index *ix, size_t first, size_t count)
     return true;
 }
 
+// ---- product quantisation -------------------------------------------------------------------------------------------
+// Rows [first, first + count) of the vector block hold the caller's f32 vectors: replace each by its quantisation.
+// Per subvector the nearest centroid under the index metric, the first minimum winning -- the rule of the reference's
+// quantize_vector / assign_to_clusters (product_quantization.c:80-124, :207-240: a strict `<` scan over usearch_distance)
+// -- found by the exact k-NN machinery (fp32-MFMA contraction, exact re-rank in the pair kernel's reduction order).
+bool pq_encode_rows(Index *ix, size_t first, size_t count)
+{
+    if(!ix->pq || count == 0) return true;
+    const uint32_t sub_chunks = (ix->pq_subdim + 3) / 4, sub_floats = sub_chunks * 4, row_floats = ix->chunks * 4;
+    float    *d_sub = nullptr;
+    uint32_t *d_near = nullptr;
+    bool ok = hipMalloc((void **)&d_sub, count * (size_t)sub_floats * 4) == hipSuccess && hipMalloc((void **)&d_near, count * 8) == hipSuccess;
+    for(uint32_t sv = 0; ok && sv < ix->pq_S; ++sv) {
+        ok = ok && launch_pq_take((const float *)ix->d_vec, row_floats, (uint32_t)first, (uint32_t)count, sv, ix->pq_subdim, sub_floats, d_sub, ix->stream) == hipSuccess;
+        ok = ok && ::exact_knn_device(ix->metric, sub_chunks, (const uint4 *)(ix->d_centers + (size_t)sv * ix->pq_C * sub_floats), ix->pq_C, (const uint4 *)d_sub,
+                                    count, 1, d_near, (float *)(d_near + count), ix->stream);
+        ok = ok && launch_pq_put((float *)ix->d_vec, row_floats, (uint32_t)first, (uint32_t)count, sv, ix->pq_subdim, ix->pq_S, d_near, ix->d_codebook,
+                                 (uint32_t)ix->opts.dimensions, ix->d_codes, ix->stream) == hipSuccess;
+    }
+    ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
+    if(d_sub) (void)hipFree(d_sub);
+    if(d_near) (void)hipFree(d_near);
+    if(!ok) set_err(ix, "lantern_gpu: HIP failure while quantising vectors");
+    return ok;
+}
+
+bool pq_decode_rows(Index *ix, size_t first, size_t count)
+{
+    if(!ix->pq || count == 0) return true;
+    HIPCHK(ix, launch_pq_decode((float *)ix->d_vec, ix->chunks * 4, (uint32_t)first, (uint32_t)count, ix->pq_subdim, ix->pq_S, ix->d_codebook,
+                                (uint32_t)ix->opts.dimensions, ix->d_codes, ix->stream));
+    return true;
+}
+
 bool ensure_bitmaps(Index *ix, size_t slots)
 {
     const size_t words = ((std::max<size_t>(ix->cap, 1) + 31) / 32 + 3) / 4 * 4;
@@ -141,6 +180,7 @@ size_t input_bytes(const Index *ix, int kind_in)
 // hands f32 arrays to usearch_add / usearch_search_ef whatever quant_bits says: build.c:128, scan.c:220)
 bool kind_accepted(const Index *ix, int kind_in)
 {
+    if(ix->b1_from_f32) return kind_in == usearch_scalar_f32_k;  // quant_bits = 1: real[] in, bits stored
     return kind_in == ix->scalar ||
            ((ix->scalar == usearch_scalar_f16_k || ix->scalar == usearch_scalar_i8_k) && kind_in == usearch_scalar_f32_k);
 }
@@ -162,7 +202,14 @@ bool pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst)
 {
     const size_t row_words = (size_t)ix->chunks * 4;
     std::memset(dst, 0, row_words * 4);
-    if(ix->scalar == usearch_scalar_f16_k && kind_in == usearch_scalar_f32_k) {
+    if(ix->b1_from_f32) {
+        // usearch's cast to b1x8: bit i = (x_i > 0), most significant bit of each byte first ("binary > 0 quantization",
+        // lantern_hnsw/test/sql/hnsw_sq.sql:33-34); NaN compares false
+        const float *f = (const float *)vec;
+        uint8_t     *b = (uint8_t *)dst;
+        for(size_t i = 0; i < ix->opts.dimensions; ++i)
+            if(f[ i ] > 0.f) b[ i >> 3 ] |= (uint8_t)(128u >> (i & 7));
+    } else if(ix->scalar == usearch_scalar_f16_k && kind_in == usearch_scalar_f32_k) {
         const float *f = (const float *)vec;
         _Float16    *h = (_Float16 *)dst;
         for(size_t i = 0; i < ix->opts.dimensions; ++i) h[ i ] = (_Float16)f[ i ];
@@ -539,6 +586,7 @@ static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_i
     up = up && hipMemcpyAsync(ix->d_upper_off + first, s.uo.data(), count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
     if(!up) { set_err(ix, "lantern_gpu: HIP failure uploading vectors"); return fail(); }
+    if(!pq_encode_rows(ix, first, count)) return fail();  // pq = true: the rows become their decodings, the codes go beside them
     if(!fill_norms(ix, first, count)) return fail();
     return run_batches(ix, labels, s, count, nullptr, ok_out);
 }
@@ -593,6 +641,7 @@ bool add_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const voi
     std::vector<uint64_t> all_labels(total);
     HIPCHK(ix, hipMemcpyAsync(all_labels.data(), lab_base, total * 8, hipMemcpyDeviceToHost, ix->stream));
     if(!sync_stream(ix, comm)) return false;
+    if(!pq_encode_rows(ix, first, total)) return false;  // every rank quantises all rows: deterministic, the replicas stay identical
     if(!fill_norms(ix, first, total)) return false;  // every rank over all rows: the replicas stay self-contained
     bool ok = true;
     run_batches(ix, all_labels.data(), s, total, comm, &ok);
@@ -721,20 +770,24 @@ size_t search_one_locked(Index *ix, Cursor *cur, const void *query, int kind, si
 
 bool import_graph_locked(Index *ix, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,
                          const uint32_t *nbr0, const uint32_t *upper_off, const uint32_t *upper_nbr, uint32_t entry_slot,
-                         int32_t max_level)
+                         int32_t max_level, bool vectors_are_codes)
 {
     if(ix->n || !ix->pend_labels.empty()) { set_err(ix, "lantern_gpu: import needs an empty index"); return false; }
     if(size == 0) return true;
     size_t blocks = 0;
     for(size_t i = 0; i < size; ++i) blocks += levels[ i ];
     if(!reserve_locked(ix, std::max(size, ix->cap)) || !reserve_upper(ix, blocks)) return false;
-    if(ix->chunks * 4 == ix->words) {
+    if(ix->pq && vectors_are_codes) {  // a file / the pages carry the codes: the rows are their decodings
+        HIPCHK(ix, hipMemcpy(ix->d_codes, vectors, size * (size_t)ix->pq_S, hipMemcpyHostToDevice));
+        if(!pq_decode_rows(ix, 0, size)) return false;
+    } else if(ix->chunks * 4 == ix->words) {
         HIPCHK(ix, hipMemcpy(ix->d_vec, vectors, size * (size_t)ix->words * 4, hipMemcpyHostToDevice));
     } else {
         HIPCHK(ix, hipMemset(ix->d_vec, 0, size * (size_t)ix->chunks * 16));
         HIPCHK(ix, hipMemcpy2D(ix->d_vec, (size_t)ix->chunks * 16, vectors, (size_t)ix->words * 4, (size_t)ix->words * 4, size,
                                hipMemcpyHostToDevice));
     }
+    if(ix->pq && !vectors_are_codes && !pq_encode_rows(ix, 0, size)) return false;  // raw f32 rows: quantise them
     if(!fill_norms(ix, 0, size)) return false;
     ix->labels.resize(size);
     for(size_t i = 0; i < size; ++i) ix->labels[ i ] = labels ? labels[ i ] : (uint64_t)i;
@@ -787,7 +840,7 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     CLEAR(e);
     if(!o) { FAIL(e, "lantern_gpu: null init options"); return nullptr; }
     if(o->metric != nullptr) { FAIL(e, "lantern_gpu: custom metric functions are not supported"); return nullptr; }
-    if(o->pq || pq_codebook) { FAIL(e, "lantern_gpu: product quantization is not supported by the device index"); return nullptr; }
+    if(o->pq != (pq_codebook != nullptr)) { FAIL(e, "lantern_gpu: pq = true needs a codebook, and a codebook needs pq = true"); return nullptr; }
     if(o->metric_kind != usearch_metric_cos_k && o->metric_kind != usearch_metric_l2sq_k &&
        o->metric_kind != usearch_metric_hamming_k) {
         FAIL(e, "lantern_gpu: unsupported metric kind (expected cos, l2sq or hamming)");  // options.c:119-127
@@ -797,9 +850,22 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     if(o->connectivity < 2 || o->connectivity > 128) { FAIL(e, "lantern_gpu: connectivity (M) must be in [2, 128]"); return nullptr; }  // options.c:165-179
     const bool ham = o->metric_kind == usearch_metric_hamming_k;
     if(ham && o->quantization != usearch_scalar_b1_k) { FAIL(e, "lantern_gpu: hamming needs b1 scalars"); return nullptr; }
-    if(!ham && o->quantization != usearch_scalar_f32_k && o->quantization != usearch_scalar_f16_k && o->quantization != usearch_scalar_i8_k) {
-        FAIL(e, "lantern_gpu: cos/l2sq indexes take f32, f16 or i8 storage (quant_bits=32, 16 or 8)");  // options.c:137-158
+    // quant_bits = 1 on real[] (options.c:154-155): bits = (x > 0); over {0, 1} values sum (a - b)^2 is exactly the Hamming
+    // distance, so an l2sq index runs on the Hamming kernels.  What the fork computes for COSINE over b1 storage cannot be
+    // read off the tree (upstream usearch has no such metric), so that combination is refused rather than guessed.
+    const bool b1f = !ham && o->quantization == usearch_scalar_b1_k;
+    if(b1f && o->metric_kind != usearch_metric_l2sq_k) { FAIL(e, "lantern_gpu: quant_bits=1 is supported for l2sq indexes only"); return nullptr; }
+    if(!ham && !b1f && o->quantization != usearch_scalar_f32_k && o->quantization != usearch_scalar_f16_k && o->quantization != usearch_scalar_i8_k) {
+        FAIL(e, "lantern_gpu: cos/l2sq indexes take f32, f16, i8 or b1 storage (quant_bits=32, 16, 8 or 1)");  // options.c:137-158
         return nullptr;
+    }
+    if(o->pq) {  // build.c:497-500, scan.c:75-81, pqtable.c:194-240
+        if(ham || o->quantization != usearch_scalar_f32_k) { FAIL(e, "lantern_gpu: pq indexes are cos / l2sq over f32 vectors"); return nullptr; }
+        if(o->num_centroids < 1 || o->num_centroids > 256) { FAIL(e, "lantern_gpu: num_centroids must be in [1, 256]"); return nullptr; }
+        if(o->num_subvectors < 1 || o->num_subvectors > o->dimensions || o->dimensions % o->num_subvectors != 0) {
+            FAIL(e, "lantern_gpu: num_subvectors must divide the dimensions");
+            return nullptr;
+        }
     }
     if(lantern_gpu_device_count() <= 0) { FAIL(e, kNoDevice); return nullptr; }
 
@@ -808,8 +874,9 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     ix->metric = (int)o->metric_kind;
     ix->scalar = (int)o->quantization;
     const bool f16 = o->quantization == usearch_scalar_f16_k, i8 = o->quantization == usearch_scalar_i8_k;
-    ix->mcode = ix->metric + (f16 ? M_F16 : i8 ? M_I8 : 0);
-    ix->words = ham ? (uint32_t)((o->dimensions + 31) / 32)
+    ix->b1_from_f32 = b1f;
+    ix->mcode = b1f ? M_HAMMING : ix->metric + (f16 ? M_F16 : i8 ? M_I8 : 0);
+    ix->words = (ham || b1f) ? (uint32_t)((o->dimensions + 31) / 32)
                 : f16 ? (uint32_t)((o->dimensions + 1) / 2)
                 : i8 ? (uint32_t)((o->dimensions + 3) / 4)
                      : (uint32_t)o->dimensions;
@@ -833,6 +900,30 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
         FAIL(e, "lantern_gpu: device allocation failed");
         return nullptr;
     }
+    if(o->pq) {
+        // the codebook as Lantern hands it over: num_centroids rows of `dimensions` floats, row c = centroid c of every
+        // subvector, concatenated (pqtable.c:194-240).  Besides it, per subvector, the table the nearest-centroid search reads.
+        ix->pq = true;
+        ix->pq_S = (uint32_t)o->num_subvectors;
+        ix->pq_C = (uint32_t)o->num_centroids;
+        ix->pq_subdim = (uint32_t)(o->dimensions / o->num_subvectors);
+        const size_t d = o->dimensions, subf = (size_t)((ix->pq_subdim + 3) / 4) * 4;
+        ix->h_codebook.assign(pq_codebook, pq_codebook + (size_t)ix->pq_C * d);
+        std::vector<float> centers((size_t)ix->pq_S * ix->pq_C * subf, 0.f);
+        for(size_t sv = 0; sv < ix->pq_S; ++sv)
+            for(size_t c = 0; c < ix->pq_C; ++c)
+                std::memcpy(&centers[ (sv * ix->pq_C + c) * subf ], pq_codebook + c * d + sv * ix->pq_subdim, (size_t)ix->pq_subdim * 4);
+        const bool ok = hipMalloc((void **)&ix->d_codebook, ix->h_codebook.size() * 4) == hipSuccess &&
+                        hipMalloc((void **)&ix->d_centers, centers.size() * 4) == hipSuccess &&
+                        hipMemcpy(ix->d_codebook, ix->h_codebook.data(), ix->h_codebook.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                        hipMemcpy(ix->d_centers, centers.data(), centers.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+        if(!ok) {
+            usearch_error_t ignore = nullptr;
+            usearch_free(ix, &ignore);
+            FAIL(e, "lantern_gpu: device allocation failed (codebook)");
+            return nullptr;
+        }
+    }
     return ix;
 }
 
@@ -841,7 +932,8 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
-    void *ptrs[] = { ix->d_vec, ix->d_norm2, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals, ix->d_tickets };
+    void *ptrs[] = { ix->d_vec, ix->d_norm2, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals, ix->d_tickets,
+                     ix->d_codebook, ix->d_centers, ix->d_codes };
     for(void *p : ptrs)
         if(p) (void)hipFree(p);
     for(void *p : ix->d_scratch)
@@ -1189,7 +1281,7 @@ void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uin
     char        *buf = (char *)scratch(ix, 5, row + n * 8 + 16);
     if(!buf) { FAIL(e, ix->err.c_str()); return; }
     std::vector<uint32_t> padded((size_t)ix->chunks * 4);
-    pad_row(ix, query, ix->scalar == usearch_scalar_b1_k ? usearch_scalar_b1_k : usearch_scalar_f32_k, padded.data());
+    pad_row(ix, query, (ix->scalar == usearch_scalar_b1_k && !ix->b1_from_f32) ? usearch_scalar_b1_k : usearch_scalar_f32_k, padded.data());
     uint32_t *d_slots = (uint32_t *)(buf + row);
     float    *d_out = (float *)(buf + row + n * 4);
     bool      ok = hipMemcpyAsync(buf, padded.data(), row, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
@@ -1269,7 +1361,7 @@ void lantern_gpu_exact_search(usearch_index_t h, const void *queries, size_t nq,
         for(size_t i = 0; i < nq * k; ++i) { slots[ i ] = EMPTY; distances[ i ] = INFINITY; }
         return;
     }
-    const int    qkind = ix->scalar == usearch_scalar_b1_k ? usearch_scalar_b1_k : usearch_scalar_f32_k;  // queries arrive as f32 / bits
+    const int    qkind = (ix->scalar == usearch_scalar_b1_k && !ix->b1_from_f32) ? usearch_scalar_b1_k : usearch_scalar_f32_k;  // queries arrive as f32 / bits
     const size_t in_bytes = input_bytes(ix, qkind);
     std::vector<uint32_t> padded(nq * row_words);
     for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, qkind, &padded[ i * row_words ]);
@@ -1461,6 +1553,17 @@ void lantern_gpu_export_graph(usearch_index_t h, uint8_t *levels, uint32_t *nbr0
         }
     }
     if(!ok) FAIL(e, "lantern_gpu: HIP failure exporting the graph");
+}
+
+void lantern_gpu_export_codes(usearch_index_t h, uint8_t *codes, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    if(!ix->pq) { FAIL(e, "lantern_gpu: not a pq index"); return; }
+    if(ix->n && hipMemcpy(codes, ix->d_codes, ix->n * (size_t)ix->pq_S, hipMemcpyDeviceToHost) != hipSuccess) FAIL(e, "lantern_gpu: HIP failure exporting the codes");
 }
 
 void lantern_gpu_import_graph(usearch_index_t h, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,

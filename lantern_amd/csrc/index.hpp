@@ -37,6 +37,20 @@ struct Index
     int      search_waves = 4, search_max_wg = 0, insert_waves = 4;
     int      search_vis_slots = -1;  // -1 = automatic size of the LDS visited set, 0 = HBM bitmap only
 
+    // ---- quantised views of f32 input ----------------------------------------------------------------------------
+    // quant_bits = 1 on real[] (options.c:154-155, test/sql/hnsw_sq.sql "binary > 0 quantization"): an l2sq index whose
+    // rows are one bit per dimension, bit = (x > 0); sum (a - b)^2 over {0, 1} values IS the Hamming distance, so the
+    // Hamming kernels run it exactly.  Callers still hand f32 arrays to usearch_add / usearch_search_ef.
+    bool     b1_from_f32 = false;
+    // pq = true (build.c:497-500, scan.c:75-81): the vector block holds every row's DECODING (concatenated centroids),
+    // d_codes its num_subvectors code bytes (what the file / the pages carry: usearch_storage.cpp:29-31)
+    bool     pq = false;
+    uint32_t pq_S = 0, pq_C = 0, pq_subdim = 0;
+    std::vector<float> h_codebook;       // [pq_C][dimensions]: row c = centroid c of every subvector, concatenated (pqtable.c:194-240)
+    float   *d_codebook = nullptr;
+    float   *d_centers = nullptr;        // [pq_S][pq_C][sub_floats]: the per-subvector centroid tables, rows zero padded to chunks
+    uint8_t *d_codes = nullptr;          // [cap][pq_S]
+
     // ---- graph state ------------------------------------------------------------------------------
     size_t   n = 0, cap = 0;
     uint32_t entry = EMPTY;
@@ -128,6 +142,8 @@ struct Index
 const char *set_err(Index *ix, const std::string &msg);
 bool        flush_locked(Index *ix);            // false -> ix->err set
 bool        ensure_bitmaps(Index *ix, size_t slots);
+bool        pq_encode_rows(Index *ix, size_t first, size_t count);  // raw f32 rows [first, first+count) in d_vec -> codes + decodings
+bool        pq_decode_rows(Index *ix, size_t first, size_t count);  // d_codes -> d_vec
 bool        fill_norms(Index *ix, size_t first, size_t count);  // after rows [first, first + count) are in d_vec
 void       *scratch(Index *ix, int which, size_t bytes);
 bool        pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst);
@@ -148,7 +164,7 @@ bool        order_launch(Index *ix, hipStream_t stream);   // before a launch th
 bool        record_launch(Index *ix, hipStream_t stream);  // behind it
 bool        import_graph_locked(Index *ix, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,
                                 const uint32_t *nbr0, const uint32_t *upper_off, const uint32_t *upper_nbr, uint32_t entry_slot,
-                                int32_t max_level);
+                                int32_t max_level, bool vectors_are_codes = false);  // pq: `vectors` = num_subvectors code bytes per row
 
 // usearch-format serialisation (usearch_file.cpp)
 size_t serialized_length(Index *ix);

@@ -6,7 +6,7 @@
 // Wire protocol, little-endian only (external_index_socket.c:337-339):
 //   server -> u32 PROTOCOL_VERSION (1), u32 SERVER_TYPE (1 = indexing server)          server.rs:183-184
 //   client -> u32 INIT_MSG 0x13333337 + external_index_params_t (11 x u32)             external_index_socket.h:24-38
-//   [pq: codebook frames + END_MSG -- refused here, PQ is out of scope]
+//   [pq = 1: num_centroids codebook frames of dim f32 each, then END_MSG                server.rs:107-127, external_index_socket.c:304-320]
 //   server -> u8 0                                                                      server.rs:206
 //   client -> rows [u64 label][dim * element_bits/8 bytes | ceil(dim/8) bytes if bits<8] server.rs:226-230, :169-174
 //   client -> u32 END_MSG 0x31333337
@@ -130,7 +130,20 @@ void serve(lantern_index_server *srv, int fd)
         o.pq = pq == 1;
         o.num_centroids = num_centroids;
         o.num_subvectors = num_subvectors;
-        index = usearch_init(&o, nullptr, &err);
+        std::vector<float> codebook;
+        if(o.pq) {  // server.rs:107-127: frames of `dim` floats until END_MSG; row c = centroid c of every subvector, concatenated
+            if(num_centroids == 0 || num_centroids > 256) throw Fail{ "Invalid number of centroids" };
+            for(;;) {
+                Frame f = read_frame(fd, buf, (size_t)dim * 4, false);
+                if(f == FRAME_EXIT) break;
+                if(f != FRAME_DATA) throw Fail{ "Invalid message received" };
+                if(codebook.size() >= (size_t)256 * dim) throw Fail{ "Codebook larger than 256 centroids" };
+                const float *row = (const float *)buf.data();
+                codebook.insert(codebook.end(), row, row + dim);
+            }
+            if(codebook.size() != (size_t)num_centroids * dim) throw Fail{ "Codebook size does not match num_centroids" };
+        }
+        index = usearch_init(&o, o.pq ? codebook.data() : nullptr, &err);
         if(err) throw Fail{ err };
         usearch_reserve(index, estimated_capacity, &err);
         if(err) throw Fail{ err };

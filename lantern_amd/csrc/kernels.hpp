@@ -114,6 +114,15 @@ hipError_t launch_apply_own_links(const View &v, uint32_t first_slot, const uint
 hipError_t launch_pack_lists(const RevlinkArgs &a, uint32_t *records, hipStream_t stream);
 hipError_t launch_apply_lists(const View &v, const uint32_t *records, uint32_t nrecords, hipStream_t stream);
 
+// ---- product quantisation (grouping.hip): a PQ index holds every row's DECODING in the vector block (all distances are
+// distances to / between decoded vectors) and the codes -- what the file and the pages carry -- beside it
+hipError_t launch_pq_take(const float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t s, uint32_t subdim, uint32_t sub_floats,
+                          float *sub, hipStream_t stream);
+hipError_t launch_pq_put(float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t s, uint32_t subdim, uint32_t S, const uint32_t *nearest,
+                         const float *codebook, uint32_t dims, uint8_t *codes, hipStream_t stream);
+hipError_t launch_pq_decode(float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t subdim, uint32_t S, const float *codebook, uint32_t dims,
+                            const uint8_t *codes, hipStream_t stream);
+
 // ||row||^2 of rows [first, first + count) into norm2 (cosine metrics only; no-op otherwise)
 hipError_t launch_fill_norms(int metric, const View &v, uint32_t first, uint32_t count, float *norm2, hipStream_t stream);
 // out[i] = metric(query, row(slots[i]))

@@ -87,7 +87,8 @@ template <typename T> void put(char *p, size_t off, T v) { std::memcpy(p + off, 
 template <typename T> T    get(const char *p, size_t off) { T v; std::memcpy(&v, p + off, sizeof(T)); return v; }
 
 // bytes of one stored vector on the tape: dimensions * bits_per_scalar / 8 (usearch_storage.cpp:63-81)
-size_t vector_bytes(const Index *ix) { return input_bytes(ix, ix->scalar); }
+// pq: num_subvectors code bytes, "assuming at most 2 ** 8 centroids (= 1 byte) per subvector" (usearch_storage.cpp:29-31)
+size_t vector_bytes(const Index *ix) { return ix->pq ? (size_t)ix->pq_S : input_bytes(ix, ix->scalar); }
 size_t node_bytes(const Index *ix, int level)
 {
     return 8 + 2 + (4 + (size_t)ix->M0 * LANTERN_SLOT_SIZE) + (size_t)level * (4 + (size_t)ix->M * LANTERN_SLOT_SIZE) + vector_bytes(ix);
@@ -135,7 +136,13 @@ bool serialize(Index *ix, char *buf, size_t len)
     std::vector<char>     rows(n * row);
     bool ok = hipMemcpy(nbr0.data(), ix->d_nbr0, nbr0.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
     if(ix->upper_blocks) ok = ok && hipMemcpy(upper.data(), ix->d_upper_nbr, ix->upper_blocks * ix->M * 4, hipMemcpyDeviceToHost) == hipSuccess;
-    ok = ok && hipMemcpy(rows.data(), ix->d_vec, rows.size(), hipMemcpyDeviceToHost) == hipSuccess;
+    size_t row_stride = row;
+    if(ix->pq) {  // the tape carries the codes
+        row_stride = ix->pq_S;
+        ok = ok && hipMemcpy(rows.data(), ix->d_codes, n * row_stride, hipMemcpyDeviceToHost) == hipSuccess;
+    } else {
+        ok = ok && hipMemcpy(rows.data(), ix->d_vec, rows.size(), hipMemcpyDeviceToHost) == hipSuccess;
+    }
     if(!ok) { set_err(ix, "lantern_gpu: HIP failure while serialising"); return false; }
     char *p = buf + USEARCH_HEADER_SIZE;
     for(size_t i = 0; i < n; ++i) {
@@ -153,7 +160,7 @@ bool serialize(Index *ix, char *buf, size_t len)
             for(uint32_t j = 0; j < cnt; ++j) put<uint32_t>(q, 4 + (size_t)j * LANTERN_SLOT_SIZE, list[ j ]);  // low 4 of 6 bytes
             q += 4 + (size_t)cap * LANTERN_SLOT_SIZE;
         }
-        std::memcpy(q, &rows[ i * row ], vb);
+        std::memcpy(q, &rows[ i * row_stride ], vb);
         p += node_bytes(ix, level);
     }
     return true;
@@ -218,13 +225,13 @@ bool deserialize(Index *ix, const char *buf, size_t len)
                 if(levels[ list[ j ] ] < l) { set_err(ix, "lantern_gpu: an upper-level list names a node that does not reach that level"); return false; }
         }
     // bit / f16 rows are stored as bytes in the file; the importer wants whole u32 words per row
-    if(vb != (size_t)ix->words * 4) {
+    if(!ix->pq && vb != (size_t)ix->words * 4) {
         std::vector<char> w(n * (size_t)ix->words * 4, 0);
         for(size_t i = 0; i < n; ++i) std::memcpy(&w[ i * (size_t)ix->words * 4 ], &vecs[ i * vb ], vb);
         vecs.swap(w);
     }
     if(!import_graph_locked(ix, n, vecs.data(), labels.data(), levels.data(), nbr0.data(), upper_off.data(), upper.data(),
-                            (uint32_t)get<uint64_t>(buf, OFF_G_ENTRY_SLOT), (int32_t)get<uint64_t>(buf, OFF_G_MAX_LEVEL)))
+                            (uint32_t)get<uint64_t>(buf, OFF_G_ENTRY_SLOT), (int32_t)get<uint64_t>(buf, OFF_G_MAX_LEVEL), ix->pq))
         return false;
     return true;
 }
@@ -249,7 +256,7 @@ bool mirror_from_retriever(Index *ix, const char *header)
     if(declared >= 0x7FFFFFFFull) { set_err(ix, "lantern_gpu: the header declares more nodes than the device index supports"); return false; }
     const uint64_t mask48 = 0xFFFFFFFFFFFFull;
     const uint64_t entry = get<uint64_t>(header, OFF_G_ENTRY_SLOT) & mask48;
-    const size_t   vb = vector_bytes(ix), wbytes = (size_t)ix->words * 4;
+    const size_t   vb = vector_bytes(ix), wbytes = ix->pq ? vb : (size_t)ix->words * 4;
     std::unordered_map<uint64_t, uint32_t> id_of;
     std::vector<uint64_t> slot_of, labels;
     std::vector<uint8_t>  levels;
@@ -307,7 +314,7 @@ bool mirror_from_retriever(Index *ix, const char *header)
         }
     }
     if(!import_graph_locked(ix, slot_of.size(), vecs.data(), labels.data(), levels.data(), nbr0.data(), upper_off.data(), upper.data(),
-                            0 /* the entry slot was interned first */, (int32_t)top))
+                            0 /* the entry slot was interned first */, (int32_t)top, ix->pq))
         return false;
     ix->page_slots.swap(slot_of);
     ix->page_ids.swap(id_of);
@@ -365,9 +372,10 @@ bool write_back_insert(Index *ix, uint32_t id, char *node_tape)
         }
     }
     // the stored vector sits behind the last list (usearch_init_node leaves it zeroed: usearch_storage.cpp:34-44)
-    const size_t row = (size_t)ix->chunks * 16;
+    const size_t row = ix->pq ? (size_t)ix->pq_S : (size_t)ix->chunks * 16;
     std::vector<char> stored(row);
-    if(hipMemcpy(stored.data(), (const char *)ix->d_vec + (size_t)id * row, row, hipMemcpyDeviceToHost) != hipSuccess) { set_err(ix, "lantern_gpu: HIP failure reading a row"); return false; }
+    const char *src = ix->pq ? (const char *)ix->d_codes + (size_t)id * row : (const char *)ix->d_vec + (size_t)id * row;
+    if(hipMemcpy(stored.data(), src, row, hipMemcpyDeviceToHost) != hipSuccess) { set_err(ix, "lantern_gpu: HIP failure reading a row"); return false; }
     std::memcpy(node_tape + tape_list_offset(ix, level + 1), stored.data(), vector_bytes(ix));
     return true;
 }

@@ -41,11 +41,20 @@ def init_frame(metric_kind, quantization, dim, m, efc, ef, capacity, element_bit
     return struct.pack("<12I", INIT_MSG, pq, metric_kind, quantization, dim, m, efc, ef, num_centroids, num_subvectors, capacity, element_bits)
 
 
-def build_index(host, port, metric_kind, dim, rows, labels, m=16, efc=128, ef=64, element_bits=32, quantization=1, capacity=None):
-    """Returns (num_added, index_file_bytes).  rows: bytes-like per row."""
+def build_index(host, port, metric_kind, dim, rows, labels, m=16, efc=128, ef=64, element_bits=32, quantization=1, capacity=None,
+                codebook=None, num_subvectors=0):
+    """Returns (num_added, index_file_bytes).  rows: bytes-like per row.  codebook: [num_centroids][dim] f32 rows (pq = true):
+    sent centroid by centroid, then END_MSG (external_index_send_codebook, external_index_socket.c:304-320)."""
     s, version, server_type = connect(host, port)
     assert (version, server_type) == (PROTOCOL_VERSION, SERVER_TYPE_INDEXER)
-    s.sendall(init_frame(metric_kind, quantization, dim, m, efc, ef, capacity if capacity is not None else len(labels), element_bits))
+    if codebook is None:
+        s.sendall(init_frame(metric_kind, quantization, dim, m, efc, ef, capacity if capacity is not None else len(labels), element_bits))
+    else:
+        s.sendall(init_frame(metric_kind, quantization, dim, m, efc, ef, capacity if capacity is not None else len(labels), element_bits,
+                             pq=1, num_centroids=len(codebook), num_subvectors=num_subvectors))
+        for row in codebook:
+            s.sendall(bytes(row))
+        s.sendall(struct.pack("<I", END_MSG))
     status = recv_exact(s, 1)
     if status != b"\x00":
         raise IndexServerError(read_error(s, status + recv_exact(s, 3)))

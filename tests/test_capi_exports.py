@@ -74,7 +74,10 @@ def test_argument_validation_precedes_device_use(capi):
     assert b"unsupported metric" in err.value
     o.metric_kind, o.pq = 3, True
     assert capi.lib().usearch_init(C.byref(o), None, C.byref(err)) is None
-    assert b"product quantization" in err.value
+    assert b"pq = true needs a codebook" in err.value  # build.c:497-500 always passes the codebook it loaded
+    o.pq, o.quantization, o.metric_kind = False, 5, 1  # quant_bits = 1 on a cosine index: the fork's arithmetic is unknown -> refused
+    assert capi.lib().usearch_init(C.byref(o), None, C.byref(err)) is None
+    assert b"quant_bits=1 is supported for l2sq indexes only" in err.value
 
 
 def test_level_draw_and_batch_plan_agree_with_the_oracle(capi):

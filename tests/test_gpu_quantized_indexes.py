@@ -1,0 +1,180 @@
+"""quant_bits = 1 on real[] input (options.c:154-155, test/sql/hnsw_sq.sql) and pq = true indexes (build.c:497-500,
+scan.c:75-81, pqtable.c:194-240) on the device.  PARITY UNPINNED BY THE REFERENCE: both arithmetic paths live in the
+un-vendored usearch fork and the reference's own expected outputs for them (hnsw_sq.out, hnsw_pq*.out) need sift1k, which
+is downloaded at test time.  What is checked is the restated semantics, bit for bit:
+  b1   bit i = (x_i > 0); the l2sq distance of {0, 1} vectors IS their Hamming distance -> identical to the oracle's
+       Hamming index over the packed bits (graph, ids, distances, D / E);
+  pq   every stored vector is replaced by its quantisation (per subvector the nearest centroid, first minimum wins);
+       all distances are distances to / between DECODED vectors -> identical to the oracle's f32 index over the decoded
+       rows; the file carries num_subvectors code bytes per node."""
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from lantern_amd import capi
+
+    capi.lib()
+    assert capi.device_count() > 0
+    return capi
+
+
+def pack_bits_msb_first(x):
+    """usearch's cast to b1x8: bit i = (x_i > 0), most significant bit of each byte first; returned as u32 words (LE)."""
+    bits = (np.asarray(x) > 0).astype(np.uint8)
+    n, d = bits.shape
+    pad = (-d) % 32
+    if pad:
+        bits = np.concatenate([bits, np.zeros((n, pad), np.uint8)], axis=1)
+    return np.packbits(bits, axis=1, bitorder="big").view(np.uint32)
+
+
+@pytest.mark.parametrize("n,d,M,efc", [(3000, 128, 8, 48), (1500, 768, 16, 64), (800, 100, 4, 24)])
+def test_quant_bits_1_on_real_input_is_the_hamming_index_of_the_sign_bits(capi, oracle, tmp_path, n, d, M, efc):
+    rng = np.random.default_rng(n + d)
+    base = (rng.standard_normal((n, d)) - 0.1).astype(np.float32)  # "v_transformed": roughly centred real values
+    base[5, :7] = [0.0, -0.0, np.nan, 1e-30, -1e-30, np.inf, -np.inf]  # only strictly positive values set a bit; NaN does not
+    queries = rng.standard_normal((200, d)).astype(np.float32)
+    labels = np.arange(n, dtype=np.uint64) + 1
+    ix = capi.GpuIndex("l2sq", d, M=M, ef_construction=efc, ef=40, seed=3, quantization="b1")
+    ix.set_add_batch(256, 16)
+    ix.add_many(labels, base)
+    words = pack_bits_msb_first(base)
+    qwords = pack_bits_msb_first(queries)
+    # the stored rows are the packed sign bits
+    g = ix.export_graph(with_vectors=True)
+    assert np.array_equal(g["vectors"], words)
+    # the graph is the oracle's Hamming graph over those bits (same batch plan), edge for edge
+    ora = oracle.OracleIndex("hamming", words.shape[1], M=M, ef_construction=efc, ef=40, seed=3)
+    ora.add_planned(labels, words, 256, 16)
+    o = ora.export_graph()
+    if d % 32 == 0:  # the oracle's hamming metric takes whole words; ragged bit counts are compared through search below
+        for key in ("levels", "nbr0", "upper_off", "upper_nbr"):
+            assert np.array_equal(g[key], o[key]), key
+    on_same = oracle.OracleIndex.from_graph("hamming", words, g, M, efc, 40, 3, oracle.SUM_SEQ)
+    o_lab, o_dist, o_slot, o_D, o_E = on_same.search_batch(qwords, 10, 40, 4)
+    lab, dist, cnt = ix.search_batch(queries, 10)
+    assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist)
+    # one query through usearch_search_ef (f32 in), the exact k-NN, the pair kernel: all on the bits
+    l1, d1 = ix.search(queries[0], 10)
+    assert np.array_equal(l1, lab[0]) and np.array_equal(d1, dist[0])
+    t_slots, t_d = ix.exact_search(queries[:32], 5)
+    b_ids, b_d = oracle.bruteforce(words, qwords[:32], 5, "hamming", oracle.SUM_SEQ, 4)
+    assert np.array_equal(t_slots, b_ids) and np.array_equal(t_d, b_d)
+    assert np.array_equal(ix.distance_gather(queries[3], t_slots[3]), t_d[3])
+    # file: ceil(d / 8) bytes per vector, header kinds l2sq ('e') + b1x8 (1); round trip
+    blob = ix.save_buffer()
+    assert blob[13:14] == b"e" and blob[14] == 1
+    assert len(blob) == 136 + sum(10 + (4 + 2 * M * 6) + int(l) * (4 + M * 6) + (d + 7) // 8 for l in g["levels"])
+    again = capi.GpuIndex("l2sq", d, M=M, ef_construction=efc, ef=40, seed=3, quantization="b1")
+    again.load_buffer(blob)
+    assert again.checksum() == ix.checksum() and np.array_equal(again.search_batch(queries, 10)[0], lab)
+    with pytest.raises(capi.LanternGpuError, match="l2sq indexes only"):
+        capi.GpuIndex("cos", d, quantization="b1")
+
+
+def make_codebook(rng, base, S, C):
+    """A codebook in the layout Lantern hands to usearch_init (pqtable.c:194-240): [C][d], row c = centroid c of every
+    subvector, concatenated.  Centroids are sampled data points per subvector (what k-means++ starts from)."""
+    n, d = base.shape
+    sub = d // S
+    cb = np.zeros((C, d), dtype=np.float32)
+    for s in range(S):
+        pick = rng.choice(n, size=C, replace=False)
+        cb[:, s * sub:(s + 1) * sub] = base[pick, s * sub:(s + 1) * sub]
+    return cb
+
+
+def quantize_reference(oracle, base, cb, S, metric):
+    """product_quantization.c:207-240 (quantize_vector): per subvector the centroid with the smallest distance under the
+    index metric, strict `<` scan -> first minimum; distances in the pair kernel's reduction order."""
+    n, d = base.shape
+    sub = d // S
+    codes = np.zeros((n, S), dtype=np.uint8)
+    for s in range(S):
+        ids, _ = oracle.bruteforce(np.ascontiguousarray(cb[:, s * sub:(s + 1) * sub]), np.ascontiguousarray(base[:, s * sub:(s + 1) * sub]), 1, metric,
+                                   oracle.SUM_WAVE64, 4)
+        codes[:, s] = ids[:, 0]
+    dec = np.zeros_like(base)
+    for s in range(S):
+        dec[:, s * sub:(s + 1) * sub] = cb[codes[:, s], s * sub:(s + 1) * sub]
+    return codes, dec
+
+
+@pytest.mark.parametrize("metric,n,d,S,C,M,efc", [("l2sq", 2500, 128, 32, 256, 8, 48), ("cos", 1500, 768, 96, 64, 16, 64), ("l2sq", 900, 60, 6, 10, 4, 24)])
+def test_pq_index_is_the_index_of_the_decoded_vectors(capi, oracle, metric, n, d, S, C, M, efc):
+    rng = np.random.default_rng(n + d + S)
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    queries = rng.standard_normal((150, d), dtype=np.float32)
+    labels = np.arange(n, dtype=np.uint64) + 1
+    cb = make_codebook(rng, base, S, C)
+    cb[1] = cb[0]  # a duplicated centroid: the FIRST minimum must win (strict `<` in the reference loop)
+    codes, dec = quantize_reference(oracle, base, cb, S, metric)
+    assert not np.any(codes == 1) or C < 2
+    ix = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=40, seed=5, pq_codebook=cb, num_subvectors=S)
+    ix.set_add_batch(256, 16)
+    ix.add_many(labels[:n // 2], base[:n // 2])  # a bulk add ...
+    for i in range(n // 2, n // 2 + 20):         # ... single adds (usearch_add, one tuple at a time) ...
+        ix.add(labels[i], base[i])
+    ix.add_many(labels[n // 2 + 20:], base[n // 2 + 20:])
+    assert np.array_equal(ix.export_codes(), codes)
+    g = ix.export_graph(with_vectors=True)
+    assert np.array_equal(g["vectors"], dec)  # HBM holds the decodings
+    # the oracle's plain f32 index over the decoded rows, same batch plan: the same graph, edge for edge
+    ora = oracle.OracleIndex(metric, d, M=M, ef_construction=efc, ef=40, seed=5, sum_mode=oracle.SUM_WAVE64)
+    plan = [n // 2] + [1] * 20 + [n - n // 2 - 20]
+    at = 0
+    for cnt in plan:  # the device flushes at every size() / single add: replay the same flush points
+        ora.add_planned(labels[at:at + cnt], dec[at:at + cnt], 256, 16)
+        at += cnt
+    o = ora.export_graph()
+    for key in ("levels", "nbr0", "upper_off", "upper_nbr"):
+        assert np.array_equal(g[key], o[key]), key
+    # search: f32 queries against decoded rows
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, 10, 40, 4)
+    lab, dist, cnt = ix.search_batch(queries, 10)
+    assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist)
+    # file: num_subvectors code bytes per node (usearch_storage.cpp:29-31); load decodes them again
+    blob = ix.save_buffer()
+    assert len(blob) == 136 + sum(10 + (4 + 2 * M * 6) + int(l) * (4 + M * 6) + S for l in g["levels"])
+    off = 136
+    for i in range(5):
+        lv = int(g["levels"][i])
+        vec_off = off + 10 + (4 + 2 * M * 6) + lv * (4 + M * 6)
+        assert blob[vec_off:vec_off + S] == codes[i].tobytes()
+        off = vec_off + S
+    again = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=40, seed=5, pq_codebook=cb, num_subvectors=S)
+    again.load_buffer(blob)
+    assert again.checksum() == ix.checksum()
+    g2 = again.export_graph(with_vectors=True)
+    assert np.array_equal(g2["vectors"], dec) and np.array_equal(again.search_batch(queries, 10)[0], lab)
+    m = ix.metadata()
+    assert m.init_options.pq and m.init_options.num_subvectors == S and m.init_options.num_centroids == C
+    with pytest.raises(capi.LanternGpuError, match="must divide"):
+        capi.GpuIndex(metric, d, pq_codebook=cb, num_subvectors=7 if d % 7 else 11)
+
+
+def test_pq_build_through_the_indexing_server(capi):
+    """CREATE INDEX ... WITH (external=true, pq=true): the codebook travels centroid by centroid before the rows
+    (external_index_socket.c:304-320,475-478; server.rs:107-127)."""
+    from tests import index_client
+
+    rng = np.random.default_rng(77)
+    n, d, S, C = 1200, 64, 16, 32
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    cb = make_codebook(rng, base, S, C)
+    srv = capi.IndexServer()
+    try:
+        added, blob = index_client.build_index(srv.host, srv.port, 3, d, [r.tobytes() for r in base], np.arange(n) + 1, m=8, efc=40, ef=32,
+                                               codebook=cb, num_subvectors=S)
+    finally:
+        srv.stop()
+    assert added == n
+    direct = capi.GpuIndex("l2sq", d, M=8, ef_construction=40, ef=32, seed=42, pq_codebook=cb, num_subvectors=S)
+    direct.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    assert direct.save_buffer() == blob
