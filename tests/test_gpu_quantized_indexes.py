@@ -127,9 +127,9 @@ def test_pq_index_is_the_index_of_the_decoded_vectors(capi, oracle, metric, n, d
     assert np.array_equal(g["vectors"], dec)  # HBM holds the decodings
     # the oracle's plain f32 index over the decoded rows, same batch plan: the same graph, edge for edge
     ora = oracle.OracleIndex(metric, d, M=M, ef_construction=efc, ef=40, seed=5, sum_mode=oracle.SUM_WAVE64)
-    plan = [n // 2] + [1] * 20 + [n - n // 2 - 20]
+    plan = [n // 2, 20, n - n // 2 - 20]
     at = 0
-    for cnt in plan:  # the device flushes at every size() / single add: replay the same flush points
+    for cnt in plan:  # the flush points of the calls above: the bulk add, the 20 buffered single adds, the second bulk add
         ora.add_planned(labels[at:at + cnt], dec[at:at + cnt], 256, 16)
         at += cnt
     o = ora.export_graph()

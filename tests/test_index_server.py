@@ -114,7 +114,7 @@ def test_hamming_and_larger_build(capi, server):
     hits = sum(int(ix.search(base[i], 1)[0][0]) == i + 1 for i in range(0, 3000, 30))
     assert n == 3000 and hits >= 95
     # an unsupported storage kind (f64) is refused with an error frame, not a hang
-    with pytest.raises(ic.IndexServerError, match="f32, f16 or i8 storage"):
+    with pytest.raises(ic.IndexServerError, match="f32, f16, i8 or b1 storage"):
         ic.build_index(server.host, server.port, 3, 32, [], [], element_bits=32, quantization=2)
     # quant_bits = 8: f32 rows in (element_bits = 32), i8 storage; raw i8 rows (element_bits = 8) give the same file
     small = (base[:600] * np.float32(0.3)).astype(np.float32)
