@@ -52,7 +52,7 @@ def parse():
     p.add_argument("--ef", type=int, default=64)
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--queries", type=int, default=8192, help="queries per step per GPU")
-    p.add_argument("--waves", type=int, default=4, help="wavefronts per query")
+    p.add_argument("--waves", type=int, default=0, help="wavefronts per query (0 = the library's automatic shape)")
     p.add_argument("--max-wg", type=int, default=0)
     p.add_argument("--add-batch", type=int, default=8192)
     p.add_argument("--truth-queries", type=int, default=1024, help="queries used for recall@k")
@@ -297,7 +297,7 @@ def main():
         if os.path.exists(prof):
             try:
                 rec = json.load(open(prof))
-                key = f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves}" + ("" if a.quant == "f32" else "_" + a.quant)
+                key = f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves or 4}" + ("" if a.quant == "f32" else "_" + a.quant)
                 traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

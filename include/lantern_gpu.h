@@ -214,7 +214,8 @@ LANTERN_GPU_EXPORT void lantern_gpu_search_batch_device(usearch_index_t, const v
                                                         size_t ef, size_t skip, uint64_t *d_labels, float *d_distances,
                                                         uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_dist_evals,
                                                         uint64_t *d_expansions, void *stream, usearch_error_t *);
-/* kernel shape of the search launch: waves per query (1..8) and resident workgroups (0 = auto) */
+/* kernel shape of the search launch: waves per query (1..8; 0 = automatic: 4 when the batch fills the chip, up to 8 for
+ * smaller batches) and resident workgroups (0 = auto) */
 LANTERN_GPU_EXPORT void lantern_gpu_set_search_shape(usearch_index_t, int waves_per_query, int max_workgroups,
                                                      usearch_error_t *);
 
@@ -356,6 +357,29 @@ LANTERN_GPU_EXPORT void lantern_scan_rescan(lantern_scan_t *, const void *query,
  * doubles k through the streaming continuation (scan.c:240-292), stops at 1000 rows (:249-252). */
 LANTERN_GPU_EXPORT bool lantern_scan_gettuple(lantern_scan_t *, usearch_label_t *label, usearch_error_t *);
 LANTERN_GPU_EXPORT void lantern_scan_end(lantern_scan_t *);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Lifecycle of the HBM mirrors of page-resident indexes.  The reference      */
+/* attaches anew per scan and per insert (scan.c:99-110, insert.c:142-151: free for a lazy view);  */
+/* a device mirror is a walk of the graph through the retriever, so a process keeps its mirrors in  */
+/* this cache, keyed by (relation = relfilenode, version = LSN of the header page or num_vectors).   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct lantern_mirror lantern_mirror_t;
+/* The resident mirror of (relation, version), or a fresh one: usearch_init(opts, pq_codebook) + usearch_view_mem_lazy(header).
+ * A newer version replaces the relation's mirror (the stale one is freed when its last holder releases it).  Returns NULL
+ * with *err == NULL when the header declares fewer than min_vectors nodes: the caller stays on the path it has. */
+LANTERN_GPU_EXPORT lantern_mirror_t *lantern_mirror_acquire(uint64_t relation, uint64_t version, usearch_init_options_t *opts,
+                                                            float *pq_codebook, char *header136, size_t min_vectors, usearch_error_t *);
+LANTERN_GPU_EXPORT usearch_index_t lantern_mirror_index(lantern_mirror_t *);
+LANTERN_GPU_EXPORT uint64_t        lantern_mirror_version(lantern_mirror_t *);
+/* the holder applied a change itself (usearch_add_external + usearch_update_header): re-stamp instead of rebuilding */
+LANTERN_GPU_EXPORT void lantern_mirror_advance(lantern_mirror_t *, uint64_t new_version);
+LANTERN_GPU_EXPORT void lantern_mirror_release(lantern_mirror_t *);
+/* DROP INDEX / REINDEX / VACUUM */
+LANTERN_GPU_EXPORT void lantern_mirror_invalidate(uint64_t relation);
+/* idle mirrors kept resident (default 8; least recently used goes first) */
+LANTERN_GPU_EXPORT void lantern_mirror_set_capacity(size_t max_resident);
+LANTERN_GPU_EXPORT void lantern_mirror_stats(uint64_t *hits, uint64_t *misses, uint64_t *rebuilds, uint64_t *resident);
 
 /* ------------------------------------------------------------------------------------------ */
 /* External indexing server (boundary B3): drop-in for `lantern-cli start-indexing-server`        */

@@ -101,6 +101,8 @@ EXPORTS = [
     "lantern_scan_server_start", "lantern_scan_server_start_fn", "lantern_scan_server_port", "lantern_scan_server_stats",
     "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_search_next",
     "lantern_scan_client_close", "lantern_scan_begin_client",
+    "lantern_mirror_acquire", "lantern_mirror_index", "lantern_mirror_version", "lantern_mirror_advance", "lantern_mirror_release",
+    "lantern_mirror_invalidate", "lantern_mirror_set_capacity", "lantern_mirror_stats",
 ]
 
 # int fn(void *ctx, const void *queries, size_t nq, size_t vec_bytes, size_t k, size_t ef, u64 *labels, f32 *dists, u32 *counts, const char **err)
@@ -215,6 +217,14 @@ def lib() -> C.CDLL:
         "lantern_scan_client_search_next": (sz, [vp, vp, sz, sz, sz, vp, vp, err]),
         "lantern_scan_client_close": (None, [vp]),
         "lantern_scan_begin_client": (vp, [vp, sz, i32, i32, err]),
+        "lantern_mirror_acquire": (vp, [u64, u64, C.POINTER(InitOptions), vp, vp, sz, err]),
+        "lantern_mirror_index": (vp, [vp]),
+        "lantern_mirror_version": (u64, [vp]),
+        "lantern_mirror_advance": (None, [vp, u64]),
+        "lantern_mirror_release": (None, [vp]),
+        "lantern_mirror_invalidate": (None, [u64]),
+        "lantern_mirror_set_capacity": (None, [sz]),
+        "lantern_mirror_stats": (None, [C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what the header declares
@@ -537,6 +547,62 @@ class GpuIndex:
     def load_buffer(self, data: bytes):
         buf = C.create_string_buffer(data, len(data))
         _call("usearch_load_buffer", self.h, C.cast(buf, C.c_void_p), len(data))
+
+
+class Mirror:
+    """lantern_mirror_*: the cached HBM mirror of a page-resident index.  `.index` is a GpuIndex view of it (not owned)."""
+
+    def __init__(self, relation, version, metric, dims, header, retriever, M=16, ef_construction=128, ef=64, min_vectors=0, retriever_mut=None):
+        self.metric = METRICS.get(metric, metric)
+        o = InitOptions()
+        o.metric_kind, o.metric, o.quantization = self.metric, None, _kind(self.metric)
+        o.dimensions = dims * 32 if self.metric == METRIC_HAMMING else dims
+        o.connectivity, o.expansion_add, o.expansion_search, o.num_threads = M, ef_construction, ef, 1
+        self._cb = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)(lambda ctx, slot: retriever(int(slot)))
+        o.retriever = C.cast(self._cb, C.c_void_p)
+        self._cb_mut = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)(lambda ctx, slot: (retriever_mut or retriever)(int(slot)))
+        o.retriever_mut = C.cast(self._cb_mut, C.c_void_p)
+        buf = C.create_string_buffer(bytes(header), USEARCH_HEADER_SIZE)
+        self.m = _call("lantern_mirror_acquire", relation, version, C.byref(o), None, C.cast(buf, C.c_void_p), min_vectors)
+        self.index = None
+        if self.m:
+            self.index = GpuIndex.__new__(GpuIndex)
+            self.index.metric, self.index.dims, self.index.M, self.index.efc, self.index.ef = self.metric, dims, M, ef_construction, ef
+            self.index.f16 = self.index.i8 = self.index.b1 = False
+            self.index.pq_S = 0
+            self.index.h = None  # not owned: GpuIndex.close() must not free it
+            self.index.__dict__["h"] = lib().lantern_mirror_index(self.m)
+            self.index.close = lambda: None
+
+    @property
+    def declined(self):
+        return not self.m
+
+    @property
+    def version(self):
+        return int(lib().lantern_mirror_version(self.m))
+
+    def advance(self, version):
+        lib().lantern_mirror_advance(self.m, version)
+
+    def release(self):
+        if self.m:
+            lib().lantern_mirror_release(self.m)
+            self.m = None
+
+    @staticmethod
+    def invalidate(relation):
+        lib().lantern_mirror_invalidate(relation)
+
+    @staticmethod
+    def set_capacity(n):
+        lib().lantern_mirror_set_capacity(n)
+
+    @staticmethod
+    def stats():
+        v = [C.c_uint64() for _ in range(4)]
+        lib().lantern_mirror_stats(*[C.byref(x) for x in v])
+        return dict(zip(("hits", "misses", "rebuilds", "resident"), (int(x.value) for x in v)))
 
 
 class Cursor:

@@ -671,6 +671,13 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
                        int waves)
 {
     if(nq == 0 || k == 0) return true;
+    if(waves <= 0) {
+        // automatic shape: four waves per query once the batch fills the chip (24 waves per CU resident); a smaller batch
+        // gets the idle wave slots -- up to eight waves per query -- so its walks finish sooner (BASELINE config[2]: 1024
+        // queries on 256 CUs = six waves each)
+        const size_t slots = (size_t)ix->num_cus * 24;
+        waves = (int)std::min<size_t>(8, std::max<size_t>(4, slots / nq));
+    }
     size_t expansion = ef ? ef : ix->ef;
     if(expansion < k + skip) expansion = k + skip;  // usearch: expansion = max(expansion, wanted)
     // LDS visited set: sized for ~3x the planner's estimate of visited nodes per query (hnsw.c:89-132 puts it at
@@ -1105,9 +1112,9 @@ void lantern_gpu_set_search_shape(usearch_index_t h, int waves, int max_wg, usea
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
-    if(waves < 1 || waves > 8) { FAIL(e, "lantern_gpu: waves_per_query must be in [1, 8]"); return; }
+    if(waves < 0 || waves > 8) { FAIL(e, "lantern_gpu: waves_per_query must be in [1, 8], or 0 = automatic"); return; }
     ix->search_waves = waves;
-    ix->insert_waves = waves;
+    ix->insert_waves = waves ? waves : 4;
     ix->search_max_wg = max_wg;
 }
 

@@ -34,7 +34,7 @@ struct Index
     uint32_t M = 16, M0 = 32, efc = 128, ef = 64;
     uint64_t seed = 42;
     size_t   add_batch_max = 8192, add_min_ratio = 16;
-    int      search_waves = 4, search_max_wg = 0, insert_waves = 4;
+    int      search_waves = 0 /* automatic */, search_max_wg = 0, insert_waves = 4;
     int      search_vis_slots = -1;  // -1 = automatic size of the LDS visited set, 0 = HBM bitmap only
 
     // ---- quantised views of f32 input ----------------------------------------------------------------------------

@@ -1,0 +1,183 @@
+// mirror_cache.cpp -- lifecycle of the HBM mirrors of page-resident indexes ("keep an HBM
+// mirror of the index keyed by (relfilenode, LSN)").
+//
+// The reference attaches to an index anew for every scan and every insert: usearch_init + usearch_view_mem_lazy per
+// ldb_ambeginscan (lantern_hnsw/src/hnsw/scan.c:99-110) and per ldb_aminsert (insert.c:142-151; "todo:: do usearch init in
+// indexInfo->ii_AmCache").  That is free there -- the view is lazy, nodes are fetched per hop through the retriever --
+// but a device mirror is a WALK of the whole graph through the retriever plus an upload, so it has to outlive the call
+// that made it.  This cache owns the mirrors of a process (a backend, or the scan-side service):
+//
+//   key       (relation, version): the index's relfilenode and whatever the caller uses as its change stamp -- the LSN
+//             of the header page, or HnswIndexHeaderPage.num_vectors (external_index.h:38-56) for an append-only index
+//   acquire   same relation + same version -> the resident mirror, reference counted (a HIT: no retriever call at all);
+//             same relation, another version -> a fresh mirror replaces it (the stale one is freed when its last user
+//             releases it); unknown relation -> a mirror is built (usearch_init + usearch_view_mem_lazy)
+//   advance   the holder of a mirror that applied a change itself (usearch_add_external + usearch_update_header in
+//             ldb_aminsert) re-stamps it instead of forcing a rebuild
+//   invalidate  DROP INDEX / REINDEX / VACUUM: the relation's mirror goes as soon as nobody holds it
+//   capacity  at most `max_resident` idle mirrors stay in HBM (least recently used goes first)
+//
+// Scans on a shared mirror keep their continuation state in their own cursor (lantern_scan_begin / lantern_gpu_cursor_*).
+// Policy, not fallback: below `min_vectors` acquire declines (returns NULL with no error) and the caller stays on the
+// path it has -- the reference's in-process usearch; this library itself never computes on the CPU.
+#include <cstring>
+#include <list>
+#include <mutex>
+#include <string>
+
+#include "../../include/lantern_gpu.h"
+
+struct lantern_mirror
+{
+    uint64_t        relation = 0, version = 0;
+    usearch_index_t index = nullptr;
+    int             refs = 0;
+    bool            stale = false;  // replaced or invalidated: free at the last release
+    uint64_t        last_use = 0;
+};
+
+namespace {
+struct Cache
+{
+    std::mutex                 mu;
+    std::list<lantern_mirror>  entries;
+    size_t                     max_resident = 8;
+    uint64_t                   clock = 0, hits = 0, misses = 0, rebuilds = 0;
+};
+Cache &cache()
+{
+    static Cache c;
+    return c;
+}
+
+void destroy(lantern_mirror &m)
+{
+    usearch_error_t ignore = nullptr;
+    if(m.index) usearch_free(m.index, &ignore);
+    m.index = nullptr;
+}
+
+// under c.mu: free stale idle entries, then idle entries beyond the capacity, least recently used first
+void trim(Cache &c)
+{
+    for(auto it = c.entries.begin(); it != c.entries.end();) {
+        if(it->stale && it->refs == 0) {
+            destroy(*it);
+            it = c.entries.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    for(;;) {
+        size_t idle = 0;
+        auto   victim = c.entries.end();
+        for(auto it = c.entries.begin(); it != c.entries.end(); ++it) {
+            if(it->refs != 0) continue;
+            ++idle;
+            if(victim == c.entries.end() || it->last_use < victim->last_use) victim = it;
+        }
+        if(idle <= c.max_resident || victim == c.entries.end()) break;
+        destroy(*victim);
+        c.entries.erase(victim);
+    }
+}
+}  // namespace
+
+extern "C" {
+
+lantern_mirror_t *lantern_mirror_acquire(uint64_t relation, uint64_t version, usearch_init_options_t *opts, float *pq_codebook, char *header136,
+                                         size_t min_vectors, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    if(!opts || !header136) { if(e) *e = "lantern_gpu: null init options or header"; return nullptr; }
+    Cache &c = cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    for(auto &m : c.entries) {
+        if(m.relation == relation && !m.stale && m.version == version) {
+            m.refs++;
+            m.last_use = ++c.clock;
+            c.hits++;
+            return &m;
+        }
+    }
+    // policy: a tiny index is not worth a mirror (the header carries the node count: external_index.h:59-66)
+    uint64_t declared = 0;
+    std::memcpy(&declared, header136 + 80, 8);
+    if(declared < min_vectors) return nullptr;
+    bool replaced = false;
+    for(auto &m : c.entries)
+        if(m.relation == relation && !m.stale) { m.stale = true; replaced = true; }
+    usearch_error_t err = nullptr;
+    usearch_index_t ix = usearch_init(opts, pq_codebook, &err);
+    if(!ix) { if(e) *e = err; return nullptr; }
+    usearch_view_mem_lazy(ix, header136, &err);
+    if(err) {
+        // the message belongs to the index: keep it alive in a static buffer before the index goes
+        static thread_local std::string kept;
+        kept = err;
+        usearch_error_t ignore = nullptr;
+        usearch_free(ix, &ignore);
+        if(e) *e = kept.c_str();
+        return nullptr;
+    }
+    (replaced ? c.rebuilds : c.misses)++;
+    c.entries.emplace_back();
+    lantern_mirror &m = c.entries.back();
+    m.relation = relation;
+    m.version = version;
+    m.index = ix;
+    m.refs = 1;
+    m.last_use = ++c.clock;
+    trim(c);
+    return &m;
+}
+
+usearch_index_t lantern_mirror_index(lantern_mirror_t *m) { return m ? m->index : nullptr; }
+uint64_t        lantern_mirror_version(lantern_mirror_t *m) { return m ? m->version : 0; }
+
+void lantern_mirror_advance(lantern_mirror_t *m, uint64_t new_version)
+{
+    if(!m) return;
+    Cache &c = cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    m->version = new_version;
+}
+
+void lantern_mirror_release(lantern_mirror_t *m)
+{
+    if(!m) return;
+    Cache &c = cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    if(m->refs > 0) m->refs--;
+    m->last_use = ++c.clock;
+    trim(c);
+}
+
+void lantern_mirror_invalidate(uint64_t relation)
+{
+    Cache &c = cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    for(auto &m : c.entries)
+        if(m.relation == relation) m.stale = true;
+    trim(c);
+}
+
+void lantern_mirror_set_capacity(size_t max_resident)
+{
+    Cache &c = cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    c.max_resident = max_resident;
+    trim(c);
+}
+
+void lantern_mirror_stats(uint64_t *hits, uint64_t *misses, uint64_t *rebuilds, uint64_t *resident)
+{
+    Cache &c = cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    if(hits) *hits = c.hits;
+    if(misses) *misses = c.misses;
+    if(rebuilds) *rebuilds = c.rebuilds;
+    if(resident) *resident = c.entries.size();
+}
+
+}  // extern "C"

@@ -66,7 +66,7 @@ def main():
         kern.append(s.elapsed_ms(e) * 1e3)
         Ds.append(int(d_D.download(1, np.uint64)[0]))
         Es.append(int(d_E.download(1, np.uint64)[0]))
-    ix.set_search_shape(4, 0)
+    ix.set_search_shape(0, 0)
     blab, _, _ = ix.search_batch(queries, a.k)
     same = float(np.mean([np.array_equal(r, b[:len(r)]) for r, b in zip(res, blab)]))
     out = {"config": f"{a.rows}x{a.dim} f32 {a.metric} M=16 efc=128 ef={a.ef} k={a.k}, one query per usearch_search_ef call",

@@ -37,7 +37,7 @@ def device_batch(hip, ix, queries, k, ef, ham=False, waves=4):
     ix.set_search_shape(waves)
     ix.search_batch_device(dq.ptr, nq, k, ef, 0, lab.ptr, dist.ptr, slot.ptr, cnt.ptr, Dv.ptr, Ev.ptr)
     hip.synchronize()
-    ix.set_search_shape(4)
+    ix.set_search_shape(0)
     return (lab.download((nq, k), np.uint64), dist.download((nq, k), np.float32), slot.download((nq, k), np.uint32),
             cnt.download(nq, np.uint32), Dv.download(nq, np.uint64), Ev.download(nq, np.uint64))
 

@@ -285,3 +285,77 @@ def test_corrupt_files_are_refused_not_trusted(capi):
     struct.pack_into("<I", bad, off + 10 + (4 + 2 * M * 6) + 4, flat)
     with pytest.raises(capi.LanternGpuError, match="does not reach that level"):
         load(bad)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mirror lifecycle: (relfilenode, LSN)-keyed cache of HBM mirrors
+# ------------------------------------------------------------------------------------------------------------------
+def test_mirror_cache_hits_rebuilds_invalidation_and_eviction(capi):
+    rng = np.random.default_rng(31)
+    n, d, M = 900, 16, 5
+    base = rng.standard_normal((n + 5, d), dtype=np.float32)
+    a = capi.GpuIndex("l2sq", d, M=M, ef_construction=32, ef=32, seed=8)
+    a.set_add_batch(1, 1)
+    a.add_many(np.arange(n, dtype=np.uint64) + 1, base[:n])
+    store = PageStore(capi, a.save_buffer(), d * 4, M)
+    kw = dict(metric="l2sq", dims=d, retriever=store.retriever, M=M, ef_construction=32, ef=32, retriever_mut=store.retriever_mut)
+    before = capi.Mirror.stats()
+    REL = 424242
+    # ldb_ambeginscan #1: a miss -> the graph is walked once through the retriever
+    m1 = capi.Mirror(REL, 1, header=store.header, **kw)
+    walked = len(store.retrieved)
+    assert walked == m1.index.graph_info().size > 0
+    # ldb_ambeginscan #2 .. #4 at the same version: hits, not a single retriever call, the SAME device index
+    m2 = capi.Mirror(REL, 1, header=store.header, **kw)
+    m3 = capi.Mirror(REL, 1, header=store.header, **kw)
+    assert len(store.retrieved) == walked and m2.index.h == m1.index.h == m3.index.h
+    q1, q2 = rng.standard_normal((2, d), dtype=np.float32)
+    s1, s2 = capi.Scan(m1.index, init_k=3), capi.Scan(m2.index, init_k=3)
+    s1.rescan(q1)
+    s2.rescan(q2)
+    rows1, rows2 = [], []
+    for _ in range(40):
+        rows1.append(s1.gettuple())
+        rows2.append(s2.gettuple())
+    direct1, direct2 = capi.Scan(a, init_k=3), capi.Scan(a, init_k=3)
+    direct1.rescan(q1)
+    direct2.rescan(q2)
+    assert rows1 == direct1.fetch(40) and rows2 == direct2.fetch(40)
+    s1.end(); s2.end()
+    m3.release()
+    # ldb_aminsert by the holder: the change is applied to the mirror and the pages, the stamp advances, no rebuild
+    addr, slot = store.new_tuple(5001, 0)
+    m1.index.add_external(5001, base[n], addr, 0, slot)
+    header2 = m1.index.update_header(store.header)
+    m1.advance(2)
+    m4 = capi.Mirror(REL, 2, header=header2, **kw)
+    assert len(store.retrieved) == walked and m4.index.h == m1.index.h and m4.version == 2
+    assert 5001 in m4.index.search(base[n], 3)[0].tolist()
+    # somebody else changed the index (version 3): a rebuild; holders of the stale mirror keep a working handle until they let go
+    m5 = capi.Mirror(REL, 3, header=header2, **kw)
+    assert len(store.retrieved) > walked and m5.index.h != m1.index.h
+    assert 5001 in m1.index.search(base[n], 3)[0].tolist()
+    for m in (m1, m2, m4):
+        m.release()
+    st = capi.Mirror.stats()
+    assert st["hits"] - before["hits"] == 3 and st["misses"] - before["misses"] == 1 and st["rebuilds"] - before["rebuilds"] == 1
+    # a tiny index is declined (policy: the caller stays on the path it has), without an error
+    assert capi.Mirror(REL + 1, 1, header=store.header, min_vectors=10_000, **kw).declined
+    # DROP INDEX: the mirror goes once nobody holds it; the next acquire walks the pages again
+    m5.release()
+    capi.Mirror.invalidate(REL)
+    calls = len(store.retrieved)
+    m6 = capi.Mirror(REL, 3, header=header2, **kw)
+    assert len(store.retrieved) > calls
+    m6.release()
+    # capacity: idle mirrors beyond it are evicted, least recently used first
+    capi.Mirror.set_capacity(1)
+    m7 = capi.Mirror(REL + 2, 1, header=header2, **kw)
+    m7.release()
+    assert capi.Mirror.stats()["resident"] == 1
+    calls = len(store.retrieved)
+    capi.Mirror(REL, 3, header=header2, **kw).release()  # was evicted: walked again
+    assert len(store.retrieved) > calls
+    capi.Mirror.set_capacity(8)
+    capi.Mirror.invalidate(REL)
+    capi.Mirror.invalidate(REL + 2)
