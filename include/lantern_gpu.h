@@ -290,6 +290,11 @@ typedef struct lantern_gpu_build_profile
 LANTERN_GPU_EXPORT void lantern_gpu_set_profiling(usearch_index_t, int on, usearch_error_t *);
 LANTERN_GPU_EXPORT lantern_gpu_build_profile lantern_gpu_build_profile_get(usearch_index_t, usearch_error_t *);
 
+/* Diagnostics of the walk kernel: while on, searches run an instrumented instantiation (f32 l2sq / cos rows of >= 128 or
+ * 32..63 chunks only) whose thread 0 sums shader-clock cycles per phase of every hop.  out6 (may be NULL) receives and
+ * clears the sums: pop | neighbour list + visited filter | distances | merge | upper-level descent | whole query. */
+LANTERN_GPU_EXPORT void lantern_gpu_search_phase_profile(usearch_index_t, int on, unsigned long long *out6, usearch_error_t *);
+
 /* order-independent-of-builder fingerprint of the graph (levels, labels, both adjacency arrays, entry point):
  * equal on two indexes iff they hold the same graph; used to check that replicas agree without moving them */
 LANTERN_GPU_EXPORT uint64_t lantern_gpu_graph_checksum(usearch_index_t, usearch_error_t *);

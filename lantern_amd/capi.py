@@ -89,7 +89,7 @@ EXPORTS = [
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_export_codes",
-    "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
+    "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_gpu_search_phase_profile", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
     "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist", "lantern_index_server_start",
     "lantern_index_server_port", "lantern_index_server_status_port", "lantern_index_server_status",
     "lantern_index_server_served", "lantern_index_server_stop",
@@ -178,6 +178,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_counters_get": (Counters, [vp, err]),
         "lantern_gpu_set_profiling": (None, [vp, i32, err]),
         "lantern_gpu_build_profile_get": (BuildProfile, [vp, err]),
+        "lantern_gpu_search_phase_profile": (None, [vp, i32, vp, err]),
         "lantern_scan_begin": (vp, [vp, i32, i32, err]),
         "lantern_scan_rescan": (None, [vp, vp, i32, err]),
         "lantern_scan_gettuple": (C.c_bool, [vp, C.POINTER(u64), err]),
@@ -476,6 +477,12 @@ class GpuIndex:
     def build_profile(self):
         p = _call("lantern_gpu_build_profile_get", self.h)
         return {n: (int(getattr(p, n)) if n == "batches" else float(getattr(p, n))) for n, _ in BuildProfile._fields_}
+
+    def phase_profile(self, on=True, read=False):
+        """Diagnostics: instrumented walk kernel; read=True returns and clears {phase: cycles}."""
+        out = np.zeros(6, dtype=np.uint64) if read else None
+        _call("lantern_gpu_search_phase_profile", self.h, 1 if on else 0, _ptr(out))
+        return dict(zip(("pop", "list_visited", "distances", "merge", "descent", "query"), (int(x) for x in out))) if read else None
 
     def metadata(self):
         return _call("usearch_index_metadata", self.h)

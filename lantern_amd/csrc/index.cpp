@@ -675,8 +675,10 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         // automatic shape: four waves per query once the batch fills the chip (24 waves per CU resident); a smaller batch
         // gets the idle wave slots -- up to eight waves per query -- so its walks finish sooner (BASELINE config[2]: 1024
         // queries on 256 CUs = six waves each)
-        const size_t slots = (size_t)ix->num_cus * 24;
-        waves = (int)std::min<size_t>(8, std::max<size_t>(4, slots / nq));
+        // Measured (1M x 768 cosine, 1024 queries): 4 waves 693 k QPS, 6 waves 525 k, 8 waves 594 k -- a hop's critical path
+        // is its serial phases (pop, list + visited filter by one wave, merge), which more waves only make costlier
+        // (wider barriers); the idle slots do not help.  So: four waves per query whatever the batch size.
+        waves = 4;
     }
     size_t expansion = ef ? ef : ix->ef;
     if(expansion < k + skip) expansion = k + skip;  // usearch: expansion = max(expansion, wanted)
@@ -714,6 +716,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.vis_slots = vis_slots;
     a.totals = ix->d_totals;
     a.ticket = next_ticket(ix, nq, grid, stream);
+    a.phase_cycles = ix->phase_profile ? ix->d_totals + 8 : nullptr;
     if(!order_launch(ix, stream)) return false;
     HIPCHK(ix, launch_search(ix->mcode, a, waves, grid, stream));
     if(!record_launch(ix, stream)) return false;
@@ -898,9 +901,9 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, ix->device) == hipSuccess) ix->num_cus = prop.multiProcessorCount;
     if(const char *tk = std::getenv("LANTERN_GPU_TICKETS")) ix->use_tickets = std::atoi(tk) != 0;
-    if(hipMalloc((void **)&ix->d_totals, 8 * sizeof(unsigned long long)) != hipSuccess ||
+    if(hipMalloc((void **)&ix->d_totals, 16 * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&ix->d_tickets, kTicketRing * sizeof(uint32_t)) != hipSuccess ||
-       hipMemset(ix->d_totals, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
+       hipMemset(ix->d_totals, 0, 16 * sizeof(unsigned long long)) != hipSuccess) {
         if(ix->d_totals) (void)hipFree(ix->d_totals);
         if(ix->d_tickets) (void)hipFree(ix->d_tickets);
         delete ix;
@@ -1493,6 +1496,22 @@ lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t h, usearch_error_t
     c.add_revlink_evals = t[ 5 ];
     c.add_reprunes = t[ 6 ];
     return c;
+}
+
+// Diagnostics: with `on`, searches run the instrumented instantiation of the walk kernel (f32 l2sq / cos at G = 64 or 16 only)
+// and accumulate shader-clock cycles per phase; out[6] = pop | list + visited | distances | merge | descent | whole query.
+void lantern_gpu_search_phase_profile(usearch_index_t h, int on, unsigned long long *out6, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(out6) {
+        (void)hipDeviceSynchronize();
+        if(hipMemcpy(out6, ix->d_totals + 8, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) FAIL(e, "lantern_gpu: HIP failure reading the phase profile");
+        (void)hipMemset(ix->d_totals + 8, 0, 8 * sizeof(unsigned long long));
+    }
+    ix->phase_profile = on != 0;
 }
 
 void lantern_gpu_set_profiling(usearch_index_t h, int on, usearch_error_t *e)

@@ -93,6 +93,7 @@ struct Index
     // ---- build profile (lantern_gpu_set_profiling): HIP events around the phases of every batch
     struct ProfBatch { hipEvent_t ev[ 6 ] = {}; };
     bool                    profiling = false;
+    bool                    phase_profile = false;  // diagnostics: instrumented walk kernel (lantern_gpu_search_phase_profile)
     std::deque<ProfBatch>   prof_pending;
     std::vector<hipEvent_t> prof_free;
     lantern_gpu_build_profile prof{};

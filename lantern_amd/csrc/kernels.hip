@@ -33,7 +33,7 @@ namespace lgpu {
 extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
 
 // ---------------------------------------------------------------------------------------------------
-template <int METRIC, int G>
+template <int METRIC, int G, bool PROF = false>
 __global__ void __launch_bounds__(512, 6) k_search(SearchArgs a)  // <= 80 VGPRs: six waves per SIMD, six 4-wave workgroups per CU
 {
     const int tid = threadIdx.x, T = blockDim.x;
@@ -53,9 +53,18 @@ __global__ void __launch_bounds__(512, 6) k_search(SearchArgs a)  // <= 80 VGPRs
         }
         uint32_t D = 0, E = 0;
         int      cnt = 0;
+        unsigned long long pc[ 6 ] = { 0, 0, 0, 0, 0, 0 }, t_q = 0;
+        if constexpr(PROF) t_q = (unsigned long long)clock64();
         if(a.view.n != 0) {
             uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
-            cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E);
+            if constexpr(PROF) pc[ 4 ] = (unsigned long long)clock64() - t_q;
+            cnt = search_level<METRIC, G, PROF>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
+        }
+        if constexpr(PROF) {
+            if(tid == 0 && a.phase_cycles) {
+                pc[ 5 ] = (unsigned long long)clock64() - t_q;
+                for(int i = 0; i < 6; ++i) atomicAdd(&a.phase_cycles[ i ], pc[ i ]);
+            }
         }
         int got = cnt - (int)a.skip;
         got = got < 0 ? 0 : (got > (int)a.k ? (int)a.k : got);
@@ -1363,6 +1372,20 @@ hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, h
     {                                                                                                         \
         (void)hipFuncSetAttribute((const void *)k_search<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_search<MM, GG>), dim3(grid), dim3(64 * waves), lds, stream, a);                 \
+    }
+    if(a.phase_cycles) {  // diagnostic instantiations: the f32 metrics at the two common row shapes
+        const int G_ = group_lanes_for(a.view.chunks);
+#define PCALL(MM, GG)                                                                                              \
+    {                                                                                                              \
+        (void)hipFuncSetAttribute((const void *)k_search<MM, GG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_search<MM, GG, true>), dim3(grid), dim3(64 * waves), lds, stream, a);                \
+    }
+        if(metric == M_L2SQ && G_ == 64) PCALL(M_L2SQ, 64)
+        else if(metric == M_L2SQ && G_ == 16) PCALL(M_L2SQ, 16)
+        else if(metric == M_COS && G_ == 64) PCALL(M_COS, 64)
+        else return hipErrorInvalidValue;
+#undef PCALL
+        return hipGetLastError();
     }
     LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL

@@ -25,7 +25,9 @@ struct SearchArgs
     uint32_t        vis_slots;   // LDS visited-set slots (a multiple of 4; 0 = HBM bitmap only)
     unsigned long long *totals;  // [2] cumulative D, E (atomicAdd) or NULL
     uint32_t       *ticket;      // zeroed before the launch: queries beyond the first gridDim.x are handed out dynamically
-};                               // (NULL = static striding); results do not depend on who runs a query
+                                 // (NULL = static striding); results do not depend on who runs a query
+    unsigned long long *phase_cycles;  // diagnostics (lantern_gpu_search_phase_profile): [8] shader-clock cycles summed over the
+};                               // launch's queries by phase: pop | list + visited | distances | merge | descent | whole query
 
 // one reverse-link request produced by the insert pass: add `new_slot` to `close`'s list at `level`
 struct LinkReq

@@ -156,12 +156,24 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
 
 // ---- search_to_find_in_base_ / search_to_insert_ -----------------------------------------------------
 // On return s.keys[0..cnt) holds the result ascending by (distance, slot); returns cnt.
-template <int METRIC, int G>
+// PROF (diagnostic instantiations only): thread 0 accumulates shader-clock cycles per phase of a hop into prof[0..4):
+// pop | neighbour list + visited filter | distances | merge.
+template <int METRIC, int G, bool PROF = false>
 __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int level, int ef,
-                            uint32_t &D, uint32_t &E)
+                            uint32_t &D, uint32_t &E, unsigned long long *prof = nullptr)
 {
     const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
     const int lane = tid & 63;
+    unsigned long long tl = 0;
+    if constexpr(PROF) tl = (unsigned long long)clock64();
+#define LGPU_MARK(i)                                                  \
+    if constexpr(PROF) {                                              \
+        if(tid == 0) {                                                \
+            const unsigned long long t_ = (unsigned long long)clock64(); \
+            prof[ i ] += t_ - tl;                                     \
+            tl = t_;                                                  \
+        }                                                             \
+    }
     // visits.clear()
     if(s.vis_slots) {
         for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
@@ -202,6 +214,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         if(pos == 0x7FFFFFFF) break;
         const uint32_t node = key_slot(s.keys[ pos ]);
         E += 1;
+        LGPU_MARK(0)
         if(!spilled && s.scal[ S_SPILL ]) {  // uniform: S_SPILL was written before the two barriers above
             uint4 *b4 = (uint4 *)bitmap;
             for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
@@ -226,6 +239,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         }
         __syncthreads();
         const int nnew = s.scal[ S_NNEW ];
+        LGPU_MARK(1)
         if(nnew == 0) continue;
         // ---- distances: one G-lane group per row, two rows in flight per group
         const uint64_t worst = cnt == ef ? s.keys[ cnt - 1 ] : ~0ull;
@@ -250,6 +264,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         }
         D += (uint32_t)nnew;
         __syncthreads();
+        LGPU_MARK(2)
         if(!s.scal[ S_ANY ]) continue;  // nothing beats the current radius: list unchanged
         // ---- merge: rank-sort the new keys, then rank-merge both lists into keys2
         for(int t = tid; t < nnew; t += T) {
@@ -272,7 +287,9 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         cnt = cnt + nnew < ef ? cnt + nnew : ef;
         uint64_t *tmp = s.keys; s.keys = s.keys2; s.keys2 = tmp;
         __syncthreads();
+        LGPU_MARK(3)
     }
+#undef LGPU_MARK
     return cnt;
 }
 
