@@ -22,7 +22,7 @@
 namespace lgpu {
 
 // scalar slots in LDS
-enum { S_POS = 0, S_NNEW, S_CNT, S_ANY, S_BAD, S_CUR, S_CURD, S_CHANGED, S_VISCNT, S_SPILL, S_QN2, S_SCALARS = 16 };
+enum { S_POS = 0, S_NNEW, S_CNT, S_ANY, S_BAD, S_CUR, S_CURD, S_CHANGED, S_VISCNT, S_SPILL, S_QN2, S_NNEW0, S_NNEW1, S_ANY0, S_ANY1, S_SCALARS = 16 };
 // S_QN2: ||query||^2 as float bits (cosine metrics; set by the kernel before a walk: device_common.hpp "cached row norms")
 
 struct WalkLds
@@ -78,7 +78,7 @@ __device__ __forceinline__ bool visit_test_and_set(WalkLds &s, uint32_t *bitmap,
             const uint32_t cur = spilled ? s.vis[ h ] : atomicCAS(&s.vis[ h ], EMPTY, x);
             if(cur == x) return true;
             if(cur == EMPTY) {
-                if(!spilled) { atomicAdd(&s.scal[ S_VISCNT ], 1); return false; }
+                if(!spilled) return false;  // recorded by the CAS; the caller counts the slots it added (one ballot per pass)
                 break;  // not in the LDS set: the bitmap decides
             }
             h = h + 1 == s.vis_slots ? 0u : h + 1;
@@ -117,13 +117,17 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
             uint32_t        cur = (uint32_t)s.scal[ S_CUR ];
             uint32_t        cap;
             const uint32_t *list = neighbors_of(v, cur, level, cap);
-            if(tid == 0) s.scal[ S_NNEW ] = 0;
-            __syncthreads();
-            // gather the (EMPTY-terminated) list
-            for(uint32_t i = tid; i < cap; i += T) {
-                uint32_t nb = list[ i ];
-                s.newids[ i ] = nb;
-                if(nb != EMPTY) atomicMax(&s.scal[ S_NNEW ], (int)i + 1);
+            // gather the (EMPTY-terminated, hole-free) list: wave 0, one ballot per 64 slots (an LDS atomicMax here is
+            // serialised by the compiler into a scalar loop over the lanes)
+            if(tid < 64) {
+                int count = 0;
+                for(uint32_t off = 0; off < cap; off += 64) {
+                    const uint32_t i = off + (uint32_t)(tid & 63);
+                    const uint32_t nb = i < cap ? list[ i ] : EMPTY;
+                    if(i < cap) s.newids[ i ] = nb;
+                    count += (int)__popcll(__ballot(nb != EMPTY));
+                }
+                if(tid == 0) s.scal[ S_NNEW ] = count;
             }
             __syncthreads();
             const int nn = s.scal[ S_NNEW ];
@@ -156,8 +160,22 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
 
 // ---- search_to_find_in_base_ / search_to_insert_ -----------------------------------------------------
 // On return s.keys[0..cnt) holds the result ascending by (distance, slot); returns cnt.
-// PROF (diagnostic instantiations only): thread 0 accumulates shader-clock cycles per phase of a hop into prof[0..4):
-// pop | neighbour list + visited filter | distances | merge.
+//
+// One hop = three phases, three barriers:
+//   (1) wave 0 alone, no barrier inside: pop (first unexpanded entry: one ballot per 64 entries), the popped node's
+//       neighbour list (ONE 128-byte request), the visited test-and-set (LDS hash set, spilling to the HBM bitmap), the
+//       ballot compaction of the new ids into LDS.  The other waves wait at the barrier.
+//   (2) all waves: one G-lane group per row, two rows in flight per group -> keys.
+//   (3) all waves: rank-merge into the ef-bounded list -- a thread per key, every position computed from the UNSORTED new
+//       keys (old key i goes to i + #{new < it}, new key t to #{new < it} + lower_bound(old, it)), so there is no
+//       intermediate sort and no barrier inside the phase.
+// Round 1 took six barriers per hop, found the pop position with an LDS atomicMin (which the compiler serialises into a
+// scalar loop over the active lanes: ~1.4 us per hop on its own) and sorted the new keys before merging; measured with
+// the instrumented kernel (scripts/profile_hop_phases.py) the three serial phases cost 3 000 - 4 000 cycles EACH, more
+// than the row evaluation of a 128-d hop.  The scalars wave 0 publishes are double-buffered by hop parity, so a wave that
+// is slow to read them is never overtaken by the next hop's values.
+// PROF (diagnostic instantiations only): thread 0 accumulates shader-clock cycles per phase into prof[0..4): pop + list +
+// visited (wave 0's section) | wait at the first barrier (other waves' view is not recorded) | distances | merge.
 template <int METRIC, int G, bool PROF = false>
 __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int level, int ef,
                             uint32_t &D, uint32_t &E, unsigned long long *prof = nullptr)
@@ -177,9 +195,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
     // visits.clear()
     if(s.vis_slots) {
         for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
-        if(tid == 0) { s.scal[ S_VISCNT ] = 0; s.scal[ S_SPILL ] = 0; }
     } else {
-        if(tid == 0) s.scal[ S_SPILL ] = 0;
         uint4 *b4 = (uint4 *)bitmap;
         for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
     }
@@ -190,58 +206,63 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
     }
     D += 1;
     __syncthreads();
-    if(tid == 0) (void)visit_test_and_set(s, bitmap, start, false);
-    int  cnt = 1;
-    bool spilled = false;
-    for(;;) {
-        // ---- pop: first unexpanded entry of the list
-        // The spill decision is taken by ONE thread and published with the pop scalars: S_VISCNT is only ever changed
-        // by wave 0 (visit_test_and_set), between the barrier after the pop and the barrier that ends the neighbour
-        // pass, so thread 0 reads its final value here and every wave branches on the same flag two barriers later
-        // (each wave reading S_VISCNT for itself could see wave 0's increments of THIS hop and take a different branch).
-        if(tid == 0) {
-            s.scal[ S_POS ] = 0x7FFFFFFF;
-            s.scal[ S_ANY ] = 0;
-            // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (rare:
-            // the set holds 3/4 * vis_slots slots, a search visits D of them)
-            if(s.vis_slots && (uint32_t)s.scal[ S_VISCNT ] + v.M0 > s.vis_slots / 4 * 3) s.scal[ S_SPILL ] = 1;
-        }
-        __syncthreads();
-        for(int i = tid; i < cnt; i += T)
-            if(!key_expanded(s.keys[ i ])) { atomicMin(&s.scal[ S_POS ], i); break; }
-        __syncthreads();
-        const int pos = s.scal[ S_POS ];
-        if(pos == 0x7FFFFFFF) break;
-        const uint32_t node = key_slot(s.keys[ pos ]);
-        E += 1;
-        LGPU_MARK(0)
-        if(!spilled && s.scal[ S_SPILL ]) {  // uniform: S_SPILL was written before the two barriers above
-            uint4 *b4 = (uint4 *)bitmap;
-            for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
-            spilled = true;
-            __syncthreads();
-        }
-        // ---- neighbour list + visited test-and-set, compacted in list order (wave 0)
+    // wave 0's private walk state: how many slots the LDS set holds, and whether it has spilled to the bitmap
+    uint32_t viscnt = 0;
+    bool     spilled = false;
+    if(tid == 0) {
+        (void)visit_test_and_set(s, bitmap, start, false);
+        viscnt = s.vis_slots ? 1u : 0u;
+    }
+    viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);  // uniform in wave 0 (tid 0 is its first lane); unused elsewhere
+    int cnt = 1;
+    for(int hop = 0;; ++hop) {
+        int *const nnew_slot = &s.scal[ (hop & 1) ? S_NNEW1 : S_NNEW0 ];
+        int *const any_slot = &s.scal[ (hop & 1) ? S_ANY1 : S_ANY0 ];
+        // ---- (1) wave 0: pop + neighbour list + visited filter
         if(tid < 64) {
-            uint32_t        cap;
-            const uint32_t *list = neighbors_of(v, node, level, cap);
-            int             base = 0;
-            for(uint32_t off = 0; off < cap; off += 64) {
-                uint32_t i = off + (uint32_t)lane;
-                uint32_t nb = i < cap ? list[ i ] : EMPTY;
-                bool     isnew = false;
-                if(nb != EMPTY) isnew = !visit_test_and_set(s, bitmap, nb, spilled);
-                unsigned long long m = __ballot(isnew);
-                if(isnew) s.newids[ base + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
-                base += __popcll(m);
+            int pos = -1;
+            for(int base = 0; base < cnt; base += 64) {  // first unexpanded entry = pop of usearch's `next` heap
+                const int                i = base + lane;
+                const bool               un = i < cnt && !key_expanded(s.keys[ i ]);
+                const unsigned long long m = __ballot(un);
+                if(m) { pos = base + (int)__builtin_ctzll(m); break; }
             }
-            if(lane == 0) { s.scal[ S_NNEW ] = base; s.keys[ pos ] |= 1ull; }
+            if(pos < 0) {
+                if(lane == 0) *nnew_slot = -1;  // the walk is over
+            } else {
+                const uint32_t node = key_slot(s.keys[ pos ]);
+                E += 1;
+                // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (rare: the set
+                // holds 3/4 * vis_slots slots, a search visits D of them).  Wave 0 clears the bitmap on its own.
+                if(s.vis_slots && !spilled && viscnt + v.M0 > s.vis_slots / 4 * 3) {
+                    uint4 *b4 = (uint4 *)bitmap;
+                    for(uint32_t i = (uint32_t)lane; i < bm_words / 4; i += 64) b4[ i ] = make_uint4(0, 0, 0, 0);
+                    spilled = true;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the clears are ordered before this wave's atomicOr's
+                }
+                uint32_t        cap;
+                const uint32_t *list = neighbors_of(v, node, level, cap);
+                int             nb_new = 0;
+                for(uint32_t off = 0; off < cap; off += 64) {
+                    const uint32_t i = off + (uint32_t)lane;
+                    const uint32_t nb = i < cap ? list[ i ] : EMPTY;
+                    bool           isnew = false;
+                    if(nb != EMPTY) isnew = !visit_test_and_set(s, bitmap, nb, spilled);
+                    const unsigned long long m = __ballot(isnew);
+                    if(isnew) s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
+                    nb_new += __popcll(m);
+                }
+                if(s.vis_slots && !spilled) viscnt += (uint32_t)nb_new;
+                if(lane == 0) { *nnew_slot = nb_new; *any_slot = 0; s.keys[ pos ] |= 1ull; }
+            }
         }
+        LGPU_MARK(0)
         __syncthreads();
-        const int nnew = s.scal[ S_NNEW ];
+        const int nnew = *nnew_slot;
         LGPU_MARK(1)
+        if(nnew < 0) break;
         if(nnew == 0) continue;
-        // ---- distances: one G-lane group per row, two rows in flight per group
+        // ---- (2) distances: one G-lane group per row, two rows in flight per group
         const uint64_t worst = cnt == ef ? s.keys[ cnt - 1 ] : ~0ull;
         for(int i = g; i < nnew; i += 2 * NG) {
             const int      j = i + NG;
@@ -259,29 +280,25 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                     s.newkeys[ j ] = k1;
                     any |= k1 < worst;
                 }
-                if(any) s.scal[ S_ANY ] = 1;
+                if(any) *any_slot = 1;
             }
         }
         D += (uint32_t)nnew;
         __syncthreads();
         LGPU_MARK(2)
-        if(!s.scal[ S_ANY ]) continue;  // nothing beats the current radius: list unchanged
-        // ---- merge: rank-sort the new keys, then rank-merge both lists into keys2
-        for(int t = tid; t < nnew; t += T) {
-            const uint64_t k = s.newkeys[ t ];
-            int            r = 0;
-            for(int j = 0; j < nnew; ++j) r += s.newkeys[ j ] < k;
-            s.sorted[ r ] = k;
-        }
-        __syncthreads();
-        for(int i = tid; i < cnt; i += T) {
-            const uint64_t k = s.keys[ i ];
-            const int      p = i + lower_bound_keys(s.sorted, nnew, k);
-            if(p < ef) s.keys2[ p ] = k;
-        }
-        for(int j = tid; j < nnew; j += T) {
-            const uint64_t k = s.sorted[ j ];
-            const int      p = j + lower_bound_keys(s.keys, cnt, k);
+        if(!*any_slot) continue;  // nothing beats the current radius: list unchanged
+        // ---- (3) merge: every key's position in the merged list straight from the unsorted new keys
+        for(int t = tid; t < cnt + nnew; t += T) {
+            const bool     is_new = t >= cnt;
+            const uint64_t k = is_new ? s.newkeys[ t - cnt ] : s.keys[ t ];
+            int            below = 0;  // new keys smaller than k (keys are distinct: a slot occurs once)
+            int            j = 0;
+            for(; j + 4 <= nnew; j += 4) {  // four broadcast reads in flight per round
+                const uint64_t a0 = s.newkeys[ j ], a1 = s.newkeys[ j + 1 ], a2 = s.newkeys[ j + 2 ], a3 = s.newkeys[ j + 3 ];
+                below += (a0 < k) + (a1 < k) + (a2 < k) + (a3 < k);
+            }
+            for(; j < nnew; ++j) below += s.newkeys[ j ] < k;
+            const int p = is_new ? below + lower_bound_keys(s.keys, cnt, k) : t + below;
             if(p < ef) s.keys2[ p ] = k;
         }
         cnt = cnt + nnew < ef ? cnt + nnew : ef;
