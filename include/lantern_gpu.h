@@ -291,9 +291,10 @@ LANTERN_GPU_EXPORT void lantern_gpu_set_profiling(usearch_index_t, int on, usear
 LANTERN_GPU_EXPORT lantern_gpu_build_profile lantern_gpu_build_profile_get(usearch_index_t, usearch_error_t *);
 
 /* Diagnostics of the walk kernel: while on, searches run an instrumented instantiation (f32 l2sq / cos rows of >= 128 or
- * 32..63 chunks only) whose thread 0 sums shader-clock cycles per phase of every hop.  out6 (may be NULL) receives and
- * clears the sums: pop | neighbour list + visited filter | distances | merge | upper-level descent | whole query. */
-LANTERN_GPU_EXPORT void lantern_gpu_search_phase_profile(usearch_index_t, int on, unsigned long long *out6, usearch_error_t *);
+ * 32..63 chunks only) whose thread 0 sums shader-clock cycles per phase of every hop.  out8 (may be NULL) receives and
+ * clears the sums: visited filter + compaction | wait at the hop's first barrier | distances | merge | pop | arrival of the
+ * neighbour list | upper-level descent | whole query. */
+LANTERN_GPU_EXPORT void lantern_gpu_search_phase_profile(usearch_index_t, int on, unsigned long long *out8, usearch_error_t *);
 
 /* order-independent-of-builder fingerprint of the graph (levels, labels, both adjacency arrays, entry point):
  * equal on two indexes iff they hold the same graph; used to check that replicas agree without moving them */

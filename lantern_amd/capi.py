@@ -480,9 +480,9 @@ class GpuIndex:
 
     def phase_profile(self, on=True, read=False):
         """Diagnostics: instrumented walk kernel; read=True returns and clears {phase: cycles}."""
-        out = np.zeros(6, dtype=np.uint64) if read else None
+        out = np.zeros(8, dtype=np.uint64) if read else None
         _call("lantern_gpu_search_phase_profile", self.h, 1 if on else 0, _ptr(out))
-        return dict(zip(("pop", "list_visited", "distances", "merge", "descent", "query"), (int(x) for x in out))) if read else None
+        return dict(zip(("visited_compact", "first_barrier", "distances", "merge", "pop", "list_arrival", "descent", "query"), (int(x) for x in out))) if read else None
 
     def metadata(self):
         return _call("usearch_index_metadata", self.h)

@@ -1499,8 +1499,9 @@ lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t h, usearch_error_t
 }
 
 // Diagnostics: with `on`, searches run the instrumented instantiation of the walk kernel (f32 l2sq / cos at G = 64 or 16 only)
-// and accumulate shader-clock cycles per phase; out[6] = pop | list + visited | distances | merge | descent | whole query.
-void lantern_gpu_search_phase_profile(usearch_index_t h, int on, unsigned long long *out6, usearch_error_t *e)
+// and accumulate shader-clock cycles per phase; out[8] = visited filter + compaction | wait at the first barrier | distances |
+// merge | pop | neighbour-list arrival | upper-level descent | whole query.
+void lantern_gpu_search_phase_profile(usearch_index_t h, int on, unsigned long long *out6 /* [8] */, usearch_error_t *e)
 {
     CLEAR(e);
     Index *ix = H(h, e);
@@ -1508,7 +1509,7 @@ void lantern_gpu_search_phase_profile(usearch_index_t h, int on, unsigned long l
     std::lock_guard<std::mutex> g(ix->mu);
     if(out6) {
         (void)hipDeviceSynchronize();
-        if(hipMemcpy(out6, ix->d_totals + 8, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) FAIL(e, "lantern_gpu: HIP failure reading the phase profile");
+        if(hipMemcpy(out6, ix->d_totals + 8, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) FAIL(e, "lantern_gpu: HIP failure reading the phase profile");
         (void)hipMemset(ix->d_totals + 8, 0, 8 * sizeof(unsigned long long));
     }
     ix->phase_profile = on != 0;

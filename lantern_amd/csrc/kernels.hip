@@ -53,17 +53,17 @@ __global__ void __launch_bounds__(512, 6) k_search(SearchArgs a)  // <= 80 VGPRs
         }
         uint32_t D = 0, E = 0;
         int      cnt = 0;
-        unsigned long long pc[ 6 ] = { 0, 0, 0, 0, 0, 0 }, t_q = 0;
+        unsigned long long pc[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_q = 0;
         if constexpr(PROF) t_q = (unsigned long long)clock64();
         if(a.view.n != 0) {
             uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
-            if constexpr(PROF) pc[ 4 ] = (unsigned long long)clock64() - t_q;
+            if constexpr(PROF) pc[ 6 ] = (unsigned long long)clock64() - t_q;
             cnt = search_level<METRIC, G, PROF>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
         }
         if constexpr(PROF) {
             if(tid == 0 && a.phase_cycles) {
-                pc[ 5 ] = (unsigned long long)clock64() - t_q;
-                for(int i = 0; i < 6; ++i) atomicAdd(&a.phase_cycles[ i ], pc[ i ]);
+                pc[ 7 ] = (unsigned long long)clock64() - t_q;
+                for(int i = 0; i < 8; ++i) atomicAdd(&a.phase_cycles[ i ], pc[ i ]);
             }
         }
         int got = cnt - (int)a.skip;

@@ -98,6 +98,48 @@ __device__ __forceinline__ int lower_bound_keys(const uint64_t *a, int n, uint64
     return lo;
 }
 
+// ---- merge helpers: four adjacent lanes (a quad) share the LDS reads of one key's position --------------------------
+// sum over the quad (every lane of the quad gets it): two DPP adds
+__device__ __forceinline__ int quad_sum(int x)
+{
+    uint32_t v = (uint32_t)x;
+    v = v + dpp_take<0xB1, 0xF>(v);
+    v = v + dpp_take<0x4E, 0xF>(v);
+    return (int)v;
+}
+// #{j < n : a[j] < k} with the reads split over the quad (sub = lane & 3): 16-byte reads of two keys, all of a lane's reads
+// independent of one another (one LDS round trip per eight keys of the lane's share)
+__device__ __forceinline__ int quad_count_below(const uint64_t *a, int n, uint64_t k, int sub)
+{
+    const uint4 *a4 = (const uint4 *)a;  // a is 16-byte aligned (carve_walk)
+    const int    pairs = n >> 1;
+    int          c = 0;
+    for(int p = sub; p < pairs; p += 4) {
+        const uint4    w = a4[ p ];
+        const uint64_t k0 = ((uint64_t)w.y << 32) | w.x, k1 = ((uint64_t)w.w << 32) | w.z;
+        c += (k0 < k) + (k1 < k);
+    }
+    if((n & 1) && sub == 0) c += a[ n - 1 ] < k;
+    return quad_sum(c);
+}
+// lower_bound over the sorted a[0..n) as two rounds of independent reads instead of log2(n) dependent ones: first the last
+// key of every block of eight (how many whole blocks lie below k), then the eight keys of the block k falls into
+__device__ __forceinline__ int quad_lower_bound(const uint64_t *a, int n, uint64_t k, int sub)
+{
+    const int nb = (n + 7) >> 3;
+    int       c = 0;
+    for(int b = sub; b < nb; b += 4) {
+        const int last = 8 * b + 7 < n ? 8 * b + 7 : n - 1;
+        c += a[ last ] < k;
+    }
+    const int blk = quad_sum(c);
+    if(blk >= nb) return n;
+    const int lo = 8 * blk, len = n - lo < 8 ? n - lo : 8;
+    int       d = 0;
+    for(int j = sub; j < len; j += 4) d += a[ lo + j ] < k;
+    return lo + quad_sum(d);
+}
+
 // ---- search_for_one_: greedy descent over levels (begin, end] ---------------------------------------
 // Returns the closest slot (same value in every thread).  D counts distance evaluations.
 template <int METRIC, int G>
@@ -174,8 +216,9 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
 // the instrumented kernel (scripts/profile_hop_phases.py) the three serial phases cost 3 000 - 4 000 cycles EACH, more
 // than the row evaluation of a 128-d hop.  The scalars wave 0 publishes are double-buffered by hop parity, so a wave that
 // is slow to read them is never overtaken by the next hop's values.
-// PROF (diagnostic instantiations only): thread 0 accumulates shader-clock cycles per phase into prof[0..4): pop + list +
-// visited (wave 0's section) | wait at the first barrier (other waves' view is not recorded) | distances | merge.
+// PROF (diagnostic instantiations only): thread 0 accumulates shader-clock cycles per phase into prof[0..6): [4] pop, [5] the
+// neighbour list's arrival, [0] visited filter + compaction (together: wave 0's section) | [1] wait at the first barrier |
+// [2] distances | [3] merge.
 template <int METRIC, int G, bool PROF = false>
 __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int level, int ef,
                             uint32_t &D, uint32_t &E, unsigned long long *prof = nullptr)
@@ -214,24 +257,35 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         viscnt = s.vis_slots ? 1u : 0u;
     }
     viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);  // uniform in wave 0 (tid 0 is its first lane); unused elsewhere
-    int cnt = 1;
+    // wave 0 fetches the runner-up's neighbour list one hop ahead (the list of a node never changes during a walk)
+    uint32_t spec_node = EMPTY, spec_val = EMPTY;
+    int      cnt = 1;
     for(int hop = 0;; ++hop) {
         int *const nnew_slot = &s.scal[ (hop & 1) ? S_NNEW1 : S_NNEW0 ];
         int *const any_slot = &s.scal[ (hop & 1) ? S_ANY1 : S_ANY0 ];
         // ---- (1) wave 0: pop + neighbour list + visited filter
         if(tid < 64) {
-            int pos = -1;
+            int      pos = -1;
+            uint32_t node = EMPTY, runner = EMPTY;
             for(int base = 0; base < cnt; base += 64) {  // first unexpanded entry = pop of usearch's `next` heap
                 const int                i = base + lane;
-                const bool               un = i < cnt && !key_expanded(s.keys[ i ]);
-                const unsigned long long m = __ballot(un);
-                if(m) { pos = base + (int)__builtin_ctzll(m); break; }
+                const uint64_t           key = i < cnt ? s.keys[ i ] : 1ull;
+                const unsigned long long m = __ballot(!key_expanded(key));
+                if(m) {
+                    const int first = (int)__builtin_ctzll(m);
+                    pos = base + first;
+                    const uint32_t lo = (uint32_t)key;  // slot : flag, the low word of the key
+                    node = (uint32_t)__builtin_amdgcn_readlane((int)lo, first) >> 1;
+                    const unsigned long long rest = m & (m - 1ull);  // the runner-up: next hop's pop unless a new key beats it
+                    if(rest) runner = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)__builtin_ctzll(rest)) >> 1;
+                    break;
+                }
             }
             if(pos < 0) {
                 if(lane == 0) *nnew_slot = -1;  // the walk is over
             } else {
-                const uint32_t node = key_slot(s.keys[ pos ]);
                 E += 1;
+                LGPU_MARK(4)
                 // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (rare: the set
                 // holds 3/4 * vis_slots slots, a search visits D of them).  Wave 0 clears the bitmap on its own.
                 if(s.vis_slots && !spilled && viscnt + v.M0 > s.vis_slots / 4 * 3) {
@@ -242,10 +296,25 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                 }
                 uint32_t        cap;
                 const uint32_t *list = neighbors_of(v, node, level, cap);
-                int             nb_new = 0;
+                // the first 64 slots of the list: what the previous hop fetched ahead, if its guess (the runner-up) was
+                // popped; otherwise a fresh request.  Then this hop's own guess goes out, to land during the row phase.
+                uint32_t first64 = spec_val;
+                if(node != spec_node) first64 = (uint32_t)lane < cap ? list[ lane ] : EMPTY;
+                spec_node = EMPTY;
+                if(runner != EMPTY) {
+                    uint32_t        rcap;
+                    const uint32_t *rlist = neighbors_of(v, runner, level, rcap);
+                    spec_val = (uint32_t)lane < rcap ? rlist[ lane ] : EMPTY;
+                    spec_node = runner;
+                }
+                int nb_new = 0;
                 for(uint32_t off = 0; off < cap; off += 64) {
                     const uint32_t i = off + (uint32_t)lane;
-                    const uint32_t nb = i < cap ? list[ i ] : EMPTY;
+                    const uint32_t nb = off == 0 ? first64 : (i < cap ? list[ i ] : EMPTY);
+                    if constexpr(PROF) {  // make the list's arrival visible to the phase clock
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        LGPU_MARK(5)
+                    }
                     bool           isnew = false;
                     if(nb != EMPTY) isnew = !visit_test_and_set(s, bitmap, nb, spilled);
                     const unsigned long long m = __ballot(isnew);
@@ -287,19 +356,18 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         __syncthreads();
         LGPU_MARK(2)
         if(!*any_slot) continue;  // nothing beats the current radius: list unchanged
-        // ---- (3) merge: every key's position in the merged list straight from the unsorted new keys
-        for(int t = tid; t < cnt + nnew; t += T) {
-            const bool     is_new = t >= cnt;
-            const uint64_t k = is_new ? s.newkeys[ t - cnt ] : s.keys[ t ];
-            int            below = 0;  // new keys smaller than k (keys are distinct: a slot occurs once)
-            int            j = 0;
-            for(; j + 4 <= nnew; j += 4) {  // four broadcast reads in flight per round
-                const uint64_t a0 = s.newkeys[ j ], a1 = s.newkeys[ j + 1 ], a2 = s.newkeys[ j + 2 ], a3 = s.newkeys[ j + 3 ];
-                below += (a0 < k) + (a1 < k) + (a2 < k) + (a3 < k);
+        // ---- (3) merge: every key's position in the merged list straight from the unsorted new keys.  A quad of lanes per
+        // key: the quad splits the LDS reads (all independent: no binary-search chain), sums with two DPP adds.
+        {
+            const int sub = tid & 3, total = cnt + nnew;
+            for(int t = tid >> 2; t < ((total + 63) & ~63); t += T >> 2) {  // whole waves iterate together (DPP needs the quad's lanes)
+                const bool     live = t < total, is_new = t >= cnt;
+                const uint64_t k = !live ? 0ull : is_new ? s.newkeys[ t - cnt ] : s.keys[ t ];
+                const int      below = quad_count_below(s.newkeys, nnew, k, sub);  // new keys smaller than k (keys are distinct)
+                int            p = t + below;
+                if(is_new) p = below + quad_lower_bound(s.keys, cnt, k, sub);
+                if(live && sub == 0 && p < ef) s.keys2[ p ] = k;
             }
-            for(; j < nnew; ++j) below += s.newkeys[ j ] < k;
-            const int p = is_new ? below + lower_bound_keys(s.keys, cnt, k) : t + below;
-            if(p < ef) s.keys2[ p ] = k;
         }
         cnt = cnt + nnew < ef ? cnt + nnew : ef;
         uint64_t *tmp = s.keys; s.keys = s.keys2; s.keys2 = tmp;

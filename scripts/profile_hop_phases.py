@@ -39,8 +39,7 @@ def measure(ix, queries, nq_per_launch, waves, launches, k=10, ef=64):
     ph = ix.phase_profile(False, read=True)
     nqs = launches * nq_per_launch
     out = {"queries": nqs, "waves": waves, "hops_per_query": hops / nqs, "evals_per_query": evals / nqs,
-           "cycles_per_hop": {"wave0_pop_list_visited": ph["pop"] / hops, "first_barrier": ph["list_visited"] / hops,
-                              "distances": ph["distances"] / hops, "merge": ph["merge"] / hops},
+           "cycles_per_hop": {k2: ph[k2] / hops for k2 in ("pop", "list_arrival", "visited_compact", "first_barrier", "distances", "merge")},
            "descent_cycles_per_query": ph["descent"] / nqs, "cycles_per_query": ph["query"] / nqs,
            "wall_us_per_launch": e0.elapsed_ms(e1) * 1e3 / launches}
     out["implied_clock_GHz_if_query_is_launch"] = out["cycles_per_query"] / out["wall_us_per_launch"] / 1e3 if nq_per_launch == 1 else None
