@@ -17,6 +17,8 @@
 //
 // All functions must be called by every thread of the workgroup (they contain barriers).
 #pragma once
+#include <type_traits>
+
 #include "device_common.hpp"
 
 namespace lgpu {
@@ -100,44 +102,44 @@ __device__ __forceinline__ int lower_bound_keys(const uint64_t *a, int n, uint64
 
 // ---- merge helpers: four adjacent lanes (a quad) share the LDS reads of one key's position --------------------------
 // sum over the quad (every lane of the quad gets it): two DPP adds
-__device__ __forceinline__ int quad_sum(int x)
+template <int L> __device__ __forceinline__ int quad_sum(int x)  // L = 2 or 4 cooperating lanes
 {
     uint32_t v = (uint32_t)x;
     v = v + dpp_take<0xB1, 0xF>(v);
-    v = v + dpp_take<0x4E, 0xF>(v);
+    if(L == 4) v = v + dpp_take<0x4E, 0xF>(v);
     return (int)v;
 }
 // #{j < n : a[j] < k} with the reads split over the quad (sub = lane & 3): 16-byte reads of two keys, all of a lane's reads
 // independent of one another (one LDS round trip per eight keys of the lane's share)
-__device__ __forceinline__ int quad_count_below(const uint64_t *a, int n, uint64_t k, int sub)
+template <int L> __device__ __forceinline__ int quad_count_below(const uint64_t *a, int n, uint64_t k, int sub)
 {
     const uint4 *a4 = (const uint4 *)a;  // a is 16-byte aligned (carve_walk)
     const int    pairs = n >> 1;
     int          c = 0;
-    for(int p = sub; p < pairs; p += 4) {
+    for(int p = sub; p < pairs; p += L) {
         const uint4    w = a4[ p ];
         const uint64_t k0 = ((uint64_t)w.y << 32) | w.x, k1 = ((uint64_t)w.w << 32) | w.z;
         c += (k0 < k) + (k1 < k);
     }
     if((n & 1) && sub == 0) c += a[ n - 1 ] < k;
-    return quad_sum(c);
+    return quad_sum<L>(c);
 }
 // lower_bound over the sorted a[0..n) as two rounds of independent reads instead of log2(n) dependent ones: first the last
 // key of every block of eight (how many whole blocks lie below k), then the eight keys of the block k falls into
-__device__ __forceinline__ int quad_lower_bound(const uint64_t *a, int n, uint64_t k, int sub)
+template <int L> __device__ __forceinline__ int quad_lower_bound(const uint64_t *a, int n, uint64_t k, int sub)
 {
     const int nb = (n + 7) >> 3;
     int       c = 0;
-    for(int b = sub; b < nb; b += 4) {
+    for(int b = sub; b < nb; b += L) {
         const int last = 8 * b + 7 < n ? 8 * b + 7 : n - 1;
         c += a[ last ] < k;
     }
-    const int blk = quad_sum(c);
+    const int blk = quad_sum<L>(c);
     if(blk >= nb) return n;
     const int lo = 8 * blk, len = n - lo < 8 ? n - lo : 8;
     int       d = 0;
-    for(int j = sub; j < len; j += 4) d += a[ lo + j ] < k;
-    return lo + quad_sum(d);
+    for(int j = sub; j < len; j += L) d += a[ lo + j ] < k;
+    return lo + quad_sum<L>(d);
 }
 
 // ---- search_for_one_: greedy descent over levels (begin, end] ---------------------------------------
@@ -257,8 +259,6 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         viscnt = s.vis_slots ? 1u : 0u;
     }
     viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);  // uniform in wave 0 (tid 0 is its first lane); unused elsewhere
-    // wave 0 fetches the runner-up's neighbour list one hop ahead (the list of a node never changes during a walk)
-    uint32_t spec_node = EMPTY, spec_val = EMPTY;
     int      cnt = 1;
     for(int hop = 0;; ++hop) {
         int *const nnew_slot = &s.scal[ (hop & 1) ? S_NNEW1 : S_NNEW0 ];
@@ -266,7 +266,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         // ---- (1) wave 0: pop + neighbour list + visited filter
         if(tid < 64) {
             int      pos = -1;
-            uint32_t node = EMPTY, runner = EMPTY;
+            uint32_t node = EMPTY;
             for(int base = 0; base < cnt; base += 64) {  // first unexpanded entry = pop of usearch's `next` heap
                 const int                i = base + lane;
                 const uint64_t           key = i < cnt ? s.keys[ i ] : 1ull;
@@ -276,8 +276,6 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                     pos = base + first;
                     const uint32_t lo = (uint32_t)key;  // slot : flag, the low word of the key
                     node = (uint32_t)__builtin_amdgcn_readlane((int)lo, first) >> 1;
-                    const unsigned long long rest = m & (m - 1ull);  // the runner-up: next hop's pop unless a new key beats it
-                    if(rest) runner = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)__builtin_ctzll(rest)) >> 1;
                     break;
                 }
             }
@@ -296,21 +294,10 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                 }
                 uint32_t        cap;
                 const uint32_t *list = neighbors_of(v, node, level, cap);
-                // the first 64 slots of the list: what the previous hop fetched ahead, if its guess (the runner-up) was
-                // popped; otherwise a fresh request.  Then this hop's own guess goes out, to land during the row phase.
-                uint32_t first64 = spec_val;
-                if(node != spec_node) first64 = (uint32_t)lane < cap ? list[ lane ] : EMPTY;
-                spec_node = EMPTY;
-                if(runner != EMPTY) {
-                    uint32_t        rcap;
-                    const uint32_t *rlist = neighbors_of(v, runner, level, rcap);
-                    spec_val = (uint32_t)lane < rcap ? rlist[ lane ] : EMPTY;
-                    spec_node = runner;
-                }
                 int nb_new = 0;
                 for(uint32_t off = 0; off < cap; off += 64) {
                     const uint32_t i = off + (uint32_t)lane;
-                    const uint32_t nb = off == 0 ? first64 : (i < cap ? list[ i ] : EMPTY);
+                    const uint32_t nb = i < cap ? list[ i ] : EMPTY;
                     if constexpr(PROF) {  // make the list's arrival visible to the phase clock
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         LGPU_MARK(5)
@@ -356,18 +343,25 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         __syncthreads();
         LGPU_MARK(2)
         if(!*any_slot) continue;  // nothing beats the current radius: list unchanged
-        // ---- (3) merge: every key's position in the merged list straight from the unsorted new keys.  A quad of lanes per
-        // key: the quad splits the LDS reads (all independent: no binary-search chain), sums with two DPP adds.
+        // ---- (3) merge: every key's position in the merged list straight from the unsorted new keys.  Two or four
+        // adjacent lanes per key (four when the workgroup has the threads for one pass over ef + 2M keys): they split the
+        // LDS reads -- all independent: no binary-search chain -- and sum with DPP adds.
         {
-            const int sub = tid & 3, total = cnt + nnew;
-            for(int t = tid >> 2; t < ((total + 63) & ~63); t += T >> 2) {  // whole waves iterate together (DPP needs the quad's lanes)
-                const bool     live = t < total, is_new = t >= cnt;
-                const uint64_t k = !live ? 0ull : is_new ? s.newkeys[ t - cnt ] : s.keys[ t ];
-                const int      below = quad_count_below(s.newkeys, nnew, k, sub);  // new keys smaller than k (keys are distinct)
-                int            p = t + below;
-                if(is_new) p = below + quad_lower_bound(s.keys, cnt, k, sub);
-                if(live && sub == 0 && p < ef) s.keys2[ p ] = k;
-            }
+            const int total = cnt + nnew;
+            auto merge_pass = [&](auto lanes) {
+                constexpr int L = decltype(lanes)::value;
+                const int     sub = tid & (L - 1);
+                for(int t = tid / L; t < ((total + 63) & ~63); t += T / L) {
+                    const bool     live = t < total, is_new = t >= cnt;
+                    const uint64_t k = !live ? 0ull : is_new ? s.newkeys[ t - cnt ] : s.keys[ t ];
+                    const int      below = quad_count_below<L>(s.newkeys, nnew, k, sub);  // new keys smaller than k (keys are distinct)
+                    int            p = t + below;
+                    if(is_new) p = below + quad_lower_bound<L>(s.keys, cnt, k, sub);
+                    if(live && sub == 0 && p < ef) s.keys2[ p ] = k;
+                }
+            };
+            if(T >= 4 * total) merge_pass(std::integral_constant<int, 4>{});
+            else merge_pass(std::integral_constant<int, 2>{});
         }
         cnt = cnt + nnew < ef ? cnt + nnew : ef;
         uint64_t *tmp = s.keys; s.keys = s.keys2; s.keys2 = tmp;
