@@ -147,8 +147,7 @@ def main():
         if rank == 0:
             print(json.dumps(line), flush=True)
         if rdv:
-            rdv.barrier()
-            rdv.cleanup()
+            rdv.finalize()
 
     if a.dry_run:  # the N>1 plumbing without a device: launch, world check, rendezvous, reductions, line shape
         elapsed = rdv.max_float(0.001 * (rank + 1)) if rdv else 0.001

@@ -267,6 +267,8 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         if(tid < 64) {
             int      pos = -1;
             uint32_t node = EMPTY;
+            bool     mine = false;  // this lane holds the popped key
+            uint64_t popped = 0;
             for(int base = 0; base < cnt; base += 64) {  // first unexpanded entry = pop of usearch's `next` heap
                 const int                i = base + lane;
                 const uint64_t           key = i < cnt ? s.keys[ i ] : 1ull;
@@ -276,6 +278,8 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                     pos = base + first;
                     const uint32_t lo = (uint32_t)key;  // slot : flag, the low word of the key
                     node = (uint32_t)__builtin_amdgcn_readlane((int)lo, first) >> 1;
+                    mine = lane == first;
+                    popped = key;
                     break;
                 }
             }
@@ -309,7 +313,8 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                     nb_new += __popcll(m);
                 }
                 if(s.vis_slots && !spilled) viscnt += (uint32_t)nb_new;
-                if(lane == 0) { *nnew_slot = nb_new; *any_slot = 0; s.keys[ pos ] |= 1ull; }
+                if(lane == 0) { *nnew_slot = nb_new; *any_slot = 0; }
+                if(mine) s.keys[ pos ] = popped | 1ull;  // mark it expanded: the lane that read the key writes it back (no LDS read-modify-write)
             }
         }
         LGPU_MARK(0)

@@ -99,7 +99,14 @@ class FileRendezvous:
                 raise RuntimeError(f"rank {self.rank}: segment of rank {r} has {len(parts[r])} bytes, expected {counts[r]}")
             buf[offsets[r]:offsets[r] + counts[r]] = np.frombuffer(parts[r], dtype=np.uint8)
 
-    def cleanup(self):
-        """Rank 0, after a final barrier."""
+    def finalize(self, timeout: float = 60.0):
+        """The last call of every rank: a barrier, then rank 0 removes the directory -- only after every peer has said that
+        it is through that barrier (a peer still polling for rank 0's file must not find the directory gone)."""
+        self.barrier(timeout)
+        self.put(f"done.{self.rank}", b"")
         if self.rank == 0:
-            shutil.rmtree(self.path, ignore_errors=True)
+            try:
+                for r in range(1, self.world):
+                    self.get(f"done.{r}", timeout)
+            finally:
+                shutil.rmtree(self.path, ignore_errors=True)
