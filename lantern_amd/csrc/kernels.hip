@@ -1066,10 +1066,30 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_regs(RevlinkA
 // Five rounds, five barriers, for what was thirty-two.  Lane/chunk ownership and the reduction tree are those of
 // group_dist<METRIC, 64> (lane l owns chunks l, l+64, ...; one fma chain per accumulator in memory order; DPP butterfly),
 // and the metrics are bitwise symmetric, so every table entry has the bits the sequential kernels / the oracle compute.
-constexpr int PAIRS_NMAX = 34;  // candidates (<= 33) + close
+//
+// CHAINS.  Requests to one (node, level) are applied in new-slot order, each against the list the previous one left: a
+// hub node that 300 new nodes of a batch picked is a chain of 300 dependent re-prunes, and with one workgroup per group
+// that chain IS the kernel's run time on hubby data (i.i.d. Gaussian rows: largest group 200-400 requests per 8192-node
+// batch; measured, the waves of this kernel were resident 28 % of its duration -- the rest was the tail of such chains).
+// A re-prune's output is greedy-consistent: every kept entry passed against all kept entries before it, in sorted order.
+// Adding ONE candidate x to such a list L needs none of L's pairs again:
+//     * entries before x in the order are kept as they were (their tests involve only entries before them);
+//     * x is kept iff no entry before it is closer to it than `close` is: d(x, y) >= d(x, close) for all y before x;
+//     * an entry c after x is kept iff x does not block it: x dropped, or d(c, x) >= d(c, close)  (entries x removes
+//       cannot have blocked anything: everything after them was kept WITH them present);
+//     * the result is cut at cap -- and is greedy-consistent again.
+// That is <= cap distances d(x, .) instead of (cap+1) cap / 2 pairs -- and none at all when the list is full and x sorts
+// behind its last entry (x is cut: the common case at a hub, decided from the request's own d(x, close)).  So after the
+// first full re-prune of a group the kept rows STAY in the waves' registers and every further request costs one row
+// (x's), <= 5 distances per wave and three barriers; the chain's critical path drops from ~5 us to <1 us per link.
+// The chain ends when a step leaves the list short of cap (later requests append unchecked; the next overflow takes the
+// full path again).  Same decisions, same order, same bits as the sequential algorithm: graphs stay edge-for-edge equal
+// to the oracle's.
+constexpr int PAIRS_NMAX = 34;   // candidates (<= 33) + close
+constexpr int PAIRS_SLOTS = 40;  // register row slots: 8 waves x 5
 __host__ __device__ inline size_t pairs_lds_bytes(int cpl)
 {
-    return (size_t)2 * 8 * 64 * cpl * 16 + (size_t)PAIRS_NMAX * PAIRS_NMAX * 4 + 7 * 160 + 320 + 64;
+    return (size_t)2 * 8 * 64 * cpl * 16 + (size_t)PAIRS_NMAX * PAIRS_NMAX * 4 + 10 * 160 + 320 + 64 + 64;
 }
 
 template <int METRIC, int CPL>
@@ -1088,8 +1108,12 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_pairs(Revlink
     uint32_t *sid = (uint32_t *)p;                 p += 160;
     int      *rank = (int *)p;                     p += 160;
     uint16_t *sidx = (uint16_t *)p;                p += 160;
+    float    *lsd = (float *)p;                    p += 160;   // chain state: d(close, list entry), list order
+    float    *dxy = (float *)p;                    p += 160;   // chain step: d(x, row slot)
+    uint8_t  *lrs = (uint8_t *)p;                  p += 64;    // chain state: row slot of list entry i
+    uint8_t  *socc = (uint8_t *)p;                 p += 64;    // chain state: row slot occupied by a list entry
     unsigned long long *blockers = (unsigned long long *)p;  p += 320;
-    int      *scal = (int *)p;
+    int      *scal = (int *)p;                     // [0] count, [1] x's row slot (-1: x dropped)
     const uint32_t nwork = *work_count;
     const int      chunks = (int)a.view.chunks;
     uint32_t       pairs = 0, reprunes = 0;
@@ -1101,6 +1125,7 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_pairs(Revlink
             v[ c ] = ch < chunks ? row[ ch ] : make_uint4(0, 0, 0, 0);
         }
     };
+    auto order_key = [](float d, uint32_t id, uint32_t centre) { return ((uint64_t)f2ord(d) << 32) | tie_mix(id, centre); };
     for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         const uint32_t gi = work[ wi ].group;
         const uint32_t begin = a.groups[ gi ].x, end = a.groups[ gi ].y;
@@ -1113,8 +1138,84 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_pairs(Revlink
         for(uint32_t i = tid; i < cap; i += T) cid[ i ] = list[ i ];
         int c = (int)cap;  // the list is full at hand-off (k_revlink_append filled it from the requests [begin, t_first))
         __syncthreads();
+        // the rows of the current list entries, in this wave's registers while a chain runs: row slot r = wave + 8 j
+        uint4 own[ 5 ][ CPL ];
+        float ownn[ 5 ];
+        bool  chain = false;  // cid / lsd / lrs / socc + `own` describe a full, greedy-consistent list
         for(uint32_t t = t_first; t < end; ++t) {
             const uint32_t vnew = a.reqs[ t ].new_slot;
+            const float    dv = a.reqs[ t ].d;
+            if(chain) {
+                // ---- one more candidate for a consistent full list (c == cap)
+                reprunes++;
+                const uint64_t kx = order_key(dv, vnew, close);
+                const bool     before = lane < c && order_key(lsd[ lane < c ? lane : 0 ], cid[ lane < c ? lane : 0 ], close) < kx;
+                const int      pos = (int)__popcll(__ballot(before));  // every wave computes it for itself: no barrier
+                if(pos == c) continue;                                 // x sorts behind the last entry of a full list: cut, unseen
+                uint4 cur[ CPL ];
+                if(wave == (int)(t & 7)) {
+                    load_row(vnew, cur);
+#pragma unroll
+                    for(int cc = 0; cc < CPL; ++cc) ring[ lane + 64 * cc ] = cur[ cc ];
+                }
+                __syncthreads();
+                if(wave != (int)(t & 7)) {
+#pragma unroll
+                    for(int cc = 0; cc < CPL; ++cc) cur[ cc ] = ring[ lane + 64 * cc ];
+                }
+                const float xn = row_norm<METRIC>(a.view, vnew);
+#pragma unroll
+                for(int j = 0; j < 5; ++j) {
+                    const int r = wave + 8 * j;
+                    if(socc[ r ]) {  // wave-uniform
+                        RowAcc<METRIC> acc;
+#pragma unroll
+                        for(int cc = 0; cc < CPL; ++cc) acc.add(own[ j ][ cc ], cur[ cc ]);
+                        const float d = acc.template finish_n<64>(ownn[ j ], xn);
+                        if(lane == 63) dxy[ r ] = d;
+                    }
+                }
+                pairs += (uint32_t)c;
+                __syncthreads();
+                if(tid < 64) {
+                    const bool  live = lane < c;
+                    const int   myslot = live ? (int)lrs[ lane ] : 0;
+                    const float di = live ? dxy[ myslot ] : 0.f, mysd = live ? lsd[ lane ] : 0.f;
+                    const uint32_t myid = live ? cid[ lane ] : 0u;
+                    const bool  x_bad = __ballot(before && di < dv) != 0ull;  // an entry before x is closer to x than `close` is
+                    int         xslot = -1, cn = c;
+                    if(!x_bad) {
+                        const bool               keep = live && (before || !(di < mysd));  // after x: dropped iff x is closer to it than `close`
+                        const unsigned long long after_kept = __ballot(keep && !before);
+                        int np = lane;  // new position
+                        if(live && !before) np = pos + 1 + (int)__popcll(after_kept & ((1ull << lane) - 1ull));
+                        const bool stays = keep && np < (int)cap;
+                        cn = pos + 1 + (int)__popcll(after_kept);
+                        if(cn > (int)cap) cn = (int)cap;
+                        // a row slot for x: free before this step (there are 40 slots for <= 33 rows)
+                        const unsigned long long free_slots = __ballot(lane < PAIRS_SLOTS && socc[ lane < PAIRS_SLOTS ? lane : 0 ] == 0);
+                        xslot = (int)__builtin_ctzll(free_slots);
+                        if(live && !stays) socc[ myslot ] = 0;
+                        if(stays) { cid[ np ] = myid; lsd[ np ] = mysd; lrs[ np ] = (uint8_t)myslot; }
+                        if(lane == 0) { cid[ pos ] = vnew; lsd[ pos ] = dv; lrs[ pos ] = (uint8_t)xslot; socc[ xslot ] = 1; }
+                    }
+                    if(lane == 0) { scal[ 0 ] = cn; scal[ 1 ] = xslot; }
+                }
+                __syncthreads();
+                c = scal[ 0 ];
+                const int xslot = scal[ 1 ];
+                if(xslot >= 0 && wave == (xslot & 7)) {  // x's row moves into its slot's registers
+#pragma unroll
+                    for(int j = 0; j < 5; ++j)
+                        if(j == (xslot >> 3)) {
+#pragma unroll
+                            for(int cc = 0; cc < CPL; ++cc) own[ j ][ cc ] = cur[ cc ];
+                            ownn[ j ] = xn;
+                        }
+                }
+                if(c < (int)cap) chain = false;  // short of cap: the following requests append unchecked
+                continue;
+            }
             if(c < (int)cap) {
                 if(tid == 0) { cid[ c ] = vnew; list[ c ] = vnew; }
                 c++;
@@ -1126,8 +1227,6 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_pairs(Revlink
             if(tid == 0) cid[ c ] = vnew;
             __syncthreads();
             // ---- this wave's rows, all in flight at once
-            uint4 own[ 5 ][ CPL ];
-            float ownn[ 5 ];
 #pragma unroll
             for(int j = 0; j < 5; ++j) {
                 const int r = wave + 8 * j;
@@ -1187,10 +1286,8 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_pairs(Revlink
             }
             __syncthreads();
             for(int cell = tid; cell < n * n; cell += T) {
-                const int      x = cell / n, j = cell - x * n;
-                const uint64_t kx = ((uint64_t)f2ord(cd[ x ]) << 32) | tie_mix(cid[ x ], close);
-                const uint64_t kj = ((uint64_t)f2ord(cd[ j ]) << 32) | tie_mix(cid[ j ], close);
-                if(kj < kx) atomicAdd(&rank[ x ], 1);
+                const int x = cell / n, j = cell - x * n;
+                if(order_key(cd[ j ], cid[ j ], close) < order_key(cd[ x ], cid[ x ], close)) atomicAdd(&rank[ x ], 1);
             }
             __syncthreads();
             for(int x = tid; x < n; x += T) {
@@ -1221,20 +1318,23 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_pairs(Revlink
                     const unsigned long long b = ((unsigned long long)hi << 32) | lo;
                     if((b & kept) == 0ull) { kept |= 1ull << cpos; submitted++; }
                 }
-                uint32_t ks = 0;
-                if(lane < submitted) {  // lane x takes the x-th kept position
+                if(lane < PAIRS_SLOTS) socc[ lane ] = 0;
+                if(lane < submitted) {  // lane x takes the x-th kept position: the list, its distances, its rows' slots
                     unsigned long long m = kept;
                     for(int s2 = 0; s2 < lane; ++s2) m &= m - 1ull;
-                    ks = sid[ __builtin_ctzll(m) ];
+                    const int kpos = __builtin_ctzll(m);
+                    cid[ lane ] = sid[ kpos ];
+                    lsd[ lane ] = sd[ kpos ];
+                    lrs[ lane ] = (uint8_t)sidx[ kpos ];
+                    socc[ sidx[ kpos ] ] = 1;
                 }
-                if(lane < submitted) cid[ lane ] = ks;
                 if(lane == 0) scal[ 0 ] = submitted;
             }
             __syncthreads();
             c = scal[ 0 ];
-            for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? cid[ i ] : EMPTY;
-            __syncthreads();
+            chain = c == (int)cap;  // the rows of the kept entries sit in `own` at their candidate indices
         }
+        for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? cid[ i ] : EMPTY;
     }
     if(tid == 0 && a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs); atomicAdd(&a.totals[ 1 ], (unsigned long long)reprunes); }
 }
