@@ -1253,6 +1253,7 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_pairs(Revlink
                         for(int cc = 0; cc < CPL; ++cc) half[ (size_t)wave * 64 * CPL + lane + 64 * cc ] = own[ t8 ][ cc ];
                     }
                     __syncthreads();  // also: everybody is done reading this half from round t8 - 2
+#pragma unroll 1  // one ring row in registers at a time: unrolled, the scheduler hoists all eight rows' LDS reads and spills
                     for(int u = 0; u < 8; ++u) {
                         const int jr = 8 * t8 + u;
                         if(jr > n) break;
@@ -1526,8 +1527,9 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
     // staged variant whenever the 2M+2 rows of a level-0 re-prune fit in LDS (d <= 1024 at M = 16)
     const size_t staged = staged_lds_bytes(a.view.chunks, a.view.M0);
     const bool i8 = mcode_is_i8(metric);  // i8 rows take the LDS-staged / generic kernels (Lantern caps d at 2000: <= 125 chunks)
-    if(!i8 && a.view.chunks >= 128 && a.view.chunks <= 256 && a.view.M0 <= 32 && work && work_count) {
-        // d = 512..1024 f32 rows, M <= 16: all-pairs re-prune with the rows in registers (k_revlink_pairs);
+    static const bool use_slab = std::getenv("LANTERN_GPU_REPRUNE") && std::string(std::getenv("LANTERN_GPU_REPRUNE")) == "slab";
+    if(!i8 && a.view.chunks >= 128 && a.view.chunks <= 512 && a.view.M0 <= 32 && work && work_count && !(use_slab && a.view.chunks > 256)) {
+        // d = 512..2048 f32 rows, M <= 16: all-pairs re-prune with the rows in registers (k_revlink_pairs);
         // LANTERN_GPU_REPRUNE=regs selects the sequential-walk kernel it replaced (A/B measurements)
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;
@@ -1535,7 +1537,7 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
         static const bool use_regs = std::getenv("LANTERN_GPU_REPRUNE") && std::string(std::getenv("LANTERN_GPU_REPRUNE")) == "regs";
         static const bool force4 = std::getenv("LANTERN_GPU_REGS_CPL4") != nullptr;  // tuning: always the four-chunks-per-lane variant
         const bool cpl3 = a.view.chunks <= 192 && !force4;
-        if(use_regs) {
+        if(use_regs && a.view.chunks <= 256) {
             const int grid = num_cus * 2;
 #define REGS(MM)                                                                                                                        \
     {                                                                                                                                   \
@@ -1553,17 +1555,18 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
 #undef REGS
             return hipGetLastError();
         }
-        const size_t lds = pairs_lds_bytes(cpl3 ? 3 : 4);
+        // chunks per lane: 3 covers d <= 768 f32 at two workgroups per CU; 4 / 6 / 8 (d <= 1024 / 1536 / 2048) run one per CU
+        const int    cpl = cpl3 ? 3 : a.view.chunks <= 256 ? 4 : a.view.chunks <= 384 ? 6 : 8;
+        const size_t lds = pairs_lds_bytes(cpl);
         const int    grid = num_cus * (cpl3 ? 2 : 1);
+#define PAIRS_ONE(MM, CC)                                                                                                               \
+    {                                                                                                                                   \
+        (void)hipFuncSetAttribute((const void *)k_revlink_pairs<MM, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        hipLaunchKernelGGL((k_revlink_pairs<MM, CC>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count);        \
+    }
 #define PAIRS(MM)                                                                                                                       \
     {                                                                                                                                   \
-        if(cpl3) {                                                                                                                      \
-            (void)hipFuncSetAttribute((const void *)k_revlink_pairs<MM, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-            hipLaunchKernelGGL((k_revlink_pairs<MM, 3>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count);     \
-        } else {                                                                                                                        \
-            (void)hipFuncSetAttribute((const void *)k_revlink_pairs<MM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-            hipLaunchKernelGGL((k_revlink_pairs<MM, 4>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count);     \
-        }                                                                                                                               \
+        if(cpl == 3) PAIRS_ONE(MM, 3) else if(cpl == 4) PAIRS_ONE(MM, 4) else if(cpl == 6) PAIRS_ONE(MM, 6) else PAIRS_ONE(MM, 8)       \
     }
         switch(metric) {
             case M_L2SQ: PAIRS(M_L2SQ); break;
@@ -1574,6 +1577,7 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
             default: return hipErrorInvalidValue;
         }
 #undef PAIRS
+#undef PAIRS_ONE
         return hipGetLastError();
     }
     if(!i8 && a.view.chunks >= 128 && a.view.M0 <= 32 && work && work_count) {
