@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(512, 6) k_insert(InsertArgs a)
 // so a candidate costs one barrier instead of a round of L2 reads.  Same lane/chunk ownership and reduction
 // tree as group_dist<METRIC, 64>, hence the same bits.  Rows that do not fit this shape (G < 64, more than 256
 // chunks, M > 16) take the generic refine().
-template <int METRIC, int G>
+template <int METRIC, int G, int CPLC = 4>  // CPLC: 16-byte chunks per lane of the register path (rows of up to 64 * CPLC chunks)
 __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
 {
     const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
     uint32_t Dr = 0;
     int      keep;
     const int chunks = (int)a.view.chunks;
-    if(G == 64 && chunks <= 256 && M <= 16 && T == 256) {
+    if(G == 64 && chunks <= 64 * CPLC && M <= 16 && T == 256) {
         // ---- sort by (distance, tie_mix(slot, me)) into sd / sid
         for(int t = tid; t < n; t += T) {
             const uint64_t k = ((uint64_t)f2ord(r.cd[ t ]) << 32) | tie_mix(r.cid[ t ], me);
@@ -203,24 +203,24 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
             keep = n;
             for(int i = tid; i < n; i += T) { kid[ i ] = r.sid[ i ]; kd[ i ] = r.sd[ i ]; }
         } else {
-            auto load_row = [&](uint32_t slot, uint4 (&v)[ 4 ]) {
+            auto load_row = [&](uint32_t slot, uint4 (&v)[ CPLC ]) {
                 const uint4 *row = row_of(a.view, slot);
 #pragma unroll
-                for(int c = 0; c < 4; ++c) {
+                for(int c = 0; c < CPLC; ++c) {
                     const int ch = lane + 64 * c;
                     v[ c ] = ch < chunks ? row[ ch ] : make_uint4(0, 0, 0, 0);
                 }
             };
-            uint4 kept[ 4 ][ 4 ], cur[ 4 ], nxt[ 4 ];
+            uint4 kept[ 4 ][ CPLC ], cur[ CPLC ], nxt[ CPLC ];
             float keptn[ 4 ] = { 0.f, 0.f, 0.f, 0.f };  // cached norms of this wave's kept rows (cosine metrics)
 #pragma unroll
             for(int j = 0; j < 4; ++j)
 #pragma unroll
-                for(int c = 0; c < 4; ++c) kept[ j ][ c ] = make_uint4(0, 0, 0, 0);
+                for(int c = 0; c < CPLC; ++c) kept[ j ][ c ] = make_uint4(0, 0, 0, 0);
             load_row(r.sid[ 0 ], cur);
             if(wave == 0) {
 #pragma unroll
-                for(int c = 0; c < 4; ++c) kept[ 0 ][ c ] = cur[ c ];
+                for(int c = 0; c < CPLC; ++c) kept[ 0 ][ c ] = cur[ c ];
                 keptn[ 0 ] = row_norm<METRIC>(a.view, r.sid[ 0 ]);
             }
             if(tid == 0) { kid[ 0 ] = r.sid[ 0 ]; kd[ 0 ] = r.sd[ 0 ]; }
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
             if(n > 1) load_row(r.sid[ 1 ], nxt);
             while(submitted < (int)M && consumed < n) {
 #pragma unroll
-                for(int c = 0; c < 4; ++c) cur[ c ] = nxt[ c ];
+                for(int c = 0; c < CPLC; ++c) cur[ c ] = nxt[ c ];
                 const float    cdist = r.sd[ consumed ];
                 const uint32_t cslot = r.sid[ consumed ];
                 const float    cn2 = row_norm<METRIC>(a.view, cslot);
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
                     if(wave + 4 * j < submitted) {  // wave-uniform
                         RowAcc<METRIC> acc;
 #pragma unroll
-                        for(int c = 0; c < 4; ++c) acc.add(cur[ c ], kept[ j ][ c ]);
+                        for(int c = 0; c < CPLC; ++c) acc.add(cur[ c ], kept[ j ][ c ]);
                         const float d = acc.template finish_n<64>(cn2, keptn[ j ]);
                         bad |= d < cdist;  // meaningful in lane 63
                     }
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
                         for(int jj = 0; jj < 4; ++jj)
                             if(jj == j) {
 #pragma unroll
-                                for(int c = 0; c < 4; ++c) kept[ jj ][ c ] = cur[ c ];
+                                for(int c = 0; c < CPLC; ++c) kept[ jj ][ c ] = cur[ c ];
                                 keptn[ jj ] = cn2;
                             }
                     }
@@ -1512,7 +1512,14 @@ hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream)
 {
     if(a.items == 0) return hipSuccess;
     const size_t lds = connect_lds_bytes(a.efc, a.view.M);
-#define CALL(MM, GG) hipLaunchKernelGGL((k_connect<MM, GG>), dim3(a.items), dim3(256), lds, stream, a)
+    // rows of more than 256 chunks (d > 1024 f32) take the register path too, with six or eight chunks per lane
+    // (one wave per SIMD: the 512-entry register file is the workgroup's)
+#define CALL(MM, GG)                                                                                                          \
+    {                                                                                                                         \
+        if(GG != 64 || a.view.chunks <= 256) hipLaunchKernelGGL((k_connect<MM, GG, 4>), dim3(a.items), dim3(256), lds, stream, a); \
+        else if(a.view.chunks <= 384) hipLaunchKernelGGL((k_connect<MM, GG == 64 ? 64 : GG, GG == 64 ? 6 : 4>), dim3(a.items), dim3(256), lds, stream, a); \
+        else hipLaunchKernelGGL((k_connect<MM, GG == 64 ? 64 : GG, GG == 64 ? 8 : 4>), dim3(a.items), dim3(256), lds, stream, a); \
+    }
     LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL
     return hipGetLastError();

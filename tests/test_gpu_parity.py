@@ -132,7 +132,10 @@ def test_search_matches_oracle_on_same_graph(capi, oracle, metric, n, d, M, efc,
 # (>= 64 chunks, M <= 16; all three metrics; 1 and 6 slabs), and the unstaged one (M = 40: 82 rows do not fit in LDS)
 @pytest.mark.parametrize("metric,n,d,M,efc", [("l2sq", 1200, 64, 8, 40), ("cos", 700, 256, 16, 64), ("hamming", 900, 8, 6, 32),
                                               ("l2sq", 300, 5, 2, 10), ("hamming", 600, 256, 8, 32), ("l2sq", 700, 1536, 16, 48),
-                                              ("cos", 500, 1000, 12, 40), ("l2sq", 400, 512, 40, 48)])
+                                              ("cos", 500, 1000, 12, 40), ("l2sq", 400, 512, 40, 48),
+                                              # small M on high-dimensional Gaussian rows: lists fill at once and hub nodes collect long CHAINS
+                                              # of re-prunes per batch (k_revlink_pairs' chain mode); 2000-d = eight chunks per lane
+                                              ("l2sq", 2500, 768, 4, 32), ("cos", 1500, 2000, 8, 40), ("l2sq", 900, 520, 16, 64)])
 @pytest.mark.parametrize("plan", [(1, 1), (64, 4), (512, 16)])
 def test_build_matches_oracle_edge_for_edge(capi, oracle, metric, n, d, M, efc, plan):
     rng = np.random.default_rng(n * 7 + d)
