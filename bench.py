@@ -288,8 +288,11 @@ def main():
         recall = float(np.mean([len(set(f.tolist()) & set(t.tolist())) / a.k for f, t in zip(found, truth)]))
 
         cpu = None
+        quality = None
         if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
             cpu = cpu_baseline(a, ix, base, queries, found)
+            if a.build_quality_rows > 0:
+                quality = build_quality(a)
 
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -333,6 +336,7 @@ def main():
                          "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": avg_kernel_s * 1e3},
             "cpu_baseline": cpu,
+            "build_quality": quality,
             "collective_build": collective,
             "setup_seconds": {"datagen": t_gen, "build": t_build, "exact_truth": t_truth},
         }
@@ -358,6 +362,43 @@ def build_roofline(a, c, prof, t_build, world):
         out[name] = {"bound": "hbm", "algorithmic_bytes": float(nbytes), "ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gbs / HBM_PEAK_GBS}
     return out
+
+
+def build_quality(a):
+    """north_star: "recall@10 within +-0.5 % of the reference".  The reference builds with one usearch_add per tuple
+    (build.c:83-135); the device builds batch-synchronously (batches of up to --add-batch, never more than size / 16).  On
+    the BASELINE config[1] shape (100k x 128, seeds 1 / 2; --build-quality-rows) both builds are made from the same rows --
+    the sequential one by the CPU port, usearch's own summation flags -- and searched ON THE DEVICE with the same queries
+    against exact truth.  (tests/test_gpu_baseline_configs.py asserts the same on this set and on a 200k x 768 low-rank set.)"""
+    from lantern_amd import capi
+    from oracle import binding as oracle
+
+    n, d = a.build_quality_rows, 128
+    base = np.random.default_rng(1).standard_normal((n, d), dtype=np.float32)
+    queries = np.random.default_rng(2).standard_normal((1000, d), dtype=np.float32)
+    labels = np.arange(n, dtype=np.uint64) + 1
+    dev = capi.GpuIndex("l2sq", d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
+    dev.reserve(n)
+    dev.set_add_batch(a.add_batch, 16)
+    t0 = time.perf_counter()
+    dev.add_many(labels, base)
+    dev.flush()
+    t_dev = time.perf_counter() - t0
+    truth, _ = dev.exact_search(queries, a.k)
+    lab, _, _ = dev.search_batch(queries, a.k, a.ef)
+    r_dev = oracle.recall_at_k(lab.astype(np.int64) - 1, truth)
+    seq = oracle.OracleIndex("l2sq", d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, sum_mode=oracle.SUM_FAST)
+    seq.reserve(n)
+    t0 = time.perf_counter()
+    seq.add_many(labels, base)
+    t_seq = time.perf_counter() - t0
+    ref = capi.GpuIndex("l2sq", d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
+    ref.import_graph(base, seq.export_graph())
+    lab2, _, _ = ref.search_batch(queries, a.k, a.ef)
+    r_seq = oracle.recall_at_k(lab2.astype(np.int64) - 1, truth)
+    return {"set": f"{n}x{d} f32 l2sq N(0,1), seeds 1 / 2 (BASELINE config[1] shape), 1000 queries, ef={a.ef}",
+            "recall_device_batched_build": r_dev, "recall_sequential_build": r_seq, "abs_diff": abs(r_dev - r_seq), "bar": 0.005,
+            "device_build_seconds": t_dev, "sequential_cpu_build_seconds": t_seq, "sequential_cpu_build_vectors_per_s": n / t_seq}
 
 
 def usable_cores() -> int:

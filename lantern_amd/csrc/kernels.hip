@@ -382,7 +382,7 @@ __host__ __device__ inline size_t staged_lds_bytes(uint32_t chunks, uint32_t cap
 {
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t n = cap + 1;
-    return (size_t)(cap + 2) * chunks * 16 + 4 * up16(n * 4) + up16(n * 2) + up16(n * n * 4) + S_SCALARS * 4;
+    return (size_t)(cap + 2) * chunks * 16 + 4 * up16(n * 4) + up16(n * 2) + up16(n * n * 4) + S_SCALARS * 4 + up16((n + 1) * 4) + 2 * up16(n + 1);
 }
 
 // k_revlink_append: the cheap half of the reverse-link step, one WAVE per (close, level) group: append
@@ -426,9 +426,10 @@ __global__ void __launch_bounds__(256) k_revlink_append(RevlinkArgs a, RevWork *
 template <int METRIC, int G>
 __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const RevWork *work, const uint32_t *work_count)
 {
-    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
+    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G, lane = tid & 63;
     const uint32_t nwork = *work_count;
     uint32_t pairs = 0, reprunes = 0;
+    auto order_key = [](float d, uint32_t id, uint32_t centre) { return ((uint64_t)f2ord(d) << 32) | tie_mix(id, centre); };
     for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
     const uint32_t gi = work[ wi ].group;
     const uint32_t begin = a.groups[ gi ].x, end = a.groups[ gi ].y;
@@ -439,6 +440,8 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
     uint32_t      *list = neighbors_of(a.view, close, level, cap);
     const int      chunks = (int)a.view.chunks;
     StagedLds s;
+    uint8_t  *lrs, *socc;  // chain state: LDS row of list entry i; row occupied by a list entry
+    float    *dxy;         // chain step: d(x, row)
     {
         auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
         unsigned char *p = lgpu_smem;
@@ -450,7 +453,10 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
         s.sid = (uint32_t *)p;   p += up16(n * 4);
         s.sidx = (uint16_t *)p;  p += up16(n * 2);
         s.pair = (float *)p;     p += up16(n * n * 4);
-        s.scal = (int *)p;
+        s.scal = (int *)p;       p += S_SCALARS * 4;
+        dxy = (float *)p;        p += up16((n + 1) * 4);
+        lrs = (uint8_t *)p;      p += up16(n + 1);
+        socc = (uint8_t *)p;
     }
     __syncthreads();  // the previous work item is done with the LDS
     // the list is full at hand-off: entries [c0, cap) were appended by k_revlink_append from the requests
@@ -461,9 +467,64 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
     for(int i = c0 + tid; i < (int)cap; i += T) s.cd[ i ] = a.reqs[ begin + (uint32_t)(i - c0) ].d;
     __syncthreads();
     bool have_d = false;
+    // CHAIN (see k_revlink_pairs): after a full re-prune that leaves the list full, s.cid / s.cd hold the greedy-consistent
+    // list in order, the entries' rows stay in LDS (row lrs[i]), and one more candidate costs its own row and <= cap
+    // distances -- or nothing, when it sorts behind the last entry.  cap <= 64 (one lane of wave 0 per entry).
+    bool chain = false;
     for(uint32_t t = t_first; t < end; ++t) {
         const uint32_t vnew = a.reqs[ t ].new_slot;
         const float    dv = a.reqs[ t ].d;
+        if(chain) {
+            reprunes++;
+            const uint64_t kx = order_key(dv, vnew, close);
+            const bool     before = lane < c && order_key(s.cd[ lane < c ? lane : 0 ], s.cid[ lane < c ? lane : 0 ], close) < kx;
+            const int      pos = (int)__popcll(__ballot(before));  // every wave for itself
+            if(pos == c) continue;                                 // cut unseen: behind the last entry of a full list
+            // x's row into a free LDS row (wave 0 finds it: there are cap + 2 rows for <= cap entries)
+            if(tid < 64) {
+                const int                nrows = (int)cap + 2;
+                const unsigned long long free_rows = __ballot(lane < nrows && socc[ lane < nrows ? lane : 0 ] == 0);
+                if(lane == 0) s.scal[ 1 ] = (int)__builtin_ctzll(free_rows);
+            }
+            __syncthreads();
+            const int xrow = s.scal[ 1 ];
+            for(int ch = tid; ch < chunks; ch += T) s.rows[ (size_t)xrow * chunks + ch ] = row_of(a.view, vnew)[ ch ];
+            __syncthreads();
+            const float xn = row_norm<METRIC>(a.view, vnew);
+            for(int i = g; i < c; i += NG) {  // d(x, entry i), one G-lane group per entry
+                const int   r = lrs[ i ];
+                const float d = group_dist_n<METRIC, G>(s.rows + (size_t)xrow * chunks, s.rows + (size_t)r * chunks, chunks, gl, xn,
+                                                        row_norm<METRIC>(a.view, s.cid[ i ]));
+                if(gl == G - 1) dxy[ i ] = d;
+            }
+            pairs += (uint32_t)c;
+            __syncthreads();
+            if(tid < 64) {
+                const bool     live = lane < c;
+                const int      myrow = live ? (int)lrs[ lane ] : 0;
+                const float    di = live ? dxy[ lane ] : 0.f, mysd = live ? s.cd[ lane ] : 0.f;
+                const uint32_t myid = live ? s.cid[ lane ] : 0u;
+                const bool     x_bad = __ballot(before && di < dv) != 0ull;
+                int            cn = c;
+                if(!x_bad) {
+                    const bool               keep = live && (before || !(di < mysd));
+                    const unsigned long long after_kept = __ballot(keep && !before);
+                    int np = lane;
+                    if(live && !before) np = pos + 1 + (int)__popcll(after_kept & ((1ull << lane) - 1ull));
+                    const bool stays = keep && np < (int)cap;
+                    cn = pos + 1 + (int)__popcll(after_kept);
+                    if(cn > (int)cap) cn = (int)cap;
+                    if(live && !stays) socc[ myrow ] = 0;
+                    if(stays) { s.cid[ np ] = myid; s.cd[ np ] = mysd; lrs[ np ] = (uint8_t)myrow; }
+                    if(lane == 0) { s.cid[ pos ] = vnew; s.cd[ pos ] = dv; lrs[ pos ] = (uint8_t)xrow; socc[ xrow ] = 1; }
+                }
+                if(lane == 0) s.scal[ S_CNT ] = cn;
+            }
+            __syncthreads();
+            c = s.scal[ S_CNT ];
+            if(c < (int)cap) { chain = false; have_d = true; }  // short of cap: appends follow; every entry's distance to `close` is in s.cd
+            continue;
+        }
         if(c < (int)cap) {
             if(tid == 0) { s.cid[ c ] = vnew; s.cd[ c ] = dv; list[ c ] = vnew; }
             c++;
@@ -510,9 +571,9 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
         }
         // ---- sort by (distance to close, tie_mix(slot, close))
         for(int x = tid; x < n; x += T) {
-            const uint64_t k = ((uint64_t)f2ord(s.cd[ x ]) << 32) | tie_mix(s.cid[ x ], close);
+            const uint64_t k = order_key(s.cd[ x ], s.cid[ x ], close);
             int            rank = 0;
-            for(int j = 0; j < n; ++j) rank += (((uint64_t)f2ord(s.cd[ j ]) << 32) | tie_mix(s.cid[ j ], close)) < k;
+            for(int j = 0; j < n; ++j) rank += order_key(s.cd[ j ], s.cid[ j ], close) < k;
             s.sd[ rank ] = s.cd[ x ];
             s.sid[ rank ] = s.cid[ x ];
             s.sidx[ rank ] = (uint16_t)x;
@@ -536,7 +597,6 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
         // ---- the heuristic on the distance matrix: wave 0, one lane per already-kept entry
         // (lane x holds the sorted positions of kept entries x, x+64, x+128, x+192; cap <= 256)
         if(tid < 64) {
-            const int lane = tid;
             int       kpos[ 4 ] = { 0, 0, 0, 0 };  // kept[0] = sorted position 0
             int       submitted = 1, consumed = 1;
             while(submitted < (int)cap && consumed < n) {
@@ -557,6 +617,10 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
                 }
                 consumed++;
             }
+            if(cap <= 62) {  // chain bookkeeping: which LDS rows the kept entries sit in (row = candidate index before the sort)
+                if(lane < (int)cap + 2) socc[ lane ] = 0;
+                if(lane < submitted) { lrs[ lane ] = (uint8_t)s.sidx[ kpos[ 0 ] ]; socc[ s.sidx[ kpos[ 0 ] ] ] = 1; }
+            }
 #pragma unroll
             for(int j = 0; j < 4; ++j) {
                 const int x = lane + 64 * j;
@@ -566,9 +630,9 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
         }
         __syncthreads();
         c = s.scal[ S_CNT ];
-        for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? s.cid[ i ] : EMPTY;
-        __syncthreads();
+        chain = c == (int)cap && cap <= 62;
     }
+    for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? s.cid[ i ] : EMPTY;
     }  // work items
     if(tid == 0 && a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs); atomicAdd(&a.totals[ 1 ], (unsigned long long)reprunes); }
 }
@@ -1605,13 +1669,15 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
         return hipGetLastError();
     }
     if(staged <= 150 * 1024 && a.view.M0 <= 256 && work && work_count) {
+        // as many 8-wave workgroups per CU as the staged rows leave LDS for (short rows: up to four)
+        const int staged_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / staged));
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;
         hipLaunchKernelGGL(k_revlink_append, dim3(append_grid), dim3(256), 0, stream, a, (RevWork *)work, work_count);
 #define CALL(MM, GG)                                                                                                    \
     {                                                                                                                   \
         (void)hipFuncSetAttribute((const void *)k_revlink_staged<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged); \
-        hipLaunchKernelGGL((k_revlink_staged<MM, GG>), dim3(num_cus), dim3(512), staged, stream, a, (const RevWork *)work, work_count); \
+        hipLaunchKernelGGL((k_revlink_staged<MM, GG>), dim3(num_cus * staged_per_cu), dim3(512), staged, stream, a, (const RevWork *)work, work_count); \
     }
         LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL
