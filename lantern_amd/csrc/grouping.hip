@@ -118,7 +118,53 @@ __global__ void __launch_bounds__(256) k_pq_decode(float *rows, uint32_t row_flo
     if(j < dims) v = codebook[ (size_t)codes[ (size_t)(first + i) * S + j / subdim ] * dims + j ];
     rows[ (size_t)(first + i) * row_floats + j ] = v;
 }
+// ---- quantised storage of f32 input, on the device: a bulk add uploads the caller's f32 rows once and this kernel writes
+// the stored rows -- the rules of pad_row (index.cpp), element for element: f16 = round to nearest even; i8 =
+// trunc(clamp(x * 100, -100, 100)), NaN -> 0; b1 = bit (x > 0), most significant bit of each byte first.  Rows are zero
+// padded to whole 16-byte chunks.  kind: 3 = f16, 4 = i8, 5 = b1 (usearch_scalar_kind_t).
+__global__ void __launch_bounds__(256) k_store_quantised(const float *src, uint32_t dims, uint32_t count, int kind, uint32_t *rows, uint32_t row_words)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = (uint32_t)(t / row_words), w = (uint32_t)(t % row_words);
+    if(i >= count) return;
+    const float *f = src + (size_t)i * dims;
+    uint32_t     out = 0;
+    if(kind == 3) {  // two halves per word, low half first
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 v = { (_Float16)0.f, (_Float16)0.f };
+        if(2 * w < dims) v[ 0 ] = (_Float16)f[ 2 * w ];
+        if(2 * w + 1 < dims) v[ 1 ] = (_Float16)f[ 2 * w + 1 ];
+        out = __builtin_bit_cast(uint32_t, v);
+    } else if(kind == 4) {  // four signed bytes per word
+        for(uint32_t b = 0; b < 4; ++b) {
+            const uint32_t e = 4 * w + b;
+            int            q = 0;
+            if(e < dims) {
+                float v = f[ e ] * 100.0f;
+                if(!(v == v)) v = 0.f;
+                v = v > 100.0f ? 100.0f : v;
+                v = v < -100.0f ? -100.0f : v;
+                q = (int)v;
+            }
+            out |= ((uint32_t)q & 0xFFu) << (8 * b);
+        }
+    } else {  // 32 bits per word; byte b of the word holds elements 32 w + 8 b .. + 7, most significant bit first
+        for(uint32_t b = 0; b < 32; ++b) {
+            const uint32_t e = 32 * w + b;
+            if(e < dims && f[ e ] > 0.f) out |= (128u >> (b & 7)) << (8 * (b >> 3));
+        }
+    }
+    rows[ (size_t)i * row_words + w ] = out;
+}
 }  // namespace
+
+hipError_t launch_store_quantised(const float *src, uint32_t dims, uint32_t count, int kind, uint32_t *rows, uint32_t row_words, hipStream_t stream)
+{
+    if(count == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)count * row_words;
+    hipLaunchKernelGGL(k_store_quantised, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, stream, src, dims, count, kind, rows, row_words);
+    return hipGetLastError();
+}
 
 hipError_t launch_pq_take(const float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t s, uint32_t subdim, uint32_t sub_floats,
                           float *sub, hipStream_t stream)

@@ -570,7 +570,10 @@ static size_t run_batches(Index *ix, const uint64_t *labels, const StagedMeta &s
 
 // Insert `count` vectors whose padded rows start at `rows` (row_words 4-byte words each).  levels[i] < 0
 // means "draw with level_for()".  Returns how many were inserted (== count unless a batch failed).
-static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_in, const uint32_t *rows, size_t count, bool *ok_out)
+// raw_f32: `rows` are the caller's f32 vectors (dimensions floats each) of an index with quantised storage: they are
+// uploaded as they are and converted to stored rows on the device (a million 768-d rows cost seconds on the host).
+static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_in, const uint32_t *rows, size_t count, bool *ok_out,
+                          bool raw_f32 = false)
 {
     *ok_out = true;
     if(count == 0) return 0;
@@ -580,7 +583,19 @@ static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_i
     // node is unreachable, so its row may sit in the table before its batch runs
     StagedMeta s;
     if(!stage_meta(ix, levels_in, count, s)) return fail();
-    bool up = hipMemcpyAsync((char *)ix->d_vec + first * row_words * 4, rows, count * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    bool up = true;
+    if(raw_f32) {
+        const size_t d = ix->opts.dimensions;
+        float *tmp = nullptr;
+        up = hipMalloc((void **)&tmp, count * d * 4) == hipSuccess;
+        up = up && hipMemcpyAsync(tmp, rows, count * d * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        up = up && launch_store_quantised(tmp, (uint32_t)d, (uint32_t)count, ix->scalar, (uint32_t *)ix->d_vec + first * row_words, (uint32_t)row_words,
+                                          ix->stream) == hipSuccess;
+        up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
+        if(tmp) (void)hipFree(tmp);
+    } else {
+        up = hipMemcpyAsync((char *)ix->d_vec + first * row_words * 4, rows, count * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    }
     up = up && hipMemcpyAsync(ix->d_labels + first, labels, count * 8, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     up = up && hipMemcpyAsync(ix->d_levels + first, s.l8.data(), count, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     up = up && hipMemcpyAsync(ix->d_upper_off + first, s.uo.data(), count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
@@ -1003,6 +1018,15 @@ static void add_common(Index *ix, const usearch_label_t *labels, const void *vec
         if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
         bool ok = true;
         insert_rows(ix, labels, nullptr, (const uint32_t *)vectors, n, &ok);
+        if(!ok) FAIL(e, ix->err.c_str());
+        return;
+    }
+    if(n >= ix->add_batch_max && (int)kind == usearch_scalar_f32_k && level < 0 &&
+       (ix->scalar == usearch_scalar_f16_k || ix->scalar == usearch_scalar_i8_k || ix->b1_from_f32)) {
+        // bulk insert of f32 rows into quantised storage: one upload, the conversion runs on the device
+        if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+        bool ok = true;
+        insert_rows(ix, labels, nullptr, (const uint32_t *)vectors, n, &ok, true);
         if(!ok) FAIL(e, ix->err.c_str());
         return;
     }

@@ -125,6 +125,9 @@ hipError_t launch_pq_put(float *rows, uint32_t row_floats, uint32_t first, uint3
 hipError_t launch_pq_decode(float *rows, uint32_t row_floats, uint32_t first, uint32_t count, uint32_t subdim, uint32_t S, const float *codebook, uint32_t dims,
                             const uint8_t *codes, hipStream_t stream);
 
+// f32 rows -> the stored rows of an f16 / i8 / b1 index, on the device (the rules of pad_row, element for element)
+hipError_t launch_store_quantised(const float *src, uint32_t dims, uint32_t count, int kind, uint32_t *rows, uint32_t row_words, hipStream_t stream);
+
 // ||row||^2 of rows [first, first + count) into norm2 (cosine metrics only; no-op otherwise)
 hipError_t launch_fill_norms(int metric, const View &v, uint32_t first, uint32_t count, float *norm2, hipStream_t stream);
 // out[i] = metric(query, row(slots[i]))

@@ -178,3 +178,29 @@ def test_pq_build_through_the_indexing_server(capi):
     direct = capi.GpuIndex("l2sq", d, M=8, ef_construction=40, ef=32, seed=42, pq_codebook=cb, num_subvectors=S)
     direct.add_many(np.arange(n, dtype=np.uint64) + 1, base)
     assert direct.save_buffer() == blob
+
+
+@pytest.mark.parametrize("quant", ["f16", "i8", "b1"])
+def test_bulk_adds_quantise_on_the_device_exactly_as_single_adds_do_on_the_host(capi, quant):
+    """A bulk add uploads f32 rows and converts them on the device; usearch_add (one tuple) converts on the host.  Same rule,
+    same bits -- including denormal halves, NaN, infinities, signed zeros, the i8 clamp and values that sit on a rounding tie."""
+    rng = np.random.default_rng(5)
+    n, d = 300, 70  # 70: a ragged tail in every storage kind (35 words f16, 17.5 words i8, 2.2 words b1)
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    base[0, :12] = [0.0, -0.0, np.nan, np.inf, -np.inf, 1e-7, -1e-7, 3e-5, 65504.0, 70000.0, 1.0009765625, 0.00048828125]
+    base[1, :8] = [0.999, 1.0, 1.001, -1.0, -1.009, 0.0149, 0.015, -0.0199]  # i8: x * 100 truncates toward zero, clamps at +-100
+    base[2] = np.float32(2.0) ** rng.integers(-26, 4, size=d)  # halves from deep denormal to normal
+    base[3] *= 1e-6
+    labels = np.arange(n, dtype=np.uint64) + 1
+    bulk = capi.GpuIndex("l2sq", d, M=4, ef_construction=16, seed=1, quantization=quant)
+    bulk.set_add_batch(64, 16)
+    bulk.add_many(labels, base)  # n >= add_batch_max: the device converts
+    single = capi.GpuIndex("l2sq", d, M=4, ef_construction=16, seed=1, quantization=quant)
+    single.set_add_batch(64, 16)
+    for l, row in zip(labels, base):  # the host converts (pad_row)
+        single.add(l, row)
+    a, b = bulk.export_graph(with_vectors=True), single.export_graph(with_vectors=True)
+    assert np.array_equal(a["vectors"].view(np.uint8), b["vectors"].view(np.uint8))
+    if quant == "f16":
+        with np.errstate(over="ignore"):
+            assert np.array_equal(a["vectors"].view(np.uint16), base.astype(np.float16).view(np.uint16))
