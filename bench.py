@@ -58,7 +58,7 @@ def parse():
     p.add_argument("--truth-queries", type=int, default=1024, help="queries used for recall@k")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     p.add_argument("--no-cpu", action="store_true")
-    p.add_argument("--quant", default="f32", choices=["f32", "f16", "i8"], help="storage kind (reloption quant_bits 32 / 16 / 8); the headline config is f32")
+    p.add_argument("--quant", default="f32", choices=["f32", "f16", "i8", "b1"], help="storage kind (reloption quant_bits 32 / 16 / 8 / 1); the headline config is f32")
     p.add_argument("--dist-backend", default="rccl", choices=["rccl", "nccl", "files", "gloo"],
                    help="exchange transport of the collective build at N>1: rccl (alias nccl; xGMI, data stays in HBM) or files (alias "
                         "gloo: the host transport over the rendezvous directory -- debugging, or several ranks on one GPU)")
@@ -240,7 +240,7 @@ def main():
     qrng = np.random.default_rng(4 + 1000 * rank)
     nq = a.queries
     queries = make_queries(qrng, nq)
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False, a.quant == "f16", a.quant == "i8"))
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False, a.quant == "f16", a.quant == "i8", a.quant == "b1"))
     d_lab, d_dist, d_slot = hip.Buffer(nq * a.k * 8), hip.Buffer(nq * a.k * 4), hip.Buffer(nq * a.k * 4)
     d_D, d_E = hip.Buffer(nq * 8), hip.Buffer(nq * 8)
     stream = hip.Stream()  # the launch stream; the events below are recorded on it
@@ -272,7 +272,7 @@ def main():
     # ---- algorithmic bytes of one launch --------------------------------------------
     D = d_D.download(nq, np.uint64).astype(np.float64)
     E = d_E.download(nq, np.uint64).astype(np.float64)
-    row_bytes = a.dim * {"f32": 4, "f16": 2, "i8": 1}[a.quant]
+    row_bytes = a.dim * {"f32": 4, "f16": 2, "i8": 1, "b1": 0.125}[a.quant]
     bytes_per_launch = float((D * row_bytes + E * (2 * a.M * 4) + row_bytes).sum())
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved = bytes_per_launch / avg_kernel_s / 1e9
@@ -316,7 +316,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16": "f32 arithmetic on f16 storage", "i8": "int32 arithmetic on i8 storage"}[a.quant],
+            "dtype": {"f32": "f32", "f16": "f32 arithmetic on f16 storage", "i8": "int32 arithmetic on i8 storage", "b1": "popcount on 1-bit storage"}[a.quant],
             "data": ("synthetic" if a.data == "gaussian" else "synthetic (low-rank)") + ("" if a.data_scale == 1.0 else f" x {a.data_scale}"),
             "config": {"workload": f"HNSW search {a.n}x{a.dim} {a.quant} {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}",
                        "queries_per_step_per_gpu": nq, "global_queries_per_step": nq * world, "waves_per_query": a.waves,
@@ -349,7 +349,7 @@ def build_roofline(a, c, prof, t_build, world):
     evaluation and one adjacency row per expansion; a re-prune needs the cap+1 candidate rows and `close`'s once."""
     if not prof or not prof.get("batches"):
         return None
-    row = a.dim * {"f32": 4, "f16": 2, "i8": 1}[a.quant]
+    row = a.dim * {"f32": 4, "f16": 2, "i8": 1, "b1": 0.125}[a.quant]
     scale = 1.0 / max(world, 1)  # counters and event times are this rank's share of a collective build
     walk_bytes = c["add_walk_evals"] * row + c["add_expansions"] * (2 * a.M * 4)
     reprune_bytes = c["add_reprunes"] * (2 * a.M + 2) * row
@@ -431,7 +431,17 @@ def cpu_baseline(a, ix, base, queries, gpu_found):
         base, queries = oracle.round_f16(base), oracle.round_f16(queries)
     if a.quant == "i8":  # the quantised integers held as f32 (int32 accumulation in the port)
         base, queries, mode = oracle.quantize_i8(base), oracle.quantize_i8(queries), oracle.SUM_I8
-    ora = oracle.OracleIndex.from_graph(a.metric, base, g, a.M, a.efc, a.ef, 42, mode)
+    metric, dim = a.metric, a.dim
+    if a.quant == "b1":  # quant_bits = 1: the sign bits, Hamming arithmetic (= l2sq over {0, 1} values)
+        def pack(x):
+            bits = (x > 0).astype(np.uint8)
+            pad = (-bits.shape[1]) % 32
+            if pad:
+                bits = np.concatenate([bits, np.zeros((bits.shape[0], pad), np.uint8)], axis=1)
+            return np.ascontiguousarray(np.packbits(bits, axis=1, bitorder="big")).view(np.uint32)
+        base, queries, metric = pack(base), pack(queries), "hamming"
+        dim = base.shape[1]
+    ora = oracle.OracleIndex.from_graph(metric, base, g, a.M, a.efc, a.ef, 42, mode)
     # size the samples from a short probe so the whole leg stays near the budget (about 30 % of it
     # for the 1-thread leg, 70 % for the all-cores leg).  The all-cores sample cycles through the
     # step's query set: 256 threads need >10^5 queries to reach steady state (each thread first
@@ -460,7 +470,7 @@ def cpu_baseline(a, ix, base, queries, gpu_found):
     # index build on the CPU: the port's sequential usearch_add (a PostgreSQL backend builds with one thread,
     # utils.c:66) on a bounded prefix of the same rows.  The rate falls as the graph grows, so this flatters the CPU.
     nb = int(min(base.shape[0], 4096))
-    cb = oracle.OracleIndex(a.metric, a.dim, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, sum_mode=mode)
+    cb = oracle.OracleIndex(metric, dim, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, sum_mode=mode)
     t0 = time.perf_counter()
     cb.add_many(np.arange(nb, dtype=np.uint64) + 1, base[:nb])
     cpu_build = nb / (time.perf_counter() - t0)

@@ -122,10 +122,19 @@ class Event:
         return float(ms.value)
 
 
-def padded_rows(x: np.ndarray, metric_is_hamming: bool, f16: bool = False, i8: bool = False) -> np.ndarray:
+def padded_rows(x: np.ndarray, metric_is_hamming: bool, f16: bool = False, i8: bool = False, b1: bool = False) -> np.ndarray:
     """Rows in STORAGE format, zero-padded to whole 16-byte chunks: the layout the device entry points expect
     (u32 words for hamming, f32, halves for an f16 index: the cast is round-to-nearest-even, or bytes for an i8
     index: trunc(clamp(x * 100, -100, 100)), the library's own rule for f32 input)."""
+    if b1:  # quant_bits = 1: bit i = (x_i > 0), most significant bit of each byte first, rows padded to 16 bytes
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        if a.ndim == 1:
+            a = a.reshape(1, -1)
+        bits = (a > 0).astype(np.uint8)
+        pad = (-bits.shape[1]) % 128
+        if pad:
+            bits = np.concatenate([bits, np.zeros((bits.shape[0], pad), np.uint8)], axis=1)
+        return np.packbits(bits, axis=1, bitorder="big")
     if i8:
         a = np.ascontiguousarray(x, dtype=np.float32)
         if a.ndim == 1:

@@ -5,7 +5,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/r02
-rm -rf "$OUT"; mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT/bench" "$OUT/gather"
 ARGS="--no-cpu --steps 5 --warmup 2"
 # ---- headline bench: kernel trace, then FETCH / WRITE / L2 passes (each its own run)
 timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/bench/trace" -o trace -- python bench.py $ARGS > "$OUT/bench/bench_trace.json" 2> "$OUT/bench_trace.log"
@@ -31,4 +31,6 @@ python scripts/profile_hop_phases.py > "$OUT/r02_hop_phases.json" 2>/dev/null
 python scripts/bench_configs.py > "$OUT/r02_configs.jsonl" 2>/dev/null
 python scripts/bench_scan_server.py > "$OUT/r02_scan_server_100kx128.json" 2>/dev/null
 python bench.py --gpus 2 --dist-backend files --no-cpu --rows 500000 --steps 10 > "$OUT/r02_bench_line_2ranks_one_gpu_files.json" 2>/dev/null
+python bench.py --no-cpu --quant b1 > "$OUT/r02_bench_line_b1.json" 2>/dev/null
+timeout 900 python bench.py --rows 10000000 --ef 128 --steps 5 --no-cpu --truth-queries 256 > "$OUT/r02_bench_line_10Mx768_ef128.json" 2>/dev/null
 ls -la "$OUT"
