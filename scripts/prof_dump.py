@@ -19,7 +19,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         if rows:
             print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
             for name, calls, total, avg, pct in rows:
-                print(f"| `{name[:90]}` | {calls} | {total / 1e6:.3f} | {avg / 1e3:.1f} | {pct:.2f} |")
+                print(f"| `{name[:90]}` | {calls} | {total / 1e3:.3f} | {avg:.1f} | {pct:.2f} |")  # rocpd's top_kernels view is in microseconds
     if "counters_collection" in tables:
         q = "select kernel_name,counter_name,count(*),avg(value),sum(value) from counters_collection where kernel_name like ? group by kernel_name,counter_name"
         last = None
