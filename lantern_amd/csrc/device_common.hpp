@@ -392,6 +392,25 @@ __device__ __forceinline__ void group_dist2_n(PA a, PB b0, PB b1, int chunks, in
     d1 = acc1.template finish_n<G>(a2, b2_1);
 }
 
+// R rows against the same `a` at once (R x the loads in flight per lane): the small-batch shape of the walk, where a CU
+// holds fewer workgroups and each must keep more bytes in flight.  Every row's chain and tree are those of group_dist_n.
+template <int METRIC, int G, int R, typename PA, typename PB>
+__device__ __forceinline__ void group_distR_n(PA a, const PB (&b)[ R ], int chunks, int gl, float a2, const float (&b2)[ R ], float (&d)[ R ])
+{
+    RowAcc<METRIC> acc[ R ];
+#pragma unroll 2
+    for(int ch = gl; ch < chunks; ch += G) {
+        uint4 x = a[ ch ];
+        uint4 y[ R ];
+#pragma unroll
+        for(int r = 0; r < R; ++r) y[ r ] = b[ r ][ ch ];
+#pragma unroll
+        for(int r = 0; r < R; ++r) acc[ r ].add(x, y[ r ]);
+    }
+#pragma unroll
+    for(int r = 0; r < R; ++r) d[ r ] = acc[ r ].template finish_n<G>(a2, b2[ r ]);
+}
+
 // lanes per row for a row of `chunks` 16-byte chunks (oracle: lo_wave_group_lanes)
 // Every lane should own at least two chunks (two 16-byte loads in flight per row per lane), so short rows are
 // shared by fewer lanes and a wave works on several rows at once: G = 64 from 128 chunks (d >= 512 f32 /

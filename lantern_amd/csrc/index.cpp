@@ -732,6 +732,9 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.totals = ix->d_totals;
     a.ticket = next_ticket(ix, nq, grid, stream);
     a.phase_cycles = ix->phase_profile ? ix->d_totals + 8 : nullptr;
+    // small batch (at most four 4-wave workgroups per CU would be resident anyway): four rows in flight per group
+    static const int wide_env = std::getenv("LANTERN_GPU_WIDE_ROWS") ? std::atoi(std::getenv("LANTERN_GPU_WIDE_ROWS")) : -1;
+    a.wide_rows = wide_env >= 0 ? wide_env : (nq * (size_t)waves <= (size_t)ix->num_cus * 16 && nq >= 64);
     if(!order_launch(ix, stream)) return false;
     HIPCHK(ix, launch_search(ix->mcode, a, waves, grid, stream));
     if(!record_launch(ix, stream)) return false;

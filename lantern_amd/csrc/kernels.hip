@@ -33,8 +33,11 @@ namespace lgpu {
 extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
 
 // ---------------------------------------------------------------------------------------------------
-template <int METRIC, int G, bool PROF = false>
-__global__ void __launch_bounds__(512, 6) k_search(SearchArgs a)  // <= 80 VGPRs: six waves per SIMD, six 4-wave workgroups per CU
+// ROWS = 4 is the SMALL-BATCH shape: when the batch cannot fill six workgroups per CU anyway (<= four 4-wave workgroups per
+// CU), every workgroup keeps four rows per group in flight instead of two and may use 128 VGPRs (four waves per SIMD): a
+// CU's fetch rate is set by the bytes it has in flight, and at 1024 queries x 768-d the two-row shape left it at ~60 %.
+template <int METRIC, int G, bool PROF = false, int ROWS = 2>
+__global__ void __launch_bounds__(512, ROWS == 2 ? 6 : 4) k_search(SearchArgs a)  // ROWS 2: <= 80 VGPRs, six 4-wave workgroups per CU
 {
     const int tid = threadIdx.x, T = blockDim.x;
     WalkLds   s;
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(512, 6) k_search(SearchArgs a)  // <= 80 VGPRs
         if(a.view.n != 0) {
             uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
             if constexpr(PROF) pc[ 6 ] = (unsigned long long)clock64() - t_q;
-            cnt = search_level<METRIC, G, PROF>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
+            cnt = search_level<METRIC, G, PROF, ROWS>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
         }
         if constexpr(PROF) {
             if(tid == 0 && a.phase_cycles) {
@@ -1537,6 +1540,23 @@ hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, h
     {                                                                                                         \
         (void)hipFuncSetAttribute((const void *)k_search<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_search<MM, GG>), dim3(grid), dim3(64 * waves), lds, stream, a);                 \
+    }
+    if(a.wide_rows && !a.phase_cycles && group_lanes_for(a.view.chunks) == 64) {  // the small-batch shape (rows of >= 128 chunks)
+#define WCALL(MM)                                                                                                  \
+    {                                                                                                              \
+        (void)hipFuncSetAttribute((const void *)k_search<MM, 64, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_search<MM, 64, false, 4>), dim3(grid), dim3(64 * waves), lds, stream, a);            \
+    }
+        switch(metric) {
+            case M_L2SQ: WCALL(M_L2SQ); break;
+            case M_COS: WCALL(M_COS); break;
+            case M_HAMMING: WCALL(M_HAMMING); break;
+            case M_L2SQ_F16: WCALL(M_L2SQ_F16); break;
+            case M_COS_F16: WCALL(M_COS_F16); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef WCALL
+        return hipGetLastError();
     }
     if(a.phase_cycles) {  // diagnostic instantiations: the f32 metrics at the two common row shapes
         const int G_ = group_lanes_for(a.view.chunks);

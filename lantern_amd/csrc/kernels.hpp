@@ -26,6 +26,7 @@ struct SearchArgs
     unsigned long long *totals;  // [2] cumulative D, E (atomicAdd) or NULL
     uint32_t       *ticket;      // zeroed before the launch: queries beyond the first gridDim.x are handed out dynamically
                                  // (NULL = static striding); results do not depend on who runs a query
+    int             wide_rows;   // small batch: the four-rows-in-flight instantiation (k_search<.., ROWS = 4>)
     unsigned long long *phase_cycles;  // diagnostics (lantern_gpu_search_phase_profile): [8] shader-clock cycles summed over the
 };                               // launch's queries by phase: pop | list + visited | distances | merge | descent | whole query
 

@@ -221,7 +221,7 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
 // PROF (diagnostic instantiations only): thread 0 accumulates shader-clock cycles per phase into prof[0..6): [4] pop, [5] the
 // neighbour list's arrival, [0] visited filter + compaction (together: wave 0's section) | [1] wait at the first barrier |
 // [2] distances | [3] merge.
-template <int METRIC, int G, bool PROF = false>
+template <int METRIC, int G, bool PROF = false, int ROWS = 2>
 __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int level, int ef,
                             uint32_t &D, uint32_t &E, unsigned long long *prof = nullptr)
 {
@@ -323,8 +323,36 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         LGPU_MARK(1)
         if(nnew < 0) break;
         if(nnew == 0) continue;
-        // ---- (2) distances: one G-lane group per row, two rows in flight per group
+        // ---- (2) distances: one G-lane group per row, two rows in flight per group (ROWS = 4: the small-batch shape)
         const uint64_t worst = cnt == ef ? s.keys[ cnt - 1 ] : ~0ull;
+        if constexpr(ROWS > 2) {
+            for(int i = g; i < nnew; i += ROWS * NG) {
+                const uint4 *rows[ ROWS ];
+                uint32_t     ids[ ROWS ];
+                float        n2[ ROWS ], d[ ROWS ];
+#pragma unroll
+                for(int r = 0; r < ROWS; ++r) {
+                    const int j = i + r * NG;
+                    ids[ r ] = s.newids[ j < nnew ? j : i ];
+                    rows[ r ] = row_of(v, ids[ r ]);
+                    n2[ r ] = row_norm<METRIC>(v, ids[ r ]);
+                }
+                group_distR_n<METRIC, G, ROWS>(s.q, rows, (int)v.chunks, gl, qn2, n2, d);
+                if(gl == G - 1) {
+                    bool any = false;
+#pragma unroll
+                    for(int r = 0; r < ROWS; ++r) {
+                        const int j = i + r * NG;
+                        if(j < nnew) {
+                            const uint64_t k = make_key(d[ r ], ids[ r ]);
+                            s.newkeys[ j ] = k;
+                            any |= k < worst;
+                        }
+                    }
+                    if(any) *any_slot = 1;
+                }
+            }
+        } else
         for(int i = g; i < nnew; i += 2 * NG) {
             const int      j = i + NG;
             const uint32_t id0 = s.newids[ i ];
