@@ -307,7 +307,22 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                         LGPU_MARK(5)
                     }
                     bool           isnew = false;
-                    if(nb != EMPTY) isnew = !visit_test_and_set(s, bitmap, nb, spilled);
+                    if(s.vis_slots && !spilled) {
+                        // the common case as straight-line code: one CAS at the home slot settles almost every lane (the set
+                        // is at most 3/4 full, usually far less); only lanes that met ANOTHER slot's key take the probing loop
+                        // (its divergent control flow costs more scalar instructions than the CAS itself)
+                        const bool     valid = nb != EMPTY;
+                        const uint32_t h = vis_hash(valid ? nb : 0u, s.vis_slots);
+                        uint32_t       cur = nb;
+                        if(valid) cur = atomicCAS(&s.vis[ h ], EMPTY, nb);
+                        isnew = valid && cur == EMPTY;
+                        const bool unsettled = valid && cur != EMPTY && cur != nb;
+                        if(__ballot(unsettled) != 0ull) {
+                            if(unsettled) isnew = !visit_test_and_set(s, bitmap, nb, false);
+                        }
+                    } else if(nb != EMPTY) {
+                        isnew = !visit_test_and_set(s, bitmap, nb, spilled);
+                    }
                     const unsigned long long m = __ballot(isnew);
                     if(isnew) s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
                     nb_new += __popcll(m);

@@ -59,7 +59,8 @@ def main():
     n = int(os.environ.get("ROWS768", "300000"))
     base = np.random.default_rng(3).standard_normal((n, 768), dtype=np.float32)
     q = np.random.default_rng(4).standard_normal((8192, 768), dtype=np.float32)
-    ix = capi.GpuIndex("l2sq", 768, M=16, ef_construction=128, ef=64, seed=42)
+    metric = os.environ.get("METRIC768", "l2sq")
+    ix = capi.GpuIndex(metric, 768, M=16, ef_construction=128, ef=64, seed=42)
     ix.reserve(n)
     ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
     ix.flush()
