@@ -22,6 +22,13 @@ static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, si
 
 namespace lgpu {
 
+// LANTERN_GPU_LDS_LIST=1: walks keep their candidate list in LDS even when it fits wave 0's registers (walk.hpp search_level vs
+// search_level_reg; identical results -- the switch exists for A/B timing and for the parity test that runs both)
+static int lds_list_env()
+{
+    const char *e = std::getenv("LANTERN_GPU_LDS_LIST");
+    return e && std::atoi(e) != 0;
+}
 static const char *kNoDevice = "lantern_gpu: no HIP device available (this library has no CPU fallback)";
 
 const char *set_err(Index *ix, const std::string &msg)
@@ -394,6 +401,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     ia.top_count = d_top_count;
     ia.bitmaps = ix->d_bitmaps;
     ia.bm_words = (uint32_t)ix->bm_words;
+    ia.lds_list = lds_list_env();
     // LDS visited set for the ef_construction-wide walk (spills to the bitmap when 3/4 full); env override for tuning
     // the largest table that still lets FIVE workgroups share a CU (160 KB / 5, minus the walk's lists): 6400 slots at
     // 768-d / efc 128, enough for the ~3700 nodes such a walk visits at the 3/4 load limit
@@ -732,6 +740,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.totals = ix->d_totals;
     a.ticket = next_ticket(ix, nq, grid, stream);
     a.phase_cycles = ix->phase_profile ? ix->d_totals + 8 : nullptr;
+    a.lds_list = lds_list_env();
     // small batch (at most four 4-wave workgroups per CU would be resident anyway): four rows in flight per group
     static const int wide_env = std::getenv("LANTERN_GPU_WIDE_ROWS") ? std::atoi(std::getenv("LANTERN_GPU_WIDE_ROWS")) : -1;
     a.wide_rows = wide_env >= 0 ? wide_env : (nq * (size_t)waves <= (size_t)ix->num_cus * 16 && nq >= 64);

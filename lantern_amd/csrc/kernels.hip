@@ -27,135 +27,11 @@
 
 #include "kernels.hpp"
 #include "walk.hpp"
+#include "dispatch.hpp"
 
 namespace lgpu {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
-
-// ---------------------------------------------------------------------------------------------------
-// ROWS = 4 is the SMALL-BATCH shape: when the batch cannot fill six workgroups per CU anyway (<= four 4-wave workgroups per
-// CU), every workgroup keeps four rows per group in flight instead of two and may use 128 VGPRs (four waves per SIMD): a
-// CU's fetch rate is set by the bytes it has in flight, and at 1024 queries x 768-d the two-row shape left it at ~60 %.
-template <int METRIC, int G, bool PROF = false, int ROWS = 2>
-__global__ void __launch_bounds__(512, ROWS == 2 ? 6 : 4) k_search(SearchArgs a)  // ROWS 2: <= 80 VGPRs, six 4-wave workgroups per CU
-{
-    const int tid = threadIdx.x, T = blockDim.x;
-    WalkLds   s;
-    carve_walk(lgpu_smem, s, a.view.chunks, a.ef, a.view.M0, a.vis_slots);
-    uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
-    const uint32_t chunks = a.view.chunks;
-    for(uint32_t q = blockIdx.x; q < a.nq;) {
-        for(uint32_t i = tid; i < chunks; i += T) s.q[ i ] = a.queries[ (size_t)q * chunks + i ];
-        __syncthreads();
-        if(kCachedNorms<METRIC>) {  // ||query||^2 once per query, by the chain Acc<M_COS> would run for every row
-            if(tid < G) {
-                const float qn = group_norm<METRIC, G>(s.q, (int)chunks, tid);
-                if(tid == G - 1) s.scal[ S_QN2 ] = __float_as_int(qn);
-            }
-            __syncthreads();
-        }
-        uint32_t D = 0, E = 0;
-        int      cnt = 0;
-        unsigned long long pc[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_q = 0;
-        if constexpr(PROF) t_q = (unsigned long long)clock64();
-        if(a.view.n != 0) {
-            uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
-            if constexpr(PROF) pc[ 6 ] = (unsigned long long)clock64() - t_q;
-            cnt = search_level<METRIC, G, PROF, ROWS>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
-        }
-        if constexpr(PROF) {
-            if(tid == 0 && a.phase_cycles) {
-                pc[ 7 ] = (unsigned long long)clock64() - t_q;
-                for(int i = 0; i < 8; ++i) atomicAdd(&a.phase_cycles[ i ], pc[ i ]);
-            }
-        }
-        int got = cnt - (int)a.skip;
-        got = got < 0 ? 0 : (got > (int)a.k ? (int)a.k : got);
-        for(uint32_t i = tid; i < a.k; i += T) {
-            const size_t o = (size_t)q * a.k + i;
-            if((int)i < got) {
-                const uint64_t key = s.keys[ a.skip + i ];
-                const uint32_t slot = key_slot(key);
-                if(a.out_labels) a.out_labels[ o ] = a.labels[ slot ];
-                if(a.out_dists) a.out_dists[ o ] = key_dist(key);
-                if(a.out_slots) a.out_slots[ o ] = slot;
-            } else {
-                if(a.out_labels) a.out_labels[ o ] = 0;  // INVALID_ELEMENT_LABEL (hnsw.h:40)
-                if(a.out_dists) a.out_dists[ o ] = __builtin_inff();
-                if(a.out_slots) a.out_slots[ o ] = EMPTY;
-            }
-        }
-        if(tid == 0) {
-            if(a.out_counts) a.out_counts[ q ] = (uint32_t)got;
-            if(a.out_D) a.out_D[ q ] = D;
-            if(a.out_E) a.out_E[ q ] = E;
-            if(a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)D); atomicAdd(&a.totals[ 1 ], (unsigned long long)E); }
-            // next query: a ticket (walks differ in length by 2x; static striding leaves workgroups idle at the end)
-            s.scal[ S_POS ] = a.ticket ? (int)(gridDim.x + atomicAdd(a.ticket, 1u)) : (int)(q + gridDim.x);
-        }
-        __syncthreads();
-        q = (uint32_t)s.scal[ S_POS ];
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// k_insert: the WALK half of an insertion.  Per new vector: descent to its level, then per level an
-// ef_construction-wide search_level whose sorted result (<= efc keys) goes to HBM for k_connect.  The start of
-// the next lower level is connect_new_node_'s first pick: the closest result under (distance, tie_mix).
-template <int METRIC, int G>
-__global__ void __launch_bounds__(512, 6) k_insert(InsertArgs a)
-{
-    const int tid = threadIdx.x, T = blockDim.x;
-    WalkLds   s;
-    carve_walk(lgpu_smem, s, a.view.chunks, a.efc, a.view.M0, a.vis_slots);
-    uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
-    const uint32_t chunks = a.view.chunks, M = a.view.M;
-    for(uint32_t b = a.b_begin + blockIdx.x; b < a.count;) {
-        const uint32_t me = a.first_slot + b;
-        const int      target = a.view.levels[ me ];
-        const uint32_t item0 = a.link_off[ b ] / M;  // one item per (node, level)
-        {
-            const uint4 *own = row_of(a.view, me);
-            for(uint32_t i = tid; i < chunks; i += T) s.q[ i ] = own[ i ];
-            for(uint32_t i = tid; i <= (uint32_t)target; i += T) a.top_count[ item0 + i ] = 0;  // levels above max_level stay empty
-            if(tid == 0) s.scal[ S_QN2 ] = __float_as_int(row_norm<METRIC>(a.view, me));     // the "query" is a stored row
-        }
-        __syncthreads();
-        uint32_t D = 0, E = 0;
-        uint32_t cur = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, target, D);
-        for(int level = target < a.view.max_level ? target : a.view.max_level; level >= 0; --level) {
-            const int cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, cur, level, (int)a.efc, D, E);
-            uint64_t *top = a.tops + (size_t)(item0 + (uint32_t)level) * a.efc;
-            for(int i = tid; i < cnt; i += T) top[ i ] = s.keys[ i ] & ~1ull;  // drop the "expanded" bit
-            if(tid == 0) {
-                a.top_count[ item0 + (uint32_t)level ] = (uint32_t)cnt;
-                // sel[0] of the heuristic = minimum by (distance, tie_mix(slot, me)): only an exact tie at the
-                // smallest distance can differ from keys[0]
-                const uint32_t d0 = (uint32_t)(s.keys[ 0 ] >> 32);
-                uint32_t       best = key_slot(s.keys[ 0 ]);
-                for(int i = 1; i < cnt && (uint32_t)(s.keys[ i ] >> 32) == d0; ++i) {
-                    const uint32_t id = key_slot(s.keys[ i ]);
-                    if(tie_mix(id, me) < tie_mix(best, me)) best = id;
-                }
-                s.scal[ S_CUR ] = (int)best;
-            }
-            __syncthreads();
-            cur = (uint32_t)s.scal[ S_CUR ];
-            __syncthreads();
-        }
-        if(tid == 0) {
-            if(a.totals) {
-                atomicAdd(&a.totals[ 0 ], (unsigned long long)D);
-                atomicAdd(&a.totals[ 1 ], (unsigned long long)E);
-            }
-            s.scal[ S_POS ] = a.ticket ? (int)(a.b_begin + gridDim.x + atomicAdd(a.ticket, 1u)) : (int)(b + gridDim.x);
-        }
-        __syncthreads();
-        b = (uint32_t)s.scal[ S_POS ];
-        __syncthreads();
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // k_connect: connect_new_node_ -- the neighbour-selection heuristic over one walk result, one workgroup of four
@@ -1490,104 +1366,6 @@ __global__ void __launch_bounds__(256) k_pairs(const uint4 *a, uint32_t na, cons
         float d = group_dist<METRIC, G>(a + (size_t)i * chunks, b + (size_t)j * chunks, (int)chunks, (int)gl);
         if(gl == G - 1) out[ p ] = d;
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// dispatch on (metric, lanes per row)
-#define LGPU_DISPATCH(metric, chunks, CALL)                                   \
-    do {                                                                      \
-        const int G_ = group_lanes_for(chunks);                               \
-        switch(metric) {                                                      \
-            case M_L2SQ:                                                      \
-                switch(G_) { case 64: CALL(M_L2SQ, 64); break; case 32: CALL(M_L2SQ, 32); break; \
-                             case 16: CALL(M_L2SQ, 16); break; default: CALL(M_L2SQ, 8); }       \
-                break;                                                        \
-            case M_COS:                                                       \
-                switch(G_) { case 64: CALL(M_COS, 64); break; case 32: CALL(M_COS, 32); break;   \
-                             case 16: CALL(M_COS, 16); break; default: CALL(M_COS, 8); }         \
-                break;                                                        \
-            case M_HAMMING:                                                   \
-                switch(G_) { case 64: CALL(M_HAMMING, 64); break; case 32: CALL(M_HAMMING, 32); break; \
-                             case 16: CALL(M_HAMMING, 16); break; default: CALL(M_HAMMING, 8); } \
-                break;                                                        \
-            case M_L2SQ_F16:                                                  \
-                switch(G_) { case 64: CALL(M_L2SQ_F16, 64); break; case 32: CALL(M_L2SQ_F16, 32); break; \
-                             case 16: CALL(M_L2SQ_F16, 16); break; default: CALL(M_L2SQ_F16, 8); } \
-                break;                                                        \
-            case M_COS_F16:                                                   \
-                switch(G_) { case 64: CALL(M_COS_F16, 64); break; case 32: CALL(M_COS_F16, 32); break; \
-                             case 16: CALL(M_COS_F16, 16); break; default: CALL(M_COS_F16, 8); } \
-                break;                                                        \
-            case M_L2SQ_I8:                                                   \
-                switch(G_) { case 64: CALL(M_L2SQ_I8, 64); break; case 32: CALL(M_L2SQ_I8, 32); break; \
-                             case 16: CALL(M_L2SQ_I8, 16); break; default: CALL(M_L2SQ_I8, 8); } \
-                break;                                                        \
-            case M_COS_I8:                                                    \
-                switch(G_) { case 64: CALL(M_COS_I8, 64); break; case 32: CALL(M_COS_I8, 32); break; \
-                             case 16: CALL(M_COS_I8, 16); break; default: CALL(M_COS_I8, 8); } \
-                break;                                                        \
-            default: return hipErrorInvalidValue;                             \
-        }                                                                     \
-    } while(0)
-
-size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots) { return walk_lds_bytes(chunks, ef_cap, M0, vis_slots); }
-size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0, uint32_t vis_slots) { return walk_lds_bytes(chunks, efc, M0, vis_slots); }
-
-hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream)
-{
-    const size_t lds = search_lds_bytes(a.view.chunks, a.ef, a.view.M0, a.vis_slots);
-#define CALL(MM, GG)                                                                                          \
-    {                                                                                                         \
-        (void)hipFuncSetAttribute((const void *)k_search<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_search<MM, GG>), dim3(grid), dim3(64 * waves), lds, stream, a);                 \
-    }
-    if(a.wide_rows && !a.phase_cycles && group_lanes_for(a.view.chunks) == 64) {  // the small-batch shape (rows of >= 128 chunks)
-#define WCALL(MM)                                                                                                  \
-    {                                                                                                              \
-        (void)hipFuncSetAttribute((const void *)k_search<MM, 64, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_search<MM, 64, false, 4>), dim3(grid), dim3(64 * waves), lds, stream, a);            \
-    }
-        switch(metric) {
-            case M_L2SQ: WCALL(M_L2SQ); break;
-            case M_COS: WCALL(M_COS); break;
-            case M_HAMMING: WCALL(M_HAMMING); break;
-            case M_L2SQ_F16: WCALL(M_L2SQ_F16); break;
-            case M_COS_F16: WCALL(M_COS_F16); break;
-            default: return hipErrorInvalidValue;
-        }
-#undef WCALL
-        return hipGetLastError();
-    }
-    if(a.phase_cycles) {  // diagnostic instantiations: the f32 metrics at the two common row shapes
-        const int G_ = group_lanes_for(a.view.chunks);
-#define PCALL(MM, GG)                                                                                              \
-    {                                                                                                              \
-        (void)hipFuncSetAttribute((const void *)k_search<MM, GG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_search<MM, GG, true>), dim3(grid), dim3(64 * waves), lds, stream, a);                \
-    }
-        if(metric == M_L2SQ && G_ == 64) PCALL(M_L2SQ, 64)
-        else if(metric == M_L2SQ && G_ == 16) PCALL(M_L2SQ, 16)
-        else if(metric == M_COS && G_ == 64) PCALL(M_COS, 64)
-        else return hipErrorInvalidValue;
-#undef PCALL
-        return hipGetLastError();
-    }
-    LGPU_DISPATCH(metric, a.view.chunks, CALL);
-#undef CALL
-    return hipGetLastError();
-}
-
-hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream)
-{
-    const size_t lds = insert_lds_bytes(a.view.chunks, a.efc, a.view.M0, a.vis_slots);
-#define CALL(MM, GG)                                                                                          \
-    {                                                                                                         \
-        (void)hipFuncSetAttribute((const void *)k_insert<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_insert<MM, GG>), dim3(grid), dim3(64 * waves), lds, stream, a);                 \
-    }
-    LGPU_DISPATCH(metric, a.view.chunks, CALL);
-#undef CALL
-    return hipGetLastError();
 }
 
 size_t connect_lds_bytes(uint32_t efc, uint32_t M) { return refine_lds_bytes(efc) + S_SCALARS * 4 + (size_t)((M + 3) & ~3u) * 8; }

@@ -26,6 +26,8 @@ struct SearchArgs
     unsigned long long *totals;  // [2] cumulative D, E (atomicAdd) or NULL
     uint32_t       *ticket;      // zeroed before the launch: queries beyond the first gridDim.x are handed out dynamically
                                  // (NULL = static striding); results do not depend on who runs a query
+    int             lds_list;    // keep the candidate list in LDS even when it fits wave 0's registers (LANTERN_GPU_LDS_LIST=1: the
+                                 // round-1 walk, kept for A/B parity runs and for ef > 128)
     int             wide_rows;   // small batch: the four-rows-in-flight instantiation (k_search<.., ROWS = 4>)
     unsigned long long *phase_cycles;  // diagnostics (lantern_gpu_search_phase_profile): [8] shader-clock cycles summed over the
 };                               // launch's queries by phase: pop | list + visited | distances | merge | descent | whole query
@@ -54,6 +56,7 @@ struct InsertArgs
     uint32_t        vis_slots;   // LDS visited-set slots (0 = HBM bitmap only)
     unsigned long long *totals;  // [2] cumulative D, E
     uint32_t       *ticket;      // as SearchArgs::ticket, over the batch members
+    int             lds_list;    // as SearchArgs::lds_list
 };
 
 // neighbour selection of the new nodes: one item per (new node, level)

@@ -1,0 +1,149 @@
+// search_kernel.hip -- k_search: usearch_search_ef (lantern_hnsw/src/hnsw/scan.c:220-228, 273-281).  One workgroup per query,
+// persistent over the batch (work handed out by ticket); greedy descent + ef-bounded base-layer walk (walk.hpp).  Its own
+// translation unit: the instantiations (metric x lanes per row x list placement x rows in flight) compile in parallel with
+// the build-side kernels.
+#include <algorithm>
+#include <cstdlib>
+
+#include "kernels.hpp"
+#include "walk.hpp"
+#include "dispatch.hpp"
+
+namespace lgpu {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
+
+// ---------------------------------------------------------------------------------------------------
+// ROWS = 4 is the SMALL-BATCH shape: when the batch cannot fill six workgroups per CU anyway (<= four 4-wave workgroups per
+// CU), every workgroup keeps four rows per group in flight instead of two and may use 128 VGPRs (four waves per SIMD): a
+// CU's fetch rate is set by the bytes it has in flight, and at 1024 queries x 768-d the two-row shape left it at ~60 %.
+template <int METRIC, int G, bool PROF = false, int ROWS = 2, bool REG = true>
+__global__ void __launch_bounds__(512, ROWS == 2 ? 6 : 4) k_search(SearchArgs a)  // ROWS 2: <= 80 VGPRs, six 4-wave workgroups per CU
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    WalkLds   s;
+    carve_walk(lgpu_smem, s, a.view.chunks, a.ef, a.view.M0, a.vis_slots);
+    uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
+    const uint32_t chunks = a.view.chunks;
+    for(uint32_t q = blockIdx.x; q < a.nq;) {
+        for(uint32_t i = tid; i < chunks; i += T) s.q[ i ] = a.queries[ (size_t)q * chunks + i ];
+        __syncthreads();
+        if(kCachedNorms<METRIC>) {  // ||query||^2 once per query, by the chain Acc<M_COS> would run for every row
+            if(tid < G) {
+                const float qn = group_norm<METRIC, G>(s.q, (int)chunks, tid);
+                if(tid == G - 1) s.scal[ S_QN2 ] = __float_as_int(qn);
+            }
+            __syncthreads();
+        }
+        uint32_t D = 0, E = 0;
+        int      cnt = 0;
+        unsigned long long pc[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_q = 0;
+        if constexpr(PROF) t_q = (unsigned long long)clock64();
+        if(a.view.n != 0) {
+            uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
+            if constexpr(PROF) pc[ 6 ] = (unsigned long long)clock64() - t_q;
+            // REG: the candidate list lives in wave 0's registers (ef <= 128, the usual case); in LDS otherwise
+            if constexpr(REG)
+                cnt = search_level_reg<METRIC, G, 2, PROF, ROWS>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
+            else
+                cnt = search_level<METRIC, G, PROF, ROWS>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
+        }
+        if constexpr(PROF) {
+            if(tid == 0 && a.phase_cycles) {
+                pc[ 7 ] = (unsigned long long)clock64() - t_q;
+                for(int i = 0; i < 8; ++i) atomicAdd(&a.phase_cycles[ i ], pc[ i ]);
+            }
+        }
+        int got = cnt - (int)a.skip;
+        got = got < 0 ? 0 : (got > (int)a.k ? (int)a.k : got);
+        for(uint32_t i = tid; i < a.k; i += T) {
+            const size_t o = (size_t)q * a.k + i;
+            if((int)i < got) {
+                const uint64_t key = s.keys[ a.skip + i ];
+                const uint32_t slot = key_slot(key);
+                if(a.out_labels) a.out_labels[ o ] = a.labels[ slot ];
+                if(a.out_dists) a.out_dists[ o ] = key_dist(key);
+                if(a.out_slots) a.out_slots[ o ] = slot;
+            } else {
+                if(a.out_labels) a.out_labels[ o ] = 0;  // INVALID_ELEMENT_LABEL (hnsw.h:40)
+                if(a.out_dists) a.out_dists[ o ] = __builtin_inff();
+                if(a.out_slots) a.out_slots[ o ] = EMPTY;
+            }
+        }
+        if(tid == 0) {
+            if(a.out_counts) a.out_counts[ q ] = (uint32_t)got;
+            if(a.out_D) a.out_D[ q ] = D;
+            if(a.out_E) a.out_E[ q ] = E;
+            if(a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)D); atomicAdd(&a.totals[ 1 ], (unsigned long long)E); }
+            // next query: a ticket (walks differ in length by 2x; static striding leaves workgroups idle at the end)
+            s.scal[ S_POS ] = a.ticket ? (int)(gridDim.x + atomicAdd(a.ticket, 1u)) : (int)(q + gridDim.x);
+        }
+        __syncthreads();
+        q = (uint32_t)s.scal[ S_POS ];
+        __syncthreads();
+    }
+}
+
+size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots) { return walk_lds_bytes(chunks, ef_cap, M0, vis_slots); }
+hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream)
+{
+    const size_t lds = search_lds_bytes(a.view.chunks, a.ef, a.view.M0, a.vis_slots);
+    const bool   reg = a.ef <= 128 && !a.lds_list;  // walk.hpp search_level_reg
+#define CALL(MM, GG)                                                                                          \
+    {                                                                                                         \
+        if(reg) {                                                                                             \
+            (void)hipFuncSetAttribute((const void *)k_search<MM, GG, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_search<MM, GG, false, 2, true>), dim3(grid), dim3(64 * waves), lds, stream, a); \
+        } else {                                                                                              \
+            (void)hipFuncSetAttribute((const void *)k_search<MM, GG, false, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_search<MM, GG, false, 2, false>), dim3(grid), dim3(64 * waves), lds, stream, a); \
+        }                                                                                                     \
+    }
+    if(a.wide_rows && !a.phase_cycles && group_lanes_for(a.view.chunks) == 64) {  // the small-batch shape (rows of >= 128 chunks)
+#define WCALL(MM)                                                                                                  \
+    {                                                                                                              \
+        if(reg) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void *)k_search<MM, 64, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_search<MM, 64, false, 4, true>), dim3(grid), dim3(64 * waves), lds, stream, a);  \
+        } else {                                                                                                   \
+            (void)hipFuncSetAttribute((const void *)k_search<MM, 64, false, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_search<MM, 64, false, 4, false>), dim3(grid), dim3(64 * waves), lds, stream, a); \
+        }                                                                                                          \
+    }
+        switch(metric) {
+            case M_L2SQ: WCALL(M_L2SQ); break;
+            case M_COS: WCALL(M_COS); break;
+            case M_HAMMING: WCALL(M_HAMMING); break;
+            case M_L2SQ_F16: WCALL(M_L2SQ_F16); break;
+            case M_COS_F16: WCALL(M_COS_F16); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef WCALL
+        return hipGetLastError();
+    }
+    if(a.phase_cycles) {  // diagnostic instantiations: the f32 metrics at the two common row shapes
+        const int G_ = group_lanes_for(a.view.chunks);
+#define PCALL(MM, GG)                                                                                              \
+    {                                                                                                              \
+        if(reg) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void *)k_search<MM, GG, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_search<MM, GG, true, 2, true>), dim3(grid), dim3(64 * waves), lds, stream, a);   \
+        } else {                                                                                                   \
+            (void)hipFuncSetAttribute((const void *)k_search<MM, GG, true, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_search<MM, GG, true, 2, false>), dim3(grid), dim3(64 * waves), lds, stream, a);  \
+        }                                                                                                          \
+    }
+        if(metric == M_L2SQ && G_ == 64) PCALL(M_L2SQ, 64)
+        else if(metric == M_L2SQ && G_ == 16) PCALL(M_L2SQ, 16)
+        else if(metric == M_COS && G_ == 64) PCALL(M_COS, 64)
+        else return hipErrorInvalidValue;
+#undef PCALL
+        return hipGetLastError();
+    }
+    LGPU_DISPATCH(metric, a.view.chunks, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+
+}  // namespace lgpu

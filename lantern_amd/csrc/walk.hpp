@@ -221,11 +221,66 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
 // PROF (diagnostic instantiations only): thread 0 accumulates shader-clock cycles per phase into prof[0..6): [4] pop, [5] the
 // neighbour list's arrival, [0] visited filter + compaction (together: wave 0's section) | [1] wait at the first barrier |
 // [2] distances | [3] merge.
+// One hop's distance phase: keys of the nnew unvisited neighbours in s.newids -> s.newkeys.  One G-lane group per row, ROWS rows in
+// flight per group.  ANY: also raise *any_slot when a key beats `worst` (the LDS-list walk skips its merge otherwise).
+template <int METRIC, int G, int ROWS, bool ANY>
+__device__ __forceinline__ void hop_distances(const View &v, WalkLds &s, int nnew, float qn2, uint64_t worst, int *any_slot)
+{
+    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
+    if constexpr(ROWS > 2) {
+        for(int i = g; i < nnew; i += ROWS * NG) {
+            const uint4 *rows[ ROWS ];
+            uint32_t     ids[ ROWS ];
+            float        n2[ ROWS ], d[ ROWS ];
+#pragma unroll
+            for(int r = 0; r < ROWS; ++r) {
+                const int j = i + r * NG;
+                ids[ r ] = s.newids[ j < nnew ? j : i ];
+                rows[ r ] = row_of(v, ids[ r ]);
+                n2[ r ] = row_norm<METRIC>(v, ids[ r ]);
+            }
+            group_distR_n<METRIC, G, ROWS>(s.q, rows, (int)v.chunks, gl, qn2, n2, d);
+            if(gl == G - 1) {
+                bool any = false;
+#pragma unroll
+                for(int r = 0; r < ROWS; ++r) {
+                    const int j = i + r * NG;
+                    if(j < nnew) {
+                        const uint64_t k = make_key(d[ r ], ids[ r ]);
+                        s.newkeys[ j ] = k;
+                        any |= k < worst;
+                    }
+                }
+                if(ANY && any) *any_slot = 1;
+            }
+        }
+    } else
+    for(int i = g; i < nnew; i += 2 * NG) {
+        const int      j = i + NG;
+        const uint32_t id0 = s.newids[ i ];
+        const uint32_t id1 = j < nnew ? s.newids[ j ] : id0;
+        float          d0, d1;
+        group_dist2_n<METRIC, G>(s.q, row_of(v, id0), row_of(v, id1), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id0),
+                                 row_norm<METRIC>(v, id1), d0, d1);
+        if(gl == G - 1) {
+            uint64_t k0 = make_key(d0, id0);
+            s.newkeys[ i ] = k0;
+            bool any = k0 < worst;
+            if(j < nnew) {
+                uint64_t k1 = make_key(d1, id1);
+                s.newkeys[ j ] = k1;
+                any |= k1 < worst;
+            }
+            if(ANY && any) *any_slot = 1;
+        }
+    }
+}
+
 template <int METRIC, int G, bool PROF = false, int ROWS = 2>
 __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int level, int ef,
                             uint32_t &D, uint32_t &E, unsigned long long *prof = nullptr)
 {
-    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
+    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G;
     const int lane = tid & 63;
     unsigned long long tl = 0;
     if constexpr(PROF) tl = (unsigned long long)clock64();
@@ -340,53 +395,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         if(nnew == 0) continue;
         // ---- (2) distances: one G-lane group per row, two rows in flight per group (ROWS = 4: the small-batch shape)
         const uint64_t worst = cnt == ef ? s.keys[ cnt - 1 ] : ~0ull;
-        if constexpr(ROWS > 2) {
-            for(int i = g; i < nnew; i += ROWS * NG) {
-                const uint4 *rows[ ROWS ];
-                uint32_t     ids[ ROWS ];
-                float        n2[ ROWS ], d[ ROWS ];
-#pragma unroll
-                for(int r = 0; r < ROWS; ++r) {
-                    const int j = i + r * NG;
-                    ids[ r ] = s.newids[ j < nnew ? j : i ];
-                    rows[ r ] = row_of(v, ids[ r ]);
-                    n2[ r ] = row_norm<METRIC>(v, ids[ r ]);
-                }
-                group_distR_n<METRIC, G, ROWS>(s.q, rows, (int)v.chunks, gl, qn2, n2, d);
-                if(gl == G - 1) {
-                    bool any = false;
-#pragma unroll
-                    for(int r = 0; r < ROWS; ++r) {
-                        const int j = i + r * NG;
-                        if(j < nnew) {
-                            const uint64_t k = make_key(d[ r ], ids[ r ]);
-                            s.newkeys[ j ] = k;
-                            any |= k < worst;
-                        }
-                    }
-                    if(any) *any_slot = 1;
-                }
-            }
-        } else
-        for(int i = g; i < nnew; i += 2 * NG) {
-            const int      j = i + NG;
-            const uint32_t id0 = s.newids[ i ];
-            const uint32_t id1 = j < nnew ? s.newids[ j ] : id0;
-            float          d0, d1;
-            group_dist2_n<METRIC, G>(s.q, row_of(v, id0), row_of(v, id1), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id0),
-                                     row_norm<METRIC>(v, id1), d0, d1);
-            if(gl == G - 1) {
-                uint64_t k0 = make_key(d0, id0);
-                s.newkeys[ i ] = k0;
-                bool any = k0 < worst;
-                if(j < nnew) {
-                    uint64_t k1 = make_key(d1, id1);
-                    s.newkeys[ j ] = k1;
-                    any |= k1 < worst;
-                }
-                if(any) *any_slot = 1;
-            }
-        }
+        hop_distances<METRIC, G, ROWS, true>(v, s, nnew, qn2, worst, any_slot);
         D += (uint32_t)nnew;
         __syncthreads();
         LGPU_MARK(2)
@@ -419,6 +428,193 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
 #undef LGPU_MARK
     return cnt;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The same walk with the candidate list in WAVE 0's REGISTERS (ef <= 64 * KPL): lane l of register r holds the (64 r + l)-th
+// smallest key, ~0 past the end.  A hop's serial bookkeeping -- merge the previous hop's keys, pop, neighbour list, visited
+// filter -- is then one barrier-free section of wave 0:
+//   * pop     = one ballot over the expanded flags + one readlane,
+//   * merge   = for every new key that beats the radius (few, once the list has settled): its rank is one ballot + popcount,
+//               the insertion one wave-wide DPP shift (wave_shr:1) -- no LDS traffic, no second pass over the list,
+// and a hop costs two barriers (after the section, after the distances) instead of three.  Inserting the keys one at a time into
+// an ef-bounded sorted list leaves the ef smallest of (list U new keys), flags intact: the same list the merge of search_level
+// produces, so results are identical (tests/test_gpu_parity.py runs both).
+__device__ __forceinline__ uint64_t wave_shr1(uint64_t x)  // lane l <- lane l-1 (lane 0 keeps its own value)
+{
+    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)x, (int)(uint32_t)x, 0x138, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(x >> 32), (int)(uint32_t)(x >> 32), 0x138, 0xF, 0xF, false);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l)  // l uniform
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+#define LGPU_MARK(i)                                                  \
+    if constexpr(PROF) {                                              \
+        if(tid == 0) {                                                \
+            const unsigned long long t_ = (unsigned long long)clock64(); \
+            prof[ i ] += t_ - tl;                                     \
+            tl = t_;                                                  \
+        }                                                             \
+    }
+template <int METRIC, int G, int KPL, bool PROF = false, int ROWS = 2>
+__device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int level, int ef,
+                                uint32_t &D, uint32_t &E, unsigned long long *prof = nullptr)
+{
+    const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G;
+    const int lane = tid & 63;
+    unsigned long long tl = 0;
+    if constexpr(PROF) tl = (unsigned long long)clock64();
+    if(s.vis_slots) {
+        for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
+    } else {
+        uint4 *b4 = (uint4 *)bitmap;
+        for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
+    }
+    const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
+    if(g == 0) {
+        float d = group_dist_n<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        if(gl == G - 1) s.newkeys[ 0 ] = make_key(d, start);
+    }
+    D += 1;
+    __syncthreads();
+    uint32_t viscnt = 0;
+    bool     spilled = false;
+    if(tid == 0) {
+        (void)visit_test_and_set(s, bitmap, start, false);
+        viscnt = s.vis_slots ? 1u : 0u;
+    }
+    viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);
+    uint64_t K[ KPL ];  // wave 0's list
+#pragma unroll
+    for(int r = 0; r < KPL; ++r) K[ r ] = ~0ull;
+    if(tid == 0) K[ 0 ] = s.newkeys[ 0 ];
+    int cnt = 1, pend = 0;
+    for(int hop = 0;; ++hop) {
+        int *const nnew_slot = &s.scal[ (hop & 1) ? S_NNEW1 : S_NNEW0 ];
+        if(tid < 64) {
+            // ---- merge the previous hop's keys
+            for(int base = 0; base < pend; base += 64) {
+                const uint64_t N = base + lane < pend ? s.newkeys[ base + lane ] : ~0ull;
+                uint64_t       worst = ~0ull;
+                if(cnt == ef) {
+                    const int wl = (ef - 1) & 63;
+#pragma unroll
+                    for(int r = 0; r < KPL; ++r)
+                        if(r == (ef - 1) >> 6) worst = readlane64(K[ r ], wl);
+                }
+                unsigned long long todo = __ballot(N < worst);
+                while(todo) {
+                    const int t = (int)__builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    const uint64_t k = readlane64(N, t);
+                    int            p = 0;
+#pragma unroll
+                    for(int r = 0; r < KPL; ++r) p += (int)__popcll(__ballot(K[ r ] < k));
+                    if(p >= ef) continue;  // the radius moved in since `todo` was taken
+                    const int r0 = p >> 6, l0 = p & 63;
+#pragma unroll
+                    for(int r = KPL - 1; r >= 0; --r) {
+                        if(r < r0) continue;  // uniform
+                        const uint64_t sh = wave_shr1(K[ r ]);
+                        if(r > r0) {
+                            const uint64_t carry = readlane64(K[ r - 1 > 0 ? r - 1 : 0 ], 63);
+                            K[ r ] = lane == 0 ? carry : sh;
+                        } else {
+                            if(lane > l0) K[ r ] = sh;
+                            if(lane == l0) K[ r ] = k;
+                        }
+                        if(r * 64 + lane >= ef) K[ r ] = ~0ull;  // the list holds ef keys
+                    }
+                    cnt = cnt < ef ? cnt + 1 : ef;
+                }
+            }
+            LGPU_MARK(3)
+            // ---- pop: the first unexpanded key (~0 carries the flag)
+            int      first = -1, fr = 0;
+            uint32_t node = EMPTY;
+#pragma unroll
+            for(int r = 0; r < KPL; ++r) {
+                const unsigned long long m = __ballot(!key_expanded(K[ r ]));
+                if(first < 0 && m) {
+                    first = (int)__builtin_ctzll(m);
+                    fr = r;
+                    node = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)K[ r ], first) >> 1;
+                }
+            }
+            if(first < 0) {
+                if(lane == 0) *nnew_slot = -1;  // the walk is over
+                pend = 0;
+            } else {
+#pragma unroll
+                for(int r = 0; r < KPL; ++r)
+                    if(r == fr && lane == first) K[ r ] |= 1ull;  // expanded
+                E += 1;
+                LGPU_MARK(4)
+                if(s.vis_slots && !spilled && viscnt + v.M0 > s.vis_slots / 4 * 3) {
+                    uint4 *b4 = (uint4 *)bitmap;
+                    for(uint32_t i = (uint32_t)lane; i < bm_words / 4; i += 64) b4[ i ] = make_uint4(0, 0, 0, 0);
+                    spilled = true;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                }
+                uint32_t        cap;
+                const uint32_t *list = neighbors_of(v, node, level, cap);
+                int nb_new = 0;
+                for(uint32_t off = 0; off < cap; off += 64) {
+                    const uint32_t i = off + (uint32_t)lane;
+                    const uint32_t nb = i < cap ? list[ i ] : EMPTY;
+                    if constexpr(PROF) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        LGPU_MARK(5)
+                    }
+                    bool isnew = false;
+                    if(s.vis_slots && !spilled) {
+                        const bool     valid = nb != EMPTY;
+                        const uint32_t h = vis_hash(valid ? nb : 0u, s.vis_slots);
+                        uint32_t       cur = nb;
+                        if(valid) cur = atomicCAS(&s.vis[ h ], EMPTY, nb);
+                        isnew = valid && cur == EMPTY;
+                        const bool unsettled = valid && cur != EMPTY && cur != nb;
+                        if(__ballot(unsettled) != 0ull) {
+                            if(unsettled) isnew = !visit_test_and_set(s, bitmap, nb, false);
+                        }
+                    } else if(nb != EMPTY) {
+                        isnew = !visit_test_and_set(s, bitmap, nb, spilled);
+                    }
+                    const unsigned long long m = __ballot(isnew);
+                    if(isnew) s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
+                    nb_new += __popcll(m);
+                }
+                if(s.vis_slots && !spilled) viscnt += (uint32_t)nb_new;
+                if(lane == 0) *nnew_slot = nb_new;
+                pend = nb_new;
+            }
+        }
+        LGPU_MARK(0)
+        __syncthreads();
+        const int nnew = *nnew_slot;
+        LGPU_MARK(1)
+        if(nnew < 0) break;
+        if(nnew == 0) continue;
+        hop_distances<METRIC, G, ROWS, false>(v, s, nnew, qn2, ~0ull, nullptr);
+        D += (uint32_t)nnew;
+        __syncthreads();
+        LGPU_MARK(2)
+    }
+    // the result goes where the callers read it: s.keys, ascending
+    if(tid < 64) {
+#pragma unroll
+        for(int r = 0; r < KPL; ++r)
+            if(r * 64 + lane < cnt) s.keys[ r * 64 + lane ] = K[ r ];
+        if(lane == 0) s.scal[ S_CNT ] = cnt;
+    }
+    __syncthreads();
+    return s.scal[ S_CNT ];
+}
+#undef LGPU_MARK
 
 // ---- refine_: the neighbour-selection heuristic --------------------------------------------------------
 struct RefineLds

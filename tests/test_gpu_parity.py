@@ -571,6 +571,56 @@ def test_visited_set_variants_give_identical_walks(capi, oracle, vis_slots, monk
     assert o_D.max() > 300  # more visits than 3/4 of 256 slots: the spill path really ran
 
 
+@pytest.mark.parametrize("lds_list", ["0", "1"])
+@pytest.mark.parametrize("ef", [1, 7, 63, 64, 65, 127, 128, 129, 200])
+def test_candidate_list_in_registers_or_lds_gives_the_oracle_walk(capi, oracle, ef, lds_list, monkeypatch):
+    # walk.hpp keeps the candidate list in wave 0's registers for ef <= 128 (one or two keys per lane) and in LDS above;
+    # LANTERN_GPU_LDS_LIST=1 forces the LDS form everywhere.  Every (ef, placement) must be the oracle's walk: same ids,
+    # distances and evaluation/expansion counts.  The lane/register boundaries (63..65, 127..129) are the point.
+    rng = np.random.default_rng(77)
+    n, d, k = 3000, 48, 10
+    base, queries = rng.standard_normal((n, d), dtype=np.float32), rng.standard_normal((64, d), dtype=np.float32)
+    base[1000:1400] = base[:400]  # exact duplicates: equal distances, the slot decides the order
+    ora = oracle.OracleIndex("l2sq", d, M=16, ef_construction=64, ef=ef, seed=9, sum_mode=oracle.SUM_WAVE64)
+    ora.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    kk = min(k, ef)
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, kk)
+    monkeypatch.setenv("LANTERN_GPU_LDS_LIST", lds_list)
+    gpu = capi.GpuIndex("l2sq", d, M=16, ef_construction=64, ef=ef, seed=9)
+    gpu.import_graph(base, ora.export_graph())
+    from lantern_amd import hip
+
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False))
+    lab, dist, D, E = hip.Buffer(64 * kk * 8), hip.Buffer(64 * kk * 4), hip.Buffer(64 * 8), hip.Buffer(64 * 8)
+    for waves in (1, 4, 8):
+        gpu.set_search_shape(waves)
+        gpu.search_batch_device(dq.ptr, 64, kk, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr)
+        hip.synchronize()
+        assert np.array_equal(lab.download((64, kk), np.uint64), o_lab), f"waves={waves}"
+        assert np.array_equal(dist.download((64, kk), np.float32), o_dist)
+        assert np.array_equal(D.download(64, np.uint64), o_D) and np.array_equal(E.download(64, np.uint64), o_E)
+
+
+@pytest.mark.parametrize("lds_list", ["0", "1"])
+@pytest.mark.parametrize("efc", [20, 64, 100, 128, 160])
+def test_build_is_the_same_graph_for_either_list_placement(capi, oracle, efc, lds_list, monkeypatch):
+    rng = np.random.default_rng(efc)
+    n, d, M = 1500, 40, 8
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    labels = np.arange(n, dtype=np.uint64) + 1
+    ora = oracle.OracleIndex("l2sq", d, M=M, ef_construction=efc, ef=32, seed=9, sum_mode=oracle.SUM_WAVE64)
+    ora.add_planned(labels, base, max_batch=64, min_ratio=4)
+    monkeypatch.setenv("LANTERN_GPU_LDS_LIST", lds_list)
+    gpu = capi.GpuIndex("l2sq", d, M=M, ef_construction=efc, ef=32, seed=9)
+    gpu.set_add_batch(64, 4)
+    gpu.add_many(labels, base)
+    gpu.flush()
+    go, gg = ora.export_graph(), gpu.export_graph()
+    assert np.array_equal(gg["levels"], go["levels"])
+    assert np.array_equal(gg["nbr0"], go["nbr0"]), "level-0 adjacency differs"
+    assert np.array_equal(gg["upper_nbr"], go["upper_nbr"]), "upper-level adjacency differs"
+
+
 # ------------------------------------------------------------------------------------------------
 # the committed fixture (tests/golden/oracle_regression.json): the device must reproduce, bit for bit, every case
 # whose summation order is the device's own (WAVE64 / WAVE64_F16 / integer metrics)
