@@ -69,25 +69,78 @@ __host__ inline size_t walk_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t
 // is three quarters full: from then on new slots are recorded in the bitmap (cleared at that moment) and a
 // lookup consults both.  With vis_slots == 0 only the bitmap is used.
 // multiply-shift onto [0, slots): any table size, so the set can be sized to the LDS a given occupancy leaves
-__device__ __forceinline__ uint32_t vis_hash(uint32_t x, uint32_t slots) { return __umulhi(x * 0x9E3779B1u, slots); }
+__device__ __forceinline__ uint32_t vis_hash(uint32_t x, uint32_t buckets) { return __umulhi(x * 0x9E3779B1u, buckets); }
+
+// The LDS visited set: open addressing over BUCKETS of four slots (one ds_read_b128 looks at a whole bucket).  A slot id lives
+// in the first bucket, counting from its home, that had a free slot when it arrived; buckets never lose entries, so a lookup
+// ends at the first bucket that holds the id or still has a free slot.  Insert-only, exact; used by the lanes of wave 0.
+struct VisProbe
+{
+    bool found;  // the id is in the bucket
+    int  e;      // a free slot of the bucket (-1: none), searched from slot `rot` on so that lanes spread over the free slots
+};
+__device__ __forceinline__ VisProbe vis_look(const WalkLds &s, uint32_t bucket, uint32_t x, int rot)
+{
+    asm volatile("" ::: "memory");  // the bucket is re-read after every CAS
+    const uint4    w = ((const uint4 *)s.vis)[ bucket ];
+    const uint32_t v[ 4 ] = { w.x, w.y, w.z, w.w };
+    VisProbe       r;
+    r.found = w.x == x || w.y == x || w.z == x || w.w == x;
+    r.e = -1;
+#pragma unroll
+    for(int i = 3; i >= 0; --i) {
+        const int j = (rot + i) & 3;
+        if(v[ j ] == EMPTY) r.e = j;
+    }
+    return r;
+}
 
 // true if `x` was already visited; otherwise records it.  Called by the lanes of wave 0 only.
 __device__ __forceinline__ bool visit_test_and_set(WalkLds &s, uint32_t *bitmap, uint32_t x, bool spilled)
 {
     if(s.vis_slots) {
-        uint32_t h = vis_hash(x, s.vis_slots);
+        const uint32_t nb4 = s.vis_slots >> 2;
+        uint32_t       b = vis_hash(x, nb4);
         for(;;) {
-            const uint32_t cur = spilled ? s.vis[ h ] : atomicCAS(&s.vis[ h ], EMPTY, x);
-            if(cur == x) return true;
-            if(cur == EMPTY) {
-                if(!spilled) return false;  // recorded by the CAS; the caller counts the slots it added (one ballot per pass)
-                break;  // not in the LDS set: the bitmap decides
+            const VisProbe p = vis_look(s, b, x, (int)(threadIdx.x & 3));
+            if(p.found) return true;
+            if(p.e < 0) {  // a full bucket: the id may live further on
+                b = b + 1 == nb4 ? 0u : b + 1;
+                continue;
             }
-            h = h + 1 == s.vis_slots ? 0u : h + 1;
+            if(spilled) break;  // not in the LDS set (read-only once spilled): the bitmap decides
+            const uint32_t cur = atomicCAS(&s.vis[ 4 * b + (uint32_t)p.e ], EMPTY, x);
+            if(cur == EMPTY) return false;  // recorded; the caller counts the slots it added (one ballot per pass)
+            if(cur == x) return true;
+            // another lane took that slot in the meantime: look at the bucket again
         }
     }
     const uint32_t bit = 1u << (x & 31);
     return (atomicOr(&bitmap[ x >> 5 ], bit) & bit) != 0;
+}
+
+// One lane's share of a hop's visited filter: is neighbour `nb` (EMPTY = no neighbour) new?  The common case is straight-line
+// code for the whole wave -- one bucket read, one CAS -- and only lanes that met a full bucket or lost a slot to another lane
+// take the probing loop (its divergent control flow costs more scalar instructions than the LDS accesses themselves).
+__device__ __forceinline__ bool hop_is_new(WalkLds &s, uint32_t *bitmap, uint32_t nb, bool spilled)
+{
+    bool isnew = false;
+    if(s.vis_slots && !spilled) {
+        const bool     valid = nb != EMPTY;
+        const uint32_t b = vis_hash(valid ? nb : 0u, s.vis_slots >> 2);
+        const VisProbe p = vis_look(s, b, nb, (int)(threadIdx.x & 3));
+        const bool     attempt = valid && !p.found && p.e >= 0;
+        uint32_t       cur = nb;
+        if(attempt) cur = atomicCAS(&s.vis[ 4 * b + (uint32_t)(p.e & 3) ], EMPTY, nb);
+        isnew = attempt && cur == EMPTY;
+        const bool unsettled = valid && !p.found && !isnew && !(attempt && cur == nb);
+        if(__ballot(unsettled) != 0ull) {
+            if(unsettled) isnew = !visit_test_and_set(s, bitmap, nb, false);
+        }
+    } else if(nb != EMPTY) {
+        isnew = !visit_test_and_set(s, bitmap, nb, spilled);
+    }
+    return isnew;
 }
 
 __device__ __forceinline__ int lower_bound_keys(const uint64_t *a, int n, uint64_t k)
@@ -361,23 +414,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         LGPU_MARK(5)
                     }
-                    bool           isnew = false;
-                    if(s.vis_slots && !spilled) {
-                        // the common case as straight-line code: one CAS at the home slot settles almost every lane (the set
-                        // is at most 3/4 full, usually far less); only lanes that met ANOTHER slot's key take the probing loop
-                        // (its divergent control flow costs more scalar instructions than the CAS itself)
-                        const bool     valid = nb != EMPTY;
-                        const uint32_t h = vis_hash(valid ? nb : 0u, s.vis_slots);
-                        uint32_t       cur = nb;
-                        if(valid) cur = atomicCAS(&s.vis[ h ], EMPTY, nb);
-                        isnew = valid && cur == EMPTY;
-                        const bool unsettled = valid && cur != EMPTY && cur != nb;
-                        if(__ballot(unsettled) != 0ull) {
-                            if(unsettled) isnew = !visit_test_and_set(s, bitmap, nb, false);
-                        }
-                    } else if(nb != EMPTY) {
-                        isnew = !visit_test_and_set(s, bitmap, nb, spilled);
-                    }
+                    const bool isnew = hop_is_new(s, bitmap, nb, spilled);
                     const unsigned long long m = __ballot(isnew);
                     if(isnew) s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
                     nb_new += __popcll(m);
@@ -570,20 +607,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         LGPU_MARK(5)
                     }
-                    bool isnew = false;
-                    if(s.vis_slots && !spilled) {
-                        const bool     valid = nb != EMPTY;
-                        const uint32_t h = vis_hash(valid ? nb : 0u, s.vis_slots);
-                        uint32_t       cur = nb;
-                        if(valid) cur = atomicCAS(&s.vis[ h ], EMPTY, nb);
-                        isnew = valid && cur == EMPTY;
-                        const bool unsettled = valid && cur != EMPTY && cur != nb;
-                        if(__ballot(unsettled) != 0ull) {
-                            if(unsettled) isnew = !visit_test_and_set(s, bitmap, nb, false);
-                        }
-                    } else if(nb != EMPTY) {
-                        isnew = !visit_test_and_set(s, bitmap, nb, spilled);
-                    }
+                    const bool isnew = hop_is_new(s, bitmap, nb, spilled);
                     const unsigned long long m = __ballot(isnew);
                     if(isnew) s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
                     nb_new += __popcll(m);
