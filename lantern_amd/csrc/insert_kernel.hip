@@ -15,7 +15,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
 // k_insert: the WALK half of an insertion.  Per new vector: descent to its level, then per level an
 // ef_construction-wide search_level whose sorted result (<= efc keys) goes to HBM for k_connect.  The start of
 // the next lower level is connect_new_node_'s first pick: the closest result under (distance, tie_mix).
-template <int METRIC, int G, bool REG = true>  // REG: as k_search
+template <int METRIC, int G, int KPL = 2>  // KPL: as k_search (keys per lane of wave 0's register list; 0 = LDS list)
 __global__ void __launch_bounds__(512, 6) k_insert(InsertArgs a)
 {
     const int tid = threadIdx.x, T = blockDim.x;
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(512, 6) k_insert(InsertArgs a)
         uint32_t cur = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, target, D);
         for(int level = target < a.view.max_level ? target : a.view.max_level; level >= 0; --level) {
             int cnt;
-            if constexpr(REG) cnt = search_level_reg<METRIC, G, 2>(a.view, s, bitmap, a.bm_words, cur, level, (int)a.efc, D, E);
+            if constexpr(KPL > 0) cnt = search_level_reg<METRIC, G, KPL>(a.view, s, bitmap, a.bm_words, cur, level, (int)a.efc, D, E);
             else cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, cur, level, (int)a.efc, D, E);
             uint64_t *top = a.tops + (size_t)(item0 + (uint32_t)level) * a.efc;
             for(int i = tid; i < cnt; i += T) top[ i ] = s.keys[ i ] & ~1ull;  // drop the "expanded" bit
@@ -76,21 +76,22 @@ size_t insert_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0, uint32_t vis
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream)
 {
     const size_t lds = insert_lds_bytes(a.view.chunks, a.efc, a.view.M0, a.vis_slots);
-    const bool   reg = a.efc <= 128 && !a.lds_list;
-#define CALL(MM, GG)                                                                                          \
-    {                                                                                                         \
-        if(reg) {                                                                                             \
-            (void)hipFuncSetAttribute((const void *)k_insert<MM, GG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_insert<MM, GG, true>), dim3(grid), dim3(64 * waves), lds, stream, a);       \
-        } else {                                                                                              \
-            (void)hipFuncSetAttribute((const void *)k_insert<MM, GG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_insert<MM, GG, false>), dim3(grid), dim3(64 * waves), lds, stream, a);      \
-        }                                                                                                     \
+    const int    kpl = a.lds_list ? 0 : a.efc <= 64 ? 1 : a.efc <= 128 ? 2 : 0;
+#define LGPU_LAUNCH_INSERT(...)                                                                                        \
+    {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void *)k_insert<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_insert<__VA_ARGS__>), dim3(grid), dim3(64 * waves), lds, stream, a);                     \
+    }
+#define CALL(MM, GG)                               \
+    {                                              \
+        if(kpl == 1) LGPU_LAUNCH_INSERT(MM, GG, 1) \
+        else if(kpl == 2) LGPU_LAUNCH_INSERT(MM, GG, 2) \
+        else LGPU_LAUNCH_INSERT(MM, GG, 0)         \
     }
     LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL
+#undef LGPU_LAUNCH_INSERT
     return hipGetLastError();
 }
-
 
 }  // namespace lgpu

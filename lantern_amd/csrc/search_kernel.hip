@@ -17,7 +17,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
 // ROWS = 4 is the SMALL-BATCH shape: when the batch cannot fill six workgroups per CU anyway (<= four 4-wave workgroups per
 // CU), every workgroup keeps four rows per group in flight instead of two and may use 128 VGPRs (four waves per SIMD): a
 // CU's fetch rate is set by the bytes it has in flight, and at 1024 queries x 768-d the two-row shape left it at ~60 %.
-template <int METRIC, int G, bool PROF = false, int ROWS = 2, bool REG = true>
+template <int METRIC, int G, bool PROF = false, int ROWS = 2, int KPL = 1>
 __global__ void __launch_bounds__(512, ROWS == 2 ? 6 : 4) k_search(SearchArgs a)  // ROWS 2: <= 80 VGPRs, six 4-wave workgroups per CU
 {
     const int tid = threadIdx.x, T = blockDim.x;
@@ -42,9 +42,9 @@ __global__ void __launch_bounds__(512, ROWS == 2 ? 6 : 4) k_search(SearchArgs a)
         if(a.view.n != 0) {
             uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
             if constexpr(PROF) pc[ 6 ] = (unsigned long long)clock64() - t_q;
-            // REG: the candidate list lives in wave 0's registers (ef <= 128, the usual case); in LDS otherwise
-            if constexpr(REG)
-                cnt = search_level_reg<METRIC, G, 2, PROF, ROWS>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
+            // KPL keys per lane of wave 0 hold the candidate list (ef <= 64 KPL); KPL = 0: the list lives in LDS
+            if constexpr(KPL > 0)
+                cnt = search_level_reg<METRIC, G, KPL, PROF, ROWS>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
             else
                 cnt = search_level<METRIC, G, PROF, ROWS>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
         }
@@ -85,65 +85,48 @@ __global__ void __launch_bounds__(512, ROWS == 2 ? 6 : 4) k_search(SearchArgs a)
 }
 
 size_t search_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots) { return walk_lds_bytes(chunks, ef_cap, M0, vis_slots); }
+// one instantiation: opt the kernel in to its dynamic LDS size, then launch
+#define LGPU_LAUNCH_SEARCH(...)                                                                                        \
+    {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void *)k_search<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_search<__VA_ARGS__>), dim3(grid), dim3(64 * waves), lds, stream, a);                     \
+    }
+// ... for the list placement of this launch (walk.hpp search_level_reg): one key per lane of wave 0 up to ef = 64, two up to
+// 128, the LDS list beyond (or when LANTERN_GPU_LDS_LIST asks for it)
+#define LGPU_LAUNCH_SEARCH_KPL(MM, GG, PP, RR)                  \
+    {                                                           \
+        if(kpl == 1) LGPU_LAUNCH_SEARCH(MM, GG, PP, RR, 1)      \
+        else if(kpl == 2) LGPU_LAUNCH_SEARCH(MM, GG, PP, RR, 2) \
+        else LGPU_LAUNCH_SEARCH(MM, GG, PP, RR, 0)              \
+    }
+
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream)
 {
     const size_t lds = search_lds_bytes(a.view.chunks, a.ef, a.view.M0, a.vis_slots);
-    const bool   reg = a.ef <= 128 && !a.lds_list;  // walk.hpp search_level_reg
-#define CALL(MM, GG)                                                                                          \
-    {                                                                                                         \
-        if(reg) {                                                                                             \
-            (void)hipFuncSetAttribute((const void *)k_search<MM, GG, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_search<MM, GG, false, 2, true>), dim3(grid), dim3(64 * waves), lds, stream, a); \
-        } else {                                                                                              \
-            (void)hipFuncSetAttribute((const void *)k_search<MM, GG, false, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_search<MM, GG, false, 2, false>), dim3(grid), dim3(64 * waves), lds, stream, a); \
-        }                                                                                                     \
-    }
-    if(a.wide_rows && !a.phase_cycles && group_lanes_for(a.view.chunks) == 64) {  // the small-batch shape (rows of >= 128 chunks)
-#define WCALL(MM)                                                                                                  \
-    {                                                                                                              \
-        if(reg) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)k_search<MM, 64, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_search<MM, 64, false, 4, true>), dim3(grid), dim3(64 * waves), lds, stream, a);  \
-        } else {                                                                                                   \
-            (void)hipFuncSetAttribute((const void *)k_search<MM, 64, false, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_search<MM, 64, false, 4, false>), dim3(grid), dim3(64 * waves), lds, stream, a); \
-        }                                                                                                          \
-    }
+    const int    kpl = a.lds_list ? 0 : a.ef <= 64 ? 1 : a.ef <= 128 ? 2 : 0;
+    const int    G_ = group_lanes_for(a.view.chunks);
+    if(a.wide_rows && !a.phase_cycles && G_ == 64) {  // the small-batch shape (rows of >= 128 chunks)
         switch(metric) {
-            case M_L2SQ: WCALL(M_L2SQ); break;
-            case M_COS: WCALL(M_COS); break;
-            case M_HAMMING: WCALL(M_HAMMING); break;
-            case M_L2SQ_F16: WCALL(M_L2SQ_F16); break;
-            case M_COS_F16: WCALL(M_COS_F16); break;
+            case M_L2SQ: LGPU_LAUNCH_SEARCH_KPL(M_L2SQ, 64, false, 4); break;
+            case M_COS: LGPU_LAUNCH_SEARCH_KPL(M_COS, 64, false, 4); break;
+            case M_HAMMING: LGPU_LAUNCH_SEARCH_KPL(M_HAMMING, 64, false, 4); break;
+            case M_L2SQ_F16: LGPU_LAUNCH_SEARCH_KPL(M_L2SQ_F16, 64, false, 4); break;
+            case M_COS_F16: LGPU_LAUNCH_SEARCH_KPL(M_COS_F16, 64, false, 4); break;
             default: return hipErrorInvalidValue;
         }
-#undef WCALL
         return hipGetLastError();
     }
     if(a.phase_cycles) {  // diagnostic instantiations: the f32 metrics at the two common row shapes
-        const int G_ = group_lanes_for(a.view.chunks);
-#define PCALL(MM, GG)                                                                                              \
-    {                                                                                                              \
-        if(reg) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)k_search<MM, GG, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_search<MM, GG, true, 2, true>), dim3(grid), dim3(64 * waves), lds, stream, a);   \
-        } else {                                                                                                   \
-            (void)hipFuncSetAttribute((const void *)k_search<MM, GG, true, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_search<MM, GG, true, 2, false>), dim3(grid), dim3(64 * waves), lds, stream, a);  \
-        }                                                                                                          \
-    }
-        if(metric == M_L2SQ && G_ == 64) PCALL(M_L2SQ, 64)
-        else if(metric == M_L2SQ && G_ == 16) PCALL(M_L2SQ, 16)
-        else if(metric == M_COS && G_ == 64) PCALL(M_COS, 64)
+        if(metric == M_L2SQ && G_ == 64) LGPU_LAUNCH_SEARCH_KPL(M_L2SQ, 64, true, 2)
+        else if(metric == M_L2SQ && G_ == 16) LGPU_LAUNCH_SEARCH_KPL(M_L2SQ, 16, true, 2)
+        else if(metric == M_COS && G_ == 64) LGPU_LAUNCH_SEARCH_KPL(M_COS, 64, true, 2)
         else return hipErrorInvalidValue;
-#undef PCALL
         return hipGetLastError();
     }
+#define CALL(MM, GG) LGPU_LAUNCH_SEARCH_KPL(MM, GG, false, 2)
     LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL
     return hipGetLastError();
 }
-
 
 }  // namespace lgpu

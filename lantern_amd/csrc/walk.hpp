@@ -525,9 +525,14 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
         viscnt = s.vis_slots ? 1u : 0u;
     }
     viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);
-    uint64_t K[ KPL ];  // wave 0's list
+    uint64_t           K[ KPL ];     // wave 0's list; lanes past position ef - 1 hold leftovers of the shifts and are masked out by
+    unsigned long long live[ KPL ];  // `live`: the lanes of register r whose position 64 r + lane is below ef
 #pragma unroll
-    for(int r = 0; r < KPL; ++r) K[ r ] = ~0ull;
+    for(int r = 0; r < KPL; ++r) {
+        K[ r ] = ~0ull;
+        const int m = ef - 64 * r;
+        live[ r ] = m >= 64 ? ~0ull : m <= 0 ? 0ull : (1ull << m) - 1ull;
+    }
     if(tid == 0) K[ 0 ] = s.newkeys[ 0 ];
     int cnt = 1, pend = 0;
     for(int hop = 0;; ++hop) {
@@ -550,7 +555,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                     const uint64_t k = readlane64(N, t);
                     int            p = 0;
 #pragma unroll
-                    for(int r = 0; r < KPL; ++r) p += (int)__popcll(__ballot(K[ r ] < k));
+                    for(int r = 0; r < KPL; ++r) p += (int)__popcll(__ballot(K[ r ] < k) & live[ r ]);
                     if(p >= ef) continue;  // the radius moved in since `todo` was taken
                     const int r0 = p >> 6, l0 = p & 63;
 #pragma unroll
@@ -564,7 +569,6 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                             if(lane > l0) K[ r ] = sh;
                             if(lane == l0) K[ r ] = k;
                         }
-                        if(r * 64 + lane >= ef) K[ r ] = ~0ull;  // the list holds ef keys
                     }
                     cnt = cnt < ef ? cnt + 1 : ef;
                 }
@@ -575,7 +579,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
             uint32_t node = EMPTY;
 #pragma unroll
             for(int r = 0; r < KPL; ++r) {
-                const unsigned long long m = __ballot(!key_expanded(K[ r ]));
+                const unsigned long long m = __ballot(!key_expanded(K[ r ])) & live[ r ];
                 if(first < 0 && m) {
                     first = (int)__builtin_ctzll(m);
                     fr = r;
