@@ -335,6 +335,9 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
 {
     const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G;
     const int lane = tid & 63;
+    // "this is wave 0" as a value the compiler KNOWS is wave-uniform: the serial section below then runs under uniform control
+    // flow (no exec save/restore around it, its counters and loop state in scalar registers)
+    const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
     unsigned long long tl = 0;
     if constexpr(PROF) tl = (unsigned long long)clock64();
 #define LGPU_MARK(i)                                                  \
@@ -372,7 +375,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         int *const nnew_slot = &s.scal[ (hop & 1) ? S_NNEW1 : S_NNEW0 ];
         int *const any_slot = &s.scal[ (hop & 1) ? S_ANY1 : S_ANY0 ];
         // ---- (1) wave 0: pop + neighbour list + visited filter
-        if(tid < 64) {
+        if(wave0) {
             int      pos = -1;
             uint32_t node = EMPTY;
             bool     mine = false;  // this lane holds the popped key
@@ -503,6 +506,9 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
 {
     const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G;
     const int lane = tid & 63;
+    // "this is wave 0" as a value the compiler KNOWS is wave-uniform: the serial section below then runs under uniform control
+    // flow (no exec save/restore around it, its counters and loop state in scalar registers)
+    const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
     unsigned long long tl = 0;
     if constexpr(PROF) tl = (unsigned long long)clock64();
     if(s.vis_slots) {
@@ -537,7 +543,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
     int cnt = 1, pend = 0;
     for(int hop = 0;; ++hop) {
         int *const nnew_slot = &s.scal[ (hop & 1) ? S_NNEW1 : S_NNEW0 ];
-        if(tid < 64) {
+        if(wave0) {
             // ---- merge the previous hop's keys
             for(int base = 0; base < pend; base += 64) {
                 const uint64_t N = base + lane < pend ? s.newkeys[ base + lane ] : ~0ull;
@@ -633,7 +639,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
         LGPU_MARK(2)
     }
     // the result goes where the callers read it: s.keys, ascending
-    if(tid < 64) {
+    if(wave0) {
 #pragma unroll
         for(int r = 0; r < KPL; ++r)
             if(r * 64 + lane < cnt) s.keys[ r * 64 + lane ] = K[ r ];
