@@ -293,7 +293,9 @@ LANTERN_GPU_EXPORT lantern_gpu_build_profile lantern_gpu_build_profile_get(usear
 /* Diagnostics of the walk kernel: while on, searches run an instrumented instantiation (f32 l2sq / cos rows of >= 128 or
  * 32..63 chunks only) whose thread 0 sums shader-clock cycles per phase of every hop.  out8 (may be NULL) receives and
  * clears the sums: visited filter + compaction | wait at the hop's first barrier | distances | merge | pop | arrival of the
- * neighbour list | upper-level descent | whole query. */
+ * neighbour list | upper-level descent | whole query.  When the walk splits a hop's bookkeeping over two waves (register
+ * list, two or more waves per query: walk.hpp search_level_reg) thread 0 never merges: slot 3 ("merge") is then its pop
+ * DECISION and slot 4 ("pop") the list wave's whole section (merge + pop + hand-off), which runs beside slots 3, 5 and 0. */
 LANTERN_GPU_EXPORT void lantern_gpu_search_phase_profile(usearch_index_t, int on, unsigned long long *out8, usearch_error_t *);
 
 /* order-independent-of-builder fingerprint of the graph (levels, labels, both adjacency arrays, entry point):

@@ -479,7 +479,8 @@ class GpuIndex:
         return {n: (int(getattr(p, n)) if n == "batches" else float(getattr(p, n))) for n, _ in BuildProfile._fields_}
 
     def phase_profile(self, on=True, read=False):
-        """Diagnostics: instrumented walk kernel; read=True returns and clears {phase: cycles}."""
+        """Diagnostics: instrumented walk kernel; read=True returns and clears {phase: cycles}.  With the two-wave split of
+        the register-list walk "merge" is thread 0's pop decision and "pop" the list wave's whole (concurrent) section."""
         out = np.zeros(8, dtype=np.uint64) if read else None
         _call("lantern_gpu_search_phase_profile", self.h, 1 if on else 0, _ptr(out))
         return dict(zip(("visited_compact", "first_barrier", "distances", "merge", "pop", "list_arrival", "descent", "query"), (int(x) for x in out))) if read else None

@@ -49,9 +49,10 @@ __global__ void __launch_bounds__(512, ROWS == 2 ? 6 : 4) k_search(SearchArgs a)
                 cnt = search_level<METRIC, G, PROF, ROWS>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E, pc);
         }
         if constexpr(PROF) {
-            if(tid == 0 && a.phase_cycles) {
-                pc[ 7 ] = (unsigned long long)clock64() - t_q;
-                for(int i = 0; i < 8; ++i) atomicAdd(&a.phase_cycles[ i ], pc[ i ]);
+            if(tid == 0) pc[ 7 ] = (unsigned long long)clock64() - t_q;
+            if((tid & 63) == 0 && a.phase_cycles) {  // thread 0, and the list wave's first lane (slot 4 of the split walk)
+                for(int i = 0; i < 8; ++i)
+                    if(tid == 0 ? (i != 4 || pc[ 4 ] != 0) : (i == 4 && pc[ 4 ] != 0)) atomicAdd(&a.phase_cycles[ i ], pc[ i ]);
             }
         }
         int got = cnt - (int)a.skip;

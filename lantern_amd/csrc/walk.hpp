@@ -24,7 +24,9 @@
 namespace lgpu {
 
 // scalar slots in LDS
-enum { S_POS = 0, S_NNEW, S_CNT, S_ANY, S_BAD, S_CUR, S_CURD, S_CHANGED, S_VISCNT, S_SPILL, S_QN2, S_NNEW0, S_NNEW1, S_ANY0, S_ANY1, S_SCALARS = 16 };
+enum { S_POS = 0, S_NNEW, S_CNT, S_ANY, S_BAD, S_CUR, S_CURD, S_CHANGED, S_VISCNT, S_SPILL, S_QN2, S_NNEW0, S_NNEW1, S_ANY0, S_ANY1,
+       S_FRONT = 16, S_WORST = 20,  // two u64 each (by hop parity): search_level_reg's hand-off from the list wave to the visit wave
+       S_SCALARS = 24 };
 // S_QN2: ||query||^2 as float bits (cosine metrics; set by the kernel before a walk: device_common.hpp "cached row norms")
 
 struct WalkLds
@@ -506,9 +508,19 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
 {
     const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G;
     const int lane = tid & 63;
-    // "this is wave 0" as a value the compiler KNOWS is wave-uniform: the serial section below then runs under uniform control
-    // flow (no exec save/restore around it, its counters and loop state in scalar registers)
-    const bool wave0 = __builtin_amdgcn_readfirstlane(tid) < 64;
+    // Wave roles, as values the compiler KNOWS are wave-uniform (the serial sections then run under uniform control flow: no
+    // exec save/restore, counters and loop state in scalar registers).  With two or more waves the hop's bookkeeping is SPLIT:
+    //   visit wave (wave 0): which node to expand -> its neighbour list -> visited filter -> compaction of the new ids;
+    //   list wave  (wave 1): merge of the previous hop's keys into the register list, pop + "expanded" mark, and the two
+    //                        values the visit wave's NEXT decision needs: the list's first unexpanded key (`front`) and its
+    //                        radius (`worst`), published in LDS slots double-buffered by hop parity.
+    // The visit wave does not wait for the merge: the node to expand is min(front, smallest new key inside the radius) -- the
+    // first unexpanded entry of the merged list (a key the merge truncates away is never that minimum) -- which it finds with a
+    // few ballots over the unsorted new keys.  Merge and list fetch + visited filter, the two long serial chains of a hop, run
+    // side by side.  A one-wave workgroup does the list role, then the visit role.
+    const int  wv = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const bool split = T >= 128;
+    const bool visit_wave = wv == 0, list_wave = split ? wv == 1 : wv == 0;  // (which second wave makes no difference: measured)
     unsigned long long tl = 0;
     if constexpr(PROF) tl = (unsigned long long)clock64();
     if(s.vis_slots) {
@@ -524,6 +536,9 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
     }
     D += 1;
     __syncthreads();
+    uint64_t *const front_pub = (uint64_t *)&s.scal[ S_FRONT ];  // [2] by hop parity
+    uint64_t *const worst_pub = (uint64_t *)&s.scal[ S_WORST ];  // [2]
+    // visit wave's private state: how many slots the LDS set holds, and whether it has spilled to the bitmap
     uint32_t viscnt = 0;
     bool     spilled = false;
     if(tid == 0) {
@@ -531,7 +546,8 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
         viscnt = s.vis_slots ? 1u : 0u;
     }
     viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);
-    uint64_t           K[ KPL ];     // wave 0's list; lanes past position ef - 1 hold leftovers of the shifts and are masked out by
+    // list wave's private state
+    uint64_t           K[ KPL ];     // the list; lanes past position ef - 1 hold leftovers of the shifts and are masked out by
     unsigned long long live[ KPL ];  // `live`: the lanes of register r whose position 64 r + lane is below ef
 #pragma unroll
     for(int r = 0; r < KPL; ++r) {
@@ -539,12 +555,25 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
         const int m = ef - 64 * r;
         live[ r ] = m >= 64 ? ~0ull : m <= 0 ? 0ull : (1ull << m) - 1ull;
     }
-    if(tid == 0) K[ 0 ] = s.newkeys[ 0 ];
     int cnt = 1, pend = 0;
+    if(list_wave) {
+        const uint64_t k0 = s.newkeys[ 0 ];
+        if(lane == 0) {
+            K[ 0 ] = k0;
+            front_pub[ 0 ] = k0;
+            worst_pub[ 0 ] = ef == 1 ? k0 : ~0ull;
+        }
+    }
+    if(split) __syncthreads();
     for(int hop = 0;; ++hop) {
-        int *const nnew_slot = &s.scal[ (hop & 1) ? S_NNEW1 : S_NNEW0 ];
-        if(wave0) {
-            // ---- merge the previous hop's keys
+        const int  par = hop & 1;
+        int *const nnew_slot = &s.scal[ par ? S_NNEW1 : S_NNEW0 ];
+        uint32_t   node = EMPTY;  // one-wave form: the list role hands the popped node to the visit role
+        unsigned long long tw = 0;
+        if constexpr(PROF) tw = (unsigned long long)clock64();
+        if(list_wave) {
+            // ---- merge the previous hop's keys: one at a time into the sorted registers (rank = one ballot, insertion = one
+            // wave-wide DPP shift); only keys inside the radius, ~4 of a hop's ~30 once the list has settled
             for(int base = 0; base < pend; base += 64) {
                 const uint64_t N = base + lane < pend ? s.newkeys[ base + lane ] : ~0ull;
                 uint64_t       worst = ~0ull;
@@ -579,10 +608,8 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                     cnt = cnt < ef ? cnt + 1 : ef;
                 }
             }
-            LGPU_MARK(3)
-            // ---- pop: the first unexpanded key (~0 carries the flag)
-            int      first = -1, fr = 0;
-            uint32_t node = EMPTY;
+            // ---- pop: the first unexpanded key (~0 carries the flag); mark it; publish the next hop's front and radius
+            int first = -1, fr = 0;
 #pragma unroll
             for(int r = 0; r < KPL; ++r) {
                 const unsigned long long m = __ballot(!key_expanded(K[ r ])) & live[ r ];
@@ -592,20 +619,63 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                     node = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)K[ r ], first) >> 1;
                 }
             }
-            if(first < 0) {
-                if(lane == 0) *nnew_slot = -1;  // the walk is over
-                pend = 0;
-            } else {
+            if(first >= 0) {
 #pragma unroll
                 for(int r = 0; r < KPL; ++r)
                     if(r == fr && lane == first) K[ r ] |= 1ull;  // expanded
+                if(split) {
+                    uint64_t nf = ~0ull, nw = ~0ull;
+                    bool     have = false;
+#pragma unroll
+                    for(int r = 0; r < KPL; ++r) {
+                        const unsigned long long m = __ballot(!key_expanded(K[ r ])) & live[ r ];
+                        if(!have && m) {
+                            nf = readlane64(K[ r ], (int)__builtin_ctzll(m));
+                            have = true;
+                        }
+                        if(cnt == ef && r == (ef - 1) >> 6) nw = readlane64(K[ r ], (ef - 1) & 63);
+                    }
+                    if(lane == 0) {
+                        front_pub[ par ^ 1 ] = nf;
+                        worst_pub[ par ^ 1 ] = nw;
+                    }
+                }
+            }
+            LGPU_MARK(3)
+            if constexpr(PROF) {  // split form: the list wave's own clock (slot 4, which the visit wave leaves alone then)
+                if(split && lane == 0) prof[ 4 ] += (unsigned long long)clock64() - tw;
+            }
+        }
+        if(visit_wave) {
+            if(split) {
+                // ---- which node the list wave is popping right now: min(front, smallest new key inside the radius)
+                const uint64_t f = front_pub[ par ], w = worst_pub[ par ];
+                uint64_t       t = f != ~0ull ? f : w;
+                bool           got = f != ~0ull;
+                for(int base = 0; base < pend; base += 64) {
+                    const uint64_t     N = base + lane < pend ? s.newkeys[ base + lane ] : ~0ull;
+                    unsigned long long m = __ballot(N < t);
+                    while(m) {  // each round at least halves the expected number of smaller keys
+                        t = readlane64(N, (int)__builtin_ctzll(m));
+                        got = true;
+                        m = __ballot(N < t);
+                    }
+                }
+                node = got ? (uint32_t)t >> 1 : EMPTY;
+                LGPU_MARK(3)
+            }
+            if(node == EMPTY) {
+                if(lane == 0) *nnew_slot = -1;  // the walk is over
+            } else {
                 E += 1;
-                LGPU_MARK(4)
+                if(!split) LGPU_MARK(4)
+                // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (rare: the set
+                // holds 3/4 * vis_slots slots, a search visits D of them).  The visit wave clears the bitmap on its own.
                 if(s.vis_slots && !spilled && viscnt + v.M0 > s.vis_slots / 4 * 3) {
                     uint4 *b4 = (uint4 *)bitmap;
                     for(uint32_t i = (uint32_t)lane; i < bm_words / 4; i += 64) b4[ i ] = make_uint4(0, 0, 0, 0);
                     spilled = true;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the clears are ordered before this wave's atomicOr's
                 }
                 uint32_t        cap;
                 const uint32_t *list = neighbors_of(v, node, level, cap);
@@ -613,7 +683,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                 for(uint32_t off = 0; off < cap; off += 64) {
                     const uint32_t i = off + (uint32_t)lane;
                     const uint32_t nb = i < cap ? list[ i ] : EMPTY;
-                    if constexpr(PROF) {
+                    if constexpr(PROF) {  // make the list's arrival visible to the phase clock
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         LGPU_MARK(5)
                     }
@@ -624,7 +694,6 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                 }
                 if(s.vis_slots && !spilled) viscnt += (uint32_t)nb_new;
                 if(lane == 0) *nnew_slot = nb_new;
-                pend = nb_new;
             }
         }
         LGPU_MARK(0)
@@ -632,6 +701,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
         const int nnew = *nnew_slot;
         LGPU_MARK(1)
         if(nnew < 0) break;
+        pend = nnew;
         if(nnew == 0) continue;
         hop_distances<METRIC, G, ROWS, false>(v, s, nnew, qn2, ~0ull, nullptr);
         D += (uint32_t)nnew;
@@ -639,7 +709,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
         LGPU_MARK(2)
     }
     // the result goes where the callers read it: s.keys, ascending
-    if(wave0) {
+    if(list_wave) {
 #pragma unroll
         for(int r = 0; r < KPL; ++r)
             if(r * 64 + lane < cnt) s.keys[ r * 64 + lane ] = K[ r ];
