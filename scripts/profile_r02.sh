@@ -13,6 +13,12 @@ timeout 400 rocprofv3 --kernel-include-regex k_search --pmc FETCH_SIZE -d "$OUT/
 timeout 400 rocprofv3 --kernel-include-regex k_search --pmc WRITE_SIZE -d "$OUT/bench/pmc_write" -o pmc -- python bench.py $ARGS > /dev/null 2> "$OUT/bench_pmc_write.log"
 timeout 400 rocprofv3 --kernel-include-regex k_search --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/bench/pmc_l2" -o pmc -- python bench.py $ARGS > /dev/null 2> "$OUT/bench_pmc_l2.log"
 python scripts/summarize_prof.py "$OUT/bench" "$OUT/r02_bench_1Mx768" > "$OUT/bench_summary.txt" 2>&1
+# ---- the cosine line of the same workload: fabric traffic next to its algorithmic bytes (is the lower fraction fewer cache hits?)
+mkdir -p "$OUT/cos"
+timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/cos/trace" -o trace -- python bench.py $ARGS --metric cos > "$OUT/cos/bench_trace.json" 2> "$OUT/cos_trace.log"
+timeout 400 rocprofv3 --kernel-include-regex k_search --pmc FETCH_SIZE -d "$OUT/cos/pmc_fetch" -o pmc -- python bench.py $ARGS --metric cos > /dev/null 2> "$OUT/cos_pmc_fetch.log"
+timeout 400 rocprofv3 --kernel-include-regex k_search --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/cos/pmc_l2" -o pmc -- python bench.py $ARGS --metric cos > /dev/null 2> "$OUT/cos_pmc_l2.log"
+python scripts/summarize_prof.py "$OUT/cos" "$OUT/r02_bench_1Mx768_cos" > "$OUT/cos_summary.txt" 2>&1
 # ---- gather ceiling
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/gather/trace" -o trace -- python scripts/bench_gather_ceiling.py > "$OUT/gather.json" 2> "$OUT/gather_trace.log"
 timeout 300 rocprofv3 --kernel-include-regex k_gather --pmc FETCH_SIZE -d "$OUT/gather/pmc_fetch" -o pmc -- python scripts/bench_gather_ceiling.py > /dev/null 2> "$OUT/gather_pmc_fetch.log"
@@ -28,6 +34,8 @@ python bench.py --no-cpu --quant i8 --data-scale 0.3 > "$OUT/r02_bench_line_i8.j
 python bench.py --no-cpu --dim 1536 --steps 5 > "$OUT/r02_bench_line_1Mx1536.json" 2>/dev/null
 python scripts/bench_single_query.py > "$OUT/r02_single_query_100kx128.json" 2>/dev/null
 python scripts/profile_hop_phases.py > "$OUT/r02_hop_phases.json" 2>/dev/null
+METRIC768=cos python scripts/profile_hop_phases.py > "$OUT/r02_hop_phases_cos.json" 2>/dev/null
+python scripts/ab_list_placement.py > "$OUT/r02_list_placement_ab.json" 2>/dev/null
 python scripts/bench_configs.py > "$OUT/r02_configs.jsonl" 2>/dev/null
 python scripts/bench_scan_server.py > "$OUT/r02_scan_server_100kx128.json" 2>/dev/null
 python bench.py --gpus 2 --dist-backend files --no-cpu --rows 500000 --steps 10 > "$OUT/r02_bench_line_2ranks_one_gpu_files.json" 2>/dev/null
