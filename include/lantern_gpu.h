@@ -273,7 +273,11 @@ typedef struct lantern_gpu_counters
 {
     uint64_t search_dist_evals, search_expansions, search_queries;
     uint64_t add_dist_evals, add_expansions, add_vectors, add_batches;
-    /* breakdown of add_dist_evals: walk / neighbour selection of the new node / reverse-link re-pruning */
+    /* breakdown of add_dist_evals: walk / neighbour selection of the new node / reverse-link re-pruning.  The walk counts are
+     * the reference algorithm's own (asserted equal to the oracle's).  The other two count what the DEVICE evaluates: a
+     * candidate is tested against all kept rows at once (k_connect) and a full list's pair table is filled up front
+     * (k_revlink_pairs), where sequential usearch stops at the first blocker -- they are >= the CPU path's counts and are the
+     * right numerators for the device's rooflines, not for a CPU comparison. */
     uint64_t add_walk_evals, add_select_evals, add_revlink_evals, add_reprunes;
 } lantern_gpu_counters;
 LANTERN_GPU_EXPORT lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t, usearch_error_t *);
