@@ -52,6 +52,8 @@ def parse():
     p.add_argument("--ef", type=int, default=64)
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--queries", type=int, default=8192, help="queries per step per GPU")
+    p.add_argument("--streams", type=int, default=1, help="search launches in flight: steps alternate over this many streams, each with its own query batch "
+                   "(independent batches of a serving workload; the second fills the machine while the first one's longest walks drain)")
     p.add_argument("--waves", type=int, default=0, help="wavefronts per query (0 = the library's automatic shape)")
     p.add_argument("--max-wg", type=int, default=0)
     p.add_argument("--add-batch", type=int, default=8192)
@@ -239,14 +241,20 @@ def main():
     # ---- this rank's queries, resident in HBM ----------------------------------------------------
     qrng = np.random.default_rng(4 + 1000 * rank)
     nq = a.queries
-    queries = make_queries(qrng, nq)
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False, a.quant == "f16", a.quant == "i8", a.quant == "b1"))
-    d_lab, d_dist, d_slot = hip.Buffer(nq * a.k * 8), hip.Buffer(nq * a.k * 4), hip.Buffer(nq * a.k * 4)
-    d_D, d_E = hip.Buffer(nq * 8), hip.Buffer(nq * 8)
-    stream = hip.Stream()  # the launch stream; the events below are recorded on it
+    S = max(1, a.streams)
+    all_queries = make_queries(qrng, nq * S)
+    queries = all_queries[:nq]  # the batch recall and the CPU baseline are taken on
+    lanes = []  # one per stream: its own query batch, outputs and launch stream
+    for i in range(S):
+        qi = all_queries[i * nq:(i + 1) * nq]
+        lanes.append({"dq": hip.Buffer.from_numpy(hip.padded_rows(qi, False, a.quant == "f16", a.quant == "i8", a.quant == "b1")),
+                      "lab": hip.Buffer(nq * a.k * 8), "dist": hip.Buffer(nq * a.k * 4), "slot": hip.Buffer(nq * a.k * 4),
+                      "D": hip.Buffer(nq * 8), "E": hip.Buffer(nq * 8), "stream": hip.Stream()})
+    d_slot = lanes[0]["slot"]
 
-    def step():
-        ix.search_batch_device(dq.ptr, nq, a.k, a.ef, 0, d_lab.ptr, d_dist.ptr, d_slot.ptr, None, d_D.ptr, d_E.ptr, stream.handle)
+    def step(i=0):
+        L = lanes[i % S]
+        ix.search_batch_device(L["dq"].ptr, nq, a.k, a.ef, 0, L["lab"].ptr, L["dist"].ptr, L["slot"].ptr, None, L["D"].ptr, L["E"].ptr, L["stream"].handle)
 
     def barrier():
         hip.synchronize()
@@ -254,15 +262,16 @@ def main():
             rdv.barrier()
         hip.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    for i in range(a.warmup):
+        step(i)
     barrier()
     ev = [(hip.Event(), hip.Event()) for _ in range(a.steps)]
     t0 = time.perf_counter()
-    for s, e in ev:
-        s.record(stream.handle)
-        step()
-        e.record(stream.handle)
+    for i, (s, e) in enumerate(ev):
+        st = lanes[i % S]["stream"].handle
+        s.record(st)
+        step(i)
+        e.record(st)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [s.elapsed_ms(e) for s, e in ev]  # HIP events on the launch stream: one search launch each
@@ -270,12 +279,18 @@ def main():
         elapsed = rdv.max_float(elapsed)
 
     # ---- algorithmic bytes of one launch --------------------------------------------
-    D = d_D.download(nq, np.uint64).astype(np.float64)
-    E = d_E.download(nq, np.uint64).astype(np.float64)
     row_bytes = a.dim * {"f32": 4, "f16": 2, "i8": 1, "b1": 0.125}[a.quant]
-    bytes_per_launch = float((D * row_bytes + E * (2 * a.M * 4) + row_bytes).sum())
+    per_lane = []
+    for L in lanes:
+        Dl = L["D"].download(nq, np.uint64).astype(np.float64)
+        El = L["E"].download(nq, np.uint64).astype(np.float64)
+        per_lane.append((Dl, El, float((Dl * row_bytes + El * (2 * a.M * 4) + row_bytes).sum())))
+    D, E = per_lane[0][0], per_lane[0][1]
+    bytes_per_launch = float(np.mean([b for _, _, b in per_lane]))
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
-    achieved = bytes_per_launch / avg_kernel_s / 1e9
+    # one launch at a time: bytes of a launch / its HIP-event duration.  Launches in flight side by side (--streams > 1) stretch
+    # each other's durations, so there the rate is all launches' bytes / the timed region
+    achieved = bytes_per_launch / avg_kernel_s / 1e9 if S == 1 else bytes_per_launch * a.steps / elapsed / 1e9
 
     out = None
     if rank == 0:
@@ -320,6 +335,7 @@ def main():
             "data": ("synthetic" if a.data == "gaussian" else "synthetic (low-rank)") + ("" if a.data_scale == 1.0 else f" x {a.data_scale}"),
             "config": {"workload": f"HNSW search {a.n}x{a.dim} {a.quant} {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}",
                        "queries_per_step_per_gpu": nq, "global_queries_per_step": nq * world, "waves_per_query": a.waves,
+                       "launches_in_flight": S,
                        "parallelism": f"replicated index, query batch sharded x{world}, no collective"},
             f"recall_at_{a.k}": recall,
             "recall_queries": tq,
@@ -334,7 +350,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command; not re-measured in this run)" if traffic else None,
                          "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": avg_kernel_s * 1e3},
+                         "avg_launch_ms": avg_kernel_s * 1e3,
+                         "note": None if S == 1 else f"{S} launches in flight: achieved = all launches' algorithmic bytes / the timed region; avg_launch_ms is "
+                                                      "the mean HIP-event duration of launches that overlap"},
             "cpu_baseline": cpu,
             "build_quality": quality,
             "collective_build": collective,

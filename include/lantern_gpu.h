@@ -209,7 +209,11 @@ LANTERN_GPU_EXPORT void lantern_gpu_search_batch(usearch_index_t, const void *qu
                                                  float *distances, uint32_t *counts, usearch_error_t *);
 /* Same, every buffer already in device memory, asynchronous on `stream` (a hipStream_t; NULL =
  * the default stream).  slots (u32 internal ids), counts, dist_evals (D) and expansions (E) may
- * be NULL.  `skip` drops that many leading results per query (streaming continuation). */
+ * be NULL.  `skip` drops that many leading results per query (streaming continuation).
+ * Launches on DIFFERENT streams overlap, two at a time (each gets its own slab of visited bitmaps; a third queues behind
+ * the slab it reuses): with independent batches -- a serving workload -- the second fills the machine while the first one's
+ * longest walks drain (1M x 768 cosine, 1024-query batches: 0.68 -> 0.87 of the HBM peak).  Insert batches run behind every
+ * search in flight, and searches queued on other streams behind them; no host synchronisation is involved. */
 LANTERN_GPU_EXPORT void lantern_gpu_search_batch_device(usearch_index_t, const void *d_queries, size_t nq, size_t k,
                                                         size_t ef, size_t skip, uint64_t *d_labels, float *d_distances,
                                                         uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_dist_evals,

@@ -240,21 +240,67 @@ static uint32_t *next_ticket(Index *ix, size_t work, int grid, hipStream_t strea
     return t;
 }
 
-// Launches that use the index's shared scratch (the per-workgroup visited bitmaps, indexed by blockIdx only) are
-// serialised ACROSS streams: lantern_gpu_search_batch_device returns as soon as its kernel is queued on the caller's
-// stream, and the index mutex is released with the kernel still running, so a launch on a different stream could
-// otherwise overlap it and share its bitmaps.  Same-stream launches are ordered by the stream itself.
-bool order_launch(Index *ix, hipStream_t stream)
+// Ordering of launches across streams (index.hpp "launch slots").  lantern_gpu_search_batch_device returns as soon as its
+// kernel is queued on the caller's stream and the index mutex is released with the kernel still running; same-stream launches
+// are ordered by the stream itself, everything else by the events below.
+static bool slot_idle(Index *ix, int s)
 {
-    if(ix->launch_pending && ix->launch_stream != stream) HIPCHK(ix, hipStreamWaitEvent(stream, ix->launch_done, 0));
+    if(ix->slot_pending[ s ] && hipEventQuery(ix->slot_done[ s ]) == hipSuccess) ix->slot_pending[ s ] = false;
+    return !ix->slot_pending[ s ];
+}
+bool order_launch(Index *ix, hipStream_t stream)  // an insert batch: after every search in flight
+{
+    for(int s = 0; s < Index::kSearchSlots; ++s)
+        if(!slot_idle(ix, s) && ix->slot_stream[ s ] != stream) HIPCHK(ix, hipStreamWaitEvent(stream, ix->slot_done[ s ], 0));
     return true;
 }
 bool record_launch(Index *ix, hipStream_t stream)
 {
-    if(!ix->launch_done) HIPCHK(ix, hipEventCreateWithFlags(&ix->launch_done, hipEventDisableTiming));
-    HIPCHK(ix, hipEventRecord(ix->launch_done, stream));
-    ix->launch_stream = stream;
-    ix->launch_pending = true;
+    if(!ix->insert_done) HIPCHK(ix, hipEventCreateWithFlags(&ix->insert_done, hipEventDisableTiming));
+    HIPCHK(ix, hipEventRecord(ix->insert_done, stream));
+    ix->insert_pending = true;
+    return true;
+}
+int acquire_search_slot(Index *ix, hipStream_t stream, size_t grid)
+{
+    // a search on another stream than the index's own runs behind the insert batches queued there
+    if(ix->insert_pending) {
+        if(hipEventQuery(ix->insert_done) == hipSuccess) ix->insert_pending = false;
+        else if(stream != ix->stream && hipStreamWaitEvent(stream, ix->insert_done, 0) != hipSuccess) { set_err(ix, "lantern_gpu: hipStreamWaitEvent failed"); return -1; }
+    }
+    int pick = -1;
+    for(int s = 0; s < Index::kSearchSlots && pick < 0; ++s)  // the slot this stream used last: the stream orders the two launches
+        if(!slot_idle(ix, s) && ix->slot_stream[ s ] == stream) pick = s;
+    for(int s = 0; s < Index::kSearchSlots && pick < 0; ++s)
+        if(slot_idle(ix, s)) pick = s;
+    if(pick < 0) {  // both slabs busy on other streams: queue behind one of them, alternating
+        pick = (int)(ix->slot_next++ % Index::kSearchSlots);
+        if(hipStreamWaitEvent(stream, ix->slot_done[ pick ], 0) != hipSuccess) { set_err(ix, "lantern_gpu: hipStreamWaitEvent failed"); return -1; }
+    }
+    if(pick == 0) {
+        if(!ensure_bitmaps(ix, grid)) return -1;
+        ix->slot_bitmaps[ 0 ] = ix->d_bitmaps;
+        ix->slot_rows[ 0 ] = ix->bitmap_slots;
+        ix->slot_words[ 0 ] = ix->bm_words;
+    } else {
+        const size_t words = ((std::max<size_t>(ix->cap, 1) + 31) / 32 + 3) / 4 * 4;
+        if(!ix->slot_bitmaps[ pick ] || ix->slot_rows[ pick ] < grid || ix->slot_words[ pick ] != words) {
+            if(ix->slot_bitmaps[ pick ]) (void)hipFree(ix->slot_bitmaps[ pick ]);  // (hipFree waits for the device)
+            ix->slot_bitmaps[ pick ] = nullptr;
+            const size_t rows = std::max(grid, ix->slot_rows[ pick ]);
+            if(hipMalloc((void **)&ix->slot_bitmaps[ pick ], rows * words * 4) != hipSuccess) { set_err(ix, "lantern_gpu: out of device memory (visited bitmaps)"); return -1; }
+            ix->slot_rows[ pick ] = rows;
+            ix->slot_words[ pick ] = words;
+        }
+    }
+    return pick;
+}
+bool release_search_slot(Index *ix, int s, hipStream_t stream)
+{
+    if(!ix->slot_done[ s ]) HIPCHK(ix, hipEventCreateWithFlags(&ix->slot_done[ s ], hipEventDisableTiming));
+    HIPCHK(ix, hipEventRecord(ix->slot_done[ s ], stream));
+    ix->slot_stream[ s ] = stream;
+    ix->slot_pending[ s ] = true;
     return true;
 }
 
@@ -719,7 +765,8 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         return false;
     }
     const int grid = search_grid(ix, nq, waves, 24);
-    if(!ensure_bitmaps(ix, (size_t)grid)) return false;
+    const int slot = acquire_search_slot(ix, stream, (size_t)grid);
+    if(slot < 0) return false;
     SearchArgs a;
     a.view = ix->view();
     a.queries = d_queries;
@@ -734,8 +781,8 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.out_counts = d_counts;
     a.out_D = d_D;
     a.out_E = d_E;
-    a.bitmaps = ix->d_bitmaps;
-    a.bm_words = (uint32_t)ix->bm_words;
+    a.bitmaps = ix->slot_bitmaps[ slot ];
+    a.bm_words = (uint32_t)ix->slot_words[ slot ];
     a.vis_slots = vis_slots;
     a.totals = ix->d_totals;
     a.ticket = next_ticket(ix, nq, grid, stream);
@@ -744,9 +791,8 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     // small batch (at most four 4-wave workgroups per CU would be resident anyway): four rows in flight per group
     static const int wide_env = std::getenv("LANTERN_GPU_WIDE_ROWS") ? std::atoi(std::getenv("LANTERN_GPU_WIDE_ROWS")) : -1;
     a.wide_rows = wide_env >= 0 ? wide_env : (nq * (size_t)waves <= (size_t)ix->num_cus * 16 && nq >= 64);
-    if(!order_launch(ix, stream)) return false;
     HIPCHK(ix, launch_search(ix->mcode, a, waves, grid, stream));
-    if(!record_launch(ix, stream)) return false;
+    if(!release_search_slot(ix, slot, stream)) return false;
     ix->c_search_queries += nq;
     return true;
 }
@@ -978,7 +1024,11 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
     prof_resolve(ix, 0);
     for(hipEvent_t ev : ix->prof_free) (void)hipEventDestroy(ev);
     if(ix->h_single) (void)hipHostFree(ix->h_single);
-    if(ix->launch_done) (void)hipEventDestroy(ix->launch_done);
+    for(int sl = 0; sl < Index::kSearchSlots; ++sl) {
+        if(sl > 0 && ix->slot_bitmaps[ sl ]) (void)hipFree(ix->slot_bitmaps[ sl ]);
+        if(ix->slot_done[ sl ]) (void)hipEventDestroy(ix->slot_done[ sl ]);
+    }
+    if(ix->insert_done) (void)hipEventDestroy(ix->insert_done);
     delete ix;
 }
 

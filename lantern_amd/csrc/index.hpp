@@ -121,12 +121,20 @@ struct Index
     char  *h_single = nullptr;
     size_t h_single_bytes = 0;
 
-    // ---- launches on one index are serialised across streams: the walk kernels share per-index scratch (the
-    // per-workgroup visited bitmaps, indexed by blockIdx only), so a launch on another stream first waits for the event
-    // recorded behind the previous one
-    hipEvent_t  launch_done = nullptr;
-    hipStream_t launch_stream = nullptr;
-    bool        launch_pending = false;
+    // ---- launches that share per-index scratch are ordered across streams.  The walk kernels use per-workgroup visited
+    // bitmaps indexed by blockIdx only, so two launches may overlap only if they use different bitmap slabs.  SEARCH launches
+    // have two slabs ("launch slots"): two batches on two streams run side by side (the second fills the machine while the
+    // first one's longest walks drain); a third waits for the slot it reuses.  INSERT batches mutate the graph: they wait for
+    // every search in flight, and searches on other streams wait for them.
+    static const int kSearchSlots = 2;
+    uint32_t   *slot_bitmaps[ kSearchSlots ] = { nullptr, nullptr };  // [0] aliases d_bitmaps (the slab inserts use too)
+    size_t      slot_rows[ kSearchSlots ] = { 0, 0 }, slot_words[ kSearchSlots ] = { 0, 0 };
+    hipEvent_t  slot_done[ kSearchSlots ] = { nullptr, nullptr };
+    hipStream_t slot_stream[ kSearchSlots ] = { nullptr, nullptr };
+    bool        slot_pending[ kSearchSlots ] = { false, false };
+    unsigned    slot_next = 0;
+    hipEvent_t  insert_done = nullptr;
+    bool        insert_pending = false;
 
     // ---- counters ----------------------------------------------------------------------------------
     uint64_t c_search_queries = 0, c_add_vectors = 0, c_add_batches = 0;
@@ -161,8 +169,10 @@ size_t      search_one_locked(Index *ix, Cursor *cur, const void *query, int kin
 // usearch_size of the index: for a mirror, the header's count plus what was inserted since
 inline size_t logical_size(const Index *ix) { return ix->page_mode ? ix->page_declared + (ix->n - ix->page_attach_n) : ix->n; }
 void        prof_resolve(Index *ix, size_t keep);          // fold finished batches' event times into ix->prof
-bool        order_launch(Index *ix, hipStream_t stream);   // before a launch that uses the index's shared scratch
+bool        order_launch(Index *ix, hipStream_t stream);   // before an insert batch (exclusive use of the index)
 bool        record_launch(Index *ix, hipStream_t stream);  // behind it
+int         acquire_search_slot(Index *ix, hipStream_t stream, size_t grid);  // before a search launch: its bitmap slab (< 0: error)
+bool        release_search_slot(Index *ix, int slot, hipStream_t stream);     // behind it
 bool        import_graph_locked(Index *ix, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,
                                 const uint32_t *nbr0, const uint32_t *upper_off, const uint32_t *upper_nbr, uint32_t entry_slot,
                                 int32_t max_level, bool vectors_are_codes = false);  // pq: `vectors` = num_subvectors code bytes per row

@@ -27,6 +27,8 @@ python scripts/prof_dump.py "$OUT/gather" k_gather > "$OUT/r02_gather_ceiling.md
 # ---- the unprofiled lines
 python bench.py > "$OUT/r02_bench_line.json" 2> "$OUT/bench_line.err"
 python bench.py --no-cpu --metric cos --queries 1024 --steps 40 > "$OUT/r02_bench_line_cos_q1024.json" 2>/dev/null
+python bench.py --no-cpu --metric cos --queries 1024 --steps 40 --streams 2 > "$OUT/r02_bench_line_cos_q1024_2streams.json" 2>/dev/null
+python bench.py --no-cpu --streams 2 > "$OUT/r02_bench_line_2streams.json" 2>/dev/null
 python bench.py --no-cpu --metric cos > "$OUT/r02_bench_line_cos.json" 2>/dev/null
 python bench.py --no-cpu --data lowrank > "$OUT/r02_bench_line_lowrank.json" 2>/dev/null
 python bench.py --no-cpu --quant f16 > "$OUT/r02_bench_line_f16.json" 2>/dev/null

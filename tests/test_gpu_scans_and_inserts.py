@@ -90,12 +90,57 @@ def test_searches_on_two_streams_share_the_index_safely(capi, monkeypatch):
     out_l = [hip.Buffer(nq * k * 8) for _ in qs]
     out_d = [hip.Buffer(nq * k * 4) for _ in qs]
     for rounds in range(3):
-        for i in (0, 1):  # queued back to back on different streams: without ordering they would overlap
+        for i in (0, 1):  # queued back to back on different streams: each gets its own bitmap slab and they overlap
             ix.search_batch_device(dq[i].ptr, nq, k, 0, 0, out_l[i].ptr, out_d[i].ptr, None, None, None, None, streams[i].handle)
         hip.synchronize()
         for i in (0, 1):
             assert np.array_equal(out_l[i].download((nq, k), np.uint64), want[i][0])
             assert np.array_equal(out_d[i].download((nq, k), np.float32), want[i][1])
+    # more launches in flight than slabs: the third and fourth queue behind the slab they reuse
+    more = [hip.Stream() for _ in range(4)]
+    o_l = [hip.Buffer(nq * k * 8) for _ in more]
+    o_d = [hip.Buffer(nq * k * 4) for _ in more]
+    for rounds in range(2):
+        for j, st in enumerate(more):
+            ix.search_batch_device(dq[j & 1].ptr, nq, k, 0, 0, o_l[j].ptr, o_d[j].ptr, None, None, None, None, st.handle)
+        hip.synchronize()
+        for j in range(len(more)):
+            assert np.array_equal(o_l[j].download((nq, k), np.uint64), want[j & 1][0])
+            assert np.array_equal(o_d[j].download((nq, k), np.float32), want[j & 1][1])
+
+
+def test_inserts_and_searches_on_other_streams_are_ordered(capi, monkeypatch):
+    """An insert batch mutates the graph: it runs behind every search in flight, and a search queued on another stream after
+    it sees all of its rows -- without any host synchronisation in between."""
+    from lantern_amd import hip
+
+    monkeypatch.setenv("LANTERN_GPU_VIS_SLOTS", "0")
+    rng = np.random.default_rng(29)
+    n1, n2, d, k, nq = 20000, 6000, 48, 10, 2000
+    base = rng.standard_normal((n1 + n2, d), dtype=np.float32)
+    labels = np.arange(n1 + n2, dtype=np.uint64) + 1
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    whole = capi.GpuIndex("l2sq", d, M=12, ef_construction=48, ef=48, seed=8)
+    whole.add_many(labels[:n1], base[:n1])
+    whole.flush()
+    want_before = whole.search_batch(q, k)
+    whole.add_many(labels[n1:], base[n1:])
+    whole.flush()
+    want_after = whole.search_batch(q, k)
+    assert not np.array_equal(want_before[0], want_after[0])
+    ix = capi.GpuIndex("l2sq", d, M=12, ef_construction=48, ef=48, seed=8)
+    ix.add_many(labels[:n1], base[:n1])
+    ix.flush()
+    sa, sb = hip.Stream(), hip.Stream()
+    dq = hip.Buffer.from_numpy(hip.padded_rows(q, False))
+    la, da, lb, db = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4), hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4)
+    ix.search_batch_device(dq.ptr, nq, k, 0, 0, la.ptr, da.ptr, None, None, None, None, sa.handle)  # in flight ...
+    ix.add_many(labels[n1:], base[n1:])                                                           # ... queued behind it
+    ix.search_batch_device(dq.ptr, nq, k, 0, 0, lb.ptr, db.ptr, None, None, None, None, sb.handle)  # ... and this behind the insert
+    hip.synchronize()
+    assert np.array_equal(la.download((nq, k), np.uint64), want_before[0]) and np.array_equal(da.download((nq, k), np.float32), want_before[1])
+    assert np.array_equal(lb.download((nq, k), np.uint64), want_after[0]) and np.array_equal(db.download((nq, k), np.float32), want_after[1])
+    assert ix.checksum() == whole.checksum()
 
 
 # ------------------------------------------------------------------------------------------------------------------
