@@ -592,7 +592,7 @@ def test_candidate_list_in_registers_or_lds_gives_the_oracle_walk(capi, oracle, 
 
     dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False))
     lab, dist, D, E = hip.Buffer(64 * kk * 8), hip.Buffer(64 * kk * 4), hip.Buffer(64 * 8), hip.Buffer(64 * 8)
-    for waves in (1, 4, 8):
+    for waves in (1, 2, 4, 8):  # 1: one wave plays both roles; 2: the list wave is also the last wave
         gpu.set_search_shape(waves)
         gpu.search_batch_device(dq.ptr, 64, kk, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr)
         hip.synchronize()
