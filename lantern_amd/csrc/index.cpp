@@ -737,7 +737,7 @@ bool flush_locked(Index *ix)
 
 bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, size_t ef, size_t skip, uint64_t *d_labels,
                        float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D, uint64_t *d_E, hipStream_t stream,
-                       int waves)
+                       int waves, uint32_t *done)
 {
     if(nq == 0 || k == 0) return true;
     if(waves <= 0) {
@@ -787,12 +787,14 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.totals = ix->d_totals;
     a.ticket = next_ticket(ix, nq, grid, stream);
     a.phase_cycles = ix->phase_profile ? ix->d_totals + 8 : nullptr;
+    a.done = done;
     a.lds_list = lds_list_env();
     // small batch (at most four 4-wave workgroups per CU would be resident anyway): four rows in flight per group
     static const int wide_env = std::getenv("LANTERN_GPU_WIDE_ROWS") ? std::atoi(std::getenv("LANTERN_GPU_WIDE_ROWS")) : -1;
     a.wide_rows = wide_env >= 0 ? wide_env : (nq * (size_t)waves <= (size_t)ix->num_cus * 16 && nq >= 64);
     HIPCHK(ix, launch_search(ix->mcode, a, waves, grid, stream));
-    if(!release_search_slot(ix, slot, stream)) return false;
+    if(done) ix->slot_pending[ slot ] = false;  // the caller waits for the kernel itself: nothing to order later launches against
+    else if(!release_search_slot(ix, slot, stream)) return false;
     ix->c_search_queries += nq;
     return true;
 }
@@ -808,28 +810,51 @@ size_t search_one_locked(Index *ix, Cursor *cur, const void *query, int kind, si
     if(ix->n == 0 || k == 0) return 0;
     const size_t want = std::min(cur->seen.size() + k, ix->n);  // enough to find k unseen ones
     const size_t row = (size_t)ix->chunks * 16;
-    const size_t need = row + want * 16 + 16;
+    const size_t need = row + want * 16 + 32;
     if(ix->h_single_bytes < need) {
         if(ix->h_single) (void)hipHostFree(ix->h_single);
-        ix->h_single = nullptr;
+        ix->h_single = ix->h_single_dev = nullptr;
         ix->h_single_bytes = 0;
         const size_t cap = need * 2 + 4096;
         if(hipHostMalloc((void **)&ix->h_single, cap, hipHostMallocMapped) != hipSuccess) {
             set_err(ix, "lantern_gpu: cannot allocate the pinned single-query block");
             return 0;
         }
+        if(hipHostGetDevicePointer((void **)&ix->h_single_dev, ix->h_single, 0) != hipSuccess) {
+            set_err(ix, "lantern_gpu: the pinned block is not device-mapped");
+            return 0;
+        }
         ix->h_single_bytes = cap;
     }
-    char *dev = nullptr;
-    if(hipHostGetDevicePointer((void **)&dev, ix->h_single, 0) != hipSuccess) { set_err(ix, "lantern_gpu: the pinned block is not device-mapped"); return 0; }
+    char *dev = ix->h_single_dev;
     pad_row(ix, query, kind, (uint32_t *)ix->h_single);
     uint64_t *d_lab = (uint64_t *)(dev + row);
     float    *d_dist = (float *)(dev + row + want * 8);
     uint32_t *d_slot = (uint32_t *)(dev + row + want * 12);
     uint32_t *d_cnt = (uint32_t *)(dev + row + want * 16);
+    // completion: the kernel bumps a counter in this block after its answers (system-scope release); the host spins on it.
+    // No event, no stream synchronisation: of a ~200 us call those cost ~5 us.  The stream is consulted only as a watchdog
+    // (a kernel that died leaves the counter at 0 and the stream idle or in error).
+    const size_t       flag_off = (row + want * 16 + 4 + 15) / 16 * 16;
+    volatile uint32_t *h_done = (volatile uint32_t *)(ix->h_single + flag_off);
+    *h_done = 0;
     // one query: spend a whole 8-wave workgroup on it (latency-bound path)
-    bool ok = run_search_device(ix, (const uint4 *)dev, 1, want, ef, 0, d_lab, d_dist, d_slot, d_cnt, nullptr, nullptr, ix->stream, 8);
-    ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
+    bool ok = run_search_device(ix, (const uint4 *)dev, 1, want, ef, 0, d_lab, d_dist, d_slot, d_cnt, nullptr, nullptr, ix->stream, 8,
+                                (uint32_t *)(dev + flag_off));
+    if(ok) {
+        for(unsigned spins = 0; *h_done == 0; ++spins) {
+            __builtin_ia32_pause();
+            if((spins & 0x3FFF) == 0x3FFF) {  // every ~100 us: is the kernel still there?
+                const hipError_t st = hipStreamQuery(ix->stream);
+                if(st == hipErrorNotReady) continue;
+                if(*h_done != 0) break;
+                ok = false;  // the stream drained (or failed) without the counter moving
+                if(st != hipSuccess) set_err(ix, std::string("lantern_gpu: ") + hipGetErrorString(st));
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     if(!ok) {
         if(ix->err.empty()) set_err(ix, "lantern_gpu: HIP failure during search");
         return 0;

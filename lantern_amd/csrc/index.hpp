@@ -118,7 +118,7 @@ struct Index
     // ---- single-query path (usearch_search_ef): one pinned, device-mapped block [query row | labels | distances |
     // slots | count] -- the kernel reads the query from it and writes the answer into it, so a lone query costs one
     // launch and one stream synchronisation, no copy commands
-    char  *h_single = nullptr;
+    char  *h_single = nullptr, *h_single_dev = nullptr;  // host / device address of the block
     size_t h_single_bytes = 0;
 
     // ---- launches that share per-index scratch are ordered across streams.  The walk kernels use per-workgroup visited
@@ -159,9 +159,11 @@ bool        pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst
 size_t      input_bytes(const Index *ix, int kind_in);
 bool        kind_accepted(const Index *ix, int kind_in);
 int         search_grid(const Index *ix, size_t nq, int waves, int waves_per_cu);
+// `done`: NULL, or a device-visible counter the kernel bumps per finished query; the caller then WAITS ON IT (not on the
+// stream) and no completion event is queued behind the launch
 bool        run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, size_t ef, size_t skip,
                               uint64_t *d_labels, float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D,
-                              uint64_t *d_E, hipStream_t stream, int waves);
+                              uint64_t *d_E, hipStream_t stream, int waves, uint32_t *done = nullptr);
 
 // one usearch_search_ef on behalf of `cur` (the caller holds ix->mu); returns the number of results
 size_t      search_one_locked(Index *ix, Cursor *cur, const void *query, int kind, size_t k, size_t ef, bool streaming,

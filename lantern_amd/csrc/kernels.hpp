@@ -30,6 +30,7 @@ struct SearchArgs
                                  // round-1 walk, kept for A/B parity runs and for ef > 128)
     int             wide_rows;   // small batch: the four-rows-in-flight instantiation (k_search<.., ROWS = 4>)
     unsigned long long *phase_cycles;  // diagnostics (lantern_gpu_search_phase_profile): [8] shader-clock cycles summed over the
+    uint32_t       *done;        // NULL, or a counter in host-visible memory: +1 (system scope) per finished query, after its answers
 };                               // launch's queries by phase: pop | list + visited | distances | merge | descent | whole query
 
 // one reverse-link request produced by the insert pass: add `new_slot` to `close`'s list at `level`

@@ -131,6 +131,15 @@ __global__ void __launch_bounds__(512, ROWS == 2 ? 6 : 4) k_search(SearchArgs)  
             s.scal[ S_POS ] = ticket ? (int)(gridDim.x + atomicAdd(ticket, 1u)) : (int)(q + gridDim.x);
         }
         __syncthreads();
+        if(tid == 0) {
+            // a host that waits on this counter instead of on the stream (the lone-query path: index.cpp search_one_locked)
+            // sees this query's answers first: they were written before the barrier above, and the fence orders them
+            uint32_t *const done = LGPU_SEARCH_ARG(kb, done);
+            if(done) {
+                __threadfence_system();
+                __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         q = (uint32_t)s.scal[ S_POS ];
         __syncthreads();
     }
