@@ -355,6 +355,18 @@ LANTERN_GPU_EXPORT void lantern_gpu_add_sharded(usearch_index_t, lantern_gpu_com
                                                 const void *vectors_shard, size_t n_shard, usearch_scalar_kind_t,
                                                 usearch_error_t *);
 
+/* Row-PARTITIONED search (SURVEY.md section 8e as written: "vectors sharded by row; each GPU produces its best candidates
+ * within its shard; all-gather; merge"), for indexes whose vectors do not fit one GPU's HBM: a COLLECTIVE over `comm`.  Every
+ * rank holds its OWN index over a disjoint share of the rows -- built independently with usearch_add / lantern_gpu_add_many, no
+ * exchange at build time, vector memory scales with the number of GPUs -- and passes the SAME queries.  Each searches its
+ * share (usearch_search_ef semantics, ef per share), the per-rank top-k (label, distance) lists are all-gathered in place in
+ * HBM (RCCL: xGMI; nq x k x 12 bytes per rank) and merged on the device by (distance, label).  Every rank returns the same
+ * global top-k.  Labels must be unique across the shares.  (The work-sharded build above keeps ONE graph, bit-identical to
+ * the single-GPU build, but needs every row in every GPU's HBM; this form trades that identity for capacity.) */
+LANTERN_GPU_EXPORT void lantern_gpu_search_partitioned(usearch_index_t, lantern_gpu_comm_t *, const void *queries, size_t nq,
+                                                       usearch_scalar_kind_t, size_t k, size_t ef, usearch_label_t *labels,
+                                                       float *distances, uint32_t *counts, usearch_error_t *);
+
 /* ------------------------------------------------------------------------------------------ */
 /* amgettuple paging shim: ldb_ambeginscan / ldb_amgettuple / ldb_amendscan (scan.c:24-338)     */
 /* ------------------------------------------------------------------------------------------ */

@@ -252,6 +252,58 @@ __global__ void __launch_bounds__(256) k_rerank(const uint4 *Q, const uint4 *B, 
     }
 }
 
+// k_merge_parts: the merge step of the row-partitioned search (index.cpp lantern_gpu_search_partitioned): per query, the
+// world x k per-rank results (label, distance; unused tails are label 0 / +inf) -> the global k smallest by (distance, label).
+// One wave per query; every candidate's rank is counted against all the others (world * k <= a few hundred).
+__global__ void __launch_bounds__(256) k_merge_parts(const uint64_t *labels, const float *dists, uint32_t world, uint32_t nq, uint32_t k,
+                                                     uint64_t *out_labels, float *out_dists, uint32_t *out_counts)
+{
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if(q >= nq) return;
+    const uint32_t total = world * k;
+    const size_t   part = (size_t)nq * k;  // entries per rank
+    uint32_t       valid = 0;
+    for(uint32_t i = lane; i < total; i += 64) {
+        const size_t   at = (size_t)(i / k) * part + (size_t)q * k + (i % k);
+        const float    d = dists[ at ];
+        const uint64_t l = labels[ at ];
+        const bool     live = !(d == __builtin_inff() && l == 0);  // an unused tail entry
+        uint32_t       rank = 0;
+        if(live) {
+            valid++;
+            const uint32_t dk = f2ord(d);
+            for(uint32_t j = 0; j < total; ++j) {
+                const size_t   aj = (size_t)(j / k) * part + (size_t)q * k + (j % k);
+                const float    dj = dists[ aj ];
+                const uint64_t lj = labels[ aj ];
+                if(dj == __builtin_inff() && lj == 0) continue;
+                const uint32_t djk = f2ord(dj);
+                rank += (djk < dk || (djk == dk && (lj < l || (lj == l && j < i)))) ? 1u : 0u;
+            }
+            if(rank < k) {
+                out_labels[ (size_t)q * k + rank ] = l;
+                out_dists[ (size_t)q * k + rank ] = d;
+            }
+        }
+    }
+    // how many came out, and the unused tail in the library's convention
+    for(int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+    const uint32_t got = valid < k ? valid : k;
+    for(uint32_t i = got + lane; i < k; i += 64) {
+        out_labels[ (size_t)q * k + i ] = 0;
+        out_dists[ (size_t)q * k + i ] = __builtin_inff();
+    }
+    if(lane == 0 && out_counts) out_counts[ q ] = got;
+}
+
+hipError_t launch_merge_parts(const uint64_t *labels, const float *dists, uint32_t world, uint32_t nq, uint32_t k, uint64_t *out_labels,
+                              float *out_dists, uint32_t *out_counts, hipStream_t stream)
+{
+    if(nq == 0 || k == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_parts, dim3((nq + 3) / 4), dim3(256), 0, stream, labels, dists, world, nq, k, out_labels, out_dists, out_counts);
+    return hipGetLastError();
+}
+
 // f16 rows (8 halves per chunk) -> f32 rows (4 floats per chunk) for the MFMA contraction
 __global__ void __launch_bounds__(256) k_dequant_f16(const uint4 *src, size_t nchunks, uint4 *dst)
 {

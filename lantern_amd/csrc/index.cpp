@@ -1163,6 +1163,66 @@ void lantern_gpu_add_sharded(usearch_index_t h, lantern_gpu_comm_t *comm, const 
     if(!add_sharded_locked(ix, (Comm *)comm, labels, vectors, n_shard, (int)kind)) FAIL(e, ix->err.c_str());
 }
 
+// Row-partitioned search (include/lantern_gpu.h): COLLECTIVE.  Every rank searches the SAME queries in its OWN index -- a
+// disjoint share of the rows, built independently -- the per-rank top-k lists are all-gathered in place in HBM (RCCL: over
+// xGMI) and merged on the device by (distance, label).
+void lantern_gpu_search_partitioned(usearch_index_t h, lantern_gpu_comm_t *comm_, const void *queries, size_t nq, usearch_scalar_kind_t kind,
+                                    size_t k, size_t ef, usearch_label_t *labels, float *distances, uint32_t *counts, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    Comm *comm = (Comm *)comm_;
+    if(!comm) { FAIL(e, "lantern_gpu: null communicator"); return; }
+    if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the queries does not match the index"); return; }
+    if(nq == 0 || k == 0) return;
+    if(!queries || !labels || !distances) { FAIL(e, "lantern_gpu: null buffer"); return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    const int    W = comm->world, R = comm->rank;
+    const size_t part = nq * k;
+    const size_t row_words = (size_t)ix->chunks * 4;
+    const size_t in_bytes = input_bytes(ix, (int)kind);
+    std::vector<uint32_t> padded(nq * row_words);
+    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
+    char *dq = (char *)scratch(ix, 5, nq * row_words * 4);
+    // [W][nq][k] labels | [W][nq][k] distances | merged labels | merged distances | merged counts
+    char *dall = (char *)scratch(ix, 6, (size_t)W * part * 12 + part * 12 + nq * 4 + 64);
+    if(!dq || !dall) { FAIL(e, ix->err.c_str()); return; }
+    uint64_t *g_lab = (uint64_t *)dall;
+    float    *g_dist = (float *)(dall + (size_t)W * part * 8);
+    uint64_t *m_lab = (uint64_t *)(dall + (size_t)W * part * 12);
+    float    *m_dist = (float *)((char *)m_lab + part * 8);
+    uint32_t *m_cnt = (uint32_t *)((char *)m_dist + part * 4);
+    bool      ok = hipMemcpyAsync(dq, padded.data(), nq * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    if(ix->n == 0) {  // an empty share contributes only unused entries
+        ok = ok && hipMemsetAsync(g_lab + (size_t)R * part, 0, part * 8, ix->stream) == hipSuccess;
+        std::vector<float> inf(part, __builtin_inff());
+        ok = ok && hipMemcpyAsync(g_dist + (size_t)R * part, inf.data(), part * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;  // `inf` is a local
+    } else {
+        ok = ok && run_search_device(ix, (const uint4 *)dq, nq, k, ef, 0, g_lab + (size_t)R * part, g_dist + (size_t)R * part, nullptr, nullptr,
+                                     nullptr, nullptr, ix->stream, ix->search_waves);
+    }
+    if(ok && W > 1) {
+        std::vector<size_t> off(W), cnt(W);
+        for(int r = 0; r < W; ++r) { off[ r ] = (size_t)r * part * 8; cnt[ r ] = part * 8; }
+        ok = comm->allgatherv_device(g_lab, off.data(), cnt.data(), ix->stream);
+        for(int r = 0; r < W; ++r) { off[ r ] = (size_t)r * part * 4; cnt[ r ] = part * 4; }
+        ok = ok && comm->allgatherv_device(g_dist, off.data(), cnt.data(), ix->stream);
+        if(!ok) set_err(ix, "lantern_gpu: exchange of the per-rank results failed: " + comm->err);
+    }
+    ok = ok && launch_merge_parts(g_lab, g_dist, (uint32_t)W, (uint32_t)nq, (uint32_t)k, m_lab, m_dist, m_cnt, ix->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(labels, m_lab, part * 8, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(distances, m_dist, part * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    if(counts) ok = ok && hipMemcpyAsync(counts, m_cnt, nq * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    ok = ok && comm->wait(ix->stream);
+    if(!ok) {
+        if(ix->err.empty()) set_err(ix, comm->err.empty() ? "lantern_gpu: HIP failure during the partitioned search" : comm->err);
+        FAIL(e, ix->err.c_str());
+    }
+}
+
 uint64_t lantern_gpu_graph_checksum(usearch_index_t h, usearch_error_t *e)
 {
     CLEAR(e);

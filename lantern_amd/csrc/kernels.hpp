@@ -131,6 +131,8 @@ hipError_t launch_pq_decode(float *rows, uint32_t row_floats, uint32_t first, ui
                             const uint8_t *codes, hipStream_t stream);
 
 // f32 rows -> the stored rows of an f16 / i8 / b1 index, on the device (the rules of pad_row, element for element)
+hipError_t launch_merge_parts(const uint64_t *labels, const float *dists, uint32_t world, uint32_t nq, uint32_t k, uint64_t *out_labels,
+                              float *out_dists, uint32_t *out_counts, hipStream_t stream);
 hipError_t launch_store_quantised(const float *src, uint32_t dims, uint32_t count, int kind, uint32_t *rows, uint32_t row_words, hipStream_t stream);
 
 // ||row||^2 of rows [first, first + count) into norm2 (cosine metrics only; no-op otherwise)
