@@ -115,8 +115,15 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     // The tile's 128 + 128 squared norms go through LDS once (the K loop ended with a barrier, As / Bs are free)
     // instead of 64 dependent global loads per thread.
-    if(tid < BM) As[ tid ] = q0 + tid < nq ? qn[ q0 + tid ] : 0.f;
-    else Bs[ tid - BM ] = c0 + (tid - BM) < nb ? bn[ c0 + (tid - BM) ] : 0.f;
+    // Cosine: the tile's 256 norms become 1 / sqrt(norm) here (0 stays 0: the zero-norm rules below test for it), so that an
+    // output costs two multiplies instead of two IEEE square roots and a divide -- 64 of those per lane were ~8 % of a tile.
+    // (These distances pick candidates / meet the 1e-5 tolerance; exact results are re-ranked in the walk's own order.)
+    {
+        float nv = tid < BM ? (q0 + tid < nq ? qn[ q0 + tid ] : 0.f) : (c0 + (tid - BM) < nb ? bn[ c0 + (tid - BM) ] : 0.f);
+        if(METRIC != M_L2SQ) nv = nv == 0.f ? 0.f : 1.f / __builtin_sqrtf(nv);
+        if(tid < BM) As[ tid ] = nv;
+        else Bs[ tid - BM ] = nv;
+    }
     __syncthreads();
 #pragma unroll
     for(int i = 0; i < 2; ++i)
@@ -135,9 +142,9 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
                     d = nq2 + nb2 - 2.f * dot;
                     d = d < 0.f ? 0.f : d;
                 } else {
-                    if(nq2 == 0.f && nb2 == 0.f) d = 0.f;
+                    if(nq2 == 0.f && nb2 == 0.f) d = 0.f;  // (nq2 / nb2 hold the INVERSE roots here)
                     else if(nq2 == 0.f || nb2 == 0.f) d = 1.f;
-                    else d = 1.f - dot / (__builtin_sqrtf(nq2) * __builtin_sqrtf(nb2));
+                    else d = 1.f - dot * (nq2 * nb2);
                 }
                 if(q < nq && c < nb) out[ (size_t)q * ldo + c ] = d;
             }
