@@ -46,9 +46,23 @@ __global__ void __launch_bounds__(256) k_row_norms(const uint4 *rows, uint32_t n
 // wave read 32 different rows at one k -> 32 different banks).
 constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 1;
 
-template <int METRIC>
+// FUSED: the tile does not write its distances; an output that can still enter its query's running top-kk -- ordered distance
+// <= the kk-th best so far, read once per tile -- is appended to that query's candidate list (cand[q][CAP], cnt[q]), which
+// k_select folds into `best` after the launch.  Once a few thousand columns have been seen that is a handful of appends per
+// query and launch instead of a 268 MB matrix written here and read back there.
+struct DenseTopk
+{
+    const uint64_t *best;  // [nq][kk] running top-kk keys (ordered distance << 32 | column), ascending
+    uint32_t        kk;
+    uint64_t       *cand;  // [nq][cap]
+    uint32_t       *cnt;   // [nq] appended so far (may exceed cap: k_select reports the overflow)
+    uint32_t        cap;
+    uint32_t        c_base;  // column id of this launch's first base row
+};
+
+template <int METRIC, bool FUSED = false>
 __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, const float *B, uint32_t nb, uint32_t stride /* floats per row */,
-                                                   const float *qn, const float *bn, float *out, uint32_t ldo)
+                                                   const float *qn, const float *bn, float *out, uint32_t ldo, DenseTopk tk)
 {
     __shared__ float As[ BM * LDK ];
     __shared__ float Bs[ BN * LDK ];
@@ -123,6 +137,11 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
         if(METRIC != M_L2SQ) nv = nv == 0.f ? 0.f : 1.f / __builtin_sqrtf(nv);
         if(tid < BM) As[ tid ] = nv;
         else Bs[ tid - BM ] = nv;
+        if(FUSED && tid < BM)  // the query's current radius: the distance of its kk-th best so far (+inf while the list is short)
+        {
+            const uint32_t hi = q0 + tid < nq ? (uint32_t)(tk.best[ (size_t)(q0 + tid) * tk.kk + tk.kk - 1 ] >> 32) : 0u;
+            As[ BM + tid ] = hi == 0xFFFFFFFFu ? __builtin_inff() : ord2f(hi);  // (rows past nq: ord2f(0) = NaN, nothing passes)
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -132,12 +151,9 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
             const int      cl = wn * 64 + j * 32 + (lane & 31);
             const uint32_t c = c0 + (uint32_t)cl;
             const float    nb2 = Bs[ cl ];
-#pragma unroll
-            for(int r = 0; r < 16; ++r) {
-                const int      ql = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const uint32_t q = q0 + (uint32_t)ql;
-                const float    dot = acc[ i ][ j ][ r ], nq2 = As[ ql ];
-                float          d;
+            auto dist_of = [&](int r, float dot) {
+                const float nq2 = As[ wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ];
+                float       d;
                 if(METRIC == M_L2SQ) {
                     d = nq2 + nb2 - 2.f * dot;
                     d = d < 0.f ? 0.f : d;
@@ -146,7 +162,37 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
                     else if(nq2 == 0.f || nb2 == 0.f) d = 1.f;
                     else d = 1.f - dot * (nq2 * nb2);
                 }
-                if(q < nq && c < nb) out[ (size_t)q * ldo + c ] = d;
+                return d;
+            };
+            if constexpr(FUSED) {
+                // straight-line pass over the 16 outputs: which of them are inside their query's radius?  (A float compare
+                // orders like the keys' f2ord; NaN never passes; rows past nq carry a NaN radius.)  Then the rare appends.
+                uint32_t pass = 0;
+#pragma unroll
+                for(int r = 0; r < 16; ++r) {
+                    const int ql = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    pass |= (dist_of(r, acc[ i ][ j ][ r ]) <= As[ BM + ql ] ? 1u : 0u) << r;
+                }
+                if(c >= nb) pass = 0;
+                while(pass) {
+                    const int r = __builtin_ctz(pass);
+                    pass &= pass - 1;
+                    float dot = 0.f;
+#pragma unroll
+                    for(int rr = 0; rr < 16; ++rr)
+                        if(rr == r) dot = acc[ i ][ j ][ rr ];
+                    const float    d = dist_of(r, dot);
+                    const uint32_t q = q0 + (uint32_t)(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                    const uint32_t p = atomicAdd(&tk.cnt[ q ], 1u);
+                    if(p < tk.cap) tk.cand[ (size_t)q * tk.cap + p ] = ((uint64_t)f2ord(d) << 32) | (uint64_t)(tk.c_base + c);
+                }
+            } else {
+#pragma unroll
+                for(int r = 0; r < 16; ++r) {
+                    const uint32_t q = q0 + (uint32_t)(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                    const float    d = dist_of(r, acc[ i ][ j ][ r ]);
+                    if(q < nq && c < nb) out[ (size_t)q * ldo + c ] = d;
+                }
             }
         }
 }
@@ -197,13 +243,24 @@ __device__ void bitonic_sort_lds(uint64_t *a, int n /* power of two */)
         }
 }
 
-__global__ void __launch_bounds__(256) k_select(const float *dist, uint32_t ldo, uint32_t ncols, uint32_t c_base, uint64_t *best, uint32_t kk)
+// With `cand` (the fused contraction's candidate lists) the source is cand[q][0 .. min(cand_cnt[q], cap)) -- ready-made keys --
+// and cand_cnt[q] is reset; a list that overflowed its capacity raises *overflow (the caller then repeats the search unfused).
+__global__ void __launch_bounds__(256) k_select(const float *dist, uint32_t ldo, uint32_t ncols, uint32_t c_base, uint64_t *best, uint32_t kk,
+                                                const uint64_t *cand, uint32_t *cand_cnt, uint32_t cap, uint32_t *overflow)
 {
     __shared__ uint64_t buf[ SEL_BUF ];
     __shared__ int      cnt;
     __shared__ uint64_t tau;
     const uint32_t q = blockIdx.x;
     const float   *row = dist + (size_t)q * ldo;
+    const uint64_t *keys = nullptr;
+    if(cand) {
+        keys = cand + (size_t)q * cap;
+        const uint32_t have = cand_cnt[ q ];
+        if(have > cap && threadIdx.x == 0) atomicOr(overflow, 1u);
+        ncols = have < cap ? have : cap;
+        if(ncols == 0) return;  // nothing to fold in (cand_cnt[q] is already 0)
+    }
     uint64_t      *mine = best + (size_t)q * kk;
     for(int i = threadIdx.x; i < SEL_BUF; i += blockDim.x) buf[ i ] = i < (int)kk ? mine[ i ] : ~0ull;
     if(threadIdx.x == 0) { cnt = (int)kk; tau = mine[ kk - 1 ]; }
@@ -213,7 +270,7 @@ __global__ void __launch_bounds__(256) k_select(const float *dist, uint32_t ldo,
         for(int u = 0; u < 4; ++u) {
             const uint32_t c = base + u * blockDim.x + threadIdx.x;
             if(c < ncols) {
-                const uint64_t key = ((uint64_t)f2ord(row[ c ]) << 32) | (uint64_t)(c_base + c);
+                const uint64_t key = keys ? keys[ c ] : ((uint64_t)f2ord(row[ c ]) << 32) | (uint64_t)(c_base + c);
                 if(key < tau) {
                     const int p = atomicAdd(&cnt, 1);
                     if(p < SEL_BUF) buf[ p ] = key;
@@ -224,13 +281,16 @@ __global__ void __launch_bounds__(256) k_select(const float *dist, uint32_t ldo,
         // at most 1024 new entries per round, so sorting whenever the buffer is more than half full
         // guarantees the next round fits
         if(cnt > SEL_BUF / 2 || base + blockDim.x * 4 >= ncols) {
-            bitonic_sort_lds(buf, SEL_BUF);
+            int n2 = 64;  // the buffer holds cnt keys, ~0 beyond: sort the smallest power of two that covers them
+            while(n2 < cnt && n2 < SEL_BUF) n2 <<= 1;
+            bitonic_sort_lds(buf, n2);
             for(int i = (int)kk + threadIdx.x; i < SEL_BUF; i += blockDim.x) buf[ i ] = ~0ull;
             if(threadIdx.x == 0) { cnt = (int)kk; tau = buf[ kk - 1 ]; }
             __syncthreads();
         }
     }
     for(int i = threadIdx.x; i < (int)kk; i += blockDim.x) mine[ i ] = buf[ i ];
+    if(cand && threadIdx.x == 0) cand_cnt[ q ] = 0;
 }
 
 // k_rerank: exact-order distances of the kk survivors, then the k smallest by (distance, slot)
@@ -387,12 +447,32 @@ hipError_t launch_dense(int metric, const uint4 *Q, uint32_t nq, const uint4 *B,
         return hipGetLastError();
     }
     const uint32_t tiles = ((nq + BM - 1) / BM) * ((nb + BN - 1) / BN);
+    const DenseTopk none = { nullptr, 0, nullptr, nullptr, 0, 0 };
     if(metric == M_L2SQ)
         hipLaunchKernelGGL((k_dense_f32<M_L2SQ>), dim3(tiles), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn, bn,
-                           out, ldo);
+                           out, ldo, none);
     else
         hipLaunchKernelGGL((k_dense_f32<M_COS>), dim3(tiles), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn, bn,
-                           out, ldo);
+                           out, ldo, none);
+    return hipGetLastError();
+}
+
+// the contraction with the top-kk filter fused into its epilogue (l2sq / cos): candidates go to cand / cnt, see k_dense_f32
+hipError_t launch_dense_topk(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t nb, uint32_t chunks, const float *qn,
+                             const float *bn, const uint64_t *best, uint32_t kk, uint64_t *cand, uint32_t *cnt, uint32_t cap, uint32_t c_base,
+                             hipStream_t stream)
+{
+    if(nq == 0 || nb == 0) return hipSuccess;
+    if(metric != M_L2SQ && metric != M_COS) return hipErrorInvalidValue;
+    const uint32_t  stride = chunks * 4;
+    const uint32_t  tiles = ((nq + BM - 1) / BM) * ((nb + BN - 1) / BN);
+    const DenseTopk tk = { best, kk, cand, cnt, cap, c_base };
+    if(metric == M_L2SQ)
+        hipLaunchKernelGGL((k_dense_f32<M_L2SQ, true>), dim3(tiles), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn,
+                           bn, (float *)nullptr, 0u, tk);
+    else
+        hipLaunchKernelGGL((k_dense_f32<M_COS, true>), dim3(tiles), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn,
+                           bn, (float *)nullptr, 0u, tk);
     return hipGetLastError();
 }
 
@@ -400,7 +480,16 @@ hipError_t launch_select(const float *dist, uint32_t ldo, uint32_t nq, uint32_t 
                          hipStream_t stream)
 {
     if(nq == 0 || ncols == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_select, dim3(nq), dim3(256), 0, stream, dist, ldo, ncols, c_base, best, kk);
+    hipLaunchKernelGGL(k_select, dim3(nq), dim3(256), 0, stream, dist, ldo, ncols, c_base, best, kk, (const uint64_t *)nullptr, (uint32_t *)nullptr, 0u,
+                       (uint32_t *)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_select_candidates(uint32_t nq, uint64_t *best, uint32_t kk, const uint64_t *cand, uint32_t *cnt, uint32_t cap, uint32_t *overflow,
+                                    hipStream_t stream)
+{
+    if(nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_select, dim3(nq), dim3(256), 0, stream, (const float *)nullptr, 0u, 0u, 0u, best, kk, cand, cnt, cap, overflow);
     return hipGetLastError();
 }
 

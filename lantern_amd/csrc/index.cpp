@@ -1476,8 +1476,13 @@ void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uin
 // Exact k-NN of nq device-resident query rows over nb device-resident base rows (both `chunks` uint4 per row):
 // fp32-MFMA contraction in chunks of 64k base rows + running top-(k+16) + exact-order re-rank.
 // Result (device): slots[nq][k] ascending by (distance, slot), dists[nq][k].
-static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
-                             uint32_t *d_slots, float *d_dists, hipStream_t st)
+// `fused`: the f32 contractions (l2sq / cos) keep their distance matrix to themselves -- the tile epilogue appends what can still
+// enter a query's top-kk to a candidate list, folded in after every launch -- once the first kSeedCols columns have given every
+// query a radius the ordinary way.  *overflowed: a candidate list ran out of room (adversarially ordered rows): the caller repeats
+// the search unfused.
+static const size_t kSeedCols = 4096, kCandCap = 4096;
+static bool exact_knn_device_impl(int mcode, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
+                                  uint32_t *d_slots, float *d_dists, hipStream_t st, bool fused, bool *overflowed)
 {
     // kk = k plus a margin: the MFMA distances (|q|^2 + |b|^2 - 2 q.b) differ from the exact-order ones in the
     // last bits, so the survivors are re-ranked exactly and only then cut to k
@@ -1486,13 +1491,22 @@ static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, si
     const bool     i8 = mcode_is_i8(mcode);
     const bool     f16 = mcode_is_f16(mcode) || i8;  // "quantised storage": the contraction runs on an f32 copy
     const int      base_metric = mcode_base(mcode);
+    if(base_metric == M_HAMMING || nb <= kSeedCols) fused = false;
     const uint32_t fchunks = i8 ? chunks * 4 : f16 ? chunks * 2 : chunks;  // chunks of the f32 view fed to the contraction
     auto dequant = [&](const uint4 *src, size_t nchunks, uint4 *dst) { return i8 ? launch_dequant_i8(src, nchunks, dst, st) : launch_dequant_f16(src, nchunks, dst, st); };
     char  *aux = nullptr;
     float *dd = nullptr;
     uint4 *fq = nullptr, *fb = nullptr;  // f32 copies of f16 rows (queries; one chunk of base rows)
+    uint64_t *cand = nullptr;            // fused: [min(nq, QT)][kCandCap] keys, then the counters and the overflow flag
+    const size_t nqt_max = std::min(nq, QT);
+    // the distance matrix of the unfused launches: a whole chunk, or only the seed columns
     bool ok = hipMalloc((void **)&aux, (nq + nb) * 4 + 8 + nq * kk * 8) == hipSuccess &&
-              hipMalloc((void **)&dd, std::min(nq, QT) * CH * 4) == hipSuccess;
+              hipMalloc((void **)&dd, nqt_max * (fused ? kSeedCols : CH) * 4) == hipSuccess;
+    if(ok && fused) {
+        ok = hipMalloc((void **)&cand, nqt_max * kCandCap * 8 + nqt_max * 4 + 16) == hipSuccess;
+        ok = ok && hipMemsetAsync((char *)cand + nqt_max * kCandCap * 8, 0, nqt_max * 4 + 16, st) == hipSuccess;
+    }
+    uint32_t *ccnt = cand ? (uint32_t *)((char *)cand + nqt_max * kCandCap * 8) : nullptr, *cover = ccnt ? ccnt + nqt_max : nullptr;
     if(ok && f16)
         ok = hipMalloc((void **)&fq, nq * (size_t)fchunks * 16) == hipSuccess && hipMalloc((void **)&fb, CH * (size_t)fchunks * 16) == hipSuccess &&
              dequant(d_q, nq * (size_t)chunks, fq) == hipSuccess;
@@ -1500,6 +1514,7 @@ static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, si
         float    *qn = (float *)aux, *bn = qn + nq;
         uint64_t *best = (uint64_t *)(aux + (nq + nb) * 4 + ((nq + nb) % 2) * 4);
         const uint4 *qv = f16 ? fq : d_q;
+        const uint32_t ldd = (uint32_t)(fused ? kSeedCols : CH);
         ok = ok && hipMemsetAsync(best, 0xFF, nq * kk * 8, st) == hipSuccess;
         if(base_metric != M_HAMMING) ok = ok && launch_row_norms(qv, (uint32_t)nq, fchunks, qn, st) == hipSuccess;
         if(base_metric != M_HAMMING && !f16) ok = ok && launch_row_norms(d_base, (uint32_t)nb, fchunks, bn, st) == hipSuccess;
@@ -1511,21 +1526,44 @@ static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, si
                 ok = ok && launch_row_norms(fb, (uint32_t)nc, fchunks, bn + c0, st) == hipSuccess;
                 bv = fb;
             }
+            // the columns of this chunk that go the ordinary way: all of them, or (fused) the seed columns of the first chunk
+            const size_t plain = !fused ? nc : (c0 == 0 ? std::min(nc, kSeedCols) : 0);
             for(size_t q0 = 0; ok && q0 < nq; q0 += QT) {
                 const size_t nqt = std::min(QT, nq - q0);
-                ok = ok && launch_dense(base_metric, qv + q0 * fchunks, (uint32_t)nqt, bv, (uint32_t)nc, fchunks, qn + q0, bn + c0, dd, (uint32_t)CH,
-                                        st) == hipSuccess;
-                ok = ok && launch_select(dd, (uint32_t)CH, (uint32_t)nqt, (uint32_t)nc, (uint32_t)c0, best + q0 * kk, kk, st) == hipSuccess;
+                if(plain) {
+                    ok = ok && launch_dense(base_metric, qv + q0 * fchunks, (uint32_t)nqt, bv, (uint32_t)plain, fchunks, qn + q0, bn + c0, dd, ldd, st) == hipSuccess;
+                    ok = ok && launch_select(dd, ldd, (uint32_t)nqt, (uint32_t)plain, (uint32_t)c0, best + q0 * kk, kk, st) == hipSuccess;
+                }
+                if(plain < nc) {
+                    ok = ok && launch_dense_topk(base_metric, qv + q0 * fchunks, (uint32_t)nqt, bv + plain * fchunks, (uint32_t)(nc - plain), fchunks, qn + q0,
+                                                 bn + c0 + plain, best + q0 * kk, kk, cand, ccnt, (uint32_t)kCandCap, (uint32_t)(c0 + plain), st) == hipSuccess;
+                    ok = ok && launch_select_candidates((uint32_t)nqt, best + q0 * kk, kk, cand, ccnt, (uint32_t)kCandCap, cover, st) == hipSuccess;
+                }
             }
         }
         ok = ok && launch_rerank(mcode, d_q, (uint32_t)nq, d_base, chunks, best, kk, (uint32_t)k, d_slots, d_dists, st) == hipSuccess;
+        uint32_t over = 0;
+        if(fused) ok = ok && hipMemcpyAsync(&over, cover, 4, hipMemcpyDeviceToHost, st) == hipSuccess;
         ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        if(overflowed) *overflowed = over != 0;
     }
     if(aux) (void)hipFree(aux);
     if(dd) (void)hipFree(dd);
+    if(cand) (void)hipFree(cand);
     if(fq) (void)hipFree(fq);
     if(fb) (void)hipFree(fb);
     return ok;
+}
+
+static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
+                             uint32_t *d_slots, float *d_dists, hipStream_t st)
+{
+    const char *env = std::getenv("LANTERN_GPU_DENSE_FUSED");  // =0: always the unfused path (A/B, tests)
+    const bool  want_fused = !(env && std::atoi(env) == 0);
+    bool over = false;
+    if(!exact_knn_device_impl(mcode, chunks, d_base, nb, d_q, nq, k, d_slots, d_dists, st, want_fused, &over)) return false;
+    if(!over) return true;
+    return exact_knn_device_impl(mcode, chunks, d_base, nb, d_q, nq, k, d_slots, d_dists, st, false, nullptr);
 }
 
 void lantern_gpu_exact_search(usearch_index_t h, const void *queries, size_t nq, size_t k, uint32_t *slots, float *distances,

@@ -150,6 +150,11 @@ hipError_t launch_dequant_f16(const uint4 *src, size_t nchunks, uint4 *dst, hipS
 hipError_t launch_dequant_i8(const uint4 *src, size_t nchunks, uint4 *dst, hipStream_t stream);
 hipError_t launch_dense(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t nb, uint32_t chunks, const float *qn,
                         const float *bn, float *out, uint32_t ldo, hipStream_t stream);
+hipError_t launch_dense_topk(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t nb, uint32_t chunks, const float *qn,
+                             const float *bn, const uint64_t *best, uint32_t kk, uint64_t *cand, uint32_t *cnt, uint32_t cap, uint32_t c_base,
+                             hipStream_t stream);
+hipError_t launch_select_candidates(uint32_t nq, uint64_t *best, uint32_t kk, const uint64_t *cand, uint32_t *cnt, uint32_t cap, uint32_t *overflow,
+                                    hipStream_t stream);
 hipError_t launch_select(const float *dist, uint32_t ldo, uint32_t nq, uint32_t ncols, uint32_t c_base, uint64_t *best, uint32_t kk,
                          hipStream_t stream);
 hipError_t launch_rerank(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t chunks, const uint64_t *best, uint32_t kk,

@@ -288,6 +288,43 @@ def test_exact_search_matches_bruteforce(capi, oracle, metric, n, d):
     assert np.array_equal(dists, t_d)
 
 
+@pytest.mark.parametrize("metric,n,d,k", [("l2sq", 30000, 64, 10), ("cos", 70000, 40, 5), ("l2sq", 9000, 200, 100)])
+def test_exact_search_fused_epilogue_equals_the_matrix_path(capi, metric, n, d, k, monkeypatch):
+    # the contraction's fused top-k epilogue (candidate lists instead of a distance matrix) against the unfused path
+    rng = np.random.default_rng(n)
+    base, queries = rng.standard_normal((n, d), dtype=np.float32), rng.standard_normal((300, d), dtype=np.float32)
+    ix = capi.GpuIndex(metric, d, M=4, ef_construction=8, seed=1)
+    g = {"levels": np.zeros(n, np.uint8), "nbr0": np.full((n, 8), 0xFFFFFFFF, np.uint32), "upper_off": np.full(n, 0xFFFFFFFF, np.uint32),
+         "upper_nbr": np.zeros((0, 4), np.uint32), "labels": None, "entry_slot": 0, "max_level": 0}
+    ix.import_graph(base, g)  # rows only: the exact search does not look at the graph
+    monkeypatch.setenv("LANTERN_GPU_DENSE_FUSED", "0")
+    want = ix.exact_search(queries, k)
+    monkeypatch.setenv("LANTERN_GPU_DENSE_FUSED", "1")
+    got = ix.exact_search(queries, k)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_exact_search_survives_adversarially_ordered_rows(capi):
+    # rows ordered so that EVERY later row is closer to the queries than all earlier ones: every column passes the fused
+    # epilogue's radius test, the candidate lists overflow, and the search must notice and repeat itself the ordinary way
+    n, d, k = 20000, 16, 10
+    t = np.linspace(100.0, 1.0, n, dtype=np.float32)
+    base = np.zeros((n, d), dtype=np.float32)
+    base[:, 0] = t
+    base[:, 1] = np.random.default_rng(0).standard_normal(n).astype(np.float32) * 1e-3
+    queries = np.zeros((5, d), dtype=np.float32)
+    queries[:, 0] = np.array([0.0, 0.5, 0.9, -3.0, 0.99], dtype=np.float32)
+    ix = capi.GpuIndex("l2sq", d, M=4, ef_construction=8, seed=1)
+    g = {"levels": np.zeros(n, np.uint8), "nbr0": np.full((n, 8), 0xFFFFFFFF, np.uint32), "upper_off": np.full(n, 0xFFFFFFFF, np.uint32),
+         "upper_nbr": np.zeros((0, 4), np.uint32), "labels": None, "entry_slot": 0, "max_level": 0}
+    ix.import_graph(base, g)
+    slots, dists = ix.exact_search(queries, k)
+    ref = ((base[None, :, :].astype(np.float64) - queries[:, None, :]) ** 2).sum(2)
+    for qi in range(5):
+        order = np.lexsort((np.arange(n), ref[qi]))[:k]
+        assert set(slots[qi].tolist()) == set(order.tolist())
+
+
 @pytest.mark.parametrize("metric,d", [("l2sq", 768), ("cos", 768), ("l2sq", 50), ("cos", 1536)])
 def test_mfma_distance_matrix_within_tolerance(capi, oracle, metric, d):
     rng = np.random.default_rng(d)
