@@ -103,6 +103,7 @@ static bool reserve_locked(Index *ix, size_t newcap)
     if(!dev_grow(ix, (void **)&ix->d_labels, oc * 8, newcap * 8, -1)) return false;
     if(!dev_grow(ix, (void **)&ix->d_levels, oc, newcap, 0)) return false;
     if(!dev_grow(ix, (void **)&ix->d_nbr0, oc * ix->M0 * 4, newcap * ix->M0 * 4, 0xFF)) return false;
+    if(!dev_grow(ix, (void **)&ix->d_radius0, oc * 4, newcap * 4, 0xFF)) return false;  // 0xFFFFFFFF is a NaN: "no state"
     if(!dev_grow(ix, (void **)&ix->d_upper_off, oc * 4, newcap * 4, 0xFF)) return false;
     ix->cap = newcap;
     // the visited bitmaps are sized by capacity
@@ -117,6 +118,7 @@ static bool reserve_upper(Index *ix, size_t need_blocks)
     if(need_blocks <= ix->upper_cap) return true;
     size_t nc = std::max<size_t>(std::max<size_t>(ix->upper_cap * 2, need_blocks), 1024);
     if(!dev_grow(ix, (void **)&ix->d_upper_nbr, ix->upper_cap * ix->M * 4, nc * ix->M * 4, 0xFF)) return false;
+    if(!dev_grow(ix, (void **)&ix->d_radius_upper, ix->upper_cap * 4, nc * 4, 0xFF)) return false;
     ix->upper_cap = nc;
     return true;
 }
@@ -529,6 +531,19 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     ra.max_groups = split ? owner_reqs[ (size_t)R ] : (uint32_t)total_links;
     ra.reqs = d_reqs;
     ra.totals = ix->d_totals + 5;
+    // the persistent re-prune state is kept by one-GPU builds (a work-sharded build overwrites other ranks' rows wholesale);
+    // whatever changes lists without maintaining it (a sharded batch, an imported graph, the switch below) marks it stale
+    const char *rs_env = std::getenv("LANTERN_GPU_REPRUNE_STATE");  // =0: every full list takes the all-pairs path (A/B, tests)
+    const bool  use_state = !split && !(rs_env && std::atoi(rs_env) == 0);
+    if(!use_state) {
+        ix->radius_stale = true;
+    } else if(ix->radius_stale) {
+        if(ix->d_radius0) HIPCHK(ix, hipMemsetAsync(ix->d_radius0, 0xFF, ix->cap * 4, ix->stream));
+        if(ix->d_radius_upper) HIPCHK(ix, hipMemsetAsync(ix->d_radius_upper, 0xFF, ix->upper_cap * 4, ix->stream));
+        ix->radius_stale = false;
+    }
+    ra.radius0 = use_state ? ix->d_radius0 : nullptr;
+    ra.radius_upper = use_state ? ix->d_radius_upper : nullptr;
     HIPCHK(ix, launch_revlink(ix->mcode, ra, (char *)d_work + 16, (uint32_t *)d_work, ix->num_cus, ix->stream));
     prof_mark(ix, 4);
     if(split) {
@@ -908,6 +923,7 @@ bool import_graph_locked(Index *ix, size_t size, const void *vectors, const uint
     if(blocks) HIPCHK(ix, hipMemcpy(ix->d_upper_nbr, upper_nbr, blocks * ix->M * 4, hipMemcpyHostToDevice));
     ix->n = size;
     ix->upper_blocks = blocks;
+    ix->radius_stale = true;  // lists from outside: no re-prune state
     ix->entry = entry_slot;
     ix->max_level = max_level;
     return true;
@@ -1041,6 +1057,7 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
     Index *ix = H(h, e);
     if(!ix) return;
     void *ptrs[] = { ix->d_vec, ix->d_norm2, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals, ix->d_tickets,
+                     ix->d_radius0, ix->d_radius_upper,
                      ix->d_codebook, ix->d_centers, ix->d_codes };
     for(void *p : ptrs)
         if(p) (void)hipFree(p);

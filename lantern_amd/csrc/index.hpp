@@ -65,6 +65,8 @@ struct Index
     uint32_t *d_nbr0 = nullptr;
     uint32_t *d_upper_off = nullptr;
     uint32_t *d_upper_nbr = nullptr;
+    float    *d_radius0 = nullptr, *d_radius_upper = nullptr;  // re-prune state per list (kernels.hpp RevlinkArgs::radius0)
+    bool      radius_stale = false;  // lists changed without the state being maintained: reset it before the next use
     uint32_t *d_bitmaps = nullptr;
     size_t    bitmap_slots = 0, bm_words = 0;
     uint32_t *d_tickets = nullptr;  // ring of work tickets, one per launch in flight (kernels.hpp SearchArgs::ticket)

@@ -294,10 +294,33 @@ __global__ void __launch_bounds__(256) k_revlink_append(RevlinkArgs a, RevWork *
     const uint32_t room = cap - c, nreq = end - begin;
     const uint32_t take = room < nreq ? room : nreq;
     for(uint32_t t = (uint32_t)lane; t < take; t += 64) list[ c + t ] = a.reqs[ begin + t ].new_slot;
-    if(take < nreq && lane == 0) {
-        const uint32_t w = atomicAdd(work_count, 1u);
-        work[ w ].group = gi;
-        work[ w ].t_start = begin + take;
+    if(take < nreq) {
+        uint32_t t0 = begin + take;
+        // PERSISTENT STATE (RevlinkArgs::radius0): a list some earlier re-prune left full is still greedy-consistent and sorted,
+        // and its radius -- d(close, last entry) -- is on record.  A request that sorts behind the radius would be cut by the
+        // re-prune without changing anything: the leading run of such requests is dropped here, without reading a row -- the
+        // common case at a hub, across batches -- and a group made of nothing else gets no work item at all.
+        if(take == 0 && a.radius0) {
+            const float rad = level == 0 ? a.radius0[ close ] : a.radius_upper[ a.view.upper_off[ close ] + (uint32_t)(level - 1) ];
+            if(rad == rad) {  // not NaN
+                const uint64_t kr = ((uint64_t)f2ord(rad) << 32) | tie_mix(list[ cap - 1 ], close);
+                uint32_t       skipped = 0;
+                for(uint32_t base = t0; base < end; base += 64) {
+                    const uint32_t t = base + (uint32_t)lane;
+                    const bool     enters = t < end && !(kr < (((uint64_t)f2ord(a.reqs[ t < end ? t : begin ].d) << 32) | tie_mix(a.reqs[ t < end ? t : begin ].new_slot, close)));
+                    const unsigned long long m = __ballot(enters);
+                    if(m) { skipped += (uint32_t)__builtin_ctzll(m); break; }
+                    skipped += end - base < 64u ? end - base : 64u;
+                }
+                t0 += skipped;
+                if(lane == 0 && skipped && a.totals) atomicAdd(&a.totals[ 1 ], (unsigned long long)skipped);  // they count as re-prunes
+            }
+        }
+        if(t0 < end && lane == 0) {
+            const uint32_t w = atomicAdd(work_count, 1u);
+            work[ w ].group = gi;
+            work[ w ].t_start = t0;
+        }
     }
     }  // groups
 }
@@ -1279,6 +1302,11 @@ __global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_pairs(Revlink
             chain = c == (int)cap;  // the rows of the kept entries sit in `own` at their candidate indices
         }
         for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? cid[ i ] : EMPTY;
+        // what later batches may rely on (k_revlink_append): a full list out of a re-prune -> its radius; else nothing
+        if(a.radius0 && tid == 0) {
+            float *const radp = level == 0 ? a.radius0 + close : a.radius_upper + (a.view.upper_off[ close ] + (uint32_t)(level - 1));
+            *radp = chain ? lsd[ c - 1 ] : __builtin_nanf("");
+        }
     }
     if(tid == 0 && a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs); atomicAdd(&a.totals[ 1 ], (unsigned long long)reprunes); }
 }

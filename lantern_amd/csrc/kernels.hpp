@@ -84,6 +84,11 @@ struct RevlinkArgs
     uint32_t        max_groups;   // host-side upper bound on *ngroups (sizes grids and the worklist)
     const LinkReq  *reqs;         // sorted by (close, level), stable: within a group in new-slot order
     unsigned long long *totals;   // [2] cumulative pair evaluations, re-prunes
+    // Persistent re-prune state (k_revlink_pairs), or NULL: radius[node] / radius_upper[upper block] = d(node, LAST list entry)
+    // when that list is FULL, greedy-consistent and stored in ascending (distance, tie) order -- i.e. it is exactly what a
+    // re-prune left -- and NaN otherwise.  A request whose own distance sorts behind the radius is cut without reading a row;
+    // any other request to such a list starts the chain form (<= cap distances) instead of the all-pairs table.
+    float          *radius0, *radius_upper;
 };
 
 // The grouping pass (grouping.hip): the reverse-link requests of a batch, as k_connect left them (new-slot-major, EMPTY
