@@ -379,6 +379,9 @@ def build_roofline(a, c, prof, t_build, world):
         gbs = nbytes / max(ms, 1e-9) / 1e6
         out[name] = {"bound": "hbm", "algorithmic_bytes": float(nbytes), "ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gbs / HBM_PEAK_GBS}
+    out["reprune"]["note"] = ("the reference algorithm's traffic: cap + 2 rows per request to a full list.  The device cuts the requests that sort "
+                              "behind a list's recorded radius without reading a row, so this is NOT what its re-prune kernels read; the phase is "
+                              "bound by the latency of the remaining chains, not by bytes")
     return out
 
 
