@@ -1,17 +1,13 @@
 // kernels.hip -- gfx950 kernels of the HNSW distance-evaluation path.
 //
-//   k_search        usearch_search_ef  (lantern_hnsw/src/hnsw/scan.c:220-228,273-281): one workgroup per
-//                   query, persistent over the batch (six 4-wave workgroups per CU, work handed out by
-//                   ticket); greedy descent + ef-bounded base-layer walk.
-//   k_insert        the walk of usearch_add (build.c:128; server.rs:349 add_raw): per new vector, descent +
-//                   per-level ef_construction walk; the sorted results go to k_connect.
+//   (k_search and k_insert, the two walk kernels, live in search_kernel.hip / insert_kernel.hip; the walk itself in walk.hpp)
 //   k_connect       connect_new_node_: neighbour selection with the kept rows in registers; writes the new
 //                   node's lists and emits the reverse-link requests.
 //   k_revlink_*     the reverse-link half (usearch reconnect_neighbor_nodes_): k_revlink_append (one wave per
-//                   (node, level) group: append while there is room), then the re-prune of full lists by row
-//                   shape: k_revlink_regs (kept rows in registers, candidates through an LDS ring),
-//                   k_revlink_slab (column slabs through LDS), k_revlink_staged / k_revlink (rows staged whole
-//                   in LDS / read from L2).
+//                   (node, level) group: append while there is room; drop the requests that sort behind a full
+//                   list's recorded radius), then the re-prune of full lists by row shape: k_revlink_pairs
+//                   (all-pairs table, rows in registers, chain form), k_revlink_staged (rows staged whole in LDS),
+//                   k_revlink (rows read from L2); k_revlink_regs / k_revlink_slab: the round-1 kernels, for A/B runs.
 //   k_fill_norms    sqrt(||row||^2) of newly stored rows for the cosine metrics (device_common.hpp).
 //   k_apply_own_links / k_pack_lists / k_apply_lists
 //                   scatter kernels either side of the all-gathers of the work-sharded build (comm.cpp).

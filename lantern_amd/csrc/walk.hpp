@@ -9,11 +9,12 @@
 //    expanded later, so a single sorted list with an "expanded" bit per entry is equivalent:
 //    "pop the best candidate" = "first unexpanded entry"; the walk ends when there is none.
 //  * all unvisited neighbours of the popped node are evaluated at once (one G-lane group per row,
-//    several rows in flight per wave), then merged into the list in one parallel rank-merge.  The
-//    result equals inserting them one by one: the list ends up holding the ef smallest of
-//    (old list U new), whatever the order of insertion.
-//  * the visited set is an open-addressing hash set in LDS that spills to a bitmap in HBM owned by the
-//    workgroup when three quarters full (visit_test_and_set below).
+//    several rows in flight per wave), then merged into the list.  The result equals inserting them one by
+//    one: the list ends up holding the ef smallest of (old list U new), whatever the order of insertion.
+//    Two forms of the list: in one wave's REGISTERS (search_level_reg: ef <= 128, the usual case; a hop's
+//    bookkeeping split over two waves) and in LDS with a parallel rank-merge (search_level: any ef).
+//  * the visited set is an open-addressing hash set in LDS (four-slot buckets) that spills to a bitmap in HBM
+//    owned by the workgroup when three quarters full (visit_test_and_set / hop_is_new below).
 //
 // All functions must be called by every thread of the workgroup (they contain barriers).
 #pragma once
