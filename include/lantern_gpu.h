@@ -207,6 +207,12 @@ LANTERN_GPU_EXPORT void lantern_gpu_add_with_level(usearch_index_t, usearch_labe
 LANTERN_GPU_EXPORT void lantern_gpu_search_batch(usearch_index_t, const void *queries, size_t nq,
                                                  usearch_scalar_kind_t, size_t k, size_t ef, usearch_label_t *labels,
                                                  float *distances, uint32_t *counts, usearch_error_t *);
+/* The same for a caller that keeps TWO batches in flight (`lane` 0 or 1, one caller thread per lane): each lane has its own
+ * stream and staging buffers inside the index, and the wait for the answers does not hold the index's lock, so the lanes'
+ * launches overlap on the device (the scan-side service below runs its two dispatchers over this). */
+LANTERN_GPU_EXPORT void lantern_gpu_search_batch_lane(usearch_index_t, int lane, const void *queries, size_t nq,
+                                                      usearch_scalar_kind_t, size_t k, size_t ef, usearch_label_t *labels,
+                                                      float *distances, uint32_t *counts, usearch_error_t *);
 /* Same, every buffer already in device memory, asynchronous on `stream` (a hipStream_t; NULL =
  * the default stream).  slots (u32 internal ids), counts, dist_evals (D) and expansions (E) may
  * be NULL.  `skip` drops that many leading results per query (streaming continuation).
@@ -441,7 +447,10 @@ typedef struct lantern_scan_client lantern_scan_client_t;
  * otherwise *err points at a message that outlives the call */
 typedef int (*lantern_batch_search_fn)(void *ctx, const void *queries, size_t nq, size_t vec_bytes, size_t k, size_t ef,
                                        uint64_t *labels, float *distances, uint32_t *counts, const char **err);
-/* serve `index` (built, loaded or mirrored; it must outlive the server) on host:port (port 0 = ephemeral) */
+/* serve `index` (built, loaded or mirrored; it must outlive the server) on host:port (port 0 = ephemeral).  Two dispatcher
+ * threads take turns -- one forms the next batch while the other's is being searched, each on its own lane of the index
+ * (lantern_gpu_search_batch_lane) -- so consecutive launches overlap on the device.  A caller-supplied back end
+ * (lantern_scan_server_start_fn) is entered by one thread only, unless LANTERN_SCAN_LANES=2 says it may be entered by two. */
 LANTERN_GPU_EXPORT lantern_scan_server_t *lantern_scan_server_start(usearch_index_t index, const char *host, int port,
                                                                     size_t max_batch, unsigned max_wait_us, usearch_error_t *);
 /* the same front end over any batch search function (tests; a host that shards queries over several GPUs) */

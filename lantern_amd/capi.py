@@ -96,7 +96,7 @@ EXPORTS = [
     "lantern_gpu_graph_checksum", "lantern_gpu_comm_unique_id", "lantern_gpu_comm_init_rccl", "lantern_gpu_comm_init_host",
     "lantern_gpu_comm_init_local", "lantern_gpu_comm_free", "lantern_gpu_comm_rank", "lantern_gpu_comm_world",
     "lantern_gpu_comm_set_timeout", "lantern_gpu_comm_stats", "lantern_gpu_comm_allgatherv_host",
-    "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded", "lantern_gpu_search_partitioned",
+    "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded", "lantern_gpu_search_partitioned", "lantern_gpu_search_batch_lane",
     "lantern_gpu_level_for", "lantern_gpu_plan_batch",
     "lantern_scan_server_start", "lantern_scan_server_start_fn", "lantern_scan_server_port", "lantern_scan_server_stats",
     "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_search_next",
@@ -207,6 +207,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_shard_range": (None, [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]),
         "lantern_gpu_add_sharded": (None, [vp, vp, vp, vp, sz, i32, err]),
         "lantern_gpu_search_partitioned": (None, [vp, vp, vp, sz, i32, sz, sz, vp, vp, vp, err]),
+        "lantern_gpu_search_batch_lane": (None, [vp, i32, vp, sz, i32, sz, sz, vp, vp, vp, err]),
         "lantern_gpu_level_for": (i32, [u64, u64, u32]),
         "lantern_gpu_plan_batch": (sz, [sz, i32, vp, sz, sz, sz]),
         "lantern_scan_server_start": (vp, [vp, C.c_char_p, i32, sz, C.c_uint, err]),
@@ -443,6 +444,16 @@ class GpuIndex:
         dists = np.zeros((nq, k), dtype=np.float32)
         counts = np.zeros(nq, dtype=np.uint32)
         _call("lantern_gpu_search_batch", self.h, _ptr(Q), nq, _kind(self.metric), k, ef, _ptr(labels), _ptr(dists), _ptr(counts))
+        return labels, dists, counts
+
+    def search_batch_lane(self, lane, queries, k, ef=0):
+        """lantern_gpu_search_batch for a caller that keeps two batches in flight (lane 0 / 1, one thread each)."""
+        Q = _rows(queries, self.metric)
+        nq = Q.shape[0]
+        labels = np.zeros((nq, k), dtype=np.uint64)
+        dists = np.zeros((nq, k), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        _call("lantern_gpu_search_batch_lane", self.h, lane, _ptr(Q), nq, _kind(self.metric), k, ef, _ptr(labels), _ptr(dists), _ptr(counts))
         return labels, dists, counts
 
     def search_partitioned(self, comm: "Comm", queries, k, ef=0):

@@ -1071,6 +1071,8 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
         if(ix->slot_done[ sl ]) (void)hipEventDestroy(ix->slot_done[ sl ]);
     }
     if(ix->insert_done) (void)hipEventDestroy(ix->insert_done);
+    for(hipStream_t ls : ix->lane_stream)
+        if(ls) (void)hipStreamDestroy(ls);
     delete ix;
 }
 
@@ -1409,6 +1411,57 @@ void lantern_gpu_search_batch(usearch_index_t h, const void *queries, size_t nq,
     ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
     if(!ok) {
         if(ix->err.empty()) set_err(ix, "lantern_gpu: HIP failure during batched search");
+        FAIL(e, ix->err.c_str());
+    }
+}
+
+// The same as lantern_gpu_search_batch for a caller that keeps TWO batches in flight (the scan-side service: one dispatcher
+// executes a batch while the other collects the next): each lane has its own stream and staging buffers, the index mutex is
+// held only while the lane's copies and its launch are queued, and the wait for the answers happens outside it -- so the two
+// lanes' launches overlap on the device (each in its own visited-bitmap slab: acquire_search_slot).
+void lantern_gpu_search_batch_lane(usearch_index_t h, int lane, const void *queries, size_t nq, usearch_scalar_kind_t kind, size_t k, size_t ef,
+                                   usearch_label_t *labels, float *distances, uint32_t *counts, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    if(lane < 0 || lane > 1) { FAIL(e, "lantern_gpu: lane must be 0 or 1"); return; }
+    if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the queries does not match the index"); return; }
+    if(nq == 0 || k == 0) return;
+    if(!queries || !labels || !distances) { FAIL(e, "lantern_gpu: null buffer"); return; }
+    const size_t row_words = (size_t)ix->chunks * 4;
+    const size_t in_bytes = input_bytes(ix, (int)kind);
+    std::vector<uint32_t> padded(nq * row_words);  // (chunks and the scalar kind are fixed at init: no lock needed yet)
+    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
+    hipStream_t st = nullptr;
+    bool        ok = true;
+    std::string msg;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+        if(!ix->lane_stream[ lane ] && hipStreamCreateWithFlags(&ix->lane_stream[ lane ], hipStreamNonBlocking) != hipSuccess) {
+            FAIL(e, "lantern_gpu: cannot create the lane's stream");
+            return;
+        }
+        st = ix->lane_stream[ lane ];
+        char *dq = (char *)scratch(ix, 12 + 2 * lane, nq * row_words * 4);
+        char *dout = (char *)scratch(ix, 13 + 2 * lane, nq * k * 12 + nq * 4 + 64);
+        if(!dq || !dout) { FAIL(e, ix->err.c_str()); return; }
+        uint64_t *d_lab = (uint64_t *)dout;
+        float    *d_dist = (float *)(dout + nq * k * 8);
+        uint32_t *d_cnt = (uint32_t *)(dout + nq * k * 12);
+        ok = hipMemcpyAsync(dq, padded.data(), nq * row_words * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = ok && run_search_device(ix, (const uint4 *)dq, nq, k, ef, 0, d_lab, d_dist, nullptr, d_cnt, nullptr, nullptr, st, ix->search_waves);
+        ok = ok && hipMemcpyAsync(labels, d_lab, nq * k * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(distances, d_dist, nq * k * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+        if(counts) ok = ok && hipMemcpyAsync(counts, d_cnt, nq * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+        if(!ok) msg = ix->err.empty() ? "lantern_gpu: HIP failure during batched search" : ix->err;
+    }
+    // the wait is the long part: outside the mutex, so that the other lane can queue its batch meanwhile
+    if(hipStreamSynchronize(st) != hipSuccess && ok) { ok = false; msg = "lantern_gpu: HIP failure during batched search"; }
+    if(!ok) {
+        std::lock_guard<std::mutex> g(ix->mu);
+        set_err(ix, msg);
         FAIL(e, ix->err.c_str());
     }
 }

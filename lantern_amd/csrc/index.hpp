@@ -75,8 +75,9 @@ struct Index
     unsigned long long *d_totals = nullptr;  // [0..1] search D,E  [2..4] insert D,E,refine  [5] revlink pairs
 
     // scratch (grown on demand)
-    void  *d_scratch[ 12 ] = {};
-    size_t scratch_bytes[ 12 ] = {};
+    void  *d_scratch[ 16 ] = {};  // [12..15]: queries / answers of the two lanes of lantern_gpu_search_batch_lane
+    size_t scratch_bytes[ 16 ] = {};
+    hipStream_t lane_stream[ 2 ] = { nullptr, nullptr };  // created on first use
 
     // ---- host mirrors ------------------------------------------------------------------------------
     std::vector<uint64_t> labels;

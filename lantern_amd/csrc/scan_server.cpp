@@ -35,6 +35,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -100,7 +101,9 @@ struct lantern_scan_server
     unsigned                max_wait_us = 200;
     int                     listen_fd = -1, port = 0;
     std::atomic<bool>       stop{ false };
-    std::thread             accept_thread, dispatch_thread;
+    std::thread             accept_thread, dispatch_thread[ 2 ];
+    int                     lanes = 1;   // dispatchers: one collects the next batch while the other's batch is on the device
+    std::mutex              collect_mu;  // held by the dispatcher that is collecting (one batch is formed at a time)
     std::mutex              mu;  // queue + connection list
     std::condition_variable cv;
     std::deque<std::shared_ptr<Pending>> queue;
@@ -116,12 +119,14 @@ struct lantern_scan_server
 
 namespace {
 
+thread_local int tl_lane = 0;  // which dispatcher this thread is (the default backend's lane)
+
 int default_backend(void *ctx, const void *queries, size_t nq, size_t, size_t k, size_t ef, uint64_t *labels, float *dists, uint32_t *counts,
                     const char **err)
 {
     lantern_scan_server *s = (lantern_scan_server *)ctx;
     usearch_error_t      e = nullptr;
-    lantern_gpu_search_batch(s->index, queries, nq, s->kind, k, ef, labels, dists, counts, &e);
+    lantern_gpu_search_batch_lane(s->index, tl_lane, queries, nq, s->kind, k, ef, labels, dists, counts, &e);
     if(e) { *err = e; return 1; }
     return 0;
 }
@@ -135,8 +140,13 @@ void fulfil(const std::shared_ptr<Pending> &p)
     p->cv.notify_all();
 }
 
-void dispatch_loop(lantern_scan_server *s)
+// Two dispatchers take turns: whoever holds collect_mu forms the next batch (first request, the window, up to max_batch) while
+// the other one's batch is being searched, so the device always has the next launch queued behind the current one -- and, the
+// two lanes' launches running in separate slots of the index, overlapping it.  Batching is as with one dispatcher: batches
+// are formed one at a time, from everything that arrived meanwhile.
+void dispatch_loop(lantern_scan_server *s, int lane)
 {
+    tl_lane = lane;
     std::vector<std::shared_ptr<Pending>> batch;
     std::vector<uint8_t>  qbuf;
     std::vector<uint64_t> labels;
@@ -145,6 +155,7 @@ void dispatch_loop(lantern_scan_server *s)
     for(;;) {
         batch.clear();
         {
+            std::lock_guard<std::mutex>  turn(s->collect_mu);
             std::unique_lock<std::mutex> lk(s->mu);
             s->cv.wait(lk, [&] { return s->stop.load() || !s->queue.empty(); });
             if(s->stop && s->queue.empty()) return;
@@ -332,7 +343,7 @@ lantern_scan_server *start_common(lantern_scan_server *s, const char *host, int 
         delete s;
         return nullptr;
     }
-    s->dispatch_thread = std::thread(dispatch_loop, s);
+    for(int l = 0; l < s->lanes; ++l) s->dispatch_thread[ l ] = std::thread(dispatch_loop, s, l);
     s->accept_thread = std::thread(accept_loop, s);
     return s;
 }
@@ -363,6 +374,7 @@ lantern_scan_server_t *lantern_scan_server_start(usearch_index_t index, const ch
     s->vec_bytes = ham ? (m.dimensions + 7) / 8 : m.dimensions * 4;
     s->fn = default_backend;
     s->fn_ctx = s;
+    s->lanes = 2;  // lantern_gpu_search_batch_lane
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }
 
@@ -375,6 +387,8 @@ lantern_scan_server_t *lantern_scan_server_start_fn(lantern_batch_search_fn fn, 
     s->fn = fn;
     s->fn_ctx = ctx;
     s->vec_bytes = vec_bytes;
+    // a caller-supplied backend is called from ONE thread unless LANTERN_SCAN_LANES=2 says it may be entered by two at a time
+    if(const char *ln = std::getenv("LANTERN_SCAN_LANES")) s->lanes = std::atoi(ln) >= 2 ? 2 : 1;
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }
 
@@ -399,7 +413,8 @@ void lantern_scan_server_stop(lantern_scan_server_t *s)
     }
     s->cv.notify_all();
     if(s->accept_thread.joinable()) s->accept_thread.join();
-    if(s->dispatch_thread.joinable()) s->dispatch_thread.join();
+    for(auto &t : s->dispatch_thread)
+        if(t.joinable()) t.join();
     // requests that were still queued when the dispatcher left: answer them so that their readers can finish
     std::deque<std::shared_ptr<Pending>> rest;
     {

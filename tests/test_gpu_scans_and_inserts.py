@@ -4,6 +4,8 @@ import ctypes as C
 import math
 import struct
 
+import threading
+
 import numpy as np
 import pytest
 
@@ -107,6 +109,34 @@ def test_searches_on_two_streams_share_the_index_safely(capi, monkeypatch):
         for j in range(len(more)):
             assert np.array_equal(o_l[j].download((nq, k), np.uint64), want[j & 1][0])
             assert np.array_equal(o_d[j].download((nq, k), np.float32), want[j & 1][1])
+
+
+def test_two_lanes_of_the_host_buffer_search_run_side_by_side(capi):
+    """lantern_gpu_search_batch_lane: two caller threads, one lane each, many rounds; every answer equals the plain batch search."""
+    rng = np.random.default_rng(31)
+    n, d, k = 20000, 32, 10
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    ix = capi.GpuIndex("l2sq", d, M=12, ef_construction=48, ef=48, seed=3)
+    ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    ix.flush()
+    qs = [rng.standard_normal((700 + 300 * lane, d), dtype=np.float32) for lane in (0, 1)]
+    want = [ix.search_batch(q, k) for q in qs]
+    errs = []
+
+    def run(lane):
+        try:
+            for _ in range(20):
+                lab, dist, cnt = ix.search_batch_lane(lane, qs[lane], k)
+                assert np.array_equal(lab, want[lane][0]) and np.array_equal(dist, want[lane][1]) and np.array_equal(cnt, want[lane][2])
+        except Exception as e:  # noqa: BLE001
+            errs.append((lane, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(lane,)) for lane in (0, 1)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    with pytest.raises(capi.LanternGpuError, match="lane must be 0 or 1"):
+        ix.search_batch_lane(2, qs[0], k)
 
 
 def test_inserts_and_searches_on_other_streams_are_ordered(capi, monkeypatch):

@@ -67,6 +67,55 @@ def test_many_clients_are_batched_and_answers_routed(capi):
     assert {(c[1], c[2]) for c in calls} == {(5, 40), (8, 0)}  # one launch per distinct (k, ef), never mixed
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_two_dispatchers_keep_two_batches_in_flight(capi, monkeypatch, lanes):
+    """One dispatcher forms the next batch while the other's batch is being searched (the default back end runs them on two
+    lanes of the index).  A caller-supplied back end is entered by one thread unless LANTERN_SCAN_LANES=2 allows two."""
+    import time
+
+    if lanes == 2:
+        monkeypatch.setenv("LANTERN_SCAN_LANES", "2")
+    else:
+        monkeypatch.delenv("LANTERN_SCAN_LANES", raising=False)
+    lock, state, calls = threading.Lock(), {"in": 0, "peak": 0}, []
+    inner = fake_backend(calls)
+
+    def slow(queries, k, ef):
+        with lock:
+            state["in"] += 1
+            state["peak"] = max(state["peak"], state["in"])
+        time.sleep(0.03)  # (releases the GIL: the other dispatcher can enter meanwhile)
+        out = inner(queries, k, ef)
+        with lock:
+            state["in"] -= 1
+        return out
+
+    srv = capi.ScanServer(batch_fn=slow, vec_bytes=16, max_batch=4, max_wait_us=500)
+    nthreads, per = 12, 5
+    got, errs = {}, []
+
+    def session(t):
+        try:
+            c = capi.ScanClient(srv.host, srv.port)
+            for i in range(per):
+                ident = t * 100 + i
+                lab, _ = c.search(np.array([ident, 0, 0, 0], dtype=np.float32), 3)
+                got[ident] = lab.copy()
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=session, args=(t,)) for t in range(nthreads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    st = srv.stats()
+    srv.stop()
+    assert not errs, errs
+    assert len(got) == nthreads * per and all(lab.tolist() == [i * 1000, i * 1000 + 1, i * 1000 + 2] for i, lab in got.items())
+    assert st["requests"] == nthreads * per and sum(c[0] for c in calls) == nthreads * per
+    assert state["peak"] == lanes, state
+
+
 def ranked_backend(table):
     """A back end with a real ranking: rows of `table` (n x 4 f32) by squared distance to the query, labels = row + 1,
     except row 3 whose label is 0 (a deleted row, skipped by the scan: scan.c:296-300)."""
