@@ -858,7 +858,11 @@ size_t search_one_locked(Index *ix, Cursor *cur, const void *query, int kind, si
                                 (uint32_t *)(dev + flag_off));
     if(ok) {
         for(unsigned spins = 0; *h_done == 0; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            __asm__ __volatile__("" ::: "memory");
+#endif
             if((spins & 0x3FFF) == 0x3FFF) {  // every ~100 us: is the kernel still there?
                 const hipError_t st = hipStreamQuery(ix->stream);
                 if(st == hipErrorNotReady) continue;
