@@ -101,7 +101,7 @@ EXPORTS = [
     "lantern_scan_server_start", "lantern_scan_server_start_fn", "lantern_scan_server_port", "lantern_scan_server_stats",
     "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_search_next",
     "lantern_scan_client_close", "lantern_scan_begin_client",
-    "lantern_mirror_acquire", "lantern_mirror_index", "lantern_mirror_version", "lantern_mirror_advance", "lantern_mirror_release",
+    "lantern_mirror_acquire", "lantern_mirror_index", "lantern_mirror_version", "lantern_mirror_rebind", "lantern_mirror_advance", "lantern_mirror_release",
     "lantern_mirror_invalidate", "lantern_mirror_set_capacity", "lantern_mirror_stats",
 ]
 
@@ -223,6 +223,7 @@ def lib() -> C.CDLL:
         "lantern_mirror_acquire": (vp, [u64, u64, C.POINTER(InitOptions), vp, vp, sz, err]),
         "lantern_mirror_index": (vp, [vp]),
         "lantern_mirror_version": (u64, [vp]),
+        "lantern_mirror_rebind": (None, [vp, C.POINTER(InitOptions)]),
         "lantern_mirror_advance": (None, [vp, u64]),
         "lantern_mirror_release": (None, [vp]),
         "lantern_mirror_invalidate": (None, [u64]),
@@ -593,6 +594,7 @@ class Mirror:
         o.retriever = C.cast(self._cb, C.c_void_p)
         self._cb_mut = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)(lambda ctx, slot: (retriever_mut or retriever)(int(slot)))
         o.retriever_mut = C.cast(self._cb_mut, C.c_void_p)
+        self._opts = o
         buf = C.create_string_buffer(bytes(header), USEARCH_HEADER_SIZE)
         self.m = _call("lantern_mirror_acquire", relation, version, C.byref(o), None, C.cast(buf, C.c_void_p), min_vectors)
         self.index = None
@@ -612,6 +614,10 @@ class Mirror:
     @property
     def version(self):
         return int(lib().lantern_mirror_version(self.m))
+
+    def rebind(self):
+        """Bind THIS holder's retriever callbacks to the shared mirror (the latest acquire / rebind wins; any release unbinds)."""
+        lib().lantern_mirror_rebind(self.m, C.byref(self._opts))
 
     def advance(self, version):
         lib().lantern_mirror_advance(self.m, version)

@@ -462,7 +462,6 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     ia.ticket = next_ticket(ix, b_hi - b_lo, grid, ix->stream);
     if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
     HIPCHK(ix, launch_insert(ix->mcode, ia, ix->insert_waves, grid, ix->stream));
-    if(!record_launch(ix, ix->stream)) return false;
     prof_mark(ix, 1);
 
     ConnectArgs ca;
@@ -569,6 +568,8 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
         if(!sync_stream(ix, comm)) return false;  // the host transport's staging buffers are reused by the next batch
     }
     prof_mark(ix, 5);
+    // behind the LAST kernel that rewrites lists: a search on another stream that waits for `insert_done` sees the whole batch
+    if(!record_launch(ix, ix->stream)) return false;
     if(ix->profiling) prof_resolve(ix, 192);  // only batches the device finished long ago are waited for
     ix->n = first + b;
     if(b == 1 && lv[ 0 ] > ix->max_level) {  // "Updating the entry point if needed"
@@ -1439,10 +1440,14 @@ void lantern_gpu_search_batch_lane(usearch_index_t h, int lane, const void *quer
     for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
     hipStream_t st = nullptr;
     bool        ok = true;
-    std::string msg;
+    // A lane's error text belongs to the calling thread: ix->err is shared by both lanes (and by every other entry point) and
+    // may be rewritten or cleared the moment the mutex is dropped, while the caller -- the scan service's dispatcher -- reads
+    // the message later and without the lock.
+    static thread_local std::string msg;
+    msg.clear();
     {
         std::lock_guard<std::mutex> g(ix->mu);
-        if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+        if(!flush_locked(ix)) { msg = ix->err; FAIL(e, msg.c_str()); return; }
         if(!ix->lane_stream[ lane ] && hipStreamCreateWithFlags(&ix->lane_stream[ lane ], hipStreamNonBlocking) != hipSuccess) {
             FAIL(e, "lantern_gpu: cannot create the lane's stream");
             return;
@@ -1450,7 +1455,7 @@ void lantern_gpu_search_batch_lane(usearch_index_t h, int lane, const void *quer
         st = ix->lane_stream[ lane ];
         char *dq = (char *)scratch(ix, 12 + 2 * lane, nq * row_words * 4);
         char *dout = (char *)scratch(ix, 13 + 2 * lane, nq * k * 12 + nq * 4 + 64);
-        if(!dq || !dout) { FAIL(e, ix->err.c_str()); return; }
+        if(!dq || !dout) { msg = ix->err; FAIL(e, msg.c_str()); return; }
         uint64_t *d_lab = (uint64_t *)dout;
         float    *d_dist = (float *)(dout + nq * k * 8);
         uint32_t *d_cnt = (uint32_t *)(dout + nq * k * 12);
@@ -1463,11 +1468,7 @@ void lantern_gpu_search_batch_lane(usearch_index_t h, int lane, const void *quer
     }
     // the wait is the long part: outside the mutex, so that the other lane can queue its batch meanwhile
     if(hipStreamSynchronize(st) != hipSuccess && ok) { ok = false; msg = "lantern_gpu: HIP failure during batched search"; }
-    if(!ok) {
-        std::lock_guard<std::mutex> g(ix->mu);
-        set_err(ix, msg);
-        FAIL(e, ix->err.c_str());
-    }
+    if(!ok) FAIL(e, msg.c_str());
 }
 
 // ---- distances ------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@
 //                   (node, level) group: append while there is room; drop the requests that sort behind a full
 //                   list's recorded radius), then the re-prune of full lists by row shape: k_revlink_pairs
 //                   (all-pairs table, rows in registers, chain form), k_revlink_staged (rows staged whole in LDS),
-//                   k_revlink (rows read from L2); k_revlink_regs / k_revlink_slab: the round-1 kernels, for A/B runs.
+//                   k_revlink (rows read from L2: lists longer than 32 entries, rows beyond 2048 f32 dims).
 //   k_fill_norms    sqrt(||row||^2) of newly stored rows for the cosine metrics (device_common.hpp).
 //   k_apply_own_links / k_pack_lists / k_apply_lists
 //                   scatter kernels either side of the all-gathers of the work-sharded build (comm.cpp).
@@ -536,487 +536,8 @@ __global__ void __launch_bounds__(512) k_revlink_staged(RevlinkArgs a, const Rev
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_revlink_slab: the re-prune for the common shape (rows of >= 128 chunks, i.e. G = 64: d >= 512 f32, and cap <= 32,
-// i.e. M <= 16), restructured so that several workgroups fit on a CU.
-//
-// A re-prune needs the distances between all <= 33 candidates (and from `close` to the old entries):
-// 561 pairs over 34 rows.  k_revlink_staged holds the 34 full rows in LDS (102 KiB at d=768: ONE
-// workgroup per CU, every phase latency-exposed).  Here the rows are swept in column slabs instead: a slab
-// is chunk range [64p, 64p+64) of every row (34 KiB), each wave owns a contiguous run of pairs and keeps
-// one accumulator per pair IN REGISTERS across the slabs.  Lane l's fma chain still runs over chunks
-// l, l+64, l+128 in that order, so every distance has the same bits as group_dist<METRIC, 64>; for
-// cosine the per-row sums (a2 / b2) are accumulated once per row instead of once per pair (the same
-// chain).  ~43 KiB of LDS and <= 128 VGPRs: two 8-wave workgroups per CU.
-constexpr int SLAB_NMAX = 33;                               // candidates of one re-prune (cap + 1)
-constexpr int SLAB_PAIRS = SLAB_NMAX * (SLAB_NMAX - 1) / 2 + SLAB_NMAX;  // + close-to-candidate
-constexpr int SLAB_WAVES = 8;
-constexpr int SLAB_PPW = (SLAB_PAIRS + SLAB_WAVES - 1) / SLAB_WAVES;     // pairs per wave (71)
-constexpr int SLAB_RPW = (SLAB_NMAX + 1 + SLAB_WAVES - 1) / SLAB_WAVES;  // rows per wave for the cosine norms (5)
-
-template <int METRIC> struct PairAcc;
-template <> struct PairAcc<M_L2SQ>
-{
-    float s = 0.f;
-    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y) { l2sq_chunk(x, y, s); }
-    __device__ __forceinline__ float sum() { return group_sum<64>(s); }
-};
-template <> struct PairAcc<M_COS>
-{
-    float s = 0.f;  // ab only; a2 / b2 are per-row
-    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y)
-    {
-        s = __builtin_fmaf(__uint_as_float(x.x), __uint_as_float(y.x), s);
-        s = __builtin_fmaf(__uint_as_float(x.y), __uint_as_float(y.y), s);
-        s = __builtin_fmaf(__uint_as_float(x.z), __uint_as_float(y.z), s);
-        s = __builtin_fmaf(__uint_as_float(x.w), __uint_as_float(y.w), s);
-    }
-    __device__ __forceinline__ float sum() { return group_sum<64>(s); }
-};
-template <> struct PairAcc<M_HAMMING>
-{
-    uint32_t s = 0;
-    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y)
-    {
-        s += __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
-    }
-    __device__ __forceinline__ float sum() { return (float)group_sum<64>(s); }
-};
-
-template <> struct PairAcc<M_L2SQ_F16>
-{
-    Acc<M_L2SQ_F16> a;
-    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y) { a.add(x, y); }
-    __device__ __forceinline__ float sum() { return group_sum<64>(a.s); }
-};
-template <> struct PairAcc<M_COS_F16>
-{
-    float s = 0.f;  // ab only
-    __device__ __forceinline__ void word(uint32_t xw, uint32_t yw)
-    {
-        float x0, x1, y0, y1;
-        unpack_h2(xw, x0, x1);
-        unpack_h2(yw, y0, y1);
-        s = __builtin_fmaf(x0, y0, s);
-        s = __builtin_fmaf(x1, y1, s);
-    }
-    __device__ __forceinline__ void add(const uint4 &x, const uint4 &y) { word(x.x, y.x); word(x.y, y.y); word(x.z, y.z); word(x.w, y.w); }
-    __device__ __forceinline__ float sum() { return group_sum<64>(s); }
-};
-// per-row sum of squares for the cosine metrics: the a2 / b2 chain of Acc<M_COS>
-template <int METRIC> __device__ __forceinline__ void norm_add(const uint4 &z, float &acc)
-{
-    if(METRIC == M_COS_F16) {
-        const uint32_t w[ 4 ] = { z.x, z.y, z.z, z.w };
-#pragma unroll
-        for(int i = 0; i < 4; ++i) {
-            float lo, hi;
-            unpack_h2(w[ i ], lo, hi);
-            acc = __builtin_fmaf(lo, lo, acc);
-            acc = __builtin_fmaf(hi, hi, acc);
-        }
-    } else {
-        acc = __builtin_fmaf(__uint_as_float(z.x), __uint_as_float(z.x), acc);
-        acc = __builtin_fmaf(__uint_as_float(z.y), __uint_as_float(z.y), acc);
-        acc = __builtin_fmaf(__uint_as_float(z.z), __uint_as_float(z.z), acc);
-        acc = __builtin_fmaf(__uint_as_float(z.w), __uint_as_float(z.w), acc);
-    }
-}
-
-__host__ __device__ inline size_t slab_lds_bytes()
-{
-    // slab + pair table + pair matrix + norms + cd/cid/sd/sid + sidx + scalars
-    return (size_t)(SLAB_NMAX + 1) * 64 * 16 + 1152 + (size_t)(SLAB_NMAX + 1) * (SLAB_NMAX + 1) * 4 + 144 + 4 * 144 + 80 + S_SCALARS * 4;
-}
-
-template <int METRIC>
-__global__ void __launch_bounds__(512, 4) k_revlink_slab(RevlinkArgs a, const RevWork *work, const uint32_t *work_count)
-{
-    constexpr int NR = SLAB_NMAX + 1;  // row NR-1 ... the row of `close` lives at index n (<= 33)
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
-    unsigned char *p = lgpu_smem;
-    uint4    *slab = (uint4 *)p;       p += (size_t)NR * 64 * 16;
-    uint8_t  *tab = (uint8_t *)p;      p += 1152;                       // (i, j) per pair
-    float    *pair = (float *)p;       p += (size_t)NR * NR * 4;        // [i][j], candidate indices, i > j; row n = close
-    float    *norm = (float *)p;       p += 144;
-    float    *cd = (float *)p;         p += 144;
-    uint32_t *cid = (uint32_t *)p;     p += 144;
-    float    *sd = (float *)p;         p += 144;
-    uint32_t *sid = (uint32_t *)p;     p += 144;
-    uint16_t *sidx = (uint16_t *)p;    p += 80;
-    int      *scal = (int *)p;
-    const uint32_t nwork = *work_count;
-    const int      chunks = (int)a.view.chunks;
-    const int      nslabs = (chunks + 63) / 64;
-    uint32_t       pairs = 0, reprunes = 0;
-    for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const uint32_t gi = work[ wi ].group;
-        const uint32_t begin = a.groups[ gi ].x, end = a.groups[ gi ].y;
-        const uint32_t t_first = work[ wi ].t_start;
-        const uint32_t close = a.reqs[ begin ].close;
-        const int      level = (int)a.reqs[ begin ].level;
-        uint32_t       cap;
-        uint32_t      *list = neighbors_of(a.view, close, level, cap);
-        __syncthreads();  // the previous work item is done with the LDS
-        for(uint32_t i = tid; i < cap; i += T) cid[ i ] = list[ i ];
-        int       c = (int)cap;
-        const int c0 = (int)cap - (int)(t_first - begin);
-        for(int i = c0 + tid; i < (int)cap; i += T) cd[ i ] = a.reqs[ begin + (uint32_t)(i - c0) ].d;
-        __syncthreads();
-        bool have_d = false;
-        for(uint32_t t = t_first; t < end; ++t) {
-            const uint32_t vnew = a.reqs[ t ].new_slot;
-            const float    dv = a.reqs[ t ].d;
-            if(c < (int)cap) {
-                if(tid == 0) { cid[ c ] = vnew; cd[ c ] = dv; list[ c ] = vnew; }
-                c++;
-                __syncthreads();
-                continue;
-            }
-            reprunes++;
-            const int n = __builtin_amdgcn_readfirstlane(c + 1);  // candidates 0..n-1, `close` = row n
-            const int npairs = (n + 1) * n / 2;
-            if(tid == 0) { cid[ c ] = vnew; cd[ c ] = dv; }
-            // The pairs are the strict lower triangle of an (n+1) x (n+1) matrix whose last row is `close`:
-            // q = i (i - 1) / 2 + j, j < i <= n.  A wave walks its contiguous run with scalar (i, j).
-            __syncthreads();
-            // ---- sweep the rows slab by slab; this wave owns pairs [p0, p1)
-            const int wv = __builtin_amdgcn_readfirstlane(wave);
-            const int p0 = wv * SLAB_PPW, p1 = (p0 + SLAB_PPW < npairs) ? p0 + SLAB_PPW : npairs;
-            int       i0 = (int)((1.f + __builtin_sqrtf(1.f + 8.f * (float)p0)) * 0.5f);
-            while(i0 * (i0 - 1) / 2 > p0) --i0;
-            while((i0 + 1) * i0 / 2 <= p0) ++i0;
-            const int j0 = p0 - i0 * (i0 - 1) / 2;
-            PairAcc<METRIC> acc[ SLAB_PPW ];
-            float           nrm[ SLAB_RPW ];
-#pragma unroll
-            for(int k = 0; k < SLAB_RPW; ++k) nrm[ k ] = 0.f;
-            for(int ph = 0; ph < nslabs; ++ph) {
-                {
-                    const int total = (n + 1) * 64;
-                    uint4     v[ 5 ];
-#pragma unroll
-                    for(int u = 0; u < 5; ++u) {
-                        const int idx = tid + u * T;
-                        v[ u ] = make_uint4(0, 0, 0, 0);
-                        if(idx < total) {
-                            const int      r = idx >> 6, ch = ph * 64 + (idx & 63);
-                            const uint32_t slot = r < n ? cid[ r ] : close;
-                            if(ch < chunks) v[ u ] = row_of(a.view, slot)[ ch ];
-                        }
-                    }
-#pragma unroll
-                    for(int u = 0; u < 5; ++u) {
-                        const int idx = tid + u * T;
-                        if(idx < total) slab[ idx ] = v[ u ];
-                    }
-                }
-                __syncthreads();
-                {
-                    // branch-free walk of this wave's run of pairs, four pairs (eight LDS reads) in flight at a
-                    // time; (i, j) are scalar.  Past the end of the triangle the walk parks on (n, 0): the
-                    // sums of those slots are never stored.
-                    int i = i0, j = j0;
-#pragma unroll
-                    for(int k = 0; k < SLAB_PPW; k += 4) {
-                        uint4 xs[ 4 ], ys[ 4 ];
-#pragma unroll
-                        for(int u = 0; u < 4; ++u) {
-                            if(k + u < SLAB_PPW) {
-                                xs[ u ] = slab[ i * 64 + lane ];
-                                ys[ u ] = slab[ j * 64 + lane ];
-                                if(++j >= i) { ++i; j = 0; }
-                                if(i > n) { i = n; j = 0; }
-                            }
-                        }
-#pragma unroll
-                        for(int u = 0; u < 4; ++u)
-                            if(k + u < SLAB_PPW) acc[ k + u ].add(xs[ u ], ys[ u ]);
-                        __builtin_amdgcn_sched_barrier(0);  // one batch of loads in flight, not all eighteen
-                    }
-                    if(METRIC == M_COS || METRIC == M_COS_F16) {  // per-row sums of squares; rows past n are clamped (result unused)
-#pragma unroll
-                        for(int k = 0; k < SLAB_RPW; ++k) {
-                            const int   r = wv + SLAB_WAVES * k;
-                            const uint4 z = slab[ (r <= n ? r : n) * 64 + lane ];
-                            norm_add<METRIC>(z, nrm[ k ]);
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            // ---- reduce: lane 63 holds the sums
-            if(METRIC == M_COS || METRIC == M_COS_F16) {
-#pragma unroll
-                for(int k = 0; k < SLAB_RPW; ++k) {
-                    const int   r = wv + SLAB_WAVES * k;
-                    const float v = group_sum<64>(nrm[ k ]);
-                    if(lane == 63 && r <= n) norm[ r ] = v;
-                }
-            }
-            {
-                int i = i0, j = j0;
-#pragma unroll
-                for(int k = 0; k < SLAB_PPW; ++k) {
-                    const float v = acc[ k ].sum();
-                    if(lane == 63 && p0 + k < p1) pair[ i * NR + j ] = v;
-                    if(++j >= i) { ++i; j = 0; }
-                    if(i > n) { i = n; j = 0; }
-                }
-            }
-            __syncthreads();
-            if(METRIC == M_COS || METRIC == M_COS_F16) {  // finish 1 - ab / (sqrt(a2) sqrt(b2)) with the zero-norm rules
-                for(int cell = tid; cell < NR * NR; cell += T) {
-                    const int i = cell / NR, j = cell - i * NR;
-                    if(j < i && i <= n) {
-                        const float ab = pair[ cell ], a2 = norm[ i ], b2 = norm[ j ];
-                        float       d;
-                        if(a2 == 0.f && b2 == 0.f) d = 0.f;
-                        else if(a2 == 0.f || b2 == 0.f) d = 1.f;
-                        else d = 1.f - ab / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));
-                        pair[ cell ] = d;
-                    }
-                }
-                __syncthreads();
-            }
-            pairs += (uint32_t)npairs;
-            if(!have_d) {  // distances of the original entries to `close` (row n of the pair matrix)
-                for(int i = tid; i < c0; i += T) cd[ i ] = pair[ n * NR + i ];
-                have_d = true;
-                __syncthreads();
-            }
-            // ---- sort by (distance to close, tie_mix(slot, close)): one thread per (x, j) comparison
-            int                *rank = (int *)norm;                 // reuse: NR ints (norms are consumed)
-            unsigned long long *blockers = (unsigned long long *)tab;  // NR x u64, 8-byte aligned (tab sits at a 16-byte offset)
-            for(int x = tid; x < NR; x += T) { rank[ x ] = 0; blockers[ x ] = 0ull; }
-            __syncthreads();
-            for(int cell = tid; cell < n * n; cell += T) {
-                const int      x = cell / n, j = cell - x * n;
-                const uint64_t kx = ((uint64_t)f2ord(cd[ x ]) << 32) | tie_mix(cid[ x ], close);
-                const uint64_t kj = ((uint64_t)f2ord(cd[ j ]) << 32) | tie_mix(cid[ j ], close);
-                if(kj < kx) atomicAdd(&rank[ x ], 1);
-            }
-            __syncthreads();
-            for(int x = tid; x < n; x += T) {
-                const int r = rank[ x ];
-                sd[ r ] = cd[ x ];
-                sid[ r ] = cid[ x ];
-                sidx[ r ] = (uint16_t)x;
-            }
-            __syncthreads();
-            // ---- the heuristic.  blockers[c] = set of sorted positions p < c that, if kept, reject c
-            // (dist(c, p) < dist(c, close)); built in parallel, then one wave resolves the sequential
-            // dependency with 64-bit masks: c is kept iff none of its blockers is kept.
-            for(int cell = tid; cell < n * n; cell += T) {
-                const int cpos = cell / n, ppos = cell - cpos * n;
-                if(ppos < cpos) {
-                    const int ci = sidx[ cpos ], pi = sidx[ ppos ];
-                    const int hi = ci > pi ? ci : pi, lo = ci > pi ? pi : ci;
-                    if(pair[ hi * NR + lo ] < sd[ cpos ]) atomicOr(&blockers[ cpos ], 1ull << ppos);
-                }
-            }
-            __syncthreads();
-            if(tid < 64) {
-                const unsigned long long mine = lane < n ? blockers[ lane ] : 0ull;
-                unsigned long long       kept = 1ull;  // sorted position 0 is always kept
-                int                      submitted = 1;
-                for(int cpos = 1; cpos < n && submitted < (int)cap; ++cpos) {
-                    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(mine & 0xFFFFFFFFull), cpos);
-                    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(mine >> 32), cpos);
-                    const unsigned long long b = ((unsigned long long)hi << 32) | lo;
-                    if((b & kept) == 0ull) { kept |= 1ull << cpos; submitted++; }
-                }
-                // lane x takes the x-th kept position
-                float    kd = 0.f;
-                uint32_t ks = 0;
-                bool     have = false;
-                if(lane < submitted) {
-                    unsigned long long m = kept;
-                    for(int s2 = 0; s2 < lane; ++s2) m &= m - 1ull;  // drop the lane lowest set bits
-                    const int kpos = __builtin_ctzll(m);
-                    kd = sd[ kpos ];
-                    ks = sid[ kpos ];
-                    have = true;
-                }
-                if(have) { cd[ lane ] = kd; cid[ lane ] = ks; }
-                if(lane == 0) scal[ S_CNT ] = submitted;
-            }
-            __syncthreads();
-            c = scal[ S_CNT ];
-            for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? cid[ i ] : EMPTY;
-            __syncthreads();
-        }
-    }
-    if(tid == 0 && a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs); atomicAdd(&a.totals[ 1 ], (unsigned long long)reprunes); }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// k_revlink_regs: the re-prune with the kept rows in REGISTERS (the k_connect scheme, eight waves: wave w owns
-// kept entries w, w+8, w+16, w+24).  For rows of 128..256 chunks (d = 512..1024 f32) and cap <= 32 it replaces the
-// column-slab sweep: a candidate costs one barrier and no LDS traffic; every wave streams the (sorted) candidate
-// rows through L1/L2 with the next one already in flight.  Same lane/chunk ownership and reduction tree as
-// group_dist<METRIC, 64>.
-// CPL = 16-byte chunks per lane per row (rows of up to 64 * CPL chunks): 3 covers d <= 768 f32 and leaves room for FOUR waves
-// per SIMD (two re-prunes per CU in flight: the per-candidate chain is latency-bound, so throughput nearly doubles, at the
-// price of some spilled registers outside the candidate loop); 4 covers d <= 1024 at two waves per SIMD.
-template <int METRIC, int CPL>
-__global__ void __launch_bounds__(512, CPL <= 3 ? 4 : 2) k_revlink_regs(RevlinkArgs a, const RevWork *work, const uint32_t *work_count)
-{
-    constexpr int NMAX = 34;
-    __shared__ float    cd[ NMAX ], sd[ NMAX ], kd[ NMAX ];
-    __shared__ uint32_t cid[ NMAX ], sid[ NMAX ], kid[ NMAX ];
-    __shared__ int      flags[ 4 ];
-    __shared__ uint4    ring[ 2 ][ 64 * CPL ];  // candidate rows on their way from the prefetching wave to all waves
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nwork = *work_count;
-    const int      chunks = (int)a.view.chunks;
-    uint32_t       pairs = 0, reprunes = 0;
-    auto load_row = [&](uint32_t slot, uint4 (&v)[ CPL ]) {
-        const uint4 *row = row_of(a.view, slot);
-#pragma unroll
-        for(int c = 0; c < CPL; ++c) {
-            const int ch = lane + 64 * c;
-            v[ c ] = ch < chunks ? row[ ch ] : make_uint4(0, 0, 0, 0);
-        }
-    };
-    for(uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const uint32_t gi = work[ wi ].group;
-        const uint32_t begin = a.groups[ gi ].x, end = a.groups[ gi ].y;
-        const uint32_t t_first = work[ wi ].t_start;
-        const uint32_t close = a.reqs[ begin ].close;
-        const int      level = (int)a.reqs[ begin ].level;
-        uint32_t       cap;
-        uint32_t      *list = neighbors_of(a.view, close, level, cap);
-        __syncthreads();  // the previous work item is done with the LDS
-        for(uint32_t i = tid; i < cap; i += T) cid[ i ] = list[ i ];
-        int       c = (int)cap;
-        const int c0 = (int)cap - (int)(t_first - begin);
-        for(int i = c0 + tid; i < (int)cap; i += T) cd[ i ] = a.reqs[ begin + (uint32_t)(i - c0) ].d;
-        __syncthreads();
-        bool have_d = false;
-        for(uint32_t t = t_first; t < end; ++t) {
-            const uint32_t vnew = a.reqs[ t ].new_slot;
-            const float    dv = a.reqs[ t ].d;
-            if(c < (int)cap) {
-                if(tid == 0) { cid[ c ] = vnew; cd[ c ] = dv; list[ c ] = vnew; }
-                c++;
-                __syncthreads();
-                continue;
-            }
-            reprunes++;
-            const int n = c + 1;
-            if(tid == 0) { cid[ c ] = vnew; cd[ c ] = dv; }
-            if(tid < 3) flags[ tid ] = 0;
-            __syncthreads();
-            uint4 kept[ 4 ][ CPL ], cur[ CPL ], nxt[ CPL ];
-            if(!have_d) {  // distances of the original entries to `close`, once (a = close, b = entry)
-                // all (<= 4) rows of this wave in flight at once, parked in the not-yet-used kept registers
-                load_row(close, cur);
-#pragma unroll
-                for(int j = 0; j < 4; ++j)
-                    if(wave + 8 * j < c0) load_row(cid[ wave + 8 * j ], kept[ j ]);
-#pragma unroll
-                for(int j = 0; j < 4; ++j) {
-                    if(wave + 8 * j < c0) {
-                        RowAcc<METRIC> acc;
-#pragma unroll
-                        for(int cc = 0; cc < CPL; ++cc) acc.add(cur[ cc ], kept[ j ][ cc ]);
-                        const float d = acc.template finish_n<64>(row_norm<METRIC>(a.view, close), row_norm<METRIC>(a.view, cid[ wave + 8 * j ]));
-                        if(lane == 63) cd[ wave + 8 * j ] = d;
-                    }
-                }
-                pairs += (uint32_t)c0;
-                have_d = true;
-                __syncthreads();
-            }
-            // ---- sort by (distance to close, tie_mix(slot, close))
-            for(int x = tid; x < n; x += T) {
-                const uint64_t k = ((uint64_t)f2ord(cd[ x ]) << 32) | tie_mix(cid[ x ], close);
-                int            rank = 0;
-                for(int j = 0; j < n; ++j) rank += (((uint64_t)f2ord(cd[ j ]) << 32) | tie_mix(cid[ j ], close)) < k;
-                sd[ rank ] = cd[ x ];
-                sid[ rank ] = cid[ x ];
-            }
-            __syncthreads();
-            // ---- the heuristic: kept rows in registers, one barrier per candidate.  The candidate rows are cold (HBM
-            // latency >> the time a step computes), so EIGHT of them are in flight at any time: candidate r >= 1 is
-            // fetched by wave (r - 1) & 7 into its `nxt` registers eight steps ahead and published to the two-slot LDS
-            // ring during step r - 1; every wave then reads it from LDS.  Same rows, same accumulation order, same bits.
-#pragma unroll
-            for(int j = 0; j < 4; ++j)
-#pragma unroll
-                for(int cc = 0; cc < CPL; ++cc) kept[ j ][ cc ] = make_uint4(0, 0, 0, 0);
-            float keptn[ 4 ] = { 0.f, 0.f, 0.f, 0.f };  // cached norms of this wave's kept rows (cosine metrics)
-            if(wave == 0) {  // candidate 0 is always kept
-                load_row(sid[ 0 ], cur);
-#pragma unroll
-                for(int cc = 0; cc < CPL; ++cc) kept[ 0 ][ cc ] = cur[ cc ];
-                keptn[ 0 ] = row_norm<METRIC>(a.view, sid[ 0 ]);
-            }
-            if(tid == 0) { kid[ 0 ] = sid[ 0 ]; kd[ 0 ] = sd[ 0 ]; }
-            if(1 + wave < n) load_row(sid[ 1 + wave ], nxt);  // candidates 1..8
-            if(wave == 0) {                                    // publish candidate 1 (n >= 2 always), refill with candidate 9
-#pragma unroll
-                for(int cc = 0; cc < CPL; ++cc) ring[ 1 ][ lane + 64 * cc ] = nxt[ cc ];
-                if(9 < n) load_row(sid[ 9 ], nxt);
-            }
-            __syncthreads();
-            int submitted = 1, consumed = 1;
-            while(submitted < (int)cap && consumed < n) {
-#pragma unroll
-                for(int cc = 0; cc < CPL; ++cc) cur[ cc ] = ring[ consumed & 1 ][ lane + 64 * cc ];
-                const float    cdist = sd[ consumed ];
-                const uint32_t cslot = sid[ consumed ];
-                const float    cn2 = row_norm<METRIC>(a.view, cslot);
-                if(consumed + 1 < n && wave == (consumed & 7)) {  // the owner of candidate consumed + 1 publishes it (the other slot
-#pragma unroll                                                      // was last read before the previous barrier) and refills
-                    for(int cc = 0; cc < CPL; ++cc) ring[ (consumed + 1) & 1 ][ lane + 64 * cc ] = nxt[ cc ];
-                    if(consumed + 9 < n) load_row(sid[ consumed + 9 ], nxt);
-                }
-                bool bad = false;
-#pragma unroll
-                for(int j = 0; j < 4; ++j) {
-                    if(wave + 8 * j < submitted) {  // wave-uniform
-                        RowAcc<METRIC> acc;
-#pragma unroll
-                        for(int cc = 0; cc < CPL; ++cc) acc.add(cur[ cc ], kept[ j ][ cc ]);
-                        const float d = acc.template finish_n<64>(cn2, keptn[ j ]);
-                        bad |= d < cdist;  // meaningful in lane 63
-                    }
-                }
-                const int slot = consumed % 3;
-                if(lane == 63 && bad) flags[ slot ] = 1;
-                if(tid == 0) flags[ (consumed + 1) % 3 ] = 0;
-                pairs += (uint32_t)submitted;
-                __syncthreads();
-                if(flags[ slot ] == 0) {
-                    const int owner = submitted & 7, j = submitted >> 3;
-                    if(wave == owner) {
-#pragma unroll
-                        for(int jj = 0; jj < 4; ++jj)
-                            if(jj == j) {
-#pragma unroll
-                                for(int cc = 0; cc < CPL; ++cc) kept[ jj ][ cc ] = cur[ cc ];
-                                keptn[ jj ] = cn2;
-                            }
-                    }
-                    if(tid == 0) { kid[ submitted ] = cslot; kd[ submitted ] = cdist; }
-                    submitted++;
-                }
-                consumed++;
-            }
-            __syncthreads();
-            c = submitted;
-            for(int i = tid; i < c; i += T) { cid[ i ] = kid[ i ]; cd[ i ] = kd[ i ]; }
-            for(uint32_t i = tid; i < cap; i += T) list[ i ] = (int)i < c ? kid[ i ] : EMPTY;
-            __syncthreads();
-        }
-    }
-    if(tid == 0 && a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)pairs); atomicAdd(&a.totals[ 1 ], (unsigned long long)reprunes); }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // k_revlink_pairs: the re-prune of a full list (rows of 128..256 chunks, cap <= 32) with NO sequential dependency in
-// its distance phase.  k_revlink_regs walks the sorted candidates one by one -- one barrier and one LDS hand-off per
+// its distance phase.  Round 1 walked the sorted candidates one by one -- one barrier and one LDS hand-off per
 // candidate, a ~0.85 us chain x 32 -- because whether candidate c is tested against candidate p depends on p having been
 // kept.  Here ALL pairs among the <= 33 candidates and `close` are evaluated up front ((n+1) n / 2 <= 561 independent
 // distances, ~18 % more than the sequential walk evaluates), then the keep/drop scan runs over that table with 64-bit
@@ -1420,34 +941,13 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
     // staged variant whenever the 2M+2 rows of a level-0 re-prune fit in LDS (d <= 1024 at M = 16)
     const size_t staged = staged_lds_bytes(a.view.chunks, a.view.M0);
     const bool i8 = mcode_is_i8(metric);  // i8 rows take the LDS-staged / generic kernels (Lantern caps d at 2000: <= 125 chunks)
-    static const bool use_slab = std::getenv("LANTERN_GPU_REPRUNE") && std::string(std::getenv("LANTERN_GPU_REPRUNE")) == "slab";
-    if(!i8 && a.view.chunks >= 128 && a.view.chunks <= 512 && a.view.M0 <= 32 && work && work_count && !(use_slab && a.view.chunks > 256)) {
-        // d = 512..2048 f32 rows, M <= 16: all-pairs re-prune with the rows in registers (k_revlink_pairs);
-        // LANTERN_GPU_REPRUNE=regs selects the sequential-walk kernel it replaced (A/B measurements)
+    if(!i8 && a.view.chunks >= 128 && a.view.chunks <= 512 && a.view.M0 <= 32 && work && work_count) {
+        // d = 512..2048 f32 rows, M <= 16: all-pairs re-prune with the rows in registers (k_revlink_pairs)
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;
         hipLaunchKernelGGL(k_revlink_append, dim3(append_grid), dim3(256), 0, stream, a, (RevWork *)work, work_count);
-        static const bool use_regs = std::getenv("LANTERN_GPU_REPRUNE") && std::string(std::getenv("LANTERN_GPU_REPRUNE")) == "regs";
         static const bool force4 = std::getenv("LANTERN_GPU_REGS_CPL4") != nullptr;  // tuning: always the four-chunks-per-lane variant
         const bool cpl3 = a.view.chunks <= 192 && !force4;
-        if(use_regs && a.view.chunks <= 256) {
-            const int grid = num_cus * 2;
-#define REGS(MM)                                                                                                                        \
-    {                                                                                                                                   \
-        if(cpl3) hipLaunchKernelGGL((k_revlink_regs<MM, 3>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count);   \
-        else hipLaunchKernelGGL((k_revlink_regs<MM, 4>), dim3(grid), dim3(512), 0, stream, a, (const RevWork *)work, work_count);       \
-    }
-            switch(metric) {
-                case M_L2SQ: REGS(M_L2SQ); break;
-                case M_COS: REGS(M_COS); break;
-                case M_HAMMING: REGS(M_HAMMING); break;
-                case M_L2SQ_F16: REGS(M_L2SQ_F16); break;
-                case M_COS_F16: REGS(M_COS_F16); break;
-                default: return hipErrorInvalidValue;
-            }
-#undef REGS
-            return hipGetLastError();
-        }
         // chunks per lane: 3 covers d <= 768 f32 at two workgroups per CU; 4 / 6 / 8 (d <= 1024 / 1536 / 2048) run one per CU
         const int    cpl = cpl3 ? 3 : a.view.chunks <= 256 ? 4 : a.view.chunks <= 384 ? 6 : 8;
         const size_t lds = pairs_lds_bytes(cpl);
@@ -1471,23 +971,6 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
         }
 #undef PAIRS
 #undef PAIRS_ONE
-        return hipGetLastError();
-    }
-    if(!i8 && a.view.chunks >= 128 && a.view.M0 <= 32 && work && work_count) {
-        // common shape (G = 64: d >= 512 f32 / 1024 f16, and M <= 16): column-slab sweep, 2 x 8 waves per CU
-        hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
-        if(e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_revlink_append, dim3(append_grid), dim3(256), 0, stream, a, (RevWork *)work, work_count);
-        const size_t lds = slab_lds_bytes();
-        const int    grid = num_cus * 2;
-        switch(metric) {
-            case M_L2SQ: hipLaunchKernelGGL((k_revlink_slab<M_L2SQ>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
-            case M_COS: hipLaunchKernelGGL((k_revlink_slab<M_COS>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
-            case M_HAMMING: hipLaunchKernelGGL((k_revlink_slab<M_HAMMING>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
-            case M_L2SQ_F16: hipLaunchKernelGGL((k_revlink_slab<M_L2SQ_F16>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
-            case M_COS_F16: hipLaunchKernelGGL((k_revlink_slab<M_COS_F16>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count); break;
-            default: return hipErrorInvalidValue;
-        }
         return hipGetLastError();
     }
     if(staged <= 150 * 1024 && a.view.M0 <= 256 && work && work_count) {

@@ -12,6 +12,9 @@
 //   acquire   same relation + same version -> the resident mirror, reference counted (a HIT: no retriever call at all);
 //             same relation, another version -> a fresh mirror replaces it (the stale one is freed when its last user
 //             releases it); unknown relation -> a mirror is built (usearch_init + usearch_view_mem_lazy)
+//   callbacks the retriever / retriever_mut / retriever_ctx of the caller's init options are the reference's per-scan, per-insert
+//             RetrieverCtx (scan.c:34,132, insert.c:130,247): the mirror carries the LATEST acquirer's (or rebind's) and drops
+//             them at any release -- no ctx pointer outlives the acquire / release pair that brought it
 //   advance   the holder of a mirror that applied a change itself (usearch_add_external + usearch_update_header in
 //             ldb_aminsert) re-stamps it instead of forcing a rebuild
 //   invalidate  DROP INDEX / REINDEX / VACUUM: the relation's mirror goes as soon as nobody holds it
@@ -25,7 +28,7 @@
 #include <mutex>
 #include <string>
 
-#include "../../include/lantern_gpu.h"
+#include "index.hpp"
 
 struct lantern_mirror
 {
@@ -48,6 +51,16 @@ Cache &cache()
 {
     static Cache c;
     return c;
+}
+
+// the mirror's callbacks become this holder's (NULL opts: nobody's -- no ctx pointer outlives an acquire / release pair)
+void rebind_retriever(lgpu::Index *ix, const usearch_init_options_t *opts)
+{
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->opts.retriever = opts ? opts->retriever : nullptr;
+    ix->opts.retriever_mut = opts ? opts->retriever_mut : nullptr;
+    ix->opts.retriever_ctx = opts ? opts->retriever_ctx : nullptr;
 }
 
 void destroy(lantern_mirror &m)
@@ -91,22 +104,27 @@ lantern_mirror_t *lantern_mirror_acquire(uint64_t relation, uint64_t version, us
     if(e) *e = nullptr;
     if(!opts || !header136) { if(e) *e = "lantern_gpu: null init options or header"; return nullptr; }
     Cache &c = cache();
-    std::lock_guard<std::mutex> g(c.mu);
-    for(auto &m : c.entries) {
-        if(m.relation == relation && !m.stale && m.version == version) {
-            m.refs++;
-            m.last_use = ++c.clock;
-            c.hits++;
-            return &m;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        for(auto &m : c.entries) {
+            if(m.relation == relation && !m.stale && m.version == version) {
+                // The reference allocates its RetrieverCtx per scan and per insert and frees it at the end (scan.c:34,132,
+                // insert.c:130,247): the callbacks and the ctx a mirror was BUILT with are gone by now.  The mirror takes
+                // this holder's for as long as it holds it (usearch_add_external writes through retriever_mut).
+                rebind_retriever((lgpu::Index *)m.index, opts);
+                m.refs++;
+                m.last_use = ++c.clock;
+                c.hits++;
+                return &m;
+            }
         }
     }
     // policy: a tiny index is not worth a mirror (the header carries the node count: external_index.h:59-66)
     uint64_t declared = 0;
     std::memcpy(&declared, header136 + 80, 8);
     if(declared < min_vectors) return nullptr;
-    bool replaced = false;
-    for(auto &m : c.entries)
-        if(m.relation == relation && !m.stale) { m.stale = true; replaced = true; }
+    // The build -- a walk of the whole page graph through the retriever plus an upload -- runs OUTSIDE the cache lock:
+    // scans of other relations keep acquiring and releasing meanwhile.
     usearch_error_t err = nullptr;
     usearch_index_t ix = usearch_init(opts, pq_codebook, &err);
     if(!ix) { if(e) *e = err; return nullptr; }
@@ -120,6 +138,22 @@ lantern_mirror_t *lantern_mirror_acquire(uint64_t relation, uint64_t version, us
         if(e) *e = kept.c_str();
         return nullptr;
     }
+    std::lock_guard<std::mutex> g(c.mu);
+    // somebody else may have built the same (relation, version) in the meantime: theirs stays, ours goes
+    for(auto &m : c.entries) {
+        if(m.relation == relation && !m.stale && m.version == version) {
+            usearch_error_t ignore = nullptr;
+            usearch_free(ix, &ignore);
+            rebind_retriever((lgpu::Index *)m.index, opts);
+            m.refs++;
+            m.last_use = ++c.clock;
+            c.hits++;
+            return &m;
+        }
+    }
+    bool replaced = false;
+    for(auto &m : c.entries)
+        if(m.relation == relation && !m.stale) { m.stale = true; replaced = true; }
     (replaced ? c.rebuilds : c.misses)++;
     c.entries.emplace_back();
     lantern_mirror &m = c.entries.back();
@@ -135,6 +169,11 @@ lantern_mirror_t *lantern_mirror_acquire(uint64_t relation, uint64_t version, us
 usearch_index_t lantern_mirror_index(lantern_mirror_t *m) { return m ? m->index : nullptr; }
 uint64_t        lantern_mirror_version(lantern_mirror_t *m) { return m ? m->version : 0; }
 
+void lantern_mirror_rebind(lantern_mirror_t *m, const usearch_init_options_t *opts)
+{
+    if(m) rebind_retriever((lgpu::Index *)m->index, opts);
+}
+
 void lantern_mirror_advance(lantern_mirror_t *m, uint64_t new_version)
 {
     if(!m) return;
@@ -149,6 +188,11 @@ void lantern_mirror_release(lantern_mirror_t *m)
     Cache &c = cache();
     std::lock_guard<std::mutex> g(c.mu);
     if(m->refs > 0) m->refs--;
+    // The releasing holder's ctx is about to be freed (scan.c:132, insert.c:247) and the entry cannot tell whose callbacks it
+    // carries: ANY release unbinds them.  Scans never call them on a mirror; an inserter that still holds the mirror binds
+    // its own again (lantern_mirror_rebind) -- without that usearch_add_external fails with a message, never through a
+    // dangling pointer.
+    rebind_retriever((lgpu::Index *)m->index, nullptr);
     m->last_use = ++c.clock;
     trim(c);
 }

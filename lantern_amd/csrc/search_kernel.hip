@@ -167,15 +167,16 @@ hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, h
     const int    kpl = a.lds_list ? 0 : a.ef <= 64 ? 1 : a.ef <= 128 ? 2 : 0;
     const int    G_ = group_lanes_for(a.view.chunks);
     if(a.wide_rows && !a.phase_cycles && G_ == 64) {  // the small-batch shape (rows of >= 128 chunks)
+        bool launched = true;
         switch(metric) {
             case M_L2SQ: LGPU_LAUNCH_SEARCH_KPL(M_L2SQ, 64, false, 4); break;
             case M_COS: LGPU_LAUNCH_SEARCH_KPL(M_COS, 64, false, 4); break;
             case M_HAMMING: LGPU_LAUNCH_SEARCH_KPL(M_HAMMING, 64, false, 4); break;
             case M_L2SQ_F16: LGPU_LAUNCH_SEARCH_KPL(M_L2SQ_F16, 64, false, 4); break;
             case M_COS_F16: LGPU_LAUNCH_SEARCH_KPL(M_COS_F16, 64, false, 4); break;
-            default: return hipErrorInvalidValue;
+            default: launched = false;  // i8 storage (rows of >= 2033 dims) has no four-row instantiation: the two-row shape below
         }
-        return hipGetLastError();
+        if(launched) return hipGetLastError();
     }
     if(a.phase_cycles) {  // diagnostic instantiations: the f32 metrics at the two common row shapes
         if(metric == M_L2SQ && G_ == 64) LGPU_LAUNCH_SEARCH_KPL(M_L2SQ, 64, true, 2)

@@ -37,6 +37,7 @@
 // u40_k ("the wide custom slot") is written and ANY value is accepted on read.
 // STATUS: UNVERIFIED against the pinned fork (rev aa4f91d); no fixture of a header produced by real usearch can be
 // made offline.  The reader accepts both upstream codes and this library's round-1 numerals.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <unordered_map>
@@ -251,8 +252,7 @@ bool mirror_from_retriever(Index *ix, const char *header)
     if(std::memcmp(header + OFF_MAGIC, "usearch", 7) != 0) { set_err(ix, "lantern_gpu: not a usearch header"); return false; }
     const uint64_t declared = get<uint64_t>(header, OFF_G_SIZE);
     if(get<uint64_t>(header, OFF_G_CONNECTIVITY) != ix->M) { set_err(ix, "lantern_gpu: header connectivity does not match the index options"); return false; }
-    ix->page_mode = true;
-    if(declared == 0) return true;
+    if(declared == 0) { ix->page_mode = true; return true; }
     if(declared >= 0x7FFFFFFFull) { set_err(ix, "lantern_gpu: the header declares more nodes than the device index supports"); return false; }
     const uint64_t mask48 = 0xFFFFFFFFFFFFull;
     const uint64_t entry = get<uint64_t>(header, OFF_G_ENTRY_SLOT) & mask48;
@@ -262,7 +262,7 @@ bool mirror_from_retriever(Index *ix, const char *header)
     std::vector<uint8_t>  levels;
     std::vector<uint32_t> nbr0, upper_off, upper;
     std::vector<char>     vecs;
-    id_of.reserve(declared * 2);
+    id_of.reserve((size_t)std::min<uint64_t>(declared, 1u << 20) * 2);  // the header is untrusted: it only hints at the table's size
     auto intern = [&](uint64_t slot) -> uint32_t {
         auto it = id_of.find(slot);
         if(it != id_of.end()) return it->second;
@@ -316,6 +316,7 @@ bool mirror_from_retriever(Index *ix, const char *header)
     if(!import_graph_locked(ix, slot_of.size(), vecs.data(), labels.data(), levels.data(), nbr0.data(), upper_off.data(), upper.data(),
                             0 /* the entry slot was interned first */, (int32_t)top, ix->pq))
         return false;
+    ix->page_mode = true;  // only a mirror that was built is in page mode
     ix->page_slots.swap(slot_of);
     ix->page_ids.swap(id_of);
     ix->page_declared = (size_t)declared;
@@ -395,7 +396,11 @@ void usearch_view_mem_lazy(usearch_index_t h, char *header136, usearch_error_t *
     if(ix) (void)hipSetDevice(ix->device);
     if(!ix || !header136) { if(e) *e = "lantern_gpu: null index handle or header"; return; }
     std::lock_guard<std::mutex> g(ix->mu);
-    if(!mirror_from_retriever(ix, header136) && e) *e = ix->err.c_str();
+    try {
+        if(!mirror_from_retriever(ix, header136) && e) *e = ix->err.c_str();
+    } catch(const std::exception &) {  // the pages are untrusted input: nothing may unwind through the C boundary into a backend
+        if(e) *e = set_err(ix, "lantern_gpu: out of host memory while mirroring the page graph");
+    }
 }
 
 // insert.c:214: write size / max level / entry slot back into the header page copy

@@ -509,6 +509,26 @@ def test_i8_storage_matches_oracle(capi, oracle, metric, n, d, M, efc):
     assert np.array_equal(other.search_batch(queries, 10)[0], lab)
 
 
+@pytest.mark.parametrize("metric", ["l2sq", "cos"])
+def test_i8_rows_wider_than_2032_dims_in_a_small_batch(capi, oracle, metric):
+    """Batches of 64 .. 4 x CUs queries take the small-batch launch shape; i8 rows of >= 128 chunks (>= 2033 dims: usearch_init
+    does not cap dimensions) have no four-row instantiation and must fall through to the two-row kernel, not fail."""
+    rng = np.random.default_rng(2100)
+    n, d, M = 700, 2100, 8
+    base = (rng.standard_normal((n, d), dtype=np.float32) * np.float32(0.4)).astype(np.float32)
+    labels = np.arange(n, dtype=np.uint64) + 1
+    gpu = capi.GpuIndex(metric, d, M=M, ef_construction=40, ef=40, seed=5, quantization="i8")
+    gpu.set_add_batch(256, 8)
+    gpu.add_many(labels, base)
+    qb = oracle.quantize_i8(base)
+    ora = oracle.OracleIndex.from_graph(metric, qb, gpu.export_graph(), M, 40, 40, 5, oracle.SUM_I8)
+    for nq in (63, 64, 200, 1024):
+        queries = (rng.standard_normal((nq, d), dtype=np.float32) * np.float32(0.4)).astype(np.float32)
+        o_lab, o_dist, _, _, _ = ora.search_batch(oracle.quantize_i8(queries), 10, 40, 4)
+        lab, dist, _ = gpu.search_batch(queries, 10)
+        assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist), nq
+
+
 # ------------------------------------------------------------------------------------------------
 # limits of the reloptions / GUCs (options.c:165-179,324-348; build.c:394-401) and concurrency
 # ------------------------------------------------------------------------------------------------

@@ -365,6 +365,45 @@ def test_corrupt_files_are_refused_not_trusted(capi):
 # ------------------------------------------------------------------------------------------------------------------
 # mirror lifecycle: (relfilenode, LSN)-keyed cache of HBM mirrors
 # ------------------------------------------------------------------------------------------------------------------
+def test_mirror_hit_inserts_through_the_second_holders_callbacks(capi):
+    """The reference allocates a RetrieverCtx per scan / per insert and frees it at the end (scan.c:34,132, insert.c:130,247).
+    A cache hit must therefore call the CURRENT holder's callbacks, never the ones the mirror was built with."""
+    import gc
+
+    rng = np.random.default_rng(77)
+    n, d, M = 600, 16, 5
+    base = rng.standard_normal((n + 3, d), dtype=np.float32)
+    a = capi.GpuIndex("l2sq", d, M=M, ef_construction=32, ef=32, seed=8)
+    a.set_add_batch(1, 1)
+    a.add_many(np.arange(n, dtype=np.uint64) + 1, base[:n])
+    store = PageStore(capi, a.save_buffer(), d * 4, M)
+    REL = 515151
+    calls = {"first": 0, "second": 0}
+
+    def counted(who, fn):
+        def f(slot):
+            calls[who] += 1
+            return fn(slot)
+        return f
+
+    kw = dict(metric="l2sq", dims=d, M=M, ef_construction=32, ef=32)
+    m1 = capi.Mirror(REL, 1, header=store.header, retriever=counted("first", store.retriever), retriever_mut=counted("first", store.retriever_mut), **kw)
+    built = calls["first"]
+    assert built > 0
+    # the first scan ends: its ctx (here: the ctypes thunks) is freed.  The idle mirror stays resident.
+    m1.release()
+    del m1
+    gc.collect()
+    m2 = capi.Mirror(REL, 1, header=store.header, retriever=counted("second", store.retriever), retriever_mut=counted("second", store.retriever_mut), **kw)
+    assert calls["second"] == 0 and calls["first"] == built  # a hit: nothing was walked
+    addr, slot = store.new_tuple(7001, 0)
+    m2.index.add_external(7001, base[n], addr, 0, slot)
+    assert calls["second"] > 0 and calls["first"] == built   # the neighbours' tapes were written through the SECOND holder's retriever_mut
+    assert 7001 in m2.index.search(base[n], 3)[0].tolist()
+    m2.release()
+    capi.Mirror.invalidate(REL)
+
+
 def test_mirror_cache_hits_rebuilds_invalidation_and_eviction(capi):
     rng = np.random.default_rng(31)
     n, d, M = 900, 16, 5
@@ -399,7 +438,12 @@ def test_mirror_cache_hits_rebuilds_invalidation_and_eviction(capi):
     s1.end(); s2.end()
     m3.release()
     # ldb_aminsert by the holder: the change is applied to the mirror and the pages, the stamp advances, no rebuild
+    # (m3's release unbound the retriever callbacks -- they were m3's, the latest acquirer's: an insert without binding
+    # one's own fails with a message instead of calling through a freed RetrieverCtx)
     addr, slot = store.new_tuple(5001, 0)
+    with pytest.raises(capi.LanternGpuError, match="retriever_mut"):
+        m1.index.add_external(5001, base[n], addr, 0, slot)
+    m1.rebind()
     m1.index.add_external(5001, base[n], addr, 0, slot)
     header2 = m1.index.update_header(store.header)
     m1.advance(2)
