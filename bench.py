@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_CEILING_GBS = 6290.0  # same guide: "6.29 TB/s measured (float4 copy, 79 %)" -- what a pure DRAM stream reaches
 
 
 def parse():
@@ -54,6 +55,8 @@ def parse():
     p.add_argument("--queries", type=int, default=8192, help="queries per step per GPU")
     p.add_argument("--streams", type=int, default=1, help="search launches in flight: steps alternate over this many streams, each with its own query batch "
                    "(independent batches of a serving workload; the second fills the machine while the first one's longest walks drain)")
+    p.add_argument("--query-batches", type=int, default=4, help="distinct resident query batches the steps rotate through (step i searches batch i mod this): "
+                   "no step replays the queries of the step before it, so no launch finds its own rows in L2 / Infinity Cache")
     p.add_argument("--waves", type=int, default=0, help="wavefronts per query (0 = the library's automatic shape)")
     p.add_argument("--max-wg", type=int, default=0)
     p.add_argument("--add-batch", type=int, default=8192)
@@ -66,8 +69,9 @@ def parse():
                         "gloo: the host transport over the rendezvous directory -- debugging, or several ranks on one GPU)")
     p.add_argument("--dry-run", action="store_true", help="launch, rendezvous, barrier and print the line's shape without touching a device (CPU test of the N>1 plumbing)")
     p.add_argument("--build-quality-rows", type=int, default=100_000, help="rows of the build-quality leg (device batched build vs sequential CPU build; 0 = skip)")
-    p.add_argument("--data", default="gaussian", choices=["gaussian", "lowrank"],
-                   help="gaussian = the prescribed i.i.d. N(0,1) set (SURVEY 8d); lowrank = 32 latent dims embedded in --dim (embedding-like)")
+    p.add_argument("--data", default="gaussian", choices=["gaussian", "lowrank", "clustered"],
+                   help="gaussian = the prescribed i.i.d. N(0,1) set (SURVEY 8d); lowrank = 32 latent dims embedded in --dim; clustered = Gaussian mixture with "
+                        "low-dimensional clusters (lantern_amd/synth.py): the set on which HNSW reaches the recall the reference asserts (>= 0.9)")
     p.add_argument("--data-scale", type=float, default=1.0, help="multiply the synthetic rows and queries (i8 storage quantises [-1, 1]: use 0.3)")
     p.add_argument("--collective-timeout", type=float, default=180.0, help="deadline of every exchange of the collective build")
     return p.parse_args()
@@ -239,22 +243,26 @@ def main():
     build_profile = ix.build_profile()
 
     # ---- this rank's queries, resident in HBM ----------------------------------------------------
+    # B distinct batches (>= 4 by default), step i searches batch i mod B on stream i mod S: consecutive steps never replay
+    # the same queries, so a launch does not find the rows of its own previous run in L2 / the 256 MiB Infinity Cache.
     qrng = np.random.default_rng(4 + 1000 * rank)
     nq = a.queries
     S = max(1, a.streams)
-    all_queries = make_queries(qrng, nq * S)
+    B = max(S, a.query_batches, 1)
+    all_queries = make_queries(qrng, nq * B)
     queries = all_queries[:nq]  # the batch recall and the CPU baseline are taken on
-    lanes = []  # one per stream: its own query batch, outputs and launch stream
-    for i in range(S):
+    streams = [hip.Stream() for _ in range(S)]
+    lanes = []  # one per query batch: its rows and outputs
+    for i in range(B):
         qi = all_queries[i * nq:(i + 1) * nq]
         lanes.append({"dq": hip.Buffer.from_numpy(hip.padded_rows(qi, False, a.quant == "f16", a.quant == "i8", a.quant == "b1")),
                       "lab": hip.Buffer(nq * a.k * 8), "dist": hip.Buffer(nq * a.k * 4), "slot": hip.Buffer(nq * a.k * 4),
-                      "D": hip.Buffer(nq * 8), "E": hip.Buffer(nq * 8), "stream": hip.Stream()})
+                      "D": hip.Buffer(nq * 8), "E": hip.Buffer(nq * 8)})
     d_slot = lanes[0]["slot"]
 
     def step(i=0):
-        L = lanes[i % S]
-        ix.search_batch_device(L["dq"].ptr, nq, a.k, a.ef, 0, L["lab"].ptr, L["dist"].ptr, L["slot"].ptr, None, L["D"].ptr, L["E"].ptr, L["stream"].handle)
+        L = lanes[i % B]
+        ix.search_batch_device(L["dq"].ptr, nq, a.k, a.ef, 0, L["lab"].ptr, L["dist"].ptr, L["slot"].ptr, None, L["D"].ptr, L["E"].ptr, streams[i % S].handle)
 
     def barrier():
         hip.synchronize()
@@ -262,13 +270,16 @@ def main():
             rdv.barrier()
         hip.synchronize()
 
-    for i in range(a.warmup):
+    for i in range(max(a.warmup, 0)):
         step(i)
+    if a.warmup < B:  # every batch's D / E counters are read below: each batch runs at least once (untimed)
+        for i in range(a.warmup, B):
+            step(i)
     barrier()
     ev = [(hip.Event(), hip.Event()) for _ in range(a.steps)]
     t0 = time.perf_counter()
     for i, (s, e) in enumerate(ev):
-        st = lanes[i % S]["stream"].handle
+        st = streams[i % S].handle
         s.record(st)
         step(i)
         e.record(st)
@@ -286,7 +297,8 @@ def main():
         El = L["E"].download(nq, np.uint64).astype(np.float64)
         per_lane.append((Dl, El, float((Dl * row_bytes + El * (2 * a.M * 4) + row_bytes).sum())))
     D, E = per_lane[0][0], per_lane[0][1]
-    bytes_per_launch = float(np.mean([b for _, _, b in per_lane]))
+    # the timed steps' own launches: step i ran batch i mod B
+    bytes_per_launch = float(np.mean([per_lane[i % B][2] for i in range(a.steps)]))
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     # one launch at a time: bytes of a launch / its HIP-event duration.  Launches in flight side by side (--streams > 1) stretch
     # each other's durations, so there the rate is all launches' bytes / the timed region
@@ -306,19 +318,25 @@ def main():
         quality = None
         if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
             cpu = cpu_baseline(a, ix, base, queries, found)
-            if a.build_quality_rows > 0:
+            if a.build_quality_rows > 0 and a.quant == "f32" and a.metric != "hamming":
                 quality = build_quality(a)
 
-        traffic = None
+        # HBM-side bytes per launch from the PMC passes of THIS command line (scripts/profile_r03.sh: separate rocprofv3 --pmc
+        # passes, FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 per MI355X_MICROARCH.md), committed under profiles/.  Counters cannot
+        # be read from inside this process; a line whose configuration has no committed pass carries traffic = null.
+        traffic = traffic_src = dram = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
                 rec = json.load(open(prof))
-                key = f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves or 4}" + ("" if a.quant == "f32" else "_" + a.quant)
-                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+                key = (f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves or 4}" + ("" if a.quant == "f32" else "_" + a.quant)
+                       + ("" if a.data == "gaussian" else "_" + a.data) + (f"_b{B}" if B > 1 else ""))
+                hit = rec.get(key, {})
+                traffic = hit.get("hbm_bytes_per_launch")
+                dram = hit.get("dram_bytes_per_launch")
+                traffic_src = hit.get("source")
             except Exception:
                 traffic = None
-
         qps = world * nq * a.steps / elapsed
         out = {
             "metric": f"QPS (recall@{a.k} alongside), {a.n}x{a.dim} f32 {a.metric} ef={a.ef} k={a.k}",
@@ -332,7 +350,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f16": "f32 arithmetic on f16 storage", "i8": "int32 arithmetic on i8 storage", "b1": "popcount on 1-bit storage"}[a.quant],
-            "data": ("synthetic" if a.data == "gaussian" else "synthetic (low-rank)") + ("" if a.data_scale == 1.0 else f" x {a.data_scale}"),
+            "data": {"gaussian": "synthetic", "lowrank": "synthetic (low-rank)", "clustered": "synthetic (clustered: " + synth.CLUSTERED_DOC + ")"}[a.data]
+                    + ("" if a.data_scale == 1.0 else f" x {a.data_scale}"),
             "config": {"workload": f"HNSW search {a.n}x{a.dim} {a.quant} {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}",
                        "queries_per_step_per_gpu": nq, "global_queries_per_step": nq * world, "waves_per_query": a.waves,
                        "launches_in_flight": S,
@@ -347,18 +366,42 @@ def main():
             "build_roofline": build_roofline(a, build_counters, build_profile, t_build, world),
             "dist_evals_per_query": float(D.mean()),
             "expansions_per_query": float(E.mean()),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command; not re-measured in this run)" if traffic else None,
-                         "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": avg_kernel_s * 1e3,
-                         "note": None if S == 1 else f"{S} launches in flight: achieved = all launches' algorithmic bytes / the timed region; avg_launch_ms is "
-                                                      "the mean HIP-event duration of launches that overlap"},
+            "roofline": roofline(achieved, traffic, dram, traffic_src, avg_kernel_s if S == 1 else elapsed / a.steps, bytes_per_launch, avg_kernel_s, S, B),
             "cpu_baseline": cpu,
             "build_quality": quality,
             "collective_build": collective,
             "setup_seconds": {"datagen": t_gen, "build": t_build, "exact_truth": t_truth},
         }
     finish(out)
+
+
+def roofline(achieved, traffic, dram, traffic_src, launch_s, bytes_per_launch, avg_kernel_s, S, B):
+    """The search kernel against the HBM roofline.  `frac` is the contract's figure: ALGORITHMIC bytes (one row per distance
+    evaluation, one adjacency row per expansion, D and E counted on the device) / launch time / the 8 TB/s spec peak.  A walk's
+    algorithmic bytes are not all DRAM bytes -- upper levels and hub rows are shared between the queries of a launch and are
+    served by L2 / the 256 MiB Infinity Cache -- so `frac` can exceed what DRAM alone could deliver; `frac_traffic` (the
+    fabric-side counter bytes over the same time) and `measured_ceiling` (what a pure stream reaches on this part) are given
+    beside it, and `note` says so whenever `frac` is above either."""
+    frac = achieved / HBM_PEAK_GBS
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+         "traffic": traffic, "traffic_source": traffic_src,
+         "frac_traffic": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+         "dram_bytes_per_launch": dram,
+         "frac_dram": (dram / launch_s / 1e9 / HBM_PEAK_GBS) if dram else None,
+         "measured_ceiling": HBM_MEASURED_CEILING_GBS, "frac_of_measured_ceiling": achieved / HBM_MEASURED_CEILING_GBS,
+         "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_kernel_s * 1e3,
+         "query_batches_rotated": B, "note": None}
+    notes = []
+    if S > 1:
+        notes.append(f"{S} launches in flight: achieved = all launches' algorithmic bytes / the timed region; avg_launch_ms is the mean HIP-event "
+                     "duration of launches that overlap")
+    if frac > 1.0 or achieved > HBM_MEASURED_CEILING_GBS:
+        notes.append("algorithmic bytes per second exceed " + ("the DRAM peak" if frac > 1.0 else "the measured streaming ceiling") +
+                     ": rows that several queries of a launch evaluate (upper levels, hub rows) are counted once per evaluation but served by "
+                     "L2 / Infinity Cache; frac_traffic (fabric-side counter bytes, which still include Infinity-Cache hits) and frac_dram "
+                     "(where the DRAM-side counters were collected) are the physical figures")
+    r["note"] = "; ".join(notes) or None
+    return r
 
 
 def build_roofline(a, c, prof, t_build, world):
@@ -370,35 +413,40 @@ def build_roofline(a, c, prof, t_build, world):
     row = a.dim * {"f32": 4, "f16": 2, "i8": 1, "b1": 0.125}[a.quant]
     scale = 1.0 / max(world, 1)  # counters and event times are this rank's share of a collective build
     walk_bytes = c["add_walk_evals"] * row + c["add_expansions"] * (2 * a.M * 4)
-    reprune_bytes = c["add_reprunes"] * (2 * a.M + 2) * row
     out = {"note": "achieved = algorithmic bytes / time of that phase's kernels (HIP events inside the library); peak 8 TB/s HBM",
            "phases_ms": {k: prof[k] for k in ("walk_ms", "connect_ms", "group_ms", "revlink_ms", "exchange_ms")},
            "device_ms_total": sum(prof[k] for k in ("walk_ms", "connect_ms", "group_ms", "revlink_ms", "exchange_ms")),
            "host_and_idle_ms": max(0.0, t_build * 1e3 - sum(prof[k] for k in ("walk_ms", "connect_ms", "group_ms", "revlink_ms", "exchange_ms")))}
-    for name, nbytes, ms in (("walk", walk_bytes, prof["walk_ms"]), ("reprune", reprune_bytes, prof["revlink_ms"])):
-        gbs = nbytes / max(ms, 1e-9) / 1e6
-        out[name] = {"bound": "hbm", "algorithmic_bytes": float(nbytes), "ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gbs / HBM_PEAK_GBS}
-    out["reprune"]["note"] = ("the reference algorithm's traffic: cap + 2 rows per request to a full list.  The device cuts the requests that sort "
-                              "behind a list's recorded radius without reading a row, so this is NOT what its re-prune kernels read; the phase is "
-                              "bound by the latency of the remaining chains, not by bytes")
+    gbs = walk_bytes / max(prof["walk_ms"], 1e-9) / 1e6
+    out["walk"] = {"bound": "hbm", "algorithmic_bytes": float(walk_bytes), "ms": prof["walk_ms"], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": gbs / HBM_PEAK_GBS}
+    # the re-prune phase is bound by the latency of its dependent chains, not by bytes: the device cuts most requests to a full
+    # list from the list's recorded radius without reading a row, so no byte roofline is claimed for it -- counts only
+    out["reprune"] = {"bound": "latency (dependent chains per list)", "ms": prof["revlink_ms"], "requests_to_full_lists": c["add_reprunes"],
+                      "distance_evaluations": c["add_revlink_evals"],
+                      "rows_read_bytes": float(c["add_revlink_evals"]) * row}
     return out
 
 
 def build_quality(a):
     """north_star: "recall@10 within +-0.5 % of the reference".  The reference builds with one usearch_add per tuple
     (build.c:83-135); the device builds batch-synchronously (batches of up to --add-batch, never more than size / 16).  On
-    the BASELINE config[1] shape (100k x 128, seeds 1 / 2; --build-quality-rows) both builds are made from the same rows --
-    the sequential one by the CPU port, usearch's own summation flags -- and searched ON THE DEVICE with the same queries
-    against exact truth.  (tests/test_gpu_baseline_configs.py asserts the same on this set and on a 200k x 768 low-rank set.)"""
+    --build-quality-rows rows of the bench's OWN shape (--dim, --metric, --data; seeds 1 / 2) both builds are made from the
+    same rows -- the sequential one by the CPU port, usearch's own summation flags -- and searched ON THE DEVICE with the same
+    queries against exact truth.  (tests/test_gpu_fullsize.py asserts the same on the full 1M x 768 headline set,
+    tests/test_gpu_baseline_configs.py on the C2 set, a low-rank and a clustered set.)"""
     from lantern_amd import capi
     from oracle import binding as oracle
 
-    n, d = a.build_quality_rows, 128
-    base = np.random.default_rng(1).standard_normal((n, d), dtype=np.float32)
-    queries = np.random.default_rng(2).standard_normal((1000, d), dtype=np.float32)
+    from lantern_amd import synth
+
+    n, d = a.build_quality_rows, a.dim
+    make = synth.query_maker(a.data, d)
+    base = make(np.random.default_rng(1), n)
+    queries = make(np.random.default_rng(2), 1000)
     labels = np.arange(n, dtype=np.uint64) + 1
-    dev = capi.GpuIndex("l2sq", d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
+    metric = a.metric
+    dev = capi.GpuIndex(metric, d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
     dev.reserve(n)
     dev.set_add_batch(a.add_batch, 16)
     t0 = time.perf_counter()
@@ -408,16 +456,16 @@ def build_quality(a):
     truth, _ = dev.exact_search(queries, a.k)
     lab, _, _ = dev.search_batch(queries, a.k, a.ef)
     r_dev = oracle.recall_at_k(lab.astype(np.int64) - 1, truth)
-    seq = oracle.OracleIndex("l2sq", d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, sum_mode=oracle.SUM_FAST)
+    seq = oracle.OracleIndex(metric, d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, sum_mode=oracle.SUM_FAST)
     seq.reserve(n)
     t0 = time.perf_counter()
     seq.add_many(labels, base)
     t_seq = time.perf_counter() - t0
-    ref = capi.GpuIndex("l2sq", d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
+    ref = capi.GpuIndex(metric, d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
     ref.import_graph(base, seq.export_graph())
     lab2, _, _ = ref.search_batch(queries, a.k, a.ef)
     r_seq = oracle.recall_at_k(lab2.astype(np.int64) - 1, truth)
-    return {"set": f"{n}x{d} f32 l2sq N(0,1), seeds 1 / 2 (BASELINE config[1] shape), 1000 queries, ef={a.ef}",
+    return {"set": f"{n}x{d} f32 {metric} {a.data}, seeds 1 / 2 (the bench's own --dim / --metric / --data), 1000 queries, ef={a.ef}",
             "recall_device_batched_build": r_dev, "recall_sequential_build": r_seq, "abs_diff": abs(r_dev - r_seq), "bar": 0.005,
             "device_build_seconds": t_dev, "sequential_cpu_build_seconds": t_seq, "sequential_cpu_build_vectors_per_s": n / t_seq}
 

@@ -900,6 +900,38 @@ __global__ void __launch_bounds__(256) k_gather(View v, const uint4 *query, cons
     }
 }
 
+// The same evaluations in the WALK's shape (calibration of the random-row fetch rate a hop's distance phase can reach:
+// scripts/bench_gather_ceiling.py): persistent workgroups of four waves, six per CU, the query row in LDS, every G-lane group
+// keeping TWO rows in flight (group_dist2_n) -- hop_distances without the hop.  Same chains, same trees: same bits as k_gather.
+template <int METRIC, int G>
+__global__ void __launch_bounds__(256, 6) k_gather_walkshape(View v, const uint4 *query, const uint32_t *slots, uint32_t n, float *out)
+{
+    uint4 *q = (uint4 *)lgpu_smem;
+    __shared__ float qn_s;
+    const uint32_t tid = threadIdx.x, gl = tid % G, NG = blockDim.x / G;
+    for(uint32_t i = tid; i < v.chunks; i += blockDim.x) q[ i ] = query[ i ];
+    __syncthreads();
+    if(kCachedNorms<METRIC>) {
+        if(tid < G) {
+            const float qn = group_norm<METRIC, G>(q, (int)v.chunks, (int)tid);
+            if(tid == G - 1) qn_s = qn;
+        }
+        __syncthreads();
+    }
+    const float    qn2 = kCachedNorms<METRIC> ? qn_s : 0.f;
+    const uint32_t gid = blockIdx.x * NG + tid / G, ngroups = gridDim.x * NG;
+    for(uint32_t i = gid; i < n; i += 2 * ngroups) {
+        const uint32_t j = i + ngroups;
+        const uint32_t id0 = slots[ i ], id1 = j < n ? slots[ j ] : id0;
+        float          d0, d1;
+        group_dist2_n<METRIC, G>(q, row_of(v, id0), row_of(v, id1), (int)v.chunks, (int)gl, qn2, row_norm<METRIC>(v, id0), row_norm<METRIC>(v, id1), d0, d1);
+        if(gl == G - 1) {
+            out[ i ] = d0;
+            if(j < n) out[ j ] = d1;
+        }
+    }
+}
+
 template <int METRIC, int G>
 __global__ void __launch_bounds__(256) k_pairs(const uint4 *a, uint32_t na, const uint4 *b, uint32_t nb, uint32_t chunks, float *out)
 {
@@ -1041,6 +1073,19 @@ hipError_t launch_gather(int metric, const View &v, const uint4 *query, const ui
     const int G_ = group_lanes_for(v.chunks);
     uint32_t  blocks = (uint32_t)(((uint64_t)n * G_ + 255) / 256);
     if(blocks > 8192) blocks = 8192;
+    if(const char *ws = std::getenv("LANTERN_GPU_GATHER_WALKSHAPE")) {  // calibration runs: the walk's launch shape (k_gather_walkshape)
+        if(std::atoi(ws) != 0) {
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)cus * 6, ((uint64_t)n * G_ + 255) / 256);
+            const size_t   lds = (size_t)v.chunks * 16;
+#define CALLW(MM, GG) hipLaunchKernelGGL((k_gather_walkshape<MM, GG>), dim3(grid), dim3(256), lds, stream, v, query, slots, n, out)
+            LGPU_DISPATCH(metric, v.chunks, CALLW);
+#undef CALLW
+            return hipGetLastError();
+        }
+    }
 #define CALL(MM, GG) hipLaunchKernelGGL((k_gather<MM, GG>), dim3(blocks), dim3(256), 0, stream, v, query, slots, n, out)
     LGPU_DISPATCH(metric, v.chunks, CALL);
 #undef CALL

@@ -88,6 +88,10 @@ def lib() -> C.CDLL:
     L.lo_add.argtypes = [vp, u64, vp]
     L.lo_add_with_level.argtypes = [vp, u64, vp, i32]
     L.lo_add_batch.argtypes = [vp, vp, vp, sz]
+    L.lo_set_wave_simd.restype = None
+    L.lo_set_wave_simd.argtypes = [i32]
+    L.lo_set_build_threads.restype = None
+    L.lo_set_build_threads.argtypes = [vp, i32]
     L.lo_plan_batch.restype = sz
     L.lo_plan_batch.argtypes = [sz, i32, vp, sz, sz, sz]
     L.lo_search.restype = sz
@@ -130,6 +134,11 @@ def distance(a, b, metric: str | int, sum_mode: int = SUM_SEQ) -> float:
     return float(lib().lo_distance(_ptr(A), _ptr(B), dims, m, sum_mode))
 
 
+def set_wave_simd(on: bool):
+    """SUM_WAVE64 over f32: the AVX2 form (default where available) or the scalar restatement -- identical bits."""
+    lib().lo_set_wave_simd(1 if on else 0)
+
+
 def round_f16(x) -> np.ndarray:
     """f32 -> f16 -> f32, round-to-nearest-even: what an f16 index stores and what it casts a query to."""
     return np.ascontiguousarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
@@ -145,6 +154,26 @@ def quantize_i8(x) -> np.ndarray:
 
 def level_for(seed: int, slot: int, M: int) -> int:
     return int(lib().lo_level_for(seed, slot, M))
+
+
+def levels_for(seed: int, first_slot: int, count: int, M: int) -> np.ndarray:
+    """lo_level_for of `count` consecutive slots (vectorised restatement of oracle/hnsw.c lo_level_for: splitmix64 hash of
+    (seed, slot) -> U in (0, 1] -> floor(-ln(U) / ln(M)); checked against the C function in tests/test_oracle_golden.py)."""
+    m64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mix(x):
+        with np.errstate(over="ignore"):
+            x = (x + np.uint64(0x9E3779B97F4A7C15)) & m64
+            x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & m64
+            x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & m64
+            return x ^ (x >> np.uint64(31))
+
+    with np.errstate(over="ignore"):
+        slots = np.arange(first_slot, first_slot + count, dtype=np.uint64)
+        h = mix(np.uint64(seed) ^ mix(slots + np.uint64(0x632BE59BD9B4E019)))
+    u = ((h >> np.uint64(11)).astype(np.float64) + 1.0) * (1.0 / 9007199254740992.0)
+    level = -np.log(u) * (1.0 / np.log(float(M)))
+    return np.minimum(level, 255.0).astype(np.int32)
 
 
 def plan_batch(size, max_level, pending_levels, max_batch, min_ratio) -> int:
@@ -208,6 +237,10 @@ class OracleIndex:
         for l, v in zip(labels, _rows(vecs, self.metric)):
             self.add(l, v)
 
+    def set_build_threads(self, nthreads):
+        """Threads for the two phases of add_batch / add_planned (the graph does not depend on the number)."""
+        lib().lo_set_build_threads(self.h, int(nthreads))
+
     def add_batch(self, labels, vecs):
         V = _rows(vecs, self.metric)
         lab = np.ascontiguousarray(labels, dtype=np.uint64)
@@ -222,7 +255,7 @@ class OracleIndex:
         while i < n:
             size = len(self)
             look = min(n - i, max_batch)
-            lv = [level_for(self.seed, size + j, self.M) for j in range(look)]
+            lv = levels_for(self.seed, size, look, self.M)
             b = plan_batch(size, self.max_level, lv, max_batch, min_ratio)
             self.add_batch(lab[i:i + b], V[i:i + b])
             i += b

@@ -10,6 +10,7 @@
  * refine_, connect_new_node_, reconnect_neighbor_nodes_) are the upstream usearch names of
  * the steps being restated.
  */
+#define _GNU_SOURCE /* qsort_r */
 #include "lantern_oracle.h"
 
 #include <math.h>
@@ -59,6 +60,7 @@ struct lo_index
     int       max_level;
     lo_ctx    ctx;
     uint64_t  last_D, last_E;
+    int       build_threads; /* lo_add_batch: threads for the two phases of a batch (results do not depend on it) */
 };
 
 /* ---------------------------------------------------------------------------------------- */
@@ -273,20 +275,19 @@ static void search_level(const lo_index *ix, lo_ctx *c, const void *q, uint32_t 
  */
 static inline uint32_t tie_mix(uint32_t id, uint32_t centre) { return (id ^ (centre * 0x9E3779B1u)) * 0x85EBCA6Bu; }
 
-static uint32_t g_sort_centre; /* qsort context (oracle is single-threaded while building) */
-static int      refine_cmp(const void *a, const void *b)
+static int refine_cmp(const void *a, const void *b, void *centre_p) /* qsort_r: phases A and B of a batch may run on several threads */
 {
-    cand_t x = *(const cand_t *)a, y = *(const cand_t *)b;
+    cand_t   x = *(const cand_t *)a, y = *(const cand_t *)b;
+    uint32_t centre = *(const uint32_t *)centre_p;
     if(x.d != y.d) return x.d < y.d ? -1 : 1;
-    uint32_t hx = tie_mix(x.id, g_sort_centre), hy = tie_mix(y.id, g_sort_centre);
+    uint32_t hx = tie_mix(x.id, centre), hy = tie_mix(y.id, centre);
     return hx < hy ? -1 : (hx > hy ? 1 : 0);
 }
 
 /* list[0..n): candidates with their distance to `centre`; sorted here; keeps <= needed. */
 static size_t refine(const lo_index *ix, cand_t *list, size_t n, size_t needed, uint32_t centre)
 {
-    g_sort_centre = centre;
-    qsort(list, n, sizeof(cand_t), refine_cmp);
+    qsort_r(list, n, sizeof(cand_t), refine_cmp, &centre);
     if(n < needed) return n;
     size_t submitted = 1, consumed = 1;
     while(submitted < needed && consumed < n) {
@@ -413,9 +414,8 @@ typedef struct
 /* phase A for one new node against the graph as it stands (entry/max_level given):
  * search_for_one_ + per level { search_to_insert_, refine_ (connect_new_node_) }.
  * Writes the node's own lists; appends its reverse-link requests to links[]. */
-static size_t insert_search(lo_index *ix, uint32_t new_slot, uint32_t entry, int max_level, link_t *links)
+static size_t insert_search(lo_index *ix, lo_ctx *c, uint32_t new_slot, uint32_t entry, int max_level, link_t *links)
 {
-    lo_ctx     *c = &ix->ctx;
     const void *q = lo_vector(ix, new_slot);
     int         target = ix->levels[ new_slot ];
     size_t      nl = 0;
@@ -446,7 +446,7 @@ int lo_add_with_level(lo_index *ix, uint64_t label, const void *vec, int level)
         return 0;
     }
     link_t *links = (link_t *)malloc(sizeof(link_t) * (size_t)ix->M * (size_t)(level + 1) + sizeof(link_t));
-    size_t  nl = insert_search(ix, slot, entry, max_level, links);
+    size_t  nl = insert_search(ix, &ix->ctx, slot, entry, max_level, links);
     for(size_t i = 0; i < nl; ++i) reverse_link(ix, links[ i ].close, links[ i ].level, slot, links[ i ].d);
     free(links);
     if(level > max_level) {
@@ -486,6 +486,73 @@ size_t lo_plan_batch(size_t current_size, int max_level, const int *pending_leve
     return b;
 }
 
+/* ---- the two phases of a batch on several threads ------------------------------------------
+ * Phase A: every new node walks the PRE-BATCH graph (new nodes have no in-links yet, so no walk reads what another
+ * walk writes: each writes only its own node's lists and its own segment of links[]).  Phase B: the requests,
+ * sorted by (close, level, new_slot), fall into groups that touch one list each; groups are independent.  Both
+ * phases therefore give the same graph on any number of threads -- the single-thread loop is the definition. */
+typedef struct
+{
+    lo_index *ix;
+    uint32_t  entry;
+    int       max_level;
+    size_t    first, n;
+    const size_t *seg;     /* [n+1] first link of each new node */
+    size_t   *seg_count;   /* [n]   links it produced */
+    link_t   *links;
+    size_t    total_links; /* phase B */
+    size_t    next;
+    pthread_mutex_t mu;
+} build_job;
+
+static void *phase_a_worker(void *arg)
+{
+    build_job *job = (build_job *)arg;
+    lo_ctx     c;
+    memset(&c, 0, sizeof(c));
+    for(;;) {
+        pthread_mutex_lock(&job->mu);
+        size_t begin = job->next;
+        job->next += 8;
+        pthread_mutex_unlock(&job->mu);
+        if(begin >= job->n) break;
+        size_t end = begin + 8 < job->n ? begin + 8 : job->n;
+        for(size_t i = begin; i < end; ++i)
+            job->seg_count[ i ] = insert_search(job->ix, &c, (uint32_t)(job->first + i), job->entry, job->max_level, job->links + job->seg[ i ]);
+    }
+    ctx_free(&c);
+    return NULL;
+}
+
+static void *phase_b_worker(void *arg)
+{
+    build_job *job = (build_job *)arg;
+    lo_index  *ix = job->ix;
+    for(;;) {
+        /* claim a run of requests, extended to whole (close, level) groups */
+        pthread_mutex_lock(&job->mu);
+        size_t begin = job->next;
+        size_t end = begin + 256 < job->total_links ? begin + 256 : job->total_links;
+        while(end < job->total_links && job->links[ end ].close == job->links[ end - 1 ].close && job->links[ end ].level == job->links[ end - 1 ].level) ++end;
+        job->next = end;
+        pthread_mutex_unlock(&job->mu);
+        if(begin >= job->total_links) break;
+        for(size_t i = begin; i < end; ++i) reverse_link(ix, job->links[ i ].close, job->links[ i ].level, job->links[ i ].new_slot, job->links[ i ].d);
+    }
+    return NULL;
+}
+
+static void run_workers(build_job *job, void *(*fn)(void *), int nthreads)
+{
+    pthread_t th[ 256 ];
+    if(nthreads > 256) nthreads = 256;
+    job->next = 0;
+    for(int t = 0; t < nthreads; ++t) pthread_create(&th[ t ], NULL, fn, job);
+    for(int t = 0; t < nthreads; ++t) pthread_join(th[ t ], NULL);
+}
+
+void lo_set_build_threads(lo_index *ix, int nthreads) { ix->build_threads = nthreads < 1 ? 1 : nthreads; }
+
 int lo_add_batch(lo_index *ix, const uint64_t *labels, const void *vecs, size_t n)
 {
     if(n == 0) return 0;
@@ -499,18 +566,47 @@ int lo_add_batch(lo_index *ix, const uint64_t *labels, const void *vecs, size_t 
     size_t   first = ix->n, total_links = 0, cap_links = 0;
     for(size_t i = 0; i < n; ++i)
         if(lo_level_for(ix->seed, first + i, ix->M) > max_level) return -2; /* planner contract violated */
+    size_t *seg = (size_t *)malloc(sizeof(size_t) * (n + 1));
     for(size_t i = 0; i < n; ++i) {
         int lvl = lo_level_for(ix->seed, ix->n, ix->M);
         node_make(ix, labels[ i ], (const uint8_t *)vecs + i * ix->vec_bytes, lvl);
+        seg[ i ] = cap_links;
         cap_links += (size_t)ix->M * (size_t)(lvl + 1);
     }
+    seg[ n ] = cap_links;
     link_t *links = (link_t *)malloc(sizeof(link_t) * (cap_links + 1));
-    /* phase A: every new node sees only the pre-batch graph (new nodes have no in-links yet) */
-    for(size_t i = 0; i < n; ++i) total_links += insert_search(ix, (uint32_t)(first + i), entry, max_level, links + total_links);
-    /* phase B: reverse links, grouped by (close, level), applied in new-slot order */
-    qsort(links, total_links, sizeof(link_t), link_cmp);
-    for(size_t i = 0; i < total_links; ++i)
-        reverse_link(ix, links[ i ].close, links[ i ].level, links[ i ].new_slot, links[ i ].d);
+    const int threads = ix->build_threads > 1 && n >= 64 ? ix->build_threads : 1;
+    if(threads == 1) {
+        /* phase A: every new node sees only the pre-batch graph (new nodes have no in-links yet) */
+        for(size_t i = 0; i < n; ++i) total_links += insert_search(ix, &ix->ctx, (uint32_t)(first + i), entry, max_level, links + total_links);
+        /* phase B: reverse links, grouped by (close, level), applied in new-slot order */
+        qsort(links, total_links, sizeof(link_t), link_cmp);
+        for(size_t i = 0; i < total_links; ++i)
+            reverse_link(ix, links[ i ].close, links[ i ].level, links[ i ].new_slot, links[ i ].d);
+    } else {
+        build_job job;
+        memset(&job, 0, sizeof(job));
+        job.ix = ix;
+        job.entry = entry;
+        job.max_level = max_level;
+        job.first = first;
+        job.n = n;
+        job.seg = seg;
+        job.seg_count = (size_t *)calloc(n, sizeof(size_t));
+        job.links = links;
+        pthread_mutex_init(&job.mu, NULL);
+        run_workers(&job, phase_a_worker, threads);
+        for(size_t i = 0; i < n; ++i) { /* compact the segments (the sort below fixes the order) */
+            if(seg[ i ] != total_links) memmove(links + total_links, links + seg[ i ], sizeof(link_t) * job.seg_count[ i ]);
+            total_links += job.seg_count[ i ];
+        }
+        qsort(links, total_links, sizeof(link_t), link_cmp);
+        job.total_links = total_links;
+        run_workers(&job, phase_b_worker, threads);
+        pthread_mutex_destroy(&job.mu);
+        free(job.seg_count);
+    }
+    free(seg);
     free(links);
     return 0;
 }

@@ -103,6 +103,12 @@ int lo_add_with_level(lo_index *, uint64_t label, const void *vec, int level);
  * is the semantics of the device builder (and approximates usearch's concurrent add_raw,
  * lantern_cli/src/external_index/server.rs:333-356). */
 int lo_add_batch(lo_index *, const uint64_t *labels, const void *vecs, size_t n);
+/* threads for the two phases of lo_add_batch (walks of a batch are independent; so are its (node, level) groups of
+ * reverse links): the graph does not depend on the number -- tests/test_oracle_golden.py builds with 1 and with 4 */
+void lo_set_build_threads(lo_index *, int nthreads);
+/* LO_SUM_WAVE64 over f32 runs eight lanes of the tree per AVX2 instruction where the host has them; 0 selects the scalar
+ * restatement (identical bits: tests compare the two) */
+void lo_set_wave_simd(int on);
 /* The device builder's batch plan: which prefix of the pending vectors forms the next batch.
  * Returned value >= 1. */
 size_t lo_plan_batch(size_t current_size, int max_level, const int *pending_levels, size_t pending,

@@ -32,3 +32,20 @@ def oracle():
     binding.build()
     binding.lib()
     return binding
+
+
+def usable_cores() -> int:
+    """Threads this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+@pytest.fixture(scope="session")
+def cores():
+    return usable_cores()

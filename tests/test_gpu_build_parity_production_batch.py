@@ -1,0 +1,96 @@
+"""Build parity at the PRODUCTION batch size.
+
+The device inserts batch-synchronously: batches of up to 8192 new nodes (never more than size / 16), every walk of a batch on
+the pre-batch graph, then the reverse links grouped by (node, level).  tests/test_gpu_parity.py pins that against the oracle
+edge for edge, but on toy sizes (batches <= 156).  The regime the late device logic was written for -- groups of 200-400
+requests per (node, level) per batch on hub-heavy Gaussian rows, k_revlink_pairs' chain form, k_revlink_append's radius cut,
+the re-prune radii that outlive a batch -- only exists with 8192-row batches.  Here: 100k-row sets built on the device with
+the default plan (8192, 16) against oracle.add_planned(8192, 16) in the device's summation order -- levels, entry point and
+EVERY adjacency row of every level equal.  (The reference builds with one usearch_add per tuple, build.c:83-135; the
+batch-synchronous plan is deviation 6 of DESIGN.md 3.4, and its effect on recall is measured separately.)"""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M, EFC = 16, 128
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from lantern_amd import capi
+
+    capi.lib()
+    assert capi.device_count() > 0
+    return capi
+
+
+def device_build(capi, metric, base, plan=(8192, 16), seed=42):
+    ix = capi.GpuIndex(metric, base.shape[1], M=M, ef_construction=EFC, ef=64, seed=seed)
+    ix.reserve(base.shape[0])
+    ix.set_add_batch(*plan)
+    ix.add_many(np.arange(base.shape[0], dtype=np.uint64) + 1, base)
+    ix.flush()
+    return ix
+
+
+def oracle_build(oracle, metric, base, cores, plan=(8192, 16), seed=42):
+    o = oracle.OracleIndex(metric, base.shape[1], M=M, ef_construction=EFC, ef=64, seed=seed, sum_mode=oracle.SUM_WAVE64)
+    o.reserve(base.shape[0])
+    o.set_build_threads(cores)  # a batch's walks and its (node, level) groups are independent: same graph on any thread count
+    o.add_planned(np.arange(base.shape[0], dtype=np.uint64) + 1, base, max_batch=plan[0], min_ratio=plan[1])
+    return o
+
+
+def assert_same_graph(gg, go):
+    assert gg["entry_slot"] == go["entry_slot"] and gg["max_level"] == go["max_level"]
+    for key in ("levels", "labels", "upper_off"):
+        assert np.array_equal(gg[key], go[key]), key
+    if not np.array_equal(gg["nbr0"], go["nbr0"]):
+        bad = np.flatnonzero((gg["nbr0"] != go["nbr0"]).any(axis=1))
+        raise AssertionError(f"level-0 adjacency differs in {bad.size} rows; first: node {bad[0]}: device {gg['nbr0'][bad[0]].tolist()} oracle {go['nbr0'][bad[0]].tolist()}")
+    assert np.array_equal(gg["upper_nbr"], go["upper_nbr"]), "upper-level adjacency differs"
+
+
+CASES = {
+    # name: (metric, seed, rows, dims, plan)
+    "c2_gaussian_100k_x_128_l2sq": ("l2sq", 1, 100_000, 128, (8192, 16)),          # SURVEY 8d C2 rows; batches grow to 6250 (size / 16)
+    "c2_gaussian_100k_x_128_l2sq_ratio4": ("l2sq", 1, 100_000, 128, (8192, 4)),    # full 8192-row batches from 32k rows on: heavier contention per list
+    "gaussian_160k_x_768_l2sq": ("l2sq", 3, 160_000, 768, (8192, 16)),             # the headline set's first rows (hub-heavy); 8192-row batches from 131k on
+    "gaussian_60k_x_768_cos": ("cos", 3, 60_000, 768, (8192, 8)),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_device_build_with_8192_row_batches_is_the_oracles_graph_edge_for_edge(capi, oracle, cores, name):
+    metric, seed, n, d, plan = CASES[name]
+    base = np.random.default_rng(seed).standard_normal((n, d), dtype=np.float32)
+    t0 = time.time()
+    dev = device_build(capi, metric, base, plan)
+    t_dev = time.time() - t0
+    c = dev.counters()
+    t0 = time.time()
+    ora = oracle_build(oracle, metric, base, cores, plan)
+    t_ora = time.time() - t0
+    print(f"{name}: device {t_dev:.1f} s, oracle {t_ora:.1f} s on {cores} threads; batches {c['add_batches']}, "
+          f"re-prunes per vector {c['add_reprunes'] / n:.2f}, re-prune evaluations per vector {c['add_revlink_evals'] / n:.0f}")
+    # the regime is the one meant: batches in the thousands, full lists re-pruned again and again
+    assert c["add_batches"] < 400 and c["add_reprunes"] > n // 2
+    assert_same_graph(dev.export_graph(), ora.export_graph())
+
+
+def test_recorded_radii_do_not_change_the_graph(capi, monkeypatch):
+    """LANTERN_GPU_REPRUNE_STATE=0 sends every request to a full list through the all-pairs re-prune; the default cuts the
+    requests that sort behind a list's recorded radius without reading a row and keeps that radius across batches.  Same
+    decisions: identical graphs (checksum over every list of every level)."""
+    base = np.random.default_rng(3).standard_normal((200_000, 768), dtype=np.float32)
+    dev = device_build(capi, "l2sq", base)
+    want = dev.checksum()
+    evals = dev.counters()["add_revlink_evals"]
+    del dev
+    monkeypatch.setenv("LANTERN_GPU_REPRUNE_STATE", "0")
+    plain = device_build(capi, "l2sq", base)
+    assert plain.checksum() == want
+    assert plain.counters()["add_revlink_evals"] > evals  # ... and the state really was off

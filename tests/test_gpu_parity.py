@@ -509,6 +509,21 @@ def test_i8_storage_matches_oracle(capi, oracle, metric, n, d, M, efc):
     assert np.array_equal(other.search_batch(queries, 10)[0], lab)
 
 
+@pytest.mark.parametrize("metric,d", [("l2sq", 768), ("cos", 768), ("l2sq", 128), ("hamming", 24), ("cos", 100)])
+def test_gather_in_the_walks_launch_shape_has_the_same_bits(capi, metric, d, monkeypatch):
+    """scripts/bench_gather_ceiling.py calibrates the random-row fetch rate with the distance phase of a hop on its own
+    (persistent four-wave workgroups, two rows in flight per group): same chains and trees as the plain gather."""
+    rng = np.random.default_rng(d)
+    base = rand_rows(rng, 3000, d, metric)
+    ix = capi.GpuIndex(metric, d, M=4, ef_construction=16, ef=16, seed=1)
+    ix.add_many(np.arange(3000, dtype=np.uint64) + 1, base)
+    q = rand_rows(rng, 1, d, metric)[0]
+    slots = rng.integers(0, 3000, 20_001).astype(np.uint32)
+    plain = ix.distance_gather(q, slots)
+    monkeypatch.setenv("LANTERN_GPU_GATHER_WALKSHAPE", "1")
+    assert np.array_equal(ix.distance_gather(q, slots), plain)
+
+
 @pytest.mark.parametrize("metric", ["l2sq", "cos"])
 def test_i8_rows_wider_than_2032_dims_in_a_small_batch(capi, oracle, metric):
     """Batches of 64 .. 4 x CUs queries take the small-batch launch shape; i8 rows of >= 128 chunks (>= 2033 dims: usearch_init

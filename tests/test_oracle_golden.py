@@ -255,3 +255,52 @@ def test_oracle_regression_fixture(oracle):
     assert sorted(want) == sorted(c[0] for c in gen.CASES)
     for c in gen.CASES:
         assert gen.run_case(*c) == want[c[0]]["expect"], c[0]
+
+
+def test_wave_order_simd_form_has_the_scalar_restatements_bits(oracle):
+    """LO_SUM_WAVE64 over f32 runs eight lanes of the device's reduction tree per AVX2 instruction (the build-parity tests at
+    100k rows need it); the scalar loops are the definition.  Every shape class: fewer chunks than lanes, ragged last chunk,
+    ragged last round, each lane-count regime (8 / 16 / 32 / 64 lanes)."""
+    import numpy as np
+
+    rng = np.random.default_rng(5)
+    try:
+        for d in list(range(1, 70)) + [96, 100, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 768, 769, 770, 771, 1000, 1536, 2000]:
+            for metric in ("l2sq", "cos"):
+                a = rng.standard_normal(d, dtype=np.float32)
+                b = rng.standard_normal(d, dtype=np.float32)
+                oracle.set_wave_simd(True)
+                x = oracle.distance(a, b, metric, oracle.SUM_WAVE64)
+                oracle.set_wave_simd(False)
+                y = oracle.distance(a, b, metric, oracle.SUM_WAVE64)
+                assert np.float32(x).tobytes() == np.float32(y).tobytes(), (d, metric)
+    finally:
+        oracle.set_wave_simd(True)
+
+
+def test_batch_phases_on_several_threads_build_the_same_graph(oracle):
+    """lo_add_batch may run a batch's walks and its (node, level) groups of reverse links on several threads (walks read only
+    the pre-batch graph, groups touch one list each): the graph must not depend on the thread count."""
+    import numpy as np
+
+    rng = np.random.default_rng(12)
+    for metric, n, d, M in (("l2sq", 4000, 48, 6), ("cos", 2500, 130, 4)):
+        base = rng.standard_normal((n, d), dtype=np.float32)
+        labels = np.arange(n, dtype=np.uint64) + 1
+        graphs = []
+        for threads in (1, 4):
+            ix = oracle.OracleIndex(metric, d, M=M, ef_construction=40, ef=32, seed=6, sum_mode=oracle.SUM_WAVE64)
+            ix.set_build_threads(threads)
+            ix.add_planned(labels, base, max_batch=1024, min_ratio=8)
+            graphs.append(ix.export_graph())
+        for key in ("levels", "nbr0", "upper_off", "upper_nbr", "labels"):
+            assert np.array_equal(graphs[0][key], graphs[1][key]), (metric, key)
+        assert graphs[0]["entry_slot"] == graphs[1]["entry_slot"]
+
+
+def test_vectorised_level_draw_is_lo_level_for(oracle):
+    import numpy as np
+
+    for seed, M, first in ((42, 16, 0), (7, 2, 12345), (1, 5, 999_000), (21, 128, 3)):
+        want = np.array([oracle.level_for(seed, first + j, M) for j in range(3000)])
+        assert np.array_equal(oracle.levels_for(seed, first, 3000, M), want)
