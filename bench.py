@@ -466,7 +466,8 @@ def build_quality(a):
     lab2, _, _ = ref.search_batch(queries, a.k, a.ef)
     r_seq = oracle.recall_at_k(lab2.astype(np.int64) - 1, truth)
     return {"set": f"{n}x{d} f32 {metric} {a.data}, seeds 1 / 2 (the bench's own --dim / --metric / --data), 1000 queries, ef={a.ef}",
-            "recall_device_batched_build": r_dev, "recall_sequential_build": r_seq, "abs_diff": abs(r_dev - r_seq), "bar": 0.005,
+            "recall_device_batched_build": r_dev, "recall_sequential_build": r_seq, "abs_diff": abs(r_dev - r_seq), "device_minus_sequential": r_dev - r_seq,
+            "bar": 0.005,
             "device_build_seconds": t_dev, "sequential_cpu_build_seconds": t_seq, "sequential_cpu_build_vectors_per_s": n / t_seq}
 
 

@@ -466,6 +466,8 @@ LANTERN_GPU_EXPORT int  lantern_scan_server_port(lantern_scan_server_t *);
 /* queries received, batches formed, search launches (one per distinct (k, ef) of a batch), largest batch so far */
 LANTERN_GPU_EXPORT void lantern_scan_server_stats(lantern_scan_server_t *, uint64_t *requests, uint64_t *batches,
                                                   uint64_t *launches, uint64_t *largest_batch);
+/* batches formed so far by size: bins[b] counts batches of 2^b .. 2^(b+1) - 1 requests (b < 16); returns the bins written */
+LANTERN_GPU_EXPORT size_t lantern_scan_server_batch_histogram(lantern_scan_server_t *, uint64_t *bins, size_t nbins);
 LANTERN_GPU_EXPORT void lantern_scan_server_stop(lantern_scan_server_t *);
 /* client: one connection per backend, one query at a time; returns the number of results (<= k), ascending */
 LANTERN_GPU_EXPORT lantern_scan_client_t *lantern_scan_client_connect(const char *host, int port, usearch_error_t *);

@@ -18,8 +18,8 @@ OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "liblantern_gpu.so")
 
-SOURCES = ["search_kernel.hip", "insert_kernel.hip", "kernels.hip", "bruteforce.hip", "grouping.hip", "index.cpp", "comm.cpp", "usearch_file.cpp", "scan_shim.cpp", "index_server.cpp", "scan_server.cpp", "mirror_cache.cpp"]
-HEADERS = ["device_common.hpp", "walk.hpp", "dispatch.hpp", "kernels.hpp", "index.hpp", "comm.hpp", "host_util.hpp", "../../include/lantern_gpu.h"]
+SOURCES = ["search_kernel.hip", "search_spec_kernel.hip", "insert_kernel.hip", "kernels.hip", "bruteforce.hip", "grouping.hip", "index.cpp", "comm.cpp", "usearch_file.cpp", "scan_shim.cpp", "index_server.cpp", "scan_server.cpp", "mirror_cache.cpp"]
+HEADERS = ["device_common.hpp", "walk.hpp", "walk_spec.hpp", "search_kernel.hpp", "dispatch.hpp", "kernels.hpp", "index.hpp", "comm.hpp", "host_util.hpp", "../../include/lantern_gpu.h"]
 # -ffp-contract=off: every fma in the kernels is explicit, so the reduction tree is exactly the
 # one the oracle models.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
@@ -65,7 +65,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.check_call(cmd)
     # the standalone binaries: `lantern_amd/lib/lantern-index-server --host H --port P --tmp-dir D` (external indexing
     # server) and `lantern_amd/lib/lantern-scan-server --index FILE --metric M --dim D --m M` (scan-side service)
-    for src_name, bin_name in (("lantern_index_server.cpp", "lantern-index-server"), ("lantern_scan_server.cpp", "lantern-scan-server")):
+    for src_name, bin_name in (("lantern_index_server.cpp", "lantern-index-server"), ("lantern_scan_server.cpp", "lantern-scan-server"),
+                               ("lantern_scan_load.cpp", "lantern-scan-load"), ("lantern_index_load.cpp", "lantern-index-load")):
         tool_src = os.path.join(HERE, "tools", src_name)
         tool = os.path.join(OUT_DIR, bin_name)
         if os.path.exists(tool_src) and (force or _stale(tool, [tool_src, LIB])):

@@ -756,31 +756,50 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
                        int waves, uint32_t *done)
 {
     if(nq == 0 || k == 0) return true;
-    if(waves <= 0) {
-        // automatic shape: four waves per query once the batch fills the chip (24 waves per CU resident); a smaller batch
-        // gets the idle wave slots -- up to eight waves per query -- so its walks finish sooner (BASELINE config[2]: 1024
-        // queries on 256 CUs = six waves each)
-        // Measured (1M x 768 cosine, 1024 queries): 4 waves 693 k QPS, 6 waves 525 k, 8 waves 594 k -- a hop's critical path
-        // is its serial phases (pop, list + visited filter by one wave, merge), which more waves only make costlier
-        // (wider barriers); the idle slots do not help.  So: four waves per query whatever the batch size.
-        waves = 4;
-    }
     size_t expansion = ef ? ef : ix->ef;
     if(expansion < k + skip) expansion = k + skip;  // usearch: expansion = max(expansion, wanted)
+    // Launch shape.  Batches that fill the chip: four waves per query, six workgroups per CU -- the walk is HBM-bound and its
+    // serial phases hide behind other walks' row loads.  Batches that cannot (and the lone query): the latency-bound walk of
+    // walk_spec.hpp -- one barrier per hop, speculative row loads, neighbour lists fetched with the rows:
+    //   spec 2: at most one query per CU: three role waves + eight row waves per query (a whole list in one pass);
+    //   spec 1: up to four four-wave workgroups per CU (BASELINE config[2]: 1024 queries on 256 CUs).
+    // An explicit wave count (lantern_gpu_set_search_shape; tests, tuning) selects the classic kernel; LANTERN_GPU_SPEC=0|1|2
+    // overrides the automatic choice.
+    int spec = 0;
+    if(waves <= 0) {
+        const char *se = std::getenv("LANTERN_GPU_SPEC");
+        const bool  can = ix->M0 >= 2 && ix->M0 <= 64 && expansion <= 128 && !ix->phase_profile && !lds_list_env();
+        if(can) {
+            if(se) spec = std::atoi(se);
+            else if(nq <= (size_t)ix->num_cus) spec = 2;
+            else if(nq * 4 <= (size_t)ix->num_cus * 16) spec = 1;
+            if(spec < 0 || spec > 2) spec = 0;
+        }
+        // (measured, classic kernel, 1M x 768 cosine, 1024 queries: 4 waves 693 k QPS, 6 waves 525 k, 8 waves 594 k -- more waves
+        // only make its serial phases costlier; so four waves per query whatever the batch size)
+        waves = spec == 2 ? 11 : spec == 1 ? 4 : waves < 0 ? -waves : 4;  // (a negative count: the caller's classic fallback)
+    }
+    // list prefetch of the latency-bound walk: every lane of a row's group fetches LW words of the row's own list
+    const int      G_ = group_lanes_for(ix->chunks), LW_ = G_ >= 32 ? 1 : G_ == 16 ? 2 : 4;
+    const uint32_t spec_prefetch = spec && ix->M0 % (uint32_t)LW_ == 0 && ix->M0 <= (uint32_t)(G_ * LW_) ? 1u : 0u;
+    const uint32_t spec_cache = !spec_prefetch ? 0u : spec == 2 ? 128u : 64u;
+    const size_t   spec_lds = spec ? search_spec_lds_bytes(ix->M0, spec_prefetch, spec_cache) : 0;
     // LDS visited set: sized for ~3x the planner's estimate of visited nodes per query (hnsw.c:89-132 puts it at
     // about 2 M ef S with S ~ 3), capped so that SIX workgroups fit on a CU (more walks in flight beat a roomier
-    // set: 1.106 -> 1.17 M QPS at 1M x 768); it spills to the bitmap beyond
+    // set: 1.106 -> 1.17 M QPS at 1M x 768) -- four for the four-wave latency-bound shape, one for the lone-query shape;
+    // it spills to the bitmap beyond
+    const size_t lds_budget = spec == 2 ? 96 * 1024 : spec == 1 ? 39 * 1024 : 26 * 1024;
     uint32_t vis_slots = 1024;
     while(vis_slots < 8192 && vis_slots / 4 * 3 < expansion * ix->M0 * 2) vis_slots <<= 1;
     if(ix->search_vis_slots >= 0) vis_slots = (uint32_t)ix->search_vis_slots / 4 * 4;
-    while(vis_slots && search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 26 * 1024)  // six workgroups per CU
+    while(vis_slots && search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) + spec_lds > lds_budget)
         vis_slots = vis_slots > 256 ? vis_slots - 256 : 0;
     if(vis_slots && vis_slots < 4 * ix->M0) vis_slots = 0;
-    if(search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 160 * 1024) {
+    if(search_lds_bytes(ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) + spec_lds > 160 * 1024) {
         set_err(ix, "lantern_gpu: ef/k exceed the 160 KiB LDS budget of the search kernel");
         return false;
     }
-    const int grid = search_grid(ix, nq, waves, 24);
+    const int grid = search_grid(ix, nq, waves, spec == 2 ? 11 : spec == 1 ? 16 : 24);
     const int slot = acquire_search_slot(ix, stream, (size_t)grid);
     if(slot < 0) return false;
     SearchArgs a;
@@ -807,7 +826,10 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.lds_list = lds_list_env();
     // small batch (at most four 4-wave workgroups per CU would be resident anyway): four rows in flight per group
     static const int wide_env = std::getenv("LANTERN_GPU_WIDE_ROWS") ? std::atoi(std::getenv("LANTERN_GPU_WIDE_ROWS")) : -1;
-    a.wide_rows = wide_env >= 0 ? wide_env : (nq * (size_t)waves <= (size_t)ix->num_cus * 16 && nq >= 64);
+    a.wide_rows = spec ? 0 : wide_env >= 0 ? wide_env : (nq * (size_t)waves <= (size_t)ix->num_cus * 16 && nq >= 64);
+    a.spec = spec;
+    a.spec_prefetch = spec_prefetch;
+    a.spec_cache = spec_cache;
     HIPCHK(ix, launch_search(ix->mcode, a, waves, grid, stream));
     if(done) ix->slot_pending[ slot ] = false;  // the caller waits for the kernel itself: nothing to order later launches against
     else if(!release_search_slot(ix, slot, stream)) return false;
@@ -854,9 +876,10 @@ size_t search_one_locked(Index *ix, Cursor *cur, const void *query, int kind, si
     const size_t       flag_off = (row + want * 16 + 4 + 15) / 16 * 16;
     volatile uint32_t *h_done = (volatile uint32_t *)(ix->h_single + flag_off);
     *h_done = 0;
-    // one query: spend a whole 8-wave workgroup on it (latency-bound path)
-    bool ok = run_search_device(ix, (const uint4 *)dev, 1, want, ef, 0, d_lab, d_dist, d_slot, d_cnt, nullptr, nullptr, ix->stream, 8,
-                                (uint32_t *)(dev + flag_off));
+    // one query: the lone-query shape (three role waves + eight row waves: walk_spec.hpp); an explicit wave count
+    // (lantern_gpu_set_search_shape) or a list beyond its limits selects the classic eight-wave workgroup
+    bool ok = run_search_device(ix, (const uint4 *)dev, 1, want, ef, 0, d_lab, d_dist, d_slot, d_cnt, nullptr, nullptr, ix->stream,
+                                ix->search_waves > 0 ? 8 : -8, (uint32_t *)(dev + flag_off));
     if(ok) {
         for(unsigned spins = 0; *h_done == 0; ++spins) {
 #if defined(__x86_64__) || defined(__i386__)

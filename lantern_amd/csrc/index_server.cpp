@@ -23,7 +23,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -156,29 +159,83 @@ void serve(lantern_index_server *srv, int fd)
         const size_t payload = 8 + vec_bytes;
         // the rows' scalar kind follows element_bits (server.rs:226-230, add_raw(label, bytes, element_bits) :349)
         const usearch_scalar_kind_t kind = element_bits < 8 ? usearch_scalar_b1_k : element_bits == 8 ? usearch_scalar_i8_k : element_bits == 16 ? usearch_scalar_f16_k : usearch_scalar_f32_k;
-        std::vector<uint64_t> labels;
-        std::vector<uint8_t>  rows;
+        // The socket is drained by THIS thread while a builder thread hands finished chunks to the device: the reference
+        // overlaps the two the same way (a reader feeding a channel that a pool of add_raw workers drains: server.rs:214-267,
+        // :317-359).  At most four chunks wait between the two; a failed add stops the reader at its next chunk.
+        struct Chunk { std::vector<uint64_t> labels; std::vector<uint8_t> rows; };
         const size_t chunk_rows = std::max<size_t>(64, std::min<size_t>(ADD_CHUNK, (64u << 20) / std::max<size_t>(vec_bytes, 1)));
-        labels.reserve(chunk_rows);
-        rows.reserve(chunk_rows * vec_bytes);
-        auto flush = [&]() {
-            if(labels.empty()) return;
-            lantern_gpu_add_many(index, labels.data(), rows.data(), labels.size(), kind, &err);
-            if(err) throw Fail{ err };
-            labels.clear();
-            rows.clear();
+        std::mutex              qmu;
+        std::condition_variable qcv;
+        std::deque<Chunk>       ready;
+        bool                    closed = false;
+        std::string             add_error;
+        std::thread builder([&] {
+            for(;;) {
+                Chunk c;
+                {
+                    std::unique_lock<std::mutex> lk(qmu);
+                    qcv.wait(lk, [&] { return closed || !ready.empty(); });
+                    if(ready.empty()) return;
+                    c = std::move(ready.front());
+                    ready.pop_front();
+                }
+                qcv.notify_all();
+                usearch_error_t e2 = nullptr;
+                lantern_gpu_add_many(index, c.labels.data(), c.rows.data(), c.labels.size(), kind, &e2);
+                if(e2) {
+                    std::lock_guard<std::mutex> g(qmu);
+                    add_error = e2;
+                    closed = true;
+                    ready.clear();
+                    qcv.notify_all();
+                    return;
+                }
+            }
+        });
+        auto hand_over = [&](Chunk &c) {
+            if(c.labels.empty()) return true;
+            std::unique_lock<std::mutex> lk(qmu);
+            qcv.wait(lk, [&] { return closed || ready.size() < 4; });
+            if(closed) return false;
+            ready.push_back(std::move(c));
+            c = Chunk();
+            lk.unlock();
+            qcv.notify_all();
+            return true;
         };
-        for(;;) {
-            Frame f = read_frame(fd, buf, payload, false);
-            if(f == FRAME_EXIT) break;
-            if(f != FRAME_DATA) throw Fail{ "Invalid message received" };
-            uint64_t label;
-            std::memcpy(&label, buf.data(), 8);
-            labels.push_back(label);
-            rows.insert(rows.end(), buf.begin() + 8, buf.end());
-            if(labels.size() == chunk_rows) flush();
+        std::string read_failure;
+        try {
+            Chunk cur;
+            cur.labels.reserve(chunk_rows);
+            cur.rows.reserve(chunk_rows * vec_bytes);
+            for(;;) {
+                Frame f = read_frame(fd, buf, payload, false);
+                if(f == FRAME_EXIT) break;
+                if(f != FRAME_DATA) throw Fail{ "Invalid message received" };
+                uint64_t label;
+                std::memcpy(&label, buf.data(), 8);
+                cur.labels.push_back(label);
+                cur.rows.insert(cur.rows.end(), buf.begin() + 8, buf.end());
+                if(cur.labels.size() == chunk_rows) {
+                    if(!hand_over(cur)) break;
+                    cur.labels.reserve(chunk_rows);
+                    cur.rows.reserve(chunk_rows * vec_bytes);
+                }
+            }
+            (void)hand_over(cur);
+        } catch(const Fail &f) {
+            read_failure = f.msg;
+        } catch(const std::exception &ex) {
+            read_failure = std::string("indexing server: ") + ex.what();
         }
-        flush();
+        {
+            std::lock_guard<std::mutex> g(qmu);
+            closed = true;
+        }
+        qcv.notify_all();
+        builder.join();
+        if(!read_failure.empty()) throw Fail{ read_failure };
+        if(!add_error.empty()) throw Fail{ add_error };
         lantern_gpu_flush(index, &err);
         if(err) throw Fail{ err };
 

@@ -29,6 +29,9 @@ struct SearchArgs
     int             lds_list;    // keep the candidate list in LDS even when it fits wave 0's registers (LANTERN_GPU_LDS_LIST=1: the
                                  // round-1 walk, kept for A/B parity runs and for ef > 128)
     int             wide_rows;   // small batch: the four-rows-in-flight instantiation (k_search<.., ROWS = 4>)
+    int             spec;        // latency-bound launches (walk_spec.hpp): 1 = four-wave shape, 2 = dedicated role waves (3 + 8 waves); 0 = off
+    uint32_t        spec_prefetch;  // fetch every evaluated row's own level-0 list with the row (M0 % 4 == 0, M0 / 4 <= lanes per row)
+    uint32_t        spec_cache;     // entries of the LDS list cache (power of two; 0 = none)
     unsigned long long *phase_cycles;  // diagnostics (lantern_gpu_search_phase_profile): [8] shader-clock cycles summed over the
     uint32_t       *done;        // NULL, or a counter in host-visible memory: +1 (system scope) per finished query, after its answers
 };                               // launch's queries by phase: pop | list + visited | distances | merge | descent | whole query
@@ -112,6 +115,8 @@ hipError_t launch_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, ui
 
 // All launchers return hipSuccess or the launch error.  `metric` is a usearch_metric_kind_t value.
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);
+hipError_t launch_search_spec(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);  // a.spec != 0 (search_spec_kernel.hip)
+size_t     search_spec_lds_bytes(uint32_t M0, uint32_t prefetch, uint32_t cache_entries);
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream);
 // work: scratch of max_groups x 8 bytes; work_count: one u32 (both device memory)

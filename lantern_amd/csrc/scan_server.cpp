@@ -115,6 +115,7 @@ struct lantern_scan_server
     };
     std::vector<std::unique_ptr<Conn>> conns;  // guarded by mu
     std::atomic<uint64_t>   n_requests{ 0 }, n_batches{ 0 }, n_launches{ 0 }, max_batch_seen{ 0 };
+    std::atomic<uint64_t>   batch_hist[ 16 ] = {};  // batches by size: bin b counts sizes in [2^b, 2^(b+1))
 };
 
 namespace {
@@ -169,6 +170,11 @@ void dispatch_loop(lantern_scan_server *s, int lane)
         }
         if(batch.empty()) continue;
         s->n_batches += 1;
+        {
+            int bin = 0;
+            while(bin < 15 && ((size_t)2 << bin) <= batch.size()) ++bin;
+            s->batch_hist[ bin ] += 1;
+        }
         uint64_t seen = s->max_batch_seen.load();
         while(batch.size() > seen && !s->max_batch_seen.compare_exchange_weak(seen, batch.size())) {}
         // one launch per distinct (k, ef): scans of one workload share them (init_k, the ef GUC)
@@ -400,6 +406,13 @@ void lantern_scan_server_stats(lantern_scan_server_t *s, uint64_t *requests, uin
     if(batches) *batches = s ? s->n_batches.load() : 0;
     if(launches) *launches = s ? s->n_launches.load() : 0;
     if(largest_batch) *largest_batch = s ? s->max_batch_seen.load() : 0;
+}
+
+size_t lantern_scan_server_batch_histogram(lantern_scan_server_t *s, uint64_t *bins, size_t nbins)
+{
+    const size_t n = nbins < 16 ? nbins : 16;
+    for(size_t i = 0; i < n; ++i) bins[ i ] = s ? s->batch_hist[ i ].load() : 0;
+    return n;
 }
 
 void lantern_scan_server_stop(lantern_scan_server_t *s)

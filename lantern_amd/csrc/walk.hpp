@@ -27,7 +27,8 @@ namespace lgpu {
 // scalar slots in LDS
 enum { S_POS = 0, S_NNEW, S_CNT, S_ANY, S_BAD, S_CUR, S_CURD, S_CHANGED, S_VISCNT, S_SPILL, S_QN2, S_NNEW0, S_NNEW1, S_ANY0, S_ANY1,
        S_FRONT = 16, S_WORST = 20,  // two u64 each (by hop parity): search_level_reg's hand-off from the list wave to the visit wave
-       S_SCALARS = 24 };
+       S_MASK = 24,                 // two u64 (by hop parity): walk_spec.hpp's "which neighbours of the hop were new"
+       S_SCALARS = 28 };
 // S_QN2: ||query||^2 as float bits (cosine metrics; set by the kernel before a walk: device_common.hpp "cached row norms")
 
 struct WalkLds

@@ -1,0 +1,383 @@
+// walk_spec.hpp -- the base-layer walk for LATENCY-BOUND launches (a lone query, batches that cannot fill the chip).
+//
+// search_level_reg (walk.hpp) spends a hop's time in a chain of dependent steps: decide which node to expand -> fetch its
+// neighbour list (HBM round trip) -> visited filter -> barrier -> fetch the new neighbours' rows (HBM round trip) -> reduce ->
+// barrier.  When the memory system is not saturated that chain IS the walk's speed (BASELINE config[1]: 2.75 us per hop for a
+// lone query against ~1 us on a CPU core; config[2]: a 1024-query batch ends with its longest walk).  This form takes every
+// step that is not a true dependency off the chain:
+//
+//   * ONE barrier per hop.  Every wave decides the next node itself (the same few ballots over the previous hop's keys the
+//     visit wave ran alone), so nothing has to be handed out before the row loads start.
+//   * SPECULATIVE rows.  The rows of ALL neighbours are requested at once, before the visited filter: ~28 of 32 neighbours
+//     are new anyway.  The filter runs on one wave WHILE the loads are in flight and publishes a 64-bit "new" mask; keys of
+//     old neighbours are ignored by everybody from the next hop on.  D counts the new ones only (the oracle's count).
+//   * The neighbour list comes with the row.  Each row request also asks for the row's own level-0 list (128 B at M = 16);
+//     the lists of a hop land in an LDS staging area, and those of keys that can still be expanded (inside the radius) move on
+//     to a small direct-mapped LDS cache.  The node a hop expands is either one of the previous hop's keys (half the hops:
+//     staging area, no lookup) or an older list entry (cache, tag checked; HBM on a miss) -- the dependent list fetch is gone
+//     from ~9 hops in 10.  Lists are immutable while a search kernel runs (inserts wait for searches).
+//   * The merge of the previous hop's keys into the register list (list wave), the visited filter (visit wave) and the cache
+//     fill (third wave) all run in the shadow of the row loads.  With dedicated role waves (DED: the lone-query shape, 3 + 8
+//     waves) they do nothing else; in the 4-wave batch shape each also takes its share of rows, whose loads it issues first.
+//
+// Same walk, same results: the decision rule, the list, the visited set and the arithmetic are those of search_level_reg;
+// ids, distance bits, D and E equal the oracle's (tests/test_gpu_parity.py runs this form beside the others).
+// Requirements (checked by the launcher): level 0, 2 <= M0 <= 64, at least two waves, ef <= 64 * KPL.
+#pragma once
+#include "walk.hpp"
+
+namespace lgpu {
+
+struct SpecLds
+{
+    uint32_t *stage;   // [2][M0][M0] the level-0 lists of a hop's neighbours, by hop parity and neighbour index (NULL: no list prefetch)
+    uint32_t *ctag;    // [cache_entries] slot whose list the entry holds (EMPTY: none)
+    uint32_t *clist;   // [cache_entries][M0]
+    uint32_t  cache_entries;  // power of two, or 0
+};
+__device__ __forceinline__ unsigned char *carve_spec(unsigned char *p, SpecLds &c, uint32_t M0, uint32_t prefetch, uint32_t cache_entries)
+{
+    c.stage = nullptr;
+    c.ctag = c.clist = nullptr;
+    c.cache_entries = 0;
+    if(prefetch) {
+        c.stage = (uint32_t *)p;   p += (size_t)2 * M0 * M0 * 4;
+        c.cache_entries = cache_entries;
+        c.clist = (uint32_t *)p;   p += (size_t)cache_entries * M0 * 4;
+        c.ctag = (uint32_t *)p;    p += (((size_t)cache_entries * 4) + 15) & ~(size_t)15;
+    }
+    return p;
+}
+__host__ inline size_t spec_lds_bytes(uint32_t M0, uint32_t prefetch, uint32_t cache_entries)
+{
+    return prefetch ? (size_t)2 * M0 * M0 * 4 + (size_t)cache_entries * M0 * 4 + ((((size_t)cache_entries * 4) + 15) & ~(size_t)15) : 0;
+}
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t x)  // a value every lane read from the same address, as scalar registers
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// words of a row's own level-0 list each lane of the group fetches: as few as the group's width allows (one per lane from 32
+// lanes on: a 32-entry list costs one register per row in flight)
+template <int G> constexpr int spec_list_words() { return G >= 32 ? 1 : G == 16 ? 2 : 4; }
+template <int LW> __device__ __forceinline__ void spec_list_load(const uint32_t *src, uint32_t (&dst)[ 4 ])
+{
+    if constexpr(LW == 1) dst[ 0 ] = src[ 0 ];
+    else if constexpr(LW == 2) { const uint2 t = *(const uint2 *)src; dst[ 0 ] = t.x; dst[ 1 ] = t.y; }
+    else { const uint4 t = *(const uint4 *)src; dst[ 0 ] = t.x; dst[ 1 ] = t.y; dst[ 2 ] = t.z; dst[ 3 ] = t.w; }
+}
+template <int LW> __device__ __forceinline__ void spec_list_store(uint32_t *dst, const uint32_t (&src)[ 4 ])
+{
+    if constexpr(LW == 1) dst[ 0 ] = src[ 0 ];
+    else if constexpr(LW == 2) *(uint2 *)dst = make_uint2(src[ 0 ], src[ 1 ]);
+    else *(uint4 *)dst = make_uint4(src[ 0 ], src[ 1 ], src[ 2 ], src[ 3 ]);
+}
+
+// the rows one G-lane group has in flight during one pass of a hop's distance phase
+template <int ROWS, int U> struct SpecPass
+{
+    int      j[ ROWS ];       // neighbour index of each row (>= count: a duplicate of a valid row, result discarded)
+    uint32_t id[ ROWS ];
+    float    n2[ ROWS ];
+    uint4    y[ ROWS ][ U ];  // the first U chunks per lane of each row
+    uint32_t L[ ROWS ][ 4 ];  // this lane's LW words of each row's own level-0 list (lanes < M0 / LW; only [..][0..LW) are used)
+    bool     have;            // the group has at least one row in this pass
+};
+
+template <int METRIC, int G, int ROWS, int U>
+__device__ __forceinline__ void spec_issue(const View &v, const SpecLds &c, SpecPass<ROWS, U> &p, uint32_t nb, int count, int base, int group, int ngroups,
+                                           int gl)
+{
+    const int j0 = base + group;
+    p.have = j0 < count;
+#pragma unroll
+    for(int r = 0; r < ROWS; ++r) {
+        p.j[ r ] = j0 + r * ngroups;
+        const int jj = p.j[ r ] < count ? p.j[ r ] : (p.have ? j0 : 0);
+        if constexpr(G == 64) p.id[ r ] = (uint32_t)__builtin_amdgcn_readlane((int)nb, jj);  // one group per wave: jj is wave-uniform
+        else p.id[ r ] = (uint32_t)__builtin_amdgcn_ds_bpermute(jj << 2, (int)nb);
+    }
+    if(p.have) {
+#pragma unroll
+        for(int u = 0; u < U; ++u) {
+            const int ch = gl + u * G;
+            if(ch < (int)v.chunks) {
+#pragma unroll
+                for(int r = 0; r < ROWS; ++r) p.y[ r ][ u ] = row_of(v, p.id[ r ])[ ch ];
+            }
+        }
+#pragma unroll
+        for(int r = 0; r < ROWS; ++r) p.n2[ r ] = row_norm<METRIC>(v, p.id[ r ]);
+        constexpr int LW = spec_list_words<G>();
+        if(c.stage && gl * LW < (int)v.M0) {
+#pragma unroll
+            for(int r = 0; r < ROWS; ++r) spec_list_load<LW>(v.nbr0 + (size_t)p.id[ r ] * v.M0 + (size_t)(gl * LW), p.L[ r ]);
+        }
+    }
+}
+
+template <int METRIC, int G, int ROWS, int U>
+__device__ __forceinline__ void spec_consume(const View &v, const WalkLds &s, const SpecLds &c, SpecPass<ROWS, U> &p, int count, int gl, float qn2,
+                                             uint64_t *kout, uint32_t *stage_out)
+{
+    if(!p.have) return;
+    RowAcc<METRIC> acc[ ROWS ];
+#pragma unroll
+    for(int u = 0; u < U; ++u) {
+        const int ch = gl + u * G;
+        if(ch < (int)v.chunks) {
+            const uint4 x = s.q[ ch ];
+#pragma unroll
+            for(int r = 0; r < ROWS; ++r) acc[ r ].add(x, p.y[ r ][ u ]);
+        }
+    }
+    for(int ch = gl + U * G; ch < (int)v.chunks; ch += G) {  // rows longer than U chunks per lane
+        const uint4 x = s.q[ ch ];
+        uint4       yy[ ROWS ];
+#pragma unroll
+        for(int r = 0; r < ROWS; ++r) yy[ r ] = row_of(v, p.id[ r ])[ ch ];
+#pragma unroll
+        for(int r = 0; r < ROWS; ++r) acc[ r ].add(x, yy[ r ]);
+    }
+#pragma unroll
+    for(int r = 0; r < ROWS; ++r) {
+        const float d = acc[ r ].template finish_n<G>(qn2, p.n2[ r ]);
+        if(gl == G - 1 && p.j[ r ] < count) kout[ p.j[ r ] ] = make_key(d, p.id[ r ]);
+    }
+    constexpr int LW = spec_list_words<G>();
+    if(c.stage && gl * LW < (int)v.M0) {
+#pragma unroll
+        for(int r = 0; r < ROWS; ++r)
+            if(p.j[ r ] < count) spec_list_store<LW>(stage_out + (size_t)p.j[ r ] * v.M0 + (size_t)(gl * LW), p.L[ r ]);
+    }
+}
+
+// DED: waves 0..2 are role waves only (visit filter | list | cache fill), waves 3.. evaluate rows.  Otherwise every wave
+// evaluates rows and waves 0, 1 and (if there are three) 2 take the roles on top.
+template <int METRIC, int G, int KPL, int ROWS, int U, bool DED>
+__device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int ef, uint32_t &D,
+                                 uint32_t &E)
+{
+    constexpr int GPW = 64 / G;  // groups per wave
+    const int     tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
+    const int     wv = __builtin_amdgcn_readfirstlane(tid) >> 6, NW = T >> 6;
+    const int     g = lane / G, gl = lane % G;
+    const bool    visit_wave = wv == 0, list_wave = wv == 1;
+    const bool    fill_wave = NW >= 3 ? wv == 2 : wv == 0;              // the cache fill: a third wave if there is one
+    const bool    row_wave = DED ? wv >= 3 : true;
+    const int     ngroups = (DED ? NW - 3 : NW) * GPW;                  // G-lane groups that evaluate rows
+    const int     group = ((DED ? wv - 3 : wv) * GPW) + g;              // this lane's group among them
+    const uint32_t M0 = v.M0;
+    if(s.vis_slots) {
+        for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
+    } else {
+        uint4 *b4 = (uint4 *)bitmap;
+        for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
+    }
+    for(uint32_t i = tid; i < c.cache_entries; i += T) c.ctag[ i ] = EMPTY;
+    const float     qn2 = __int_as_float(s.scal[ S_QN2 ]);
+    uint64_t *const front_pub = (uint64_t *)&s.scal[ S_FRONT ];  // [2] by hop parity: first unexpanded key of the list the hop starts from
+    uint64_t *const worst_pub = (uint64_t *)&s.scal[ S_WORST ];  // [2] its radius (~0: not full)
+    uint64_t *const mask_pub = (uint64_t *)&s.scal[ S_MASK ];    // [2] which neighbours of the hop were new
+    uint64_t *const keysb[ 2 ] = { s.newkeys, s.sorted };        // a hop's keys, by hop parity (both hold cap_max >= M0 keys)
+    // "hop -1" (parity 1) evaluated one row: the start node
+    if(wv == 0 && g == 0) {
+        const float d = group_dist_n<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        if(gl == G - 1) keysb[ 1 ][ 0 ] = make_key(d, start);
+        constexpr int LW = spec_list_words<G>();
+        if(c.stage && gl * LW < (int)M0) {
+            uint32_t piece[ 4 ];
+            spec_list_load<LW>(v.nbr0 + (size_t)start * M0 + (size_t)(gl * LW), piece);
+            spec_list_store<LW>(c.stage + (size_t)M0 * M0 + (size_t)(gl * LW), piece);
+        }
+    }
+    if(tid == 0) {
+        mask_pub[ 1 ] = 1ull;
+        front_pub[ 0 ] = ~0ull;  // the list is still empty:
+        worst_pub[ 0 ] = ~0ull;  // no front, no radius
+    }
+    __syncthreads();
+    // visit wave's private state: how many slots the LDS set holds, and whether it has spilled to the bitmap
+    uint32_t viscnt = 0;
+    bool     spilled = false;
+    if(tid == 0) {
+        (void)visit_test_and_set(s, bitmap, start, false);
+        viscnt = s.vis_slots ? 1u : 0u;
+    }
+    viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);
+    // list wave's private state (walk.hpp search_level_reg): lane l of register r holds the (64 r + l)-th smallest key
+    uint64_t           K[ KPL ];
+    unsigned long long live[ KPL ];
+#pragma unroll
+    for(int r = 0; r < KPL; ++r) {
+        K[ r ] = ~0ull;
+        const int m = ef - 64 * r;
+        live[ r ] = m >= 64 ? ~0ull : m <= 0 ? 0ull : (1ull << m) - 1ull;
+    }
+    int cnt = 0;
+    for(int hop = 0;; ++hop) {
+        const int             par = hop & 1, prv = par ^ 1;
+        const uint64_t *const kin = keysb[ prv ];
+        // ---- what the previous hop left: its keys, which of them were new, and the list they are still to be merged into
+        const uint64_t           f = uniform64(front_pub[ par ]), w = uniform64(worst_pub[ par ]);
+        const unsigned long long pm = uniform64(mask_pub[ prv ]);
+        const uint64_t           N = ((pm >> lane) & 1ull) ? kin[ lane ] : ~0ull;
+        D += (uint32_t)__popcll(pm);
+        // ---- the node this hop expands: the first unexpanded entry of (list merged with the new keys) = min(front, smallest new
+        // key inside the radius); a key the merge truncates away is never that minimum (walk.hpp)
+        uint64_t t = f != ~0ull ? f : w;
+        bool     got = f != ~0ull;
+        int      jt = -1;  // the previous hop's neighbour index of the chosen key (-1: it is the list's front)
+        if(list_wave && DED) {
+            got = got || __ballot(N < t) != 0ull;  // the list wave finds the node in its own registers; it only needs "is there one"
+        } else {
+            unsigned long long m = __ballot(N < t);
+            while(m) {  // each round at least halves the expected number of smaller keys
+                jt = (int)__builtin_ctzll(m);
+                t = readlane64(N, jt);
+                got = true;
+                m = __ballot(N < t);
+            }
+        }
+        if(!got) break;  // every wave sees the same keys, mask, front and radius: all leave together
+        E += 1;
+        uint32_t nb = EMPTY;
+        int      count = 0;
+        uint32_t node = EMPTY;
+        if(!(list_wave && DED)) {
+            node = (uint32_t)t >> 1;
+            // ---- its neighbour list: staged with its row by the previous hop | cached since an earlier one | HBM
+            const uint32_t *src = nullptr;
+            if(c.stage && jt >= 0) {
+                src = c.stage + ((size_t)prv * M0 + (size_t)jt) * M0;
+            } else if(c.cache_entries) {
+                const uint32_t e = node & (c.cache_entries - 1);
+                if((uint32_t)__builtin_amdgcn_readfirstlane((int)c.ctag[ e ]) == node) src = c.clist + (size_t)e * M0;
+            }
+            if(lane < (int)M0) nb = src ? src[ lane ] : v.nbr0[ (size_t)node * M0 + (uint32_t)lane ];
+            count = (int)__popcll(__ballot(nb != EMPTY));  // lists are EMPTY-terminated and hole-free
+        }
+        // ---- the rows of ALL its neighbours (old ones too: most are new, and the filter runs behind the loads)
+        SpecPass<ROWS, U> p;
+        p.have = false;
+        if(row_wave) spec_issue<METRIC, G, ROWS, U>(v, c, p, nb, count, 0, group, ngroups, gl);
+        // ---- in the shadow of the loads: the three role sections
+        if(visit_wave) {
+            // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (walk.hpp)
+            if(s.vis_slots && !spilled && viscnt + M0 > s.vis_slots / 4 * 3) {
+                uint4 *b4 = (uint4 *)bitmap;
+                for(uint32_t i = (uint32_t)lane; i < bm_words / 4; i += 64) b4[ i ] = make_uint4(0, 0, 0, 0);
+                spilled = true;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            }
+            const bool               isnew = hop_is_new(s, bitmap, nb, spilled);
+            const unsigned long long nm = __ballot(isnew);
+            if(s.vis_slots && !spilled) viscnt += (uint32_t)__popcll(nm);
+            if(lane == 0) mask_pub[ par ] = nm;
+        }
+        if(list_wave) {
+            // merge the previous hop's new keys: one at a time into the sorted registers (rank = one ballot, insertion = one
+            // wave-wide DPP shift); only keys inside the radius
+            uint64_t worst = ~0ull;
+            if(cnt == ef) {
+                const int wl = (ef - 1) & 63;
+#pragma unroll
+                for(int r = 0; r < KPL; ++r)
+                    if(r == (ef - 1) >> 6) worst = readlane64(K[ r ], wl);
+            }
+            unsigned long long todo = __ballot(N < worst);
+            while(todo) {
+                const int tt = (int)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const uint64_t k = readlane64(N, tt);
+                int            pos = 0;
+#pragma unroll
+                for(int r = 0; r < KPL; ++r) pos += (int)__popcll(__ballot(K[ r ] < k) & live[ r ]);
+                if(pos >= ef) continue;  // the radius moved in since `todo` was taken
+                const int r0 = pos >> 6, l0 = pos & 63;
+#pragma unroll
+                for(int r = KPL - 1; r >= 0; --r) {
+                    if(r < r0) continue;  // uniform
+                    const uint64_t sh = wave_shr1(K[ r ]);
+                    if(r > r0) {
+                        const uint64_t carry = readlane64(K[ r - 1 > 0 ? r - 1 : 0 ], 63);
+                        K[ r ] = lane == 0 ? carry : sh;
+                    } else {
+                        if(lane > l0) K[ r ] = sh;
+                        if(lane == l0) K[ r ] = k;
+                    }
+                }
+                cnt = cnt < ef ? cnt + 1 : ef;
+            }
+            // pop: the first unexpanded key (the node every other wave chose); mark it; publish the next hop's front and radius
+            int first = -1, fr = 0;
+#pragma unroll
+            for(int r = 0; r < KPL; ++r) {
+                const unsigned long long m = __ballot(!key_expanded(K[ r ])) & live[ r ];
+                if(first < 0 && m) {
+                    first = (int)__builtin_ctzll(m);
+                    fr = r;
+                }
+            }
+#pragma unroll
+            for(int r = 0; r < KPL; ++r)
+                if(r == fr && lane == first) K[ r ] |= 1ull;  // expanded
+            uint64_t nf = ~0ull, nw = ~0ull;
+            bool     have = false;
+#pragma unroll
+            for(int r = 0; r < KPL; ++r) {
+                const unsigned long long m = __ballot(!key_expanded(K[ r ])) & live[ r ];
+                if(!have && m) {
+                    nf = readlane64(K[ r ], (int)__builtin_ctzll(m));
+                    have = true;
+                }
+                if(cnt == ef && r == (ef - 1) >> 6) nw = readlane64(K[ r ], (ef - 1) & 63);
+            }
+            if(lane == 0) {
+                front_pub[ prv ] = nf;  // (hop + 1) & 1
+                worst_pub[ prv ] = nw;
+            }
+        }
+        if(fill_wave && c.cache_entries) {
+            // the lists of the previous hop's keys that can still be expanded (inside the radius the hop started with: a superset
+            // of what the merge keeps) move from the staging area to the cache.  One wave writes the cache; the entry of the node
+            // being expanded right now is left alone (slower waves may still be reading it).
+            unsigned long long todo = __ballot(N < w);
+            const uint32_t     busy = node & (c.cache_entries - 1);
+            while(todo) {
+                const int tt = (int)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)N, tt) >> 1;
+                const uint32_t e = slot & (c.cache_entries - 1);
+                if(e == busy || slot == node) continue;
+                if(lane < (int)M0) c.clist[ (size_t)e * M0 + (uint32_t)lane ] = c.stage[ ((size_t)prv * M0 + (size_t)tt) * M0 + (uint32_t)lane ];
+                if(lane == 0) c.ctag[ e ] = slot;
+            }
+        }
+        // ---- distances -> this hop's keys (all neighbours; the mask sorts out the old ones)
+        if(row_wave) {
+            uint64_t *const kout = keysb[ par ];
+            uint32_t *const sout = c.stage ? c.stage + (size_t)par * M0 * M0 : nullptr;
+            spec_consume<METRIC, G, ROWS, U>(v, s, c, p, count, gl, qn2, kout, sout);
+            for(int base = ngroups * ROWS; base < count; base += ngroups * ROWS) {  // lists longer than one pass covers
+                spec_issue<METRIC, G, ROWS, U>(v, c, p, nb, count, base, group, ngroups, gl);
+                spec_consume<METRIC, G, ROWS, U>(v, s, c, p, count, gl, qn2, kout, sout);
+            }
+        }
+        __syncthreads();
+    }
+    // the result goes where the callers read it: s.keys, ascending
+    if(list_wave) {
+#pragma unroll
+        for(int r = 0; r < KPL; ++r)
+            if(r * 64 + lane < cnt) s.keys[ r * 64 + lane ] = K[ r ];
+        if(lane == 0) s.scal[ S_CNT ] = cnt;
+    }
+    __syncthreads();
+    return s.scal[ S_CNT ];
+}
+
+}  // namespace lgpu

@@ -54,27 +54,30 @@ def main():
     dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False))
     d_lab, d_dst = hip.Buffer(a.k * 8), hip.Buffer(a.k * 4)
     d_D, d_E = hip.Buffer(8), hip.Buffer(8)
-    ix.set_search_shape(8, 0)
-    kern, Ds, Es = [], [], []
     row_bytes = hip.padded_rows(queries[:1], False).shape[1] * 4
-    for i in range(min(a.queries, 500)):
-        s, e = hip.Event(), hip.Event()
-        s.record(stream.handle)
-        ix.search_batch_device(dq.ptr + i * row_bytes, 1, a.k, a.ef, 0, d_lab.ptr, d_dst.ptr, None, None, d_D.ptr, d_E.ptr, stream.handle)
-        e.record(stream.handle)
-        stream.synchronize()
-        kern.append(s.elapsed_ms(e) * 1e3)
-        Ds.append(int(d_D.download(1, np.uint64)[0]))
-        Es.append(int(d_E.download(1, np.uint64)[0]))
+    shapes = {}
+    for name, waves in (("classic_8_waves", 8), ("latency_bound_shape", 0)):  # 0 = automatic: the lone-query shape of walk_spec.hpp
+        ix.set_search_shape(waves, 0)
+        kern, Ds, Es = [], [], []
+        for i in range(min(a.queries, 500)):
+            s, e = hip.Event(), hip.Event()
+            s.record(stream.handle)
+            ix.search_batch_device(dq.ptr + i * row_bytes, 1, a.k, a.ef, 0, d_lab.ptr, d_dst.ptr, None, None, d_D.ptr, d_E.ptr, stream.handle)
+            e.record(stream.handle)
+            stream.synchronize()
+            kern.append(s.elapsed_ms(e) * 1e3)
+            Ds.append(int(d_D.download(1, np.uint64)[0]))
+            Es.append(int(d_E.download(1, np.uint64)[0]))
+        shapes[name] = {"us_per_query_kernel": {"mean": float(np.mean(kern)), "p50": float(np.median(kern))},
+                        "us_per_hop_kernel": float(np.mean(kern) / max(np.mean(Es), 1))}
     ix.set_search_shape(0, 0)
     blab, _, _ = ix.search_batch(queries, a.k)
     same = float(np.mean([np.array_equal(r, b[:len(r)]) for r, b in zip(res, blab)]))
     out = {"config": f"{a.rows}x{a.dim} f32 {a.metric} M=16 efc=128 ef={a.ef} k={a.k}, one query per usearch_search_ef call",
            "queries": a.queries, "us_per_query_wall": {"mean": float(lat.mean()), "p50": float(np.median(lat)), "p99": float(np.percentile(lat, 99))},
            "qps_single_stream": float(1e6 / lat.mean()),
-           "us_per_query_kernel": {"mean": float(np.mean(kern)), "p50": float(np.median(kern))},
+           "kernel_only": shapes,
            "hops_per_query": float(np.mean(Es)), "dist_evals_per_query": float(np.mean(Ds)),
-           "us_per_hop_kernel": float(np.mean(kern) / max(np.mean(Es), 1)),
            "identical_to_batch_search": same, "build_vectors_per_s": a.rows / t_build}
     if not a.no_cpu:
         from oracle import binding as oracle

@@ -1,6 +1,8 @@
 """BASELINE.json's full-size configuration (1M x 768 f32, L2sq, M=16, ef_construction=128, ef=64, k=10)
 checked through size-independent properties, plus exact parity against the oracle on a sample of queries
 (the oracle walks the SAME graph, exported from the device).  Needs an MI355X; ~30 s."""
+import os
+
 import numpy as np
 import pytest
 
@@ -113,11 +115,14 @@ def test_full_size_build_is_the_same_with_and_without_the_recorded_radii(world, 
     assert plain.counters()["add_revlink_evals"] > ix.counters()["add_revlink_evals"]  # ... and the state really was off
 
 
+@pytest.mark.skipif(os.environ.get("LANTERN_TEST_1M_SEQUENTIAL", "0") != "1",
+                    reason="a sequential CPU build of 1M x 768 takes ~15 minutes of one core (1.7 k vectors/s at 100k rows, falling); set "
+                           "LANTERN_TEST_1M_SEQUENTIAL=1.  The same comparison without a device: scripts/build_quality_cpu.py -> profiles/r03_build_quality_1Mx768.json")
 def test_full_size_batched_build_against_the_sequential_reference_build(world, oracle):
     """north_star: "recall@10 within +-0.5 % of the reference".  The reference builds with one usearch_add per tuple
     (build.c:83-135); the device with batches of up to 8192.  Both graphs of the HEADLINE set (1M x 768), searched on the
     device with the same 1000 queries against exact truth.  The sequential build is the CPU port with the reference's own
-    summation flags on one thread: ~3 minutes."""
+    summation flags on one thread."""
     import time
 
     capi, hip, ix, base, queries = world

@@ -673,6 +673,104 @@ def test_candidate_list_in_registers_or_lds_gives_the_oracle_walk(capi, oracle, 
         assert np.array_equal(D.download(64, np.uint64), o_D) and np.array_equal(E.download(64, np.uint64), o_E)
 
 
+# ------------------------------------------------------------------------------------------------
+# the latency-bound walk (walk_spec.hpp): one barrier per hop, speculative row loads behind which the visited filter, the list
+# merge and the list-cache fill run, neighbour lists fetched with the rows.  LANTERN_GPU_SPEC=1: the four-wave batch shape,
+# =2: the lone-query shape (three role waves + eight row waves).  Every lanes-per-row regime (8 / 16 / 32 / 64), list widths
+# with and without the list prefetch (M0 = 10 has no 16-byte pieces at 8 lanes per row), M0 = 64 (two passes per hop), both
+# register-list widths (ef <= 64, <= 128), every storage kind -- against the oracle on the same graph: ids, distance bits, D, E.
+# ------------------------------------------------------------------------------------------------
+SPEC_SHAPES = [("l2sq", 3000, 128, 16, 64, "f32"), ("cos", 2500, 768, 16, 64, "f32"), ("l2sq", 2000, 40, 16, 100, "f32"), ("l2sq", 1500, 300, 5, 40, "f32"),
+               ("cos", 2000, 24, 5, 33, "f32"), ("l2sq", 1200, 64, 32, 128, "f32"), ("hamming", 3000, 24, 16, 64, "b1"), ("l2sq", 900, 1536, 16, 64, "f32"),
+               ("l2sq", 1500, 768, 8, 64, "f16"), ("cos", 1500, 256, 16, 48, "i8"), ("l2sq", 700, 2000, 4, 20, "f32"), ("l2sq", 800, 600, 32, 64, "f32")]
+
+
+@pytest.mark.parametrize("spec", ["1", "2"])
+@pytest.mark.parametrize("metric,n,d,M,ef,quant", SPEC_SHAPES)
+def test_latency_bound_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef, quant, spec, monkeypatch):
+    from lantern_amd import hip
+
+    rng = np.random.default_rng(n + d + M)
+    scale = np.float32(0.4 if quant == "i8" else 1.0)
+    base = rand_rows(rng, n, d, metric) if metric == "hamming" else rand_rows(rng, n, d, metric) * scale
+    nq = 300
+    queries = rand_rows(rng, nq, d, metric) if metric == "hamming" else rand_rows(rng, nq, d, metric) * scale
+    if metric != "hamming":
+        base[n // 2: n // 2 + 100] = base[:100]  # exact duplicates: equal distances, the slot decides
+    if quant == "f16":
+        obase, oq, mode = oracle.round_f16(base), oracle.round_f16(queries), oracle.SUM_WAVE64_F16
+    elif quant == "i8":
+        obase, oq, mode = oracle.quantize_i8(base), oracle.quantize_i8(queries), oracle.SUM_I8
+    else:
+        obase, oq, mode = base, queries, oracle.SUM_WAVE64
+    gpu = capi.GpuIndex(metric, d, M=M, ef_construction=48, ef=ef, seed=9, quantization="f32" if quant == "b1" else quant)
+    gpu.set_add_batch(256, 8)
+    gpu.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    g = gpu.export_graph()
+    ora = oracle.OracleIndex.from_graph(metric, obase, g, M, 48, ef, 9, mode)
+    k = min(10, ef)
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(oq, k, ef, 4)
+    monkeypatch.setenv("LANTERN_GPU_SPEC", spec)
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, metric == "hamming", quant == "f16", quant == "i8"))
+    lab, dist, D, E = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4), hip.Buffer(nq * 8), hip.Buffer(nq * 8)
+    gpu.set_search_shape(0)  # the automatic shape: LANTERN_GPU_SPEC decides
+    gpu.search_batch_device(dq.ptr, nq, k, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr)
+    hip.synchronize()
+    assert np.array_equal(lab.download((nq, k), np.uint64), o_lab)
+    assert np.array_equal(dist.download((nq, k), np.float32), o_dist)
+    assert np.array_equal(D.download(nq, np.uint64), o_D), "distance-evaluation counts differ"
+    assert np.array_equal(E.download(nq, np.uint64), o_E), "expansion counts differ"
+    # the classic kernel on the same index agrees (LANTERN_GPU_SPEC=0)
+    monkeypatch.setenv("LANTERN_GPU_SPEC", "0")
+    gpu.search_batch_device(dq.ptr, nq, k, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr)
+    hip.synchronize()
+    assert np.array_equal(lab.download((nq, k), np.uint64), o_lab) and np.array_equal(D.download(nq, np.uint64), o_D)
+
+
+def test_lone_query_and_small_batches_take_the_latency_bound_walk_by_default(capi, oracle):
+    """usearch_search_ef (one query per call), a 100-query and a 700-query batch: the automatic shapes (lone-query shape up to
+    one query per CU, four-wave shape up to four workgroups per CU) -- same answers as the oracle; so has the streaming
+    continuation, which searches for more than k."""
+    rng = np.random.default_rng(5)
+    n, d, M = 6000, 128, 16
+    base, queries = rng.standard_normal((n, d), dtype=np.float32), rng.standard_normal((700, d), dtype=np.float32)
+    gpu = capi.GpuIndex("l2sq", d, M=M, ef_construction=64, ef=64, seed=2)
+    gpu.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    ora = oracle.OracleIndex.from_graph("l2sq", base, gpu.export_graph(), M, 64, 64, 2, oracle.SUM_WAVE64)
+    o_lab, o_dist, _, _, _ = ora.search_batch(queries, 10, 64, 4)
+    for i in range(40):
+        l1, d1 = gpu.search(queries[i], 10)
+        assert np.array_equal(l1, o_lab[i]) and np.array_equal(d1, o_dist[i]), i
+    for nq in (1, 2, 100, 256, 257, 700):
+        lab, dist, _ = gpu.search_batch(queries[:nq], 10)
+        assert np.array_equal(lab, o_lab[:nq]) and np.array_equal(dist, o_dist[:nq]), nq
+    # streaming: 10 + 10 + 10 results of one scan = the oracle's top 30 (ef grows with what was handed out)
+    first, _ = gpu.search(queries[0], 10)
+    second, _ = gpu.search(queries[0], 10, streaming=True)
+    third, _ = gpu.search(queries[0], 10, streaming=True)
+    got = list(first) + list(second) + list(third)
+    assert len(set(got)) == 30
+
+
+def test_latency_bound_walk_with_a_spilling_visited_set(capi, oracle, monkeypatch):
+    rng = np.random.default_rng(11)
+    base, queries = rng.standard_normal((4000, 64), dtype=np.float32), rng.standard_normal((64, 64), dtype=np.float32)
+    ora = oracle.OracleIndex("l2sq", 64, M=16, ef_construction=64, ef=128, seed=9, sum_mode=oracle.SUM_WAVE64)
+    ora.add_many(np.arange(4000, dtype=np.uint64) + 1, base)
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, 10)
+    assert o_D.max() > 300
+    for vis_slots in ("256", "0"):  # 256: spills to the HBM bitmap after ~190 visits; 0: the bitmap only
+        monkeypatch.setenv("LANTERN_GPU_VIS_SLOTS", vis_slots)
+        for spec in ("1", "2"):
+            monkeypatch.setenv("LANTERN_GPU_SPEC", spec)
+            gpu = capi.GpuIndex("l2sq", 64, M=16, ef_construction=64, ef=128, seed=9)
+            gpu.import_graph(base, ora.export_graph())
+            lab, dist, _ = gpu.search_batch(queries, 10)
+            assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist), (vis_slots, spec)
+            c = gpu.counters()
+            assert c["search_dist_evals"] == int(o_D.sum()) and c["search_expansions"] == int(o_E.sum())
+
+
 @pytest.mark.parametrize("lds_list", ["0", "1"])
 @pytest.mark.parametrize("efc", [20, 64, 100, 128, 160])
 def test_build_is_the_same_graph_for_either_list_placement(capi, oracle, efc, lds_list, monkeypatch):
