@@ -273,6 +273,19 @@ LANTERN_GPU_EXPORT void lantern_gpu_export_graph(usearch_index_t, uint8_t *level
                                                  usearch_error_t *);
 /* pq indexes: the code bytes, codes[size][num_subvectors] (export_graph's `vectors` are the decoded f32 rows) */
 LANTERN_GPU_EXPORT void lantern_gpu_export_codes(usearch_index_t, uint8_t *codes, usearch_error_t *);
+/* pq = true indexes, COMPACT form.  A node of a PQ index carries num_subvectors code bytes (usearch_storage.cpp:29-31); the
+ * device keeps every row's DECODING next to the codes because adding evaluates stored row against stored row.  A read-mostly
+ * index -- the scan-side mirror of a built index (scan.c:75-110) -- gives the decodings up: lantern_gpu_pq_compact frees them
+ * (10M x 768 at 96 subvectors: 0.96 GB of rows instead of 30.7 GB) and every search from then on evaluates rows by asymmetric
+ * distance computation over the code bytes: a per-query table of partial sums (subvector x centroid) in LDS, num_subvectors
+ * table entries added per row (lantern_amd/csrc/search_adc_kernel.hip; summation order defined there and restated by the
+ * oracle -- distances agree with the decoded-row path to 1e-5 relative, not bit for bit: PARITY UNPINNED BY THE REFERENCE).
+ * Anything that needs rows again (usearch_add, the exact search, an export with vectors) decodes them back first, as does
+ * lantern_gpu_pq_expand.  LANTERN_GPU_PQ_COMPACT=1 compacts a pq index right after it is loaded or mirrored. */
+LANTERN_GPU_EXPORT void lantern_gpu_pq_compact(usearch_index_t, usearch_error_t *);
+LANTERN_GPU_EXPORT void lantern_gpu_pq_expand(usearch_index_t, usearch_error_t *);
+/* HBM held by the index: the vector block (the code rows of a compact pq index) | adjacency, labels, levels, norms, codes */
+LANTERN_GPU_EXPORT void lantern_gpu_memory_usage(usearch_index_t, size_t *row_bytes, size_t *other_bytes, usearch_error_t *);
 LANTERN_GPU_EXPORT void lantern_gpu_import_graph(usearch_index_t, size_t size, const void *vectors,
                                                  const uint64_t *labels, const uint8_t *levels, const uint32_t *nbr0,
                                                  const uint32_t *upper_off, const uint32_t *upper_nbr,
@@ -311,6 +324,10 @@ LANTERN_GPU_EXPORT lantern_gpu_build_profile lantern_gpu_build_profile_get(usear
  * list, two or more waves per query: walk.hpp search_level_reg) thread 0 never merges: slot 3 ("merge") is then its pop
  * DECISION and slot 4 ("pop") the list wave's whole section (merge + pop + hand-off), which runs beside slots 3, 5 and 0. */
 LANTERN_GPU_EXPORT void lantern_gpu_search_phase_profile(usearch_index_t, int on, unsigned long long *out8, usearch_error_t *);
+/* the same for the latency-bound walk (lantern_amd/csrc/walk_spec.hpp): out32[8 * wave + i], waves 0..3 = visit | list | cache
+ * fill | a row wave; i = 0 decision, 1 neighbour list, 2 issuing the row loads, 3 the wave's role section, 4 loads landing +
+ * distances, 5 wait at the hop's barrier, 6 hops, 7 where lists came from (wave 0: staging area, wave 3: cache, wave 2: HBM) */
+LANTERN_GPU_EXPORT void lantern_gpu_spec_profile(usearch_index_t, int on, unsigned long long *out32, usearch_error_t *);
 
 /* order-independent-of-builder fingerprint of the graph (levels, labels, both adjacency arrays, entry point):
  * equal on two indexes iff they hold the same graph; used to check that replicas agree without moving them */

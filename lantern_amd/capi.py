@@ -87,6 +87,7 @@ EXPORTS = [
     "lantern_gpu_set_seed", "lantern_gpu_set_add_batch", "lantern_gpu_add_many", "lantern_gpu_flush",
     "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device",
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
+    "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile",
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_export_codes",
     "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_gpu_search_phase_profile", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
@@ -169,6 +170,10 @@ def lib() -> C.CDLL:
         "lantern_gpu_set_search_shape": (None, [vp, i32, i32, err]),
         "lantern_gpu_exact_search": (None, [vp, vp, sz, sz, vp, vp, err]),
         "lantern_gpu_distance_gather": (None, [vp, vp, vp, sz, vp, err]),
+        "lantern_gpu_spec_profile": (None, [vp, i32, vp, err]),
+        "lantern_gpu_pq_compact": (None, [vp, err]),
+        "lantern_gpu_pq_expand": (None, [vp, err]),
+        "lantern_gpu_memory_usage": (None, [vp, C.POINTER(sz), C.POINTER(sz), err]),
         "lantern_gpu_distance_matrix": (None, [vp, sz, vp, sz, i32, sz, i32, i32, vp, err]),
         "lantern_gpu_assign_to_clusters": (None, [vp, sz, sz, sz, sz, vp, sz, i32, vp, vp, err]),
         "lantern_gpu_graph_info_get": (GraphInfo, [vp, err]),
@@ -410,6 +415,28 @@ class GpuIndex:
         lab = np.ascontiguousarray(labels, dtype=np.uint64)
         assert V.shape[1] == self.dims and lab.size == V.shape[0]
         _call("lantern_gpu_add_sharded", self.h, comm.h, _ptr(lab), _ptr(V), V.shape[0], _kind(self.metric))
+
+    def spec_profile(self, on, read=False):
+        """The instrumented latency-bound walk: {wave role: {section: cycles}} accumulated since the last read (read=True)."""
+        out = (C.c_ulonglong * 32)() if read else None
+        _call("lantern_gpu_spec_profile", self.h, 1 if on else 0, out)
+        if not read:
+            return None
+        names = ("decision", "neighbour_list", "issue", "role_section", "loads_and_distances", "barrier_wait", "hops", "list_source")
+        return {role: {n: int(out[8 * w + i]) for i, n in enumerate(names)} for w, role in enumerate(("visit", "list", "fill", "row"))}
+
+    def pq_compact(self):
+        """pq = true: drop the decoded rows from HBM; searches run ADC over the code bytes."""
+        _call("lantern_gpu_pq_compact", self.h)
+
+    def pq_expand(self):
+        _call("lantern_gpu_pq_expand", self.h)
+
+    def memory_usage(self):
+        """(bytes of the vector block or of a compact pq index's code rows, bytes of everything else that grows with the nodes)"""
+        a, b = C.c_size_t(), C.c_size_t()
+        _call("lantern_gpu_memory_usage", self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def checksum(self) -> int:
         return int(_call("lantern_gpu_graph_checksum", self.h))

@@ -34,9 +34,21 @@ constexpr int M_L2SQ_F16 = M_L2SQ + M_F16;
 constexpr int M_I8 = 200;
 constexpr int M_COS_I8 = M_COS + M_I8;
 constexpr int M_L2SQ_I8 = M_L2SQ + M_I8;
+// PQ CODE storage searched by asymmetric distance computation (pq = true, compact: usearch_storage.cpp:29-31 -- a node carries
+// num_subvectors code bytes): a row is its code bytes, zero padded to 16-byte chunks; the "query" is a per-query table in LDS,
+// lut[s][c] = the metric's partial sum between subvector s of the query and centroid c (search_adc_kernel.hip).  Internal
+// codes = metric + 400; only the search kernel is instantiated for them.
+constexpr int M_ADC = 400;
+constexpr int M_COS_ADC = M_COS + M_ADC;
+constexpr int M_L2SQ_ADC = M_L2SQ + M_ADC;
+constexpr int ADC_LUT_STRIDE = 256;  // table row stride in floats (num_centroids <= 256: external_index.c:283-296)
 __host__ __device__ inline bool mcode_is_f16(int m) { return m >= M_F16 && m < M_I8; }
-__host__ __device__ inline bool mcode_is_i8(int m) { return m >= M_I8; }
-__host__ __device__ inline int  mcode_base(int m) { return m >= M_I8 ? m - M_I8 : m >= M_F16 ? m - M_F16 : m; }
+__host__ __device__ inline bool mcode_is_i8(int m) { return m >= M_I8 && m < M_ADC; }
+__host__ __device__ inline bool mcode_is_adc(int m) { return m >= M_ADC; }
+__host__ __device__ inline int  mcode_base(int m) { return m >= M_ADC ? m - M_ADC : m >= M_I8 ? m - M_I8 : m >= M_F16 ? m - M_F16 : m; }
+
+// every kernel's dynamic LDS; the ADC accumulators read their table from its first bytes
+extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
 
 // ---- order-preserving float <-> u32, and the (distance, slot) candidate key ---------------------
 __device__ __forceinline__ uint32_t f2ord(float f)
@@ -277,7 +289,7 @@ __device__ __forceinline__ void group_dist2(PA a, PB b0, PB b1, int chunks, int 
 // evaluation is then ONE chain (ab), ONE G-lane sum, one multiply and one divide: the bits of
 // 1 - ab / (sqrt(a2) * sqrt(b2)) are those of the one-pass accumulator (usearch metric_cos_gt).  The query's
 // sqrt(a2) is computed once per query the same way.
-template <int METRIC> constexpr bool kCachedNorms = (METRIC == M_COS || METRIC == M_COS_F16);
+template <int METRIC> constexpr bool kCachedNorms = (METRIC == M_COS || METRIC == M_COS_F16 || METRIC == M_COS_ADC);
 
 __device__ __forceinline__ float cos_finish(float ab, float a2, float b2)
 {
@@ -360,6 +372,37 @@ template <> struct RowAcc<M_COS_F16>
         s = __builtin_fmaf(x1, y1, s);
     }
     __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb) { word(xa.x, yb.x); word(xa.y, yb.y); word(xa.z, yb.z); word(xa.w, yb.w); }
+    template <int G> __device__ __forceinline__ float finish_n(float ra, float rb) { return cos_finish_rooted(group_sum<G>(s), ra, rb); }
+};
+
+// ---- ADC: the "row" is 16 code bytes per chunk, the first operand only says WHICH chunk (AdcQuery below); every code adds
+// one table entry, in code order -- a plain f32 addition chain per lane, then the G-lane tree (the oracle: lo_adc_distance).
+// Padding codes (chunks are 16 codes wide) are 0 and hit table rows whose entry 0 is +0.0: adding it changes nothing.
+struct AdcQuery
+{
+    __device__ __forceinline__ uint4 operator[](int ch) const { return make_uint4((uint32_t)ch, 0u, 0u, 0u); }
+};
+__device__ __forceinline__ float adc_chunk_sum(float s, uint32_t chunk, const uint4 &codes)
+{
+    const float   *lut = (const float *)lgpu_smem + (size_t)chunk * 16 * ADC_LUT_STRIDE;
+    const uint32_t w[ 4 ] = { codes.x, codes.y, codes.z, codes.w };
+#pragma unroll
+    for(int i = 0; i < 4; ++i) {
+#pragma unroll
+        for(int b = 0; b < 4; ++b) s = s + lut[ (i * 4 + b) * ADC_LUT_STRIDE + ((w[ i ] >> (8 * b)) & 255u) ];
+    }
+    return s;
+}
+template <> struct RowAcc<M_L2SQ_ADC>
+{
+    float s = 0.f;
+    __device__ __forceinline__ void add(const uint4 &which, const uint4 &codes) { s = adc_chunk_sum(s, which.x, codes); }
+    template <int G> __device__ __forceinline__ float finish_n(float, float) { return group_sum<G>(s); }
+};
+template <> struct RowAcc<M_COS_ADC>
+{
+    float s = 0.f;
+    __device__ __forceinline__ void add(const uint4 &which, const uint4 &codes) { s = adc_chunk_sum(s, which.x, codes); }
     template <int G> __device__ __forceinline__ float finish_n(float ra, float rb) { return cos_finish_rooted(group_sum<G>(s), ra, rb); }
 };
 

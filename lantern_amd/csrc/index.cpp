@@ -96,6 +96,7 @@ static bool reserve_locked(Index *ix, size_t newcap)
 {
     if(newcap <= ix->cap) return true;
     if(newcap >= 0x7FFFFFFFull) { set_err(ix, "lantern_gpu: capacity above 2^31-1 slots is not supported"); return false; }
+    if(!pq_expand_locked(ix)) return false;  // growing means adding: a compact pq index gets its rows back first
     const size_t oc = ix->cap, row = (size_t)ix->chunks * 16;
     if(!dev_grow(ix, (void **)&ix->d_vec, oc * row, newcap * row, -1)) return false;
     if(mcode_base(ix->mcode) == M_COS && !mcode_is_i8(ix->mcode) && !dev_grow(ix, (void **)&ix->d_norm2, oc * 4, newcap * 4, -1)) return false;
@@ -161,6 +162,47 @@ bool pq_decode_rows(Index *ix, size_t first, size_t count)
     if(!ix->pq || count == 0) return true;
     HIPCHK(ix, launch_pq_decode((float *)ix->d_vec, ix->chunks * 4, (uint32_t)first, (uint32_t)count, ix->pq_subdim, ix->pq_S, ix->d_codebook,
                                 (uint32_t)ix->opts.dimensions, ix->d_codes, ix->stream));
+    return true;
+}
+
+// A pq index needs its decodings only to ADD (the walk of a new node, the selection heuristic and the re-prunes evaluate
+// stored row against stored row).  A read-mostly index -- the scan-side mirror of a built index -- drops them: num_subvectors
+// bytes per row stay resident (10M x 768 at 96 subvectors: 0.96 GB instead of 30.7 GB) and searches evaluate rows by ADC.
+bool pq_compact_locked(Index *ix)
+{
+    if(!ix->pq) { set_err(ix, "lantern_gpu: not a pq index"); return false; }
+    if(ix->pq_compact) return true;
+    if(!flush_locked(ix)) return false;
+    const uint32_t S16 = (ix->pq_S + 15) / 16 * 16;
+    if(S16 > 128 || ix->pq_C > (uint32_t)ADC_LUT_STRIDE) { set_err(ix, "lantern_gpu: the compact form takes up to 128 subvectors and 256 centroids"); return false; }
+    HIPCHK(ix, hipStreamSynchronize(ix->stream));
+    for(int l = 0; l < 2; ++l)
+        if(ix->lane_stream[ l ]) HIPCHK(ix, hipStreamSynchronize(ix->lane_stream[ l ]));
+    if(ix->d_codes16) { (void)hipFree(ix->d_codes16); ix->d_codes16 = nullptr; }
+    const size_t rows = std::max<size_t>(ix->n, 1);
+    if(hipMalloc((void **)&ix->d_codes16, rows * S16) != hipSuccess) { set_err(ix, "lantern_gpu: out of device memory (code rows)"); return false; }
+    HIPCHK(ix, hipMemset(ix->d_codes16, 0, rows * S16));
+    if(ix->n) HIPCHK(ix, hipMemcpy2D(ix->d_codes16, S16, ix->d_codes, ix->pq_S, ix->pq_S, ix->n, hipMemcpyDeviceToDevice));
+    ix->pq_S16 = S16;
+    if(ix->d_vec) { HIPCHK(ix, hipFree(ix->d_vec)); ix->d_vec = nullptr; }
+    ix->pq_compact = true;
+    return true;
+}
+
+bool pq_expand_locked(Index *ix)
+{
+    if(!ix->pq_compact) return true;
+    const size_t row = (size_t)ix->chunks * 16;
+    if(hipMalloc((void **)&ix->d_vec, std::max<size_t>(ix->cap, 1) * row) != hipSuccess) {
+        ix->d_vec = nullptr;
+        set_err(ix, "lantern_gpu: out of device memory (decoding a compact pq index)");
+        return false;
+    }
+    ix->pq_compact = false;
+    HIPCHK(ix, hipMemsetAsync(ix->d_vec, 0, std::max<size_t>(ix->cap, 1) * row, ix->stream));
+    if(!pq_decode_rows(ix, 0, ix->n)) return false;
+    HIPCHK(ix, hipStreamSynchronize(ix->stream));
+    if(ix->d_codes16) { (void)hipFree(ix->d_codes16); ix->d_codes16 = nullptr; }
     return true;
 }
 
@@ -648,6 +690,7 @@ static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_i
     *ok_out = true;
     if(count == 0) return 0;
     auto fail = [&]() { *ok_out = false; return (size_t)0; };
+    if(!pq_expand_locked(ix)) return fail();  // a compact pq index gets its decodings back before anything is added
     const size_t first = ix->n, row_words = (size_t)ix->chunks * 4;
     // ---- levels and upper-block offsets of everything, then ONE upload of rows and metadata: an unlinked
     // node is unreachable, so its row may sit in the table before its batch runs
@@ -758,6 +801,57 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     if(nq == 0 || k == 0) return true;
     size_t expansion = ef ? ef : ix->ef;
     if(expansion < k + skip) expansion = k + skip;  // usearch: expansion = max(expansion, wanted)
+    if(ix->pq_compact) {
+        // ---- a compact pq index: ADC over the code rows (search_adc_kernel.hip).  One 8-wave workgroup per query; the per-query
+        // table takes num_subvectors16 x 256 floats of LDS (98 KB at 96 subvectors: one workgroup per CU, three at 32).
+        const uint32_t code_chunks = ix->pq_S16 / 16;
+        uint32_t       vis_slots = 2048;
+        if(ix->search_vis_slots >= 0) vis_slots = (uint32_t)ix->search_vis_slots / 4 * 4;
+        while(vis_slots && search_adc_lds_bytes(code_chunks, ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 150 * 1024) vis_slots = vis_slots > 256 ? vis_slots - 256 : 0;
+        if(vis_slots && vis_slots < 4 * ix->M0) vis_slots = 0;
+        const size_t lds = search_adc_lds_bytes(code_chunks, ix->chunks, (uint32_t)expansion, ix->M0, vis_slots);
+        if(lds > 160 * 1024) { set_err(ix, "lantern_gpu: ef/k exceed the 160 KiB LDS budget of the ADC search kernel"); return false; }
+        const int aw = waves > 0 ? std::min(waves, 8) : 8;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+        size_t     g = (size_t)ix->num_cus * (size_t)per_cu;
+        if(ix->search_max_wg > 0) g = (size_t)ix->search_max_wg;
+        const int grid = (int)std::max<size_t>(1, std::min(g, nq));
+        const int slot = acquire_search_slot(ix, stream, (size_t)grid);
+        if(slot < 0) return false;
+        SearchArgs a{};
+        a.view = ix->view();
+        a.view.vec = (const uint4 *)ix->d_codes16;
+        a.view.chunks = code_chunks;
+        a.queries = d_queries;
+        a.nq = (uint32_t)nq;
+        a.k = (uint32_t)k;
+        a.ef = (uint32_t)expansion;
+        a.skip = (uint32_t)skip;
+        a.labels = ix->d_labels;
+        a.out_labels = d_labels;
+        a.out_dists = d_dists;
+        a.out_slots = d_slots;
+        a.out_counts = d_counts;
+        a.out_D = d_D;
+        a.out_E = d_E;
+        a.bitmaps = ix->slot_bitmaps[ slot ];
+        a.bm_words = (uint32_t)ix->slot_words[ slot ];
+        a.vis_slots = vis_slots;
+        a.totals = ix->d_totals;
+        a.ticket = next_ticket(ix, nq, grid, stream);
+        a.done = done;
+        a.lds_list = lds_list_env();
+        a.adc_centers = ix->d_centers;
+        a.adc_S = ix->pq_S;
+        a.adc_C = ix->pq_C;
+        a.adc_subdim = ix->pq_subdim;
+        a.adc_qchunks = ix->chunks;
+        HIPCHK(ix, launch_search_adc(ix->metric + M_ADC, a, aw, grid, stream));
+        if(done) ix->slot_pending[ slot ] = false;
+        else if(!release_search_slot(ix, slot, stream)) return false;
+        ix->c_search_queries += nq;
+        return true;
+    }
     // Launch shape.  Batches that fill the chip: four waves per query, six workgroups per CU -- the walk is HBM-bound and its
     // serial phases hide behind other walks' row loads.  Batches that cannot (and the lone query): the latency-bound walk of
     // walk_spec.hpp -- one barrier per hop, speculative row loads, neighbour lists fetched with the rows:
@@ -778,6 +872,12 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         // (measured, classic kernel, 1M x 768 cosine, 1024 queries: 4 waves 693 k QPS, 6 waves 525 k, 8 waves 594 k -- more waves
         // only make its serial phases costlier; so four waves per query whatever the batch size)
         waves = spec == 2 ? 11 : spec == 1 ? 4 : waves < 0 ? -waves : 4;  // (a negative count: the caller's classic fallback)
+        if(spec) {  // tuning: LANTERN_GPU_SPEC_WAVES = waves per query of the latency-bound shapes (spec 1: 2..8; spec 2: 4..11)
+            if(const char *sw = std::getenv("LANTERN_GPU_SPEC_WAVES")) {
+                const int w = std::atoi(sw);
+                if(w >= (spec == 2 ? 4 : 2) && w <= (spec == 2 ? 11 : 8)) waves = w;
+            }
+        }
     }
     // list prefetch of the latency-bound walk: every lane of a row's group fetches LW words of the row's own list
     const int      G_ = group_lanes_for(ix->chunks), LW_ = G_ >= 32 ? 1 : G_ == 16 ? 2 : 4;
@@ -799,7 +899,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         set_err(ix, "lantern_gpu: ef/k exceed the 160 KiB LDS budget of the search kernel");
         return false;
     }
-    const int grid = search_grid(ix, nq, waves, spec == 2 ? 11 : spec == 1 ? 16 : 24);
+    const int grid = search_grid(ix, nq, waves, spec == 2 ? waves : spec == 1 ? 16 : 24);
     const int slot = acquire_search_slot(ix, stream, (size_t)grid);
     if(slot < 0) return false;
     SearchArgs a;
@@ -821,7 +921,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.vis_slots = vis_slots;
     a.totals = ix->d_totals;
     a.ticket = next_ticket(ix, nq, grid, stream);
-    a.phase_cycles = ix->phase_profile ? ix->d_totals + 8 : nullptr;
+    a.phase_cycles = spec ? (ix->spec_profile ? ix->d_totals + 16 : nullptr) : ix->phase_profile ? ix->d_totals + 8 : nullptr;
     a.done = done;
     a.lds_list = lds_list_env();
     // small batch (at most four 4-wave workgroups per CU would be resident anyway): four rows in flight per group
@@ -954,6 +1054,11 @@ bool import_graph_locked(Index *ix, size_t size, const void *vectors, const uint
     ix->radius_stale = true;  // lists from outside: no re-prune state
     ix->entry = entry_slot;
     ix->max_level = max_level;
+    // a pq index that was loaded or mirrored (not built here) is read-mostly: LANTERN_GPU_PQ_COMPACT=1 drops its decodings at once
+    if(ix->pq) {
+        const char *pc = std::getenv("LANTERN_GPU_PQ_COMPACT");
+        if(pc && std::atoi(pc) != 0 && !pq_compact_locked(ix)) return false;
+    }
     return true;
 }
 
@@ -1043,9 +1148,9 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, ix->device) == hipSuccess) ix->num_cus = prop.multiProcessorCount;
     if(const char *tk = std::getenv("LANTERN_GPU_TICKETS")) ix->use_tickets = std::atoi(tk) != 0;
-    if(hipMalloc((void **)&ix->d_totals, 16 * sizeof(unsigned long long)) != hipSuccess ||
+    if(hipMalloc((void **)&ix->d_totals, 64 * sizeof(unsigned long long)) != hipSuccess ||
        hipMalloc((void **)&ix->d_tickets, kTicketRing * sizeof(uint32_t)) != hipSuccess ||
-       hipMemset(ix->d_totals, 0, 16 * sizeof(unsigned long long)) != hipSuccess) {
+       hipMemset(ix->d_totals, 0, 64 * sizeof(unsigned long long)) != hipSuccess) {
         if(ix->d_totals) (void)hipFree(ix->d_totals);
         if(ix->d_tickets) (void)hipFree(ix->d_tickets);
         delete ix;
@@ -1086,7 +1191,7 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
     if(!ix) return;
     void *ptrs[] = { ix->d_vec, ix->d_norm2, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals, ix->d_tickets,
                      ix->d_radius0, ix->d_radius_upper,
-                     ix->d_codebook, ix->d_centers, ix->d_codes };
+                     ix->d_codebook, ix->d_centers, ix->d_codes, ix->d_codes16 };
     for(void *p : ptrs)
         if(p) (void)hipFree(p);
     for(void *p : ix->d_scratch)
@@ -1553,7 +1658,7 @@ void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uin
     Index *ix = H(h, e);
     if(!ix || n == 0) return;
     std::lock_guard<std::mutex> g(ix->mu);
-    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    if(!flush_locked(ix) || !pq_expand_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
     for(size_t i = 0; i < n; ++i)
         if(slots[ i ] >= ix->n) { FAIL(e, "lantern_gpu: slot out of range"); return; }
     const size_t row = (size_t)ix->chunks * 16;
@@ -1672,7 +1777,7 @@ void lantern_gpu_exact_search(usearch_index_t h, const void *queries, size_t nq,
     if(!ix || nq == 0 || k == 0) return;
     if(k > 240) { FAIL(e, "lantern_gpu: exact_search supports k <= 240"); return; }
     std::lock_guard<std::mutex> g(ix->mu);
-    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    if(!flush_locked(ix) || !pq_expand_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
     const size_t n = ix->n, row_words = (size_t)ix->chunks * 4;
     if(n == 0) {
         for(size_t i = 0; i < nq * k; ++i) { slots[ i ] = EMPTY; distances[ i ] = INFINITY; }
@@ -1822,6 +1927,23 @@ void lantern_gpu_search_phase_profile(usearch_index_t h, int on, unsigned long l
     ix->phase_profile = on != 0;
 }
 
+// the instrumented latency-bound walk (walk_spec.hpp PROF): out32[8 * wave + i], waves 0..3 = visit | list | fill | a row wave;
+// i: 0 decision, 1 neighbour list, 2 issue, 3 role section, 4 loads + distances, 5 barrier wait, 6 hops, 7 list source count
+// (wave 0: staging area, wave 3: cache, wave 2: HBM).  Reading resets the counters.
+void lantern_gpu_spec_profile(usearch_index_t h, int on, unsigned long long *out32, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(out32) {
+        (void)hipDeviceSynchronize();
+        if(hipMemcpy(out32, ix->d_totals + 16, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) FAIL(e, "lantern_gpu: HIP failure reading the profile");
+        (void)hipMemset(ix->d_totals + 16, 0, 32 * sizeof(unsigned long long));
+    }
+    ix->spec_profile = on != 0;
+}
+
 void lantern_gpu_set_profiling(usearch_index_t h, int on, usearch_error_t *e)
 {
     CLEAR(e);
@@ -1878,6 +2000,7 @@ void lantern_gpu_export_graph(usearch_index_t h, uint8_t *levels, uint32_t *nbr0
     if(nbr0 && n) ok = ok && hipMemcpy(nbr0, ix->d_nbr0, n * ix->M0 * 4, hipMemcpyDeviceToHost) == hipSuccess;
     if(upper_nbr && ix->upper_blocks)
         ok = ok && hipMemcpy(upper_nbr, ix->d_upper_nbr, ix->upper_blocks * ix->M * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(vectors && n && !pq_expand_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
     if(vectors && n) {
         if(ix->chunks * 4 == ix->words) {
             ok = ok && hipMemcpy(vectors, ix->d_vec, n * (size_t)ix->words * 4, hipMemcpyDeviceToHost) == hipSuccess;
@@ -1887,6 +2010,40 @@ void lantern_gpu_export_graph(usearch_index_t h, uint8_t *levels, uint32_t *nbr0
         }
     }
     if(!ok) FAIL(e, "lantern_gpu: HIP failure exporting the graph");
+}
+
+// pq = true indexes: drop / restore the decoded rows (index.hpp pq_compact)
+void lantern_gpu_pq_compact(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!pq_compact_locked(ix)) FAIL(e, ix->err.c_str());
+}
+
+void lantern_gpu_pq_expand(usearch_index_t h, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!pq_expand_locked(ix)) FAIL(e, ix->err.c_str());
+}
+
+// HBM held by the index: the vector block (or the code rows of a compact pq index) | everything else that grows with the
+// number of nodes (adjacency, labels, levels, norms, re-prune state, codes)
+void lantern_gpu_memory_usage(usearch_index_t h, size_t *row_bytes, size_t *other_bytes, usearch_error_t *e)
+{
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    const size_t cap = ix->cap;
+    if(row_bytes) *row_bytes = ix->pq_compact ? std::max<size_t>(ix->n, 1) * ix->pq_S16 : (ix->d_vec ? cap * (size_t)ix->chunks * 16 : 0);
+    if(other_bytes)
+        *other_bytes = cap * ((size_t)ix->M0 * 4 + 8 + 1 + 4 + 4) + ix->upper_cap * ((size_t)ix->M * 4 + 4) + (ix->d_norm2 ? cap * 4 : 0) +
+                       (ix->pq ? cap * (size_t)ix->pq_S : 0);
 }
 
 void lantern_gpu_export_codes(usearch_index_t h, uint8_t *codes, usearch_error_t *e)

@@ -50,6 +50,12 @@ struct Index
     float   *d_codebook = nullptr;
     float   *d_centers = nullptr;        // [pq_S][pq_C][sub_floats]: the per-subvector centroid tables, rows zero padded to chunks
     uint8_t *d_codes = nullptr;          // [cap][pq_S]
+    // COMPACT form of a pq index (lantern_gpu_pq_compact): the decodings are gone from HBM (d_vec == NULL) and searches run
+    // ADC over the code rows (search_adc_kernel.hip); whatever needs rows again -- an insert, the exact search -- decodes
+    // them back first (pq_expand_locked)
+    bool     pq_compact = false;
+    uint8_t *d_codes16 = nullptr;        // [n][pq_S16]: the code rows zero padded to whole 16-byte chunks
+    uint32_t pq_S16 = 0;
 
     // ---- graph state ------------------------------------------------------------------------------
     size_t   n = 0, cap = 0;
@@ -97,6 +103,7 @@ struct Index
     struct ProfBatch { hipEvent_t ev[ 6 ] = {}; };
     bool                    profiling = false;
     bool                    phase_profile = false;  // diagnostics: instrumented walk kernel (lantern_gpu_search_phase_profile)
+    bool                    spec_profile = false;   // diagnostics: the instrumented latency-bound walk (lantern_gpu_spec_profile)
     std::deque<ProfBatch>   prof_pending;
     std::vector<hipEvent_t> prof_free;
     lantern_gpu_build_profile prof{};
@@ -156,6 +163,8 @@ bool        flush_locked(Index *ix);            // false -> ix->err set
 bool        ensure_bitmaps(Index *ix, size_t slots);
 bool        pq_encode_rows(Index *ix, size_t first, size_t count);  // raw f32 rows [first, first+count) in d_vec -> codes + decodings
 bool        pq_decode_rows(Index *ix, size_t first, size_t count);  // d_codes -> d_vec
+bool        pq_compact_locked(Index *ix);  // drop the decodings, keep the codes (searches: ADC)
+bool        pq_expand_locked(Index *ix);   // decode them back (no-op unless compact)
 bool        fill_norms(Index *ix, size_t first, size_t count);  // after rows [first, first + count) are in d_vec
 void       *scratch(Index *ix, int which, size_t bytes);
 bool        pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst);

@@ -205,21 +205,43 @@ void serve(lantern_index_server *srv, int fd)
         };
         std::string read_failure;
         try {
+            // The tuples arrive one write each (external_index_socket.c:517-536) but the kernel coalesces them: the socket is
+            // read a megabyte at a time and the frames are cut out of the buffer ([u64 label][vector] each; a 4-byte END_MSG
+            // closes the stream -- the reference's read_frame looks at the first four bytes of what one read returned in the same
+            // way, server.rs:275-309).
             Chunk cur;
             cur.labels.reserve(chunk_rows);
             cur.rows.reserve(chunk_rows * vec_bytes);
-            for(;;) {
-                Frame f = read_frame(fd, buf, payload, false);
-                if(f == FRAME_EXIT) break;
-                if(f != FRAME_DATA) throw Fail{ "Invalid message received" };
-                uint64_t label;
-                std::memcpy(&label, buf.data(), 8);
-                cur.labels.push_back(label);
-                cur.rows.insert(cur.rows.end(), buf.begin() + 8, buf.end());
-                if(cur.labels.size() == chunk_rows) {
-                    if(!hand_over(cur)) break;
-                    cur.labels.reserve(chunk_rows);
-                    cur.rows.reserve(chunk_rows * vec_bytes);
+            std::vector<uint8_t> inbuf(std::max<size_t>(1u << 20, payload * 4));
+            size_t have = 0;
+            bool   ended = false;
+            while(!ended) {
+                const ssize_t got = ::recv(fd, inbuf.data() + have, inbuf.size() - have, 0);
+                if(got <= 0) throw Fail{ have ? "failed to fill whole buffer" : "Invalid frame received" };
+                have += (size_t)got;
+                size_t pos = 0;
+                for(;;) {
+                    if(have - pos < 4) break;
+                    uint32_t hdr;
+                    std::memcpy(&hdr, inbuf.data() + pos, 4);
+                    // a frame that starts with END_MSG ends the stream (the reference decides on the first four bytes of a frame in
+                    // the same way; a tuple whose label happens to start with these bytes is misread there too)
+                    if(hdr == END_MSG) { ended = true; break; }
+                    if(have - pos < payload) break;
+                    uint64_t label;
+                    std::memcpy(&label, inbuf.data() + pos, 8);
+                    cur.labels.push_back(label);
+                    cur.rows.insert(cur.rows.end(), inbuf.data() + pos + 8, inbuf.data() + pos + payload);
+                    pos += payload;
+                    if(cur.labels.size() == chunk_rows) {
+                        if(!hand_over(cur)) { ended = true; break; }
+                        cur.labels.reserve(chunk_rows);
+                        cur.rows.reserve(chunk_rows * vec_bytes);
+                    }
+                }
+                if(pos) {
+                    std::memmove(inbuf.data(), inbuf.data() + pos, have - pos);
+                    have -= pos;
                 }
             }
             (void)hand_over(cur);

@@ -9,8 +9,6 @@
 
 namespace lgpu {
 
-extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
-
 // ---------------------------------------------------------------------------------------------------
 // k_insert: the WALK half of an insertion.  Per new vector: descent to its level, then per level an
 // ef_construction-wide search_level whose sorted result (<= efc keys) goes to HBM for k_connect.  The start of

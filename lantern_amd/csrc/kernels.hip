@@ -27,8 +27,6 @@
 
 namespace lgpu {
 
-extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
-
 // ---------------------------------------------------------------------------------------------------
 // k_connect: connect_new_node_ -- the neighbour-selection heuristic over one walk result, one workgroup of four
 // waves per (new node, level).  It is its own kernel because its best shape differs from the walk's: the kept

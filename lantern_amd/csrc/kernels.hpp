@@ -32,6 +32,10 @@ struct SearchArgs
     int             spec;        // latency-bound launches (walk_spec.hpp): 1 = four-wave shape, 2 = dedicated role waves (3 + 8 waves); 0 = off
     uint32_t        spec_prefetch;  // fetch every evaluated row's own level-0 list with the row (M0 % 4 == 0, M0 / 4 <= lanes per row)
     uint32_t        spec_cache;     // entries of the LDS list cache (power of two; 0 = none)
+    // ADC over PQ codes (search_adc_kernel.hip; view.vec = the code rows, view.chunks = 16-byte chunks per code row)
+    const float    *adc_centers;    // [S][C][sub_floats] per-subvector centroid tables, rows zero padded to whole chunks
+    uint32_t        adc_S, adc_C, adc_subdim;
+    uint32_t        adc_qchunks;    // 16-byte chunks of a (raw f32) query row
     unsigned long long *phase_cycles;  // diagnostics (lantern_gpu_search_phase_profile): [8] shader-clock cycles summed over the
     uint32_t       *done;        // NULL, or a counter in host-visible memory: +1 (system scope) per finished query, after its answers
 };                               // launch's queries by phase: pop | list + visited | distances | merge | descent | whole query
@@ -117,6 +121,8 @@ hipError_t launch_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, ui
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_search_spec(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);  // a.spec != 0 (search_spec_kernel.hip)
 size_t     search_spec_lds_bytes(uint32_t M0, uint32_t prefetch, uint32_t cache_entries);
+hipError_t launch_search_adc(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);  // metric = M_L2SQ_ADC / M_COS_ADC
+size_t     search_adc_lds_bytes(uint32_t code_chunks, uint32_t qchunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots);
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream);
 // work: scratch of max_groups x 8 bytes; work_count: one u32 (both device memory)

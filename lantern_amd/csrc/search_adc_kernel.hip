@@ -1,0 +1,137 @@
+// search_adc_kernel.hip -- k_search_adc: usearch_search_ef (scan.c:220-228) over a pq = true index that keeps only its CODE
+// BYTES in HBM (usearch_storage.cpp:29-31: a node carries num_subvectors bytes; scan.c:75-81, build.c:497-500,
+// product_quantization.c:207-240).  The walk is walk.hpp's; what changes is the evaluation of a row:
+//
+//   per query   the table lut[s][c] (s < num_subvectors, c < num_centroids) = the metric's partial sum between subvector s of
+//               the query and centroid c of that subvector: l2sq: one fma chain of (q - c)^2 over the subvector's dimensions in
+//               memory order; cos: the chain of q * c.  98 KB of LDS at 96 subvectors x 256 centroids (one workgroup per CU).
+//   per row     num_subvectors table entries added up: lane l of the row's 8-lane group owns the 16 codes of chunk l and adds
+//               their entries in code order; the lanes' sums meet in the 8-lane tree (device_common.hpp RowAcc<M_*_ADC>).
+//               cos: 1 - sum / (|q| * |row|), |row| = the cached norm of the row's decoding, |q| in the f32 kernels' own order.
+//
+// A distance to a decoded vector, as the reference defines a PQ index's distances -- in ADC's summation order, which is ours
+// to define (the fork's is not in the tree): the oracle restates exactly this (oracle/hnsw.c lo_set_pq_view), device and
+// oracle agree bit for bit, and both agree with the decoded-row distances to 1e-5 relative.  PARITY UNPINNED BY THE REFERENCE.
+// Memory: 10M x 768 at 96 subvectors = 0.96 GB of rows instead of 30.7 GB.
+#include "search_kernel.hpp"
+
+namespace lgpu {
+
+template <int METRIC, int KPL>
+__global__ void __launch_bounds__(512, 2) k_search_adc(SearchArgs a)
+{
+    constexpr int G = 8;  // rows are at most 8 chunks (128 codes)
+    const int     tid = threadIdx.x, T = blockDim.x;
+    const uint32_t S = a.adc_S, C = a.adc_C, subdim = a.adc_subdim, sub_floats = ((subdim + 3) / 4) * 4, qchunks = a.adc_qchunks;
+    const uint32_t S16 = a.view.chunks * 16, lut_chunks = S16 * ADC_LUT_STRIDE / 4;
+    WalkLds        s;
+    carve_walk(lgpu_smem, s, lut_chunks + qchunks, a.ef, a.view.M0, a.vis_slots);  // s.q = the table, then the raw query row
+    float *const       lut = (float *)s.q;
+    const uint4 *const rawq4 = s.q + lut_chunks;
+    const float *const rawq = (const float *)rawq4;
+    uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
+    for(uint32_t q = blockIdx.x; q < a.nq;) {
+        uint32_t D = 0, E = 0;
+        int      cnt = 0;
+        for(uint32_t i = tid; i < qchunks; i += T) ((uint4 *)rawq4)[ i ] = a.queries[ (size_t)q * qchunks + i ];
+        __syncthreads();
+        // the table: one thread per (subvector, centroid) entry, one fma chain each; entry 0 of the padding rows is +0.0
+        for(uint32_t e = tid; e < S * C; e += T) {
+            const uint32_t sv = e / C, c = e % C;
+            const float   *cent = a.adc_centers + ((size_t)sv * C + c) * sub_floats;
+            const float   *qs = rawq + (size_t)sv * subdim;
+            float          acc = 0.f;
+            for(uint32_t j = 0; j < subdim; ++j) {
+                if constexpr(METRIC == M_L2SQ_ADC) {
+                    const float t = qs[ j ] - cent[ j ];
+                    acc = __builtin_fmaf(t, t, acc);
+                } else {
+                    acc = __builtin_fmaf(qs[ j ], cent[ j ], acc);
+                }
+            }
+            lut[ (size_t)sv * ADC_LUT_STRIDE + c ] = acc;
+        }
+        for(uint32_t sv = S + tid; sv < S16; sv += T) lut[ (size_t)sv * ADC_LUT_STRIDE ] = 0.f;
+        if constexpr(METRIC == M_COS_ADC) {  // |query|: the chain and tree the f32 cosine kernels use for a row of this many chunks
+            const int Gq = group_lanes_for(qchunks);
+            if(tid < Gq) {
+                float qn;
+                switch(Gq) {
+                    case 64: qn = group_norm<M_COS, 64>(rawq4, (int)qchunks, tid); break;
+                    case 32: qn = group_norm<M_COS, 32>(rawq4, (int)qchunks, tid); break;
+                    case 16: qn = group_norm<M_COS, 16>(rawq4, (int)qchunks, tid); break;
+                    default: qn = group_norm<M_COS, 8>(rawq4, (int)qchunks, tid); break;
+                }
+                if(tid == Gq - 1) s.scal[ S_QN2 ] = __float_as_int(qn);
+            }
+        }
+        __syncthreads();
+        if(a.view.n != 0) {
+            const uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
+            if constexpr(KPL > 0) cnt = search_level_reg<METRIC, G, KPL>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E);
+            else cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E);
+        }
+        int got = cnt - (int)a.skip;
+        got = got < 0 ? 0 : (got > (int)a.k ? (int)a.k : got);
+        for(uint32_t i = tid; i < a.k; i += T) {
+            const size_t o = (size_t)q * a.k + i;
+            if((int)i < got) {
+                const uint64_t key = s.keys[ a.skip + i ];
+                const uint32_t slot = key_slot(key);
+                if(a.out_labels) a.out_labels[ o ] = a.labels[ slot ];
+                if(a.out_dists) a.out_dists[ o ] = key_dist(key);
+                if(a.out_slots) a.out_slots[ o ] = slot;
+            } else {
+                if(a.out_labels) a.out_labels[ o ] = 0;  // INVALID_ELEMENT_LABEL (hnsw.h:40)
+                if(a.out_dists) a.out_dists[ o ] = __builtin_inff();
+                if(a.out_slots) a.out_slots[ o ] = EMPTY;
+            }
+        }
+        if(tid == 0) {
+            if(a.out_counts) a.out_counts[ q ] = (uint32_t)got;
+            if(a.out_D) a.out_D[ q ] = D;
+            if(a.out_E) a.out_E[ q ] = E;
+            if(a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)D); atomicAdd(&a.totals[ 1 ], (unsigned long long)E); }
+            s.scal[ S_POS ] = a.ticket ? (int)(gridDim.x + atomicAdd(a.ticket, 1u)) : (int)(q + gridDim.x);
+        }
+        __syncthreads();
+        if(tid == 0 && a.done) {
+            __threadfence_system();
+            __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        q = (uint32_t)s.scal[ S_POS ];
+        __syncthreads();
+    }
+}
+
+size_t search_adc_lds_bytes(uint32_t code_chunks, uint32_t qchunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots)
+{
+    return walk_lds_bytes(code_chunks * 16 * ADC_LUT_STRIDE / 4 + qchunks, ef_cap, M0, vis_slots);
+}
+
+hipError_t launch_search_adc(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream)
+{
+    if(a.view.chunks == 0 || a.view.chunks > 8 || a.adc_C == 0 || a.adc_C > (uint32_t)ADC_LUT_STRIDE) return hipErrorInvalidValue;
+    const size_t lds = search_adc_lds_bytes(a.view.chunks, a.adc_qchunks, a.ef, a.view.M0, a.vis_slots);
+    const int    kpl = a.lds_list ? 0 : a.ef <= 64 ? 1 : a.ef <= 128 ? 2 : 0;
+#define LGPU_ADC(MM)                                                                                                        \
+    {                                                                                                                       \
+        if(kpl == 1) {                                                                                                      \
+            (void)hipFuncSetAttribute((const void *)k_search_adc<MM, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_search_adc<MM, 1>), dim3(grid), dim3(64 * waves), lds, stream, a);                        \
+        } else if(kpl == 2) {                                                                                               \
+            (void)hipFuncSetAttribute((const void *)k_search_adc<MM, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_search_adc<MM, 2>), dim3(grid), dim3(64 * waves), lds, stream, a);                        \
+        } else {                                                                                                            \
+            (void)hipFuncSetAttribute((const void *)k_search_adc<MM, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_search_adc<MM, 0>), dim3(grid), dim3(64 * waves), lds, stream, a);                        \
+        }                                                                                                                   \
+    }
+    if(metric == M_L2SQ_ADC) LGPU_ADC(M_L2SQ_ADC)
+    else if(metric == M_COS_ADC) LGPU_ADC(M_COS_ADC)
+    else return hipErrorInvalidValue;
+#undef LGPU_ADC
+    return hipGetLastError();
+}
+
+}  // namespace lgpu

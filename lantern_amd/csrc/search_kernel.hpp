@@ -14,8 +14,6 @@
 
 namespace lgpu {
 
-extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
-
 // ---------------------------------------------------------------------------------------------------
 // ROWS = 4 is the SMALL-BATCH shape: when the batch cannot fill six workgroups per CU anyway (<= four 4-wave workgroups per
 // CU), every workgroup keeps four rows per group in flight instead of two and may use 128 VGPRs (four waves per SIMD): a
@@ -89,16 +87,20 @@ k_search(SearchArgs)
             }
             if constexpr(PROF) t_q = (unsigned long long)clock64();
             if(v.n != 0) {
-                uint32_t start = greedy_descent<METRIC, G>(v, s, v.entry, v.max_level, 0, D);
+                uint32_t start;
+                if constexpr(SPEC != 0) start = greedy_descent_spec<METRIC, G>(v, s, v.entry, v.max_level, 0, D);
+                else start = greedy_descent<METRIC, G>(v, s, v.entry, v.max_level, 0, D);
                 if constexpr(PROF) pc[ 6 ] = (unsigned long long)clock64() - t_q;
                 // KPL keys per lane of wave 0 hold the candidate list (ef <= 64 KPL); KPL = 0: the list lives in LDS
-                if constexpr(SPEC != 0) cnt = search_level_spec<METRIC, G, KPL, ROWS, (G == 64 && SPEC == 2 ? 3 : 2), SPEC == 2>(v, s, sc, bitmap, bm_words, start, ef, D, E);
+                if constexpr(SPEC != 0)
+                    cnt = search_level_spec<METRIC, G, KPL, ROWS, (G == 64 && SPEC == 2 ? 3 : 2), SPEC == 2, PROF>(v, s, sc, bitmap, bm_words, start, ef, D, E,
+                                                                                                                     PROF ? LGPU_SEARCH_ARG(ka, phase_cycles) : nullptr);
                 else if constexpr(KPL > 0) cnt = search_level_reg<METRIC, G, KPL, PROF, ROWS>(v, s, bitmap, bm_words, start, 0, ef, D, E, pc);
                 else cnt = search_level<METRIC, G, PROF, ROWS>(v, s, bitmap, bm_words, start, 0, ef, D, E, pc);
             }
         }
         const KernargBytes kb = kernarg_opaque();
-        if constexpr(PROF) {
+        if constexpr(PROF && SPEC == 0) {
             unsigned long long *const phase_cycles = LGPU_SEARCH_ARG(kb, phase_cycles);
             if(tid == 0) pc[ 7 ] = (unsigned long long)clock64() - t_q;
             if((tid & 63) == 0 && phase_cycles) {  // thread 0, and the list wave's first lane (slot 4 of the split walk)

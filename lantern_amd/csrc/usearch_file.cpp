@@ -439,6 +439,9 @@ void usearch_add_external(usearch_index_t h, usearch_label_t label, const void *
     uint32_t id;
     {
         std::lock_guard<std::mutex> g(ix->mu);
+        // everything that can refuse the insertion is checked BEFORE the mirror changes: a mirror whose callbacks were unbound
+        // (lantern_mirror_release by another holder) must fail here, not after the node has been linked on the device
+        if(ix->page_mode && !ix->opts.retriever_mut) { if(e) *e = set_err(ix, "lantern_gpu: usearch_add_external needs init_options.retriever_mut"); return; }
         id = (uint32_t)ix->n;
         if(ix->page_mode) {
             const uint64_t s48 = slot & 0xFFFFFFFFFFFFull;

@@ -44,6 +44,14 @@ struct WalkLds
     uint32_t  vis_slots;
 };
 
+// the first operand of a (query, row) evaluation: the query row in LDS -- or, for ADC over PQ codes, just the chunk index (the
+// table sits at the start of LDS: device_common.hpp AdcQuery)
+template <int METRIC> __device__ __forceinline__ auto walk_query(const WalkLds &s)
+{
+    if constexpr(METRIC >= M_ADC) return AdcQuery{};
+    else return (const uint4 *)s.q;
+}
+
 // Carve the workgroup's dynamic LDS.  Every offset stays 16-byte aligned.
 __device__ __forceinline__ unsigned char *carve_walk(unsigned char *p, WalkLds &s, uint32_t chunks, uint32_t ef_cap, uint32_t cap_max,
                                                      uint32_t vis_slots = 0)
@@ -208,7 +216,7 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
     float *newd = (float *)s.newkeys;  // reuse: one f32 per neighbour
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
-        float d = group_dist_n<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) { s.scal[ S_CUR ] = (int)start; s.scal[ S_CURD ] = __float_as_int(d); }
     }
     D += 1;
@@ -234,7 +242,7 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
             const int nn = s.scal[ S_NNEW ];
             for(int i = g; i < nn; i += NG) {
                 const uint32_t id = s.newids[ i ];
-                float d = group_dist_n<METRIC, G>(s.q, row_of(v, id), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id));
+                float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, id), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id));
                 if(gl == G - 1) newd[ i ] = d;
             }
             D += (uint32_t)nn;
@@ -296,7 +304,7 @@ __device__ __forceinline__ void hop_distances(const View &v, WalkLds &s, int nne
                 rows[ r ] = row_of(v, ids[ r ]);
                 n2[ r ] = row_norm<METRIC>(v, ids[ r ]);
             }
-            group_distR_n<METRIC, G, ROWS>(s.q, rows, (int)v.chunks, gl, qn2, n2, d);
+            group_distR_n<METRIC, G, ROWS>(walk_query<METRIC>(s), rows, (int)v.chunks, gl, qn2, n2, d);
             if(gl == G - 1) {
                 bool any = false;
 #pragma unroll
@@ -317,7 +325,7 @@ __device__ __forceinline__ void hop_distances(const View &v, WalkLds &s, int nne
         const uint32_t id0 = s.newids[ i ];
         const uint32_t id1 = j < nnew ? s.newids[ j ] : id0;
         float          d0, d1;
-        group_dist2_n<METRIC, G>(s.q, row_of(v, id0), row_of(v, id1), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id0),
+        group_dist2_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, id0), row_of(v, id1), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id0),
                                  row_norm<METRIC>(v, id1), d0, d1);
         if(gl == G - 1) {
             uint64_t k0 = make_key(d0, id0);
@@ -361,7 +369,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
     }
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
-        float d = group_dist_n<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) s.keys[ 0 ] = make_key(d, start);
     }
     D += 1;
@@ -533,7 +541,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
     }
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
-        float d = group_dist_n<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) s.newkeys[ 0 ] = make_key(d, start);
     }
     D += 1;

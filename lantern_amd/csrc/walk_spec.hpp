@@ -155,12 +155,82 @@ __device__ __forceinline__ void spec_consume(const View &v, const WalkLds &s, co
     }
 }
 
+// ---- search_for_one_ for the latency-bound launches: greedy descent over levels (begin, end] with ONE barrier per step.
+// Every wave reads the current node's list itself (64 bytes at M = 16), the rows are spread over all groups of the workgroup,
+// their distances meet in LDS (double-buffered by step parity), and every wave finds the step's winner itself: the sequential
+// scan of search_for_one_ -- "first strictly closer wins, in list order" -- ends at the smallest distance, the lowest list index
+// among equals, and only if that is strictly closer than the current node: a 64-bit minimum over (distance, index).
+// Same node, same D as greedy_descent (walk.hpp), a third of its barriers and no single-thread scan.
+template <int METRIC, int G>
+__device__ uint32_t greedy_descent_spec(const View &v, WalkLds &s, uint32_t start, int begin_level, int end_level, uint32_t &D)
+{
+    constexpr int GPW = 64 / G;
+    const int     tid = threadIdx.x, lane = tid & 63;
+    const int     wv = __builtin_amdgcn_readfirstlane(tid) >> 6, NW = blockDim.x >> 6;
+    const int     g = lane / G, gl = lane % G, NG = NW * GPW, group = wv * GPW + g;
+    float *const  newd = (float *)s.newkeys;  // [2][M] by step parity (cap_max >= 2 M keys of 8 bytes: room for 4 M floats)
+    const float   qn2 = __int_as_float(s.scal[ S_QN2 ]);
+    if(wv == 0 && g == 0) {
+        const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        if(gl == G - 1) s.scal[ S_CURD ] = __float_as_int(d);
+    }
+    D += 1;
+    __syncthreads();
+    uint32_t cur = start;
+    float    curd = __int_as_float(__builtin_amdgcn_readfirstlane(s.scal[ S_CURD ]));
+    int      step = 0;
+    for(int level = begin_level; level > end_level; --level) {
+        for(;;) {
+            const uint32_t *list = v.upper_nbr + ((size_t)v.upper_off[ cur ] + (size_t)(level - 1)) * v.M;  // level >= 1 here
+            const uint32_t  nb = lane < (int)v.M ? list[ lane ] : EMPTY;
+            const int       nn = (int)__popcll(__ballot(nb != EMPTY));
+            float *const    out = newd + (size_t)(step & 1) * v.M;
+            for(int base = 0; base < nn; base += NG) {
+                const int      i = base + group;
+                const uint32_t id = (uint32_t)__builtin_amdgcn_ds_bpermute((i < nn ? i : 0) << 2, (int)nb);
+                if(i < nn) {
+                    const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, id), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id));
+                    if(gl == G - 1) out[ i ] = d;
+                }
+            }
+            D += (uint32_t)nn;
+            __syncthreads();
+            ++step;
+            const uint64_t key = lane < nn ? (((uint64_t)f2ord(out[ lane ]) << 32) | (uint32_t)lane) : ~0ull;
+            uint64_t           t = ~0ull;
+            unsigned long long m = __ballot(key < t);
+            while(m) {
+                t = readlane64(key, (int)__builtin_ctzll(m));
+                m = __ballot(key < t);
+            }
+            if(t == ~0ull) break;  // an empty list
+            const float dmin = ord2f((uint32_t)(t >> 32));
+            if(!(dmin < curd)) break;
+            curd = dmin;
+            cur = (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)(t & 63ull));
+        }
+    }
+    return cur;
+}
+
 // DED: waves 0..2 are role waves only (visit filter | list | cache fill), waves 3.. evaluate rows.  Otherwise every wave
 // evaluates rows and waves 0, 1 and (if there are three) 2 take the roles on top.
-template <int METRIC, int G, int KPL, int ROWS, int U, bool DED>
+// PROF (diagnostic instantiations): waves 0..3 (visit | list | fill | a row wave; in the four-wave shape all four evaluate rows)
+// add up shader-clock cycles per section of a hop -- [0] decision, [1] neighbour list, [2] issuing the row loads, [3] the role
+// section, [4] loads landing + distances, [5] the wait at the barrier -- and [6] hops into prof[8 * wave + i]; [7] of waves
+// 0 / 3 / 2 counts where the lists came from: staging area | cache | HBM.
+template <int METRIC, int G, int KPL, int ROWS, int U, bool DED, bool PROF = false>
 __device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int ef, uint32_t &D,
-                                 uint32_t &E)
+                                 uint32_t &E, unsigned long long *prof = nullptr)
 {
+    unsigned long long pacc[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tl = 0;
+    unsigned           src_stage = 0, src_cache = 0, src_hbm = 0;
+#define LGPU_SMARK(i)                                                      \
+    if constexpr(PROF) {                                                   \
+        const unsigned long long t_ = (unsigned long long)clock64();       \
+        pacc[ i ] += t_ - tl;                                              \
+        tl = t_;                                                           \
+    }
     constexpr int GPW = 64 / G;  // groups per wave
     const int     tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
     const int     wv = __builtin_amdgcn_readfirstlane(tid) >> 6, NW = T >> 6;
@@ -218,6 +288,7 @@ __device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, ui
         live[ r ] = m >= 64 ? ~0ull : m <= 0 ? 0ull : (1ull << m) - 1ull;
     }
     int cnt = 0;
+    if constexpr(PROF) tl = (unsigned long long)clock64();
     for(int hop = 0;; ++hop) {
         const int             par = hop & 1, prv = par ^ 1;
         const uint64_t *const kin = keysb[ prv ];
@@ -244,6 +315,7 @@ __device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, ui
         }
         if(!got) break;  // every wave sees the same keys, mask, front and radius: all leave together
         E += 1;
+        LGPU_SMARK(0)
         uint32_t nb = EMPTY;
         int      count = 0;
         uint32_t node = EMPTY;
@@ -253,17 +325,22 @@ __device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, ui
             const uint32_t *src = nullptr;
             if(c.stage && jt >= 0) {
                 src = c.stage + ((size_t)prv * M0 + (size_t)jt) * M0;
+                src_stage += 1;
             } else if(c.cache_entries) {
                 const uint32_t e = node & (c.cache_entries - 1);
                 if((uint32_t)__builtin_amdgcn_readfirstlane((int)c.ctag[ e ]) == node) src = c.clist + (size_t)e * M0;
+                src_cache += src != nullptr;
             }
+            src_hbm += src == nullptr;
             if(lane < (int)M0) nb = src ? src[ lane ] : v.nbr0[ (size_t)node * M0 + (uint32_t)lane ];
             count = (int)__popcll(__ballot(nb != EMPTY));  // lists are EMPTY-terminated and hole-free
         }
+        LGPU_SMARK(1)
         // ---- the rows of ALL its neighbours (old ones too: most are new, and the filter runs behind the loads)
         SpecPass<ROWS, U> p;
         p.have = false;
         if(row_wave) spec_issue<METRIC, G, ROWS, U>(v, c, p, nb, count, 0, group, ngroups, gl);
+        LGPU_SMARK(2)
         // ---- in the shadow of the loads: the three role sections
         if(visit_wave) {
             // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (walk.hpp)
@@ -357,6 +434,7 @@ __device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, ui
                 if(lane == 0) c.ctag[ e ] = slot;
             }
         }
+        LGPU_SMARK(3)
         // ---- distances -> this hop's keys (all neighbours; the mask sorts out the old ones)
         if(row_wave) {
             uint64_t *const kout = keysb[ par ];
@@ -367,7 +445,18 @@ __device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, ui
                 spec_consume<METRIC, G, ROWS, U>(v, s, c, p, count, gl, qn2, kout, sout);
             }
         }
+        if constexpr(PROF) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        LGPU_SMARK(4)
         __syncthreads();
+        LGPU_SMARK(5)
+        pacc[ 6 ] += 1;
+    }
+#undef LGPU_SMARK
+    if constexpr(PROF) {
+        if(prof && lane == 0 && wv < 4) {
+            pacc[ 7 ] = wv == 0 ? src_stage : wv == 3 ? src_cache : wv == 2 ? src_hbm : 0;  // (the dedicated list wave looks nothing up)
+            for(int i = 0; i < 8; ++i) atomicAdd(&prof[ 8 * wv + i ], pacc[ i ]);
+        }
     }
     // the result goes where the callers read it: s.keys, ascending
     if(list_wave) {

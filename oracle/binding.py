@@ -88,6 +88,8 @@ def lib() -> C.CDLL:
     L.lo_add.argtypes = [vp, u64, vp]
     L.lo_add_with_level.argtypes = [vp, u64, vp, i32]
     L.lo_add_batch.argtypes = [vp, vp, vp, sz]
+    L.lo_set_pq_view.restype = i32
+    L.lo_set_pq_view.argtypes = [vp, u32, u32, vp, vp]
     L.lo_set_wave_simd.restype = None
     L.lo_set_wave_simd.argtypes = [i32]
     L.lo_set_build_threads.restype = None
@@ -236,6 +238,15 @@ class OracleIndex:
     def add_many(self, labels, vecs):
         for l, v in zip(labels, _rows(vecs, self.metric)):
             self.add(l, v)
+
+    def set_pq_view(self, codebook, codes):
+        """Searches evaluate rows by ADC over `codes` ([n][num_subvectors] u8) with `codebook` ([num_centroids][dims] f32); the
+        index's vectors must be the decoded rows."""
+        cb = np.ascontiguousarray(codebook, dtype=np.float32)
+        cd = np.ascontiguousarray(codes, dtype=np.uint8)
+        assert cd.shape[0] == len(self) and cb.shape[1] == self.dims
+        rc = lib().lo_set_pq_view(self.h, cd.shape[1], cb.shape[0], _ptr(cb), _ptr(cd))
+        assert rc == 0, rc
 
     def set_build_threads(self, nthreads):
         """Threads for the two phases of add_batch / add_planned (the graph does not depend on the number)."""

@@ -19,6 +19,8 @@
 #include <string.h>
 
 float lo_hamming_fast(const void *pa, const void *pb, size_t bits); /* metrics_fast.c */
+float lo_norm_wave(const float *a, size_t d);                        /* metrics.c */
+float lo_tree_sum(float *p, int G);                                  /* metrics.c */
 
 typedef struct
 {
@@ -39,6 +41,8 @@ typedef struct
     cand_t   *top; /* ascending sorted buffer, bounded ("top" in usearch) */
     size_t    top_n, top_cap;
     uint64_t  D, E; /* distance evaluations / expanded nodes */
+    float    *lut;  /* ADC over PQ codes: the per-query table [S16][256] (NULL outside such a search) */
+    float     qnorm;
 } lo_ctx;
 
 struct lo_index
@@ -61,12 +65,18 @@ struct lo_index
     lo_ctx    ctx;
     uint64_t  last_D, last_E;
     int       build_threads; /* lo_add_batch: threads for the two phases of a batch (results do not depend on it) */
+    /* ADC view of a pq index (lo_set_pq_view): searches evaluate a row as the sum of per-subvector table entries */
+    uint32_t  pq_S, pq_C, pq_subdim, pq_S16;
+    float    *pq_centers; /* [S][C][subdim] */
+    uint8_t  *pq_codes16; /* [n][S16], zero padded */
+    float    *pq_rownorm; /* [n] sqrt(||decoded row||^2), device order (cosine) */
 };
 
 /* ---------------------------------------------------------------------------------------- */
 
 static void ctx_free(lo_ctx *c)
 {
+    free(c->lut);
     free(c->visited);
     free(c->next);
     free(c->top);
@@ -167,9 +177,54 @@ static inline float measure_raw(const lo_index *ix, const void *a, const void *b
     return lo_distance(a, b, ix->dims, ix->metric, ix->sum_mode);
 }
 
+/* ---- ADC over PQ codes: lantern_amd/csrc/search_adc_kernel.hip restated (the summation order is the device's own: the
+ * fork's is not in the reference tree -- PARITY UNPINNED).  Per query a table lut[s][c] = one fma chain over the subvector's
+ * dimensions between subvector s of the query and centroid c ((q - c)^2 for l2sq, q * c for cos); per row: lane l of eight adds
+ * the table entries of the 16 codes of chunk l in code order (plain additions), the lanes meet in the eight-lane tree. */
+static void adc_prepare(const lo_index *ix, lo_ctx *c, const float *q)
+{
+    const size_t n = (size_t)ix->pq_S16 * 256;
+    c->lut = (float *)realloc(c->lut, n * sizeof(float));
+    memset(c->lut, 0, n * sizeof(float));
+    for(uint32_t sv = 0; sv < ix->pq_S; ++sv)
+        for(uint32_t ce = 0; ce < ix->pq_C; ++ce) {
+            const float *cent = ix->pq_centers + ((size_t)sv * ix->pq_C + ce) * ix->pq_subdim;
+            const float *qs = q + (size_t)sv * ix->pq_subdim;
+            float        acc = 0.f;
+            for(uint32_t j = 0; j < ix->pq_subdim; ++j) {
+                if(ix->metric == LO_METRIC_L2SQ) {
+                    float t = qs[ j ] - cent[ j ];
+                    acc = fmaf(t, t, acc);
+                } else {
+                    acc = fmaf(qs[ j ], cent[ j ], acc);
+                }
+            }
+            c->lut[ (size_t)sv * 256 + ce ] = acc;
+        }
+    c->qnorm = ix->metric == LO_METRIC_COS ? lo_norm_wave(q, ix->dims) : 0.f;
+}
+
+static float adc_measure(const lo_index *ix, const lo_ctx *c, uint32_t slot)
+{
+    const uint8_t *codes = ix->pq_codes16 + (size_t)slot * ix->pq_S16;
+    float          p[ 8 ] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    for(uint32_t l = 0; l < ix->pq_S16 / 16; ++l) {
+        float s = 0.f;
+        for(uint32_t i = 0; i < 16; ++i) s = s + c->lut[ (size_t)(l * 16 + i) * 256 + codes[ l * 16 + i ] ];
+        p[ l ] = s;
+    }
+    const float sum = lo_tree_sum(p, 8);
+    if(ix->metric == LO_METRIC_L2SQ) return sum;
+    const float ra = c->qnorm, rb = ix->pq_rownorm[ slot ];
+    if(ra == 0.f && rb == 0.f) return 0.f;
+    if(ra == 0.f || rb == 0.f) return 1.f;
+    return 1.f - sum / (ra * rb);
+}
+
 static inline float measure(const lo_index *ix, lo_ctx *c, const void *q, uint32_t slot)
 {
     c->D++;
+    if(c->lut && ix->pq_S) return adc_measure(ix, c, slot);
     return measure_raw(ix, q, lo_vector(ix, slot));
 }
 
@@ -345,9 +400,34 @@ lo_index *lo_create(int metric, size_t dims, uint32_t M, uint32_t efc, uint32_t 
     return ix;
 }
 
+int lo_set_pq_view(lo_index *ix, uint32_t S, uint32_t C, const float *codebook, const uint8_t *codes)
+{
+    if(ix->metric == LO_METRIC_HAMMING || S == 0 || C == 0 || C > 256 || ix->dims % S != 0 || (S + 15) / 16 > 8) return -1;
+    free(ix->pq_centers);
+    free(ix->pq_codes16);
+    free(ix->pq_rownorm);
+    ix->pq_S = S;
+    ix->pq_C = C;
+    ix->pq_subdim = (uint32_t)(ix->dims / S);
+    ix->pq_S16 = (S + 15) / 16 * 16;
+    ix->pq_centers = (float *)malloc(sizeof(float) * (size_t)S * C * ix->pq_subdim);
+    for(uint32_t sv = 0; sv < S; ++sv) /* codebook: [C][dims], row c = centroid c of every subvector, concatenated (pqtable.c:194-240) */
+        for(uint32_t ce = 0; ce < C; ++ce)
+            memcpy(ix->pq_centers + ((size_t)sv * C + ce) * ix->pq_subdim, codebook + (size_t)ce * ix->dims + (size_t)sv * ix->pq_subdim,
+                   sizeof(float) * ix->pq_subdim);
+    ix->pq_codes16 = (uint8_t *)calloc(ix->n ? ix->n : 1, ix->pq_S16);
+    for(size_t i = 0; i < ix->n; ++i) memcpy(ix->pq_codes16 + i * ix->pq_S16, codes + i * S, S);
+    ix->pq_rownorm = (float *)malloc(sizeof(float) * (ix->n ? ix->n : 1));
+    for(size_t i = 0; i < ix->n; ++i) ix->pq_rownorm[ i ] = lo_norm_wave((const float *)lo_vector(ix, (uint32_t)i), ix->dims); /* the rows ARE the decodings */
+    return 0;
+}
+
 void lo_free(lo_index *ix)
 {
     if(!ix) return;
+    free(ix->pq_centers);
+    free(ix->pq_codes16);
+    free(ix->pq_rownorm);
     if(!ix->vecs_borrowed) free(ix->vecs);
     free(ix->labels);
     free(ix->levels);
@@ -622,8 +702,13 @@ static size_t search_with_ctx(const lo_index *ix, lo_ctx *c, const void *q, size
     size_t expansion = ef ? ef : ix->ef;
     if(expansion < wanted) expansion = wanted; /* usearch: expansion = max(expansion, wanted) */
     ctx_fit(c, ix->cap ? ix->cap : ix->n, expansion);
+    if(ix->pq_S) adc_prepare(ix, c, (const float *)q);
     uint32_t closest = search_for_one(ix, c, q, ix->entry, ix->max_level, 0);
     search_level(ix, c, q, closest, 0, expansion);
+    if(ix->pq_S) { /* the table belongs to this search: inserts through the same context evaluate rows */
+        free(c->lut);
+        c->lut = NULL;
+    }
     size_t got = 0;
     for(size_t i = skip; i < c->top_n && got < k; ++i, ++got) {
         if(out_labels) out_labels[ got ] = ix->labels[ c->top[ i ].id ];

@@ -106,6 +106,10 @@ int lo_add_batch(lo_index *, const uint64_t *labels, const void *vecs, size_t n)
 /* threads for the two phases of lo_add_batch (walks of a batch are independent; so are its (node, level) groups of
  * reverse links): the graph does not depend on the number -- tests/test_oracle_golden.py builds with 1 and with 4 */
 void lo_set_build_threads(lo_index *, int nthreads);
+/* ADC view of a pq = true index (lantern_amd/csrc/search_adc_kernel.hip restated): the index's vectors are the DECODED rows,
+ * `codes` their num_subvectors code bytes, `codebook` [num_centroids][dims]; searches from now on evaluate a row as the sum of
+ * per-subvector table entries in the device's order.  PARITY UNPINNED BY THE REFERENCE (the fork's PQ metric is not in the tree). */
+int lo_set_pq_view(lo_index *, uint32_t num_subvectors, uint32_t num_centroids, const float *codebook, const uint8_t *codes);
 /* LO_SUM_WAVE64 over f32 runs eight lanes of the tree per AVX2 instruction where the host has them; 0 selects the scalar
  * restatement (identical bits: tests compare the two) */
 void lo_set_wave_simd(int on);

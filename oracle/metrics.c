@@ -247,6 +247,33 @@ static float cos_wave(const float *a, const float *b, size_t d, size_t epc)
     return cos_finish(pab[ 0 ], pa2[ 0 ], pb2[ 0 ]);
 }
 
+/* sqrt(||a||^2) in the device's order: the a2 chain and tree of cos_wave (the cached row norms of the cosine kernels, and the
+ * query norm of the ADC search) */
+float lo_norm_wave(const float *a, size_t d)
+{
+    int    G = group_lanes(d, 4);
+    size_t chunks = (d + 3) / 4;
+    float  p[ 64 ];
+    for(int l = 0; l < G; ++l) {
+        float acc = 0.f;
+        for(size_t ch = (size_t)l; ch < chunks; ch += (size_t)G)
+            for(size_t c = 0; c < 4; ++c) {
+                size_t i = ch * 4 + c;
+                float  x = i < d ? a[ i ] : 0.f;
+                acc = fmaf(x, x, acc);
+            }
+        p[ l ] = acc;
+    }
+    butterfly(p, G);
+    return sqrtf(p[ 0 ]);
+}
+/* the G-lane tree on its own (ADC row sums: eight lanes) */
+float lo_tree_sum(float *p, int G)
+{
+    butterfly(p, G);
+    return p[ 0 ];
+}
+
 /* ---- LO_SUM_I8: usearch l2sq_i8_t / cos_i8_t -- int32 accumulators over the quantised integers ------------- */
 static float l2sq_i8(const float *a, const float *b, size_t d)
 {

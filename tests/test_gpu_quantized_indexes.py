@@ -159,6 +159,76 @@ def test_pq_index_is_the_index_of_the_decoded_vectors(capi, oracle, metric, n, d
         capi.GpuIndex(metric, d, pq_codebook=cb, num_subvectors=7 if d % 7 else 11)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# The COMPACT form of a pq index: the decodings leave HBM, searches run ADC over the code bytes (search_adc_kernel.hip).  The
+# summation order of ADC is the device's own definition (the fork's PQ metric is not in the reference tree: PARITY UNPINNED);
+# the oracle restates it (lo_set_pq_view) and must agree bit for bit; against the decoded-row path distances agree to 1e-5.
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric,n,d,S,C,M,ef", [("l2sq", 3000, 128, 32, 256, 8, 40), ("cos", 2000, 768, 96, 64, 16, 64), ("l2sq", 1500, 60, 6, 10, 4, 100),
+                                                  ("cos", 1800, 256, 128, 256, 16, 48)])
+def test_compact_pq_index_searches_by_adc_over_the_code_bytes(capi, oracle, metric, n, d, S, C, M, ef, monkeypatch):
+    from lantern_amd import hip
+
+    rng = np.random.default_rng(n + d + S)
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    nq = 200
+    queries = rng.standard_normal((nq, d), dtype=np.float32)
+    labels = np.arange(n, dtype=np.uint64) + 1
+    cb = make_codebook(rng, base, S, C)
+    ix = capi.GpuIndex(metric, d, M=M, ef_construction=48, ef=ef, seed=5, pq_codebook=cb, num_subvectors=S)
+    ix.set_add_batch(256, 16)
+    ix.add_many(labels[: n - 50], base[: n - 50])
+    codes = ix.export_codes()
+    g = ix.export_graph(with_vectors=True)
+    dec = g["vectors"]
+    lab_dec, dist_dec, _ = ix.search_batch(queries, 10)
+    blob = ix.save_buffer()
+    rows_before, other = ix.memory_usage()
+    # ---- compact: num_subvectors bytes per row (padded to 16) instead of 4 * d
+    ix.pq_compact()
+    rows_after, other_after = ix.memory_usage()
+    S16 = (S + 15) // 16 * 16
+    assert rows_after == (n - 50) * S16 and rows_before >= (n - 50) * d * 4 and other_after == other
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False))
+    lab, dist, slot = hip.Buffer(nq * 10 * 8), hip.Buffer(nq * 10 * 4), hip.Buffer(nq * 10 * 4)
+    D, E = hip.Buffer(nq * 8), hip.Buffer(nq * 8)
+    ix.search_batch_device(dq.ptr, nq, 10, 0, 0, lab.ptr, dist.ptr, slot.ptr, None, D.ptr, E.ptr)
+    hip.synchronize()
+    lab, dist, D, E = lab.download((nq, 10), np.uint64), dist.download((nq, 10), np.float32), D.download(nq, np.uint64), E.download(nq, np.uint64)
+    # the oracle's ADC on the same graph: identical ids, distance bits, evaluation and expansion counts
+    ora = oracle.OracleIndex.from_graph(metric, dec, g, M, 48, ef, 5, oracle.SUM_WAVE64)
+    ora.set_pq_view(cb, codes)
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, 10, ef, 4)
+    assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist)
+    assert np.array_equal(D, o_D) and np.array_equal(E, o_E)
+    # against the decoded-row path: the same neighbours up to near-ties, distances within the north-star's tolerance
+    same = lab == lab_dec
+    assert same.mean() > 0.97
+    assert np.all(np.abs(dist[same] - dist_dec[same]) <= 1e-5 * np.maximum(1.0, np.abs(dist_dec[same])) + 1e-6)
+    # one query through usearch_search_ef, and the host-buffer batch entry point
+    l1, d1 = ix.search(queries[0], 10)
+    assert np.array_equal(l1, lab[0]) and np.array_equal(d1, dist[0])
+    hl, hd, _ = ix.search_batch(queries[:33], 10)
+    assert np.array_equal(hl, lab[:33]) and np.array_equal(hd, dist[:33])
+    # the file is the codes' either way
+    assert ix.save_buffer() == blob
+    # adding decodes the rows back first (and the graph goes on exactly as if it had never been compact)
+    ix.add_many(labels[n - 50:], base[n - 50:])
+    twin = capi.GpuIndex(metric, d, M=M, ef_construction=48, ef=ef, seed=5, pq_codebook=cb, num_subvectors=S)
+    twin.set_add_batch(256, 16)
+    twin.add_many(labels[: n - 50], base[: n - 50])
+    twin.add_many(labels[n - 50:], base[n - 50:])
+    assert ix.checksum() == twin.checksum() and ix.memory_usage()[0] >= n * d * 4
+    assert np.array_equal(ix.search_batch(queries, 10)[0], twin.search_batch(queries, 10)[0])
+    # a loaded index compacts itself on request (the scan-side mirror of a built index)
+    monkeypatch.setenv("LANTERN_GPU_PQ_COMPACT", "1")
+    again = capi.GpuIndex(metric, d, M=M, ef_construction=48, ef=ef, seed=5, pq_codebook=cb, num_subvectors=S)
+    again.load_buffer(blob)
+    assert again.memory_usage()[0] == (n - 50) * S16
+    al, ad, _ = again.search_batch(queries, 10)
+    assert np.array_equal(al, lab) and np.array_equal(ad, dist)
+
+
 def test_pq_build_through_the_indexing_server(capi):
     """CREATE INDEX ... WITH (external=true, pq=true): the codebook travels centroid by centroid before the rows
     (external_index_socket.c:304-320,475-478; server.rs:107-127)."""
