@@ -856,7 +856,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     // serial phases hide behind other walks' row loads.  Batches that cannot (and the lone query): the latency-bound walk of
     // walk_spec.hpp -- one barrier per hop, speculative row loads, neighbour lists fetched with the rows:
     //   spec 2: at most one query per CU: three role waves + eight row waves per query (a whole list in one pass);
-    //   spec 1: up to four four-wave workgroups per CU (BASELINE config[2]: 1024 queries on 256 CUs).
+    //   spec 1: up to four four-wave workgroups per CU (on request: LANTERN_GPU_SPEC=1).
     // An explicit wave count (lantern_gpu_set_search_shape; tests, tuning) selects the classic kernel; LANTERN_GPU_SPEC=0|1|2
     // overrides the automatic choice.
     int spec = 0;
@@ -864,9 +864,11 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         const char *se = std::getenv("LANTERN_GPU_SPEC");
         const bool  can = ix->M0 >= 2 && ix->M0 <= 64 && expansion <= 128 && !ix->phase_profile && !lds_list_env();
         if(can) {
+            // (measured, 1M x 768 cosine, one 1024-query batch: the four-wave latency-bound shape 796 k QPS, the classic kernel
+            // 819 k -- with every walk of the batch resident the row loads saturate HBM for most of the launch and the speculative
+            // rows cost bandwidth; so spec 1 is chosen only on request, spec 2 whenever every query can have a CU of its own)
             if(se) spec = std::atoi(se);
             else if(nq <= (size_t)ix->num_cus) spec = 2;
-            else if(nq * 4 <= (size_t)ix->num_cus * 16) spec = 1;
             if(spec < 0 || spec > 2) spec = 0;
         }
         // (measured, classic kernel, 1M x 768 cosine, 1024 queries: 4 waves 693 k QPS, 6 waves 525 k, 8 waves 594 k -- more waves

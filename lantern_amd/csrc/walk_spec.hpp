@@ -60,6 +60,23 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t x)  // a value every lane
     return ((uint64_t)hi << 32) | lo;
 }
 
+// minimum of a u32 over the wave's 64 lanes, complete in lane 63 (the butterfly of group_sum with min for +, ~0 as the value of
+// lanes a step does not write): six DPP ops instead of a ballot / readlane round per candidate
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_take_or_max(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
+{
+    x = min(x, dpp_take_or_max<0xB1, 0xF>(x));   // quad_perm [1,0,3,2]
+    x = min(x, dpp_take_or_max<0x4E, 0xF>(x));   // quad_perm [2,3,0,1]
+    x = min(x, dpp_take_or_max<0x141, 0xF>(x));  // row_half_mirror
+    x = min(x, dpp_take_or_max<0x140, 0xF>(x));  // row_mirror
+    x = min(x, dpp_take_or_max<0x142, 0xA>(x));  // row_bcast15 -> rows 1, 3
+    x = min(x, dpp_take_or_max<0x143, 0xC>(x));  // row_bcast31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 // words of a row's own level-0 list each lane of the group fetches: as few as the group's width allows (one per lane from 32
 // lanes on: a 32-entry list costs one register per row in flight)
 template <int G> constexpr int spec_list_words() { return G >= 32 ? 1 : G == 16 ? 2 : 4; }
@@ -305,12 +322,22 @@ __device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, ui
         if(list_wave && DED) {
             got = got || __ballot(N < t) != 0ull;  // the list wave finds the node in its own registers; it only needs "is there one"
         } else {
-            unsigned long long m = __ballot(N < t);
-            while(m) {  // each round at least halves the expected number of smaller keys
+            // the smallest new key below t: the wave-wide minimum of the distance words (six DPP ops), then the lanes that hold
+            // it -- one, unless two new rows are at exactly the same distance, which the slot words then decide
+            const uint32_t hi = N < t ? (uint32_t)(N >> 32) : 0xFFFFFFFFu;
+            const uint32_t mh = wave_min_u32(hi);
+            unsigned long long m = __ballot(N < t && (uint32_t)(N >> 32) == mh);
+            if(m) {
                 jt = (int)__builtin_ctzll(m);
                 t = readlane64(N, jt);
                 got = true;
-                m = __ballot(N < t);
+                m &= m - 1ull;
+                while(m) {  // exact ties in distance: the smaller slot wins (keys are (distance, slot))
+                    const int      j2 = (int)__builtin_ctzll(m);
+                    const uint64_t t2 = readlane64(N, j2);
+                    if(t2 < t) { t = t2; jt = j2; }
+                    m &= m - 1ull;
+                }
             }
         }
         if(!got) break;  // every wave sees the same keys, mask, front and radius: all leave together
@@ -322,17 +349,24 @@ __device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, ui
         if(!(list_wave && DED)) {
             node = (uint32_t)t >> 1;
             // ---- its neighbour list: staged with its row by the previous hop | cached since an earlier one | HBM
-            const uint32_t *src = nullptr;
+            // (the cache's tag and its entry are read together -- one LDS round trip -- and the entry is dropped on a mismatch)
+            bool hit = false;
             if(c.stage && jt >= 0) {
-                src = c.stage + ((size_t)prv * M0 + (size_t)jt) * M0;
+                if(lane < (int)M0) nb = c.stage[ ((size_t)prv * M0 + (size_t)jt) * M0 + (uint32_t)lane ];
+                hit = true;
                 src_stage += 1;
             } else if(c.cache_entries) {
                 const uint32_t e = node & (c.cache_entries - 1);
-                if((uint32_t)__builtin_amdgcn_readfirstlane((int)c.ctag[ e ]) == node) src = c.clist + (size_t)e * M0;
-                src_cache += src != nullptr;
+                const uint32_t tag = c.ctag[ e ];
+                const uint32_t ent = lane < (int)M0 ? c.clist[ (size_t)e * M0 + (uint32_t)lane ] : EMPTY;
+                hit = (uint32_t)__builtin_amdgcn_readfirstlane((int)tag) == node;
+                if(hit) nb = ent;
+                src_cache += hit;
             }
-            src_hbm += src == nullptr;
-            if(lane < (int)M0) nb = src ? src[ lane ] : v.nbr0[ (size_t)node * M0 + (uint32_t)lane ];
+            if(!hit) {
+                if(lane < (int)M0) nb = v.nbr0[ (size_t)node * M0 + (uint32_t)lane ];
+                src_hbm += 1;
+            }
             count = (int)__popcll(__ballot(nb != EMPTY));  // lists are EMPTY-terminated and hole-free
         }
         LGPU_SMARK(1)

@@ -11,6 +11,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -51,7 +52,7 @@ int main(int argc, char **argv)
 {
     std::string host;
     int         port = 0;
-    size_t      rows = 1000000, dim = 1536, m = 16, efc = 128, ef = 64;
+    size_t      rows = 1000000, dim = 1536, m = 16, efc = 128, ef = 64, per_write = 1;
     uint32_t    metric = 3;  // l2sq (cli.rs:56-69)
     for(int i = 1; i < argc; ++i) {
         auto val = [&](const char *name) -> const char * { return std::strcmp(argv[ i ], name) == 0 && i + 1 < argc ? argv[ ++i ] : nullptr; };
@@ -63,6 +64,7 @@ int main(int argc, char **argv)
         else if(const char *v = val("--ef-construction")) efc = (size_t)std::atoll(v);
         else if(const char *v = val("--ef")) ef = (size_t)std::atoll(v);
         else if(const char *v = val("--metric")) metric = std::strcmp(v, "cos") == 0 ? 1u : 3u;
+        else if(const char *v = val("--tuples-per-write")) per_write = std::max<size_t>(1, (size_t)std::atoll(v));  // 1 = what PostgreSQL does
         else {
             std::fprintf(stderr, "usage: %s [--host H --port P] [--rows N --dim D --m M --ef-construction E --ef E --metric l2sq|cos]\n", argv[ 0 ]);
             return 2;
@@ -111,8 +113,10 @@ int main(int argc, char **argv)
     uint8_t        ok = 1;
     if(!write_all(fd, init, sizeof(init)) || !read_exact(fd, &ok, 1) || ok != 0) { std::fprintf(stderr, "the server refused the init frame\n"); return 1; }
     const auto t0 = Clock::now();
-    for(size_t r = 0; r < rows; ++r)
-        if(!write_all(fd, &data[ r * tuple ], tuple)) { std::fprintf(stderr, "the stream broke at tuple %zu\n", r); return 1; }  // one write per tuple, as PostgreSQL
+    for(size_t r = 0; r < rows; r += per_write) {  // one write per tuple, as PostgreSQL (more per write only to find the server's own limit)
+        const size_t cnt = std::min(per_write, rows - r);
+        if(!write_all(fd, &data[ r * tuple ], tuple * cnt)) { std::fprintf(stderr, "the stream broke at tuple %zu\n", r); return 1; }
+    }
     if(!write_all(fd, &END_MSG, 4)) return 1;
     const auto t_sent = Clock::now();
     uint64_t   added = 0, size = 0;
@@ -138,9 +142,9 @@ int main(int argc, char **argv)
     std::printf("{\"tool\": \"lantern-index-load\", \"rows\": %zu, \"dim\": %zu, \"m\": %zu, \"ef_construction\": %zu, \"metric\": %u, \"rows_added\": %llu, "
                 "\"stream_seconds\": %.3f, \"stream_vectors_per_s\": %.0f, \"stream_GB_per_s\": %.2f, \"until_index_ready_seconds\": %.3f, "
                 "\"index_file_bytes\": %llu, \"file_download_seconds\": %.3f, \"end_to_end_seconds\": %.3f, \"end_to_end_vectors_per_s\": %.0f, "
-                "\"server\": \"%s\"}\n",
+                "\"server\": \"%s\", \"tuples_per_write\": %zu}\n",
                 rows, dim, m, efc, metric, (unsigned long long)added, secs(t0, t_sent), (double)rows / secs(t0, t_sent), (double)(rows * tuple) / secs(t0, t_sent) / 1e9,
-                secs(t0, t_built), (unsigned long long)size, secs(t_built, t_end), secs(t0, t_end), (double)rows / secs(t0, t_end), srv ? "in-process liblantern_gpu.so" : "remote");
+                secs(t0, t_built), (unsigned long long)size, secs(t_built, t_end), secs(t0, t_end), (double)rows / secs(t0, t_end), srv ? "in-process liblantern_gpu.so" : "remote", per_write);
     if(srv) lantern_index_server_stop(srv);
     return added == rows ? 0 : 1;
 }

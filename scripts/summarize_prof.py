@@ -33,7 +33,7 @@ for f in dbs("trace"):
     for r in cur.execute("select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x from kernels where name like '%k_search%' limit 1"):
         lines.append(f"k_search resources: vgpr={r[0]} agpr={r[1]} sgpr={r[2]} lds={r[3]} B grid={r[4]} threads, workgroup={r[5]}")
 pmc = {}
-for sub in ("pmc_fetch", "pmc_write", "pmc_l2"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_dram"):
     for f in dbs(sub):
         cur = sqlite3.connect(f).cursor()
         for ctr, n, mean in cur.execute("select counter_name,count(*),avg(value) from counters_collection where kernel_name like '%k_search%' group by counter_name"):
@@ -50,6 +50,15 @@ if "FETCH_SIZE" in pmc:
     summary.update(hbm_read_bytes_per_launch_corrected=rd, hbm_write_bytes_per_launch_uncalibrated=wr, hbm_bytes_per_launch=rd + wr)
     lines.append(f"- HBM bytes per launch = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x 1024 = {rd + wr:.5g} "
                  f"(read {rd:.5g}, write {wr:.5g})")
+if "TCC_EA0_RDREQ_sum" in pmc and "TCC_EA0_RDREQ_DRAM_sum" in pmc and pmc["TCC_EA0_RDREQ_sum"]["mean_per_launch"] > 0:
+    # which share of the L2's fabric-side read requests went on to DRAM (the rest was served by the 256 MiB Infinity Cache, or
+    # peer / IO): applied to the corrected FETCH_SIZE bytes, so no request size has to be assumed
+    share = pmc["TCC_EA0_RDREQ_DRAM_sum"]["mean_per_launch"] / pmc["TCC_EA0_RDREQ_sum"]["mean_per_launch"]
+    summary["dram_share_of_fabric_reads"] = share
+    lines.append(f"- TCC_EA0_RDREQ_DRAM_sum / TCC_EA0_RDREQ_sum = {share:.4f} of the fabric-side read requests are destined for DRAM")
+    if "hbm_read_bytes_per_launch_corrected" in summary:
+        summary["dram_read_bytes_per_launch"] = summary["hbm_read_bytes_per_launch_corrected"] * share
+        lines.append(f"- DRAM read bytes per launch = corrected FETCH_SIZE bytes x that share = {summary['dram_read_bytes_per_launch']:.5g}")
 if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
     h, m = pmc["TCC_HIT_sum"]["mean_per_launch"], pmc["TCC_MISS_sum"]["mean_per_launch"]
     lines.append(f"- L2 hit rate = {h / (h + m):.3f}")
