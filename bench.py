@@ -176,7 +176,11 @@ def main():
 
     t0 = time.time()
     make_queries = synth.query_maker(a.data, a.dim)
-    base = synth.base_rows(a.data, a.n, a.dim)
+    if world > 1:  # every rank synthesises (and later uploads) only the shard it contributes to the collective build
+        shard_lo, shard_hi = capi.shard_range(a.n, world, rank)
+        base = synth.shard_rows(a.data, a.n, a.dim, shard_lo, shard_hi)
+    else:
+        base = synth.base_rows(a.data, a.n, a.dim)
     if a.data_scale != 1.0:
         raw_queries = make_queries
         make_queries = lambda r, n: raw_queries(r, n) * np.float32(a.data_scale)
@@ -202,7 +206,7 @@ def main():
         t0 = time.time()
         err = None
         try:
-            ix.add_sharded(comm, labels[lo:hi], np.ascontiguousarray(base[lo:hi]))
+            ix.add_sharded(comm, labels[lo:hi], base)  # (this rank's shard: generated above, nothing else is on this host)
             ix.flush()
             hip.synchronize()
         except Exception as e:  # noqa: BLE001 -- every rank fails together: a collective that misses its deadline fails on all
@@ -219,7 +223,10 @@ def main():
             ix.set_profiling(True)
             hip.synchronize()
             t0 = time.time()
-            ix.add_many(labels, base)
+            for r in range(world):  # the same rows the collective build would have seen: every rank's shard, in rank order
+                r_lo, r_hi = capi.shard_range(a.n, world, r)
+                part = base if r == rank else synth.shard_rows(a.data, a.n, a.dim, r_lo, r_hi) * np.float32(a.data_scale)
+                ix.add_many(labels[r_lo:r_hi], part)
             ix.flush()
             hip.synchronize()
             t_build = time.time() - t0
@@ -398,8 +405,9 @@ def roofline(achieved, traffic, dram, traffic_src, launch_s, bytes_per_launch, a
     if frac > 1.0 or achieved > HBM_MEASURED_CEILING_GBS:
         notes.append("algorithmic bytes per second exceed " + ("the DRAM peak" if frac > 1.0 else "the measured streaming ceiling") +
                      ": rows that several queries of a launch evaluate (upper levels, hub rows) are counted once per evaluation but served by "
-                     "L2 / Infinity Cache; frac_traffic (fabric-side counter bytes, which still include Infinity-Cache hits) and frac_dram "
-                     "(where the DRAM-side counters were collected) are the physical figures")
+                     "L2 / Infinity Cache; frac_traffic (fabric-side counter bytes) is the physical figure this part lets one measure -- it "
+                     "still includes Infinity-Cache hits: on gfx950 TCC_EA0_RDREQ_DRAM equals TCC_EA0_RDREQ (it counts requests to DRAM "
+                     "address space) and rocprofv3 lists no MALL counter, so frac_dram stays null (profiles/r03_counter_notes.md)")
     r["note"] = "; ".join(notes) or None
     return r
 

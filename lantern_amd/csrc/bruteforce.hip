@@ -197,7 +197,8 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
         }
 }
 
-// hamming: 16 queries in LDS per workgroup, one base row per thread
+// hamming (COSB1: the cosine of the {0, 1} vectors, device_common.hpp M_COS_B1): 16 queries in LDS per workgroup, one base row per thread
+template <bool COSB1>
 __global__ void __launch_bounds__(256) k_dense_ham(const uint32_t *Q, uint32_t nq, const uint32_t *B, uint32_t nb, uint32_t stride /* words */,
                                                    float *out, uint32_t ldo)
 {
@@ -210,18 +211,30 @@ __global__ void __launch_bounds__(256) k_dense_ham(const uint32_t *Q, uint32_t n
     __syncthreads();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if(c >= nb) return;
-    uint32_t acc[ 16 ];
+    uint32_t acc[ 16 ], qpop[ 16 ], bpop = 0;
 #pragma unroll
-    for(int j = 0; j < 16; ++j) acc[ j ] = 0;
+    for(int j = 0; j < 16; ++j) acc[ j ] = qpop[ j ] = 0;
     const uint32_t *row = B + (size_t)c * stride;
     for(uint32_t w = 0; w < stride; ++w) {
         const uint32_t x = row[ w ];
+        if(COSB1) bpop += __popc(x);
 #pragma unroll
-        for(int j = 0; j < 16; ++j) acc[ j ] += __popc(x ^ qs[ j * stride + w ]);
+        for(int j = 0; j < 16; ++j) {
+            const uint32_t qw = qs[ j * stride + w ];
+            acc[ j ] += COSB1 ? __popc(x & qw) : __popc(x ^ qw);
+            if(COSB1) qpop[ j ] += __popc(qw);
+        }
     }
 #pragma unroll
     for(int j = 0; j < 16; ++j)
-        if(q0 + j < nq) out[ (size_t)(q0 + j) * ldo + c ] = (float)acc[ j ];
+        if(q0 + j < nq) {
+            float d = (float)acc[ j ];
+            if(COSB1) {
+                const float a2 = (float)qpop[ j ], b2 = (float)bpop;
+                d = (a2 == 0.f && b2 == 0.f) ? 0.f : (a2 == 0.f || b2 == 0.f) ? 1.f : 1.f - d / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));
+            }
+            out[ (size_t)(q0 + j) * ldo + c ] = d;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -440,10 +453,12 @@ hipError_t launch_dense(int metric, const uint4 *Q, uint32_t nq, const uint4 *B,
 {
     if(nq == 0 || nb == 0) return hipSuccess;
     const uint32_t stride = chunks * 4;
-    if(metric == M_HAMMING) {
+    if(metric == M_HAMMING || metric == M_COS_B1) {
         dim3 grid((nb + 255) / 256, (nq + 15) / 16);
-        hipLaunchKernelGGL(k_dense_ham, grid, dim3(256), 16 * stride * 4, stream, (const uint32_t *)Q, nq, (const uint32_t *)B, nb, stride, out,
-                           ldo);
+        if(metric == M_HAMMING)
+            hipLaunchKernelGGL(k_dense_ham<false>, grid, dim3(256), 16 * stride * 4, stream, (const uint32_t *)Q, nq, (const uint32_t *)B, nb, stride, out, ldo);
+        else
+            hipLaunchKernelGGL(k_dense_ham<true>, grid, dim3(256), 16 * stride * 4, stream, (const uint32_t *)Q, nq, (const uint32_t *)B, nb, stride, out, ldo);
         return hipGetLastError();
     }
     const uint32_t tiles = ((nq + BM - 1) / BM) * ((nb + BN - 1) / BN);
@@ -504,6 +519,7 @@ hipError_t launch_rerank(int metric, const uint4 *Q, uint32_t nq, const uint4 *B
         case M_L2SQ: RRG(M_L2SQ); break;
         case M_COS: RRG(M_COS); break;
         case M_HAMMING: RRG(M_HAMMING); break;
+        case M_COS_B1: RRG(M_COS_B1); break;
         case M_L2SQ_F16: RRG(M_L2SQ_F16); break;
         case M_COS_F16: RRG(M_COS_F16); break;
         case M_L2SQ_I8: RRG(M_L2SQ_I8); break;

@@ -21,6 +21,12 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr int M_COS = 1;
 constexpr int M_L2SQ = 3;
 constexpr int M_HAMMING = 8;
+// COSINE over b1 STORAGE (quant_bits = 1 on a dist_cos_ops index: options.c:154-155 returns b1 for any metric, and the
+// reference's integration test builds such indexes, scripts/integration_tests.py:664-667).  The metrics over b1 storage are the
+// f32 metrics over the {0, 1} values the bits stand for: sum (a - b)^2 is the Hamming distance (M_HAMMING serves l2sq), and the
+// cosine is 1 - |a & b| / (sqrt |a| sqrt |b|) with the f32 metric's zero-norm rules -- three popcounts, integer-exact.  What the
+// fork computes there cannot be read off the tree (upstream usearch has no cos metric for b1x8): PARITY UNPINNED.
+constexpr int M_COS_B1 = 9;
 // the same metrics over f16 STORAGE (quant_bits = 16, lantern_hnsw/src/hnsw/options.c:137-158): rows hold 8
 // halves per 16-byte chunk; every element is converted to f32 (exactly) and the arithmetic is the f32
 // arithmetic above -- usearch's metric_*_gt<f16_t, f32>.  Internal codes = metric + 100.
@@ -162,6 +168,24 @@ template <> struct Acc<M_HAMMING>
     template <int G> __device__ __forceinline__ float finish()
     {
         return (float)group_sum<G>(s);
+    }
+};
+
+template <> struct Acc<M_COS_B1>
+{
+    uint32_t ab = 0, a2 = 0, b2 = 0;
+    __device__ __forceinline__ void add(const uint4 &xa, const uint4 &yb)
+    {
+        ab += __popc(xa.x & yb.x) + __popc(xa.y & yb.y) + __popc(xa.z & yb.z) + __popc(xa.w & yb.w);
+        a2 += __popc(xa.x) + __popc(xa.y) + __popc(xa.z) + __popc(xa.w);
+        b2 += __popc(yb.x) + __popc(yb.y) + __popc(yb.z) + __popc(yb.w);
+    }
+    template <int G> __device__ __forceinline__ float finish()
+    {
+        const float fab = (float)group_sum<G>(ab), fa2 = (float)group_sum<G>(a2), fb2 = (float)group_sum<G>(b2);
+        if(fa2 == 0.f && fb2 == 0.f) return 0.f;  // the zero-norm rules of the f32 metric
+        if(fa2 == 0.f || fb2 == 0.f) return 1.f;
+        return 1.f - fab / (__builtin_sqrtf(fa2) * __builtin_sqrtf(fb2));
     }
 };
 

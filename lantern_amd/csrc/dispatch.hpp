@@ -19,6 +19,10 @@
                 switch(G_) { case 64: CALL(M_HAMMING, 64); break; case 32: CALL(M_HAMMING, 32); break; \
                              case 16: CALL(M_HAMMING, 16); break; default: CALL(M_HAMMING, 8); } \
                 break;                                                        \
+            case M_COS_B1:                                                    \
+                switch(G_) { case 64: CALL(M_COS_B1, 64); break; case 32: CALL(M_COS_B1, 32); break; \
+                             case 16: CALL(M_COS_B1, 16); break; default: CALL(M_COS_B1, 8); } \
+                break;                                                        \
             case M_L2SQ_F16:                                                  \
                 switch(G_) { case 64: CALL(M_L2SQ_F16, 64); break; case 32: CALL(M_L2SQ_F16, 32); break; \
                              case 16: CALL(M_L2SQ_F16, 16); break; default: CALL(M_L2SQ_F16, 8); } \

@@ -607,7 +607,10 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
             if(!comm->allgatherv_device(d_rec, off.data(), cnt.data(), ix->stream)) { set_err(ix, comm->err); return false; }
             HIPCHK(ix, launch_apply_lists(ra.view, (const uint32_t *)d_rec, (uint32_t)total_recs, ix->stream));
         }
-        if(!sync_stream(ix, comm)) return false;  // the host transport's staging buffers are reused by the next batch
+        // the host transport's staging buffers are reused by the next batch: it waits here.  RCCL works in place in HBM on the
+        // index stream: the next batch queues behind this one, and the one wait per batch that is left (the owner counts that
+        // size exchange 2, above) is where a stuck collective meets its deadline
+        if(!comm->rccl && !sync_stream(ix, comm)) return false;
     }
     prof_mark(ix, 5);
     // behind the LAST kernel that rewrites lists: a search on another stream that waits for `insert_done` sees the whole batch
@@ -1109,11 +1112,11 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     if(o->connectivity < 2 || o->connectivity > 128) { FAIL(e, "lantern_gpu: connectivity (M) must be in [2, 128]"); return nullptr; }  // options.c:165-179
     const bool ham = o->metric_kind == usearch_metric_hamming_k;
     if(ham && o->quantization != usearch_scalar_b1_k) { FAIL(e, "lantern_gpu: hamming needs b1 scalars"); return nullptr; }
-    // quant_bits = 1 on real[] (options.c:154-155): bits = (x > 0); over {0, 1} values sum (a - b)^2 is exactly the Hamming
-    // distance, so an l2sq index runs on the Hamming kernels.  What the fork computes for COSINE over b1 storage cannot be
-    // read off the tree (upstream usearch has no such metric), so that combination is refused rather than guessed.
+    // quant_bits = 1 on real[] (options.c:154-155 returns b1 for ANY metric): bits = (x > 0).  The metrics over b1 storage are
+    // the f32 metrics over the {0, 1} values the bits stand for: sum (a - b)^2 is exactly the Hamming distance (an l2sq index
+    // runs on the Hamming kernels), the cosine is 1 - |a & b| / (sqrt |a| sqrt |b|) (M_COS_B1: three popcounts).  What the fork
+    // computes for cosine cannot be read off the tree (upstream usearch has no such metric): that half is PARITY UNPINNED.
     const bool b1f = !ham && o->quantization == usearch_scalar_b1_k;
-    if(b1f && o->metric_kind != usearch_metric_l2sq_k) { FAIL(e, "lantern_gpu: quant_bits=1 is supported for l2sq indexes only"); return nullptr; }
     if(!ham && !b1f && o->quantization != usearch_scalar_f32_k && o->quantization != usearch_scalar_f16_k && o->quantization != usearch_scalar_i8_k) {
         FAIL(e, "lantern_gpu: cos/l2sq indexes take f32, f16, i8 or b1 storage (quant_bits=32, 16, 8 or 1)");  // options.c:137-158
         return nullptr;
@@ -1134,7 +1137,7 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     ix->scalar = (int)o->quantization;
     const bool f16 = o->quantization == usearch_scalar_f16_k, i8 = o->quantization == usearch_scalar_i8_k;
     ix->b1_from_f32 = b1f;
-    ix->mcode = b1f ? M_HAMMING : ix->metric + (f16 ? M_F16 : i8 ? M_I8 : 0);
+    ix->mcode = b1f ? (ix->metric == (int)usearch_metric_cos_k ? M_COS_B1 : M_HAMMING) : ix->metric + (f16 ? M_F16 : i8 ? M_I8 : 0);
     ix->words = (ham || b1f) ? (uint32_t)((o->dimensions + 31) / 32)
                 : f16 ? (uint32_t)((o->dimensions + 1) / 2)
                 : i8 ? (uint32_t)((o->dimensions + 3) / 4)
@@ -1696,7 +1699,8 @@ static bool exact_knn_device_impl(int mcode, uint32_t chunks, const uint4 *d_bas
     const bool     i8 = mcode_is_i8(mcode);
     const bool     f16 = mcode_is_f16(mcode) || i8;  // "quantised storage": the contraction runs on an f32 copy
     const int      base_metric = mcode_base(mcode);
-    if(base_metric == M_HAMMING || nb <= kSeedCols) fused = false;
+    const bool bits = base_metric == M_HAMMING || base_metric == M_COS_B1;  // popcount metrics: no MFMA contraction, no row norms
+    if(bits || nb <= kSeedCols) fused = false;
     const uint32_t fchunks = i8 ? chunks * 4 : f16 ? chunks * 2 : chunks;  // chunks of the f32 view fed to the contraction
     auto dequant = [&](const uint4 *src, size_t nchunks, uint4 *dst) { return i8 ? launch_dequant_i8(src, nchunks, dst, st) : launch_dequant_f16(src, nchunks, dst, st); };
     char  *aux = nullptr;
@@ -1721,8 +1725,8 @@ static bool exact_knn_device_impl(int mcode, uint32_t chunks, const uint4 *d_bas
         const uint4 *qv = f16 ? fq : d_q;
         const uint32_t ldd = (uint32_t)(fused ? kSeedCols : CH);
         ok = ok && hipMemsetAsync(best, 0xFF, nq * kk * 8, st) == hipSuccess;
-        if(base_metric != M_HAMMING) ok = ok && launch_row_norms(qv, (uint32_t)nq, fchunks, qn, st) == hipSuccess;
-        if(base_metric != M_HAMMING && !f16) ok = ok && launch_row_norms(d_base, (uint32_t)nb, fchunks, bn, st) == hipSuccess;
+        if(!bits) ok = ok && launch_row_norms(qv, (uint32_t)nq, fchunks, qn, st) == hipSuccess;
+        if(!bits && !f16) ok = ok && launch_row_norms(d_base, (uint32_t)nb, fchunks, bn, st) == hipSuccess;
         for(size_t c0 = 0; ok && c0 < nb; c0 += CH) {
             const size_t nc = std::min(CH, nb - c0);
             const uint4 *bv = d_base + c0 * chunks;

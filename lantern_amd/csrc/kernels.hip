@@ -971,7 +971,7 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
     // staged variant whenever the 2M+2 rows of a level-0 re-prune fit in LDS (d <= 1024 at M = 16)
     const size_t staged = staged_lds_bytes(a.view.chunks, a.view.M0);
     const bool i8 = mcode_is_i8(metric);  // i8 rows take the LDS-staged / generic kernels (Lantern caps d at 2000: <= 125 chunks)
-    if(!i8 && a.view.chunks >= 128 && a.view.chunks <= 512 && a.view.M0 <= 32 && work && work_count) {
+    if(!i8 && metric != M_COS_B1 && a.view.chunks >= 128 && a.view.chunks <= 512 && a.view.M0 <= 32 && work && work_count) {
         // d = 512..2048 f32 rows, M <= 16: all-pairs re-prune with the rows in registers (k_revlink_pairs)
         hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;

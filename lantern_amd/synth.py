@@ -61,3 +61,11 @@ def query_maker(kind: str, dim: int):
 
 def base_rows(kind: str, n: int, dim: int) -> np.ndarray:
     return query_maker(kind, dim)(np.random.default_rng(BASE_SEED), n)
+
+
+def shard_rows(kind: str, n: int, dim: int, lo: int, hi: int) -> np.ndarray:
+    """Rows [lo, hi) of a multi-rank job's base set WITHOUT generating the rest: every rank of `bench.py --gpus N` draws its own
+    shard from its own stream (seed = (BASE_SEED, lo)), so host memory and generation time per rank fall with the world size
+    instead of every rank synthesising all n rows.  The set is the same distribution as base_rows(kind, n, dim), not the same
+    rows (a rank cannot skip ahead in a Gaussian stream); a one-rank job keeps base_rows."""
+    return query_maker(kind, dim)(np.random.default_rng([BASE_SEED, lo]), hi - lo)

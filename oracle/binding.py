@@ -15,11 +15,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liblantern_oracle.so")
 NATIVE_LIB_PATH = os.path.join(HERE, "_build_native", "liblantern_oracle.so")
 
-METRIC_COS, METRIC_L2SQ, METRIC_HAMMING = 1, 3, 8
+METRIC_COS, METRIC_L2SQ, METRIC_HAMMING, METRIC_COS_B1 = 1, 3, 8, 9
 SUM_SEQ, SUM_WAVE64, SUM_FAST, SUM_WAVE64_F16, SUM_I8 = 0, 1, 2, 3, 4
 EMPTY = 0xFFFFFFFF
 
-METRICS = {"cos": METRIC_COS, "l2sq": METRIC_L2SQ, "hamming": METRIC_HAMMING}
+METRICS = {"cos": METRIC_COS, "l2sq": METRIC_L2SQ, "hamming": METRIC_HAMMING, "cos_b1": METRIC_COS_B1}
+BIT_METRICS = (METRIC_HAMMING, METRIC_COS_B1)  # rows are u32 words of bits
 
 
 def build(force: bool = False) -> str:
@@ -122,7 +123,7 @@ def _ptr(a):
 
 def _rows(x, metric):
     """f32 rows for cos/l2sq, u32 words for hamming; C-contiguous 2-D."""
-    dt = np.uint32 if metric == METRIC_HAMMING else np.float32
+    dt = np.uint32 if metric in BIT_METRICS else np.float32
     a = np.ascontiguousarray(x, dtype=dt)
     return a.reshape(1, -1) if a.ndim == 1 else a
 
@@ -132,7 +133,7 @@ def distance(a, b, metric: str | int, sum_mode: int = SUM_SEQ) -> float:
     A, B = _rows(a, m)[0], _rows(b, m)[0]
     if A.shape != B.shape:
         raise ValueError("expected equally sized arrays")
-    dims = A.size * 32 if m == METRIC_HAMMING else A.size
+    dims = A.size * 32 if m in BIT_METRICS else A.size
     return float(lib().lo_distance(_ptr(A), _ptr(B), dims, m, sum_mode))
 
 
@@ -186,7 +187,7 @@ def plan_batch(size, max_level, pending_levels, max_batch, min_ratio) -> int:
 def bruteforce(rows, queries, k, metric, sum_mode=SUM_SEQ, nthreads=1):
     m = METRICS.get(metric, metric)
     R, Q = _rows(rows, m), _rows(queries, m)
-    dims = R.shape[1] * 32 if m == METRIC_HAMMING else R.shape[1]
+    dims = R.shape[1] * 32 if m in BIT_METRICS else R.shape[1]
     ids = np.empty((Q.shape[0], k), dtype=np.uint32)
     dists = np.empty((Q.shape[0], k), dtype=np.float32)
     lib().lo_bruteforce(_ptr(R), R.shape[0], dims, m, sum_mode, _ptr(Q), Q.shape[0], k, _ptr(ids), _ptr(dists), nthreads)
@@ -202,7 +203,7 @@ class OracleIndex:
         self.dims = dims  # f32 scalars, or u32 WORDS for hamming (bits = 32*dims, scan.c:84-88)
         self.M, self.efc, self.ef, self.seed, self.sum_mode = M, ef_construction, ef, seed, sum_mode
         self._keep = _keep
-        bits_or_dims = dims * 32 if self.metric == METRIC_HAMMING else dims
+        bits_or_dims = dims * 32 if self.metric in BIT_METRICS else dims
         self.h = _handle or lib().lo_create(self.metric, bits_or_dims, M, ef_construction, ef, seed, sum_mode)
         if not self.h:
             raise ValueError("lo_create failed")
@@ -317,7 +318,7 @@ class OracleIndex:
         m = METRICS.get(metric, metric)
         V = _rows(vectors, m)
         n, dims = V.shape
-        bits_or_dims = dims * 32 if m == METRIC_HAMMING else dims
+        bits_or_dims = dims * 32 if m in BIT_METRICS else dims
         levels = np.ascontiguousarray(graph["levels"], dtype=np.uint8)
         nbr0 = np.ascontiguousarray(graph["nbr0"], dtype=np.uint32)
         upper_off = np.ascontiguousarray(graph["upper_off"], dtype=np.uint32)

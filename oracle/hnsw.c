@@ -174,6 +174,7 @@ static inline float measure_raw(const lo_index *ix, const void *a, const void *b
         if(ix->sum_mode == LO_SUM_FAST) return lo_hamming_fast(a, b, ix->dims);
         return lo_distance(a, b, ix->dims, LO_METRIC_HAMMING, 0);
     }
+    if(ix->metric == LO_METRIC_COS_B1) return lo_distance(a, b, ix->dims, LO_METRIC_COS_B1, 0);
     return lo_distance(a, b, ix->dims, ix->metric, ix->sum_mode);
 }
 
@@ -389,7 +390,7 @@ lo_index *lo_create(int metric, size_t dims, uint32_t M, uint32_t efc, uint32_t 
     ix->metric = metric;
     ix->sum_mode = sum_mode;
     ix->dims = dims;
-    ix->vec_bytes = metric == LO_METRIC_HAMMING ? (dims + 7) / 8 : dims * sizeof(float);
+    ix->vec_bytes = LO_METRIC_IS_BITS(metric) ? (dims + 7) / 8 : dims * sizeof(float);
     ix->M = M;
     ix->M0 = 2 * M; /* validate_index.c:140-151: level 0 holds 2M slots, upper levels M */
     ix->efc = efc ? efc : 128;
@@ -402,7 +403,7 @@ lo_index *lo_create(int metric, size_t dims, uint32_t M, uint32_t efc, uint32_t 
 
 int lo_set_pq_view(lo_index *ix, uint32_t S, uint32_t C, const float *codebook, const uint8_t *codes)
 {
-    if(ix->metric == LO_METRIC_HAMMING || S == 0 || C == 0 || C > 256 || ix->dims % S != 0 || (S + 15) / 16 > 8) return -1;
+    if(LO_METRIC_IS_BITS(ix->metric) || S == 0 || C == 0 || C > 256 || ix->dims % S != 0 || (S + 15) / 16 > 8) return -1;
     free(ix->pq_centers);
     free(ix->pq_codes16);
     free(ix->pq_rownorm);
@@ -883,7 +884,7 @@ void lo_bruteforce(const void *rows, size_t n, size_t dims, int metric, int sum_
                    size_t k, uint32_t *out_ids, float *out_dists, int nthreads)
 {
     bf_job job = { (const uint8_t *)rows, (const uint8_t *)queries, n, dims, nq, k,
-                   metric == LO_METRIC_HAMMING ? (dims + 7) / 8 : dims * sizeof(float), 0, metric, sum_mode, out_ids,
+                   LO_METRIC_IS_BITS(metric) ? (dims + 7) / 8 : dims * sizeof(float), 0, metric, sum_mode, out_ids,
                    out_dists, PTHREAD_MUTEX_INITIALIZER };
     if(k == 0 || nq == 0) return;
     if(nthreads < 1) nthreads = 1;

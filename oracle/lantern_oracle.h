@@ -46,7 +46,10 @@ extern "C" {
 
 /* metric / scalar enum values follow usearch as seen from Lantern:
  * lantern_cli/src/external_index/cli.rs:56-69, server.rs:94-101 */
-enum { LO_METRIC_COS = 1, LO_METRIC_L2SQ = 3, LO_METRIC_HAMMING = 8 };
+/* LO_METRIC_COS_B1: the cosine of the {0, 1} vectors that bit rows stand for (quant_bits = 1 on a cosine index; rows are bits like
+ * hamming's): 1 - |a & b| / (sqrt |a| sqrt |b|), the f32 metric's zero-norm rules.  PARITY UNPINNED BY THE REFERENCE. */
+enum { LO_METRIC_COS = 1, LO_METRIC_L2SQ = 3, LO_METRIC_HAMMING = 8, LO_METRIC_COS_B1 = 9 };
+#define LO_METRIC_IS_BITS(m) ((m) == LO_METRIC_HAMMING || (m) == LO_METRIC_COS_B1)
 
 /* summation order for f32 metrics */
 enum {

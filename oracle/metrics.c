@@ -57,6 +57,19 @@ static float hamming_bits(const uint8_t *a, const uint8_t *b, size_t bits)
     return (float)total;
 }
 
+/* cosine of the {0, 1} vectors: integer-exact popcounts, then the f32 metric's finish (device_common.hpp Acc<M_COS_B1>) */
+static float cos_bits(const uint8_t *a, const uint8_t *b, size_t bits)
+{
+    size_t   bytes = (bits + 7) / 8;
+    uint32_t ab = 0, a2 = 0, b2 = 0;
+    for(size_t i = 0; i != bytes; ++i) {
+        ab += (uint32_t)__builtin_popcount((unsigned)(a[ i ] & b[ i ]));
+        a2 += (uint32_t)__builtin_popcount((unsigned)a[ i ]);
+        b2 += (uint32_t)__builtin_popcount((unsigned)b[ i ]);
+    }
+    return cos_finish((float)ab, (float)a2, (float)b2);
+}
+
 /* ---- LO_SUM_WAVE64: the device reduction tree ------------------- */
 /*
  * A row of d f32 scalars is zero-padded to d4 = 4*ceil(d/4).  G lanes cooperate
@@ -300,6 +313,7 @@ static float cos_i8(const float *a, const float *b, size_t d)
 float lo_distance(const void *a, const void *b, size_t dims, int metric, int sum_mode)
 {
     if(metric == LO_METRIC_HAMMING) return hamming_bits((const uint8_t *)a, (const uint8_t *)b, dims);
+    if(metric == LO_METRIC_COS_B1) return cos_bits((const uint8_t *)a, (const uint8_t *)b, dims);
     if(sum_mode == LO_SUM_I8) {
         if(metric == LO_METRIC_L2SQ) return l2sq_i8((const float *)a, (const float *)b, dims);
         if(metric == LO_METRIC_COS) return cos_i8((const float *)a, (const float *)b, dims);

@@ -32,6 +32,12 @@ timeout 300 rocprofv3 --kernel-include-regex k_gather --pmc FETCH_SIZE -d "$OUT/
 timeout 300 rocprofv3 --kernel-include-regex k_gather --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum -d "$OUT/gather/pmc_dram" -o pmc -- python scripts/bench_gather_ceiling.py > /dev/null 2> "$OUT/gather_pmc_dram.log"
 unset LANTERN_GPU_GATHER_WALKSHAPE
 python scripts/prof_dump.py "$OUT/gather" k_gather > "$OUT/r03_gather_ceiling.md" 2>&1
+# the rocpd databases are tens of MB each and gpurun brings back at most 64 MiB: keep the summaries, drop the raw files
+for d in bench cos clustered gather; do
+  for l in "$OUT/$d"/*.log; do head -c 600 "$l" > "$l.head" 2>/dev/null; rm -f "$l"; done
+  find "$OUT/$d" -type f ! -name "*.head" ! -name "bench_trace.json" -delete; find "$OUT/$d" -type d -empty -delete
+done
+du -sh "$OUT"
 # ---- the lines
 python bench.py > "$OUT/r03_bench_line.json" 2> "$OUT/bench_line.err"
 python bench.py --no-cpu --streams 2 > "$OUT/r03_bench_line_2streams.json" 2>/dev/null
@@ -48,4 +54,4 @@ for c in 64 256 512; do timeout 60 lantern_amd/lib/lantern-scan-load --connectio
 timeout 200 lantern_amd/lib/lantern-index-load --rows 1000000 --dim 1536 > "$OUT/r03_index_load_1Mx1536.json" 2> "$OUT/indexload.err"
 timeout 200 lantern_amd/lib/lantern-index-load --rows 1000000 --dim 1536 --tuples-per-write 64 > "$OUT/r03_index_load_1Mx1536_64_per_write.json" 2>> "$OUT/indexload.err"
 timeout 900 python bench.py --rows 10000000 --ef 128 --steps 5 --no-cpu --truth-queries 256 > "$OUT/r03_bench_line_10Mx768_ef128.json" 2>/dev/null
-ls -la "$OUT"; tail -n 3 "$OUT/t_spec.log"
+du -sh "$OUT"; ls "$OUT"; tail -n 3 "$OUT/t_spec.log"

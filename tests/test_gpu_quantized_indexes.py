@@ -3,7 +3,7 @@ scan.c:75-81, pqtable.c:194-240) on the device.  PARITY UNPINNED BY THE REFERENC
 un-vendored usearch fork and the reference's own expected outputs for them (hnsw_sq.out, hnsw_pq*.out) need sift1k, which
 is downloaded at test time.  What is checked is the restated semantics, bit for bit:
   b1   bit i = (x_i > 0); the l2sq distance of {0, 1} vectors IS their Hamming distance -> identical to the oracle's
-       Hamming index over the packed bits (graph, ids, distances, D / E);
+       Hamming index over the packed bits (graph, ids, distances, D / E); the cosine of {0, 1} vectors is three popcounts;
   pq   every stored vector is replaced by its quantisation (per subvector the nearest centroid, first minimum wins);
        all distances are distances to / between DECODED vectors -> identical to the oracle's f32 index over the decoded
        rows; the file carries num_subvectors code bytes per node."""
@@ -34,14 +34,19 @@ def pack_bits_msb_first(x):
     return np.packbits(bits, axis=1, bitorder="big").view(np.uint32)
 
 
+@pytest.mark.parametrize("metric", ["l2sq", "cos"])
 @pytest.mark.parametrize("n,d,M,efc", [(3000, 128, 8, 48), (1500, 768, 16, 64), (800, 100, 4, 24)])
-def test_quant_bits_1_on_real_input_is_the_hamming_index_of_the_sign_bits(capi, oracle, tmp_path, n, d, M, efc):
+def test_quant_bits_1_on_real_input_is_the_hamming_index_of_the_sign_bits(capi, oracle, tmp_path, n, d, M, efc, metric):
+    # l2sq over {0, 1} values IS the Hamming distance; cosine over them is 1 - |a & b| / (sqrt |a| sqrt |b|) (the oracle's cos_b1).
+    # The reference builds both (scripts/integration_tests.py:664-667: metric x quant_bits); what the fork's cosine computes on bits
+    # cannot be read off the tree: PARITY UNPINNED for that half.
+    bit_metric = "hamming" if metric == "l2sq" else "cos_b1"
     rng = np.random.default_rng(n + d)
     base = (rng.standard_normal((n, d)) - 0.1).astype(np.float32)  # "v_transformed": roughly centred real values
     base[5, :7] = [0.0, -0.0, np.nan, 1e-30, -1e-30, np.inf, -np.inf]  # only strictly positive values set a bit; NaN does not
     queries = rng.standard_normal((200, d)).astype(np.float32)
     labels = np.arange(n, dtype=np.uint64) + 1
-    ix = capi.GpuIndex("l2sq", d, M=M, ef_construction=efc, ef=40, seed=3, quantization="b1")
+    ix = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=40, seed=3, quantization="b1")
     ix.set_add_batch(256, 16)
     ix.add_many(labels, base)
     words = pack_bits_msb_first(base)
@@ -50,13 +55,13 @@ def test_quant_bits_1_on_real_input_is_the_hamming_index_of_the_sign_bits(capi, 
     g = ix.export_graph(with_vectors=True)
     assert np.array_equal(g["vectors"], words)
     # the graph is the oracle's Hamming graph over those bits (same batch plan), edge for edge
-    ora = oracle.OracleIndex("hamming", words.shape[1], M=M, ef_construction=efc, ef=40, seed=3)
+    ora = oracle.OracleIndex(bit_metric, words.shape[1], M=M, ef_construction=efc, ef=40, seed=3)
     ora.add_planned(labels, words, 256, 16)
     o = ora.export_graph()
     if d % 32 == 0:  # the oracle's hamming metric takes whole words; ragged bit counts are compared through search below
         for key in ("levels", "nbr0", "upper_off", "upper_nbr"):
             assert np.array_equal(g[key], o[key]), key
-    on_same = oracle.OracleIndex.from_graph("hamming", words, g, M, efc, 40, 3, oracle.SUM_SEQ)
+    on_same = oracle.OracleIndex.from_graph(bit_metric, words, g, M, efc, 40, 3, oracle.SUM_SEQ)
     o_lab, o_dist, o_slot, o_D, o_E = on_same.search_batch(qwords, 10, 40, 4)
     lab, dist, cnt = ix.search_batch(queries, 10)
     assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist)
@@ -64,18 +69,16 @@ def test_quant_bits_1_on_real_input_is_the_hamming_index_of_the_sign_bits(capi, 
     l1, d1 = ix.search(queries[0], 10)
     assert np.array_equal(l1, lab[0]) and np.array_equal(d1, dist[0])
     t_slots, t_d = ix.exact_search(queries[:32], 5)
-    b_ids, b_d = oracle.bruteforce(words, qwords[:32], 5, "hamming", oracle.SUM_SEQ, 4)
+    b_ids, b_d = oracle.bruteforce(words, qwords[:32], 5, bit_metric, oracle.SUM_SEQ, 4)
     assert np.array_equal(t_slots, b_ids) and np.array_equal(t_d, b_d)
     assert np.array_equal(ix.distance_gather(queries[3], t_slots[3]), t_d[3])
     # file: ceil(d / 8) bytes per vector, header kinds l2sq ('e') + b1x8 (1); round trip
     blob = ix.save_buffer()
-    assert blob[13:14] == b"e" and blob[14] == 1
+    assert blob[13:14] == (b"e" if metric == "l2sq" else b"c") and blob[14] == 1
     assert len(blob) == 136 + sum(10 + (4 + 2 * M * 6) + int(l) * (4 + M * 6) + (d + 7) // 8 for l in g["levels"])
-    again = capi.GpuIndex("l2sq", d, M=M, ef_construction=efc, ef=40, seed=3, quantization="b1")
+    again = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=40, seed=3, quantization="b1")
     again.load_buffer(blob)
     assert again.checksum() == ix.checksum() and np.array_equal(again.search_batch(queries, 10)[0], lab)
-    with pytest.raises(capi.LanternGpuError, match="l2sq indexes only"):
-        capi.GpuIndex("cos", d, quantization="b1")
 
 
 def make_codebook(rng, base, S, C):
