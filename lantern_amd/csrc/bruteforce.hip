@@ -44,7 +44,12 @@ __global__ void __launch_bounds__(256) k_row_norms(const uint4 *rows, uint32_t n
 // 128 x 128 output tile per 256-thread workgroup; 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles of
 // 32 x 32; K staged through LDS 32 floats at a time (row stride 33 words: the 32 lanes of a half
 // wave read 32 different rows at one k -> 32 different banks).
-constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 1;
+// [r3] LDS row stride 36 words: rows start 16-byte aligned, so a thread's float4 of a row goes to LDS as ONE 16-byte store (row
+// stride 33 took four 4-byte stores: 32 ds_write_b32 per thread and K step, ~12 % of a step's MFMA time); the price is a
+// two-way bank conflict on the fragment reads (rows r and r + 16 of a 32-row fragment share a bank), which are 8-byte reads of
+// two k values now -- half as many instructions.  The k values of a 4-wide group are dealt to the two MFMAs of a pair as
+// {4j + 2h, 4j + 2h + 1} (h = lane / 32): a permutation of the contraction index, which a dot product does not notice.
+constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 4;
 
 // FUSED: the tile does not write its distances; an output that can still enter its query's running top-kk -- ordered distance
 // <= the kk-th best so far, read once per tile -- is appended to that query's candidate list (cand[q][CAP], cnt[q]), which
@@ -61,7 +66,7 @@ struct DenseTopk
 };
 
 template <int METRIC, bool FUSED = false>
-__global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, const float *B, uint32_t nb, uint32_t stride /* floats per row */,
+__global__ void __launch_bounds__(256, 3) k_dense_f32(const float *Q, uint32_t nq, const float *B, uint32_t nb, uint32_t stride /* floats per row */,
                                                    const float *qn, const float *bn, float *out, uint32_t ldo, DenseTopk tk)
 {
     __shared__ float As[ BM * LDK ];
@@ -103,26 +108,29 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
         for(int it = 0; it < 4; ++it) {
             const int f = tid + it * 256;
             const int row = f >> 3, kq = (f & 7) * 4;
-            float    *pa = As + row * LDK + kq, *pb = Bs + row * LDK + kq;
-            pa[ 0 ] = pa4[ it ].x; pa[ 1 ] = pa4[ it ].y; pa[ 2 ] = pa4[ it ].z; pa[ 3 ] = pa4[ it ].w;
-            pb[ 0 ] = pb4[ it ].x; pb[ 1 ] = pb4[ it ].y; pb[ 2 ] = pb4[ it ].z; pb[ 3 ] = pb4[ it ].w;
+            *(float4 *)(As + row * LDK + kq) = pa4[ it ];
+            *(float4 *)(Bs + row * LDK + kq) = pb4[ it ];
         }
     };
-    const float *a0 = As + (wm * 64 + (lane & 31)) * LDK + (lane >> 5);
-    const float *b0 = Bs + (wn * 64 + (lane & 31)) * LDK + (lane >> 5);
+    const float *a0 = As + (wm * 64 + (lane & 31)) * LDK + 2 * (lane >> 5);
+    const float *b0 = Bs + (wn * 64 + (lane & 31)) * LDK + 2 * (lane >> 5);
     fetch(0);
     for(uint32_t k0 = 0; k0 < stride; k0 += BK) {
         stash();
         __syncthreads();
         if(k0 + BK < stride) fetch(k0 + BK);  // in flight during the MFMA loop below
 #pragma unroll
-        for(int kk = 0; kk < BK; kk += 2) {
-            const float av0 = a0[ kk ], av1 = a0[ 32 * LDK + kk ];
-            const float bv0 = b0[ kk ], bv1 = b0[ 32 * LDK + kk ];
-            acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc[ 0 ][ 0 ], 0, 0, 0);
-            acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv1, acc[ 0 ][ 1 ], 0, 0, 0);
-            acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv0, acc[ 1 ][ 0 ], 0, 0, 0);
-            acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc[ 1 ][ 1 ], 0, 0, 0);
+        for(int kk = 0; kk < BK; kk += 4) {  // four k values per round: this lane's two, {kk + 2h, kk + 2h + 1}, feed two MFMAs each
+            const float2 av0 = *(const float2 *)(a0 + kk), av1 = *(const float2 *)(a0 + 32 * LDK + kk);
+            const float2 bv0 = *(const float2 *)(b0 + kk), bv1 = *(const float2 *)(b0 + 32 * LDK + kk);
+            acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bv0.x, acc[ 0 ][ 0 ], 0, 0, 0);
+            acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bv1.x, acc[ 0 ][ 1 ], 0, 0, 0);
+            acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bv0.x, acc[ 1 ][ 0 ], 0, 0, 0);
+            acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bv1.x, acc[ 1 ][ 1 ], 0, 0, 0);
+            acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bv0.y, acc[ 0 ][ 0 ], 0, 0, 0);
+            acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bv1.y, acc[ 0 ][ 1 ], 0, 0, 0);
+            acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bv0.y, acc[ 1 ][ 0 ], 0, 0, 0);
+            acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bv1.y, acc[ 1 ][ 1 ], 0, 0, 0);
         }
         __syncthreads();
     }
