@@ -1695,7 +1695,10 @@ static bool exact_knn_device_impl(int mcode, uint32_t chunks, const uint4 *d_bas
     // kk = k plus a margin: the MFMA distances (|q|^2 + |b|^2 - 2 q.b) differ from the exact-order ones in the
     // last bits, so the survivors are re-ranked exactly and only then cut to k
     const uint32_t kk = (uint32_t)k + 16;
-    const size_t   QT = 1024, CH = std::min<size_t>(nb, 65536);
+    // column chunk: 768 column tiles of 128 -- with 1024 queries (8 row tiles) that is 6144 tiles = exactly eight rounds of the 768
+    // workgroups the contraction keeps resident (three per CU x 256 CUs).  [r3] 65536 columns gave 4096 tiles = 5.33 rounds: the last
+    // round ran a third full and cost 11 % (rocprofv3: the same 829 us per launch before and after the kernel's LDS re-layout)
+    const size_t   QT = 1024, CH = std::min<size_t>(nb, 98304);
     const bool     i8 = mcode_is_i8(mcode);
     const bool     f16 = mcode_is_f16(mcode) || i8;  // "quantised storage": the contraction runs on an f32 copy
     const int      base_metric = mcode_base(mcode);
