@@ -64,6 +64,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--quant", default="f32", choices=["f32", "f16", "i8", "b1"], help="storage kind (reloption quant_bits 32 / 16 / 8 / 1); the headline config is f32")
+    p.add_argument("--pq-subvectors", type=int, default=0, help="pq = true with this many subvectors (0 = off): the index is built with the decodings "
+                   "resident, then COMPACTED (codes only in HBM) and searched by ADC over the code bytes (lantern_gpu_pq_compact)")
+    p.add_argument("--pq-centroids", type=int, default=256)
     p.add_argument("--dist-backend", default="rccl", choices=["rccl", "nccl", "files", "gloo"],
                    help="exchange transport of the collective build at N>1: rccl (alias nccl; xGMI, data stays in HBM) or files (alias "
                         "gloo: the host transport over the rendezvous directory -- debugging, or several ranks on one GPU)")
@@ -192,7 +195,19 @@ def main():
     # work of every insertion batch is split over the ranks, the top-M neighbour lists and the re-written adjacency rows
     # are all-gathered -- which leaves a bit-identical replica in every GPU's HBM: exactly what the
     # query-sharded search leg needs.
-    ix = capi.GpuIndex(a.metric, a.dim, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, quantization=a.quant)
+    pq_kw = {}
+    if a.pq_subvectors:
+        # a codebook in the layout Lantern hands to usearch_init (pqtable.c:194-240): [C][dim], centroid c of every subvector
+        # concatenated; the centroids are sampled rows per subvector (what k-means++ starts from) -- the bench measures the
+        # search over code bytes, not codebook quality
+        assert world == 1 and a.quant == "f32" and a.dim % a.pq_subvectors == 0
+        crng = np.random.default_rng(91)
+        sub = a.dim // a.pq_subvectors
+        cb = np.zeros((a.pq_centroids, a.dim), dtype=np.float32)
+        for sv in range(a.pq_subvectors):
+            cb[:, sv * sub:(sv + 1) * sub] = base[crng.choice(a.n, size=a.pq_centroids, replace=False), sv * sub:(sv + 1) * sub]
+        pq_kw = {"pq_codebook": cb, "num_subvectors": a.pq_subvectors}
+    ix = capi.GpuIndex(a.metric, a.dim, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, quantization=a.quant, **pq_kw)
     ix.reserve(a.n)
     ix.set_add_batch(a.add_batch, 16)
     ix.set_search_shape(a.waves, a.max_wg)
@@ -248,6 +263,18 @@ def main():
         t_build = time.time() - t0
     build_counters = ix.counters()
     build_profile = ix.build_profile()
+    pq_info = None
+    pq_truth = None
+    if a.pq_subvectors:
+        # recall truth = exact k-NN over the DECODED rows (what a PQ index's distances are distances to), taken before the rows go
+        mem_before = ix.memory_usage()
+        tq0 = make_queries(np.random.default_rng(4 + 1000 * rank), a.queries * max(a.streams, a.query_batches, 1))[:min(a.truth_queries, a.queries)]  # = queries[:tq] below
+        pq_truth, _ = ix.exact_search(tq0, a.k)
+        ix.pq_compact()
+        mem_after = ix.memory_usage()
+        pq_info = {"num_subvectors": a.pq_subvectors, "num_centroids": a.pq_centroids, "row_bytes_decoded_form": mem_before[0], "row_bytes_compact_form": mem_after[0],
+                   "other_index_bytes": mem_after[1], "search": "ADC over the code bytes: per-query table (subvector x centroid) in LDS, lantern_amd/csrc/search_adc_kernel.hip",
+                   "recall_truth": "exact k-NN over the decoded rows"}
 
     # ---- this rank's queries, resident in HBM ----------------------------------------------------
     # B distinct batches (>= 4 by default), step i searches batch i mod B on stream i mod S: consecutive steps never replay
@@ -298,6 +325,8 @@ def main():
 
     # ---- algorithmic bytes of one launch --------------------------------------------
     row_bytes = a.dim * {"f32": 4, "f16": 2, "i8": 1, "b1": 0.125}[a.quant]
+    if a.pq_subvectors:
+        row_bytes = (a.pq_subvectors + 15) // 16 * 16  # a compact pq index evaluates a row from its code bytes
     per_lane = []
     for L in lanes:
         Dl = L["D"].download(nq, np.uint64).astype(np.float64)
@@ -316,14 +345,14 @@ def main():
         # ---- recall@k against exact f32 k-NN (fp32-MFMA contraction + exact re-rank) --------------
         tq = min(a.truth_queries, nq)
         t0 = time.time()
-        truth, _ = ix.exact_search(queries[:tq], a.k)
+        truth = pq_truth[:tq] if pq_truth is not None else ix.exact_search(queries[:tq], a.k)[0]
         t_truth = time.time() - t0
         found = d_slot.download((nq, a.k), np.uint32)[:tq]
         recall = float(np.mean([len(set(f.tolist()) & set(t.tolist())) / a.k for f, t in zip(found, truth)]))
 
         cpu = None
         quality = None
-        if world == 1 and not a.no_cpu and a.cpu_seconds > 0:
+        if world == 1 and not a.no_cpu and a.cpu_seconds > 0 and not a.pq_subvectors:
             cpu = cpu_baseline(a, ix, base, queries, found)
             if a.build_quality_rows > 0 and a.quant == "f32" and a.metric != "hamming":
                 quality = build_quality(a)
@@ -375,6 +404,7 @@ def main():
             "expansions_per_query": float(E.mean()),
             "roofline": roofline(achieved, traffic, dram, traffic_src, avg_kernel_s if S == 1 else elapsed / a.steps, bytes_per_launch, avg_kernel_s, S, B),
             "cpu_baseline": cpu,
+            "pq": pq_info,
             "build_quality": quality,
             "collective_build": collective,
             "setup_seconds": {"datagen": t_gen, "build": t_build, "exact_truth": t_truth},

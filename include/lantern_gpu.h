@@ -198,6 +198,11 @@ LANTERN_GPU_EXPORT size_t lantern_gpu_plan_batch(size_t current_size, int max_le
                                                  size_t max_batch, size_t min_ratio);
 /* apply all buffered inserts now */
 LANTERN_GPU_EXPORT void lantern_gpu_flush(usearch_index_t, usearch_error_t *);
+/* page-locked host memory for rows that are about to be handed to lantern_gpu_add_many / usearch_add: the upload runs at the
+ * host link's rate instead of through the runtime's pageable staging (the indexing server's row chunks: 50 MB each).  NULL on
+ * failure (callers fall back to ordinary memory). */
+LANTERN_GPU_EXPORT void *lantern_gpu_host_alloc(size_t bytes);
+LANTERN_GPU_EXPORT void  lantern_gpu_host_free(void *);
 /* usearch_add with a caller-drawn level (insert.c:32-46); usearch_add_external is this plus the write-back to the pages */
 LANTERN_GPU_EXPORT void lantern_gpu_add_with_level(usearch_index_t, usearch_label_t, const void *vector,
                                                    usearch_scalar_kind_t, int level, usearch_error_t *);

@@ -87,7 +87,7 @@ EXPORTS = [
     "lantern_gpu_set_seed", "lantern_gpu_set_add_batch", "lantern_gpu_add_many", "lantern_gpu_flush",
     "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device",
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
-    "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile",
+    "lantern_gpu_host_alloc", "lantern_gpu_host_free", "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile",
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_export_codes",
     "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_gpu_search_phase_profile", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",

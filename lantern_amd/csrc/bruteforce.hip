@@ -66,7 +66,7 @@ struct DenseTopk
 };
 
 template <int METRIC, bool FUSED = false>
-__global__ void __launch_bounds__(256, 3) k_dense_f32(const float *Q, uint32_t nq, const float *B, uint32_t nb, uint32_t stride /* floats per row */,
+__global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, const float *B, uint32_t nb, uint32_t stride /* floats per row */,
                                                    const float *qn, const float *bn, float *out, uint32_t ldo, DenseTopk tk)
 {
     __shared__ float As[ BM * LDK ];

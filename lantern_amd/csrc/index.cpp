@@ -1289,6 +1289,17 @@ void usearch_add(usearch_index_t h, usearch_label_t label, const void *vector, u
     if(ix) add_common(ix, &label, vector, 1, kind, -1, e);
 }
 
+void *lantern_gpu_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if(lantern_gpu_device_count() <= 0 || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void lantern_gpu_host_free(void *p)
+{
+    if(p) (void)hipHostFree(p);
+}
+
 void lantern_gpu_add_many(usearch_index_t h, const usearch_label_t *labels, const void *vectors, size_t n,
                           usearch_scalar_kind_t kind, usearch_error_t *e)
 {
@@ -1695,10 +1706,10 @@ static bool exact_knn_device_impl(int mcode, uint32_t chunks, const uint4 *d_bas
     // kk = k plus a margin: the MFMA distances (|q|^2 + |b|^2 - 2 q.b) differ from the exact-order ones in the
     // last bits, so the survivors are re-ranked exactly and only then cut to k
     const uint32_t kk = (uint32_t)k + 16;
-    // column chunk: 768 column tiles of 128 -- with 1024 queries (8 row tiles) that is 6144 tiles = exactly eight rounds of the 768
-    // workgroups the contraction keeps resident (three per CU x 256 CUs).  [r3] 65536 columns gave 4096 tiles = 5.33 rounds: the last
-    // round ran a third full and cost 11 % (rocprofv3: the same 829 us per launch before and after the kernel's LDS re-layout)
-    const size_t   QT = 1024, CH = std::min<size_t>(nb, 98304);
+    // column chunk.  [r3] 65536 columns x 1024 queries are 4096 tiles = 5.33 rounds of the 768 workgroups the contraction keeps
+    // resident (three per CU): the last round runs a third full.  98304 columns (6144 tiles = 8 rounds) were tried: l2sq 14.9 -> 14.5 ms
+    // per 1024 x 1M x 768 call, but cosine 15.4 -> 20.1 ms (the fused call repeated itself unfused), so the chunk stays.
+    const size_t   QT = 1024, CH = std::min<size_t>(nb, 65536);
     const bool     i8 = mcode_is_i8(mcode);
     const bool     f16 = mcode_is_f16(mcode) || i8;  // "quantised storage": the contraction runs on an f32 copy
     const int      base_metric = mcode_base(mcode);

@@ -24,6 +24,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -162,26 +164,54 @@ void serve(lantern_index_server *srv, int fd)
         // The socket is drained by THIS thread while a builder thread hands finished chunks to the device: the reference
         // overlaps the two the same way (a reader feeding a channel that a pool of add_raw workers drains: server.rs:214-267,
         // :317-359).  At most four chunks wait between the two; a failed add stops the reader at its next chunk.
-        struct Chunk { std::vector<uint64_t> labels; std::vector<uint8_t> rows; };
+        // row buffers are page-locked and recycled (six of them): a chunk's 50 MB go up at the host link's rate, not through the
+        // runtime's pageable staging (which cost as much as the device batches of the chunk: the builder was the stream's limit)
+        struct Chunk { std::vector<uint64_t> labels; uint8_t *rows = nullptr; size_t bytes = 0; };
         const size_t chunk_rows = std::max<size_t>(64, std::min<size_t>(ADD_CHUNK, (64u << 20) / std::max<size_t>(vec_bytes, 1)));
+        // where the stream's time goes (LANTERN_INDEX_SERVER_TRACE=1 prints it to stderr when the rows have been received)
+        double t_recv = 0, t_parse = 0, t_blocked = 0, t_add = 0, t_idle = 0;
+        auto   now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         std::mutex              qmu;
         std::condition_variable qcv;
         std::deque<Chunk>       ready;
+        const size_t            buf_bytes = chunk_rows * vec_bytes;
+        std::vector<uint8_t *>  pool, all_bufs;
+        std::vector<std::vector<uint8_t>> fallback;  // ordinary memory if page-locking fails
+        for(int i = 0; i < 6; ++i) {
+            uint8_t *b = (uint8_t *)lantern_gpu_host_alloc(buf_bytes);
+            if(!b) {
+                fallback.emplace_back(buf_bytes);
+                b = fallback.back().data();
+            } else {
+                all_bufs.push_back(b);
+            }
+            pool.push_back(b);
+        }
+        struct PoolGuard { std::vector<uint8_t *> &v; ~PoolGuard() { for(uint8_t *b : v) lantern_gpu_host_free(b); } } pool_guard{ all_bufs };
         bool                    closed = false;
         std::string             add_error;
         std::thread builder([&] {
             for(;;) {
                 Chunk c;
                 {
+                    const double                 w0 = now_s();
                     std::unique_lock<std::mutex> lk(qmu);
                     qcv.wait(lk, [&] { return closed || !ready.empty(); });
+                    t_idle += now_s() - w0;
                     if(ready.empty()) return;
                     c = std::move(ready.front());
                     ready.pop_front();
                 }
                 qcv.notify_all();
                 usearch_error_t e2 = nullptr;
-                lantern_gpu_add_many(index, c.labels.data(), c.rows.data(), c.labels.size(), kind, &e2);
+                const double    a0 = now_s();
+                lantern_gpu_add_many(index, c.labels.data(), c.rows, c.labels.size(), kind, &e2);
+                t_add += now_s() - a0;
+                {
+                    std::lock_guard<std::mutex> g(qmu);
+                    pool.push_back(c.rows);  // (add_many has copied the rows to the device: the buffer is free again)
+                }
+                qcv.notify_all();
                 if(e2) {
                     std::lock_guard<std::mutex> g(qmu);
                     add_error = e2;
@@ -192,16 +222,30 @@ void serve(lantern_index_server *srv, int fd)
                 }
             }
         });
+        // hand a filled chunk to the builder and take an empty buffer for the next one (waiting for the builder if all six are full)
+        auto take_buffer = [&](Chunk &c) {
+            const double                 b0 = now_s();
+            std::unique_lock<std::mutex> lk(qmu);
+            qcv.wait(lk, [&] { return closed || !pool.empty(); });
+            t_blocked += now_s() - b0;
+            if(closed || pool.empty()) return false;
+            c.rows = pool.back();
+            pool.pop_back();
+            c.bytes = 0;
+            c.labels.clear();
+            c.labels.reserve(chunk_rows);
+            return true;
+        };
         auto hand_over = [&](Chunk &c) {
             if(c.labels.empty()) return true;
-            std::unique_lock<std::mutex> lk(qmu);
-            qcv.wait(lk, [&] { return closed || ready.size() < 4; });
-            if(closed) return false;
-            ready.push_back(std::move(c));
+            {
+                std::lock_guard<std::mutex> g(qmu);
+                if(closed) return false;
+                ready.push_back(std::move(c));
+            }
             c = Chunk();
-            lk.unlock();
             qcv.notify_all();
-            return true;
+            return take_buffer(c);
         };
         std::string read_failure;
         try {
@@ -210,13 +254,15 @@ void serve(lantern_index_server *srv, int fd)
             // closes the stream -- the reference's read_frame looks at the first four bytes of what one read returned in the same
             // way, server.rs:275-309).
             Chunk cur;
-            cur.labels.reserve(chunk_rows);
-            cur.rows.reserve(chunk_rows * vec_bytes);
+            if(!take_buffer(cur)) throw Fail{ "indexing server: no row buffer" };
             std::vector<uint8_t> inbuf(std::max<size_t>(1u << 20, payload * 4));
             size_t have = 0;
             bool   ended = false;
             while(!ended) {
+                const double  r0 = now_s();
                 const ssize_t got = ::recv(fd, inbuf.data() + have, inbuf.size() - have, 0);
+                const double  r1 = now_s();
+                t_recv += r1 - r0;
                 if(got <= 0) throw Fail{ have ? "failed to fill whole buffer" : "Invalid frame received" };
                 have += (size_t)got;
                 size_t pos = 0;
@@ -231,20 +277,22 @@ void serve(lantern_index_server *srv, int fd)
                     uint64_t label;
                     std::memcpy(&label, inbuf.data() + pos, 8);
                     cur.labels.push_back(label);
-                    cur.rows.insert(cur.rows.end(), inbuf.data() + pos + 8, inbuf.data() + pos + payload);
+                    std::memcpy(cur.rows + cur.bytes, inbuf.data() + pos + 8, vec_bytes);
+                    cur.bytes += vec_bytes;
                     pos += payload;
-                    if(cur.labels.size() == chunk_rows) {
-                        if(!hand_over(cur)) { ended = true; break; }
-                        cur.labels.reserve(chunk_rows);
-                        cur.rows.reserve(chunk_rows * vec_bytes);
-                    }
+                    if(cur.labels.size() == chunk_rows && !hand_over(cur)) { ended = true; break; }
                 }
                 if(pos) {
                     std::memmove(inbuf.data(), inbuf.data() + pos, have - pos);
                     have -= pos;
                 }
+                t_parse += now_s() - r1;
             }
-            (void)hand_over(cur);
+            if(!cur.labels.empty()) {  // the last, partial chunk (no further buffer is needed behind it)
+                std::lock_guard<std::mutex> g(qmu);
+                if(!closed) ready.push_back(std::move(cur));
+            }
+            qcv.notify_all();
         } catch(const Fail &f) {
             read_failure = f.msg;
         } catch(const std::exception &ex) {
@@ -256,6 +304,9 @@ void serve(lantern_index_server *srv, int fd)
         }
         qcv.notify_all();
         builder.join();
+        if(std::getenv("LANTERN_INDEX_SERVER_TRACE"))
+            std::fprintf(stderr, "index server: reader recv %.2f s, parse+copy %.2f s (of which blocked on the builder %.2f s); builder add_many %.2f s, idle %.2f s\n",
+                         t_recv, t_parse, t_blocked, t_add, t_idle);
         if(!read_failure.empty()) throw Fail{ read_failure };
         if(!add_error.empty()) throw Fail{ add_error };
         lantern_gpu_flush(index, &err);

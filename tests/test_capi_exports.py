@@ -75,9 +75,16 @@ def test_argument_validation_precedes_device_use(capi):
     o.metric_kind, o.pq = 3, True
     assert capi.lib().usearch_init(C.byref(o), None, C.byref(err)) is None
     assert b"pq = true needs a codebook" in err.value  # build.c:497-500 always passes the codebook it loaded
-    o.pq, o.quantization, o.metric_kind = False, 5, 1  # quant_bits = 1 on a cosine index: the fork's arithmetic is unknown -> refused
+    o.pq, o.quantization, o.metric_kind = False, 4, 8  # hamming over i8 scalars: hamming is a metric over bits
     assert capi.lib().usearch_init(C.byref(o), None, C.byref(err)) is None
-    assert b"quant_bits=1 is supported for l2sq indexes only" in err.value
+    assert b"hamming needs b1 scalars" in err.value
+    o.quantization, o.metric_kind = 5, 1  # quant_bits = 1 on a cosine index is accepted since round 3: without a device it fails on THAT
+    h = capi.lib().usearch_init(C.byref(o), None, C.byref(err))
+    if capi.device_count() > 0:
+        assert h is not None
+        capi.lib().usearch_free(h, C.byref(err))
+    else:
+        assert h is None and b"no HIP device" in err.value
 
 
 def test_level_draw_and_batch_plan_agree_with_the_oracle(capi):
