@@ -65,144 +65,237 @@ struct DenseTopk
     uint32_t        c_base;  // column id of this launch's first base row
 };
 
+// Persistent workgroups over a stream of K steps.  A launch starts DENSE_WGS_PER_CU workgroups per CU; each walks its own list
+// of tiles, and the K steps of all its tiles form ONE software pipeline: while step s is on the matrix cores, the registers hold
+// step s + 1 (on its way into the other LDS buffer) and the global loads of step s + 2 are in flight -- across tile boundaries
+// too, so only a workgroup's very first step ever waits for HBM.  A step is eight half-rounds of 8 MFMAs, and everything else it
+// has to do is dealt out BETWEEN them, in the shadow of the MFMA just issued:
+//   half-rounds 0..3   write a quarter of step s + 1 (registers, loaded a whole step ago) to the OTHER LDS buffer and issue the
+//                      buffer loads of the same quarter of step s + 2 into the registers just freed
+//   half-round 4       the step's one barrier: the other buffer is complete, this one has no reader left (the fragment reads
+//                      of the last round were issued at the start of half-round 4)
+//   half-round 6       read round 0's fragments of the NEXT step from the other buffer
+//   even half-rounds   read the next round's fragments into the second fragment register set
+// What this replaced (r1-r2: loads, then 64 MFMAs, then stash, two barriers per step) left every wave standing between a
+// barrier and its first MFMA once per step, and the two waves of a SIMD fell into step with each other instead of covering for
+// one another: 0.79 of the fp32-matrix peak where the same loop without its loads ran at 0.89 and without anything but MFMAs at
+// 0.94 (profiles/r03_dense_variants.md).
+// Tile order: workgroup b runs on XCD b % 8; every XCD gets a contiguous range of the tn-major tile order and its workgroups
+// take consecutive tiles of it, so the tiles_m workgroups sharing a B tile run on ONE XCD at about the same time and its L2
+// serves all but the first read.  Loads are branch-free buffer loads: the descriptor of a tile starts at its first row and ends
+// with its last one that exists, so rows past the end read as zeros, and so does a k past the end (offset pushed out of range).
+constexpr int DENSE_WGS_PER_CU = 2;  // 72 KB of LDS each
+
 template <int METRIC, bool FUSED = false>
 __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, const float *B, uint32_t nb, uint32_t stride /* floats per row */,
                                                    const float *qn, const float *bn, float *out, uint32_t ldo, DenseTopk tk)
 {
-    __shared__ float As[ BM * LDK ];
-    __shared__ float Bs[ BN * LDK ];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware tile order: consecutive workgroups (which land on different XCDs) walk the query
-    // dimension first, so the 8 XCDs stream 8 different Q tiles against the same B tile column
-    const uint32_t tiles_m = (nq + BM - 1) / BM;
-    const uint32_t tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
-    const uint32_t q0 = tm * BM, c0 = tn * BN;
-    floatx16 acc[ 2 ][ 2 ];
-#pragma unroll
-    for(int i = 0; i < 2; ++i)
-#pragma unroll
-        for(int j = 0; j < 2; ++j)
-#pragma unroll
-            for(int r = 0; r < 16; ++r) acc[ i ][ j ][ r ] = 0.f;
+    __shared__ float As2[ 2 ][ BM * LDK ];
+    __shared__ float Bs2[ 2 ][ BN * LDK ];
+    __shared__ float Ns[ 2 ][ 3 * 128 ];  // per tile parity: 128 query norms, 128 base norms (cosine: inverse roots), 128 query radii
+    const int        tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int        wm = wave >> 1, wn = wave & 1;
+    const uint32_t   tiles_m = (nq + BM - 1) / BM, T = tiles_m * ((nb + BN - 1) / BN);
+    const uint32_t   x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const uint32_t   wx = (gridDim.x - x + 7) >> 3;  // workgroups on this XCD
+    const uint32_t   cnt = (T >> 3) + (x < (T & 7) ? 1u : 0u), start = x * (T >> 3) + (x < (T & 7) ? x : (T & 7));  // its tiles
+    const uint32_t   my_n = cnt > j ? (cnt - j + wx - 1) / wx : 0u;
+    if(my_n == 0) return;
+    auto tile_origin = [&](uint32_t i, uint32_t &q0, uint32_t &c0) {
+        const uint32_t lin = start + j + i * wx;
+        q0 = (lin % tiles_m) * BM;
+        c0 = (lin / tiles_m) * BN;
+    };
 
-    // Software pipeline over K: the global loads of tile k0 + BK are issued BEFORE the MFMA loop of tile k0 and land
-    // in registers while the matrix cores work; they are written to LDS after the loop.  (Single-buffered LDS, two
-    // barriers per tile; 8 float4 = 32 VGPRs of prefetch per thread.)
-    float4 pa4[ 4 ], pb4[ 4 ];
-    auto fetch = [&](uint32_t k0) {
+    floatx16 acc[ 2 ][ 2 ];
+    auto     zero_acc = [&]() {
 #pragma unroll
-        for(int it = 0; it < 4; ++it) {
-            const int      f = tid + it * 256;  // float4 index in the tile: 128 rows x 8 float4
-            const int      row = f >> 3, kq = (f & 7) * 4;
-            const uint32_t k = k0 + (uint32_t)kq;
-            float4         a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if(q0 + row < nq && k < stride) a = *(const float4 *)(Q + (size_t)(q0 + row) * stride + k);
-            if(c0 + row < nb && k < stride) b = *(const float4 *)(B + (size_t)(c0 + row) * stride + k);
-            pa4[ it ] = a;
-            pb4[ it ] = b;
+        for(int i = 0; i < 2; ++i)
+#pragma unroll
+            for(int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for(int r = 0; r < 16; ++r) acc[ i ][ jj ][ r ] = 0.f;
+    };
+    zero_acc();
+
+    // ---- the load side of the pipeline: (tile li, k position lk), two steps ahead of the MFMAs
+    float4                 pa4[ 4 ], pb4[ 4 ];
+    const int              kq = (tid & 7) * 4, r0 = tid >> 3;  // this thread's float4 of rows r0 + 32 it
+    const uint32_t         voff = ((uint32_t)r0 * stride + (uint32_t)kq) * 4u, vstep = 32u * stride * 4u;
+    uint32_t               li = 0, lk = 0;
+    __amdgpu_buffer_rsrc_t rq, rb;
+    auto                   set_load_tile = [&](uint32_t i) {
+        if(i < my_n) {
+            uint32_t q0, c0;
+            tile_origin(i, q0, c0);
+            const uint32_t rows_q = nq - q0 < (uint32_t)BM ? nq - q0 : (uint32_t)BM, rows_b = nb - c0 < (uint32_t)BN ? nb - c0 : (uint32_t)BN;
+            rq = __builtin_amdgcn_make_buffer_rsrc((void *)(Q + (size_t)q0 * stride), 0, (int)(rows_q * stride * 4u), 0x00020000);
+            rb = __builtin_amdgcn_make_buffer_rsrc((void *)(B + (size_t)c0 * stride), 0, (int)(rows_b * stride * 4u), 0x00020000);
+        } else {  // past this workgroup's last tile: empty descriptors, every load returns zeros
+            rq = __builtin_amdgcn_make_buffer_rsrc((void *)Q, 0, 0, 0x00020000);
+            rb = __builtin_amdgcn_make_buffer_rsrc((void *)B, 0, 0, 0x00020000);
         }
     };
-    auto stash = [&]() {
-#pragma unroll
-        for(int it = 0; it < 4; ++it) {
-            const int f = tid + it * 256;
-            const int row = f >> 3, kq = (f & 7) * 4;
-            *(float4 *)(As + row * LDK + kq) = pa4[ it ];
-            *(float4 *)(Bs + row * LDK + kq) = pb4[ it ];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto fetch1 = [&](int it) {
+        const uint32_t off = lk + (uint32_t)kq < stride ? voff + (uint32_t)it * vstep + lk * 4u : 0x80000000u;
+        const u32x4    a = __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0);
+        pa4[ it ] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+        pb4[ it ] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+    };
+    auto advance = [&]() {
+        lk += BK;
+        if(lk >= stride) {
+            lk = 0;
+            set_load_tile(++li);
         }
     };
-    const float *a0 = As + (wm * 64 + (lane & 31)) * LDK + 2 * (lane >> 5);
-    const float *b0 = Bs + (wn * 64 + (lane & 31)) * LDK + 2 * (lane >> 5);
-    fetch(0);
-    for(uint32_t k0 = 0; k0 < stride; k0 += BK) {
-        stash();
-        __syncthreads();
-        if(k0 + BK < stride) fetch(k0 + BK);  // in flight during the MFMA loop below
-#pragma unroll
-        for(int kk = 0; kk < BK; kk += 4) {  // four k values per round: this lane's two, {kk + 2h, kk + 2h + 1}, feed two MFMAs each
-            const float2 av0 = *(const float2 *)(a0 + kk), av1 = *(const float2 *)(a0 + 32 * LDK + kk);
-            const float2 bv0 = *(const float2 *)(b0 + kk), bv1 = *(const float2 *)(b0 + 32 * LDK + kk);
-            acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bv0.x, acc[ 0 ][ 0 ], 0, 0, 0);
-            acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bv1.x, acc[ 0 ][ 1 ], 0, 0, 0);
-            acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bv0.x, acc[ 1 ][ 0 ], 0, 0, 0);
-            acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bv1.x, acc[ 1 ][ 1 ], 0, 0, 0);
-            acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bv0.y, acc[ 0 ][ 0 ], 0, 0, 0);
-            acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bv1.y, acc[ 0 ][ 1 ], 0, 0, 0);
-            acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bv0.y, acc[ 1 ][ 0 ], 0, 0, 0);
-            acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bv1.y, acc[ 1 ][ 1 ], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    // The tile's 128 + 128 squared norms go through LDS once (the K loop ended with a barrier, As / Bs are free)
-    // instead of 64 dependent global loads per thread.
-    // Cosine: the tile's 256 norms become 1 / sqrt(norm) here (0 stays 0: the zero-norm rules below test for it), so that an
-    // output costs two multiplies instead of two IEEE square roots and a divide -- 64 of those per lane were ~8 % of a tile.
-    // (These distances pick candidates / meet the 1e-5 tolerance; exact results are re-ranked in the walk's own order.)
-    {
-        float nv = tid < BM ? (q0 + tid < nq ? qn[ q0 + tid ] : 0.f) : (c0 + (tid - BM) < nb ? bn[ c0 + (tid - BM) ] : 0.f);
+    auto stash1 = [&](int it, uint32_t buf) {
+        *(float4 *)(As2[ buf ] + (r0 + 32 * it) * LDK + kq) = pa4[ it ];
+        *(float4 *)(Bs2[ buf ] + (r0 + 32 * it) * LDK + kq) = pb4[ it ];
+    };
+    // ---- a tile's norms and radii: loaded a tile ahead into two registers, written to LDS in the tile's first step
+    float    nreg = 0.f;
+    uint32_t rreg = 0;
+    auto     load_norms = [&](uint32_t i) {
+        uint32_t q0, c0;
+        tile_origin(i, q0, c0);
+        nreg = tid < BM ? (q0 + tid < nq ? qn[ q0 + tid ] : 0.f) : (c0 + (tid - BM) < nb ? bn[ c0 + (tid - BM) ] : 0.f);
+        if(FUSED && tid < BM)  // the query's current radius: the distance of its kk-th best so far (all ones while the list is short)
+            rreg = q0 + tid < nq ? (uint32_t)(tk.best[ (size_t)(q0 + tid) * tk.kk + tk.kk - 1 ] >> 32) : 0u;
+    };
+    auto store_norms = [&](uint32_t par) {
+        // Cosine: the norms become 1 / sqrt(norm) here (0 stays 0: the zero-norm rules of the epilogue test for it), so that an
+        // output costs two multiplies instead of two IEEE square roots and a divide.  (These distances pick candidates / meet the
+        // 1e-5 tolerance; exact results are re-ranked in the walk's own order.)
+        float nv = nreg;
         if(METRIC != M_L2SQ) nv = nv == 0.f ? 0.f : 1.f / __builtin_sqrtf(nv);
-        if(tid < BM) As[ tid ] = nv;
-        else Bs[ tid - BM ] = nv;
-        if(FUSED && tid < BM)  // the query's current radius: the distance of its kk-th best so far (+inf while the list is short)
-        {
-            const uint32_t hi = q0 + tid < nq ? (uint32_t)(tk.best[ (size_t)(q0 + tid) * tk.kk + tk.kk - 1 ] >> 32) : 0u;
-            As[ BM + tid ] = hi == 0xFFFFFFFFu ? __builtin_inff() : ord2f(hi);  // (rows past nq: ord2f(0) = NaN, nothing passes)
-        }
-    }
+        Ns[ par ][ tid ] = nv;
+        if(FUSED && tid < BM) Ns[ par ][ 256 + tid ] = rreg == 0xFFFFFFFFu ? __builtin_inff() : ord2f(rreg);  // (rows past nq: ord2f(0) = NaN, nothing passes)
+    };
+    // ---- fragments: {4 j + 2 h, 4 j + 2 h + 1} (h = lane / 32) of a 4-wide k group go to the two MFMAs of a pair -- a
+    // permutation of the contraction index, which a dot product does not notice
+    const int fo = (lane & 31) * LDK + 2 * (lane >> 5);
+    float2    fa[ 2 ][ 4 ], fb[ 2 ][ 4 ];  // [fragment set][{row block 0, row block 1} x {kk, kk + 4}]
+    auto      frag = [&](int set, uint32_t buf, int kk) {
+        const float *a0 = As2[ buf ] + wm * 64 * LDK + fo + kk, *b0 = Bs2[ buf ] + wn * 64 * LDK + fo + kk;
+        fa[ set ][ 0 ] = *(const float2 *)(a0);
+        fa[ set ][ 1 ] = *(const float2 *)(a0 + 4);
+        fa[ set ][ 2 ] = *(const float2 *)(a0 + 32 * LDK);
+        fa[ set ][ 3 ] = *(const float2 *)(a0 + 32 * LDK + 4);
+        fb[ set ][ 0 ] = *(const float2 *)(b0);
+        fb[ set ][ 1 ] = *(const float2 *)(b0 + 4);
+        fb[ set ][ 2 ] = *(const float2 *)(b0 + 32 * LDK);
+        fb[ set ][ 3 ] = *(const float2 *)(b0 + 32 * LDK + 4);
+    };
+    auto mfma8 = [&](int set, int h) {
+        const float2 av0 = fa[ set ][ h ], av1 = fa[ set ][ 2 + h ], bv0 = fb[ set ][ h ], bv1 = fb[ set ][ 2 + h ];
+        acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bv0.x, acc[ 0 ][ 0 ], 0, 0, 0);
+        acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bv1.x, acc[ 0 ][ 1 ], 0, 0, 0);
+        acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bv0.x, acc[ 1 ][ 0 ], 0, 0, 0);
+        acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bv1.x, acc[ 1 ][ 1 ], 0, 0, 0);
+        acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bv0.y, acc[ 0 ][ 0 ], 0, 0, 0);
+        acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bv1.y, acc[ 0 ][ 1 ], 0, 0, 0);
+        acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bv0.y, acc[ 1 ][ 0 ], 0, 0, 0);
+        acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bv1.y, acc[ 1 ][ 1 ], 0, 0, 0);
+    };
+
+    // ---- fill the pipeline: step 0 into LDS buffer 0, step 1 into the registers
+    set_load_tile(0);
+    load_norms(0);
+#pragma unroll
+    for(int it = 0; it < 4; ++it) fetch1(it);
+    advance();
+#pragma unroll
+    for(int it = 0; it < 4; ++it) stash1(it, 0);
+#pragma unroll
+    for(int it = 0; it < 4; ++it) fetch1(it);
+    advance();
     __syncthreads();
+    frag(0, 0, 0);
+    const uint32_t KS = (stride + BK - 1) / BK;
+    uint32_t       cur = 0;
+    for(uint32_t ti = 0; ti < my_n; ++ti) {
+        for(uint32_t ks = 0; ks < KS; ++ks, cur ^= 1) {
+            if(ks == 0) {
+                store_norms(ti & 1);
+                if(ti + 1 < my_n) load_norms(ti + 1);
+            }
 #pragma unroll
-    for(int i = 0; i < 2; ++i)
-#pragma unroll
-        for(int j = 0; j < 2; ++j) {
-            const int      cl = wn * 64 + j * 32 + (lane & 31);
-            const uint32_t c = c0 + (uint32_t)cl;
-            const float    nb2 = Bs[ cl ];
-            auto dist_of = [&](int r, float dot) {
-                const float nq2 = As[ wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ];
-                float       d;
-                if(METRIC == M_L2SQ) {
-                    d = nq2 + nb2 - 2.f * dot;
-                    d = d < 0.f ? 0.f : d;
-                } else {
-                    if(nq2 == 0.f && nb2 == 0.f) d = 0.f;  // (nq2 / nb2 hold the INVERSE roots here)
-                    else if(nq2 == 0.f || nb2 == 0.f) d = 1.f;
-                    else d = 1.f - dot * (nq2 * nb2);
+            for(int h = 0; h < 8; ++h) {
+                const int r = h >> 1;
+                if((h & 1) == 0 && r < 3) frag((r + 1) & 1, cur, (r + 1) * 8);
+                if(h == 6) frag(0, cur ^ 1, 0);
+                __builtin_amdgcn_sched_barrier(0);  // (the compiler would sink the reads back to their use to save 16 registers)
+                mfma8(r & 1, h & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if(h < 4) {
+                    stash1(h, cur ^ 1);
+                    fetch1(h);
                 }
-                return d;
-            };
-            if constexpr(FUSED) {
-                // straight-line pass over the 16 outputs: which of them are inside their query's radius?  (A float compare
-                // orders like the keys' f2ord; NaN never passes; rows past nq carry a NaN radius.)  Then the rare appends.
-                uint32_t pass = 0;
-#pragma unroll
-                for(int r = 0; r < 16; ++r) {
-                    const int ql = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    pass |= (dist_of(r, acc[ i ][ j ][ r ]) <= As[ BM + ql ] ? 1u : 0u) << r;
-                }
-                if(c >= nb) pass = 0;
-                while(pass) {
-                    const int r = __builtin_ctz(pass);
-                    pass &= pass - 1;
-                    float dot = 0.f;
-#pragma unroll
-                    for(int rr = 0; rr < 16; ++rr)
-                        if(rr == r) dot = acc[ i ][ j ][ rr ];
-                    const float    d = dist_of(r, dot);
-                    const uint32_t q = q0 + (uint32_t)(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                    const uint32_t p = atomicAdd(&tk.cnt[ q ], 1u);
-                    if(p < tk.cap) tk.cand[ (size_t)q * tk.cap + p ] = ((uint64_t)f2ord(d) << 32) | (uint64_t)(tk.c_base + c);
-                }
-            } else {
-#pragma unroll
-                for(int r = 0; r < 16; ++r) {
-                    const uint32_t q = q0 + (uint32_t)(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                    const float    d = dist_of(r, acc[ i ][ j ][ r ]);
-                    if(q < nq && c < nb) out[ (size_t)q * ldo + c ] = d;
-                }
+                if(h == 3) advance();
+                if(h == 4) __syncthreads();
             }
         }
+        // ---- the tile's epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+        // Its norms and radii are in Ns[ti & 1] since the barrier of its first step; the next tile's first step is already in
+        // the other LDS buffer and its fragments in registers, so the MFMAs resume right after.
+        uint32_t q0, c0;
+        tile_origin(ti, q0, c0);
+        const float *Nq = Ns[ ti & 1 ], *Nb = Ns[ ti & 1 ] + 128, *Nr = Ns[ ti & 1 ] + 256;
+#pragma unroll
+        for(int i = 0; i < 2; ++i)
+#pragma unroll
+            for(int jj = 0; jj < 2; ++jj) {
+                const int      cl = wn * 64 + jj * 32 + (lane & 31);
+                const uint32_t c = c0 + (uint32_t)cl;
+                const float    nb2 = Nb[ cl ];
+                auto           dist_of = [&](int r, float dot) {
+                    const float nq2 = Nq[ wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ];
+                    float       d;
+                    if(METRIC == M_L2SQ) {
+                        d = nq2 + nb2 - 2.f * dot;
+                        d = d < 0.f ? 0.f : d;
+                    } else {
+                        if(nq2 == 0.f && nb2 == 0.f) d = 0.f;  // (nq2 / nb2 hold the INVERSE roots here)
+                        else if(nq2 == 0.f || nb2 == 0.f) d = 1.f;
+                        else d = 1.f - dot * (nq2 * nb2);
+                    }
+                    return d;
+                };
+                if constexpr(FUSED) {
+                    // straight-line pass over the 16 outputs: which of them are inside their query's radius?  (A float compare
+                    // orders like the keys' f2ord; NaN never passes; rows past nq carry a NaN radius.)  Then the rare appends.
+                    uint32_t pass = 0;
+#pragma unroll
+                    for(int r = 0; r < 16; ++r) {
+                        const int ql = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        pass |= (dist_of(r, acc[ i ][ jj ][ r ]) <= Nr[ ql ] ? 1u : 0u) << r;
+                    }
+                    if(c >= nb) pass = 0;
+                    while(pass) {
+                        const int r = __builtin_ctz(pass);
+                        pass &= pass - 1;
+                        float dot = 0.f;
+#pragma unroll
+                        for(int rr = 0; rr < 16; ++rr)
+                            if(rr == r) dot = acc[ i ][ jj ][ rr ];
+                        const float    d = dist_of(r, dot);
+                        const uint32_t q = q0 + (uint32_t)(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                        const uint32_t p = atomicAdd(&tk.cnt[ q ], 1u);
+                        if(p < tk.cap) tk.cand[ (size_t)q * tk.cap + p ] = ((uint64_t)f2ord(d) << 32) | (uint64_t)(tk.c_base + c);
+                    }
+                } else {
+#pragma unroll
+                    for(int r = 0; r < 16; ++r) {
+                        const uint32_t q = q0 + (uint32_t)(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                        const float    d = dist_of(r, acc[ i ][ jj ][ r ]);
+                        if(q < nq && c < nb) out[ (size_t)q * ldo + c ] = d;
+                    }
+                }
+            }
+        zero_acc();
+    }
 }
 
 // hamming (COSB1: the cosine of the {0, 1} vectors, device_common.hpp M_COS_B1): 16 queries in LDS per workgroup, one base row per thread
@@ -456,6 +549,20 @@ hipError_t launch_row_norms(const uint4 *rows, uint32_t n, uint32_t chunks, floa
     return hipGetLastError();
 }
 
+// persistent grid of k_dense_f32: DENSE_WGS_PER_CU workgroups per CU of the current device (fewer if there are fewer tiles)
+static uint32_t dense_grid(uint32_t tiles)
+{
+    static int cus[ 64 ];  // per device ordinal; filled once (racing fillers write the same value)
+    int        dev = 0;
+    if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if(cus[ dev ] == 0) {
+        int v = 0;
+        cus[ dev ] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
+    }
+    const uint32_t g = (uint32_t)DENSE_WGS_PER_CU * (uint32_t)cus[ dev ];
+    return tiles < g ? tiles : g;
+}
+
 hipError_t launch_dense(int metric, const uint4 *Q, uint32_t nq, const uint4 *B, uint32_t nb, uint32_t chunks, const float *qn,
                         const float *bn, float *out, uint32_t ldo, hipStream_t stream)
 {
@@ -472,10 +579,10 @@ hipError_t launch_dense(int metric, const uint4 *Q, uint32_t nq, const uint4 *B,
     const uint32_t tiles = ((nq + BM - 1) / BM) * ((nb + BN - 1) / BN);
     const DenseTopk none = { nullptr, 0, nullptr, nullptr, 0, 0 };
     if(metric == M_L2SQ)
-        hipLaunchKernelGGL((k_dense_f32<M_L2SQ>), dim3(tiles), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn, bn,
+        hipLaunchKernelGGL((k_dense_f32<M_L2SQ>), dim3(dense_grid(tiles)), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn, bn,
                            out, ldo, none);
     else
-        hipLaunchKernelGGL((k_dense_f32<M_COS>), dim3(tiles), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn, bn,
+        hipLaunchKernelGGL((k_dense_f32<M_COS>), dim3(dense_grid(tiles)), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn, bn,
                            out, ldo, none);
     return hipGetLastError();
 }
@@ -491,10 +598,10 @@ hipError_t launch_dense_topk(int metric, const uint4 *Q, uint32_t nq, const uint
     const uint32_t  tiles = ((nq + BM - 1) / BM) * ((nb + BN - 1) / BN);
     const DenseTopk tk = { best, kk, cand, cnt, cap, c_base };
     if(metric == M_L2SQ)
-        hipLaunchKernelGGL((k_dense_f32<M_L2SQ, true>), dim3(tiles), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn,
+        hipLaunchKernelGGL((k_dense_f32<M_L2SQ, true>), dim3(dense_grid(tiles)), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn,
                            bn, (float *)nullptr, 0u, tk);
     else
-        hipLaunchKernelGGL((k_dense_f32<M_COS, true>), dim3(tiles), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn,
+        hipLaunchKernelGGL((k_dense_f32<M_COS, true>), dim3(dense_grid(tiles)), dim3(256), 0, stream, (const float *)Q, nq, (const float *)B, nb, stride, qn,
                            bn, (float *)nullptr, 0u, tk);
     return hipGetLastError();
 }
