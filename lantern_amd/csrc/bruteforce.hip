@@ -41,15 +41,9 @@ __global__ void __launch_bounds__(256) k_row_norms(const uint4 *rows, uint32_t n
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 128 x 128 output tile per 256-thread workgroup; 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles of
-// 32 x 32; K staged through LDS 32 floats at a time (row stride 33 words: the 32 lanes of a half
-// wave read 32 different rows at one k -> 32 different banks).
-// [r3] LDS row stride 36 words: rows start 16-byte aligned, so a thread's float4 of a row goes to LDS as ONE 16-byte store (row
-// stride 33 took four 4-byte stores: 32 ds_write_b32 per thread and K step, ~12 % of a step's MFMA time); the price is a
-// two-way bank conflict on the fragment reads (rows r and r + 16 of a 32-row fragment share a bank), which are 8-byte reads of
-// two k values now -- half as many instructions.  The k values of a 4-wide group are dealt to the two MFMAs of a pair as
-// {4j + 2h, 4j + 2h + 1} (h = lane / 32): a permutation of the contraction index, which a dot product does not notice.
-constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 4;
+// 128 x 128 output tile per 256-thread workgroup; 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles of 32 x 32 (64 accumulator
+// registers per lane); K staged through LDS 32 floats at a time.
+constexpr int BM = 128, BN = 128, BK = 32;
 
 // FUSED: the tile does not write its distances; an output that can still enter its query's running top-kk -- ordered distance
 // <= the kk-th best so far, read once per tile -- is appended to that query's candidate list (cand[q][CAP], cnt[q]), which
@@ -66,32 +60,37 @@ struct DenseTopk
 };
 
 // Persistent workgroups over a stream of K steps.  A launch starts DENSE_WGS_PER_CU workgroups per CU; each walks its own list
-// of tiles, and the K steps of all its tiles form ONE software pipeline: while step s is on the matrix cores, the registers hold
-// step s + 1 (on its way into the other LDS buffer) and the global loads of step s + 2 are in flight -- across tile boundaries
-// too, so only a workgroup's very first step ever waits for HBM.  A step is eight half-rounds of 8 MFMAs, and everything else it
-// has to do is dealt out BETWEEN them, in the shadow of the MFMA just issued:
-//   half-rounds 0..3   write a quarter of step s + 1 (registers, loaded a whole step ago) to the OTHER LDS buffer and issue the
-//                      buffer loads of the same quarter of step s + 2 into the registers just freed
-//   half-round 4       the step's one barrier: the other buffer is complete, this one has no reader left (the fragment reads
-//                      of the last round were issued at the start of half-round 4)
-//   half-round 6       read round 0's fragments of the NEXT step from the other buffer
-//   even half-rounds   read the next round's fragments into the second fragment register set
-// What this replaced (r1-r2: loads, then 64 MFMAs, then stash, two barriers per step) left every wave standing between a
+// of tiles, and the K steps of all its tiles form ONE software pipeline over two LDS buffers: while step s (buffer P) is on the
+// matrix cores, step s + 1 is landing in the other buffer and, from the step's barrier on, step s + 2 is being loaded into
+// buffer P itself -- across tile boundaries too, so only a workgroup's first two steps ever wait for HBM with nothing to do.
+// The loads are `buffer_load_dwordx4 ... lds`: global memory to LDS without a register in between and without a ds_write (gfx950
+// moves 16 bytes per lane that way).  A step is eight half-rounds of 8 MFMAs, and everything else it has to do is dealt out
+// BETWEEN them, in the shadow of the MFMA just issued:
+//   even half-rounds   read the next round's fragments (one 16-byte read per lane and row block) into the second register set
+//   half-round 4       wait for this wave's loads of step s + 1, then the step's one barrier: the other buffer is complete for
+//                      everyone, and this one has no reader left (its last fragment reads were issued at the start of the
+//                      half-round)
+//   half-rounds 5, 6   issue the loads of step s + 2 into this buffer; read round 0's fragments of step s + 1 from the other
+// What this replaced (r1-r2: loads into registers, 64 MFMAs, stash, two barriers per step) left every wave standing between a
 // barrier and its first MFMA once per step, and the two waves of a SIMD fell into step with each other instead of covering for
-// one another: 0.79 of the fp32-matrix peak where the same loop without its loads ran at 0.89 and without anything but MFMAs at
-// 0.94 (profiles/r03_dense_variants.md).
+// one another: 0.79 of the fp32-matrix peak where the same loop without its loads ran at 0.89 and with nothing but MFMAs at
+// 0.94; the same pipeline with the tiles staged through registers (ds_write_b128 into padded rows) reached 0.87
+// (profiles/r03_dense_variants.md has every step of that).
 // Tile order: workgroup b runs on XCD b % 8; every XCD gets a contiguous range of the tn-major tile order and its workgroups
 // take consecutive tiles of it, so the tiles_m workgroups sharing a B tile run on ONE XCD at about the same time and its L2
-// serves all but the first read.  Loads are branch-free buffer loads: the descriptor of a tile starts at its first row and ends
-// with its last one that exists, so rows past the end read as zeros, and so does a k past the end (offset pushed out of range).
-constexpr int DENSE_WGS_PER_CU = 2;  // 72 KB of LDS each
+// serves all but the first read.  Loads are branch-free: the descriptor of a tile starts at its first row and ends with its
+// last one that exists, so rows past the end land as zeros, and so does a k past the end (offset pushed out of range).
+constexpr int DENSE_WGS_PER_CU = 2;  // 67 KB of LDS each
 
 template <int METRIC, bool FUSED = false>
-__global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, const float *B, uint32_t nb, uint32_t stride /* floats per row */,
+__global__ void __launch_bounds__(256, 2) k_dense_f32(const float *Q, uint32_t nq, const float *B, uint32_t nb, uint32_t stride /* floats per row */,
                                                    const float *qn, const float *bn, float *out, uint32_t ldo, DenseTopk tk)
 {
-    __shared__ float As2[ 2 ][ BM * LDK ];
-    __shared__ float Bs2[ 2 ][ BN * LDK ];
+    // two buffers of a 128 x 32 slab per matrix, rows unpadded (128 B), filled by buffer loads that write LDS directly: a load
+    // instruction of a wave lands as 1 KB of consecutive 16-byte units (lane i -> unit i), i.e. 8 rows; WHICH k-quad of its row
+    // a lane fetches is the lane's choice, and it picks quad (i & 7) ^ ((row >> 1) & 7) -- an XOR swizzle that makes the
+    // 16-byte fragment reads of 16 consecutive rows hit 16 different bank groups.
+    __shared__ float A_0[ BM * BK ], A_1[ BM * BK ], B_0[ BN * BK ], B_1[ BN * BK ];
     __shared__ float Ns[ 2 ][ 3 * 128 ];  // per tile parity: 128 query norms, 128 base norms (cosine: inverse roots), 128 query radii
     const int        tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int        wm = wave >> 1, wn = wave & 1;
@@ -118,41 +117,52 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
     };
     zero_acc();
 
-    // ---- the load side of the pipeline: (tile li, k position lk), two steps ahead of the MFMAs
-    float4                 pa4[ 4 ], pb4[ 4 ];
-    const int              kq = (tid & 7) * 4, r0 = tid >> 3;  // this thread's float4 of rows r0 + 32 it
-    const uint32_t         voff = ((uint32_t)r0 * stride + (uint32_t)kq) * 4u, vstep = 32u * stride * 4u;
+    // ---- the load side of the pipeline: (tile li, k position lk), up to two steps ahead of the MFMAs
+    const int      wu = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t kq = (((uint32_t)lane & 7u) ^ (((uint32_t)wu * 4u + ((uint32_t)lane >> 4)) & 7u)) * 4u;  // the k-quad this lane fetches
+    const uint32_t voff = ((uint32_t)(wu * 8 + (lane >> 3)) * stride + kq) * 4u, vstep = 32u * stride * 4u;
     uint32_t               li = 0, lk = 0;
-    __amdgpu_buffer_rsrc_t rq, rb;
-    auto                   set_load_tile = [&](uint32_t i) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rq, rb;  // buffer descriptors as words: base, base_hi (stride 0), bytes, flags
+    auto  make_desc = [](const float *base, uint32_t bytes) {
+        const uint64_t a = (uint64_t)(uintptr_t)base;
+        u32x4          d;
+        d.x = (uint32_t)a;
+        d.y = (uint32_t)(a >> 32) & 0xFFFFu;
+        d.z = bytes;
+        d.w = 0x00020000u;
+        return d;
+    };
+    auto set_load_tile = [&](uint32_t i) {
         if(i < my_n) {
             uint32_t q0, c0;
             tile_origin(i, q0, c0);
             const uint32_t rows_q = nq - q0 < (uint32_t)BM ? nq - q0 : (uint32_t)BM, rows_b = nb - c0 < (uint32_t)BN ? nb - c0 : (uint32_t)BN;
-            rq = __builtin_amdgcn_make_buffer_rsrc((void *)(Q + (size_t)q0 * stride), 0, (int)(rows_q * stride * 4u), 0x00020000);
-            rb = __builtin_amdgcn_make_buffer_rsrc((void *)(B + (size_t)c0 * stride), 0, (int)(rows_b * stride * 4u), 0x00020000);
+            rq = make_desc(Q + (size_t)q0 * stride, rows_q * stride * 4u);
+            rb = make_desc(B + (size_t)c0 * stride, rows_b * stride * 4u);
         } else {  // past this workgroup's last tile: empty descriptors, every load returns zeros
-            rq = __builtin_amdgcn_make_buffer_rsrc((void *)Q, 0, 0, 0x00020000);
-            rb = __builtin_amdgcn_make_buffer_rsrc((void *)B, 0, 0, 0x00020000);
+            rq = make_desc(Q, 0);
+            rb = make_desc(B, 0);
         }
     };
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    auto fetch1 = [&](int it) {
-        const uint32_t off = lk + (uint32_t)kq < stride ? voff + (uint32_t)it * vstep + lk * 4u : 0x80000000u;
-        const u32x4    a = __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0);
-        pa4[ it ] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
-        pb4[ it ] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+    // rows 8 (4 it + wave) .. + 8 of step (li, lk), 16 bytes per lane, straight into LDS.  Inline assembly, because the
+    // compiler's own bookkeeping of such loads makes EVERY later LDS read wait for all of them (it cannot tell the two
+    // buffers apart once there are more than a few load instructions); the wait that is needed -- all of a step's loads, before
+    // the barrier that precedes their first read -- is dma_wait() below.  (M0, the LDS base of such a load, is written and used
+    // inside one statement; nothing else in this file's kernels touches it.)
+    auto lds_addr = [](const float *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)p; };
+    auto dma1 = [&](int it, const float *Ap, const float *Bp) {
+        const uint32_t off = lk + kq < stride ? voff + (uint32_t)it * vstep + lk * 4u : 0x80000000u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr(Ap + (it * 4 + wu) * 256)), "v"(off), "s"(rq) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr(Bp + (it * 4 + wu) * 256)), "v"(off), "s"(rb) : "memory");
     };
+    auto dma_wait = []() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); };
     auto advance = [&]() {
         lk += BK;
         if(lk >= stride) {
             lk = 0;
             set_load_tile(++li);
         }
-    };
-    auto stash1 = [&](int it, uint32_t buf) {
-        *(float4 *)(As2[ buf ] + (r0 + 32 * it) * LDK + kq) = pa4[ it ];
-        *(float4 *)(Bs2[ buf ] + (r0 + 32 * it) * LDK + kq) = pb4[ it ];
     };
     // ---- a tile's norms and radii: loaded a tile ahead into two registers, written to LDS in the tile's first step
     float    nreg = 0.f;
@@ -173,70 +183,36 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
         Ns[ par ][ tid ] = nv;
         if(FUSED && tid < BM) Ns[ par ][ 256 + tid ] = rreg == 0xFFFFFFFFu ? __builtin_inff() : ord2f(rreg);  // (rows past nq: ord2f(0) = NaN, nothing passes)
     };
-    // ---- fragments: {4 j + 2 h, 4 j + 2 h + 1} (h = lane / 32) of a 4-wide k group go to the two MFMAs of a pair -- a
-    // permutation of the contraction index, which a dot product does not notice
-    const int fo = (lane & 31) * LDK + 2 * (lane >> 5);
-    float2    fa[ 2 ][ 4 ], fb[ 2 ][ 4 ];  // [fragment set][{row block 0, row block 1} x {kk, kk + 4}]
-    auto      frag = [&](int set, uint32_t buf, int kk) {
-        const float *a0 = As2[ buf ] + wm * 64 * LDK + fo + kk, *b0 = Bs2[ buf ] + wn * 64 * LDK + fo + kk;
-        fa[ set ][ 0 ] = *(const float2 *)(a0);
-        fa[ set ][ 1 ] = *(const float2 *)(a0 + 4);
-        fa[ set ][ 2 ] = *(const float2 *)(a0 + 32 * LDK);
-        fa[ set ][ 3 ] = *(const float2 *)(a0 + 32 * LDK + 4);
-        fb[ set ][ 0 ] = *(const float2 *)(b0);
-        fb[ set ][ 1 ] = *(const float2 *)(b0 + 4);
-        fb[ set ][ 2 ] = *(const float2 *)(b0 + 32 * LDK);
-        fb[ set ][ 3 ] = *(const float2 *)(b0 + 32 * LDK + 4);
+    // ---- fragments: one 16-byte read per lane, row block and round j: half h = lane / 32 reads k-quad 2 j + h of its row, and
+    // MFMA e (0..3) of the round contracts the pair {8 j + e, 8 j + 4 + e} -- a permutation of the contraction index, which a
+    // dot product does not notice
+    uint32_t foff[ 4 ];
+#pragma unroll
+    for(int jq = 0; jq < 4; ++jq) foff[ jq ] = (((uint32_t)(2 * jq) + ((uint32_t)lane >> 5)) ^ (((uint32_t)lane >> 1) & 7u)) * 4u;
+    const uint32_t rowa = (uint32_t)(wm * 64 + (lane & 31)) * BK, rowb = (uint32_t)(wn * 64 + (lane & 31)) * BK;
+    float4         fa[ 2 ][ 2 ], fb[ 2 ][ 2 ];  // [fragment set][row block]
+    auto           frag = [&](int set, const float *Ap, const float *Bp, int jq) {
+        fa[ set ][ 0 ] = *(const float4 *)(Ap + rowa + foff[ jq ]);
+        fa[ set ][ 1 ] = *(const float4 *)(Ap + rowa + 32 * BK + foff[ jq ]);
+        fb[ set ][ 0 ] = *(const float4 *)(Bp + rowb + foff[ jq ]);
+        fb[ set ][ 1 ] = *(const float4 *)(Bp + rowb + 32 * BK + foff[ jq ]);
     };
-    auto mfma8 = [&](int set, int h) {
-        const float2 av0 = fa[ set ][ h ], av1 = fa[ set ][ 2 + h ], bv0 = fb[ set ][ h ], bv1 = fb[ set ][ 2 + h ];
-        acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bv0.x, acc[ 0 ][ 0 ], 0, 0, 0);
-        acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bv1.x, acc[ 0 ][ 1 ], 0, 0, 0);
-        acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bv0.x, acc[ 1 ][ 0 ], 0, 0, 0);
-        acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bv1.x, acc[ 1 ][ 1 ], 0, 0, 0);
-        acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bv0.y, acc[ 0 ][ 0 ], 0, 0, 0);
-        acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bv1.y, acc[ 0 ][ 1 ], 0, 0, 0);
-        acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bv0.y, acc[ 1 ][ 0 ], 0, 0, 0);
-        acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bv1.y, acc[ 1 ][ 1 ], 0, 0, 0);
+    auto mfma4 = [&](float a0, float a1, float b0, float b1) {
+        acc[ 0 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[ 0 ][ 0 ], 0, 0, 0);
+        acc[ 0 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[ 0 ][ 1 ], 0, 0, 0);
+        acc[ 1 ][ 0 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[ 1 ][ 0 ], 0, 0, 0);
+        acc[ 1 ][ 1 ] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[ 1 ][ 1 ], 0, 0, 0);
     };
-
-    // ---- fill the pipeline: step 0 into LDS buffer 0, step 1 into the registers
-    set_load_tile(0);
-    load_norms(0);
-#pragma unroll
-    for(int it = 0; it < 4; ++it) fetch1(it);
-    advance();
-#pragma unroll
-    for(int it = 0; it < 4; ++it) stash1(it, 0);
-#pragma unroll
-    for(int it = 0; it < 4; ++it) fetch1(it);
-    advance();
-    __syncthreads();
-    frag(0, 0, 0);
-    const uint32_t KS = (stride + BK - 1) / BK;
-    uint32_t       cur = 0;
-    for(uint32_t ti = 0; ti < my_n; ++ti) {
-        for(uint32_t ks = 0; ks < KS; ++ks, cur ^= 1) {
-            if(ks == 0) {
-                store_norms(ti & 1);
-                if(ti + 1 < my_n) load_norms(ti + 1);
-            }
-#pragma unroll
-            for(int h = 0; h < 8; ++h) {
-                const int r = h >> 1;
-                if((h & 1) == 0 && r < 3) frag((r + 1) & 1, cur, (r + 1) * 8);
-                if(h == 6) frag(0, cur ^ 1, 0);
-                __builtin_amdgcn_sched_barrier(0);  // (the compiler would sink the reads back to their use to save 16 registers)
-                mfma8(r & 1, h & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if(h < 4) {
-                    stash1(h, cur ^ 1);
-                    fetch1(h);
-                }
-                if(h == 3) advance();
-                if(h == 4) __syncthreads();
-            }
+    auto mfma8 = [&](int set, int h) {  // h = 0: e = 0, 1;  h = 1: e = 2, 3
+        if(h == 0) {
+            mfma4(fa[ set ][ 0 ].x, fa[ set ][ 1 ].x, fb[ set ][ 0 ].x, fb[ set ][ 1 ].x);
+            mfma4(fa[ set ][ 0 ].y, fa[ set ][ 1 ].y, fb[ set ][ 0 ].y, fb[ set ][ 1 ].y);
+        } else {
+            mfma4(fa[ set ][ 0 ].z, fa[ set ][ 1 ].z, fb[ set ][ 0 ].z, fb[ set ][ 1 ].z);
+            mfma4(fa[ set ][ 0 ].w, fa[ set ][ 1 ].w, fb[ set ][ 0 ].w, fb[ set ][ 1 ].w);
         }
+    };
+    auto epilogue = [&](uint32_t ti) {
         // ---- the tile's epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
         // Its norms and radii are in Ns[ti & 1] since the barrier of its first step; the next tile's first step is already in
         // the other LDS buffer and its fragments in registers, so the MFMAs resume right after.
@@ -294,8 +270,77 @@ __global__ void __launch_bounds__(256) k_dense_f32(const float *Q, uint32_t nq, 
                     }
                 }
             }
-        zero_acc();
+    };
+    // ---- fill the pipeline: steps 0 and 1 into the two LDS buffers
+    set_load_tile(0);
+    load_norms(0);
+#pragma unroll
+    for(int it = 0; it < 4; ++it) dma1(it, A_0, B_0);
+    advance();
+#pragma unroll
+    for(int it = 0; it < 4; ++it) dma1(it, A_1, B_1);
+    advance();
+    dma_wait();
+    __syncthreads();
+    frag(0, A_0, B_0, 0);
+    const uint32_t KS = (stride + BK - 1) / BK;
+    uint32_t       ti = 0, ks = 0;
+    // One step on buffer P.  Its barrier sits after half-round 4: by then every wave has read the last fragments of this buffer
+    // (so it can be refilled, with step s + 2, from half-round 5 on) and the loads of step s + 1 into the other buffer --
+    // issued a step ago -- are waited for (so its first fragments can be read in half-round 6).
+#define LGPU_FENCE __builtin_amdgcn_sched_barrier(0)
+#define LGPU_DENSE_STEP(P)                                                          \
+    {                                                                               \
+        float *const Ap = (P) ? A_1 : A_0, *const Bp = (P) ? B_1 : B_0;             \
+        float *const Ao = (P) ? A_0 : A_1, *const Bo = (P) ? B_0 : B_1;             \
+        frag(1, Ap, Bp, 1);                                                         \
+        LGPU_FENCE;                                                                 \
+        mfma8(0, 0);                                                                \
+        mfma8(0, 1);                                                                \
+        LGPU_FENCE;                                                                 \
+        frag(0, Ap, Bp, 2);                                                         \
+        LGPU_FENCE;                                                                 \
+        mfma8(1, 0);                                                                \
+        mfma8(1, 1);                                                                \
+        LGPU_FENCE;                                                                 \
+        frag(1, Ap, Bp, 3);                                                         \
+        LGPU_FENCE;                                                                 \
+        mfma8(0, 0);                                                                \
+        LGPU_FENCE;                                                                 \
+        dma_wait();                                                                 \
+        __syncthreads();                                                            \
+        if(ks == 0) { /* (behind the wait for the loads: the norms' own load is long done) */ \
+            store_norms(ti & 1);                                                    \
+            if(ti + 1 < my_n) load_norms(ti + 1);                                   \
+        }                                                                           \
+        mfma8(0, 1);                                                                \
+        LGPU_FENCE;                                                                 \
+        dma1(0, Ap, Bp);                                                            \
+        dma1(1, Ap, Bp);                                                            \
+        frag(0, Ao, Bo, 0);                                                         \
+        LGPU_FENCE;                                                                 \
+        mfma8(1, 0);                                                                \
+        LGPU_FENCE;                                                                 \
+        dma1(2, Ap, Bp);                                                            \
+        dma1(3, Ap, Bp);                                                            \
+        advance();                                                                  \
+        LGPU_FENCE;                                                                 \
+        mfma8(1, 1);                                                                \
+        LGPU_FENCE;                                                                 \
+        if(++ks == KS) {                                                            \
+            if(KS == 1) __syncthreads(); /* the norms were written after this step's only barrier */ \
+            epilogue(ti);                                                           \
+            zero_acc();                                                             \
+            ks = 0;                                                                 \
+            if(++ti == my_n) break;                                                 \
+        }                                                                           \
     }
+    for(;;) {
+        LGPU_DENSE_STEP(0)
+        LGPU_DENSE_STEP(1)
+    }
+#undef LGPU_DENSE_STEP
+#undef LGPU_FENCE
 }
 
 // hamming (COSB1: the cosine of the {0, 1} vectors, device_common.hpp M_COS_B1): 16 queries in LDS per workgroup, one base row per thread

@@ -325,10 +325,13 @@ def test_exact_search_survives_adversarially_ordered_rows(capi):
         assert set(slots[qi].tolist()) == set(order.tolist())
 
 
-@pytest.mark.parametrize("metric,d", [("l2sq", 768), ("cos", 768), ("l2sq", 50), ("cos", 1536)])
-def test_mfma_distance_matrix_within_tolerance(capi, oracle, metric, d):
+# (na, nb): ragged last tiles; 300 x 40000 = 939 tiles on the kernel's persistent grid of 512 workgroups (two tiles per workgroup, the
+# K steps of both in one pipeline); d = 36 / 50: a K tail; d = 7, 20: a single K step per tile; 1 x 1: one workgroup, one row each
+@pytest.mark.parametrize("metric,d,na,nb", [("l2sq", 768, 130, 257), ("cos", 768, 130, 257), ("l2sq", 50, 130, 257), ("cos", 1536, 130, 257),
+                                            ("cos", 36, 300, 40000), ("l2sq", 20, 129, 70000), ("l2sq", 7, 8, 6), ("cos", 33, 257, 130)])
+def test_mfma_distance_matrix_within_tolerance(capi, oracle, metric, d, na, nb):
     rng = np.random.default_rng(d)
-    A, B = rng.standard_normal((130, d), dtype=np.float32), rng.standard_normal((257, d), dtype=np.float32)
+    A, B = rng.standard_normal((na, d), dtype=np.float32), rng.standard_normal((nb, d), dtype=np.float32)
     A[3] = 0  # zero-norm rows exercise the cosine rules in the epilogue
     B[5] = 0
     got = capi.distance_matrix(A, B, metric, exact_order=False)
