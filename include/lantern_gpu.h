@@ -203,6 +203,14 @@ LANTERN_GPU_EXPORT void lantern_gpu_flush(usearch_index_t, usearch_error_t *);
  * failure (callers fall back to ordinary memory). */
 LANTERN_GPU_EXPORT void *lantern_gpu_host_alloc(size_t bytes);
 LANTERN_GPU_EXPORT void  lantern_gpu_host_free(void *);
+/* usearch_save_buffer without the buffer: the index file (the bytes usearch_save_buffer would produce) handed to `write` as a
+ * sequence of spans, up to 1024 per call, in file order -- header, then per node its formatted prefix and its vector bytes
+ * straight out of a page-locked staging buffer that the rows reach in ~64 MB chunks, the next chunk's copy overlapping this
+ * one's consumption.  A span is layout-compatible with struct iovec: the indexing server passes them to writev(2)
+ * (server.rs:388-422 sends the file it has just written to disk).  `write` returns 0 to go on, anything else aborts. */
+typedef struct lantern_gpu_span { const void *data; size_t size; } lantern_gpu_span;
+typedef int (*lantern_gpu_write_fn)(void *ctx, const lantern_gpu_span *spans, size_t count);
+LANTERN_GPU_EXPORT void lantern_gpu_save_stream(usearch_index_t, lantern_gpu_write_fn write, void *ctx, usearch_error_t *);
 /* usearch_add with a caller-drawn level (insert.c:32-46); usearch_add_external is this plus the write-back to the pages */
 LANTERN_GPU_EXPORT void lantern_gpu_add_with_level(usearch_index_t, usearch_label_t, const void *vector,
                                                    usearch_scalar_kind_t, int level, usearch_error_t *);

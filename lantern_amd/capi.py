@@ -87,7 +87,7 @@ EXPORTS = [
     "lantern_gpu_set_seed", "lantern_gpu_set_add_batch", "lantern_gpu_add_many", "lantern_gpu_flush",
     "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device",
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
-    "lantern_gpu_host_alloc", "lantern_gpu_host_free", "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile",
+    "lantern_gpu_host_alloc", "lantern_gpu_host_free", "lantern_gpu_save_stream", "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile",
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_export_codes",
     "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_gpu_search_phase_profile", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
@@ -171,6 +171,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_exact_search": (None, [vp, vp, sz, sz, vp, vp, err]),
         "lantern_gpu_distance_gather": (None, [vp, vp, vp, sz, vp, err]),
         "lantern_gpu_spec_profile": (None, [vp, i32, vp, err]),
+        "lantern_gpu_save_stream": (None, [vp, vp, vp, err]),
         "lantern_gpu_pq_compact": (None, [vp, err]),
         "lantern_gpu_pq_expand": (None, [vp, err]),
         "lantern_gpu_memory_usage": (None, [vp, C.POINTER(sz), C.POINTER(sz), err]),
@@ -603,6 +604,22 @@ class GpuIndex:
         buf = (C.c_char * n)()
         _call("usearch_save_buffer", self.h, C.cast(buf, C.c_void_p), n)
         return bytes(buf)
+
+    def save_stream(self) -> bytes:
+        """lantern_gpu_save_stream: the file as the spans the callback is handed, joined (the bytes of save_buffer())."""
+        class Span(C.Structure):
+            _fields_ = [("data", C.c_void_p), ("size", C.c_size_t)]
+
+        parts = []
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Span), C.c_size_t)
+        def write(_ctx, spans, count):
+            for i in range(count):
+                parts.append(C.string_at(spans[i].data, spans[i].size))
+            return 0
+
+        _call("lantern_gpu_save_stream", self.h, C.cast(write, C.c_void_p), None)
+        return b"".join(parts)
 
     def load_buffer(self, data: bytes):
         buf = C.create_string_buffer(data, len(data))

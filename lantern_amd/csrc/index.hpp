@@ -7,6 +7,7 @@
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
+#include <functional>
 #include <vector>
 
 #include "../../include/lantern_gpu.h"
@@ -194,6 +195,8 @@ bool        import_graph_locked(Index *ix, size_t size, const void *vectors, con
 // usearch-format serialisation (usearch_file.cpp)
 size_t serialized_length(Index *ix);
 bool   serialize(Index *ix, char *buf, size_t len);
+using SpanSink = std::function<bool(const lantern_gpu_span *, size_t)>;
+bool   serialize_stream(Index *ix, const SpanSink &sink);  // the same bytes as a sequence of spans (rows staged in chunks)
 bool   deserialize(Index *ix, const char *buf, size_t len);
 
 }  // namespace lgpu

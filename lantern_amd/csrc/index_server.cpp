@@ -18,12 +18,14 @@
 #include <netinet/tcp.h>
 #include <sys/socket.h>
 #include <sys/time.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -75,6 +77,36 @@ void write_all(int fd, const void *buf, size_t n)
         p += w;
         n -= (size_t)w;
     }
+}
+// gather-write of lantern_gpu_save_stream's spans: sendmsg (writev with MSG_NOSIGNAL), resumed after partial writes
+static_assert(sizeof(lantern_gpu_span) == sizeof(struct iovec) && offsetof(lantern_gpu_span, data) == offsetof(struct iovec, iov_base) &&
+                  offsetof(lantern_gpu_span, size) == offsetof(struct iovec, iov_len),
+              "lantern_gpu_span must be layout-compatible with struct iovec");
+int send_spans(void *ctx, const lantern_gpu_span *spans, size_t count)
+{
+    const int    fd = *(const int *)ctx;
+    struct iovec iov[ 1024 ];
+    while(count) {
+        const size_t m = std::min<size_t>(count, 1024);
+        std::memcpy(iov, spans, m * sizeof(struct iovec));
+        size_t first = 0;
+        while(first < m) {
+            struct msghdr mh;
+            std::memset(&mh, 0, sizeof(mh));
+            mh.msg_iov = iov + first;
+            mh.msg_iovlen = m - first;
+            ssize_t w = ::sendmsg(fd, &mh, MSG_NOSIGNAL);
+            if(w <= 0) return -1;
+            while(first < m && (size_t)w >= iov[ first ].iov_len) w -= (ssize_t)iov[ first++ ].iov_len;
+            if(first < m && w > 0) {
+                iov[ first ].iov_base = (char *)iov[ first ].iov_base + w;
+                iov[ first ].iov_len -= (size_t)w;
+            }
+        }
+        spans += m;
+        count -= m;
+    }
+    return 0;
 }
 void read_exact(int fd, void *buf, size_t n)
 {
@@ -318,12 +350,13 @@ void serve(lantern_index_server *srv, int fd)
         write_all(fd, &count, 8);
         const size_t len = usearch_serialized_length(index, &err);
         if(err) throw Fail{ err };
-        std::vector<char> file(len);
-        usearch_save_buffer(index, file.data(), len, &err);
-        if(err) throw Fail{ err };
         const uint64_t len64 = len;
         write_all(fd, &len64, 8);
-        write_all(fd, file.data(), len);
+        // the file goes out as it is formatted: node prefixes + vector bytes from page-locked row chunks, gathered by sendmsg
+        // (r2 built the whole 6.4 GB file in memory first: 5 of the 9 s of a 1M x 1536 build)
+        int sink_fd = fd;
+        lantern_gpu_save_stream(index, send_spans, &sink_fd, &err);
+        if(err) throw Fail{ err };
         set_status(srv, SUCCEEDED);
     } catch(const Fail &f) {
         failure = f.msg;

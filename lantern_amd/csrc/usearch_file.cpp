@@ -40,6 +40,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <unordered_map>
 #include <vector>
 
@@ -125,46 +126,101 @@ static void write_header(const Index *ix, char *h)
     put<uint64_t>(h, OFF_G_ENTRY_SLOT, ix->n ? (uint64_t)ix->entry : 0);
 }
 
+// The file as a stream of spans: header, then per node a formatted prefix (label, level, neighbour lists) and its vector bytes
+// straight out of a page-locked staging buffer.  Rows leave the device in chunks of ~64 MB on a stream of their own, two buffers
+// deep, so the copy of chunk c + 1 runs while chunk c is formatted and consumed; nothing the size of the index is ever
+// allocated on the host (the r2 form built a pageable copy of all rows and then the whole file in memory: 5 of the 9 seconds
+// of a 1M x 1536 build through the indexing server).  `sink` gets up to 1024 spans per call and returns false to abort.
+bool serialize_stream(Index *ix, const SpanSink &sink)
+{
+    char header[ USEARCH_HEADER_SIZE ];
+    write_header(ix, header);
+    {
+        const lantern_gpu_span h = { header, USEARCH_HEADER_SIZE };
+        if(!sink(&h, 1)) { set_err(ix, "lantern_gpu: the serialisation sink failed"); return false; }
+    }
+    const size_t n = ix->n;
+    if(n == 0) return true;
+    const size_t row = (size_t)ix->chunks * 16, vb = vector_bytes(ix);
+    const size_t row_stride = ix->pq ? (size_t)ix->pq_S : row;
+    const char  *d_rows = ix->pq ? (const char *)ix->d_codes : (const char *)ix->d_vec;
+    std::vector<uint32_t> nbr0(n * ix->M0), upper(ix->upper_blocks * ix->M + 1);
+    bool ok = hipMemcpy(nbr0.data(), ix->d_nbr0, nbr0.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(ix->upper_blocks) ok = ok && hipMemcpy(upper.data(), ix->d_upper_nbr, ix->upper_blocks * ix->M * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if(!ok) { set_err(ix, "lantern_gpu: HIP failure while serialising"); return false; }
+
+    const size_t per = std::min(n, std::max<size_t>(256, ((size_t)64 << 20) / std::max<size_t>(row_stride, 1)));
+    const size_t max_prefix = 8 + 2 + (4 + (size_t)ix->M0 * LANTERN_SLOT_SIZE) + (size_t)255 * (4 + (size_t)ix->M * LANTERN_SLOT_SIZE);
+    char        *stage[ 2 ] = { nullptr, nullptr };
+    hipStream_t  st = nullptr;
+    hipEvent_t   ev[ 2 ] = { nullptr, nullptr };
+    std::vector<char>             prefix;
+    std::vector<lantern_gpu_span> spans;
+    const char                   *fail = nullptr;
+    ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    for(int b = 0; ok && b < 2; ++b)
+        ok = hipHostMalloc((void **)&stage[ b ], per * row_stride, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[ b ], hipEventDisableTiming) == hipSuccess;
+    auto issue = [&](size_t c) {  // chunk c -> stage[c & 1]
+        const size_t i0 = c * per, cnt = std::min(per, n - i0);
+        return hipMemcpyAsync(stage[ c & 1 ], d_rows + i0 * row_stride, cnt * row_stride, hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipEventRecord(ev[ c & 1 ], st) == hipSuccess;
+    };
+    const size_t nchunks = (n + per - 1) / per;
+    if(!ok || !issue(0)) fail = "lantern_gpu: HIP failure while serialising";
+    for(size_t c = 0; !fail && c < nchunks; ++c) {
+        if(c + 1 < nchunks && !issue(c + 1)) { fail = "lantern_gpu: HIP failure while serialising"; break; }  // (its buffer was consumed with chunk c - 1)
+        const size_t i0 = c * per, cnt = std::min(per, n - i0);
+        // prefixes of the chunk's nodes while its rows are still on their way
+        size_t need = 0;
+        for(size_t i = i0; i < i0 + cnt; ++i) need += node_bytes(ix, ix->levels[ i ]) - vb;
+        if(need > cnt * max_prefix) { fail = "lantern_gpu: node level out of range while serialising"; break; }
+        prefix.assign(need, 0);
+        spans.resize(cnt * 2);
+        char *p = prefix.data();
+        for(size_t i = i0; i < i0 + cnt; ++i) {
+            const int level = ix->levels[ i ];
+            char     *q = p + 10;
+            put<uint64_t>(p, 0, ix->labels[ i ]);
+            put<uint16_t>(p, 8, (uint16_t)level);
+            for(int l = 0; l <= level; ++l) {
+                const uint32_t  cap = l == 0 ? ix->M0 : ix->M;
+                const uint32_t *list = l == 0 ? &nbr0[ i * ix->M0 ] : &upper[ ((size_t)ix->upper_off[ i ] + (size_t)(l - 1)) * ix->M ];
+                uint32_t        k = 0;
+                while(k < cap && list[ k ] != EMPTY) ++k;
+                put<uint32_t>(q, 0, k);
+                for(uint32_t j = 0; j < k; ++j) put<uint32_t>(q, 4 + (size_t)j * LANTERN_SLOT_SIZE, list[ j ]);  // low 4 of 6 bytes
+                q += 4 + (size_t)cap * LANTERN_SLOT_SIZE;
+            }
+            spans[ (i - i0) * 2 ] = { p, (size_t)(q - p) };
+            spans[ (i - i0) * 2 + 1 ] = { stage[ c & 1 ] + (i - i0) * row_stride, vb };
+            p = q;
+        }
+        if(hipEventSynchronize(ev[ c & 1 ]) != hipSuccess) { fail = "lantern_gpu: HIP failure while serialising"; break; }
+        for(size_t o = 0; o < spans.size() && !fail; o += 1024)
+            if(!sink(&spans[ o ], std::min<size_t>(1024, spans.size() - o))) fail = "lantern_gpu: the serialisation sink failed";
+    }
+    if(st) (void)hipStreamSynchronize(st);  // (an aborted run may still have a copy in flight into a buffer about to be freed)
+    for(int b = 0; b < 2; ++b) {
+        if(ev[ b ]) (void)hipEventDestroy(ev[ b ]);
+        if(stage[ b ]) (void)hipHostFree(stage[ b ]);
+    }
+    if(st) (void)hipStreamDestroy(st);
+    if(fail) { set_err(ix, fail); return false; }
+    return true;
+}
+
 bool serialize(Index *ix, char *buf, size_t len)
 {
     const size_t need = serialized_length(ix);
     if(len < need) { set_err(ix, "lantern_gpu: serialisation buffer too small"); return false; }
-    write_header(ix, buf);
-    const size_t n = ix->n;
-    if(n == 0) return true;
-    const size_t row = (size_t)ix->chunks * 16, vb = vector_bytes(ix);
-    std::vector<uint32_t> nbr0(n * ix->M0), upper(ix->upper_blocks * ix->M + 1);
-    std::vector<char>     rows(n * row);
-    bool ok = hipMemcpy(nbr0.data(), ix->d_nbr0, nbr0.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
-    if(ix->upper_blocks) ok = ok && hipMemcpy(upper.data(), ix->d_upper_nbr, ix->upper_blocks * ix->M * 4, hipMemcpyDeviceToHost) == hipSuccess;
-    size_t row_stride = row;
-    if(ix->pq) {  // the tape carries the codes
-        row_stride = ix->pq_S;
-        ok = ok && hipMemcpy(rows.data(), ix->d_codes, n * row_stride, hipMemcpyDeviceToHost) == hipSuccess;
-    } else {
-        ok = ok && hipMemcpy(rows.data(), ix->d_vec, rows.size(), hipMemcpyDeviceToHost) == hipSuccess;
-    }
-    if(!ok) { set_err(ix, "lantern_gpu: HIP failure while serialising"); return false; }
-    char *p = buf + USEARCH_HEADER_SIZE;
-    for(size_t i = 0; i < n; ++i) {
-        const int level = ix->levels[ i ];
-        std::memset(p, 0, node_bytes(ix, level));
-        put<uint64_t>(p, 0, ix->labels[ i ]);
-        put<uint16_t>(p, 8, (uint16_t)level);
-        char *q = p + 10;
-        for(int l = 0; l <= level; ++l) {
-            const uint32_t  cap = l == 0 ? ix->M0 : ix->M;
-            const uint32_t *list = l == 0 ? &nbr0[ i * ix->M0 ] : &upper[ ((size_t)ix->upper_off[ i ] + (size_t)(l - 1)) * ix->M ];
-            uint32_t        cnt = 0;
-            while(cnt < cap && list[ cnt ] != EMPTY) ++cnt;
-            put<uint32_t>(q, 0, cnt);
-            for(uint32_t j = 0; j < cnt; ++j) put<uint32_t>(q, 4 + (size_t)j * LANTERN_SLOT_SIZE, list[ j ]);  // low 4 of 6 bytes
-            q += 4 + (size_t)cap * LANTERN_SLOT_SIZE;
+    char *p = buf;
+    return serialize_stream(ix, [&](const lantern_gpu_span *sp, size_t cnt) {
+        for(size_t i = 0; i < cnt; ++i) {
+            std::memcpy(p, sp[ i ].data, sp[ i ].size);
+            p += sp[ i ].size;
         }
-        std::memcpy(q, &rows[ i * row_stride ], vb);
-        p += node_bytes(ix, level);
-    }
-    return true;
+        return true;
+    });
 }
 
 bool deserialize(Index *ix, const char *buf, size_t len)
@@ -498,15 +554,29 @@ void usearch_save(usearch_index_t h, const char *path, usearch_error_t *e)
     if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) { if(e) *e = ix->err.c_str(); return; }
-    std::vector<char> buf(serialized_length(ix));
-    if(!serialize(ix, buf.data(), buf.size())) { if(e) *e = ix->err.c_str(); return; }
     FILE *f = std::fopen(path, "wb");
-    if(!f || std::fwrite(buf.data(), 1, buf.size(), f) != buf.size()) {
-        if(f) std::fclose(f);
-        if(e) *e = set_err(ix, std::string("lantern_gpu: cannot write index file ") + path);
-        return;
+    if(!f) { if(e) *e = set_err(ix, std::string("lantern_gpu: cannot write index file ") + path); return; }
+    bool wrote = true;
+    const bool ok = serialize_stream(ix, [&](const lantern_gpu_span *sp, size_t cnt) {
+        for(size_t i = 0; i < cnt && wrote; ++i) wrote = std::fwrite(sp[ i ].data, 1, sp[ i ].size, f) == sp[ i ].size;
+        return wrote;
+    });
+    if(std::fclose(f) != 0) wrote = false;
+    if(!wrote) { if(e) *e = set_err(ix, std::string("lantern_gpu: cannot write index file ") + path); return; }
+    if(!ok && e) *e = ix->err.c_str();
+}
+
+void lantern_gpu_save_stream(usearch_index_t h, lantern_gpu_write_fn fn, void *ctx, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    Index *ix = (Index *)h;
+    if(ix) (void)hipSetDevice(ix->device);
+    if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
+    if(!fn) { if(e) *e = "lantern_gpu: null write callback"; return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix) || !serialize_stream(ix, [&](const lantern_gpu_span *sp, size_t cnt) { return fn(ctx, sp, cnt) == 0; })) {
+        if(e) *e = ix->err.c_str();
     }
-    std::fclose(f);
 }
 
 void usearch_load_buffer(usearch_index_t h, const char *buffer, size_t length, usearch_error_t *e)

@@ -249,6 +249,7 @@ def test_file_round_trip(capi, oracle, tmp_path):
         ix = capi.GpuIndex(metric, d, M=4, ef_construction=24, seed=2)
         ix.add_many(np.arange(500) + 1, base)
         blob = ix.save_buffer()
+        assert ix.save_stream() == blob  # the span stream of the indexing server: the same bytes
         g = ix.export_graph()
         # layout: 136-byte header + node tapes: 8+2+(4+2M*6)+level*(4+M*6)+vector (usearch_storage.cpp:19-32)
         vb = d * 4
