@@ -366,7 +366,7 @@ def main():
             try:
                 rec = json.load(open(prof))
                 key = (f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves or 4}" + ("" if a.quant == "f32" else "_" + a.quant)
-                       + ("" if a.data == "gaussian" else "_" + a.data) + (f"_b{B}" if B > 1 else ""))
+                       + ("" if a.data == "gaussian" else "_" + a.data) + (f"_b{B}" if B > 1 else "") + (f"_pq{a.pq_subvectors}" if a.pq_subvectors else ""))
                 hit = rec.get(key, {})
                 traffic = hit.get("hbm_bytes_per_launch")
                 dram = hit.get("dram_bytes_per_launch")
@@ -402,7 +402,8 @@ def main():
             "build_roofline": build_roofline(a, build_counters, build_profile, t_build, world),
             "dist_evals_per_query": float(D.mean()),
             "expansions_per_query": float(E.mean()),
-            "roofline": roofline(achieved, traffic, dram, traffic_src, avg_kernel_s if S == 1 else elapsed / a.steps, bytes_per_launch, avg_kernel_s, S, B),
+            "roofline": roofline(achieved, traffic, dram, traffic_src, avg_kernel_s if S == 1 else elapsed / a.steps, bytes_per_launch, avg_kernel_s, S, B,
+                                 adc=bool(a.pq_subvectors)),
             "cpu_baseline": cpu,
             "pq": pq_info,
             "build_quality": quality,
@@ -412,7 +413,7 @@ def main():
     finish(out)
 
 
-def roofline(achieved, traffic, dram, traffic_src, launch_s, bytes_per_launch, avg_kernel_s, S, B):
+def roofline(achieved, traffic, dram, traffic_src, launch_s, bytes_per_launch, avg_kernel_s, S, B, adc=False):
     """The search kernel against the HBM roofline.  `frac` is the contract's figure: ALGORITHMIC bytes (one row per distance
     evaluation, one adjacency row per expansion, D and E counted on the device) / launch time / the 8 TB/s spec peak.  A walk's
     algorithmic bytes are not all DRAM bytes -- upper levels and hub rows are shared between the queries of a launch and are
@@ -429,6 +430,11 @@ def roofline(achieved, traffic, dram, traffic_src, launch_s, bytes_per_launch, a
          "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_kernel_s * 1e3,
          "query_batches_rotated": B, "note": None}
     notes = []
+    if adc:
+        r["kernel"] = "k_search_adc"
+        notes.append("a compact pq index: a row is its code bytes (1/32 of the f32 row at 96 subvectors), so the HBM fraction says how far "
+                     "this kernel is from being bandwidth-bound, not how good it is: its per-query table (subvectors x 256 f32) takes 98 KB of "
+                     "LDS at 96 subvectors -- one walk per CU -- and what bounds it is the latency of a hop (lantern_amd/csrc/search_adc_kernel.hip)")
     if S > 1:
         notes.append(f"{S} launches in flight: achieved = all launches' algorithmic bytes / the timed region; avg_launch_ms is the mean HIP-event "
                      "duration of launches that overlap")

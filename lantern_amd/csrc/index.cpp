@@ -812,10 +812,24 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         if(ix->search_vis_slots >= 0) vis_slots = (uint32_t)ix->search_vis_slots / 4 * 4;
         while(vis_slots && search_adc_lds_bytes(code_chunks, ix->chunks, (uint32_t)expansion, ix->M0, vis_slots) > 150 * 1024) vis_slots = vis_slots > 256 ? vis_slots - 256 : 0;
         if(vis_slots && vis_slots < 4 * ix->M0) vis_slots = 0;
-        const size_t lds = search_adc_lds_bytes(code_chunks, ix->chunks, (uint32_t)expansion, ix->M0, vis_slots);
+        size_t lds = search_adc_lds_bytes(code_chunks, ix->chunks, (uint32_t)expansion, ix->M0, vis_slots);
         if(lds > 160 * 1024) { set_err(ix, "lantern_gpu: ef/k exceed the 160 KiB LDS budget of the ADC search kernel"); return false; }
-        const int aw = waves > 0 ? std::min(waves, 8) : 8;
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+        int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+        // A table that leaves room for one workgroup per CU anyway (96 subvectors x 256 centroids): every query walks alone on
+        // its CU, so it runs the walk that is fastest alone -- walk_spec.hpp's lone-query shape, 3 role + 8 row waves
+        // (LANTERN_GPU_ADC_SPEC=0|1 overrides; an explicit wave count selects the classic kernel as for the f32 walk).
+        bool adc_spec = false;
+        const uint32_t adc_prefetch = ix->M0 % 4 == 0 && ix->M0 <= 32 ? 1u : 0u, adc_cache = adc_prefetch ? 128u : 0u;  // (8-lane groups: four list words per lane)
+        if(waves <= 0 && ix->M0 >= 2 && ix->M0 <= 64 && expansion <= 128 && !lds_list_env()) {
+            const size_t with_spec = lds + search_spec_lds_bytes(ix->M0, adc_prefetch, adc_cache);
+            const char  *se = std::getenv("LANTERN_GPU_ADC_SPEC");
+            adc_spec = with_spec <= 160 * 1024 && (se ? std::atoi(se) != 0 : per_cu == 1);
+            if(adc_spec) {
+                lds = with_spec;
+                per_cu = 1;
+            }
+        }
+        const int aw = adc_spec ? 11 : waves > 0 ? std::min(waves, 8) : 8;
         size_t     g = (size_t)ix->num_cus * (size_t)per_cu;
         if(ix->search_max_wg > 0) g = (size_t)ix->search_max_wg;
         const int grid = (int)std::max<size_t>(1, std::min(g, nq));
@@ -849,6 +863,9 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         a.adc_C = ix->pq_C;
         a.adc_subdim = ix->pq_subdim;
         a.adc_qchunks = ix->chunks;
+        a.spec = adc_spec ? 2 : 0;
+        a.spec_prefetch = adc_spec ? adc_prefetch : 0;
+        a.spec_cache = adc_spec ? adc_cache : 0;
         HIPCHK(ix, launch_search_adc(ix->metric + M_ADC, a, aw, grid, stream));
         if(done) ix->slot_pending[ slot ] = false;
         else if(!release_search_slot(ix, slot, stream)) return false;

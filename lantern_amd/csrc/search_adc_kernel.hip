@@ -17,15 +17,72 @@
 
 namespace lgpu {
 
-template <int METRIC, int KPL>
-__global__ void __launch_bounds__(512, 2) k_search_adc(SearchArgs a)
+// The per-query table: one thread per (subvector, centroid) entry, one fma chain each.  B entries per thread at a time, their
+// centroid loads issued together: the table of centroids comes from L2 (786 KB per query at 96 x 256 x 8), and one chain per
+// thread at a time left the loads' latency bare -- 35 round trips per query, a third of a query's time at ef = 64.
+template <int METRIC, int B>
+__device__ __forceinline__ void adc_build_table(float *lut, const float *centers, const float *rawq, uint32_t S, uint32_t C, uint32_t subdim, uint32_t sub_floats,
+                                                uint32_t tid, uint32_t T)
+{
+    for(uint32_t e0 = tid; e0 < S * C; e0 += B * T) {
+        const float *cent[ B ], *qs[ B ];
+        float        acc[ B ];
+        bool         on[ B ];
+#pragma unroll
+        for(int u = 0; u < B; ++u) {
+            const uint32_t e = e0 + (uint32_t)u * T;
+            on[ u ] = e < S * C;
+            const uint32_t ee = on[ u ] ? e : 0u, sv = ee / C, c = ee % C;
+            cent[ u ] = centers + ((size_t)sv * C + c) * sub_floats;
+            qs[ u ] = rawq + (size_t)sv * subdim;
+            acc[ u ] = 0.f;
+        }
+        for(uint32_t j4 = 0; j4 < sub_floats; j4 += 4) {
+            float4 cv[ B ];
+#pragma unroll
+            for(int u = 0; u < B; ++u) cv[ u ] = *(const float4 *)(cent[ u ] + j4);  // (rows of the centroid table are padded to whole float4s)
+#pragma unroll
+            for(int u = 0; u < B; ++u) {
+                const float cj[ 4 ] = { cv[ u ].x, cv[ u ].y, cv[ u ].z, cv[ u ].w };
+#pragma unroll
+                for(int jj = 0; jj < 4; ++jj) {
+                    if(j4 + (uint32_t)jj < subdim) {
+                        const float qv = qs[ u ][ j4 + (uint32_t)jj ];
+                        if constexpr(METRIC == M_L2SQ_ADC) {
+                            const float t = qv - cj[ jj ];
+                            acc[ u ] = __builtin_fmaf(t, t, acc[ u ]);
+                        } else {
+                            acc[ u ] = __builtin_fmaf(qv, cj[ jj ], acc[ u ]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for(int u = 0; u < B; ++u) {
+            const uint32_t e = e0 + (uint32_t)u * T;
+            if(on[ u ]) lut[ (size_t)(e / C) * ADC_LUT_STRIDE + e % C ] = acc[ u ];
+        }
+    }
+}
+
+// SPEC: the latency-bound walk of walk_spec.hpp in its lone-query shape (three role waves + eight row waves, one barrier per hop,
+// neighbour lists fetched with the rows).  A table of 96 x 256 entries leaves room for ONE workgroup per CU, so every query of
+// a batch walks alone on its CU whatever the batch size: the walk that is fastest alone is the one to run.
+template <int METRIC, int KPL, bool SPEC = false>
+__global__ void __launch_bounds__(SPEC ? 704 : 512, SPEC ? 1 : 2) k_search_adc(SearchArgs a)
 {
     constexpr int G = 8;  // rows are at most 8 chunks (128 codes)
     const int     tid = threadIdx.x, T = blockDim.x;
     const uint32_t S = a.adc_S, C = a.adc_C, subdim = a.adc_subdim, sub_floats = ((subdim + 3) / 4) * 4, qchunks = a.adc_qchunks;
     const uint32_t S16 = a.view.chunks * 16, lut_chunks = S16 * ADC_LUT_STRIDE / 4;
     WalkLds        s;
-    carve_walk(lgpu_smem, s, lut_chunks + qchunks, a.ef, a.view.M0, a.vis_slots);  // s.q = the table, then the raw query row
+    SpecLds        sc;
+    {
+        unsigned char *end = carve_walk(lgpu_smem, s, lut_chunks + qchunks, a.ef, a.view.M0, a.vis_slots);  // s.q = the table, then the raw query row
+        if constexpr(SPEC) carve_spec(end, sc, a.view.M0, a.spec_prefetch, a.spec_cache);
+        else (void)end;
+    }
     float *const       lut = (float *)s.q;
     const uint4 *const rawq4 = s.q + lut_chunks;
     const float *const rawq = (const float *)rawq4;
@@ -35,22 +92,8 @@ __global__ void __launch_bounds__(512, 2) k_search_adc(SearchArgs a)
         int      cnt = 0;
         for(uint32_t i = tid; i < qchunks; i += T) ((uint4 *)rawq4)[ i ] = a.queries[ (size_t)q * qchunks + i ];
         __syncthreads();
-        // the table: one thread per (subvector, centroid) entry, one fma chain each; entry 0 of the padding rows is +0.0
-        for(uint32_t e = tid; e < S * C; e += T) {
-            const uint32_t sv = e / C, c = e % C;
-            const float   *cent = a.adc_centers + ((size_t)sv * C + c) * sub_floats;
-            const float   *qs = rawq + (size_t)sv * subdim;
-            float          acc = 0.f;
-            for(uint32_t j = 0; j < subdim; ++j) {
-                if constexpr(METRIC == M_L2SQ_ADC) {
-                    const float t = qs[ j ] - cent[ j ];
-                    acc = __builtin_fmaf(t, t, acc);
-                } else {
-                    acc = __builtin_fmaf(qs[ j ], cent[ j ], acc);
-                }
-            }
-            lut[ (size_t)sv * ADC_LUT_STRIDE + c ] = acc;
-        }
+        // entry 0 of the padding rows is +0.0
+        adc_build_table<METRIC, 4>(lut, a.adc_centers, rawq, S, C, subdim, sub_floats, (uint32_t)tid, (uint32_t)T);  // (8 and 16 at a time: no faster)
         for(uint32_t sv = S + tid; sv < S16; sv += T) lut[ (size_t)sv * ADC_LUT_STRIDE ] = 0.f;
         if constexpr(METRIC == M_COS_ADC) {  // |query|: the chain and tree the f32 cosine kernels use for a row of this many chunks
             const int Gq = group_lanes_for(qchunks);
@@ -67,9 +110,15 @@ __global__ void __launch_bounds__(512, 2) k_search_adc(SearchArgs a)
         }
         __syncthreads();
         if(a.view.n != 0) {
-            const uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
-            if constexpr(KPL > 0) cnt = search_level_reg<METRIC, G, KPL>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E);
-            else cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E);
+            if constexpr(SPEC) {
+                static_assert(!SPEC || KPL > 0, "the latency-bound walk keeps its list in registers");
+                const uint32_t start = greedy_descent_spec<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
+                cnt = search_level_spec<METRIC, G, (KPL > 0 ? KPL : 1), 1, 2, true, false>(a.view, s, sc, bitmap, a.bm_words, start, (int)a.ef, D, E, nullptr);
+            } else {
+                const uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
+                if constexpr(KPL > 0) cnt = search_level_reg<METRIC, G, KPL>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E);
+                else cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E);
+            }
         }
         int got = cnt - (int)a.skip;
         got = got < 0 ? 0 : (got > (int)a.k ? (int)a.k : got);
@@ -112,25 +161,28 @@ size_t search_adc_lds_bytes(uint32_t code_chunks, uint32_t qchunks, uint32_t ef_
 hipError_t launch_search_adc(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream)
 {
     if(a.view.chunks == 0 || a.view.chunks > 8 || a.adc_C == 0 || a.adc_C > (uint32_t)ADC_LUT_STRIDE) return hipErrorInvalidValue;
-    const size_t lds = search_adc_lds_bytes(a.view.chunks, a.adc_qchunks, a.ef, a.view.M0, a.vis_slots);
-    const int    kpl = a.lds_list ? 0 : a.ef <= 64 ? 1 : a.ef <= 128 ? 2 : 0;
-#define LGPU_ADC(MM)                                                                                                        \
-    {                                                                                                                       \
-        if(kpl == 1) {                                                                                                      \
-            (void)hipFuncSetAttribute((const void *)k_search_adc<MM, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_search_adc<MM, 1>), dim3(grid), dim3(64 * waves), lds, stream, a);                        \
-        } else if(kpl == 2) {                                                                                               \
-            (void)hipFuncSetAttribute((const void *)k_search_adc<MM, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_search_adc<MM, 2>), dim3(grid), dim3(64 * waves), lds, stream, a);                        \
-        } else {                                                                                                            \
-            (void)hipFuncSetAttribute((const void *)k_search_adc<MM, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_search_adc<MM, 0>), dim3(grid), dim3(64 * waves), lds, stream, a);                        \
-        }                                                                                                                   \
+    const int kpl = a.lds_list ? 0 : a.ef <= 64 ? 1 : a.ef <= 128 ? 2 : 0;
+    if(a.spec && (kpl == 0 || waves < 4 || waves > 11 || a.view.M0 > 64 || a.view.M0 < 2)) return hipErrorInvalidValue;
+    const size_t lds = search_adc_lds_bytes(a.view.chunks, a.adc_qchunks, a.ef, a.view.M0, a.vis_slots) + (a.spec ? spec_lds_bytes(a.view.M0, a.spec_prefetch, a.spec_cache) : 0);
+#define LGPU_ADC1(MM, KK, SS)                                                                                                   \
+    {                                                                                                                           \
+        (void)hipFuncSetAttribute((const void *)k_search_adc<MM, KK, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_search_adc<MM, KK, SS>), dim3(grid), dim3(64 * waves), lds, stream, a);                           \
+    }
+#define LGPU_ADC(MM)                                  \
+    {                                                 \
+        if(a.spec) {                                  \
+            if(kpl == 1) LGPU_ADC1(MM, 1, true)       \
+            else LGPU_ADC1(MM, 2, true)               \
+        } else if(kpl == 1) LGPU_ADC1(MM, 1, false)   \
+        else if(kpl == 2) LGPU_ADC1(MM, 2, false)     \
+        else LGPU_ADC1(MM, 0, false)                  \
     }
     if(metric == M_L2SQ_ADC) LGPU_ADC(M_L2SQ_ADC)
     else if(metric == M_COS_ADC) LGPU_ADC(M_COS_ADC)
     else return hipErrorInvalidValue;
 #undef LGPU_ADC
+#undef LGPU_ADC1
     return hipGetLastError();
 }
 

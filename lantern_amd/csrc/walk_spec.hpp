@@ -146,13 +146,13 @@ __device__ __forceinline__ void spec_consume(const View &v, const WalkLds &s, co
     for(int u = 0; u < U; ++u) {
         const int ch = gl + u * G;
         if(ch < (int)v.chunks) {
-            const uint4 x = s.q[ ch ];
+            const uint4 x = walk_query<METRIC>(s)[ ch ];
 #pragma unroll
             for(int r = 0; r < ROWS; ++r) acc[ r ].add(x, p.y[ r ][ u ]);
         }
     }
     for(int ch = gl + U * G; ch < (int)v.chunks; ch += G) {  // rows longer than U chunks per lane
-        const uint4 x = s.q[ ch ];
+        const uint4 x = walk_query<METRIC>(s)[ ch ];
         uint4       yy[ ROWS ];
 #pragma unroll
         for(int r = 0; r < ROWS; ++r) yy[ r ] = row_of(v, p.id[ r ])[ ch ];
@@ -272,7 +272,7 @@ __device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, ui
     uint64_t *const keysb[ 2 ] = { s.newkeys, s.sorted };        // a hop's keys, by hop parity (both hold cap_max >= M0 keys)
     // "hop -1" (parity 1) evaluated one row: the start node
     if(wv == 0 && g == 0) {
-        const float d = group_dist_n<METRIC, G>(s.q, row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) keysb[ 1 ][ 0 ] = make_key(d, start);
         constexpr int LW = spec_list_words<G>();
         if(c.stage && gl * LW < (int)M0) {

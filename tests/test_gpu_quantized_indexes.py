@@ -204,6 +204,16 @@ def test_compact_pq_index_searches_by_adc_over_the_code_bytes(capi, oracle, metr
     o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, 10, ef, 4)
     assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist)
     assert np.array_equal(D, o_D) and np.array_equal(E, o_E)
+    # both walks of the ADC kernel (the default picks by table size: the lone-query shape of walk_spec.hpp when the table leaves room
+    # for one workgroup per CU, the classic 8-wave walk otherwise): the same ids, distance bits, D and E
+    for forced in ("0", "1"):
+        monkeypatch.setenv("LANTERN_GPU_ADC_SPEC", forced)
+        lab2, dist2, D2, E2 = hip.Buffer(nq * 10 * 8), hip.Buffer(nq * 10 * 4), hip.Buffer(nq * 8), hip.Buffer(nq * 8)
+        ix.search_batch_device(dq.ptr, nq, 10, 0, 0, lab2.ptr, dist2.ptr, None, None, D2.ptr, E2.ptr)
+        hip.synchronize()
+        assert np.array_equal(lab2.download((nq, 10), np.uint64), o_lab) and np.array_equal(dist2.download((nq, 10), np.float32), o_dist), forced
+        assert np.array_equal(D2.download(nq, np.uint64), o_D) and np.array_equal(E2.download(nq, np.uint64), o_E), forced
+    monkeypatch.delenv("LANTERN_GPU_ADC_SPEC")
     # against the decoded-row path: the same neighbours up to near-ties, distances within the north-star's tolerance
     same = lab == lab_dec
     assert same.mean() > 0.97
