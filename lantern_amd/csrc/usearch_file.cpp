@@ -39,6 +39,7 @@
 // made offline.  The reader accepts both upstream codes and this library's round-1 numerals.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <unordered_map>
@@ -149,7 +150,9 @@ bool serialize_stream(Index *ix, const SpanSink &sink)
     if(ix->upper_blocks) ok = ok && hipMemcpy(upper.data(), ix->d_upper_nbr, ix->upper_blocks * ix->M * 4, hipMemcpyDeviceToHost) == hipSuccess;
     if(!ok) { set_err(ix, "lantern_gpu: HIP failure while serialising"); return false; }
 
-    const size_t per = std::min(n, std::max<size_t>(256, ((size_t)64 << 20) / std::max<size_t>(row_stride, 1)));
+    size_t chunk_bytes = (size_t)64 << 20;
+    if(const char *cb = std::getenv("LANTERN_GPU_SAVE_CHUNK_BYTES")) chunk_bytes = std::max<size_t>(1, (size_t)std::strtoull(cb, nullptr, 10));  // (tests: many small chunks)
+    const size_t per = std::min(n, std::max<size_t>(1, chunk_bytes / std::max<size_t>(row_stride, 1)));
     const size_t max_prefix = 8 + 2 + (4 + (size_t)ix->M0 * LANTERN_SLOT_SIZE) + (size_t)255 * (4 + (size_t)ix->M * LANTERN_SLOT_SIZE);
     char        *stage[ 2 ] = { nullptr, nullptr };
     hipStream_t  st = nullptr;

@@ -242,7 +242,7 @@ def test_golden_insert_dimension_errors_and_misc(capi, golden):
     assert m.neighbors_bytes == 4 + 16 * 6 and m.neighbors_base_bytes == 4 + 32 * 6 and m.connectivity == 16
 
 
-def test_file_round_trip(capi, oracle, tmp_path):
+def test_file_round_trip(capi, oracle, tmp_path, monkeypatch):
     rng = np.random.default_rng(8)
     for metric, d in (("l2sq", 24), ("hamming", 3)):
         base = rand_rows(rng, 500, d, metric)
@@ -250,6 +250,9 @@ def test_file_round_trip(capi, oracle, tmp_path):
         ix.add_many(np.arange(500) + 1, base)
         blob = ix.save_buffer()
         assert ix.save_stream() == blob  # the span stream of the indexing server: the same bytes
+        monkeypatch.setenv("LANTERN_GPU_SAVE_CHUNK_BYTES", "5000")  # rows leave the device in ~10 chunks through the two staging buffers
+        assert ix.save_stream() == blob and ix.save_buffer() == blob
+        monkeypatch.delenv("LANTERN_GPU_SAVE_CHUNK_BYTES")
         g = ix.export_graph()
         # layout: 136-byte header + node tapes: 8+2+(4+2M*6)+level*(4+M*6)+vector (usearch_storage.cpp:19-32)
         vb = d * 4
@@ -269,6 +272,8 @@ def test_file_round_trip(capi, oracle, tmp_path):
         assert np.array_equal(third.search(q, 5)[0], ix.search(q, 5)[0])
         # first node tape: label, level
         assert int.from_bytes(blob[136:144], "little") == 1 and int.from_bytes(blob[144:146], "little") == int(g["levels"][0])
+    empty = capi.GpuIndex("l2sq", 8, M=4, ef_construction=8, seed=1)
+    assert len(empty.save_buffer()) == 136 and empty.save_stream() == empty.save_buffer()  # an empty index is its header
 
 
 # ------------------------------------------------------------------------------------------------
