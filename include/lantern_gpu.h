@@ -207,7 +207,8 @@ LANTERN_GPU_EXPORT void  lantern_gpu_host_free(void *);
  * sequence of spans, up to 1024 per call, in file order -- header, then per node its formatted prefix and its vector bytes
  * straight out of a page-locked staging buffer that the rows reach in ~64 MB chunks, the next chunk's copy overlapping this
  * one's consumption.  A span is layout-compatible with struct iovec: the indexing server passes them to writev(2)
- * (server.rs:388-422 sends the file it has just written to disk).  `write` returns 0 to go on, anything else aborts. */
+ * (server.rs:388-422 sends the file it has just written to disk).  `write` returns 0 to go on, anything else aborts.  The index
+ * stays locked until the last span has been consumed: other calls on it wait for a slow consumer. */
 typedef struct lantern_gpu_span { const void *data; size_t size; } lantern_gpu_span;
 typedef int (*lantern_gpu_write_fn)(void *ctx, const lantern_gpu_span *spans, size_t count);
 LANTERN_GPU_EXPORT void lantern_gpu_save_stream(usearch_index_t, lantern_gpu_write_fn write, void *ctx, usearch_error_t *);

@@ -546,7 +546,11 @@ void usearch_save_buffer(usearch_index_t h, char *buffer, size_t length, usearch
     if(ix) (void)hipSetDevice(ix->device);
     if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
     std::lock_guard<std::mutex> g(ix->mu);
-    if(!flush_locked(ix) || !serialize(ix, buffer, length)) { if(e) *e = ix->err.c_str(); }
+    try {
+        if(!flush_locked(ix) || !serialize(ix, buffer, length)) { if(e) *e = ix->err.c_str(); }
+    } catch(const std::exception &ex) {  // (an allocation failure must not leave through the C boundary)
+        if(e) *e = set_err(ix, std::string("lantern_gpu: ") + ex.what());
+    }
 }
 
 void usearch_save(usearch_index_t h, const char *path, usearch_error_t *e)
@@ -559,11 +563,15 @@ void usearch_save(usearch_index_t h, const char *path, usearch_error_t *e)
     if(!flush_locked(ix)) { if(e) *e = ix->err.c_str(); return; }
     FILE *f = std::fopen(path, "wb");
     if(!f) { if(e) *e = set_err(ix, std::string("lantern_gpu: cannot write index file ") + path); return; }
-    bool wrote = true;
-    const bool ok = serialize_stream(ix, [&](const lantern_gpu_span *sp, size_t cnt) {
-        for(size_t i = 0; i < cnt && wrote; ++i) wrote = std::fwrite(sp[ i ].data, 1, sp[ i ].size, f) == sp[ i ].size;
-        return wrote;
-    });
+    bool wrote = true, ok = false;
+    try {
+        ok = serialize_stream(ix, [&](const lantern_gpu_span *sp, size_t cnt) {
+            for(size_t i = 0; i < cnt && wrote; ++i) wrote = std::fwrite(sp[ i ].data, 1, sp[ i ].size, f) == sp[ i ].size;
+            return wrote;
+        });
+    } catch(const std::exception &ex) {
+        set_err(ix, std::string("lantern_gpu: ") + ex.what());
+    }
     if(std::fclose(f) != 0) wrote = false;
     if(!wrote) { if(e) *e = set_err(ix, std::string("lantern_gpu: cannot write index file ") + path); return; }
     if(!ok && e) *e = ix->err.c_str();
@@ -577,8 +585,12 @@ void lantern_gpu_save_stream(usearch_index_t h, lantern_gpu_write_fn fn, void *c
     if(!ix) { if(e) *e = "lantern_gpu: null index handle"; return; }
     if(!fn) { if(e) *e = "lantern_gpu: null write callback"; return; }
     std::lock_guard<std::mutex> g(ix->mu);
-    if(!flush_locked(ix) || !serialize_stream(ix, [&](const lantern_gpu_span *sp, size_t cnt) { return fn(ctx, sp, cnt) == 0; })) {
-        if(e) *e = ix->err.c_str();
+    try {
+        if(!flush_locked(ix) || !serialize_stream(ix, [&](const lantern_gpu_span *sp, size_t cnt) { return fn(ctx, sp, cnt) == 0; })) {
+            if(e) *e = ix->err.c_str();
+        }
+    } catch(const std::exception &ex) {
+        if(e) *e = set_err(ix, std::string("lantern_gpu: ") + ex.what());
     }
 }
 
