@@ -21,19 +21,33 @@
 // continuation is served as a search for |handed out| + k rows from which the rows already handed out are dropped
 // (by label: a heap TID is indexed once; rows with label 0 -- deleted, skipped by the scan -- are dropped by count).
 //
-// Threads: an acceptor; one reader per connection (blocking read -> enqueue -> wait for the answer -> write); one
-// dispatcher that takes up to `max_batch` queued requests -- waiting at most `max_wait_us` after the first one for
-// company -- groups them by (k, ef) and calls the batch search function once per group.
+// Threads: an acceptor, a few I/O threads and the dispatchers (two on a device index, one in front of a caller-supplied back
+// end unless it says it may be entered twice) -- no thread per connection.  Every connection belongs to one I/O thread's epoll
+// set, armed one-shot: it is disarmed from the moment its request has been read until its answer has been written (a backend has
+// one request outstanding; whatever it sends meanwhile waits in the socket).  An I/O thread reads the requests of its
+// connections that are ready and queues them; the dispatcher whose turn it is closes the batch when it is full, when the window
+// (`max_wait_us` after the first request) ends, or when nobody is left who could join -- every open connection already has a
+// request queued or in a batch being searched.  It hands the turn over, groups the batch by (k, ef), calls the batch search
+// once per group, gives each answer back to the I/O thread of its connection (one wake-up per I/O thread and batch), which
+// filters it against the scan's history, writes it and re-arms the connection.  A request costs three system calls spread
+// over the I/O threads and no context switch of its own: wake-ups are shared by whatever is ready.
+// (r2-r3 had a blocking reader thread per connection: 512 wake-ups per round of 256 backends on the server alone, 316-396 k
+// queries/s on 16 cores.  One thread doing all socket work -- tried on the way -- is worse: a send on a loopback socket wakes
+// its receiver, ~10 us per request in series.)
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <sys/epoll.h>
+#include <sys/eventfd.h>
 #include <sys/socket.h>
+#include <sys/syscall.h>
 #include <sys/time.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cerrno>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +57,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -76,17 +91,37 @@ bool write_all(int fd, const void *buf, size_t n)
     return true;
 }
 
-struct Pending
+// one connection = one backend: its read buffer, the request it has outstanding, and the scan it is paging through
+struct Conn
 {
-    uint32_t             k = 0, ef = 0;
+    int                  fd = -1, io = 0;  // its socket; the I/O thread it belongs to
+    std::vector<uint8_t> in;  // bytes read so far of the next request
+    // the outstanding request
+    bool                 cont = false;
+    uint32_t             want = 0, k = 0, ef = 0;  // rows the client asked for; rows the search is asked for (handed out + want)
     std::vector<uint8_t> vec;
-    // filled by the dispatcher
-    bool                     done = false;
-    std::string              error;
-    std::vector<uint64_t>    labels;
-    std::vector<float>       dists;
-    std::mutex               mu;
-    std::condition_variable  cv;
+    // this connection's scan: labels handed out since its last fresh request, and how many label-0 rows among them
+    std::unordered_set<uint64_t> seen;
+    size_t                       seen_zero = 0;
+};
+
+// a request's way back to its connection
+struct Done
+{
+    Conn                 *c = nullptr;
+    std::string           error;  // non-empty: an error frame
+    std::vector<uint64_t> labels;
+    std::vector<float>    dists;
+};
+
+struct IoThread
+{
+    int                  epfd = -1, evfd = -1;  // its connections, one-shot; completions / new connections / stop
+    std::thread          t;
+    std::mutex           mu;  // the two lists below
+    std::vector<Done>    done;
+    std::vector<std::unique_ptr<Conn>> incoming;
+    std::unordered_map<int, std::unique_ptr<Conn>> conns;  // touched by the thread itself only
 };
 
 }  // namespace
@@ -103,18 +138,12 @@ struct lantern_scan_server
     std::atomic<bool>       stop{ false };
     std::thread             accept_thread, dispatch_thread[ 2 ];
     int                     lanes = 1;   // dispatchers: one collects the next batch while the other's batch is on the device
+    std::vector<std::unique_ptr<IoThread>> io;
     std::mutex              collect_mu;  // held by the dispatcher that is collecting (one batch is formed at a time)
-    std::mutex              mu;  // queue + connection list
+    std::mutex              mu;          // the queue and the two counts below
     std::condition_variable cv;
-    std::deque<std::shared_ptr<Pending>> queue;
-    struct Conn
-    {
-        std::thread       t;
-        int               fd = -1;
-        std::atomic<bool> done{ false };
-    };
-    std::vector<std::unique_ptr<Conn>> conns;  // guarded by mu
-    size_t                  open_conns = 0, in_flight = 0;  // guarded by mu: connections being served; requests taken into a batch and not answered yet
+    std::deque<Conn *>      queue;       // connections whose request has been read (disarmed until answered)
+    size_t                  open_conns = 0, in_flight = 0;  // connections being served; requests in a closed batch, not answered yet
     std::atomic<uint64_t>   n_requests{ 0 }, n_batches{ 0 }, n_launches{ 0 }, max_batch_seen{ 0 };
     std::atomic<uint64_t>   batch_hist[ 16 ] = {};  // batches by size: bin b counts sizes in [2^b, 2^(b+1))
 };
@@ -133,41 +162,186 @@ int default_backend(void *ctx, const void *queries, size_t nq, size_t, size_t k,
     return 0;
 }
 
-void fulfil(const std::shared_ptr<Pending> &p)
+bool reply_error(int fd, const std::string &msg)
 {
-    {
-        std::lock_guard<std::mutex> g(p->mu);
-        p->done = true;
-    }
-    p->cv.notify_all();
+    uint32_t head[ 3 ] = { REP_MAGIC, 1u, (uint32_t)msg.size() };
+    return write_all(fd, head, sizeof(head)) && write_all(fd, msg.data(), msg.size());
 }
 
-// Two dispatchers take turns: whoever holds collect_mu forms the next batch (first request, the window, up to max_batch) while
-// the other one's batch is being searched, so the device always has the next launch queued behind the current one -- and, the
-// two lanes' launches running in separate slots of the index, overlapping it.  Batching is as with one dispatcher: batches
-// are formed one at a time, from everything that arrived meanwhile.
+bool arm(IoThread *t, Conn *c, int op)
+{
+    epoll_event ev;
+    std::memset(&ev, 0, sizeof(ev));
+    ev.events = EPOLLIN | EPOLLRDHUP | EPOLLONESHOT;
+    ev.data.ptr = c;
+    return ::epoll_ctl(t->epfd, op, c->fd, &ev) == 0;
+}
+
+// the connection is over: out of its epoll set and table, descriptor closed (by its I/O thread, its only holder while armed
+// or while its answer is being written)
+void drop(lantern_scan_server *s, IoThread *t, Conn *c)
+{
+    const int fd = c->fd;
+    ::epoll_ctl(t->epfd, EPOLL_CTL_DEL, fd, nullptr);
+    t->conns.erase(fd);  // (frees c)
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        s->open_conns -= 1;
+    }
+    s->cv.notify_all();  // (a collecting dispatcher may have been waiting for this connection's next request)
+    ::shutdown(fd, SHUT_RDWR);
+    ::close(fd);
+}
+
+// Reads what the socket holds of the connection's next request -- never past its end: a valid request is 16 + vec_bytes long, and
+// a connection's following request stays in the socket until the connection is armed again.  1 = a complete, valid request is
+// in c (vec, k, ef, want); 0 = not yet, or an error frame went out and the connection waits for its next request: re-arm;
+// -1 = the connection is over.
+int read_request(lantern_scan_server *s, Conn *c)
+{
+    for(;;) {
+        size_t goal = 16 + s->vec_bytes;
+        if(c->in.size() >= 16) {
+            uint32_t nbytes;
+            std::memcpy(&nbytes, c->in.data() + 12, 4);
+            if(nbytes > MAX_VEC_BYTES) { reply_error(c->fd, "lantern_scan_server: vector too large"); return -1; }
+            goal = 16 + (size_t)nbytes;
+            if(c->in.size() >= goal) break;
+        }
+        uint8_t       tmp[ 16384 ];
+        const ssize_t r = ::recv(c->fd, tmp, std::min(sizeof(tmp), goal - c->in.size()), MSG_DONTWAIT);
+        if(r > 0) c->in.insert(c->in.end(), tmp, tmp + r);
+        else if(r == 0) return -1;  // peer closed
+        else if(errno == EAGAIN || errno == EWOULDBLOCK) return 0;
+        else if(errno != EINTR) return -1;
+    }
+    uint32_t head[ 4 ];
+    std::memcpy(head, c->in.data(), 16);
+    const uint32_t k = head[ 1 ], ef = head[ 2 ], nbytes = head[ 3 ];
+    if(head[ 0 ] != REQ_MAGIC && head[ 0 ] != CONT_MAGIC) { reply_error(c->fd, "lantern_scan_server: bad request magic"); return -1; }
+    c->cont = head[ 0 ] == CONT_MAGIC;
+    c->vec.assign(c->in.begin() + 16, c->in.begin() + 16 + (ptrdiff_t)nbytes);
+    c->in.erase(c->in.begin(), c->in.begin() + 16 + (ptrdiff_t)nbytes);
+    if(nbytes != s->vec_bytes)  // the reference's text for a wrong dimension: hnsw.c:474-476
+        return reply_error(c->fd, "lantern_scan_server: query of " + std::to_string(nbytes) + " bytes, the index takes " + std::to_string(s->vec_bytes)) ? 0 : -1;
+    if(k == 0 || k > MAX_K) return reply_error(c->fd, "lantern_scan_server: k out of range") ? 0 : -1;
+    if(!c->cont) { c->seen.clear(); c->seen_zero = 0; }
+    const size_t handed = c->seen.size() + c->seen_zero;
+    if(handed + k > MAX_K) return reply_error(c->fd, "lantern_scan_server: the scan has paged past the service's row limit") ? 0 : -1;
+    c->want = k;
+    c->k = (uint32_t)(handed + k);  // enough rows to find k that were not handed out yet
+    c->ef = ef;
+    return 1;
+}
+
+// the answer of one request: drop what this scan already has, keep the first `want` of the rest
+bool reply_rows(Conn *c, const uint64_t *labels, const float *dists, size_t count)
+{
+    std::vector<uint8_t>  out(12 + (size_t)c->want * 12);
+    std::vector<uint64_t> ls;
+    std::vector<float>    ds;
+    size_t                zeros_to_skip = c->seen_zero;
+    for(size_t i = 0; i < count && ls.size() < c->want; ++i) {
+        const uint64_t l = labels[ i ];
+        if(l == 0) {
+            if(zeros_to_skip) { --zeros_to_skip; continue; }
+            ++c->seen_zero;
+        } else if(!c->seen.insert(l).second) {
+            continue;
+        }
+        ls.push_back(l);
+        ds.push_back(dists[ i ]);
+    }
+    const uint32_t n = (uint32_t)ls.size();
+    const uint32_t rep[ 3 ] = { REP_MAGIC, 0u, n };
+    std::memcpy(out.data(), rep, 12);
+    if(n) {
+        std::memcpy(out.data() + 12, ls.data(), (size_t)n * 8);
+        std::memcpy(out.data() + 12 + (size_t)n * 8, ds.data(), (size_t)n * 4);
+    }
+    return write_all(c->fd, out.data(), 12 + (size_t)n * 12);  // one send per answer
+}
+
+void io_loop(lantern_scan_server *s, IoThread *t)
+{
+    epoll_event       events[ 256 ];
+    std::vector<Done> done;
+    std::vector<std::unique_ptr<Conn>> fresh;
+    for(;;) {
+        const int n = ::epoll_wait(t->epfd, events, 256, -1);
+        if(n < 0 && errno != EINTR) return;
+        size_t queued = 0;
+        for(int i = 0; i < n; ++i) {
+            Conn *c = (Conn *)events[ i ].data.ptr;
+            if(c) {  // a connection with something to read
+                const int got = read_request(s, c);
+                if(got < 0) drop(s, t, c);
+                else if(got == 0) { if(!arm(t, c, EPOLL_CTL_MOD)) drop(s, t, c); }
+                else {
+                    s->n_requests += 1;
+                    std::lock_guard<std::mutex> g(s->mu);
+                    s->queue.push_back(c);
+                    ++queued;
+                }
+                continue;
+            }
+            // the event descriptor: answers to write, connections to adopt, or the end
+            uint64_t v;
+            (void)!::read(t->evfd, &v, 8);
+            if(s->stop) return;
+            {
+                std::lock_guard<std::mutex> g(t->mu);
+                done.swap(t->done);
+                fresh.swap(t->incoming);
+            }
+            for(auto &up : fresh) {
+                Conn *nc = up.get();
+                t->conns[ nc->fd ] = std::move(up);
+                if(!arm(t, nc, EPOLL_CTL_ADD)) drop(s, t, nc);
+            }
+            fresh.clear();
+            for(Done &d : done) {
+                const bool sent = d.error.empty() ? reply_rows(d.c, d.labels.data(), d.dists.data(), d.labels.size()) : reply_error(d.c->fd, d.error);
+                if(!sent || !arm(t, d.c, EPOLL_CTL_MOD)) drop(s, t, d.c);  // answered: the connection may speak again
+            }
+            done.clear();
+        }
+        if(queued) s->cv.notify_all();  // one wake-up for everything this round read
+    }
+}
+
+// Two dispatchers take turns: whoever holds collect_mu forms the next batch while the other one's batch is being searched, so
+// the device always has the next launch queued behind the current one -- and, the two lanes' launches running in separate
+// slots of the index, overlapping it.
 void dispatch_loop(lantern_scan_server *s, int lane)
 {
     tl_lane = lane;
-    std::vector<std::shared_ptr<Pending>> batch;
+    std::vector<Conn *>   batch;
     std::vector<uint8_t>  qbuf;
     std::vector<uint64_t> labels;
     std::vector<float>    dists;
     std::vector<uint32_t> counts;
+    std::vector<char>     touched;
     for(;;) {
         batch.clear();
         {
             std::lock_guard<std::mutex>  turn(s->collect_mu);
             std::unique_lock<std::mutex> lk(s->mu);
             s->cv.wait(lk, [&] { return s->stop.load() || !s->queue.empty(); });
-            if(s->stop && s->queue.empty()) return;
+            if(s->stop) return;
             // the first request is here: give the others `max_wait_us` to join, unless the batch is already full -- or nobody is
             // left who could join: a backend has one request outstanding at a time (amgettuple is synchronous), so once every open
             // connection has a request queued here or in the other dispatcher's batch, the window would only add latency
-            // (64 backends in a closed loop: 488 -> ~290 us per scan)
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(s->max_wait_us);
-            s->cv.wait_until(lk, deadline, [&] { return s->stop.load() || s->queue.size() >= s->max_batch || s->queue.size() + s->in_flight >= s->open_conns; });
-            while(!s->queue.empty() && batch.size() < s->max_batch) {
+            // With two dispatchers a batch also closes at its SHARE of the backends (open connections / dispatchers): the two halves
+            // of a population that moves in step then take turns -- one half on the device while the other half's answers and next
+            // requests are on the wire -- instead of everybody waiting for the device and then the device waiting for everybody.
+            const auto   deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(s->max_wait_us);
+            const size_t lanes = (size_t)s->lanes;
+            auto         share = [&] { return std::min(s->max_batch, std::max<size_t>(1, (s->open_conns + lanes - 1) / lanes)); };
+            s->cv.wait_until(lk, deadline, [&] { return s->stop.load() || s->queue.size() >= share() || s->queue.size() + s->in_flight >= s->open_conns; });
+            if(s->stop) return;
+            const size_t take = share();
+            while(!s->queue.empty() && batch.size() < take) {
                 batch.push_back(s->queue.front());
                 s->queue.pop_front();
             }
@@ -185,6 +359,7 @@ void dispatch_loop(lantern_scan_server *s, int lane)
         // one launch per distinct (k, ef): scans of one workload share them (init_k, the ef GUC)
         std::map<std::pair<uint32_t, uint32_t>, std::vector<size_t>> groups;
         for(size_t i = 0; i < batch.size(); ++i) groups[ { batch[ i ]->k, batch[ i ]->ef } ].push_back(i);
+        touched.assign(s->io.size(), 0);
         for(auto &kv : groups) {
             const size_t k = kv.first.first, ef = kv.first.second, nq = kv.second.size();
             qbuf.resize(nq * s->vec_bytes);
@@ -195,108 +370,29 @@ void dispatch_loop(lantern_scan_server *s, int lane)
             const char *err = nullptr;
             const int   rc = s->fn(s->fn_ctx, qbuf.data(), nq, s->vec_bytes, k, ef, labels.data(), dists.data(), counts.data(), &err);
             s->n_launches += 1;
-            for(size_t j = 0; j < nq; ++j) {
-                Pending &p = *batch[ kv.second[ j ] ];
+            const std::string msg = rc != 0 ? std::string(err ? err : "lantern_scan_server: the batch search failed") : std::string();
+            for(size_t j = 0; j < nq; ++j) {  // every answer back to the I/O thread of its connection
+                Done d;
+                d.c = batch[ kv.second[ j ] ];
                 if(rc != 0) {
-                    p.error = err ? err : "lantern_scan_server: the batch search failed";
+                    d.error = msg;
                 } else {
-                    const size_t c = std::min<size_t>(counts[ j ], k);
-                    p.labels.assign(labels.begin() + (ptrdiff_t)(j * k), labels.begin() + (ptrdiff_t)(j * k + c));
-                    p.dists.assign(dists.begin() + (ptrdiff_t)(j * k), dists.begin() + (ptrdiff_t)(j * k + c));
+                    const size_t cn = std::min<size_t>(counts[ j ], k);
+                    d.labels.assign(labels.begin() + (ptrdiff_t)(j * k), labels.begin() + (ptrdiff_t)(j * k + cn));
+                    d.dists.assign(dists.begin() + (ptrdiff_t)(j * k), dists.begin() + (ptrdiff_t)(j * k + cn));
                 }
-                fulfil(batch[ kv.second[ j ] ]);
+                IoThread *t = s->io[ (size_t)d.c->io ].get();
+                touched[ (size_t)d.c->io ] = 1;
+                std::lock_guard<std::mutex> g(t->mu);
+                t->done.push_back(std::move(d));
             }
         }
-        {
-            std::lock_guard<std::mutex> g(s->mu);
-            s->in_flight -= batch.size();
-        }
-    }
-}
-
-bool reply_error(int fd, const std::string &msg)
-{
-    uint32_t head[ 3 ] = { REP_MAGIC, 1u, (uint32_t)msg.size() };
-    return write_all(fd, head, sizeof(head)) && write_all(fd, msg.data(), msg.size());
-}
-
-void reader_loop(lantern_scan_server *s, lantern_scan_server::Conn *conn)
-{
-    const int fd = conn->fd;
-    // this connection's scan: labels handed out since its last fresh request, and how many label-0 rows among them
-    std::unordered_set<uint64_t> seen;
-    size_t                       seen_zero = 0;
-    for(;;) {
-        uint32_t head[ 4 ];
-        if(!read_exact(fd, head, sizeof(head))) break;  // peer closed, or the server is stopping (shutdown on the fd)
-        if(head[ 0 ] != REQ_MAGIC && head[ 0 ] != CONT_MAGIC) { reply_error(fd, "lantern_scan_server: bad request magic"); break; }
-        const bool     cont = head[ 0 ] == CONT_MAGIC;
-        const uint32_t k = head[ 1 ], ef = head[ 2 ], nbytes = head[ 3 ];
-        if(nbytes > MAX_VEC_BYTES) { reply_error(fd, "lantern_scan_server: vector too large"); break; }
-        auto p = std::make_shared<Pending>();
-        p->k = k;
-        p->ef = ef;
-        p->vec.resize(nbytes);
-        if(nbytes && !read_exact(fd, p->vec.data(), nbytes)) break;
-        if(nbytes != s->vec_bytes) {  // the reference's text for a wrong dimension: hnsw.c:474-476
-            if(!reply_error(fd, "lantern_scan_server: query of " + std::to_string(nbytes) + " bytes, the index takes " + std::to_string(s->vec_bytes))) break;
-            continue;
-        }
-        if(k == 0 || k > MAX_K) {
-            if(!reply_error(fd, "lantern_scan_server: k out of range")) break;
-            continue;
-        }
-        if(!cont) { seen.clear(); seen_zero = 0; }
-        const size_t handed = seen.size() + seen_zero;
-        if(handed + k > MAX_K) {
-            if(!reply_error(fd, "lantern_scan_server: the scan has paged past the service's row limit")) break;
-            continue;
-        }
-        p->k = (uint32_t)(handed + k);  // enough rows to find k that were not handed out yet
-        s->n_requests += 1;
-        {
-            std::lock_guard<std::mutex> g(s->mu);
-            if(s->stop) { reply_error(fd, "lantern_scan_server: stopping"); break; }
-            s->queue.push_back(p);
-        }
-        s->cv.notify_all();
-        {
-            std::unique_lock<std::mutex> lk(p->mu);
-            p->cv.wait(lk, [&] { return p->done; });
-        }
-        if(!p->error.empty()) {
-            if(!reply_error(fd, p->error)) break;
-            continue;
-        }
-        // drop what this scan already has; keep the first k of the rest
-        std::vector<uint64_t> out_l;
-        std::vector<float>    out_d;
-        size_t                zeros_to_skip = seen_zero;
-        for(size_t i = 0; i < p->labels.size() && out_l.size() < k; ++i) {
-            const uint64_t l = p->labels[ i ];
-            if(l == 0) {
-                if(zeros_to_skip) { --zeros_to_skip; continue; }
-                ++seen_zero;
-            } else if(!seen.insert(l).second) {
-                continue;
-            }
-            out_l.push_back(l);
-            out_d.push_back(p->dists[ i ]);
-        }
-        const uint32_t c = (uint32_t)out_l.size();
-        uint32_t       rep[ 3 ] = { REP_MAGIC, 0u, c };
-        if(!write_all(fd, rep, sizeof(rep)) || (c && (!write_all(fd, out_l.data(), c * 8) || !write_all(fd, out_d.data(), c * 4)))) break;
-    }
-    {
-        // the descriptor leaves the server's books BEFORE it is closed: stop() must never shut down a recycled number
+        const uint64_t one = 1;
+        for(size_t i = 0; i < s->io.size(); ++i)
+            if(touched[ i ]) (void)!::write(s->io[ i ]->evfd, &one, 8);
         std::lock_guard<std::mutex> g(s->mu);
-        conn->fd = -1;
-        s->open_conns -= 1;
+        s->in_flight -= batch.size();
     }
-    s->cv.notify_all();  // (a collecting dispatcher may have been waiting for this connection's next request)
-    ::shutdown(fd, SHUT_RDWR);
-    ::close(fd);
-    conn->done = true;
 }
 
 int listen_on(const char *host, int port, int *bound_port)
@@ -310,7 +406,7 @@ int listen_on(const char *host, int port, int *bound_port)
     a.sin_family = AF_INET;
     a.sin_port = htons((uint16_t)port);
     if(::inet_pton(AF_INET, host && *host ? host : "127.0.0.1", &a.sin_addr) != 1 || ::bind(fd, (sockaddr *)&a, sizeof(a)) != 0 ||
-       ::listen(fd, 256) != 0) {
+       ::listen(fd, 1024) != 0) {
         ::close(fd);
         return -1;
     }
@@ -324,6 +420,7 @@ int listen_on(const char *host, int port, int *bound_port)
 
 void accept_loop(lantern_scan_server *s)
 {
+    size_t next = 0;
     while(!s->stop) {
         int fd = ::accept(s->listen_fd, nullptr, nullptr);
         if(fd < 0) continue;
@@ -331,23 +428,21 @@ void accept_loop(lantern_scan_server *s)
         ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
         timeval never{ 0, 0 };  // Linux hands the listener's receive timeout down to accepted sockets: a backend may idle for hours
         ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &never, sizeof(never));
-        std::lock_guard<std::mutex> g(s->mu);
-        if(s->stop) { ::close(fd); break; }
-        // reap the readers of connections that have ended (a backend connects once per session, but sessions come and go)
-        for(size_t i = 0; i < s->conns.size();) {
-            if(s->conns[ i ]->done) {
-                s->conns[ i ]->t.join();
-                s->conns.erase(s->conns.begin() + (ptrdiff_t)i);
-            } else {
-                ++i;
-            }
-        }
-        auto conn = std::make_unique<lantern_scan_server::Conn>();
+        auto conn = std::make_unique<Conn>();
         conn->fd = fd;
-        lantern_scan_server::Conn *raw = conn.get();
-        s->open_conns += 1;
-        conn->t = std::thread(reader_loop, s, raw);
-        s->conns.push_back(std::move(conn));
+        conn->io = (int)(next++ % s->io.size());
+        IoThread *t = s->io[ (size_t)conn->io ].get();
+        {
+            std::lock_guard<std::mutex> g(s->mu);
+            if(s->stop) { ::close(fd); break; }
+            s->open_conns += 1;
+        }
+        {
+            std::lock_guard<std::mutex> g(t->mu);
+            t->incoming.push_back(std::move(conn));
+        }
+        const uint64_t one64 = 1;
+        (void)!::write(t->evfd, &one64, 8);
     }
 }
 
@@ -361,6 +456,32 @@ lantern_scan_server *start_common(lantern_scan_server *s, const char *host, int 
         delete s;
         return nullptr;
     }
+    // socket work is spread over a few threads (a send on a loopback socket wakes its receiver: ~10 us apiece in series)
+    size_t nio = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+    if(const char *ev = std::getenv("LANTERN_SCAN_IO_THREADS")) nio = (size_t)std::max(1, std::min(64, std::atoi(ev)));
+    bool ok = true;
+    for(size_t i = 0; i < nio && ok; ++i) {
+        auto t = std::make_unique<IoThread>();
+        t->epfd = ::epoll_create1(EPOLL_CLOEXEC);
+        t->evfd = ::eventfd(0, EFD_CLOEXEC | EFD_NONBLOCK);
+        epoll_event wev;
+        std::memset(&wev, 0, sizeof(wev));
+        wev.events = EPOLLIN;
+        wev.data.ptr = nullptr;
+        ok = t->epfd >= 0 && t->evfd >= 0 && ::epoll_ctl(t->epfd, EPOLL_CTL_ADD, t->evfd, &wev) == 0;
+        s->io.push_back(std::move(t));
+    }
+    if(!ok) {
+        if(e) *e = "lantern_gpu: cannot set up the scan server's epoll sets";
+        for(auto &t : s->io) {
+            if(t->epfd >= 0) ::close(t->epfd);
+            if(t->evfd >= 0) ::close(t->evfd);
+        }
+        ::close(s->listen_fd);
+        delete s;
+        return nullptr;
+    }
+    for(auto &t : s->io) t->t = std::thread(io_loop, s, t.get());
     for(int l = 0; l < s->lanes; ++l) s->dispatch_thread[ l ] = std::thread(dispatch_loop, s, l);
     s->accept_thread = std::thread(accept_loop, s);
     return s;
@@ -433,26 +554,28 @@ void lantern_scan_server_stop(lantern_scan_server_t *s)
     {
         std::lock_guard<std::mutex> g(s->mu);
         s->stop = true;
-        for(auto &c : s->conns)
-            if(c->fd >= 0) ::shutdown(c->fd, SHUT_RDWR);  // wakes readers blocked in recv
     }
     s->cv.notify_all();
+    const uint64_t one = 1;
+    for(auto &t : s->io) (void)!::write(t->evfd, &one, 8);
     if(s->accept_thread.joinable()) s->accept_thread.join();
     for(auto &t : s->dispatch_thread)
         if(t.joinable()) t.join();
-    // requests that were still queued when the dispatcher left: answer them so that their readers can finish
-    std::deque<std::shared_ptr<Pending>> rest;
-    {
-        std::lock_guard<std::mutex> g(s->mu);
-        rest.swap(s->queue);
+    for(auto &t : s->io)
+        if(t->t.joinable()) t->t.join();
+    // nobody else is left.  Requests that were read but never searched, answers that were never written: an error frame each;
+    // then everything still connected is closed (clients see "went away")
+    for(Conn *c : s->queue) reply_error(c->fd, "lantern_scan_server: stopping");
+    for(auto &t : s->io) {
+        for(Done &d : t->done) reply_error(d.c->fd, "lantern_scan_server: stopping");
+        for(auto &kv : t->conns) {
+            ::shutdown(kv.first, SHUT_RDWR);
+            ::close(kv.first);
+        }
+        for(auto &c : t->incoming) ::close(c->fd);
+        ::close(t->epfd);
+        ::close(t->evfd);
     }
-    for(auto &p : rest) {
-        p->error = "lantern_scan_server: stopping";
-        fulfil(p);
-    }
-    // the acceptor has ended, so `conns` no longer changes; readers may still be locking mu to retire their descriptor
-    for(auto &c : s->conns)
-        if(c->t.joinable()) c->t.join();
     if(s->listen_fd >= 0) ::close(s->listen_fd);
     delete s;
 }

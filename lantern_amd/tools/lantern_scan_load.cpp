@@ -6,6 +6,16 @@
 // back for --seconds (lantern_scan_client_search: what ldb_amgettuple calls in place of usearch_search_ef,
 // lantern_hnsw/src/hnsw/scan.c:220-228).  Prints one JSON line: queries/s, latency percentiles, the service's batch-size
 // histogram.  Everything goes through the C ABI of liblantern_gpu.so; the clients speak TCP to the server like separate processes.
+// --client-threads T (T > 0) drives the same number of connections from T threads instead, each multiplexing its share with
+// epoll and speaking the wire protocol of scan_server.cpp itself: the generator's own scheduling cost (two context switches per
+// query and connection thread, on the cores the server shares with it) leaves the picture, and what remains is the service.
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/epoll.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -23,7 +33,7 @@ using Clock = std::chrono::steady_clock;
 
 int main(int argc, char **argv)
 {
-    size_t   rows = 100000, dim = 128, m = 16, efc = 128, ef = 64, k = 10, connections = 256, max_batch = 1024, pool = 8192;
+    size_t   rows = 100000, dim = 128, m = 16, efc = 128, ef = 64, k = 10, connections = 256, max_batch = 1024, pool = 8192, client_threads = 0;
     unsigned wait_us = 200;
     double   seconds = 5.0, warm = 1.0;
     for(int i = 1; i < argc; ++i) {
@@ -35,13 +45,14 @@ int main(int argc, char **argv)
         else if(const char *v = val("--ef")) ef = (size_t)std::atoll(v);
         else if(const char *v = val("--k")) k = (size_t)std::atoll(v);
         else if(const char *v = val("--connections")) connections = (size_t)std::atoll(v);
+        else if(const char *v = val("--client-threads")) client_threads = (size_t)std::atoll(v);
         else if(const char *v = val("--max-batch")) max_batch = (size_t)std::atoll(v);
         else if(const char *v = val("--max-wait-us")) wait_us = (unsigned)std::atoi(v);
         else if(const char *v = val("--seconds")) seconds = std::atof(v);
         else if(const char *v = val("--warmup-seconds")) warm = std::atof(v);
         else {
             std::fprintf(stderr, "usage: %s [--rows N --dim D --m M --ef-construction E --ef E --k K] [--connections C] [--max-batch B] "
-                                 "[--max-wait-us U] [--seconds S] [--warmup-seconds W]\n", argv[ 0 ]);
+                                 "[--max-wait-us U] [--seconds S] [--warmup-seconds W] [--client-threads T]\n", argv[ 0 ]);
             return 2;
         }
     }
@@ -80,7 +91,83 @@ int main(int argc, char **argv)
     std::atomic<size_t>   failures{ 0 }, connected{ 0 };
     std::vector<std::vector<uint32_t>> lat(connections);  // microseconds, timed phase only
     std::vector<std::thread>           threads;
-    for(size_t c = 0; c < connections; ++c) {
+    // ---- T threads, each with its share of the connections behind one epoll set
+    for(size_t w = 0; w < client_threads; ++w) {
+        threads.emplace_back([&, w] {
+            struct Cl
+            {
+                int                  fd = -1;
+                Clock::time_point    t0;
+                std::vector<uint8_t> in;
+                std::mt19937         pick;
+            };
+            const size_t lo = connections * w / client_threads, hi = connections * (w + 1) / client_threads;
+            std::vector<Cl> cls(hi - lo);
+            const int       ep = ::epoll_create1(0);
+            std::vector<uint8_t> req(16 + dim * 4);
+            auto send_next = [&](Cl &c) {
+                const float   *q = &queries[ (size_t)(c.pick() % pool) * dim ];
+                const uint32_t head[ 4 ] = { 0x5152534Cu, (uint32_t)k, 0u, (uint32_t)(dim * 4) };
+                std::memcpy(req.data(), head, 16);
+                std::memcpy(req.data() + 16, q, dim * 4);
+                c.t0 = Clock::now();
+                c.in.clear();
+                size_t off = 0;
+                while(off < req.size()) {
+                    const ssize_t r = ::send(c.fd, req.data() + off, req.size() - off, MSG_NOSIGNAL);
+                    if(r <= 0) return false;
+                    off += (size_t)r;
+                }
+                return true;
+            };
+            for(size_t i = 0; i < cls.size(); ++i) {
+                Cl &c = cls[ i ];
+                c.pick.seed((unsigned)(lo + i) * 7919u + 13u);
+                c.fd = ::socket(AF_INET, SOCK_STREAM, 0);
+                sockaddr_in a;
+                std::memset(&a, 0, sizeof(a));
+                a.sin_family = AF_INET;
+                a.sin_port = htons((uint16_t)port);
+                ::inet_pton(AF_INET, "127.0.0.1", &a.sin_addr);
+                if(c.fd < 0 || ::connect(c.fd, (sockaddr *)&a, sizeof(a)) != 0) { failures++; if(c.fd >= 0) ::close(c.fd); c.fd = -1; continue; }
+                int one = 1;
+                ::setsockopt(c.fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+                connected++;
+                epoll_event ev;
+                std::memset(&ev, 0, sizeof(ev));
+                ev.events = EPOLLIN;
+                ev.data.u64 = i;
+                ::epoll_ctl(ep, EPOLL_CTL_ADD, c.fd, &ev);
+                if(!send_next(c)) failures++;
+            }
+            auto &mylat = lat[ lo < lat.size() ? lo : 0 ];
+            mylat.reserve(1 << 20);
+            epoll_event evs[ 256 ];
+            const size_t full = 12 + k * 12;  // an answer with k rows
+            while(phase.load(std::memory_order_relaxed) < 2) {
+                const int n = ::epoll_wait(ep, evs, 256, 50);
+                for(int e = 0; e < n; ++e) {
+                    Cl     &c = cls[ evs[ e ].data.u64 ];
+                    uint8_t tmp[ 4096 ];
+                    const ssize_t r = ::recv(c.fd, tmp, std::min(sizeof(tmp), full - c.in.size()), MSG_DONTWAIT);
+                    if(r <= 0) { if(r == 0 || (errno != EAGAIN && errno != EINTR)) { failures++; ::epoll_ctl(ep, EPOLL_CTL_DEL, c.fd, nullptr); } continue; }
+                    c.in.insert(c.in.end(), tmp, tmp + r);
+                    if(c.in.size() < 12) continue;
+                    uint32_t rep[ 3 ];
+                    std::memcpy(rep, c.in.data(), 12);
+                    if(rep[ 0 ] != 0x5052534Cu || rep[ 1 ] != 0 || rep[ 2 ] != k) { failures++; ::epoll_ctl(ep, EPOLL_CTL_DEL, c.fd, nullptr); continue; }
+                    if(c.in.size() < full) continue;
+                    if(phase.load(std::memory_order_relaxed) == 1)
+                        mylat.push_back((uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - c.t0).count());
+                    if(!send_next(c)) { failures++; ::epoll_ctl(ep, EPOLL_CTL_DEL, c.fd, nullptr); }
+                }
+            }
+            for(Cl &c : cls)
+                if(c.fd >= 0) ::close(c.fd);
+            ::close(ep);
+        });
+    }
+    for(size_t c = 0; client_threads == 0 && c < connections; ++c) {
         threads.emplace_back([&, c] {
             usearch_error_t          e = nullptr;
             lantern_scan_client_t   *cl = lantern_scan_client_connect("127.0.0.1", port, &e);
@@ -123,10 +210,10 @@ int main(int argc, char **argv)
     for(uint32_t x : all) mean += x;
     mean = all.empty() ? 0 : mean / (double)all.size();
     std::printf("{\"tool\": \"lantern-scan-load\", \"index\": \"%zux%zu f32 l2sq M=%zu ef_construction=%zu ef=%zu\", \"k\": %zu, \"connections\": %zu, "
-                "\"connected\": %zu, \"max_batch\": %zu, \"max_wait_us\": %u, \"seconds\": %.3f, \"queries\": %zu, \"queries_per_s\": %.1f, "
+                "\"connected\": %zu, \"client_threads\": %zu, \"max_batch\": %zu, \"max_wait_us\": %u, \"seconds\": %.3f, \"queries\": %zu, \"queries_per_s\": %.1f, "
                 "\"latency_us\": {\"mean\": %.1f, \"p50\": %u, \"p90\": %u, \"p99\": %u, \"max\": %u}, \"failures\": %zu, "
                 "\"service\": {\"requests\": %llu, \"batches\": %llu, \"launches\": %llu, \"mean_batch\": %.1f, \"largest_batch\": %llu, \"batch_size_histogram\": {",
-                rows, dim, m, efc, ef, k, connections, connected.load(), max_batch, wait_us, elapsed, all.size(), (double)all.size() / elapsed, mean, pct(0.5), pct(0.9),
+                rows, dim, m, efc, ef, k, connections, connected.load(), client_threads, max_batch, wait_us, elapsed, all.size(), (double)all.size() / elapsed, mean, pct(0.5), pct(0.9),
                 pct(0.99), all.empty() ? 0u : all.back(), failures.load(), (unsigned long long)(r1 - r0), (unsigned long long)(b1 - b0),
                 (unsigned long long)(l1 - l0), b1 > b0 ? (double)(r1 - r0) / (double)(b1 - b0) : 0.0, (unsigned long long)big);
     bool first = true;
