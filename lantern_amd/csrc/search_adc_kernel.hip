@@ -70,83 +70,111 @@ __device__ __forceinline__ void adc_build_table(float *lut, const float *centers
 // neighbour lists fetched with the rows).  A table of 96 x 256 entries leaves room for ONE workgroup per CU, so every query of
 // a batch walks alone on its CU whatever the batch size: the walk that is fastest alone is the one to run.
 template <int METRIC, int KPL, bool SPEC = false>
-__global__ void __launch_bounds__(SPEC ? 704 : 512, SPEC ? 1 : 2) k_search_adc(SearchArgs a)
+__global__ void __launch_bounds__(SPEC ? 704 : 512, SPEC ? 1 : 2) k_search_adc(SearchArgs)
 {
+    // (arguments are re-read from the kernarg segment where a query needs them, as in k_search -- search_kernel.hpp: kept live
+    // across the persistent loop they cost the hop loop ~120 scalar-register spill reloads)
     constexpr int G = 8;  // rows are at most 8 chunks (128 codes)
     const int     tid = threadIdx.x, T = blockDim.x;
-    const uint32_t S = a.adc_S, C = a.adc_C, subdim = a.adc_subdim, sub_floats = ((subdim + 3) / 4) * 4, qchunks = a.adc_qchunks;
-    const uint32_t S16 = a.view.chunks * 16, lut_chunks = S16 * ADC_LUT_STRIDE / 4;
-    WalkLds        s;
-    SpecLds        sc;
+    WalkLds       s;
+    SpecLds       sc;
+    uint32_t      lut_chunks;
     {
-        unsigned char *end = carve_walk(lgpu_smem, s, lut_chunks + qchunks, a.ef, a.view.M0, a.vis_slots);  // s.q = the table, then the raw query row
-        if constexpr(SPEC) carve_spec(end, sc, a.view.M0, a.spec_prefetch, a.spec_cache);
+        const KernargBytes ka = kernarg_opaque();
+        lut_chunks = LGPU_VIEW_ARG(ka, SearchArgs, chunks) * 16 * ADC_LUT_STRIDE / 4;
+        unsigned char *end = carve_walk(lgpu_smem, s, lut_chunks + LGPU_SEARCH_ARG(ka, adc_qchunks), LGPU_SEARCH_ARG(ka, ef), LGPU_VIEW_ARG(ka, SearchArgs, M0),
+                                        LGPU_SEARCH_ARG(ka, vis_slots));  // s.q = the table, then the raw query row
+        if constexpr(SPEC) carve_spec(end, sc, LGPU_VIEW_ARG(ka, SearchArgs, M0), LGPU_SEARCH_ARG(ka, spec_prefetch), LGPU_SEARCH_ARG(ka, spec_cache));
         else (void)end;
     }
     float *const       lut = (float *)s.q;
     const uint4 *const rawq4 = s.q + lut_chunks;
     const float *const rawq = (const float *)rawq4;
-    uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
-    for(uint32_t q = blockIdx.x; q < a.nq;) {
+    for(uint32_t q = blockIdx.x; q < LGPU_SEARCH_ARG(kernarg_opaque(), nq);) {
         uint32_t D = 0, E = 0;
         int      cnt = 0;
-        for(uint32_t i = tid; i < qchunks; i += T) ((uint4 *)rawq4)[ i ] = a.queries[ (size_t)q * qchunks + i ];
-        __syncthreads();
-        // entry 0 of the padding rows is +0.0
-        adc_build_table<METRIC, 4>(lut, a.adc_centers, rawq, S, C, subdim, sub_floats, (uint32_t)tid, (uint32_t)T);  // (8 and 16 at a time: no faster)
-        for(uint32_t sv = S + tid; sv < S16; sv += T) lut[ (size_t)sv * ADC_LUT_STRIDE ] = 0.f;
-        if constexpr(METRIC == M_COS_ADC) {  // |query|: the chain and tree the f32 cosine kernels use for a row of this many chunks
-            const int Gq = group_lanes_for(qchunks);
-            if(tid < Gq) {
-                float qn;
-                switch(Gq) {
-                    case 64: qn = group_norm<M_COS, 64>(rawq4, (int)qchunks, tid); break;
-                    case 32: qn = group_norm<M_COS, 32>(rawq4, (int)qchunks, tid); break;
-                    case 16: qn = group_norm<M_COS, 16>(rawq4, (int)qchunks, tid); break;
-                    default: qn = group_norm<M_COS, 8>(rawq4, (int)qchunks, tid); break;
+        {
+            const KernargBytes ka = kernarg_opaque();
+            const uint32_t     S = LGPU_SEARCH_ARG(ka, adc_S), C = LGPU_SEARCH_ARG(ka, adc_C), subdim = LGPU_SEARCH_ARG(ka, adc_subdim),
+                           sub_floats = ((subdim + 3) / 4) * 4, qchunks = LGPU_SEARCH_ARG(ka, adc_qchunks), S16 = LGPU_VIEW_ARG(ka, SearchArgs, chunks) * 16;
+            const uint4 *queries = LGPU_SEARCH_ARG(ka, queries);
+            for(uint32_t i = tid; i < qchunks; i += T) ((uint4 *)rawq4)[ i ] = queries[ (size_t)q * qchunks + i ];
+            __syncthreads();
+            // entry 0 of the padding rows is +0.0
+            adc_build_table<METRIC, 4>(lut, LGPU_SEARCH_ARG(ka, adc_centers), rawq, S, C, subdim, sub_floats, (uint32_t)tid, (uint32_t)T);  // (8 and 16 at a time: no faster)
+            for(uint32_t sv = S + tid; sv < S16; sv += T) lut[ (size_t)sv * ADC_LUT_STRIDE ] = 0.f;
+            if constexpr(METRIC == M_COS_ADC) {  // |query|: the chain and tree the f32 cosine kernels use for a row of this many chunks
+                const int Gq = group_lanes_for(qchunks);
+                if(tid < Gq) {
+                    float qn;
+                    switch(Gq) {
+                        case 64: qn = group_norm<M_COS, 64>(rawq4, (int)qchunks, tid); break;
+                        case 32: qn = group_norm<M_COS, 32>(rawq4, (int)qchunks, tid); break;
+                        case 16: qn = group_norm<M_COS, 16>(rawq4, (int)qchunks, tid); break;
+                        default: qn = group_norm<M_COS, 8>(rawq4, (int)qchunks, tid); break;
+                    }
+                    if(tid == Gq - 1) s.scal[ S_QN2 ] = __float_as_int(qn);
                 }
-                if(tid == Gq - 1) s.scal[ S_QN2 ] = __float_as_int(qn);
+            }
+            __syncthreads();
+        }
+        {
+            const KernargBytes ka = kernarg_opaque();
+            View               v;
+            LGPU_LOAD_VIEW(v, ka, SearchArgs)
+            const uint32_t bm_words = LGPU_SEARCH_ARG(ka, bm_words);
+            uint32_t      *bitmap = LGPU_SEARCH_ARG(ka, bitmaps) + (size_t)blockIdx.x * bm_words;
+            const int      ef = (int)LGPU_SEARCH_ARG(ka, ef);
+            if(v.n != 0) {
+                if constexpr(SPEC) {
+                    static_assert(!SPEC || KPL > 0, "the latency-bound walk keeps its list in registers");
+                    const uint32_t start = greedy_descent_spec<METRIC, G>(v, s, v.entry, v.max_level, 0, D);
+                    cnt = search_level_spec<METRIC, G, (KPL > 0 ? KPL : 1), 1, 2, true, false>(v, s, sc, bitmap, bm_words, start, ef, D, E, nullptr);
+                } else {
+                    const uint32_t start = greedy_descent<METRIC, G>(v, s, v.entry, v.max_level, 0, D);
+                    if constexpr(KPL > 0) cnt = search_level_reg<METRIC, G, KPL>(v, s, bitmap, bm_words, start, 0, ef, D, E);
+                    else cnt = search_level<METRIC, G>(v, s, bitmap, bm_words, start, 0, ef, D, E);
+                }
             }
         }
-        __syncthreads();
-        if(a.view.n != 0) {
-            if constexpr(SPEC) {
-                static_assert(!SPEC || KPL > 0, "the latency-bound walk keeps its list in registers");
-                const uint32_t start = greedy_descent_spec<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
-                cnt = search_level_spec<METRIC, G, (KPL > 0 ? KPL : 1), 1, 2, true, false>(a.view, s, sc, bitmap, a.bm_words, start, (int)a.ef, D, E, nullptr);
-            } else {
-                const uint32_t start = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, 0, D);
-                if constexpr(KPL > 0) cnt = search_level_reg<METRIC, G, KPL>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E);
-                else cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, start, 0, (int)a.ef, D, E);
-            }
-        }
-        int got = cnt - (int)a.skip;
-        got = got < 0 ? 0 : (got > (int)a.k ? (int)a.k : got);
-        for(uint32_t i = tid; i < a.k; i += T) {
-            const size_t o = (size_t)q * a.k + i;
+        const KernargBytes kb = kernarg_opaque();
+        const uint32_t     k = LGPU_SEARCH_ARG(kb, k), skip = LGPU_SEARCH_ARG(kb, skip);
+        const uint64_t    *labels = LGPU_SEARCH_ARG(kb, labels);
+        uint64_t          *out_labels = LGPU_SEARCH_ARG(kb, out_labels);
+        float             *out_dists = LGPU_SEARCH_ARG(kb, out_dists);
+        uint32_t          *out_slots = LGPU_SEARCH_ARG(kb, out_slots);
+        int                got = cnt - (int)skip;
+        got = got < 0 ? 0 : (got > (int)k ? (int)k : got);
+        for(uint32_t i = tid; i < k; i += T) {
+            const size_t o = (size_t)q * k + i;
             if((int)i < got) {
-                const uint64_t key = s.keys[ a.skip + i ];
+                const uint64_t key = s.keys[ skip + i ];
                 const uint32_t slot = key_slot(key);
-                if(a.out_labels) a.out_labels[ o ] = a.labels[ slot ];
-                if(a.out_dists) a.out_dists[ o ] = key_dist(key);
-                if(a.out_slots) a.out_slots[ o ] = slot;
+                if(out_labels) out_labels[ o ] = labels[ slot ];
+                if(out_dists) out_dists[ o ] = key_dist(key);
+                if(out_slots) out_slots[ o ] = slot;
             } else {
-                if(a.out_labels) a.out_labels[ o ] = 0;  // INVALID_ELEMENT_LABEL (hnsw.h:40)
-                if(a.out_dists) a.out_dists[ o ] = __builtin_inff();
-                if(a.out_slots) a.out_slots[ o ] = EMPTY;
+                if(out_labels) out_labels[ o ] = 0;  // INVALID_ELEMENT_LABEL (hnsw.h:40)
+                if(out_dists) out_dists[ o ] = __builtin_inff();
+                if(out_slots) out_slots[ o ] = EMPTY;
             }
         }
+        uint32_t *const done = LGPU_SEARCH_ARG(kb, done);
         if(tid == 0) {
-            if(a.out_counts) a.out_counts[ q ] = (uint32_t)got;
-            if(a.out_D) a.out_D[ q ] = D;
-            if(a.out_E) a.out_E[ q ] = E;
-            if(a.totals) { atomicAdd(&a.totals[ 0 ], (unsigned long long)D); atomicAdd(&a.totals[ 1 ], (unsigned long long)E); }
-            s.scal[ S_POS ] = a.ticket ? (int)(gridDim.x + atomicAdd(a.ticket, 1u)) : (int)(q + gridDim.x);
+            uint32_t *const           out_counts = LGPU_SEARCH_ARG(kb, out_counts);
+            uint64_t *const           out_D = LGPU_SEARCH_ARG(kb, out_D), *const out_E = LGPU_SEARCH_ARG(kb, out_E);
+            unsigned long long *const totals = LGPU_SEARCH_ARG(kb, totals);
+            uint32_t *const           ticket = LGPU_SEARCH_ARG(kb, ticket);
+            if(out_counts) out_counts[ q ] = (uint32_t)got;
+            if(out_D) out_D[ q ] = D;
+            if(out_E) out_E[ q ] = E;
+            if(totals) { atomicAdd(&totals[ 0 ], (unsigned long long)D); atomicAdd(&totals[ 1 ], (unsigned long long)E); }
+            s.scal[ S_POS ] = ticket ? (int)(gridDim.x + atomicAdd(ticket, 1u)) : (int)(q + gridDim.x);
         }
         __syncthreads();
-        if(tid == 0 && a.done) {
+        if(tid == 0 && done) {
             __threadfence_system();
-            __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         q = (uint32_t)s.scal[ S_POS ];
         __syncthreads();
