@@ -886,9 +886,10 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         if(can) {
             // (measured, 1M x 768 cosine, one 1024-query batch: the four-wave latency-bound shape 796 k QPS, the classic kernel
             // 819 k -- with every walk of the batch resident the row loads saturate HBM for most of the launch and the speculative
-            // rows cost bandwidth; so spec 1 is chosen only on request, spec 2 whenever every query can have a CU of its own)
+            // rows cost bandwidth; so spec 1 is chosen only on request, spec 2 up to two queries per CU -- one workgroup per CU, the
+            // second query after the first: two workgroups side by side measure the same, 631 vs 627 k at 512 queries)
             if(se) spec = std::atoi(se);
-            else if(nq <= (size_t)ix->num_cus) spec = 2;
+            else if(nq <= (size_t)ix->num_cus * 2) spec = 2;  // (1M x 768 cosine: 384 queries 528 k vs 389 k, 512: 624 k vs 500 k, 768: 658 k vs 691 k)
             if(spec < 0 || spec > 2) spec = 0;
         }
         // (measured, classic kernel, 1M x 768 cosine, 1024 queries: 4 waves 693 k QPS, 6 waves 525 k, 8 waves 594 k -- more waves

@@ -236,10 +236,10 @@ __device__ uint32_t greedy_descent_spec(const View &v, WalkLds &s, uint32_t star
 // add up shader-clock cycles per section of a hop -- [0] decision, [1] neighbour list, [2] issuing the row loads, [3] the role
 // section, [4] loads landing + distances, [5] the wait at the barrier -- and [6] hops into prof[8 * wave + i]; [7] of waves
 // 0 / 3 / 2 counts where the lists came from: staging area | cache | HBM.
-// ROLE >= 0 (dedicated role waves only): the instantiation for ONE role -- 0 visit | 1 list | 2 fill | 3 rows -- with the other
-// roles' sections compiled out.  The four run side by side in one workgroup (search_level_spec below sends each wave to its
-// own), meet at the same barriers, and each keeps only its own role's scalars live: the all-roles-in-one-loop form reloads ~40
-// spilled scalar registers per hop, most of them inside the list wave's merge loop.
+// ROLE >= 0: the instantiation for ONE wave's set of roles -- bits 1 visit | 2 list | 4 fill | 8 rows -- with the other roles'
+// sections compiled out.  The instantiations run side by side in one workgroup (search_level_spec below sends each wave to its
+// own), meet at the same barriers, and each keeps only its own roles' scalars live: the all-roles-in-one-loop form of the
+// dedicated-role shape reloads 43 spilled scalar registers per pass of the hop loop, 41 of them inside the list wave's merge loop.
 template <int METRIC, int G, int KPL, int ROWS, int U, bool DED, bool PROF, int ROLE>
 __device__ int search_level_spec_impl(const View &v, WalkLds &s, const SpecLds &c, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int ef, uint32_t &D,
                                       uint32_t &E, unsigned long long *prof)
@@ -256,9 +256,9 @@ __device__ int search_level_spec_impl(const View &v, WalkLds &s, const SpecLds &
     const int     tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
     const int     wv = __builtin_amdgcn_readfirstlane(tid) >> 6, NW = T >> 6;
     const int     g = lane / G, gl = lane % G;
-    const bool    visit_wave = ROLE >= 0 ? ROLE == 0 : wv == 0, list_wave = ROLE >= 0 ? ROLE == 1 : wv == 1;
-    const bool    fill_wave = ROLE >= 0 ? ROLE == 2 : NW >= 3 ? wv == 2 : wv == 0;  // the cache fill: a third wave if there is one
-    const bool    row_wave = ROLE >= 0 ? ROLE == 3 : DED ? wv >= 3 : true;
+    const bool    visit_wave = ROLE >= 0 ? (ROLE & 1) != 0 : wv == 0, list_wave = ROLE >= 0 ? (ROLE & 2) != 0 : wv == 1;
+    const bool    fill_wave = ROLE >= 0 ? (ROLE & 4) != 0 : NW >= 3 ? wv == 2 : wv == 0;  // the cache fill: a third wave if there is one
+    const bool    row_wave = ROLE >= 0 ? (ROLE & 8) != 0 : DED ? wv >= 3 : true;
     const int     ngroups = (DED ? NW - 3 : NW) * GPW;                  // G-lane groups that evaluate rows
     const int     group = ((DED ? wv - 3 : wv) * GPW) + g;              // this lane's group among them
     const uint32_t M0 = v.M0;
@@ -511,15 +511,22 @@ template <int METRIC, int G, int KPL, int ROWS, int U, bool DED, bool PROF = fal
 __device__ int search_level_spec(const View &v, WalkLds &s, const SpecLds &c, uint32_t *bitmap, uint32_t bm_words, uint32_t start, int ef, uint32_t &D,
                                  uint32_t &E, unsigned long long *prof = nullptr)
 {
-    if constexpr(DED && !PROF) {  // (at least four waves: three roles + rows)
-        const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
-        if(wv == 0) return search_level_spec_impl<METRIC, G, KPL, ROWS, U, DED, PROF, 0>(v, s, c, bitmap, bm_words, start, ef, D, E, prof);
-        if(wv == 1) return search_level_spec_impl<METRIC, G, KPL, ROWS, U, DED, PROF, 1>(v, s, c, bitmap, bm_words, start, ef, D, E, prof);
-        if(wv == 2) return search_level_spec_impl<METRIC, G, KPL, ROWS, U, DED, PROF, 2>(v, s, c, bitmap, bm_words, start, ef, D, E, prof);
-        return search_level_spec_impl<METRIC, G, KPL, ROWS, U, DED, PROF, 3>(v, s, c, bitmap, bm_words, start, ef, D, E, prof);
+#define LGPU_SPEC_ROLE(R) return search_level_spec_impl<METRIC, G, KPL, ROWS, U, DED, PROF, R>(v, s, c, bitmap, bm_words, start, ef, D, E, prof)
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+    if constexpr(PROF) {
+        LGPU_SPEC_ROLE(-1);
+    } else if constexpr(DED) {  // (at least four waves: three role waves, then row waves)
+        if(wv == 0) LGPU_SPEC_ROLE(1);
+        if(wv == 1) LGPU_SPEC_ROLE(2);
+        if(wv == 2) LGPU_SPEC_ROLE(4);
+        LGPU_SPEC_ROLE(8);
     } else {
-        return search_level_spec_impl<METRIC, G, KPL, ROWS, U, DED, PROF, -1>(v, s, c, bitmap, bm_words, start, ef, D, E, prof);
+        // (four waves that all evaluate rows: per-role instantiations were measured too -- 107 -> 30..77 reloads per pass, no gain on
+        // the 1024-query batch it is meant for, twice the compile time -- and left out)
+        (void)wv;
+        LGPU_SPEC_ROLE(-1);
     }
+#undef LGPU_SPEC_ROLE
 }
 
 }  // namespace lgpu

@@ -737,9 +737,9 @@ def test_latency_bound_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef
 
 
 def test_lone_query_and_small_batches_take_the_latency_bound_walk_by_default(capi, oracle):
-    """usearch_search_ef (one query per call), a 100-query and a 700-query batch: the automatic shapes (lone-query shape up to
-    one query per CU, four-wave shape up to four workgroups per CU) -- same answers as the oracle; so has the streaming
-    continuation, which searches for more than k."""
+    """usearch_search_ef (one query per call) and batches around the switch points of the automatic shapes (the lone-query shape up
+    to two queries per CU -- the second after the first on the same workgroup --, the classic four-wave walk beyond) -- same answers
+    as the oracle; so has the streaming continuation, which searches for more than k."""
     rng = np.random.default_rng(5)
     n, d, M = 6000, 128, 16
     base, queries = rng.standard_normal((n, d), dtype=np.float32), rng.standard_normal((700, d), dtype=np.float32)
@@ -750,7 +750,7 @@ def test_lone_query_and_small_batches_take_the_latency_bound_walk_by_default(cap
     for i in range(40):
         l1, d1 = gpu.search(queries[i], 10)
         assert np.array_equal(l1, o_lab[i]) and np.array_equal(d1, o_dist[i]), i
-    for nq in (1, 2, 100, 256, 257, 700):
+    for nq in (1, 2, 100, 256, 257, 512, 513, 700):
         lab, dist, _ = gpu.search_batch(queries[:nq], 10)
         assert np.array_equal(lab, o_lab[:nq]) and np.array_equal(dist, o_dist[:nq]), nq
     # streaming: 10 + 10 + 10 results of one scan = the oracle's top 30 (ef grows with what was handed out)
