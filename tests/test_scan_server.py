@@ -269,6 +269,106 @@ def test_an_idle_connection_stays_open(capi):
     srv.stop()
 
 
+def _raw_request(ident, k, nfloats=2, magic=0x5152534C):
+    import struct
+
+    vec = np.zeros(nfloats, dtype=np.float32)
+    vec[0] = ident
+    return struct.pack("<IIII", magic, k, 0, vec.nbytes) + vec.tobytes()
+
+
+def _raw_reply(sock, k):
+    import struct
+
+    buf = b""
+    while len(buf) < 12:
+        chunk = sock.recv(12 - len(buf))
+        assert chunk, "the server closed the connection"
+        buf += chunk
+    magic, status, count = struct.unpack("<III", buf)
+    assert magic == 0x5052534C
+    body = b""
+    want = count if status else count * 12
+    while len(body) < want:
+        chunk = sock.recv(want - len(body))
+        assert chunk
+        body += chunk
+    if status:
+        return status, body.decode()
+    return 0, np.frombuffer(body[: count * 8], dtype=np.uint64).tolist()
+
+
+def test_requests_in_pieces_back_to_back_and_abandoned(capi):
+    """The server's connections are state machines behind epoll, not blocking readers: a request may arrive a few bytes at a time,
+    two may arrive in one segment (the second waits in the socket until the first is answered), and a client may vanish in the
+    middle of a request -- none of which disturbs the other connections."""
+    import socket
+
+    srv = capi.ScanServer(batch_fn=fake_backend([]), vec_bytes=8, max_batch=16, max_wait_us=500)
+    slow = socket.create_connection((srv.host, srv.port))
+    slow.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+    req = _raw_request(7, 3)
+    for i in range(0, len(req), 5):  # 24 bytes in five pieces
+        slow.sendall(req[i:i + 5])
+        time.sleep(0.02)
+    assert _raw_reply(slow, 3) == (0, [7000, 7001, 7002])
+    # two requests in one write: answered one after the other, in order
+    slow.sendall(_raw_request(8, 2) + _raw_request(9, 4))
+    assert _raw_reply(slow, 2) == (0, [8000, 8001])
+    assert _raw_reply(slow, 4) == (0, [9000, 9001, 9002, 9003])
+    # a client that dies with half a request on the wire
+    gone = socket.create_connection((srv.host, srv.port))
+    gone.sendall(_raw_request(1, 3)[:10])
+    gone.close()
+    # a wrong vector size (error frame, connection survives), then a bad magic (error frame, connection closed)
+    slow.sendall(_raw_request(5, 3, nfloats=3))
+    status, msg = _raw_reply(slow, 3)
+    assert status == 1 and "query of 12 bytes, the index takes 8" in msg
+    slow.sendall(_raw_request(6, 1))
+    assert _raw_reply(slow, 1) == (0, [6000])
+    bad = socket.create_connection((srv.host, srv.port))
+    bad.sendall(_raw_request(1, 3, magic=0x12345678))
+    status, msg = _raw_reply(bad, 3)
+    assert status == 1 and "bad request magic" in msg
+    assert bad.recv(1) == b""  # closed by the server
+    # everybody else is served as if nothing had happened
+    c = capi.ScanClient(srv.host, srv.port)
+    assert c.search(np.array([4, 0], dtype=np.float32), 2)[0].tolist() == [4000, 4001]
+    c.close()
+    slow.close()
+    bad.close()
+    srv.stop()
+
+
+def test_more_connections_than_io_threads_and_idle_ones_do_not_stall_the_window(capi, monkeypatch):
+    """Three I/O threads, forty connections of which thirty never say a word: the active ones are answered within the window
+    (nobody waits for the idle ones beyond it), and every connection is served by the thread it was dealt to."""
+    monkeypatch.setenv("LANTERN_SCAN_IO_THREADS", "3")
+    srv = capi.ScanServer(batch_fn=fake_backend([]), vec_bytes=8, max_batch=64, max_wait_us=2000)
+    idle = [capi.ScanClient(srv.host, srv.port) for _ in range(30)]
+    active = [capi.ScanClient(srv.host, srv.port) for _ in range(10)]
+    out, errs = {}, []
+
+    def session(i):
+        try:
+            for r in range(15):
+                out[(i, r)] = active[i].search(np.array([i * 20 + r, 0], dtype=np.float32), 2)[0].tolist()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=session, args=(i,)) for i in range(10)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    took = time.perf_counter() - t0
+    assert not errs, errs
+    assert all(out[(i, r)] == [(i * 20 + r) * 1000, (i * 20 + r) * 1000 + 1] for i in range(10) for r in range(15))
+    assert took < 15 * 0.2, took  # 15 rounds, each at most the 2 ms window plus the round trip -- not a stall
+    assert idle[0].search(np.array([3, 0], dtype=np.float32), 1)[0].tolist() == [3000]  # an idle one wakes up and is served
+    [c.close() for c in idle + active]
+    srv.stop()
+
+
 def test_server_on_an_index_needs_a_device(capi):
     if capi.device_count() > 0:
         pytest.skip("a device is present")
