@@ -475,7 +475,12 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     prof_mark(ix, 0);
     HIPCHK(ix, launch_batch_layout(ix->d_levels + first, (uint32_t)b, ix->M, d_link_off, d_item_node, ix->stream));
 
-    const int grid = search_grid(ix, b_hi - b_lo, ix->insert_waves, 20);
+    // A handful of insertions -- ldb_aminsert's one row, the first batches of a build -- walk alone on their CUs: level 0 by the
+    // lone-query walk (insert_spec_kernel.hip), up to two insertions per CU one after the other (LANTERN_GPU_INSERT_SPEC=0: off).
+    static const bool ins_spec_env = !(std::getenv("LANTERN_GPU_INSERT_SPEC") && std::atoi(std::getenv("LANTERN_GPU_INSERT_SPEC")) == 0);
+    const bool ins_spec = ins_spec_env && !comm && b_hi - b_lo <= (size_t)ix->num_cus * 2 && insert_spec_supported(ix->mcode, ix->efc, ix->M0) && !lds_list_env();
+    const int  ins_waves = ins_spec ? 11 : ix->insert_waves;
+    const int  grid = ins_spec ? (int)std::max<size_t>(1, std::min<size_t>(b_hi - b_lo, (size_t)ix->num_cus)) : search_grid(ix, b_hi - b_lo, ix->insert_waves, 20);
     if(!ensure_bitmaps(ix, (size_t)grid)) return false;
     if(!order_launch(ix, ix->stream)) return false;  // a search may still be running on a caller's stream
     auto link_at = [&](size_t i) { return i < b ? (size_t)link_off[ i ] : total_links; };
@@ -497,13 +502,20 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     // 768-d / efc 128, enough for the ~3700 nodes such a walk visits at the 3/4 load limit
     uint32_t ivis = 8192;
     if(const char *vs = std::getenv("LANTERN_GPU_INSERT_VIS_SLOTS")) ivis = (uint32_t)std::atoi(vs) / 4 * 4;
-    while(ivis && insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 31 * 1024) ivis = ivis > 256 ? ivis - 256 : 0;
+    const int      G_ = group_lanes_for(ix->chunks), LW_ = G_ >= 32 ? 1 : G_ == 16 ? 2 : 4;  // list words a lane of a row's group fetches
+    ia.spec_prefetch = ins_spec && ix->M0 % (uint32_t)LW_ == 0 && ix->M0 <= (uint32_t)(G_ * LW_) ? 1u : 0u;
+    ia.spec_cache = ia.spec_prefetch ? 128u : 0u;
+    auto ins_lds = [&](uint32_t vis) {
+        return ins_spec ? insert_spec_lds_bytes(ix->chunks, ix->efc, ix->M0, vis, ia.spec_prefetch, ia.spec_cache) : insert_lds_bytes(ix->chunks, ix->efc, ix->M0, vis);
+    };
+    while(ivis && ins_lds(ivis) > (ins_spec ? 96u : 31u) * 1024) ivis = ivis > 256 ? ivis - 256 : 0;  // (one workgroup per CU in the lone-walk shape)
     if(ivis && ivis < 4 * ix->M0) ivis = 0;
     ia.vis_slots = ivis;
     ia.totals = ix->d_totals + 2;
     ia.ticket = next_ticket(ix, b_hi - b_lo, grid, ix->stream);
-    if(insert_lds_bytes(ix->chunks, ix->efc, ix->M0, ivis) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
-    HIPCHK(ix, launch_insert(ix->mcode, ia, ix->insert_waves, grid, ix->stream));
+    if(ins_lds(ivis) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
+    if(ins_spec) HIPCHK(ix, launch_insert_spec(ix->mcode, ia, ins_waves, grid, ix->stream));
+    else HIPCHK(ix, launch_insert(ix->mcode, ia, ix->insert_waves, grid, ix->stream));
     prof_mark(ix, 1);
 
     ConnectArgs ca;

@@ -65,6 +65,7 @@ struct InsertArgs
     unsigned long long *totals;  // [2] cumulative D, E
     uint32_t       *ticket;      // as SearchArgs::ticket, over the batch members
     int             lds_list;    // as SearchArgs::lds_list
+    uint32_t        spec_prefetch, spec_cache;  // the latency-bound form (insert_spec_kernel.hip): as SearchArgs'
 };
 
 // neighbour selection of the new nodes: one item per (new node, level)
@@ -124,6 +125,10 @@ size_t     search_spec_lds_bytes(uint32_t M0, uint32_t prefetch, uint32_t cache_
 hipError_t launch_search_adc(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);  // metric = M_L2SQ_ADC / M_COS_ADC
 size_t     search_adc_lds_bytes(uint32_t code_chunks, uint32_t qchunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots);
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);
+// a handful of insertions (ldb_aminsert, the first batches of a build): level 0 by the lone-query walk (f32 l2sq / cos, efc <= 128)
+bool       insert_spec_supported(int metric, uint32_t efc, uint32_t M0);
+size_t     insert_spec_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0, uint32_t vis_slots, uint32_t prefetch, uint32_t cache_entries);
+hipError_t launch_insert_spec(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream);
 // work: scratch of max_groups x 8 bytes; work_count: one u32 (both device memory)
 hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream);
