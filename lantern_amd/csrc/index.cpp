@@ -835,7 +835,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         if(waves <= 0 && ix->M0 >= 2 && ix->M0 <= 64 && expansion <= 128 && !lds_list_env()) {
             const size_t with_spec = lds + search_spec_lds_bytes(ix->M0, adc_prefetch, adc_cache);
             const char  *se = std::getenv("LANTERN_GPU_ADC_SPEC");
-            adc_spec = with_spec <= 160 * 1024 && (se ? std::atoi(se) != 0 : per_cu == 1);
+            adc_spec = with_spec <= 160 * 1024 && (se ? std::atoi(se) != 0 : (per_cu == 1 || nq <= (size_t)ix->num_cus * 2));  // (small batches: as the f32 walk)
             if(adc_spec) {
                 lds = with_spec;
                 per_cu = 1;
