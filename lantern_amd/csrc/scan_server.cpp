@@ -109,6 +109,7 @@ struct Conn
 struct Done
 {
     Conn                 *c = nullptr;
+    bool                  gone = false;  // the dispatcher answered it itself and the write failed: only the connection's end is left to do
     std::string           error;  // non-empty: an error frame
     std::vector<uint64_t> labels;
     std::vector<float>    dists;
@@ -301,7 +302,7 @@ void io_loop(lantern_scan_server *s, IoThread *t)
             }
             fresh.clear();
             for(Done &d : done) {
-                const bool sent = d.error.empty() ? reply_rows(d.c, d.labels.data(), d.dists.data(), d.labels.size()) : reply_error(d.c->fd, d.error);
+                const bool sent = !d.gone && (d.error.empty() ? reply_rows(d.c, d.labels.data(), d.dists.data(), d.labels.size()) : reply_error(d.c->fd, d.error));
                 if(!sent || !arm(t, d.c, EPOLL_CTL_MOD)) drop(s, t, d.c);  // answered: the connection may speak again
             }
             done.clear();
@@ -371,10 +372,21 @@ void dispatch_loop(lantern_scan_server *s, int lane)
             const int   rc = s->fn(s->fn_ctx, qbuf.data(), nq, s->vec_bytes, k, ef, labels.data(), dists.data(), counts.data(), &err);
             s->n_launches += 1;
             const std::string msg = rc != 0 ? std::string(err ? err : "lantern_scan_server: the batch search failed") : std::string();
+            // A handful of answers the dispatcher writes itself (a disarmed connection has one holder at a time, and this is it):
+            // one thread hand-off less on the path of a lone backend.  Larger batches go back to the I/O threads, whose sends
+            // run side by side.
+            const bool direct = batch.size() <= 8;
             for(size_t j = 0; j < nq; ++j) {  // every answer back to the I/O thread of its connection
                 Done d;
                 d.c = batch[ kv.second[ j ] ];
-                if(rc != 0) {
+                if(direct) {
+                    const bool sent = rc != 0 ? reply_error(d.c->fd, msg)
+                                              : reply_rows(d.c, &labels[ j * k ], &dists[ j * k ], std::min<size_t>(counts[ j ], k));
+                    if(sent && arm(s->io[ (size_t)d.c->io ].get(), d.c, EPOLL_CTL_MOD)) continue;
+                    d.gone = true;  // its I/O thread takes it down
+                }
+                if(d.gone) {
+                } else if(rc != 0) {
                     d.error = msg;
                 } else {
                     const size_t cn = std::min<size_t>(counts[ j ], k);
