@@ -1241,6 +1241,8 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
     if(ix->insert_done) (void)hipEventDestroy(ix->insert_done);
     for(hipStream_t ls : ix->lane_stream)
         if(ls) (void)hipStreamDestroy(ls);
+    for(char *lh : ix->lane_host)
+        if(lh) (void)hipHostFree(lh);
     delete ix;
 }
 
@@ -1561,6 +1563,20 @@ void lantern_gpu_search_batch_device(usearch_index_t h, const void *d_queries, s
         FAIL(e, ix->err.c_str());
 }
 
+// the page-locked staging block `which` (0 / 1: the lanes, 2: lantern_gpu_search_batch), grown on demand; nullptr on failure
+static char *host_stage(Index *ix, int which, size_t need)
+{
+    if(ix->lane_host_bytes[ which ] < need) {
+        if(ix->lane_host[ which ]) (void)hipHostFree(ix->lane_host[ which ]);
+        ix->lane_host[ which ] = nullptr;
+        ix->lane_host_bytes[ which ] = 0;
+        const size_t grow = need + need / 2;
+        if(hipHostMalloc((void **)&ix->lane_host[ which ], grow, hipHostMallocDefault) != hipSuccess) return nullptr;
+        ix->lane_host_bytes[ which ] = grow;
+    }
+    return ix->lane_host[ which ];
+}
+
 void lantern_gpu_search_batch(usearch_index_t h, const void *queries, size_t nq, usearch_scalar_kind_t kind, size_t k, size_t ef,
                               usearch_label_t *labels, float *distances, uint32_t *counts, usearch_error_t *e)
 {
@@ -1573,25 +1589,33 @@ void lantern_gpu_search_batch(usearch_index_t h, const void *queries, size_t nq,
     if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
     const size_t row_words = (size_t)ix->chunks * 4;
     const size_t in_bytes = input_bytes(ix, (int)kind);
-    std::vector<uint32_t> padded(nq * row_words);
+    // queries and answers pass through one page-locked block: one copy up, one down (labels | distances | counts as they lie),
+    // at the link's rate instead of through the runtime's staging of pageable memory
+    const size_t q_bytes = nq * row_words * 4, out_bytes = nq * k * 12 + nq * 4;
+    char *const  hs = host_stage(ix, 2, q_bytes + out_bytes + 64);
+    if(!hs) { FAIL(e, "lantern_gpu: cannot allocate the page-locked staging block"); return; }
+    uint32_t *const padded = (uint32_t *)hs;
+    char *const     h_out = hs + ((q_bytes + 63) & ~(size_t)63);
     for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
-    char *dq = (char *)scratch(ix, 5, nq * row_words * 4);
-    char *dout = (char *)scratch(ix, 6, nq * k * 12 + nq * 4 + 64);
+    char *dq = (char *)scratch(ix, 5, q_bytes);
+    char *dout = (char *)scratch(ix, 6, out_bytes + 64);
     if(!dq || !dout) { FAIL(e, ix->err.c_str()); return; }
     uint64_t *d_lab = (uint64_t *)dout;
     float    *d_dist = (float *)(dout + nq * k * 8);
     uint32_t *d_cnt = (uint32_t *)(dout + nq * k * 12);
-    bool      ok = hipMemcpyAsync(dq, padded.data(), nq * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    bool      ok = hipMemcpyAsync(dq, padded, q_bytes, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     ok = ok && run_search_device(ix, (const uint4 *)dq, nq, k, ef, 0, d_lab, d_dist, nullptr, d_cnt, nullptr, nullptr, ix->stream,
                                  ix->search_waves);
-    ok = ok && hipMemcpyAsync(labels, d_lab, nq * k * 8, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(distances, d_dist, nq * k * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
-    if(counts) ok = ok && hipMemcpyAsync(counts, d_cnt, nq * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(h_out, dout, out_bytes, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
     if(!ok) {
         if(ix->err.empty()) set_err(ix, "lantern_gpu: HIP failure during batched search");
         FAIL(e, ix->err.c_str());
+        return;
     }
+    std::memcpy(labels, h_out, nq * k * 8);
+    std::memcpy(distances, h_out + nq * k * 8, nq * k * 4);
+    if(counts) std::memcpy(counts, h_out + nq * k * 12, nq * 4);
 }
 
 // The same as lantern_gpu_search_batch for a caller that keeps TWO batches in flight (the scan-side service: one dispatcher
@@ -1610,7 +1634,14 @@ void lantern_gpu_search_batch_lane(usearch_index_t h, int lane, const void *quer
     if(!queries || !labels || !distances) { FAIL(e, "lantern_gpu: null buffer"); return; }
     const size_t row_words = (size_t)ix->chunks * 4;
     const size_t in_bytes = input_bytes(ix, (int)kind);
-    std::vector<uint32_t> padded(nq * row_words);  // (chunks and the scalar kind are fixed at init: no lock needed yet)
+    // Queries and answers pass through ONE page-locked block per lane (a lane has one caller at a time): the padded queries go up
+    // in one copy, labels + distances + counts come back in one, both at the link's rate and without the runtime's staging of
+    // pageable memory (four copies of it before: ~40 us of a small batch's ~150).
+    const size_t q_bytes = nq * row_words * 4, out_bytes = nq * k * 12 + nq * 4, need = q_bytes + out_bytes + 64;
+    char *const hs = host_stage(ix, lane, need);
+    if(!hs) { FAIL(e, "lantern_gpu: cannot allocate the lane's page-locked staging block"); return; }
+    uint32_t *const padded = (uint32_t *)hs;  // (chunks and the scalar kind are fixed at init: no lock needed yet)
+    char *const     h_out = hs + ((q_bytes + 63) & ~(size_t)63);
     for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
     hipStream_t st = nullptr;
     bool        ok = true;
@@ -1633,16 +1664,17 @@ void lantern_gpu_search_batch_lane(usearch_index_t h, int lane, const void *quer
         uint64_t *d_lab = (uint64_t *)dout;
         float    *d_dist = (float *)(dout + nq * k * 8);
         uint32_t *d_cnt = (uint32_t *)(dout + nq * k * 12);
-        ok = hipMemcpyAsync(dq, padded.data(), nq * row_words * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = hipMemcpyAsync(dq, padded, q_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
         ok = ok && run_search_device(ix, (const uint4 *)dq, nq, k, ef, 0, d_lab, d_dist, nullptr, d_cnt, nullptr, nullptr, st, ix->search_waves);
-        ok = ok && hipMemcpyAsync(labels, d_lab, nq * k * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
-        ok = ok && hipMemcpyAsync(distances, d_dist, nq * k * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-        if(counts) ok = ok && hipMemcpyAsync(counts, d_cnt, nq * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(h_out, dout, out_bytes, hipMemcpyDeviceToHost, st) == hipSuccess;  // labels | distances | counts, as they lie
         if(!ok) msg = ix->err.empty() ? "lantern_gpu: HIP failure during batched search" : ix->err;
     }
     // the wait is the long part: outside the mutex, so that the other lane can queue its batch meanwhile
     if(hipStreamSynchronize(st) != hipSuccess && ok) { ok = false; msg = "lantern_gpu: HIP failure during batched search"; }
-    if(!ok) FAIL(e, msg.c_str());
+    if(!ok) { FAIL(e, msg.c_str()); return; }
+    std::memcpy(labels, h_out, nq * k * 8);
+    std::memcpy(distances, h_out + nq * k * 8, nq * k * 4);
+    if(counts) std::memcpy(counts, h_out + nq * k * 12, nq * 4);
 }
 
 // ---- distances ------------------------------------------------------------------------------------

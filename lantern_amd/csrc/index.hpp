@@ -85,6 +85,8 @@ struct Index
     void  *d_scratch[ 16 ] = {};  // [12..15]: queries / answers of the two lanes of lantern_gpu_search_batch_lane
     size_t scratch_bytes[ 16 ] = {};
     hipStream_t lane_stream[ 2 ] = { nullptr, nullptr };  // created on first use
+    char       *lane_host[ 3 ] = { nullptr, nullptr, nullptr };  // page-locked staging of queries and answers: the two lanes (one caller each), [2] lantern_gpu_search_batch (under mu)
+    size_t      lane_host_bytes[ 3 ] = { 0, 0, 0 };
 
     // ---- host mirrors ------------------------------------------------------------------------------
     std::vector<uint64_t> labels;
