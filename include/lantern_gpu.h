@@ -474,8 +474,10 @@ LANTERN_GPU_EXPORT void     lantern_index_server_stop(lantern_index_server_t *);
 /* many PostgreSQL backends, coalesced into batched launches.  A backend's ldb_amgettuple          */
 /* (scan.c:167-338) calls lantern_scan_client_search where it calls usearch_search_ef today; the   */
 /* server waits at most `max_wait_us` after the first queued query for company (at most            */
-/* `max_batch` queries per launch), runs one lantern_gpu_search_batch per distinct (k, ef) and     */
-/* routes the answers back.  Wire format: lantern_amd/csrc/scan_server.cpp.                         */
+/* `max_batch` queries per launch; less if every connected backend is already accounted for or    */
+/* a dispatcher's share of them is), runs one lantern_gpu_search_batch per distinct (k, ef) and    */
+/* routes the answers back.  No thread per connection: a few epoll I/O threads                    */
+/* (LANTERN_SCAN_IO_THREADS) carry all sockets.  Wire format: lantern_amd/csrc/scan_server.cpp.    */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct lantern_scan_server lantern_scan_server_t;
 typedef struct lantern_scan_client lantern_scan_client_t;
