@@ -60,6 +60,8 @@ CASES = {
     "c2_gaussian_100k_x_128_l2sq_ratio4": ("l2sq", 1, 100_000, 128, (8192, 4)),    # full 8192-row batches from 32k rows on: heavier contention per list
     "gaussian_160k_x_768_l2sq": ("l2sq", 3, 160_000, 768, (8192, 16)),             # the headline set's first rows (hub-heavy); 8192-row batches from 131k on
     "gaussian_60k_x_768_cos": ("cos", 3, 60_000, 768, (8192, 8)),
+    "c5_gaussian_64k_x_1536_l2sq": ("l2sq", 7, 65_536, 1536, (8192, 4)),           # SURVEY 8d C5 rows (seed 7), 6 KiB rows: k_connect's widest register path,
+                                                                                   # k_revlink_pairs at 384 chunks; full 8192-row batches from 32k rows on
 }
 
 
