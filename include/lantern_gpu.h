@@ -171,6 +171,23 @@ LANTERN_GPU_EXPORT void usearch_update_header(usearch_index_t, char *header136, 
 LANTERN_GPU_EXPORT uint64_t usearch_header_get_entry_slot(char *header136);
 LANTERN_GPU_EXPORT void     usearch_header_set_entry_slot(char *header136, uint64_t slot);
 
+/* Lantern's node-tape helpers (lantern_hnsw/src/hnsw/usearch_storage.hpp:9-23).  They are Lantern's own functions, but the
+ * reference compiles them against usearch's C++ templates (usearch_storage.cpp:2-16: node_at<>), so whatever replaces usearch
+ * brings them: same names, same signatures (`ldb_unaligned_slot_union_t *` = the 6-byte slots of hnsw.h:42-49, returned as
+ * void * here; Lantern keeps its own declaration).  Host-only byte arithmetic over
+ *   [key u64][level u16] { [count u32][slot 6 B x cap] } x (level + 1) [vector bytes]        (validate_index.c:105-226)
+ * Callers: external_index.c:96-97,394-398,488, insert.c:207, delete.c:54-58, utils.c:93. */
+#ifndef HNSW_USEARCH_STORAGE_H
+LANTERN_GPU_EXPORT uint32_t UsearchNodeBytes(const metadata_t *metadata, int vector_bytes, int level);
+LANTERN_GPU_EXPORT void usearch_init_node(metadata_t *meta, char *tape, usearch_key_t key, uint32_t level, uint64_t slot_id,
+                                          void *vector, size_t vector_len);
+LANTERN_GPU_EXPORT uint32_t node_tuple_size(char *node, uint32_t vector_dim, const metadata_t *meta);
+LANTERN_GPU_EXPORT usearch_label_t label_from_node(char *node);
+LANTERN_GPU_EXPORT unsigned long level_from_node(char *node);
+LANTERN_GPU_EXPORT void reset_node_label(char *node);
+LANTERN_GPU_EXPORT void *get_node_neighbors_mut(const metadata_t *meta, char *node, uint32_t level, uint32_t *neighbors_count);
+#endif
+
 /* ------------------------------------------------------------------------------------------ */
 /* (2) batched / device-resident forms                                                         */
 /* ------------------------------------------------------------------------------------------ */

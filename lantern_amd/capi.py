@@ -104,6 +104,8 @@ EXPORTS = [
     "lantern_scan_client_close", "lantern_scan_begin_client",
     "lantern_mirror_acquire", "lantern_mirror_index", "lantern_mirror_version", "lantern_mirror_rebind", "lantern_mirror_advance", "lantern_mirror_release",
     "lantern_mirror_invalidate", "lantern_mirror_set_capacity", "lantern_mirror_stats",
+    # Lantern's node-tape helpers (usearch_storage.hpp:9-23), host-only
+    "UsearchNodeBytes", "usearch_init_node", "node_tuple_size", "label_from_node", "level_from_node", "reset_node_label", "get_node_neighbors_mut",
 ]
 
 # int fn(void *ctx, const void *queries, size_t nq, size_t vec_bytes, size_t k, size_t ef, u64 *labels, f32 *dists, u32 *counts, const char **err)
@@ -236,6 +238,13 @@ def lib() -> C.CDLL:
         "lantern_mirror_invalidate": (None, [u64]),
         "lantern_mirror_set_capacity": (None, [sz]),
         "lantern_mirror_stats": (None, [C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
+        "UsearchNodeBytes": (u32, [C.POINTER(Metadata), i32, i32]),
+        "usearch_init_node": (None, [C.POINTER(Metadata), vp, u64, u32, u64, vp, sz]),
+        "node_tuple_size": (u32, [vp, u32, C.POINTER(Metadata)]),
+        "label_from_node": (u64, [vp]),
+        "level_from_node": (C.c_ulong, [vp]),
+        "reset_node_label": (None, [vp]),
+        "get_node_neighbors_mut": (vp, [C.POINTER(Metadata), vp, u32, C.POINTER(u32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what the header declares
@@ -715,6 +724,22 @@ class Cursor:
             self.close()
         except Exception:
             pass
+
+
+def metadata_for(M: int, dims: int, quantization: int = SCALAR_F32, metric: int = METRIC_L2SQ, pq: bool = False, num_subvectors: int = 0,
+                 num_centroids: int = 0) -> Metadata:
+    """The metadata_t usearch_index_metadata returns for such an index (list sizes in bytes: 4 + 2M*6 at level 0, 4 + M*6 above;
+    usearch_storage.cpp:19-32 reads exactly these), built without an index: node-tape arithmetic needs no device."""
+    import math
+
+    m = Metadata()
+    m.neighbors_bytes, m.neighbors_base_bytes = 4 + M * 6, 4 + 2 * M * 6
+    m.inverse_log_connectivity = 1.0 / math.log(M)
+    m.connectivity, m.dimensions = M, dims
+    o = m.init_options
+    o.metric_kind, o.quantization, o.dimensions, o.connectivity = metric, quantization, dims, M
+    o.pq, o.num_subvectors, o.num_centroids = pq, num_subvectors, num_centroids
+    return m
 
 
 def header_entry_slot(header: bytes) -> int:

@@ -1,10 +1,16 @@
-"""A stand-in for the PostgreSQL side of a Lantern index, for tests: node tapes in "pages" addressed by 6-byte
+"""A stand-in for the PostgreSQL side of a Lantern index, for tests: node tapes in 8 KB pages addressed by 6-byte
 ItemPointers, the retriever callbacks, and the slot rewrite StoreExternalIndex performs on import.
 
-Follows lantern_hnsw/src/hnsw/external_index.c:298-418 (import: node i goes to some (block, offset); every neighbour
-slot -- a u32 sequential id in the low 4 of its 6 bytes -- and the header's entry slot are rewritten to that
+Follows lantern_hnsw/src/hnsw/external_index.c:46-177 (StoreExternalIndexNodes: how node tapes are packed into pages),
+:240-432 (StoreExternalIndex: header page, codebook pages of a pq index, node i goes to some (block, offset); every
+neighbour slot -- a u32 sequential id in the low 4 of its 6 bytes -- and the header's entry slot are rewritten to that
 ItemPointer), :613-697 (retriever / retriever_mut: slot -> pointer to the tape) and usearch_storage.cpp:19-44
 (tape layout; usearch_init_node zeroes a new tape and sets key + level only).
+
+The page arithmetic is PostgreSQL's (bufpage.h / bufpage.c, BLCKSZ 8192): a page starts with a 24-byte PageHeaderData,
+line pointers (ItemIdData, 4 bytes each) grow up from it, items grow down from the special area (here
+MAXALIGN(sizeof(HnswIndexPageSpecialBlock)) = 16 bytes, external_index.h:68-74), every item is stored MAXALIGNed (8).
+An item is an HnswIndexTuple: seqid u32, size u32, then the node tape (external_index.h:76-82).
 """
 from __future__ import annotations
 
@@ -13,10 +19,54 @@ import struct
 
 import numpy as np
 
+BLCKSZ = 8192
+PAGE_HEADER = 24          # SizeOfPageHeaderData
+ITEM_ID = 4               # sizeof(ItemIdData)
+SPECIAL = 16              # MAXALIGN(sizeof(HnswIndexPageSpecialBlock)): three uint32 -> 12 -> 16
+TUPLE_HEADER = 8          # offsetof(HnswIndexTuple, node): seqid u32 + size u32
 
-def item_pointer(i: int) -> int:
-    """ItemPointerData{bi_hi u16, bi_lo u16, posid u16} of the i-th node, as the low 48 bits of a u64."""
-    block, pos = 1 + i // 40, 1 + i % 40
+
+def maxalign(n: int) -> int:
+    return (n + 7) & ~7
+
+
+def pack_nodes(node_sizes, first_block: int = 1):
+    """StoreExternalIndexNodes (external_index.c:46-177) over nodes of the given tape sizes, in order, starting on a fresh
+    page at `first_block`: a new page is begun when PageGetFreeSpace(page) < sizeof(HnswIndexTuple) + node_size (:104) or
+    when PageAddItem refuses the MAXALIGNed item (:151-155).  Returns [(block, offset)] per node and the number of data
+    pages used."""
+    out = []
+    block = first_block - 1
+    lower = upper = 0
+    fresh = True
+    for size in node_sizes:
+        item = TUPLE_HEADER + size
+        assert PAGE_HEADER + ITEM_ID + maxalign(item) + SPECIAL <= BLCKSZ, "node does not fit a page (external_index.c:60)"
+        while True:
+            free = max(0, upper - lower - ITEM_ID) if not fresh else -1    # PageGetFreeSpace: room left after one more line pointer
+            if fresh or free < item:
+                block += 1
+                lower, upper, fresh = PAGE_HEADER, BLCKSZ - SPECIAL, False
+                continue
+            if lower + ITEM_ID > upper - maxalign(item):                   # PageAddItem: InvalidOffsetNumber -> force a new page
+                fresh = True
+                continue
+            lower += ITEM_ID
+            upper -= maxalign(item)
+            out.append((block, (lower - PAGE_HEADER) // ITEM_ID))
+            break
+    return out, (block - first_block + 1 if out else 0)
+
+
+def index_relation_pages(node_sizes, pq: bool = False, dims: int = 0) -> int:
+    """Pages of the whole index relation StoreExternalIndex leaves behind (external_index.c:240-432): the header page, for a
+    pq index ceil(256 * dims * 4 / BLCKSZ) codebook pages (:283-296), then the data pages."""
+    codebook = -(-256 * dims * 4 // BLCKSZ) if pq else 0
+    return 1 + codebook + pack_nodes(node_sizes, 1 + codebook)[1]
+
+
+def item_pointer_of(block: int, pos: int) -> int:
+    """ItemPointerData{bi_hi u16, bi_lo u16, posid u16} as the low 48 bits of a u64."""
     return int.from_bytes(struct.pack("<HHH", block >> 16, block & 0xFFFF, pos), "little")
 
 
@@ -36,6 +86,8 @@ class PageStore:
             tapes.append(bytearray(blob[off:off + size]))
             off += size
         assert off == len(blob)
+        self.placed, self.data_pages = pack_nodes([len(t) for t in tapes])
+        item_pointer = lambda i: item_pointer_of(*self.placed[i])
         for i, t in enumerate(tapes):
             for l, q, cap, cnt in self._lists(t):
                 for j in range(cnt):
@@ -72,8 +124,11 @@ class PageStore:
 
     # ---- what ldb_aminsert does around usearch_add_external (insert.c:182-214) ------------------------------------
     def new_tuple(self, label: int, level: int) -> tuple[int, int]:
-        """PrepareIndexTuple + usearch_init_node: a zeroed tape with key and level set.  Returns (address, slot)."""
-        slot = item_pointer(len(self.order))
+        """PrepareIndexTuple + usearch_init_node: a zeroed tape with key and level set.  Returns (address, slot).
+        (external_index.c:478-560: the tuple goes to the last data page if it fits, else to a new one.)"""
+        sizes = [len(self.pages[s]) for s in self.order] + [self.tape_bytes(level)]
+        self.placed, self.data_pages = pack_nodes(sizes)
+        slot = item_pointer_of(*self.placed[-1])
         buf = C.create_string_buffer(self.tape_bytes(level))
         struct.pack_into("<QH", buf, 0, label, level)
         self.pages[slot] = buf

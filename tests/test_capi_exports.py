@@ -21,7 +21,8 @@ def capi():
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "lantern_gpu.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"LANTERN_GPU_EXPORT[^;(]*?\b((?:usearch|lantern)_[a-z0-9_]+)\s*\(", text)
+    text = text.replace("#define LANTERN_GPU_EXPORT", "")
+    names = re.findall(r"LANTERN_GPU_EXPORT[^;(]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
     assert len(names) > 30
     return sorted(set(names))
 
