@@ -1,5 +1,6 @@
 // comm.cpp -- transports of the work-sharded build's exchange step (see comm.hpp).
 #include "comm.hpp"
+#include "abi_guard.hpp"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -208,7 +209,7 @@ static const char *keep_err(const std::string &s)
 extern "C" {
 
 void lantern_gpu_comm_unique_id(char *id128, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     int ndev = 0;
     if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { FAIL(e, "lantern_gpu: no HIP device available (this library has no CPU fallback)"); return; }
@@ -220,9 +221,10 @@ void lantern_gpu_comm_unique_id(char *id128, usearch_error_t *e)
     static_assert(sizeof(id) == LANTERN_GPU_COMM_ID_BYTES, "unique id size");
     std::memcpy(id128, &id, sizeof(id));
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 lantern_gpu_comm_t *lantern_gpu_comm_init_rccl(int rank, int world, const char *id128, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     if(world < 1 || rank < 0 || rank >= world || !id128) { FAIL(e, "lantern_gpu: bad rank / world / id"); return nullptr; }
     // the device check comes first: a host without a GPU never maps librccl (573 MB, and a process that later imports
@@ -243,9 +245,10 @@ lantern_gpu_comm_t *lantern_gpu_comm_init_rccl(int rank, int world, const char *
     c->nccl_comm = nc;
     return (lantern_gpu_comm_t *)c;
 }
+LANTERN_ABI_CATCH(e)
 
 lantern_gpu_comm_t *lantern_gpu_comm_init_host(int rank, int world, lantern_gpu_allgatherv_fn fn, void *ctx, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     if(world < 1 || rank < 0 || rank >= world || !fn) { FAIL(e, "lantern_gpu: bad rank / world / callback"); return nullptr; }
     Comm *c = new Comm();
@@ -255,9 +258,10 @@ lantern_gpu_comm_t *lantern_gpu_comm_init_host(int rank, int world, lantern_gpu_
     c->fn_ctx = ctx;
     return (lantern_gpu_comm_t *)c;
 }
+LANTERN_ABI_CATCH(e)
 
 void lantern_gpu_comm_init_local(int world, lantern_gpu_comm_t **out, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     if(world < 1 || !out) { FAIL(e, "lantern_gpu: bad world size"); return; }
     auto hub = std::make_shared<LocalHub>();
@@ -273,52 +277,59 @@ void lantern_gpu_comm_init_local(int world, lantern_gpu_comm_t **out, usearch_er
         out[ r ] = (lantern_gpu_comm_t *)c;
     }
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_comm_free(lantern_gpu_comm_t *h)
-{
+try {
     Comm *c = (Comm *)h;
     if(!c) return;
     if(c->rccl && c->nccl_comm) (void)rccl_api()->CommDestroy((ncclComm_t)c->nccl_comm);
     delete c;
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 int lantern_gpu_comm_rank(lantern_gpu_comm_t *h) { return h ? ((Comm *)h)->rank : 0; }
 int lantern_gpu_comm_world(lantern_gpu_comm_t *h) { return h ? ((Comm *)h)->world : 1; }
 
 void lantern_gpu_comm_set_timeout(lantern_gpu_comm_t *h, double seconds)
-{
+try {
     if(h && seconds > 0) ((Comm *)h)->timeout_s = seconds;
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 void lantern_gpu_comm_stats(lantern_gpu_comm_t *h, uint64_t *bytes_received, uint64_t *collectives)
-{
+try {
     Comm *c = (Comm *)h;
     if(bytes_received) *bytes_received = c ? c->bytes_exchanged : 0;
     if(collectives) *collectives = c ? c->collectives : 0;
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 void lantern_gpu_comm_allgatherv_host(lantern_gpu_comm_t *h, void *host_buf, const size_t *offsets, const size_t *counts, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Comm *c = (Comm *)h;
     if(!c || !host_buf || !offsets || !counts) { FAIL(e, "lantern_gpu: bad arguments"); return; }
     if(!c->allgatherv_host(host_buf, offsets, counts)) FAIL(e, c->err.c_str());
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_comm_allgatherv_device(lantern_gpu_comm_t *h, void *device_buf, const size_t *offsets, const size_t *counts, void *stream,
                                         usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Comm *c = (Comm *)h;
     if(!c || !device_buf || !offsets || !counts) { FAIL(e, "lantern_gpu: bad arguments"); return; }
     if(!c->allgatherv_device(device_buf, offsets, counts, (hipStream_t)stream) || !c->wait((hipStream_t)stream)) FAIL(e, c->err.c_str());
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_shard_range(size_t n, int world, int rank, size_t *begin, size_t *end)
-{
+try {
     if(world < 1) world = 1;
     if(begin) *begin = n * (size_t)rank / (size_t)world;
     if(end) *end = n * ((size_t)rank + 1) / (size_t)world;
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 // the whole life of the index; the host keeps only labels/levels (for serialisation) and the
 // buffer of not-yet-inserted vectors.
 #include "index.hpp"
+#include "abi_guard.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -1121,14 +1122,15 @@ extern "C" {
 const char *lantern_gpu_version(void) { return "lantern_gpu 0.1 (gfx950)"; }
 
 int lantern_gpu_device_count(void)
-{
+try {
     int n = 0;
     if(hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+LANTERN_ABI_CATCH(nullptr)
 
 usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     if(!o) { FAIL(e, "lantern_gpu: null init options"); return nullptr; }
     if(o->metric != nullptr) { FAIL(e, "lantern_gpu: custom metric functions are not supported"); return nullptr; }
@@ -1218,9 +1220,10 @@ usearch_index_t usearch_init(usearch_init_options_t *o, float *pq_codebook, usea
     }
     return ix;
 }
+LANTERN_ABI_CATCH(e)
 
 void usearch_free(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -1245,44 +1248,49 @@ void usearch_free(usearch_index_t h, usearch_error_t *e)
         if(lh) (void)hipHostFree(lh);
     delete ix;
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void usearch_reserve(usearch_index_t h, size_t capacity, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
     std::lock_guard<std::mutex> g(ix->mu);
     if(!reserve_locked(ix, capacity)) FAIL(e, ix->err.c_str());
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 size_t usearch_size(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return 0;
     std::lock_guard<std::mutex> g(ix->mu);
     return logical_size(ix) + ix->pend_labels.size();  // logical size; build.c:117 polls this per tuple
 }
+LANTERN_ABI_CATCH(e)
 
 size_t usearch_capacity(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return 0;
     std::lock_guard<std::mutex> g(ix->mu);
     return std::max(ix->cap, ix->n + ix->pend_labels.size());
 }
+LANTERN_ABI_CATCH(e)
 
 size_t usearch_dimensions(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     return ix ? ix->opts.dimensions : 0;
 }
+LANTERN_ABI_CATCH(e)
 
 static void add_common(Index *ix, const usearch_label_t *labels, const void *vectors, size_t n, usearch_scalar_kind_t kind,
                        int level, usearch_error_t *e)
-{
+try {
     if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the vector does not match the index"); return; }
     if(!vectors || !labels) { FAIL(e, "lantern_gpu: null vector or label pointer"); return; }
     std::lock_guard<std::mutex> g(ix->mu);
@@ -1307,52 +1315,66 @@ static void add_common(Index *ix, const usearch_label_t *labels, const void *vec
         return;
     }
     const size_t base = ix->pend_labels.size();
-    ix->pend_labels.insert(ix->pend_labels.end(), labels, labels + n);
-    ix->pend_levels.insert(ix->pend_levels.end(), n, level);
-    ix->pend_rows.resize((base + n) * row_words);
+    try {
+        ix->pend_labels.insert(ix->pend_labels.end(), labels, labels + n);
+        ix->pend_levels.insert(ix->pend_levels.end(), n, level);
+        ix->pend_rows.resize((base + n) * row_words);
+    } catch(...) {  // an allocation failure half way: the three pending arrays go back to describing the same `base` vectors
+        ix->pend_labels.resize(base);
+        ix->pend_levels.resize(base);
+        ix->pend_rows.resize(base * row_words);
+        throw;      // ... and the caller gets the error string (abi_guard.hpp)
+    }
     for(size_t i = 0; i < n; ++i) pad_row(ix, (const char *)vectors + i * in_bytes, (int)kind, &ix->pend_rows[ (base + i) * row_words ]);
     if(ix->pend_labels.size() >= ix->add_batch_max && !flush_locked(ix)) FAIL(e, ix->err.c_str());
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void usearch_add(usearch_index_t h, usearch_label_t label, const void *vector, usearch_scalar_kind_t kind, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(ix) add_common(ix, &label, vector, 1, kind, -1, e);
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void *lantern_gpu_host_alloc(size_t bytes)
-{
+try {
     void *p = nullptr;
     if(lantern_gpu_device_count() <= 0 || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
     return p;
 }
+LANTERN_ABI_CATCH(nullptr)
+
 void lantern_gpu_host_free(void *p)
-{
+try {
     if(p) (void)hipHostFree(p);
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 void lantern_gpu_add_many(usearch_index_t h, const usearch_label_t *labels, const void *vectors, size_t n,
                           usearch_scalar_kind_t kind, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(ix && n) add_common(ix, labels, vectors, n, kind, -1, e);
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_add_with_level(usearch_index_t h, usearch_label_t label, const void *vector, usearch_scalar_kind_t kind,
                                 int level, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
     if(level < 0 || level > 255) { FAIL(e, "lantern_gpu: level out of range"); return; }
     add_common(ix, &label, vector, 1, kind, level, e);
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_add_sharded(usearch_index_t h, lantern_gpu_comm_t *comm, const usearch_label_t *labels, const void *vectors,
                              size_t n_shard, usearch_scalar_kind_t kind, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -1362,13 +1384,14 @@ void lantern_gpu_add_sharded(usearch_index_t h, lantern_gpu_comm_t *comm, const 
     std::lock_guard<std::mutex> g(ix->mu);
     if(!add_sharded_locked(ix, (Comm *)comm, labels, vectors, n_shard, (int)kind)) FAIL(e, ix->err.c_str());
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // Row-partitioned search (include/lantern_gpu.h): COLLECTIVE.  Every rank searches the SAME queries in its OWN index -- a
 // disjoint share of the rows, built independently -- the per-rank top-k lists are all-gathered in place in HBM (RCCL: over
 // xGMI) and merged on the device by (distance, label).
 void lantern_gpu_search_partitioned(usearch_index_t h, lantern_gpu_comm_t *comm_, const void *queries, size_t nq, usearch_scalar_kind_t kind,
                                     size_t k, size_t ef, usearch_label_t *labels, float *distances, uint32_t *counts, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -1422,9 +1445,10 @@ void lantern_gpu_search_partitioned(usearch_index_t h, lantern_gpu_comm_t *comm_
         FAIL(e, ix->err.c_str());
     }
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 uint64_t lantern_gpu_graph_checksum(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return 0;
@@ -1442,6 +1466,7 @@ uint64_t lantern_gpu_graph_checksum(usearch_index_t h, usearch_error_t *e)
     for(uint32_t v : upper) hsh = splitmix64(hsh ^ v);
     return hsh;
 }
+LANTERN_ABI_CATCH(e)
 
 // the host-side rules a second builder (the test oracle, a CPU fallback on the reference side) must share to
 // reproduce a device build: the stateless level draw and the batch plan (host_util.hpp)
@@ -1449,29 +1474,32 @@ int lantern_gpu_level_for(uint64_t seed, uint64_t slot, uint32_t connectivity) {
 
 size_t lantern_gpu_plan_batch(size_t current_size, int max_level, const int *pending_levels, size_t pending, size_t max_batch,
                               size_t min_ratio)
-{
+try {
     if(!pending_levels) return 0;
     return plan_batch(current_size, max_level, pending_levels, pending, max_batch ? max_batch : 1, min_ratio ? min_ratio : 1);
 }
+LANTERN_ABI_CATCH(nullptr)
 
 void lantern_gpu_flush(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) FAIL(e, ix->err.c_str());
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_set_seed(usearch_index_t h, uint64_t seed, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(ix) ix->seed = seed;
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_set_add_batch(usearch_index_t h, size_t max_batch, size_t min_ratio, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -1480,9 +1508,10 @@ void lantern_gpu_set_add_batch(usearch_index_t h, size_t max_batch, size_t min_r
     ix->add_batch_max = max_batch;
     ix->add_min_ratio = min_ratio;
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_set_search_shape(usearch_index_t h, int waves, int max_wg, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -1491,10 +1520,11 @@ void lantern_gpu_set_search_shape(usearch_index_t h, int waves, int max_wg, usea
     ix->insert_waves = waves ? waves : 4;
     ix->search_max_wg = max_wg;
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 size_t usearch_search_ef(usearch_index_t h, const void *query, usearch_scalar_kind_t kind, size_t k, size_t ef, bool streaming,
                          usearch_label_t *labels, float *distances, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return 0;
@@ -1508,6 +1538,7 @@ size_t usearch_search_ef(usearch_index_t h, const void *query, usearch_scalar_ki
     if(!ix->err.empty()) FAIL(e, ix->err.c_str());
     return out;
 }
+LANTERN_ABI_CATCH(e)
 
 // ---- cursors: the per-scan half of usearch_search_ef's streaming contract ------------------------------------------
 struct lantern_gpu_cursor
@@ -1517,7 +1548,7 @@ struct lantern_gpu_cursor
 };
 
 lantern_gpu_cursor_t *lantern_gpu_cursor_open(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return nullptr;
@@ -1526,10 +1557,11 @@ lantern_gpu_cursor_t *lantern_gpu_cursor_open(usearch_index_t h, usearch_error_t
     c->ix = ix;
     return c;
 }
+LANTERN_ABI_CATCH(e)
 
 size_t lantern_gpu_cursor_search(lantern_gpu_cursor_t *c, const void *query, usearch_scalar_kind_t kind, size_t k, size_t ef,
                                  bool streaming, usearch_label_t *labels, float *distances, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     if(!c) { FAIL(e, "lantern_gpu: null cursor"); return 0; }
     Index *ix = H(c->ix, e);
@@ -1544,6 +1576,7 @@ size_t lantern_gpu_cursor_search(lantern_gpu_cursor_t *c, const void *query, use
     if(!ix->err.empty()) FAIL(e, ix->err.c_str());
     return out;
 }
+LANTERN_ABI_CATCH(e)
 
 size_t lantern_gpu_cursor_seen(lantern_gpu_cursor_t *c) { return c ? c->cur.seen.size() : 0; }
 
@@ -1552,7 +1585,7 @@ void lantern_gpu_cursor_close(lantern_gpu_cursor_t *c) { delete c; }
 void lantern_gpu_search_batch_device(usearch_index_t h, const void *d_queries, size_t nq, size_t k, size_t ef, size_t skip,
                                      uint64_t *d_labels, float *d_distances, uint32_t *d_slots, uint32_t *d_counts,
                                      uint64_t *d_D, uint64_t *d_E, void *stream, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -1562,10 +1595,11 @@ void lantern_gpu_search_batch_device(usearch_index_t h, const void *d_queries, s
                           (hipStream_t)stream, ix->search_waves))
         FAIL(e, ix->err.c_str());
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // the page-locked staging block `which` (0 / 1: the lanes, 2: lantern_gpu_search_batch), grown on demand; nullptr on failure
 static char *host_stage(Index *ix, int which, size_t need)
-{
+try {
     if(ix->lane_host_bytes[ which ] < need) {
         if(ix->lane_host[ which ]) (void)hipHostFree(ix->lane_host[ which ]);
         ix->lane_host[ which ] = nullptr;
@@ -1576,10 +1610,11 @@ static char *host_stage(Index *ix, int which, size_t need)
     }
     return ix->lane_host[ which ];
 }
+LANTERN_ABI_CATCH(nullptr)
 
 void lantern_gpu_search_batch(usearch_index_t h, const void *queries, size_t nq, usearch_scalar_kind_t kind, size_t k, size_t ef,
                               usearch_label_t *labels, float *distances, uint32_t *counts, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -1617,6 +1652,7 @@ void lantern_gpu_search_batch(usearch_index_t h, const void *queries, size_t nq,
     std::memcpy(distances, h_out + nq * k * 8, nq * k * 4);
     if(counts) std::memcpy(counts, h_out + nq * k * 12, nq * 4);
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // The same as lantern_gpu_search_batch for a caller that keeps TWO batches in flight (the scan-side service: one dispatcher
 // executes a batch while the other collects the next): each lane has its own stream and staging buffers, the index mutex is
@@ -1624,7 +1660,7 @@ void lantern_gpu_search_batch(usearch_index_t h, const void *queries, size_t nq,
 // lanes' launches overlap on the device (each in its own visited-bitmap slab: acquire_search_slot).
 void lantern_gpu_search_batch_lane(usearch_index_t h, int lane, const void *queries, size_t nq, usearch_scalar_kind_t kind, size_t k, size_t ef,
                                    usearch_label_t *labels, float *distances, uint32_t *counts, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -1676,6 +1712,7 @@ void lantern_gpu_search_batch_lane(usearch_index_t h, int lane, const void *quer
     std::memcpy(distances, h_out + nq * k * 8, nq * k * 4);
     if(counts) std::memcpy(counts, h_out + nq * k * 12, nq * 4);
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // ---- distances ------------------------------------------------------------------------------------
 
@@ -1683,7 +1720,7 @@ static bool metric_ok(usearch_metric_kind_t m) { return m == usearch_metric_cos_
 
 void lantern_gpu_distance_matrix(const void *a, size_t na, const void *b, size_t nb, usearch_scalar_kind_t kind, size_t dims,
                                  usearch_metric_kind_t metric, int exact_order, float *out, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     if(!metric_ok(metric)) { FAIL(e, "lantern_gpu: unsupported metric kind (expected cos, l2sq or hamming)"); return; }
     const bool ham = metric == usearch_metric_hamming_k;
@@ -1720,18 +1757,20 @@ void lantern_gpu_distance_matrix(const void *a, size_t na, const void *b, size_t
     if(dn) (void)hipFree(dn);
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in distance_matrix");
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 float usearch_distance(const void *a, const void *b, usearch_scalar_kind_t kind, size_t dims, usearch_metric_kind_t metric,
                        usearch_error_t *e)
-{
+try {
     float out = 0.f;
     lantern_gpu_distance_matrix(a, 1, b, 1, kind, dims, metric, 1, &out, e);
     return out;
 }
+LANTERN_ABI_CATCH(e)
 
 void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uint32_t *slots, size_t n, float *out,
                                  usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix || n == 0) return;
@@ -1753,6 +1792,7 @@ void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uin
     ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in distance_gather");
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // Exact k-NN of nq device-resident query rows over nb device-resident base rows (both `chunks` uint4 per row):
 // fp32-MFMA contraction in chunks of 64k base rows + running top-(k+16) + exact-order re-rank.
@@ -1764,7 +1804,7 @@ void lantern_gpu_distance_gather(usearch_index_t h, const void *query, const uin
 static const size_t kSeedCols = 4096, kCandCap = 4096;
 static bool exact_knn_device_impl(int mcode, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
                                   uint32_t *d_slots, float *d_dists, hipStream_t st, bool fused, bool *overflowed)
-{
+try {
     // kk = k plus a margin: the MFMA distances (|q|^2 + |b|^2 - 2 q.b) differ from the exact-order ones in the
     // last bits, so the survivors are re-ranked exactly and only then cut to k
     const uint32_t kk = (uint32_t)k + 16;
@@ -1839,10 +1879,11 @@ static bool exact_knn_device_impl(int mcode, uint32_t chunks, const uint4 *d_bas
     if(fb) (void)hipFree(fb);
     return ok;
 }
+LANTERN_ABI_CATCH(nullptr)
 
 static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
                              uint32_t *d_slots, float *d_dists, hipStream_t st)
-{
+try {
     const char *env = std::getenv("LANTERN_GPU_DENSE_FUSED");  // =0: always the unfused path (A/B, tests)
     const bool  want_fused = !(env && std::atoi(env) == 0);
     bool over = false;
@@ -1850,10 +1891,11 @@ static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, si
     if(!over) return true;
     return exact_knn_device_impl(mcode, chunks, d_base, nb, d_q, nq, k, d_slots, d_dists, st, false, nullptr);
 }
+LANTERN_ABI_CATCH(nullptr)
 
 void lantern_gpu_exact_search(usearch_index_t h, const void *queries, size_t nq, size_t k, uint32_t *slots, float *distances,
                               usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix || nq == 0 || k == 0) return;
@@ -1881,13 +1923,14 @@ void lantern_gpu_exact_search(usearch_index_t h, const void *queries, size_t nq,
     ok = ok && hipMemcpy(distances, d_dists, nq * k * 4, hipMemcpyDeviceToHost) == hipSuccess;
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in exact_search");
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // PQ k-means assignment (product_quantization.c:80-124 assign_to_clusters): the one dense N x k contraction in
 // Lantern's C code -- N x k usearch_distance calls there, one fp32-MFMA pass + exact re-rank here.
 void lantern_gpu_assign_to_clusters(const float *dataset, size_t n, size_t row_dims, size_t subvector_start, size_t subvector_dim,
                                     const float *centers, size_t k, usearch_metric_kind_t metric, uint32_t *out_cluster,
                                     float *out_distance, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     if(metric != usearch_metric_cos_k && metric != usearch_metric_l2sq_k) { FAIL(e, "lantern_gpu: assign_to_clusters needs cos or l2sq"); return; }
     if(!dataset || !centers || !out_cluster || subvector_dim == 0 || subvector_start + subvector_dim > row_dims || k == 0) {
@@ -1915,46 +1958,51 @@ void lantern_gpu_assign_to_clusters(const float *dataset, size_t n, size_t row_d
     if(dout) (void)hipFree(dout);
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in assign_to_clusters");
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // ---- SQL-callable semantics (hnsw.c:296-405) ---------------------------------------------------------
 
 static thread_local char g_dim_msg[ 160 ];
 
 static bool same_dims(int a_dim, int b_dim, usearch_error_t *e)
-{
+try {
     if(a_dim == b_dim) return true;
     // hnsw.c:301-303
     std::snprintf(g_dim_msg, sizeof(g_dim_msg), "expected equally sized arrays but got arrays with dimensions %d and %d", a_dim, b_dim);
     FAIL(e, g_dim_msg);
     return false;
 }
+LANTERN_ABI_CATCH(e)
 
 float lantern_l2sq_dist(const float *a, int a_dim, const float *b, int b_dim, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     if(!same_dims(a_dim, b_dim, e)) return 0.f;
     return usearch_distance(a, b, usearch_scalar_f32_k, (size_t)a_dim, usearch_metric_l2sq_k, e);
 }
+LANTERN_ABI_CATCH(e)
 
 float lantern_cos_dist(const float *a, int a_dim, const float *b, int b_dim, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     if(!same_dims(a_dim, b_dim, e)) return 0.f;
     return usearch_distance(a, b, usearch_scalar_f32_k, (size_t)a_dim, usearch_metric_cos_k, e);
 }
+LANTERN_ABI_CATCH(e)
 
 int32_t lantern_hamming_dist(const int32_t *a, int a_dim, const int32_t *b, int b_dim, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     if(!same_dims(a_dim, b_dim, e)) return 0;
     // hnsw.c:317-319: dims = a_dim * sizeof(int32) * CHAR_BIT bits; result cast to int32 (hnsw.c:375)
     return (int32_t)usearch_distance(a, b, usearch_scalar_b1_k, (size_t)a_dim * 32, usearch_metric_hamming_k, e);
 }
+LANTERN_ABI_CATCH(e)
 
 // ---- metadata / counters / graph exchange --------------------------------------------------------------
 
 metadata_t usearch_index_metadata(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     metadata_t m;
     std::memset(&m, 0, sizeof(m));
@@ -1968,9 +2016,10 @@ metadata_t usearch_index_metadata(usearch_index_t h, usearch_error_t *e)
     m.init_options = ix->opts;
     return m;
 }
+LANTERN_ABI_CATCH(e)
 
 lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     lantern_gpu_counters c;
     std::memset(&c, 0, sizeof(c));
@@ -1991,12 +2040,13 @@ lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t h, usearch_error_t
     c.add_reprunes = t[ 6 ];
     return c;
 }
+LANTERN_ABI_CATCH(e)
 
 // Diagnostics: with `on`, searches run the instrumented instantiation of the walk kernel (f32 l2sq / cos at G = 64 or 16 only)
 // and accumulate shader-clock cycles per phase; out[8] = visited filter + compaction | wait at the first barrier | distances |
 // merge | pop | neighbour-list arrival | upper-level descent | whole query.
 void lantern_gpu_search_phase_profile(usearch_index_t h, int on, unsigned long long *out6 /* [8] */, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -2008,12 +2058,13 @@ void lantern_gpu_search_phase_profile(usearch_index_t h, int on, unsigned long l
     }
     ix->phase_profile = on != 0;
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // the instrumented latency-bound walk (walk_spec.hpp PROF): out32[8 * wave + i], waves 0..3 = visit | list | fill | a row wave;
 // i: 0 decision, 1 neighbour list, 2 issue, 3 role section, 4 loads + distances, 5 barrier wait, 6 hops, 7 list source count
 // (wave 0: staging area, wave 3: cache, wave 2: HBM).  Reading resets the counters.
 void lantern_gpu_spec_profile(usearch_index_t h, int on, unsigned long long *out32, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -2025,18 +2076,20 @@ void lantern_gpu_spec_profile(usearch_index_t h, int on, unsigned long long *out
     }
     ix->spec_profile = on != 0;
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_set_profiling(usearch_index_t h, int on, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
     std::lock_guard<std::mutex> g(ix->mu);
     ix->profiling = on != 0;
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 lantern_gpu_build_profile lantern_gpu_build_profile_get(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     lantern_gpu_build_profile out;
     std::memset(&out, 0, sizeof(out));
@@ -2047,9 +2100,10 @@ lantern_gpu_build_profile lantern_gpu_build_profile_get(usearch_index_t h, usear
     prof_resolve(ix, 0);
     return ix->prof;
 }
+LANTERN_ABI_CATCH(e)
 
 lantern_gpu_graph_info lantern_gpu_graph_info_get(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     lantern_gpu_graph_info gi;
     std::memset(&gi, 0, sizeof(gi));
@@ -2065,10 +2119,11 @@ lantern_gpu_graph_info lantern_gpu_graph_info_get(usearch_index_t h, usearch_err
     gi.vector_words = ix->words;
     return gi;
 }
+LANTERN_ABI_CATCH(e)
 
 void lantern_gpu_export_graph(usearch_index_t h, uint8_t *levels, uint32_t *nbr0, uint32_t *upper_off, uint32_t *upper_nbr,
                               uint64_t *labels, void *vectors, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -2093,30 +2148,33 @@ void lantern_gpu_export_graph(usearch_index_t h, uint8_t *levels, uint32_t *nbr0
     }
     if(!ok) FAIL(e, "lantern_gpu: HIP failure exporting the graph");
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // pq = true indexes: drop / restore the decoded rows (index.hpp pq_compact)
 void lantern_gpu_pq_compact(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
     std::lock_guard<std::mutex> g(ix->mu);
     if(!pq_compact_locked(ix)) FAIL(e, ix->err.c_str());
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_pq_expand(usearch_index_t h, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
     std::lock_guard<std::mutex> g(ix->mu);
     if(!pq_expand_locked(ix)) FAIL(e, ix->err.c_str());
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // HBM held by the index: the vector block (or the code rows of a compact pq index) | everything else that grows with the
 // number of nodes (adjacency, labels, levels, norms, re-prune state, codes)
 void lantern_gpu_memory_usage(usearch_index_t h, size_t *row_bytes, size_t *other_bytes, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -2127,9 +2185,10 @@ void lantern_gpu_memory_usage(usearch_index_t h, size_t *row_bytes, size_t *othe
         *other_bytes = cap * ((size_t)ix->M0 * 4 + 8 + 1 + 4 + 4) + ix->upper_cap * ((size_t)ix->M * 4 + 4) + (ix->d_norm2 ? cap * 4 : 0) +
                        (ix->pq ? cap * (size_t)ix->pq_S : 0);
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_export_codes(usearch_index_t h, uint8_t *codes, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
@@ -2138,16 +2197,18 @@ void lantern_gpu_export_codes(usearch_index_t h, uint8_t *codes, usearch_error_t
     if(!ix->pq) { FAIL(e, "lantern_gpu: not a pq index"); return; }
     if(ix->n && hipMemcpy(codes, ix->d_codes, ix->n * (size_t)ix->pq_S, hipMemcpyDeviceToHost) != hipSuccess) FAIL(e, "lantern_gpu: HIP failure exporting the codes");
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_import_graph(usearch_index_t h, size_t size, const void *vectors, const uint64_t *labels, const uint8_t *levels,
                               const uint32_t *nbr0, const uint32_t *upper_off, const uint32_t *upper_nbr, uint32_t entry_slot,
                               int32_t max_level, usearch_error_t *e)
-{
+try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
     std::lock_guard<std::mutex> g(ix->mu);
     if(!import_graph_locked(ix, size, vectors, labels, levels, nbr0, upper_off, upper_nbr, entry_slot, max_level)) FAIL(e, ix->err.c_str());
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 }  // extern "C"

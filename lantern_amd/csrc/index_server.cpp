@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "../../include/lantern_gpu.h"
+#include "abi_guard.hpp"
 
 namespace {
 
@@ -445,7 +446,7 @@ void status_loop(lantern_index_server *srv)
 extern "C" {
 
 lantern_index_server_t *lantern_index_server_start(const char *host, int port, int status_port, const char *tmp_dir, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     lantern_index_server *s = new lantern_index_server();
     s->tmp_dir = tmp_dir ? tmp_dir : "/tmp";
@@ -463,6 +464,7 @@ lantern_index_server_t *lantern_index_server_start(const char *host, int port, i
     s->accept_thread = std::thread(accept_loop, s);
     return s;
 }
+LANTERN_ABI_CATCH(e)
 
 int lantern_index_server_port(lantern_index_server_t *s) { return s ? s->port : -1; }
 int lantern_index_server_status_port(lantern_index_server_t *s) { return s ? s->status_port : -1; }
@@ -470,7 +472,7 @@ int lantern_index_server_status(lantern_index_server_t *s) { return s ? s->statu
 uint64_t lantern_index_server_served(lantern_index_server_t *s) { return s ? s->served.load() : 0; }
 
 void lantern_index_server_stop(lantern_index_server_t *s)
-{
+try {
     if(!s) return;
     s->stop = true;
     if(s->accept_thread.joinable()) s->accept_thread.join();
@@ -479,5 +481,6 @@ void lantern_index_server_stop(lantern_index_server_t *s)
     if(s->status_fd >= 0) ::close(s->status_fd);
     delete s;
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 }  // extern "C"

@@ -29,6 +29,7 @@
 #include <string>
 
 #include "index.hpp"
+#include "abi_guard.hpp"
 
 struct lantern_mirror
 {
@@ -100,7 +101,7 @@ extern "C" {
 
 lantern_mirror_t *lantern_mirror_acquire(uint64_t relation, uint64_t version, usearch_init_options_t *opts, float *pq_codebook, char *header136,
                                          size_t min_vectors, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     if(!opts || !header136) { if(e) *e = "lantern_gpu: null init options or header"; return nullptr; }
     Cache &c = cache();
@@ -165,25 +166,28 @@ lantern_mirror_t *lantern_mirror_acquire(uint64_t relation, uint64_t version, us
     trim(c);
     return &m;
 }
+LANTERN_ABI_CATCH(e)
 
 usearch_index_t lantern_mirror_index(lantern_mirror_t *m) { return m ? m->index : nullptr; }
 uint64_t        lantern_mirror_version(lantern_mirror_t *m) { return m ? m->version : 0; }
 
 void lantern_mirror_rebind(lantern_mirror_t *m, const usearch_init_options_t *opts)
-{
+try {
     if(m) rebind_retriever((lgpu::Index *)m->index, opts);
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 void lantern_mirror_advance(lantern_mirror_t *m, uint64_t new_version)
-{
+try {
     if(!m) return;
     Cache &c = cache();
     std::lock_guard<std::mutex> g(c.mu);
     m->version = new_version;
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 void lantern_mirror_release(lantern_mirror_t *m)
-{
+try {
     if(!m) return;
     Cache &c = cache();
     std::lock_guard<std::mutex> g(c.mu);
@@ -196,26 +200,29 @@ void lantern_mirror_release(lantern_mirror_t *m)
     m->last_use = ++c.clock;
     trim(c);
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 void lantern_mirror_invalidate(uint64_t relation)
-{
+try {
     Cache &c = cache();
     std::lock_guard<std::mutex> g(c.mu);
     for(auto &m : c.entries)
         if(m.relation == relation) m.stale = true;
     trim(c);
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 void lantern_mirror_set_capacity(size_t max_resident)
-{
+try {
     Cache &c = cache();
     std::lock_guard<std::mutex> g(c.mu);
     c.max_resident = max_resident;
     trim(c);
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 void lantern_mirror_stats(uint64_t *hits, uint64_t *misses, uint64_t *rebuilds, uint64_t *resident)
-{
+try {
     Cache &c = cache();
     std::lock_guard<std::mutex> g(c.mu);
     if(hits) *hits = c.hits;
@@ -223,5 +230,6 @@ void lantern_mirror_stats(uint64_t *hits, uint64_t *misses, uint64_t *rebuilds, 
     if(rebuilds) *rebuilds = c.rebuilds;
     if(resident) *resident = c.entries.size();
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 }  // extern "C"

@@ -62,6 +62,7 @@
 #include <vector>
 
 #include "../../include/lantern_gpu.h"
+#include "abi_guard.hpp"
 
 namespace {
 
@@ -511,7 +512,7 @@ extern "C" {
 
 lantern_scan_server_t *lantern_scan_server_start(usearch_index_t index, const char *host, int port, size_t max_batch, unsigned max_wait_us,
                                                  usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     if(!index) { if(e) *e = "lantern_gpu: null index handle"; return nullptr; }
     usearch_error_t err = nullptr;
@@ -528,10 +529,11 @@ lantern_scan_server_t *lantern_scan_server_start(usearch_index_t index, const ch
     s->lanes = 2;  // lantern_gpu_search_batch_lane
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }
+LANTERN_ABI_CATCH(e)
 
 lantern_scan_server_t *lantern_scan_server_start_fn(lantern_batch_search_fn fn, void *ctx, size_t vec_bytes, const char *host, int port,
                                                     size_t max_batch, unsigned max_wait_us, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     if(!fn || vec_bytes == 0 || vec_bytes > MAX_VEC_BYTES) { if(e) *e = "lantern_gpu: bad scan server arguments"; return nullptr; }
     lantern_scan_server *s = new lantern_scan_server();
@@ -542,26 +544,29 @@ lantern_scan_server_t *lantern_scan_server_start_fn(lantern_batch_search_fn fn, 
     if(const char *ln = std::getenv("LANTERN_SCAN_LANES")) s->lanes = std::atoi(ln) >= 2 ? 2 : 1;
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }
+LANTERN_ABI_CATCH(e)
 
 int lantern_scan_server_port(lantern_scan_server_t *s) { return s ? s->port : -1; }
 
 void lantern_scan_server_stats(lantern_scan_server_t *s, uint64_t *requests, uint64_t *batches, uint64_t *launches, uint64_t *largest_batch)
-{
+try {
     if(requests) *requests = s ? s->n_requests.load() : 0;
     if(batches) *batches = s ? s->n_batches.load() : 0;
     if(launches) *launches = s ? s->n_launches.load() : 0;
     if(largest_batch) *largest_batch = s ? s->max_batch_seen.load() : 0;
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 size_t lantern_scan_server_batch_histogram(lantern_scan_server_t *s, uint64_t *bins, size_t nbins)
-{
+try {
     const size_t n = nbins < 16 ? nbins : 16;
     for(size_t i = 0; i < n; ++i) bins[ i ] = s ? s->batch_hist[ i ].load() : 0;
     return n;
 }
+LANTERN_ABI_CATCH(nullptr)
 
 void lantern_scan_server_stop(lantern_scan_server_t *s)
-{
+try {
     if(!s) return;
     {
         std::lock_guard<std::mutex> g(s->mu);
@@ -591,11 +596,12 @@ void lantern_scan_server_stop(lantern_scan_server_t *s)
     if(s->listen_fd >= 0) ::close(s->listen_fd);
     delete s;
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 // ---- client side: what a backend's ldb_amgettuple calls in place of usearch_search_ef ---------------------------------
 
 lantern_scan_client_t *lantern_scan_client_connect(const char *host, int port, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     int fd = ::socket(AF_INET, SOCK_STREAM, 0);
     sockaddr_in a;
@@ -613,10 +619,11 @@ lantern_scan_client_t *lantern_scan_client_connect(const char *host, int port, u
     c->fd = fd;
     return c;
 }
+LANTERN_ABI_CATCH(e)
 
 static size_t client_request(lantern_scan_client_t *c, uint32_t magic, const void *query, size_t query_bytes, size_t k, size_t ef,
                              usearch_label_t *labels, float *distances, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     if(!c || c->fd < 0) { if(e) *e = "lantern_gpu: the scan client is not connected"; return 0; }
     if(!query || !labels || !distances || k == 0 || k > MAX_K || query_bytes > MAX_VEC_BYTES) { if(e) *e = "lantern_gpu: bad scan client arguments"; return 0; }
@@ -644,22 +651,25 @@ static size_t client_request(lantern_scan_client_t *c, uint32_t magic, const voi
         return fail("lantern_gpu: the scan server went away");
     return count;
 }
+LANTERN_ABI_CATCH(e)
 
 size_t lantern_scan_client_search(lantern_scan_client_t *c, const void *query, size_t query_bytes, size_t k, size_t ef, usearch_label_t *labels,
                                   float *distances, usearch_error_t *e)
-{
+try {
     return client_request(c, REQ_MAGIC, query, query_bytes, k, ef, labels, distances, e);
 }
+LANTERN_ABI_CATCH(e)
 
 // the next k rows of the scan this connection started with lantern_scan_client_search (same query)
 size_t lantern_scan_client_search_next(lantern_scan_client_t *c, const void *query, size_t query_bytes, size_t k, size_t ef,
                                        usearch_label_t *labels, float *distances, usearch_error_t *e)
-{
+try {
     return client_request(c, CONT_MAGIC, query, query_bytes, k, ef, labels, distances, e);
 }
+LANTERN_ABI_CATCH(e)
 
 void lantern_scan_client_close(lantern_scan_client_t *c)
-{
+try {
     if(!c) return;
     if(c->fd >= 0) {
         ::shutdown(c->fd, SHUT_RDWR);
@@ -667,5 +677,6 @@ void lantern_scan_client_close(lantern_scan_client_t *c)
     }
     delete c;
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 }  // extern "C"

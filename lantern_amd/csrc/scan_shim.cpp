@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "index.hpp"
+#include "abi_guard.hpp"
 
 struct lantern_scan
 {
@@ -52,7 +53,7 @@ static size_t scan_search(lantern_scan *s, size_t k, bool streaming, usearch_err
 extern "C" {
 
 lantern_scan_t *lantern_scan_begin(usearch_index_t index, int init_k, int ef, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     if(!index) { if(e) *e = "lantern_gpu: null index handle"; return nullptr; }
     if(init_k < 1 || init_k > 1000) { if(e) *e = "lantern_hnsw.init_k must be in [1, 1000]"; return nullptr; }  // options.c:324-336
@@ -65,9 +66,10 @@ lantern_scan_t *lantern_scan_begin(usearch_index_t index, int init_k, int ef, us
     s->ef = ef;
     return s;
 }
+LANTERN_ABI_CATCH(e)
 
 lantern_scan_t *lantern_scan_begin_client(lantern_scan_client_t *client, size_t query_bytes, int init_k, int ef, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     if(!client || query_bytes == 0) { if(e) *e = "lantern_gpu: null scan-service connection or empty query size"; return nullptr; }
     if(init_k < 1 || init_k > 1000) { if(e) *e = "lantern_hnsw.init_k must be in [1, 1000]"; return nullptr; }
@@ -78,9 +80,10 @@ lantern_scan_t *lantern_scan_begin_client(lantern_scan_client_t *client, size_t 
     s->ef = ef;
     return s;
 }
+LANTERN_ABI_CATCH(e)
 
 void lantern_scan_rescan(lantern_scan_t *s, const void *query, usearch_scalar_kind_t kind, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     if(!s || !query) { if(e) *e = "cannot scan hnsw index without order"; return; }  // scan.c:192
     size_t bytes = s->client_query_bytes;
@@ -95,9 +98,10 @@ void lantern_scan_rescan(lantern_scan_t *s, const void *query, usearch_scalar_ki
     s->armed = true;
     s->count = s->current = 0;
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 bool lantern_scan_gettuple(lantern_scan_t *s, usearch_label_t *label, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     if(!s || !s->armed) { if(e) *e = "cannot scan hnsw index without order"; return false; }
     usearch_error_t err = nullptr;
@@ -130,12 +134,14 @@ bool lantern_scan_gettuple(lantern_scan_t *s, usearch_label_t *label, usearch_er
     }
     return false;
 }
+LANTERN_ABI_CATCH(e)
 
 void lantern_scan_end(lantern_scan_t *s)
-{
+try {
     if(!s) return;
     lantern_gpu_cursor_close(s->cursor);
     delete s;
 }
+LANTERN_ABI_CATCH_VOID(nullptr)
 
 }  // extern "C"

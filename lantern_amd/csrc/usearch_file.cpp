@@ -46,6 +46,7 @@
 #include <vector>
 
 #include "index.hpp"
+#include "abi_guard.hpp"
 
 namespace lgpu {
 
@@ -449,7 +450,7 @@ extern "C" {
 // scan.c:110, insert.c:151.  "Lazy" in usearch (nodes are fetched per hop); here the whole reachable graph is
 // mirrored into HBM once.  A scan-side shim keeps the mirror alive across scans.
 void usearch_view_mem_lazy(usearch_index_t h, char *header136, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
     if(ix) (void)hipSetDevice(ix->device);
@@ -461,10 +462,11 @@ void usearch_view_mem_lazy(usearch_index_t h, char *header136, usearch_error_t *
         if(e) *e = set_err(ix, "lantern_gpu: out of host memory while mirroring the page graph");
     }
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // insert.c:214: write size / max level / entry slot back into the header page copy
 void usearch_update_header(usearch_index_t h, char *header136, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
     if(ix) (void)hipSetDevice(ix->device);
@@ -478,6 +480,7 @@ void usearch_update_header(usearch_index_t h, char *header136, usearch_error_t *
     // (external_index.c:411-418), in a file a sequential id
     if(ix->n) put<uint64_t>(header136, OFF_G_ENTRY_SLOT, ix->page_mode ? ix->page_slots[ ix->entry ] : (uint64_t)ix->entry);
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 // insert.c:209.  `node_tape` is the new node's tape inside a PostgreSQL page, already sized and headed by
 // usearch_init_node (usearch_storage.cpp:34-44); `slot` its 48-bit page slot.  The node is linked into the HBM mirror
@@ -486,7 +489,7 @@ void usearch_update_header(usearch_index_t h, char *header136, usearch_error_t *
 // the nodes it linked to through init_options.retriever_mut (external_index.c:673-697 marks those buffers dirty).
 void usearch_add_external(usearch_index_t h, usearch_label_t label, const void *vector, void *node_tape, usearch_scalar_kind_t kind,
                           int16_t level, uint64_t slot, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
     if(ix) (void)hipSetDevice(ix->device);
@@ -523,13 +526,14 @@ void usearch_add_external(usearch_index_t h, usearch_label_t label, const void *
     }
     if(!write_back_insert(ix, id, (char *)node_tape) && e) *e = ix->err.c_str();
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 
 uint64_t usearch_header_get_entry_slot(char *h) { return get<uint64_t>(h, OFF_G_ENTRY_SLOT); }
 void     usearch_header_set_entry_slot(char *h, uint64_t slot) { put<uint64_t>(h, OFF_G_ENTRY_SLOT, slot); }
 
 size_t usearch_serialized_length(usearch_index_t h, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
     if(ix) (void)hipSetDevice(ix->device);
@@ -538,9 +542,10 @@ size_t usearch_serialized_length(usearch_index_t h, usearch_error_t *e)
     if(!flush_locked(ix)) { if(e) *e = ix->err.c_str(); return 0; }
     return serialized_length(ix);
 }
+LANTERN_ABI_CATCH(e)
 
 void usearch_save_buffer(usearch_index_t h, char *buffer, size_t length, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
     if(ix) (void)hipSetDevice(ix->device);
@@ -552,9 +557,10 @@ void usearch_save_buffer(usearch_index_t h, char *buffer, size_t length, usearch
         if(e) *e = set_err(ix, std::string("lantern_gpu: ") + ex.what());
     }
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void usearch_save(usearch_index_t h, const char *path, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
     if(ix) (void)hipSetDevice(ix->device);
@@ -576,9 +582,10 @@ void usearch_save(usearch_index_t h, const char *path, usearch_error_t *e)
     if(!wrote) { if(e) *e = set_err(ix, std::string("lantern_gpu: cannot write index file ") + path); return; }
     if(!ok && e) *e = ix->err.c_str();
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void lantern_gpu_save_stream(usearch_index_t h, lantern_gpu_write_fn fn, void *ctx, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
     if(ix) (void)hipSetDevice(ix->device);
@@ -593,9 +600,10 @@ void lantern_gpu_save_stream(usearch_index_t h, lantern_gpu_write_fn fn, void *c
         if(e) *e = set_err(ix, std::string("lantern_gpu: ") + ex.what());
     }
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void usearch_load_buffer(usearch_index_t h, const char *buffer, size_t length, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
     if(ix) (void)hipSetDevice(ix->device);
@@ -603,9 +611,10 @@ void usearch_load_buffer(usearch_index_t h, const char *buffer, size_t length, u
     std::lock_guard<std::mutex> g(ix->mu);
     if(!deserialize(ix, buffer, length) && e) *e = ix->err.c_str();
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 void usearch_load(usearch_index_t h, const char *path, usearch_error_t *e)
-{
+try {
     if(e) *e = nullptr;
     Index *ix = (Index *)h;
     if(ix) (void)hipSetDevice(ix->device);
@@ -621,5 +630,6 @@ void usearch_load(usearch_index_t h, const char *path, usearch_error_t *e)
     if(!rd) { if(e) *e = set_err(ix, std::string("lantern_gpu: short read on ") + path); return; }
     usearch_load_buffer(h, buf.data(), buf.size(), e);
 }
+LANTERN_ABI_CATCH_VOID(e)
 
 }  // extern "C"

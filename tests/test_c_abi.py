@@ -40,3 +40,34 @@ def test_c_caller_without_a_device_gets_error_strings(binary):
 def test_c_caller_builds_and_searches_on_the_device(binary):
     p = subprocess.run([binary], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and p.stdout.startswith("ok: 5 results, nearest label 18"), p.stdout + p.stderr
+
+
+def test_allocation_failures_come_back_as_error_strings(tmp_path):
+    """std::bad_alloc / std::length_error inside the library must not cross the C boundary (lantern_amd/csrc/abi_guard.hpp):
+    tests/c_abi/alloc_failure.cpp replaces operator new with one that fails the calling thread's N-th allocation and sweeps N
+    over host-only entry points.  (Matches the reference's own rule: lantern_hnsw/src/hnsw/utils.h:22-25, hnsw.c:341-343.)"""
+    from lantern_amd import build
+
+    lib = build.build()
+    libdir = os.path.dirname(lib)
+    out = str(tmp_path / "alloc_failure")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "alloc_failure.cpp"),
+                           "-o", out, "-L" + libdir, "-llantern_gpu", "-Wl,-rpath," + libdir, "-lpthread"])
+    p = subprocess.run([out], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.startswith("ok:"), p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+def test_absurd_reserve_is_an_error_and_the_index_survives():
+    import numpy as np
+
+    from lantern_amd import capi
+
+    ix = capi.GpuIndex("l2sq", 8, M=4)
+    for cap in ((1 << 64) // 8 - 1, (1 << 31) - 2):  # above the slot range; inside it but far beyond HBM (17 GB of labels alone)
+        with pytest.raises(capi.LanternGpuError):
+            ix.reserve(cap)
+    rows = np.random.default_rng(0).standard_normal((64, 8), dtype=np.float32)
+    ix.add_many(np.arange(64, dtype=np.uint64) + 1, rows)
+    lab, dist = ix.search(rows[5], 1)
+    assert lab[0] == 6 and dist[0] == 0

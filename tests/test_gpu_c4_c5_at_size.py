@@ -207,8 +207,8 @@ def test_c5_batched_build_against_the_sequential_reference_build_at_100k_x_1536(
     ref = capi.GpuIndex("l2sq", C5_D, M=M, ef_construction=EFC, ef=64, seed=42)
     ref.import_graph(base, gs)
     r_seq = oracle.recall_at_k(run(hip, ref, queries, 64)[2], truth)
-    print(f"100k x 1536: recall@10 device-batched build {r_dev:.4f} ({t_dev:.2f} s), sequential reference build {r_seq:.4f} (CPU, {t_seq:.0f} s, "
-          f"{n / t_seq:.0f} vectors/s)")
+    print(f"100k x 1536, {queries.shape[0]} queries: recall@10 device-batched build {r_dev:.4f} ({t_dev:.2f} s), sequential reference build {r_seq:.4f} "
+          f"(CPU, {t_seq:.0f} s, {n / t_seq:.0f} vectors/s)")
     assert abs(r_dev - r_seq) <= 0.005, (r_dev, r_seq)
     gd = dev.export_graph()
     deg_dev = (gd["nbr0"] != 0xFFFFFFFF).sum(axis=1).mean()
