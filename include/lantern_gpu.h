@@ -455,9 +455,11 @@ LANTERN_GPU_EXPORT lantern_mirror_t *lantern_mirror_acquire(uint64_t relation, u
 LANTERN_GPU_EXPORT usearch_index_t lantern_mirror_index(lantern_mirror_t *);
 LANTERN_GPU_EXPORT uint64_t        lantern_mirror_version(lantern_mirror_t *);
 /* The mirror's retriever callbacks (init_options.retriever / retriever_mut / retriever_ctx -- the reference's per-scan,
- * per-insert RetrieverCtx: scan.c:34,132, insert.c:130,247) are those of the LATEST acquire or rebind, and ANY release
- * drops them: no ctx pointer outlives the acquire / release pair that brought it.  A holder that inserts after another
- * holder came or went binds its own again first; usearch_add_external without bound callbacks fails with a message. */
+ * per-insert RetrieverCtx: scan.c:34,132, insert.c:130,247) are kept PER HOLDER, a holder being a host thread (a PostgreSQL
+ * backend is one; a threaded service runs one holder per thread): bound by that thread's acquire or rebind, dropped by that
+ * thread's release -- no ctx pointer outlives the acquire / release pair that brought it, and one holder's release never takes
+ * away another's.  usearch_add_external uses the calling thread's and fails with a message when it has none (a thread that
+ * holds several handles of one mirror and released one of them binds its own again first). */
 LANTERN_GPU_EXPORT void lantern_mirror_rebind(lantern_mirror_t *, const usearch_init_options_t *opts);
 /* the holder applied a change itself (usearch_add_external + usearch_update_header): re-stamp instead of rebuilding */
 LANTERN_GPU_EXPORT void lantern_mirror_advance(lantern_mirror_t *, uint64_t new_version);

@@ -193,16 +193,23 @@ bool pq_compact_locked(Index *ix)
 bool pq_expand_locked(Index *ix)
 {
     if(!ix->pq_compact) return true;
-    const size_t row = (size_t)ix->chunks * 16;
-    if(hipMalloc((void **)&ix->d_vec, std::max<size_t>(ix->cap, 1) * row) != hipSuccess) {
-        ix->d_vec = nullptr;
+    // decode into a buffer of its own: the index stays compact -- and searchable by ADC -- unless every step succeeded
+    const size_t row = (size_t)ix->chunks * 16, bytes = std::max<size_t>(ix->cap, 1) * row;
+    void        *fresh = nullptr;
+    if(hipMalloc(&fresh, bytes) != hipSuccess) {
         set_err(ix, "lantern_gpu: out of device memory (decoding a compact pq index)");
         return false;
     }
+    ix->d_vec = (uint4 *)fresh;  // pq_decode_rows writes through the index's view
+    const bool ok = hipMemsetAsync(fresh, 0, bytes, ix->stream) == hipSuccess && pq_decode_rows(ix, 0, ix->n) &&
+                    hipStreamSynchronize(ix->stream) == hipSuccess;
+    if(!ok) {
+        ix->d_vec = nullptr;
+        (void)hipFree(fresh);
+        if(ix->err.empty()) set_err(ix, "lantern_gpu: HIP failure while decoding a compact pq index");
+        return false;
+    }
     ix->pq_compact = false;
-    HIPCHK(ix, hipMemsetAsync(ix->d_vec, 0, std::max<size_t>(ix->cap, 1) * row, ix->stream));
-    if(!pq_decode_rows(ix, 0, ix->n)) return false;
-    HIPCHK(ix, hipStreamSynchronize(ix->stream));
     if(ix->d_codes16) { (void)hipFree(ix->d_codes16); ix->d_codes16 = nullptr; }
     return true;
 }
@@ -1061,6 +1068,7 @@ bool import_graph_locked(Index *ix, size_t size, const void *vectors, const uint
 {
     if(ix->n || !ix->pend_labels.empty()) { set_err(ix, "lantern_gpu: import needs an empty index"); return false; }
     if(size == 0) return true;
+    if(!pq_expand_locked(ix)) return false;  // an empty index that was compacted has no row block: the import writes rows
     size_t blocks = 0;
     for(size_t i = 0; i < size; ++i) blocks += levels[ i ];
     if(!reserve_locked(ix, std::max(size, ix->cap)) || !reserve_upper(ix, blocks)) return false;

@@ -5,6 +5,7 @@
 #include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <functional>
@@ -127,6 +128,19 @@ struct Index
     size_t                                 page_declared = 0, page_attach_n = 0;
     std::vector<uint64_t>                  page_slots;
     std::unordered_map<uint64_t, uint32_t> page_ids;
+    // A mirror kept by the cache (mirror_cache.cpp) outlives the RetrieverCtx it was built with and is shared by holders that
+    // each bring their own (scan.c:34,132, insert.c:130,247): its callbacks are looked up PER HOLDER -- a holder is a host
+    // thread (a PostgreSQL backend is one; a threaded service runs one holder per thread) -- instead of in `opts`.
+    struct HolderBinding { usearch_node_retriever_t retriever = nullptr, retriever_mut = nullptr; void *ctx = nullptr; };
+    bool                                               holder_bound = false;  // true: `holders` decides, `opts.retriever*` are unused
+    std::unordered_map<std::thread::id, HolderBinding> holders;
+    // the calling thread's callbacks (ix->mu held)
+    HolderBinding current_holder() const
+    {
+        if(!holder_bound) return HolderBinding{ opts.retriever, opts.retriever_mut, opts.retriever_ctx };
+        auto it = holders.find(std::this_thread::get_id());
+        return it == holders.end() ? HolderBinding{} : it->second;
+    }
 
     // ---- single-query path (usearch_search_ef): one pinned, device-mapped block [query row | labels | distances |
     // slots | count] -- the kernel reads the query from it and writes the answer into it, so a lone query costs one

@@ -141,7 +141,7 @@ void serve(lantern_index_server *srv, int fd)
     usearch_index_t index = nullptr;
     usearch_error_t err = nullptr;
     std::string     failure;
-    bool            failed = false;
+    bool            failed = false, length_sent = false;
     try {
         uint32_t hello[ 2 ] = { PROTOCOL_VERSION, SERVER_TYPE };
         write_all(fd, hello, 8);
@@ -353,6 +353,7 @@ void serve(lantern_index_server *srv, int fd)
         if(err) throw Fail{ err };
         const uint64_t len64 = len;
         write_all(fd, &len64, 8);
+        length_sent = true;  // from here on the client reads `len64` bytes of index file: a failure may only cut the stream short
         // the file goes out as it is formatted: node prefixes + vector bytes from page-locked row chunks, gathered by sendmsg
         // (r2 built the whole 6.4 GB file in memory first: 5 of the 9 s of a 1M x 1536 build)
         int sink_fd = fd;
@@ -369,8 +370,11 @@ void serve(lantern_index_server *srv, int fd)
         failure = "indexing server: unexpected failure";
         failed = true;
     }
-    if(failed) {
-        set_status(srv, FAILED);
+    if(failed) set_status(srv, FAILED);
+    // An error frame is only a frame BEFORE the file length has gone out (the reference builds the whole file first, so its
+    // failures always arrive as clean frames: server.rs:382-435).  Once the client is reading file bytes, anything appended
+    // would be parsed as node tapes: the stream is simply closed and the client sees a short read.
+    if(failed && !length_sent) {
         uint8_t        out[ 8 ];
         const uint32_t hdr = ERR_MSG, n = (uint32_t)failure.size();
         std::memcpy(out, &hdr, 4);

@@ -13,8 +13,10 @@
 //             same relation, another version -> a fresh mirror replaces it (the stale one is freed when its last user
 //             releases it); unknown relation -> a mirror is built (usearch_init + usearch_view_mem_lazy)
 //   callbacks the retriever / retriever_mut / retriever_ctx of the caller's init options are the reference's per-scan, per-insert
-//             RetrieverCtx (scan.c:34,132, insert.c:130,247): the mirror carries the LATEST acquirer's (or rebind's) and drops
-//             them at any release -- no ctx pointer outlives the acquire / release pair that brought it
+//             RetrieverCtx (scan.c:34,132, insert.c:130,247).  The mirror keeps them PER HOLDER -- a holder is a host thread: a
+//             PostgreSQL backend is one, a threaded service runs one holder per thread -- bound by that thread's acquire /
+//             rebind and dropped by that thread's release: no ctx pointer outlives the acquire / release pair that brought
+//             it, and one holder's release never takes away another's (usearch_add_external looks up the CALLING thread's)
 //   advance   the holder of a mirror that applied a change itself (usearch_add_external + usearch_update_header in
 //             ldb_aminsert) re-stamps it instead of forcing a rebuild
 //   invalidate  DROP INDEX / REINDEX / VACUUM: the relation's mirror goes as soon as nobody holds it
@@ -54,14 +56,19 @@ Cache &cache()
     return c;
 }
 
-// the mirror's callbacks become this holder's (NULL opts: nobody's -- no ctx pointer outlives an acquire / release pair)
+// the calling thread's callbacks on this mirror (NULL opts: it has none any more).  Takes the INDEX's lock, so it is never
+// called under the cache lock: a long operation on one mirror must not hold up acquire / release of every other relation.
 void rebind_retriever(lgpu::Index *ix, const usearch_init_options_t *opts)
 {
     if(!ix) return;
     std::lock_guard<std::mutex> g(ix->mu);
-    ix->opts.retriever = opts ? opts->retriever : nullptr;
-    ix->opts.retriever_mut = opts ? opts->retriever_mut : nullptr;
-    ix->opts.retriever_ctx = opts ? opts->retriever_ctx : nullptr;
+    ix->holder_bound = true;
+    ix->opts.retriever = ix->opts.retriever_mut = nullptr;  // the RetrieverCtx the mirror was built with is not ours to keep
+    ix->opts.retriever_ctx = nullptr;
+    if(opts && (opts->retriever || opts->retriever_mut))
+        ix->holders[ std::this_thread::get_id() ] = lgpu::Index::HolderBinding{ opts->retriever, opts->retriever_mut, opts->retriever_ctx };
+    else
+        ix->holders.erase(std::this_thread::get_id());
 }
 
 void destroy(lantern_mirror &m)
@@ -106,18 +113,25 @@ try {
     if(!opts || !header136) { if(e) *e = "lantern_gpu: null init options or header"; return nullptr; }
     Cache &c = cache();
     {
-        std::lock_guard<std::mutex> g(c.mu);
-        for(auto &m : c.entries) {
-            if(m.relation == relation && !m.stale && m.version == version) {
-                // The reference allocates its RetrieverCtx per scan and per insert and frees it at the end (scan.c:34,132,
-                // insert.c:130,247): the callbacks and the ctx a mirror was BUILT with are gone by now.  The mirror takes
-                // this holder's for as long as it holds it (usearch_add_external writes through retriever_mut).
-                rebind_retriever((lgpu::Index *)m.index, opts);
-                m.refs++;
-                m.last_use = ++c.clock;
-                c.hits++;
-                return &m;
+        lantern_mirror *hit = nullptr;
+        {
+            std::lock_guard<std::mutex> g(c.mu);
+            for(auto &m : c.entries) {
+                if(m.relation == relation && !m.stale && m.version == version) {
+                    m.refs++;  // ours from here on: the entry cannot go away while the cache lock is dropped
+                    m.last_use = ++c.clock;
+                    c.hits++;
+                    hit = &m;
+                    break;
+                }
             }
+        }
+        if(hit) {
+            // The reference allocates its RetrieverCtx per scan and per insert and frees it at the end (scan.c:34,132,
+            // insert.c:130,247): the callbacks and the ctx a mirror was BUILT with are gone by now.  The mirror takes
+            // this holder's for as long as it holds it (usearch_add_external writes through retriever_mut).
+            rebind_retriever((lgpu::Index *)hit->index, opts);
+            return hit;
         }
     }
     // policy: a tiny index is not worth a mirror (the header carries the node count: external_index.h:59-66)
@@ -139,32 +153,41 @@ try {
         if(e) *e = kept.c_str();
         return nullptr;
     }
-    std::lock_guard<std::mutex> g(c.mu);
-    // somebody else may have built the same (relation, version) in the meantime: theirs stays, ours goes
-    for(auto &m : c.entries) {
-        if(m.relation == relation && !m.stale && m.version == version) {
-            usearch_error_t ignore = nullptr;
-            usearch_free(ix, &ignore);
-            rebind_retriever((lgpu::Index *)m.index, opts);
-            m.refs++;
+    // the mirror was built through this holder's callbacks: from now on they are looked up per holder (ours is the first)
+    rebind_retriever((lgpu::Index *)ix, opts);
+    lantern_mirror *theirs = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        // somebody else may have built the same (relation, version) in the meantime: theirs stays, ours goes
+        for(auto &m : c.entries) {
+            if(m.relation == relation && !m.stale && m.version == version) {
+                m.refs++;
+                m.last_use = ++c.clock;
+                c.hits++;
+                theirs = &m;
+                break;
+            }
+        }
+        if(!theirs) {
+            bool replaced = false;
+            for(auto &m : c.entries)
+                if(m.relation == relation && !m.stale) { m.stale = true; replaced = true; }
+            (replaced ? c.rebuilds : c.misses)++;
+            c.entries.emplace_back();
+            lantern_mirror &m = c.entries.back();
+            m.relation = relation;
+            m.version = version;
+            m.index = ix;
+            m.refs = 1;
             m.last_use = ++c.clock;
-            c.hits++;
+            trim(c);
             return &m;
         }
     }
-    bool replaced = false;
-    for(auto &m : c.entries)
-        if(m.relation == relation && !m.stale) { m.stale = true; replaced = true; }
-    (replaced ? c.rebuilds : c.misses)++;
-    c.entries.emplace_back();
-    lantern_mirror &m = c.entries.back();
-    m.relation = relation;
-    m.version = version;
-    m.index = ix;
-    m.refs = 1;
-    m.last_use = ++c.clock;
-    trim(c);
-    return &m;
+    usearch_error_t ignore = nullptr;
+    usearch_free(ix, &ignore);
+    rebind_retriever((lgpu::Index *)theirs->index, opts);
+    return theirs;
 }
 LANTERN_ABI_CATCH(e)
 
@@ -189,14 +212,15 @@ LANTERN_ABI_CATCH_VOID(nullptr)
 void lantern_mirror_release(lantern_mirror_t *m)
 try {
     if(!m) return;
+    // The releasing holder's ctx is about to be freed (scan.c:132, insert.c:247): its binding goes first, while its reference
+    // still keeps the index alive and before the cache lock is taken.  Only THIS holder's: another thread that holds the same
+    // mirror keeps its own.  (Several handles held by one thread share that thread's binding: after releasing one of them an
+    // insert through another needs lantern_mirror_rebind, and fails with a message -- never through a dangling pointer --
+    // without it.)
+    rebind_retriever((lgpu::Index *)m->index, nullptr);
     Cache &c = cache();
     std::lock_guard<std::mutex> g(c.mu);
     if(m->refs > 0) m->refs--;
-    // The releasing holder's ctx is about to be freed (scan.c:132, insert.c:247) and the entry cannot tell whose callbacks it
-    // carries: ANY release unbinds them.  Scans never call them on a mirror; an inserter that still holds the mirror binds
-    // its own again (lantern_mirror_rebind) -- without that usearch_add_external fails with a message, never through a
-    // dangling pointer.
-    rebind_retriever((lgpu::Index *)m->index, nullptr);
     m->last_use = ++c.clock;
     trim(c);
 }

@@ -37,6 +37,7 @@
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/epoll.h>
 #include <sys/eventfd.h>
 #include <sys/socket.h>
@@ -80,7 +81,7 @@ bool read_exact(int fd, void *buf, size_t n)
     }
     return true;
 }
-bool write_all(int fd, const void *buf, size_t n)
+bool write_all(int fd, const void *buf, size_t n)  // the CLIENT's side: a blocking send of its one outstanding request
 {
     const char *p = (const char *)buf;
     while(n) {
@@ -88,6 +89,37 @@ bool write_all(int fd, const void *buf, size_t n)
         if(r <= 0) return false;
         p += r;
         n -= (size_t)r;
+    }
+    return true;
+}
+// The SERVER's side never blocks on a backend.  Answers are written by a dispatcher (batches of up to eight) or by one of a few
+// shared I/O threads: a backend that sends requests but stops reading its answers (stuck, SIGSTOPped, pipelining without
+// reading) would otherwise park that thread in send() once its socket buffers are full -- and with it every connection the
+// thread serves, or, in the dispatcher's case, the whole service.  An answer is at most a few hundred bytes and a backend has
+// one request outstanding, so a healthy connection always has room: the send is non-blocking, a short one waits for POLLOUT
+// for at most kSendGraceMs in total, and a connection that still cannot take its answer is reported as gone (it is closed by
+// its I/O thread, the backend sees a reset instead of a silent stall).
+constexpr int kSendGraceMs = 20;
+bool write_answer(int fd, const void *buf, size_t n)
+{
+    const char *p = (const char *)buf;
+    int         grace = kSendGraceMs;
+    while(n) {
+        ssize_t r = ::send(fd, p, n, MSG_NOSIGNAL | MSG_DONTWAIT);
+        if(r > 0) {
+            p += r;
+            n -= (size_t)r;
+            continue;
+        }
+        if(r < 0 && errno == EINTR) continue;
+        if(r < 0 && (errno == EAGAIN || errno == EWOULDBLOCK) && grace > 0) {
+            pollfd    pf{ fd, POLLOUT, 0 };
+            const int step = std::min(grace, 5);
+            (void)::poll(&pf, 1, step);
+            grace -= step;
+            continue;
+        }
+        return false;
     }
     return true;
 }
@@ -167,7 +199,7 @@ int default_backend(void *ctx, const void *queries, size_t nq, size_t, size_t k,
 bool reply_error(int fd, const std::string &msg)
 {
     uint32_t head[ 3 ] = { REP_MAGIC, 1u, (uint32_t)msg.size() };
-    return write_all(fd, head, sizeof(head)) && write_all(fd, msg.data(), msg.size());
+    return write_answer(fd, head, sizeof(head)) && write_answer(fd, msg.data(), msg.size());
 }
 
 bool arm(IoThread *t, Conn *c, int op)
@@ -261,7 +293,7 @@ bool reply_rows(Conn *c, const uint64_t *labels, const float *dists, size_t coun
         std::memcpy(out.data() + 12, ls.data(), (size_t)n * 8);
         std::memcpy(out.data() + 12 + (size_t)n * 8, ds.data(), (size_t)n * 4);
     }
-    return write_all(c->fd, out.data(), 12 + (size_t)n * 12);  // one send per answer
+    return write_answer(c->fd, out.data(), 12 + (size_t)n * 12);  // one send per answer
 }
 
 void io_loop(lantern_scan_server *s, IoThread *t)

@@ -426,8 +426,9 @@ bool write_back_insert(Index *ix, uint32_t id, char *node_tape)
         if(hipMemcpy(own.data(), src, (size_t)cap * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err(ix, "lantern_gpu: HIP failure reading a neighbour list"); return false; }
         for(uint32_t j = 0; j < cap && own[ j ] != EMPTY; ++j) {
             if(!ix->page_mode) continue;  // no pages behind this index: the device lists are the only copy
-            if(!ix->opts.retriever_mut) { set_err(ix, "lantern_gpu: usearch_add_external needs init_options.retriever_mut"); return false; }
-            char *tape = (char *)ix->opts.retriever_mut(ix->opts.retriever_ctx, ix->page_slots[ own[ j ] ]);
+            const Index::HolderBinding hb = ix->current_holder();
+            if(!hb.retriever_mut) { set_err(ix, "lantern_gpu: usearch_add_external needs init_options.retriever_mut"); return false; }
+            char *tape = (char *)hb.retriever_mut(hb.ctx, ix->page_slots[ own[ j ] ]);
             if(!tape) { set_err(ix, "lantern_gpu: retriever_mut returned NULL"); return false; }
             if(!write_list_to_tape(ix, own[ j ], l, tape)) return false;
         }
@@ -503,7 +504,7 @@ try {
         std::lock_guard<std::mutex> g(ix->mu);
         // everything that can refuse the insertion is checked BEFORE the mirror changes: a mirror whose callbacks were unbound
         // (lantern_mirror_release by another holder) must fail here, not after the node has been linked on the device
-        if(ix->page_mode && !ix->opts.retriever_mut) { if(e) *e = set_err(ix, "lantern_gpu: usearch_add_external needs init_options.retriever_mut"); return; }
+        if(ix->page_mode && !ix->current_holder().retriever_mut) { if(e) *e = set_err(ix, "lantern_gpu: usearch_add_external needs init_options.retriever_mut"); return; }
         id = (uint32_t)ix->n;
         if(ix->page_mode) {
             const uint64_t s48 = slot & 0xFFFFFFFFFFFFull;

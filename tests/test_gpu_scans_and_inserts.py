@@ -404,6 +404,53 @@ def test_mirror_hit_inserts_through_the_second_holders_callbacks(capi):
     capi.Mirror.invalidate(REL)
 
 
+def test_mirror_holders_on_different_threads_keep_their_own_callbacks(capi):
+    """A threaded host (the scan service, the test harnesses) runs one holder per thread on a shared mirror: holder B coming and
+    going between A's acquire and A's insert neither hands A's writes to B's RetrieverCtx nor leaves A without callbacks."""
+    import threading
+
+    rng = np.random.default_rng(78)
+    n, d, M = 500, 16, 5
+    base = rng.standard_normal((n + 2, d), dtype=np.float32)
+    a = capi.GpuIndex("l2sq", d, M=M, ef_construction=32, ef=32, seed=8)
+    a.set_add_batch(1, 1)
+    a.add_many(np.arange(n, dtype=np.uint64) + 1, base[:n])
+    store = PageStore(capi, a.save_buffer(), d * 4, M)
+    REL = 616161
+    calls = {"A": 0, "B": 0}
+
+    def counted(who, fn):
+        def f(slot):
+            calls[who] += 1
+            return fn(slot)
+        return f
+
+    kw = dict(metric="l2sq", dims=d, M=M, ef_construction=32, ef=32)
+    mA = capi.Mirror(REL, 1, header=store.header, retriever=counted("A", store.retriever), retriever_mut=counted("A", store.retriever_mut), **kw)
+    built = calls["A"]
+    errs = []
+
+    def holder_b():
+        try:
+            mB = capi.Mirror(REL, 1, header=store.header, retriever=counted("B", store.retriever), retriever_mut=counted("B", store.retriever_mut), **kw)
+            assert mB.index.h == mA.index.h  # the same device index
+            assert len(mB.index.search(base[3], 3)[0]) == 3
+            mB.release()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    t = threading.Thread(target=holder_b)
+    t.start()
+    t.join()
+    assert not errs, errs
+    addr, slot = store.new_tuple(9001, 0)
+    mA.index.add_external(9001, base[n], addr, 0, slot)  # no rebind needed: B's release took B's binding, not A's
+    assert calls["A"] > built and calls["B"] == 0
+    assert 9001 in mA.index.search(base[n], 3)[0].tolist()
+    mA.release()
+    capi.Mirror.invalidate(REL)
+
+
 def test_mirror_cache_hits_rebuilds_invalidation_and_eviction(capi):
     rng = np.random.default_rng(31)
     n, d, M = 900, 16, 5

@@ -340,6 +340,38 @@ def test_requests_in_pieces_back_to_back_and_abandoned(capi):
     srv.stop()
 
 
+def test_a_backend_that_stops_reading_its_answers_is_dropped_and_stalls_nobody(capi):
+    """A backend that keeps sending requests but never reads an answer fills its socket buffers; the server's answer writes are
+    non-blocking (write_answer), so neither a dispatcher nor an I/O thread ever parks in send(): the others are served at their
+    usual latency the whole time, and the deaf connection is closed once it cannot take an answer."""
+    import socket
+
+    srv = capi.ScanServer(batch_fn=fake_backend([]), vec_bytes=8, max_batch=16, max_wait_us=300)
+    deaf = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    deaf.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 4096)  # before connect: a small receive window fills quickly
+    deaf.connect((srv.host, srv.port))
+    deaf.setblocking(False)
+    good = capi.ScanClient(srv.host, srv.port)
+    req = _raw_request(3, 100) * 64  # 100 results per answer: 1 212 bytes each
+    worst, dropped, sent = 0.0, False, 0
+    t_end = time.time() + 20.0
+    while time.time() < t_end and not dropped:
+        try:
+            sent += deaf.send(req)
+        except BlockingIOError:
+            pass
+        except (ConnectionResetError, BrokenPipeError):
+            dropped = True
+        t0 = time.time()
+        assert good.search(np.array([4, 0], dtype=np.float32), 2)[0].tolist() == [4000, 4001]
+        worst = max(worst, time.time() - t0)
+    assert dropped, f"the deaf connection was still open after {sent} request bytes"
+    assert worst < 0.5, f"a healthy backend waited {worst:.3f} s behind a deaf one"
+    good.close()
+    deaf.close()
+    srv.stop()
+
+
 def test_more_connections_than_io_threads_and_idle_ones_do_not_stall_the_window(capi, monkeypatch):
     """Three I/O threads, forty connections of which thirty never say a word: the active ones are answered within the window
     (nobody waits for the idle ones beyond it), and every connection is served by the thread it was dealt to."""
