@@ -77,6 +77,11 @@ def parse():
                         "low-dimensional clusters (lantern_amd/synth.py): the set on which HNSW reaches the recall the reference asserts (>= 0.9)")
     p.add_argument("--data-scale", type=float, default=1.0, help="multiply the synthetic rows and queries (i8 storage quantises [-1, 1]: use 0.3)")
     p.add_argument("--collective-timeout", type=float, default=180.0, help="deadline of every exchange of the collective build")
+    p.add_argument("--no-pmc", action="store_true", help="skip the counter passes (roofline.traffic then comes from the committed profiles/pmc_traffic.json, if it has this "
+                   "configuration): by default, when rocprofv3 is on PATH, the search leg is re-executed under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
+                   "(two short passes restricted to k_search) after the timed region and roofline.traffic is THIS run's")
+    p.add_argument("--pmc-steps", type=int, default=4, help="search launches per counter pass")
+    p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the re-executed search leg: build, launch, print the graph checksum, exit
     return p.parse_args()
 
 
@@ -322,6 +327,9 @@ def main():
     kernel_ms = [s.elapsed_ms(e) for s, e in ev]  # HIP events on the launch stream: one search launch each
     if rdv:
         elapsed = rdv.max_float(elapsed)
+    if a.pmc_child:  # a counter pass of measure_traffic(): the launches above are what rocprofv3 counted
+        print(json.dumps({"pmc_child": True, "checksum": f"{ix.checksum():016x}", "launches": max(a.warmup, B) + a.steps, "queries_per_launch": nq}), flush=True)
+        return
 
     # ---- algorithmic bytes of one launch --------------------------------------------
     row_bytes = a.dim * {"f32": 4, "f16": 2, "i8": 1, "b1": 0.125}[a.quant]
@@ -357,22 +365,28 @@ def main():
             if a.build_quality_rows > 0 and a.quant == "f32" and a.metric != "hamming":
                 quality = build_quality(a)
 
-        # HBM-side bytes per launch from the PMC passes of THIS command line (scripts/profile_r03.sh: separate rocprofv3 --pmc
-        # passes, FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 per MI355X_MICROARCH.md), committed under profiles/.  Counters cannot
-        # be read from inside this process; a line whose configuration has no committed pass carries traffic = null.
+        # ---- HBM-side bytes per launch: counter passes of THIS run (measure_traffic), else the committed passes of this command line
         traffic = traffic_src = dram = None
+        measured_here = False
+        pmc_detail = None
+        key = (f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves or 4}" + ("" if a.quant == "f32" else "_" + a.quant)
+               + ("" if a.data == "gaussian" else "_" + a.data) + (f"_b{B}" if B > 1 else "") + (f"_pq{a.pq_subvectors}" if a.pq_subvectors else ""))
+        if world == 1 and not a.no_pmc and S == 1:
+            pmc_detail = measure_traffic(a, f"{ix.checksum():016x}")
+            if pmc_detail and pmc_detail.get("hbm_bytes_per_launch"):
+                traffic, measured_here = pmc_detail["hbm_bytes_per_launch"], True
+                traffic_src = pmc_detail["source"]
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
+        if traffic is None and os.path.exists(prof):
             try:
-                rec = json.load(open(prof))
-                key = (f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves or 4}" + ("" if a.quant == "f32" else "_" + a.quant)
-                       + ("" if a.data == "gaussian" else "_" + a.data) + (f"_b{B}" if B > 1 else "") + (f"_pq{a.pq_subvectors}" if a.pq_subvectors else ""))
-                hit = rec.get(key, {})
+                hit = json.load(open(prof)).get(key, {})
                 traffic = hit.get("hbm_bytes_per_launch")
                 dram = hit.get("dram_bytes_per_launch")
                 traffic_src = hit.get("source")
             except Exception:
                 traffic = None
+        # ---- distinct rows a launch evaluates (device bitmap, instrumented walk): the cold-miss lower bound of its DRAM bytes
+        unique = unique_rows_per_launch(a, ix, step, B, hip) if world == 1 and not a.pq_subvectors else None
         qps = world * nq * a.steps / elapsed
         out = {
             "metric": f"QPS (recall@{a.k} alongside), {a.n}x{a.dim} f32 {a.metric} ef={a.ef} k={a.k}",
@@ -403,7 +417,8 @@ def main():
             "dist_evals_per_query": float(D.mean()),
             "expansions_per_query": float(E.mean()),
             "roofline": roofline(achieved, traffic, dram, traffic_src, avg_kernel_s if S == 1 else elapsed / a.steps, bytes_per_launch, avg_kernel_s, S, B,
-                                 adc=bool(a.pq_subvectors)),
+                                 adc=bool(a.pq_subvectors), measured_here=measured_here, pmc_detail=pmc_detail, unique=unique, row_bytes=row_bytes,
+                                 list_bytes=2 * a.M * 4, expansions_per_launch=float(np.mean([per_lane[i % B][1].sum() for i in range(a.steps)]))),
             "cpu_baseline": cpu,
             "pq": pq_info,
             "build_quality": quality,
@@ -413,37 +428,142 @@ def main():
     finish(out)
 
 
-def roofline(achieved, traffic, dram, traffic_src, launch_s, bytes_per_launch, avg_kernel_s, S, B, adc=False):
-    """The search kernel against the HBM roofline.  `frac` is the contract's figure: ALGORITHMIC bytes (one row per distance
-    evaluation, one adjacency row per expansion, D and E counted on the device) / launch time / the 8 TB/s spec peak.  A walk's
-    algorithmic bytes are not all DRAM bytes -- upper levels and hub rows are shared between the queries of a launch and are
-    served by L2 / the 256 MiB Infinity Cache -- so `frac` can exceed what DRAM alone could deliver; `frac_traffic` (the
-    fabric-side counter bytes over the same time) and `measured_ceiling` (what a pure stream reaches on this part) are given
-    beside it, and `note` says so whenever `frac` is above either."""
-    frac = achieved / HBM_PEAK_GBS
-    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
-         "traffic": traffic, "traffic_source": traffic_src,
-         "frac_traffic": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-         "dram_bytes_per_launch": dram,
-         "frac_dram": (dram / launch_s / 1e9 / HBM_PEAK_GBS) if dram else None,
-         "measured_ceiling": HBM_MEASURED_CEILING_GBS, "frac_of_measured_ceiling": achieved / HBM_MEASURED_CEILING_GBS,
+GATHER_CEILING_GBS = 6730.0  # profiles/r03_gather_ceiling.md: uniformly random 3 KiB rows in the walk's own launch shape (k_gather_walkshape), algorithmic bytes
+
+
+def measure_traffic(a, checksum):
+    """roofline.traffic of THIS run: the search leg re-executed under rocprofv3, one pass per counter (FETCH_SIZE takes three of
+    the four TCC slots, WRITE_SIZE two: MI355X_MICROARCH.md "rocprofv3 PMC slots"; gpurun refuses counter passes combined with
+    trace domains), restricted to the search kernel.  The child builds the same index from the same seeds (checked: graph
+    checksum), runs max(warmup, batches) + --pmc-steps launches over the same rotating query batches and exits; the mean
+    counter value per launch is converted as the guide's HBM section prescribes: FETCH_SIZE is KiB and on gfx950 reports
+    exactly 1/2 of the bytes of wide coalesced reads -> x 1024 x 2; WRITE_SIZE KiB x 1024 (uncalibrated there; < 0.01 % here).
+    Returns None when rocprofv3 is not on PATH or a pass fails (the committed profiles/pmc_traffic.json is used then)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--no-pmc", "--no-cpu", "--truth-queries", "0", "--build-quality-rows", "0",
+             "--steps", str(max(1, a.pmc_steps)), "--warmup", "1", "--rows", str(a.n), "--dim", str(a.dim), "--metric", a.metric, "--M", str(a.M),
+             "--efc", str(a.efc), "--ef", str(a.ef), "--k", str(a.k), "--queries", str(a.queries), "--query-batches", str(a.query_batches),
+             "--waves", str(a.waves), "--max-wg", str(a.max_wg), "--add-batch", str(a.add_batch), "--quant", a.quant, "--data", a.data,
+             "--data-scale", str(a.data_scale), "--pq-subvectors", str(a.pq_subvectors), "--pq-centroids", str(a.pq_centroids)]
+    out = {"counters": {}, "passes": []}
+    t0 = time.time()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="lantern_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-include-regex", "k_search", "--pmc", ctr, "-d", tmp, "-o", "pmc", "--"] + child
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            line = next((json.loads(l) for l in p.stdout.splitlines() if l.startswith("{") and "pmc_child" in l), None)
+            if p.returncode != 0 or not line:
+                out["passes"].append({"counter": ctr, "error": f"rc {p.returncode}: {(p.stderr or p.stdout)[-300:]}"})
+                continue
+            if line["checksum"] != checksum:
+                out["passes"].append({"counter": ctr, "error": "the child built a different graph"})
+                continue
+            vals = []
+            for db in glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True):
+                cur = sqlite3.connect(db).cursor()
+                vals += [float(v) for (v,) in cur.execute("select value from counters_collection where kernel_name like '%k_search%' and counter_name = ?", (ctr,))]
+            if not vals:
+                out["passes"].append({"counter": ctr, "error": "no counter rows for k_search in the rocprofv3 output"})
+                continue
+            out["counters"][ctr] = {"launches": len(vals), "mean_per_launch": float(np.mean(vals)), "min": float(np.min(vals)), "max": float(np.max(vals))}
+            out["passes"].append({"counter": ctr, "launches": len(vals), "command": "rocprofv3 --kernel-include-regex k_search --pmc " + ctr + " -- python bench.py --pmc-child ..."})
+        except Exception as e:  # noqa: BLE001
+            out["passes"].append({"counter": ctr, "error": repr(e)[:300]})
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    out["seconds"] = time.time() - t0
+    if "FETCH_SIZE" not in out["counters"]:
+        out["hbm_bytes_per_launch"] = None
+        return out
+    rd = out["counters"]["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
+    wr = out["counters"].get("WRITE_SIZE", {}).get("mean_per_launch", 0.0) * 1024
+    out.update(read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
+               source="this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes restricted to k_search, over a re-execution of the search leg "
+                      "(same seeds, same graph checksum, same rotating query batches); FETCH_SIZE KiB x 1024 x 2 (gfx950: the counter reports half the "
+                      "bytes of wide coalesced reads), WRITE_SIZE KiB x 1024 -- /opt/skills/guides/MI355X_MICROARCH.md, HBM")
+    return out
+
+
+def unique_rows_per_launch(a, ix, step, B, hip):
+    """Distinct rows the queries of ONE launch evaluate, averaged over the B resident batches (lantern_gpu_search_unique_rows:
+    the instrumented walk sets one bit per evaluated row in a device bitmap).  None where the instrumented kernel does not
+    exist (quantised storage, narrow rows)."""
+    if a.quant != "f32" or a.metric not in ("l2sq", "cos"):
+        return None
+    counts = []
+    try:
+        for i in range(B):
+            ix.unique_rows(True)
+            step(i)
+            hip.synchronize()
+            counts.append(ix.unique_rows(False, read=True))
+    except Exception:  # noqa: BLE001 -- a diagnostic: the line stands without it
+        try:
+            ix.unique_rows(False)
+        except Exception:  # noqa: BLE001
+            pass
+        return None
+    return float(np.mean(counts)) if counts else None
+
+
+def roofline(achieved_alg, traffic, dram, traffic_src, launch_s, bytes_per_launch, avg_kernel_s, S, B, adc=False, measured_here=False, pmc_detail=None,
+             unique=None, row_bytes=0.0, list_bytes=0.0, expansions_per_launch=0.0):
+    """The search kernel against the HBM roofline (8 TB/s spec peak).
+
+    `frac` / `achieved` are PHYSICAL: the bytes the L2 requested from the fabric during a launch (rocprofv3 counters, `traffic`,
+    measured in this run when rocprofv3 is present) / the launch's HIP-event duration.  They can not exceed the peak by
+    construction of the hardware, and they still include what the 256 MiB Infinity Cache served (the part exposes no counter
+    that separates DRAM from it: profiles/r03_counter_notes.md) -- an upper bound of the DRAM rate.
+    `frac_algorithmic` / `achieved_algorithmic` are SURVEY 8d's bytes -- one row per distance evaluation, one adjacency row per
+    expansion, D and E counted on the device and equal to the oracle's -- over the same time: what the walk ASKS for.  Rows that
+    several queries of a launch evaluate (upper levels, hub rows of un-normalised Gaussian data under L2sq) are counted once
+    per evaluation there but come from L2 / Infinity Cache, so this figure may exceed 1; counter bytes BELOW algorithmic bytes
+    mean no wasted re-reads.
+    `frac_cold_miss_lower_bound`: distinct rows of a launch x row bytes (+ its adjacency rows) / time / peak -- what DRAM must
+    deliver even with perfect caches.  The true DRAM fraction lies between this and `frac`."""
+    alg_frac = achieved_alg / HBM_PEAK_GBS
+    phys = (traffic / launch_s / 1e9) if traffic else None
+    r = {"bound": "hbm",
+         "achieved": phys if phys is not None else achieved_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": (phys if phys is not None else achieved_alg) / HBM_PEAK_GBS,
+         "frac_basis": ("fabric-side counter bytes per launch (roofline.traffic) / HIP-event launch time" if phys is not None else
+                        "ALGORITHMIC bytes (no counter pass available for this configuration: rocprofv3 absent and no committed pass) / launch time"),
+         "traffic": traffic, "traffic_measured_in_this_run": bool(measured_here), "traffic_source": traffic_src,
+         "achieved_algorithmic": achieved_alg, "frac_algorithmic": alg_frac,
+         "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
+         "unique_rows_per_launch": unique,
+         "cold_miss_bytes_per_launch": None, "frac_cold_miss_lower_bound": None,
+         "dram_bytes_per_launch": dram, "frac_dram": (dram / launch_s / 1e9 / HBM_PEAK_GBS) if dram else None,
+         "gather_ceiling": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r03_gather_ceiling.md (uniformly random 3 KiB rows in the walk's launch shape, algorithmic bytes)",
+         "algorithmic_over_gather_ceiling": achieved_alg / GATHER_CEILING_GBS,
+         "streaming_ceiling": HBM_MEASURED_CEILING_GBS,
          "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_kernel_s * 1e3,
-         "query_batches_rotated": B, "note": None}
+         "query_batches_rotated": B, "pmc": pmc_detail, "note": None}
+    if unique is not None:
+        cold = unique * (row_bytes + list_bytes)  # every distinct row once, and (at most) its own adjacency row
+        cold = min(cold, unique * row_bytes + expansions_per_launch * list_bytes)
+        r["cold_miss_bytes_per_launch"] = cold
+        r["frac_cold_miss_lower_bound"] = cold / launch_s / 1e9 / HBM_PEAK_GBS
     notes = []
     if adc:
         r["kernel"] = "k_search_adc"
         notes.append("a compact pq index: a row is its code bytes (1/32 of the f32 row at 96 subvectors), so the HBM fraction says how far "
-                     "this kernel is from being bandwidth-bound, not how good it is: its per-query table (subvectors x 256 f32) takes 98 KB of "
-                     "LDS at 96 subvectors -- one walk per CU -- and what bounds it is the latency of a hop (lantern_amd/csrc/search_adc_kernel.hip)")
+                     "this kernel is from being bandwidth-bound, not how good it is (lantern_amd/csrc/search_adc_kernel.hip)")
     if S > 1:
-        notes.append(f"{S} launches in flight: achieved = all launches' algorithmic bytes / the timed region; avg_launch_ms is the mean HIP-event "
+        notes.append(f"{S} launches in flight: rates = all launches' bytes / the timed region; avg_launch_ms is the mean HIP-event "
                      "duration of launches that overlap")
-    if frac > 1.0 or achieved > HBM_MEASURED_CEILING_GBS:
-        notes.append("algorithmic bytes per second exceed " + ("the DRAM peak" if frac > 1.0 else "the measured streaming ceiling") +
-                     ": rows that several queries of a launch evaluate (upper levels, hub rows) are counted once per evaluation but served by "
-                     "L2 / Infinity Cache; frac_traffic (fabric-side counter bytes) is the physical figure this part lets one measure -- it "
-                     "still includes Infinity-Cache hits: on gfx950 TCC_EA0_RDREQ_DRAM equals TCC_EA0_RDREQ (it counts requests to DRAM "
-                     "address space) and rocprofv3 lists no MALL counter, so frac_dram stays null (profiles/r03_counter_notes.md)")
+    if alg_frac > 1.0 or achieved_alg > GATHER_CEILING_GBS:
+        notes.append("frac_algorithmic exceeds " + ("1" if alg_frac > 1.0 else "the random-row gather ceiling") + ": rows shared by the queries of a launch "
+                     "(upper levels, hub rows) are counted once per evaluation but served by L2 / Infinity Cache; `frac` (counter bytes) is the physical figure")
     r["note"] = "; ".join(notes) or None
     return r
 

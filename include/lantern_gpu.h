@@ -355,6 +355,11 @@ LANTERN_GPU_EXPORT lantern_gpu_build_profile lantern_gpu_build_profile_get(usear
  * list, two or more waves per query: walk.hpp search_level_reg) thread 0 never merges: slot 3 ("merge") is then its pop
  * DECISION and slot 4 ("pop") the list wave's whole section (merge + pop + hand-off), which runs beside slots 3, 5 and 0. */
 LANTERN_GPU_EXPORT void lantern_gpu_search_phase_profile(usearch_index_t, int on, unsigned long long *out8, usearch_error_t *);
+/* Diagnostics: how many DISTINCT rows the searches between (on = 1) and the read (on = 0, rows != NULL) evaluated, over all their
+ * queries: unique rows x row bytes is the cold-miss lower bound of a launch's DRAM traffic (every such row has to come from
+ * HBM at least once), to put beside the algorithmic bytes (one row per evaluation) and the counters' fabric-side bytes.  Runs
+ * the instrumented instantiation of the walk kernel (f32 l2sq / cos; same walk, same D and E; slower). */
+LANTERN_GPU_EXPORT void lantern_gpu_search_unique_rows(usearch_index_t, int on, uint64_t *rows, usearch_error_t *);
 /* the same for the latency-bound walk (lantern_amd/csrc/walk_spec.hpp): out32[8 * wave + i], waves 0..3 = visit | list | cache
  * fill | a row wave; i = 0 decision, 1 neighbour list, 2 issuing the row loads, 3 the wave's role section, 4 loads landing +
  * distances, 5 wait at the hop's barrier, 6 hops, 7 where lists came from (wave 0: staging area, wave 3: cache, wave 2: HBM) */

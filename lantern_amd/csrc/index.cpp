@@ -945,7 +945,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     const int grid = search_grid(ix, nq, waves, spec == 2 ? waves : spec == 1 ? 16 : 24);
     const int slot = acquire_search_slot(ix, stream, (size_t)grid);
     if(slot < 0) return false;
-    SearchArgs a;
+    SearchArgs a{};
     a.view = ix->view();
     a.queries = d_queries;
     a.nq = (uint32_t)nq;
@@ -965,6 +965,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.totals = ix->d_totals;
     a.ticket = next_ticket(ix, nq, grid, stream);
     a.phase_cycles = spec ? (ix->spec_profile ? ix->d_totals + 16 : nullptr) : ix->phase_profile ? ix->d_totals + 8 : nullptr;
+    a.touched = (!spec && ix->phase_profile) ? ix->d_touched : nullptr;
     a.done = done;
     a.lds_list = lds_list_env();
     // small batch (at most four 4-wave workgroups per CU would be resident anyway): four rows in flight per group
@@ -1237,7 +1238,7 @@ try {
     if(!ix) return;
     void *ptrs[] = { ix->d_vec, ix->d_norm2, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals, ix->d_tickets,
                      ix->d_radius0, ix->d_radius_upper,
-                     ix->d_codebook, ix->d_centers, ix->d_codes, ix->d_codes16 };
+                     ix->d_codebook, ix->d_centers, ix->d_codes, ix->d_codes16, ix->d_touched };
     for(void *p : ptrs)
         if(p) (void)hipFree(p);
     for(void *p : ix->d_scratch)
@@ -2063,6 +2064,48 @@ try {
         (void)hipDeviceSynchronize();
         if(hipMemcpy(out6, ix->d_totals + 8, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) FAIL(e, "lantern_gpu: HIP failure reading the phase profile");
         (void)hipMemset(ix->d_totals + 8, 0, 8 * sizeof(unsigned long long));
+    }
+    ix->phase_profile = on != 0;
+}
+LANTERN_ABI_CATCH_VOID(e)
+
+// Diagnostics: the number of DISTINCT rows the searches launched between `on` and the read evaluated -- over all their queries.
+// A launch has to bring each of them in from HBM at least once, whatever the caches do with the re-reads: unique rows x row
+// bytes is the cold-miss LOWER bound of its DRAM traffic, beside the counters' fabric-side bytes (which include Infinity-Cache
+// hits) and the algorithmic bytes (one row per evaluation).  Runs the instrumented instantiation of the walk (as
+// lantern_gpu_search_phase_profile: f32 l2sq / cos rows of >= 128 or 32..63 chunks); same walk, same D and E.
+//   on = 1: zero the row bitmap and switch the instrumented kernel on;  on = 0 with `rows`: read the count, switch it off.
+void lantern_gpu_search_unique_rows(usearch_index_t h, int on, uint64_t *rows, usearch_error_t *e)
+try {
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    const size_t words = (std::max<size_t>(ix->cap, 1) + 31) / 32;
+    (void)hipDeviceSynchronize();
+    if(rows) {
+        *rows = 0;
+        if(ix->d_touched) {
+            std::vector<uint32_t> bits(words);
+            if(hipMemcpy(bits.data(), ix->d_touched, words * 4, hipMemcpyDeviceToHost) != hipSuccess) { FAIL(e, "lantern_gpu: HIP failure reading the row bitmap"); return; }
+            uint64_t n = 0;
+            for(uint32_t w : bits) n += (uint64_t)__builtin_popcount(w);
+            *rows = n;
+        }
+    }
+    if(on) {
+        const int G_ = group_lanes_for(ix->chunks);
+        if(!((ix->mcode == M_L2SQ && (G_ == 64 || G_ == 16)) || (ix->mcode == M_COS && G_ == 64))) {
+            FAIL(e, "lantern_gpu: the instrumented walk exists for f32 l2sq (rows of >= 128 or 32..63 chunks) and f32 cos (>= 128 chunks) only");
+            return;
+        }
+        if(ix->d_touched && ix->touched_words < words) { (void)hipFree(ix->d_touched); ix->d_touched = nullptr; }
+        if(!ix->d_touched) {
+            if(hipMalloc((void **)&ix->d_touched, words * 4) != hipSuccess) { ix->d_touched = nullptr; FAIL(e, "lantern_gpu: out of device memory (row bitmap)"); return; }
+            ix->touched_words = words;
+        }
+        if(hipMemset(ix->d_touched, 0, ix->touched_words * 4) != hipSuccess) { FAIL(e, "lantern_gpu: HIP failure clearing the row bitmap"); return; }
     }
     ix->phase_profile = on != 0;
 }

@@ -108,6 +108,8 @@ struct Index
     bool                    profiling = false;
     bool                    phase_profile = false;  // diagnostics: instrumented walk kernel (lantern_gpu_search_phase_profile)
     bool                    spec_profile = false;   // diagnostics: the instrumented latency-bound walk (lantern_gpu_spec_profile)
+    uint32_t               *d_touched = nullptr;    // diagnostics: one bit per row evaluated by the instrumented searches (lantern_gpu_search_unique_rows)
+    size_t                  touched_words = 0;
     std::deque<ProfBatch>   prof_pending;
     std::vector<hipEvent_t> prof_free;
     lantern_gpu_build_profile prof{};

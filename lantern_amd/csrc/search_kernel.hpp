@@ -85,11 +85,14 @@ k_search(SearchArgs)
                 }
                 __syncthreads();
             }
-            if constexpr(PROF) t_q = (unsigned long long)clock64();
+            if constexpr(PROF) {
+                t_q = (unsigned long long)clock64();
+                s.touched = LGPU_SEARCH_ARG(ka, touched);
+            }
             if(v.n != 0) {
                 uint32_t start;
                 if constexpr(SPEC != 0) start = greedy_descent_spec<METRIC, G>(v, s, v.entry, v.max_level, 0, D);
-                else start = greedy_descent<METRIC, G>(v, s, v.entry, v.max_level, 0, D);
+                else start = greedy_descent<METRIC, G, PROF>(v, s, v.entry, v.max_level, 0, D);
                 if constexpr(PROF) pc[ 6 ] = (unsigned long long)clock64() - t_q;
                 // KPL keys per lane of wave 0 hold the candidate list (ef <= 64 KPL); KPL = 0: the list lives in LDS
                 if constexpr(SPEC != 0)

@@ -42,7 +42,21 @@ struct WalkLds
     int      *scal;     // S_* scalars
     uint32_t *vis;      // visited hash set (vis_slots entries, any multiple of 4; 0 = the HBM bitmap only)
     uint32_t  vis_slots;
+    uint32_t *touched;  // diagnostic instantiations only (PROF): one bit per row of the index, set when ANY query of the launch
+                        // evaluates the row (lantern_gpu_search_unique_rows); never read, and never set, elsewhere
 };
+
+// PROF: record that row `id` was evaluated by this launch (the union over the launch's queries = the rows the launch needs at
+// least once from HBM: the cold-miss lower bound of its DRAM traffic)
+template <bool PROF> __device__ __forceinline__ void mark_touched(const WalkLds &s, uint32_t id)
+{
+    if constexpr(PROF) {
+        if(s.touched) atomicOr(&s.touched[ id >> 5 ], 1u << (id & 31));
+    } else {
+        (void)s;
+        (void)id;
+    }
+}
 
 // the first operand of a (query, row) evaluation: the query row in LDS -- or, for ADC over PQ codes, just the chunk index (the
 // table sits at the start of LDS: device_common.hpp AdcQuery)
@@ -209,7 +223,7 @@ template <int L> __device__ __forceinline__ int quad_lower_bound(const uint64_t 
 
 // ---- search_for_one_: greedy descent over levels (begin, end] ---------------------------------------
 // Returns the closest slot (same value in every thread).  D counts distance evaluations.
-template <int METRIC, int G>
+template <int METRIC, int G, bool PROF = false>
 __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, int begin_level, int end_level, uint32_t &D)
 {
     const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
@@ -217,7 +231,7 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
         float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
-        if(gl == G - 1) { s.scal[ S_CUR ] = (int)start; s.scal[ S_CURD ] = __float_as_int(d); }
+        if(gl == G - 1) { s.scal[ S_CUR ] = (int)start; s.scal[ S_CURD ] = __float_as_int(d); mark_touched<PROF>(s, start); }
     }
     D += 1;
     __syncthreads();
@@ -243,7 +257,7 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
             for(int i = g; i < nn; i += NG) {
                 const uint32_t id = s.newids[ i ];
                 float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, id), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id));
-                if(gl == G - 1) newd[ i ] = d;
+                if(gl == G - 1) { newd[ i ] = d; mark_touched<PROF>(s, id); }
             }
             D += (uint32_t)nn;
             __syncthreads();
@@ -370,7 +384,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
         float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
-        if(gl == G - 1) s.keys[ 0 ] = make_key(d, start);
+        if(gl == G - 1) { s.keys[ 0 ] = make_key(d, start); mark_touched<PROF>(s, start); }
     }
     D += 1;
     __syncthreads();
@@ -431,7 +445,10 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                     }
                     const bool isnew = hop_is_new(s, bitmap, nb, spilled);
                     const unsigned long long m = __ballot(isnew);
-                    if(isnew) s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
+                    if(isnew) {
+                        s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
+                        mark_touched<PROF>(s, nb);
+                    }
                     nb_new += __popcll(m);
                 }
                 if(s.vis_slots && !spilled) viscnt += (uint32_t)nb_new;
@@ -542,7 +559,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
         float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
-        if(gl == G - 1) s.newkeys[ 0 ] = make_key(d, start);
+        if(gl == G - 1) { s.newkeys[ 0 ] = make_key(d, start); mark_touched<PROF>(s, start); }
     }
     D += 1;
     __syncthreads();
@@ -699,7 +716,10 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                     }
                     const bool isnew = hop_is_new(s, bitmap, nb, spilled);
                     const unsigned long long m = __ballot(isnew);
-                    if(isnew) s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
+                    if(isnew) {
+                        s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
+                        mark_touched<PROF>(s, nb);
+                    }
                     nb_new += __popcll(m);
                 }
                 if(s.vis_slots && !spilled) viscnt += (uint32_t)nb_new;
