@@ -177,7 +177,7 @@ bool pq_compact_locked(Index *ix)
     const uint32_t S16 = (ix->pq_S + 15) / 16 * 16;
     if(S16 > 128 || ix->pq_C > (uint32_t)ADC_LUT_STRIDE) { set_err(ix, "lantern_gpu: the compact form takes up to 128 subvectors and 256 centroids"); return false; }
     HIPCHK(ix, hipStreamSynchronize(ix->stream));
-    for(int l = 0; l < 2; ++l)
+    for(int l = 0; l < Index::kLanes; ++l)
         if(ix->lane_stream[ l ]) HIPCHK(ix, hipStreamSynchronize(ix->lane_stream[ l ]));
     if(ix->d_codes16) { (void)hipFree(ix->d_codes16); ix->d_codes16 = nullptr; }
     const size_t rows = std::max<size_t>(ix->n, 1);
@@ -1606,7 +1606,7 @@ try {
 }
 LANTERN_ABI_CATCH_VOID(e)
 
-// the page-locked staging block `which` (0 / 1: the lanes, 2: lantern_gpu_search_batch), grown on demand; nullptr on failure
+// the page-locked staging block `which` (0 .. kLanes - 1: the lanes, kLanes: lantern_gpu_search_batch), grown on demand; nullptr on failure
 static char *host_stage(Index *ix, int which, size_t need)
 try {
     if(ix->lane_host_bytes[ which ] < need) {
@@ -1636,7 +1636,7 @@ try {
     // queries and answers pass through one page-locked block: one copy up, one down (labels | distances | counts as they lie),
     // at the link's rate instead of through the runtime's staging of pageable memory
     const size_t q_bytes = nq * row_words * 4, out_bytes = nq * k * 12 + nq * 4;
-    char *const  hs = host_stage(ix, 2, q_bytes + out_bytes + 64);
+    char *const  hs = host_stage(ix, Index::kLanes, q_bytes + out_bytes + 64);
     if(!hs) { FAIL(e, "lantern_gpu: cannot allocate the page-locked staging block"); return; }
     uint32_t *const padded = (uint32_t *)hs;
     char *const     h_out = hs + ((q_bytes + 63) & ~(size_t)63);
@@ -1663,8 +1663,8 @@ try {
 }
 LANTERN_ABI_CATCH_VOID(e)
 
-// The same as lantern_gpu_search_batch for a caller that keeps TWO batches in flight (the scan-side service: one dispatcher
-// executes a batch while the other collects the next): each lane has its own stream and staging buffers, the index mutex is
+// The same as lantern_gpu_search_batch for a caller that keeps SEVERAL batches in flight (the scan-side service: up to four
+// dispatchers, each executing a batch while another collects the next): each lane has its own stream and staging buffers, the index mutex is
 // held only while the lane's copies and its launch are queued, and the wait for the answers happens outside it -- so the two
 // lanes' launches overlap on the device (each in its own visited-bitmap slab: acquire_search_slot).
 void lantern_gpu_search_batch_lane(usearch_index_t h, int lane, const void *queries, size_t nq, usearch_scalar_kind_t kind, size_t k, size_t ef,
@@ -1673,7 +1673,7 @@ try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
-    if(lane < 0 || lane > 1) { FAIL(e, "lantern_gpu: lane must be 0 or 1"); return; }
+    if(lane < 0 || lane >= Index::kLanes) { FAIL(e, "lantern_gpu: lane must be in [0, 4)"); return; }
     if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the queries does not match the index"); return; }
     if(nq == 0 || k == 0) return;
     if(!queries || !labels || !distances) { FAIL(e, "lantern_gpu: null buffer"); return; }

@@ -83,11 +83,12 @@ struct Index
     unsigned long long *d_totals = nullptr;  // [0..1] search D,E  [2..4] insert D,E,refine  [5] revlink pairs
 
     // scratch (grown on demand)
-    void  *d_scratch[ 16 ] = {};  // [12..15]: queries / answers of the two lanes of lantern_gpu_search_batch_lane
-    size_t scratch_bytes[ 16 ] = {};
-    hipStream_t lane_stream[ 2 ] = { nullptr, nullptr };  // created on first use
-    char       *lane_host[ 3 ] = { nullptr, nullptr, nullptr };  // page-locked staging of queries and answers: the two lanes (one caller each), [2] lantern_gpu_search_batch (under mu)
-    size_t      lane_host_bytes[ 3 ] = { 0, 0, 0 };
+    static const int kLanes = 4;  // lantern_gpu_search_batch_lane: batches one caller each may keep in flight side by side
+    void  *d_scratch[ 12 + 2 * kLanes ] = {};  // [12 ..]: queries / answers of the lanes of lantern_gpu_search_batch_lane
+    size_t scratch_bytes[ 12 + 2 * kLanes ] = {};
+    hipStream_t lane_stream[ kLanes ] = {};  // created on first use
+    char       *lane_host[ kLanes + 1 ] = {};  // page-locked staging of queries and answers: the lanes (one caller each), [kLanes] lantern_gpu_search_batch (under mu)
+    size_t      lane_host_bytes[ kLanes + 1 ] = {};
 
     // ---- host mirrors ------------------------------------------------------------------------------
     std::vector<uint64_t> labels;
@@ -155,12 +156,12 @@ struct Index
     // have two slabs ("launch slots"): two batches on two streams run side by side (the second fills the machine while the
     // first one's longest walks drain); a third waits for the slot it reuses.  INSERT batches mutate the graph: they wait for
     // every search in flight, and searches on other streams wait for them.
-    static const int kSearchSlots = 2;
-    uint32_t   *slot_bitmaps[ kSearchSlots ] = { nullptr, nullptr };  // [0] aliases d_bitmaps (the slab inserts use too)
-    size_t      slot_rows[ kSearchSlots ] = { 0, 0 }, slot_words[ kSearchSlots ] = { 0, 0 };
-    hipEvent_t  slot_done[ kSearchSlots ] = { nullptr, nullptr };
-    hipStream_t slot_stream[ kSearchSlots ] = { nullptr, nullptr };
-    bool        slot_pending[ kSearchSlots ] = { false, false };
+    static const int kSearchSlots = kLanes;  // one slab of visited bitmaps per search launch in flight (allocated on first use)
+    uint32_t   *slot_bitmaps[ kSearchSlots ] = {};  // [0] aliases d_bitmaps (the slab inserts use too)
+    size_t      slot_rows[ kSearchSlots ] = {}, slot_words[ kSearchSlots ] = {};
+    hipEvent_t  slot_done[ kSearchSlots ] = {};
+    hipStream_t slot_stream[ kSearchSlots ] = {};
+    bool        slot_pending[ kSearchSlots ] = {};
     unsigned    slot_next = 0;
     hipEvent_t  insert_done = nullptr;
     bool        insert_pending = false;

@@ -160,6 +160,8 @@ struct IoThread
 
 }  // namespace
 
+constexpr int kMaxLanes = 4;  // = Index::kLanes of the device library (lantern_gpu_search_batch_lane)
+
 struct lantern_scan_server
 {
     lantern_batch_search_fn fn = nullptr;
@@ -170,7 +172,7 @@ struct lantern_scan_server
     unsigned                max_wait_us = 200;
     int                     listen_fd = -1, port = 0;
     std::atomic<bool>       stop{ false };
-    std::thread             accept_thread, dispatch_thread[ 2 ];
+    std::thread             accept_thread, dispatch_thread[ kMaxLanes ];
     int                     lanes = 1;   // dispatchers: one collects the next batch while the other's batch is on the device
     std::vector<std::unique_ptr<IoThread>> io;
     std::mutex              collect_mu;  // held by the dispatcher that is collecting (one batch is formed at a time)
@@ -558,7 +560,10 @@ try {
     s->vec_bytes = ham ? (m.dimensions + 7) / 8 : m.dimensions * 4;
     s->fn = default_backend;
     s->fn_ctx = s;
-    s->lanes = 2;  // lantern_gpu_search_batch_lane
+    // dispatchers = lanes of lantern_gpu_search_batch_lane (up to four batches in flight on the device, each in its own slab of
+    // visited bitmaps).  Default two; LANTERN_SCAN_LANES = 1 .. 4.  (Measured with lantern-scan-load, 100k x 128: see DESIGN.md 4.6b.)
+    s->lanes = 2;
+    if(const char *ln = std::getenv("LANTERN_SCAN_LANES")) s->lanes = std::min(kMaxLanes, std::max(1, std::atoi(ln)));
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }
 LANTERN_ABI_CATCH(e)
@@ -572,8 +577,8 @@ try {
     s->fn = fn;
     s->fn_ctx = ctx;
     s->vec_bytes = vec_bytes;
-    // a caller-supplied backend is called from ONE thread unless LANTERN_SCAN_LANES=2 says it may be entered by two at a time
-    if(const char *ln = std::getenv("LANTERN_SCAN_LANES")) s->lanes = std::atoi(ln) >= 2 ? 2 : 1;
+    // a caller-supplied backend is called from ONE thread unless LANTERN_SCAN_LANES = 2 .. 4 says it may be entered by that many at a time
+    if(const char *ln = std::getenv("LANTERN_SCAN_LANES")) s->lanes = std::min(kMaxLanes, std::max(1, std::atoi(ln)));
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }
 LANTERN_ABI_CATCH(e)

@@ -63,11 +63,12 @@ def test_absurd_reserve_is_an_error_and_the_index_survives():
 
     from lantern_amd import capi
 
-    ix = capi.GpuIndex("l2sq", 8, M=4)
-    for cap in ((1 << 64) // 8 - 1, (1 << 31) - 2):  # above the slot range; inside it but far beyond HBM (17 GB of labels alone)
+    d = 1024
+    ix = capi.GpuIndex("l2sq", d, M=4)
+    for cap in ((1 << 64) // 8 - 1, (1 << 31) - 2):  # above the slot range; inside it but far beyond HBM (8.8 TB of rows)
         with pytest.raises(capi.LanternGpuError):
             ix.reserve(cap)
-    rows = np.random.default_rng(0).standard_normal((64, 8), dtype=np.float32)
+    rows = np.random.default_rng(0).standard_normal((64, d), dtype=np.float32)
     ix.add_many(np.arange(64, dtype=np.uint64) + 1, rows)
     lab, dist = ix.search(rows[5], 1)
     assert lab[0] == 6 and dist[0] == 0
