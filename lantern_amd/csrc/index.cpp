@@ -35,6 +35,10 @@ static const char *kNoDevice = "lantern_gpu: no HIP device available (this libra
 const char *set_err(Index *ix, const std::string &msg)
 {
     ix->err = msg;
+    // HIP keeps the last error of the thread until somebody reads it, and every launch wrapper ends in hipGetLastError(): a
+    // failed allocation (an absurd usearch_reserve) would otherwise fail the NEXT kernel launch of an index that is perfectly
+    // usable.  Every failure path ends here, so here it is taken off.
+    (void)hipGetLastError();
     return ix->err.c_str();
 }
 
@@ -51,10 +55,16 @@ static bool dev_grow(Index *ix, void **p, size_t old_bytes, size_t new_bytes, in
 {
     void *q = nullptr;
     HIPCHK(ix, hipMalloc(&q, new_bytes ? new_bytes : 16));
-    if(*p && old_bytes) HIPCHK(ix, hipMemcpyAsync(q, *p, old_bytes, hipMemcpyDeviceToDevice, ix->stream));
-    if(fill_new_with >= 0 && new_bytes > old_bytes)
-        HIPCHK(ix, hipMemsetAsync((char *)q + old_bytes, fill_new_with, new_bytes - old_bytes, ix->stream));
-    HIPCHK(ix, hipStreamSynchronize(ix->stream));
+    bool ok = true;
+    if(*p && old_bytes) ok = hipMemcpyAsync(q, *p, old_bytes, hipMemcpyDeviceToDevice, ix->stream) == hipSuccess;
+    if(ok && fill_new_with >= 0 && new_bytes > old_bytes)
+        ok = hipMemsetAsync((char *)q + old_bytes, fill_new_with, new_bytes - old_bytes, ix->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
+    if(!ok) {  // the old block stays the index's
+        (void)hipFree(q);
+        set_err(ix, "lantern_gpu: HIP failure while growing a device array");
+        return false;
+    }
     if(*p) HIPCHK(ix, hipFree(*p));
     *p = q;
     return true;
@@ -849,7 +859,15 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
                 per_cu = 1;
             }
         }
-        const int aw = adc_spec ? 11 : waves > 0 ? std::min(waves, 8) : 8;
+        // (rows of at most 8 chunks: a row wave holds eight 8-lane groups, so FOUR row waves cover a 32-entry list in one pass --
+        // measured, LANTERN_GPU_SPEC_WAVES=7: 1.84 M queries/s against 1.96 M with eight: the shorter row waves matter more)
+        int aw = adc_spec ? 11 : waves > 0 ? std::min(waves, 8) : 8;
+        if(adc_spec) {
+            if(const char *sw = std::getenv("LANTERN_GPU_SPEC_WAVES")) {
+                const int w = std::atoi(sw);
+                if(w >= 4 && w <= 11) aw = w;
+            }
+        }
         size_t     g = (size_t)ix->num_cus * (size_t)per_cu;
         if(ix->search_max_wg > 0) g = (size_t)ix->search_max_wg;
         const int grid = (int)std::max<size_t>(1, std::min(g, nq));
@@ -910,28 +928,31 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
             // second query after the first: two workgroups side by side measure the same, 631 vs 627 k at 512 queries)
             if(se) spec = std::atoi(se);
             else if(nq <= (size_t)ix->num_cus * 2) spec = 2;  // (1M x 768 cosine: 384 queries 528 k vs 389 k, 512: 624 k vs 500 k, 768: 658 k vs 691 k)
-            if(spec < 0 || spec > 2) spec = 0;
+            if(spec < 0 || spec > 3) spec = 0;
+            // (3: two nodes per round, the second speculative -- walk_twin.hpp; on request only: measured slower)
+            if(spec == 3 && !(expansion <= 64 && (ix->mcode == M_L2SQ || ix->mcode == M_COS) && (group_lanes_for(ix->chunks) == 64 || (ix->mcode == M_L2SQ && group_lanes_for(ix->chunks) == 16))))
+                spec = 2;
         }
         // (measured, classic kernel, 1M x 768 cosine, 1024 queries: 4 waves 693 k QPS, 6 waves 525 k, 8 waves 594 k -- more waves
         // only make its serial phases costlier; so four waves per query whatever the batch size)
-        waves = spec == 2 ? 11 : spec == 1 ? 4 : waves < 0 ? -waves : 4;  // (a negative count: the caller's classic fallback)
+        waves = spec >= 2 ? 11 : spec == 1 ? 4 : waves < 0 ? -waves : 4;  // (a negative count: the caller's classic fallback)
         if(spec) {  // tuning: LANTERN_GPU_SPEC_WAVES = waves per query of the latency-bound shapes (spec 1: 2..8; spec 2: 4..11)
             if(const char *sw = std::getenv("LANTERN_GPU_SPEC_WAVES")) {
                 const int w = std::atoi(sw);
-                if(w >= (spec == 2 ? 4 : 2) && w <= (spec == 2 ? 11 : 8)) waves = w;
+                if(w >= (spec >= 2 ? 4 : 2) && w <= (spec >= 2 ? 11 : 8)) waves = w;
             }
         }
     }
     // list prefetch of the latency-bound walk: every lane of a row's group fetches LW words of the row's own list
     const int      G_ = group_lanes_for(ix->chunks), LW_ = G_ >= 32 ? 1 : G_ == 16 ? 2 : 4;
     const uint32_t spec_prefetch = spec && ix->M0 % (uint32_t)LW_ == 0 && ix->M0 <= (uint32_t)(G_ * LW_) ? 1u : 0u;
-    const uint32_t spec_cache = !spec_prefetch ? 0u : spec == 2 ? 128u : 64u;
-    const size_t   spec_lds = spec ? search_spec_lds_bytes(ix->M0, spec_prefetch, spec_cache) : 0;
+    const uint32_t spec_cache = !spec_prefetch ? 0u : spec >= 2 ? 128u : 64u;
+    const size_t   spec_lds = spec ? search_spec_lds_bytes(ix->M0, spec_prefetch, spec_cache, spec == 3) : 0;
     // LDS visited set: sized for ~3x the planner's estimate of visited nodes per query (hnsw.c:89-132 puts it at
     // about 2 M ef S with S ~ 3), capped so that SIX workgroups fit on a CU (more walks in flight beat a roomier
     // set: 1.106 -> 1.17 M QPS at 1M x 768) -- four for the four-wave latency-bound shape, one for the lone-query shape;
     // it spills to the bitmap beyond
-    const size_t lds_budget = spec == 2 ? 96 * 1024 : spec == 1 ? 39 * 1024 : 26 * 1024;
+    const size_t lds_budget = spec >= 2 ? 96 * 1024 : spec == 1 ? 39 * 1024 : 26 * 1024;
     uint32_t vis_slots = 1024;
     while(vis_slots < 8192 && vis_slots / 4 * 3 < expansion * ix->M0 * 2) vis_slots <<= 1;
     if(ix->search_vis_slots >= 0) vis_slots = (uint32_t)ix->search_vis_slots / 4 * 4;
@@ -942,7 +963,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         set_err(ix, "lantern_gpu: ef/k exceed the 160 KiB LDS budget of the search kernel");
         return false;
     }
-    const int grid = search_grid(ix, nq, waves, spec == 2 ? waves : spec == 1 ? 16 : 24);
+    const int grid = search_grid(ix, nq, waves, spec >= 2 ? waves : spec == 1 ? 16 : 24);
     const int slot = acquire_search_slot(ix, stream, (size_t)grid);
     if(slot < 0) return false;
     SearchArgs a{};

@@ -29,7 +29,8 @@ struct SearchArgs
     int             lds_list;    // keep the candidate list in LDS even when it fits wave 0's registers (LANTERN_GPU_LDS_LIST=1: the
                                  // round-1 walk, kept for A/B parity runs and for ef > 128)
     int             wide_rows;   // small batch: the four-rows-in-flight instantiation (k_search<.., ROWS = 4>)
-    int             spec;        // latency-bound launches (walk_spec.hpp): 1 = four-wave shape, 2 = dedicated role waves (3 + 8 waves); 0 = off
+    int             spec;        // latency-bound launches (walk_spec.hpp): 1 = four-wave shape, 2 = dedicated role waves (3 + 8 waves), 3 = the same with two
+                                 // nodes per round, the second speculative (walk_twin.hpp); 0 = off
     uint32_t        spec_prefetch;  // fetch every evaluated row's own level-0 list with the row (M0 % 4 == 0, M0 / 4 <= lanes per row)
     uint32_t        spec_cache;     // entries of the LDS list cache (power of two; 0 = none)
     // ADC over PQ codes (search_adc_kernel.hip; view.vec = the code rows, view.chunks = 16-byte chunks per code row)
@@ -123,7 +124,7 @@ hipError_t launch_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, ui
 // All launchers return hipSuccess or the launch error.  `metric` is a usearch_metric_kind_t value.
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_search_spec(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);  // a.spec != 0 (search_spec_kernel.hip)
-size_t     search_spec_lds_bytes(uint32_t M0, uint32_t prefetch, uint32_t cache_entries);
+size_t     search_spec_lds_bytes(uint32_t M0, uint32_t prefetch, uint32_t cache_entries, uint32_t twin = 0);
 hipError_t launch_search_adc(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);  // metric = M_L2SQ_ADC / M_COS_ADC
 size_t     search_adc_lds_bytes(uint32_t code_chunks, uint32_t qchunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots);
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);

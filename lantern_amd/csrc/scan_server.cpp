@@ -561,8 +561,10 @@ try {
     s->fn = default_backend;
     s->fn_ctx = s;
     // dispatchers = lanes of lantern_gpu_search_batch_lane (up to four batches in flight on the device, each in its own slab of
-    // visited bitmaps).  Default two; LANTERN_SCAN_LANES = 1 .. 4.  (Measured with lantern-scan-load, 100k x 128: see DESIGN.md 4.6b.)
-    s->lanes = 2;
+    // visited bitmaps).  Default four; LANTERN_SCAN_LANES = 1 .. 4.  Measured with lantern-scan-load on 100k x 128 (round 4,
+    // profiles/r04_scan_load_lanes.jsonl; lanes 1 / 2 / 3 / 4): 16 backends p50 201 / 214 / 193 / 173 us, 64: 301 / 243 / 235 / 227 us,
+    // 256: 389 k / 560 k / 563 k / 628 k scans/s; 8 backends 157 us whatever the number.
+    s->lanes = 4;
     if(const char *ln = std::getenv("LANTERN_SCAN_LANES")) s->lanes = std::min(kMaxLanes, std::max(1, std::atoi(ln)));
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }

@@ -69,7 +69,9 @@ __device__ __forceinline__ void adc_build_table(float *lut, const float *centers
 // SPEC: the latency-bound walk of walk_spec.hpp in its lone-query shape (three role waves + eight row waves, one barrier per hop,
 // neighbour lists fetched with the rows).  A table of 96 x 256 entries leaves room for ONE workgroup per CU, so every query of
 // a batch walks alone on its CU whatever the batch size: the walk that is fastest alone is the one to run.
-template <int METRIC, int KPL, bool SPEC = false>
+// (SPEC 2 = the lone-query shape.  The two-nodes-per-round form of walk_twin.hpp was measured here too -- 1.98 -> 1.65 M queries/s at
+// 96 subvectors -- and is not instantiated.)
+template <int METRIC, int KPL, int SPEC = 0>
 __global__ void __launch_bounds__(SPEC ? 704 : 512, SPEC ? 1 : 2) k_search_adc(SearchArgs)
 {
     // (arguments are re-read from the kernarg segment where a query needs them, as in k_search -- search_kernel.hpp: kept live
@@ -84,7 +86,7 @@ __global__ void __launch_bounds__(SPEC ? 704 : 512, SPEC ? 1 : 2) k_search_adc(S
         lut_chunks = LGPU_VIEW_ARG(ka, SearchArgs, chunks) * 16 * ADC_LUT_STRIDE / 4;
         unsigned char *end = carve_walk(lgpu_smem, s, lut_chunks + LGPU_SEARCH_ARG(ka, adc_qchunks), LGPU_SEARCH_ARG(ka, ef), LGPU_VIEW_ARG(ka, SearchArgs, M0),
                                         LGPU_SEARCH_ARG(ka, vis_slots));  // s.q = the table, then the raw query row
-        if constexpr(SPEC) carve_spec(end, sc, LGPU_VIEW_ARG(ka, SearchArgs, M0), LGPU_SEARCH_ARG(ka, spec_prefetch), LGPU_SEARCH_ARG(ka, spec_cache));
+        if constexpr(SPEC != 0) carve_spec(end, sc, LGPU_VIEW_ARG(ka, SearchArgs, M0), LGPU_SEARCH_ARG(ka, spec_prefetch), LGPU_SEARCH_ARG(ka, spec_cache));
         else (void)end;
     }
     float *const       lut = (float *)s.q;
@@ -126,8 +128,8 @@ __global__ void __launch_bounds__(SPEC ? 704 : 512, SPEC ? 1 : 2) k_search_adc(S
             uint32_t      *bitmap = LGPU_SEARCH_ARG(ka, bitmaps) + (size_t)blockIdx.x * bm_words;
             const int      ef = (int)LGPU_SEARCH_ARG(ka, ef);
             if(v.n != 0) {
-                if constexpr(SPEC) {
-                    static_assert(!SPEC || KPL > 0, "the latency-bound walk keeps its list in registers");
+                if constexpr(SPEC != 0) {
+                    static_assert(SPEC == 0 || KPL > 0, "the latency-bound walk keeps its list in registers");
                     const uint32_t start = greedy_descent_spec<METRIC, G>(v, s, v.entry, v.max_level, 0, D);
                     cnt = search_level_spec<METRIC, G, (KPL > 0 ? KPL : 1), 1, 2, true, false>(v, s, sc, bitmap, bm_words, start, ef, D, E, nullptr);
                 } else {
@@ -200,11 +202,11 @@ hipError_t launch_search_adc(int metric, const SearchArgs &a, int waves, int gri
 #define LGPU_ADC(MM)                                  \
     {                                                 \
         if(a.spec) {                                  \
-            if(kpl == 1) LGPU_ADC1(MM, 1, true)       \
-            else LGPU_ADC1(MM, 2, true)               \
-        } else if(kpl == 1) LGPU_ADC1(MM, 1, false)   \
-        else if(kpl == 2) LGPU_ADC1(MM, 2, false)     \
-        else LGPU_ADC1(MM, 0, false)                  \
+            if(kpl == 1) LGPU_ADC1(MM, 1, 2)          \
+            else LGPU_ADC1(MM, 2, 2)                  \
+        } else if(kpl == 1) LGPU_ADC1(MM, 1, 0)       \
+        else if(kpl == 2) LGPU_ADC1(MM, 2, 0)         \
+        else LGPU_ADC1(MM, 0, 0)                      \
     }
     if(metric == M_L2SQ_ADC) LGPU_ADC(M_L2SQ_ADC)
     else if(metric == M_COS_ADC) LGPU_ADC(M_COS_ADC)

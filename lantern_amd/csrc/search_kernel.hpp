@@ -10,6 +10,7 @@
 #include "kernels.hpp"
 #include "walk.hpp"
 #include "walk_spec.hpp"
+#include "walk_twin.hpp"
 #include "dispatch.hpp"
 
 namespace lgpu {
@@ -49,9 +50,10 @@ __device__ __forceinline__ KernargBytes kernarg_opaque()
     }
 
 // SPEC: the latency-bound walk of walk_spec.hpp -- 1: every wave evaluates rows and waves 0..2 carry the roles on top (the
-// small-batch shape, four waves); 2: three dedicated role waves + row waves (the lone-query shape, 3 + 8 waves).
+// small-batch shape, four waves); 2: three dedicated role waves + row waves (the lone-query shape, 3 + 8 waves); 3: the same
+// shape with two nodes per round, the second one speculative (walk_twin.hpp).
 template <int METRIC, int G, bool PROF = false, int ROWS = 2, int KPL = 1, int SPEC = 0>
-__global__ void __launch_bounds__(SPEC == 2 ? 704 : 512, SPEC == 2 ? 3 : (SPEC == 1 || ROWS != 2) ? 4 : 6)  // SPEC 0, ROWS 2: <= 80 VGPRs, six 4-wave workgroups per CU
+__global__ void __launch_bounds__(SPEC >= 2 ? 704 : 512, SPEC >= 2 ? 3 : (SPEC == 1 || ROWS != 2) ? 4 : 6)  // SPEC 0, ROWS 2: <= 80 VGPRs, six 4-wave workgroups per CU
 k_search(SearchArgs)
 {
     const int tid = threadIdx.x, T = blockDim.x;
@@ -61,7 +63,7 @@ k_search(SearchArgs)
         const KernargBytes ka = kernarg_opaque();
         unsigned char     *end = carve_walk(lgpu_smem, s, LGPU_VIEW_ARG(ka, SearchArgs, chunks), LGPU_SEARCH_ARG(ka, ef), LGPU_VIEW_ARG(ka, SearchArgs, M0),
                                             LGPU_SEARCH_ARG(ka, vis_slots));
-        if constexpr(SPEC != 0) carve_spec(end, sc, LGPU_VIEW_ARG(ka, SearchArgs, M0), LGPU_SEARCH_ARG(ka, spec_prefetch), LGPU_SEARCH_ARG(ka, spec_cache));
+        if constexpr(SPEC != 0) carve_spec(end, sc, LGPU_VIEW_ARG(ka, SearchArgs, M0), LGPU_SEARCH_ARG(ka, spec_prefetch), LGPU_SEARCH_ARG(ka, spec_cache), SPEC == 3 ? 1u : 0u);
         else (void)end;
     }
     for(uint32_t q = blockIdx.x; q < LGPU_SEARCH_ARG(kernarg_opaque(), nq);) {
@@ -95,7 +97,10 @@ k_search(SearchArgs)
                 else start = greedy_descent<METRIC, G, PROF>(v, s, v.entry, v.max_level, 0, D);
                 if constexpr(PROF) pc[ 6 ] = (unsigned long long)clock64() - t_q;
                 // KPL keys per lane of wave 0 hold the candidate list (ef <= 64 KPL); KPL = 0: the list lives in LDS
-                if constexpr(SPEC != 0)
+                if constexpr(SPEC == 3)
+                    cnt = search_level_twin<METRIC, G, KPL, ROWS, (G == 64 ? 3 : 2), PROF>(v, s, sc, bitmap, bm_words, start, ef, D, E,
+                                                                                           PROF ? LGPU_SEARCH_ARG(ka, phase_cycles) : nullptr);
+                else if constexpr(SPEC != 0)
                     cnt = search_level_spec<METRIC, G, KPL, ROWS, (G == 64 && SPEC == 2 ? 3 : 2), SPEC == 2, PROF>(v, s, sc, bitmap, bm_words, start, ef, D, E,
                                                                                                                      PROF ? LGPU_SEARCH_ARG(ka, phase_cycles) : nullptr);
                 else if constexpr(KPL > 0) cnt = search_level_reg<METRIC, G, KPL, PROF, ROWS>(v, s, bitmap, bm_words, start, 0, ef, D, E, pc);

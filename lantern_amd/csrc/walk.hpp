@@ -145,6 +145,24 @@ __device__ __forceinline__ bool visit_test_and_set(WalkLds &s, uint32_t *bitmap,
     return (atomicOr(&bitmap[ x >> 5 ], bit) & bit) != 0;
 }
 
+// Was `x` visited?  Nothing is recorded (the two-nodes-per-round walk tests the neighbours of the node it expands speculatively
+// and records them only once the speculation has come true: walk_twin.hpp).
+__device__ __forceinline__ bool visit_test(const WalkLds &s, uint32_t *bitmap, uint32_t x, bool spilled)
+{
+    if(s.vis_slots) {
+        const uint32_t nb4 = s.vis_slots >> 2;
+        uint32_t       b = vis_hash(x, nb4);
+        for(;;) {
+            const VisProbe p = vis_look(s, b, x, 0);
+            if(p.found) return true;
+            if(p.e >= 0) break;  // a bucket with a free slot ends the chain: not in the LDS set
+            b = b + 1 == nb4 ? 0u : b + 1;
+        }
+        if(!spilled) return false;
+    }
+    return ((atomicOr(&bitmap[ x >> 5 ], 0u) >> (x & 31)) & 1u) != 0;  // (an atomic read: the bits are set by atomics, past the CU's L1)
+}
+
 // One lane's share of a hop's visited filter: is neighbour `nb` (EMPTY = no neighbour) new?  The common case is straight-line
 // code for the whole wave -- one bucket read, one CAS -- and only lanes that met a full bucket or lost a slot to another lane
 // take the probing loop (its divergent control flow costs more scalar instructions than the LDS accesses themselves).

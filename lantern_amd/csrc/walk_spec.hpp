@@ -34,11 +34,17 @@ struct SpecLds
     uint32_t *ctag;    // [cache_entries] slot whose list the entry holds (EMPTY: none)
     uint32_t *clist;   // [cache_entries][M0]
     uint32_t  cache_entries;  // power of two, or 0
+    // the two-nodes-per-round walk (walk_twin.hpp) on top: the same for the SPECULATIVE node of a round
+    uint32_t *stage2;  // [2][M0][M0]
+    uint64_t *keys2;   // [2][M0] its neighbours' keys, by round parity
+    uint64_t *tw;      // [2][8] by round parity: the list's first three unexpanded keys | its radius | the two "new" masks
 };
-__device__ __forceinline__ unsigned char *carve_spec(unsigned char *p, SpecLds &c, uint32_t M0, uint32_t prefetch, uint32_t cache_entries)
+constexpr int TW_F0 = 0, TW_W = 3, TW_MASK1 = 4, TW_MASK2 = 5, TW_STRIDE = 8;
+__device__ __forceinline__ unsigned char *carve_spec(unsigned char *p, SpecLds &c, uint32_t M0, uint32_t prefetch, uint32_t cache_entries, uint32_t twin = 0)
 {
-    c.stage = nullptr;
+    c.stage = c.stage2 = nullptr;
     c.ctag = c.clist = nullptr;
+    c.keys2 = c.tw = nullptr;
     c.cache_entries = 0;
     if(prefetch) {
         c.stage = (uint32_t *)p;   p += (size_t)2 * M0 * M0 * 4;
@@ -46,11 +52,17 @@ __device__ __forceinline__ unsigned char *carve_spec(unsigned char *p, SpecLds &
         c.clist = (uint32_t *)p;   p += (size_t)cache_entries * M0 * 4;
         c.ctag = (uint32_t *)p;    p += (((size_t)cache_entries * 4) + 15) & ~(size_t)15;
     }
+    if(twin) {
+        if(prefetch) { c.stage2 = (uint32_t *)p; p += (size_t)2 * M0 * M0 * 4; }
+        c.keys2 = (uint64_t *)p;   p += (((size_t)2 * M0 * 8) + 15) & ~(size_t)15;
+        c.tw = (uint64_t *)p;      p += (size_t)2 * TW_STRIDE * 8;
+    }
     return p;
 }
-__host__ inline size_t spec_lds_bytes(uint32_t M0, uint32_t prefetch, uint32_t cache_entries)
+__host__ inline size_t spec_lds_bytes(uint32_t M0, uint32_t prefetch, uint32_t cache_entries, uint32_t twin = 0)
 {
-    return prefetch ? (size_t)2 * M0 * M0 * 4 + (size_t)cache_entries * M0 * 4 + ((((size_t)cache_entries * 4) + 15) & ~(size_t)15) : 0;
+    return (prefetch ? (size_t)2 * M0 * M0 * 4 + (size_t)cache_entries * M0 * 4 + ((((size_t)cache_entries * 4) + 15) & ~(size_t)15) : 0) +
+           (twin ? (prefetch ? (size_t)2 * M0 * M0 * 4 : 0) + ((((size_t)2 * M0 * 8) + 15) & ~(size_t)15) + (size_t)2 * TW_STRIDE * 8 : 0);
 }
 
 __device__ __forceinline__ uint64_t uniform64(uint64_t x)  // a value every lane read from the same address, as scalar registers
@@ -273,11 +285,15 @@ __device__ int search_level_spec_impl(const View &v, WalkLds &s, const SpecLds &
     uint64_t *const front_pub = (uint64_t *)&s.scal[ S_FRONT ];  // [2] by hop parity: first unexpanded key of the list the hop starts from
     uint64_t *const worst_pub = (uint64_t *)&s.scal[ S_WORST ];  // [2] its radius (~0: not full)
     uint64_t *const mask_pub = (uint64_t *)&s.scal[ S_MASK ];    // [2] which neighbours of the hop were new
-    uint64_t *const keysb[ 2 ] = { s.newkeys, s.sorted };        // a hop's keys, by hop parity (both hold cap_max >= M0 keys)
+    // a hop's keys, by hop parity: s.newkeys | s.sorted (both hold cap_max >= M0 keys), addressed as ONE base + parity * stride -- a
+    // select between two pointers loses their LDS address space and the accesses become flat_load / flat_store (seen in the ISA:
+    // every wave's first load of a hop, on the critical path, and the row waves' key stores)
+    uint64_t *const keys0 = s.newkeys;
+    const ptrdiff_t kstride = s.sorted - s.newkeys;
     // "hop -1" (parity 1) evaluated one row: the start node
     if(wv == 0 && g == 0) {
         const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
-        if(gl == G - 1) keysb[ 1 ][ 0 ] = make_key(d, start);
+        if(gl == G - 1) keys0[ kstride ] = make_key(d, start);
         constexpr int LW = spec_list_words<G>();
         if(c.stage && gl * LW < (int)M0) {
             uint32_t piece[ 4 ];
@@ -312,7 +328,7 @@ __device__ int search_level_spec_impl(const View &v, WalkLds &s, const SpecLds &
     if constexpr(PROF) tl = (unsigned long long)clock64();
     for(int hop = 0;; ++hop) {
         const int             par = hop & 1, prv = par ^ 1;
-        const uint64_t *const kin = keysb[ prv ];
+        const uint64_t *const kin = keys0 + (ptrdiff_t)prv * kstride;
         // ---- what the previous hop left: its keys, which of them were new, and the list they are still to be merged into
         const uint64_t           f = uniform64(front_pub[ par ]), w = uniform64(worst_pub[ par ]);
         const unsigned long long pm = uniform64(mask_pub[ prv ]);
@@ -475,7 +491,7 @@ __device__ int search_level_spec_impl(const View &v, WalkLds &s, const SpecLds &
         LGPU_SMARK(3)
         // ---- distances -> this hop's keys (all neighbours; the mask sorts out the old ones)
         if(row_wave) {
-            uint64_t *const kout = keysb[ par ];
+            uint64_t *const kout = keys0 + (ptrdiff_t)par * kstride;
             uint32_t *const sout = c.stage ? c.stage + (size_t)par * M0 * M0 : nullptr;
             spec_consume<METRIC, G, ROWS, U>(v, s, c, p, count, gl, qn2, kout, sout);
             for(int base = ngroups * ROWS; base < count; base += ngroups * ROWS) {  // lists longer than one pass covers

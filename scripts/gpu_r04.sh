@@ -48,4 +48,71 @@ for f in ('cos','clustered'):
 P
 }
 
+# the rest of the test list of `traffic` (it stops at the first failure), then the scan service with 1 / 2 / 3 / 4 lanes
+lanes() {
+  timeout 900 python -m pytest tests/test_c_abi.py tests/test_reference_index_sizes.py tests/test_gpu_scans_and_inserts.py tests/test_gpu_quantized_indexes.py tests/test_scan_server.py \
+     "tests/test_gpu_build_parity_production_batch.py::test_device_build_with_8192_row_batches_is_the_oracles_graph_edge_for_edge[c5_gaussian_64k_x_1536_l2sq]" \
+     tests/test_gpu_c4_c5_at_size.py::test_c5_batched_build_against_the_sequential_reference_build_at_100k_x_1536 -q -s --durations=8 > $OUT/lanes_tests.log 2>&1
+  tail -15 $OUT/lanes_tests.log
+  rm -f $OUT/r04_scan_load_lanes.jsonl
+  for l in 1 2 3 4; do for c in 1 8 16 64 256; do
+    echo "{\"lanes\": $l}" >> $OUT/r04_scan_load_lanes.jsonl
+    LANTERN_SCAN_LANES=$l timeout 60 lantern_amd/lib/lantern-scan-load --connections $c --seconds 3 >> $OUT/r04_scan_load_lanes.jsonl 2>> $OUT/scanload.err
+  done; done
+  python - <<'P'
+import json
+lanes=None
+for l in open('gpurun_out/r04/r04_scan_load_lanes.jsonl'):
+    d=json.loads(l)
+    if 'lanes' in d and len(d)==1: lanes=d['lanes']; continue
+    print(lanes, {k:d.get(k) for k in ('connections','qps','latency_us_p50','latency_us_p99','mean_batch')} if 'qps' in d else list(d.items())[:8])
+P
+}
+
+# the two-nodes-per-round walk: parity in every regime, then the lone query and the compact pq index with and without it
+twin() {
+  timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "latency_bound or lone_query" > $OUT/twin_tests.log 2>&1; tail -6 $OUT/twin_tests.log
+  timeout 300 python -m pytest tests/test_gpu_quantized_indexes.py tests/test_c_abi.py "tests/test_gpu_scans_and_inserts.py" -q > $OUT/twin_tests2.log 2>&1; tail -4 $OUT/twin_tests2.log
+  for t in 0 1; do
+    LANTERN_GPU_TWIN=$t timeout 200 python scripts/bench_single_query.py > $OUT/single_twin$t.json 2> $OUT/single_twin$t.err
+    python -c "
+import json; d=json.load(open('$OUT/single_twin$t.json')); print('twin=$t', d['us_per_query_wall'], d['kernel_only']['latency_bound_shape'], d['identical_to_batch_search'], d.get('cpu_port_us_per_query_1_thread'))"
+  done
+  for t in 0 1; do
+    LANTERN_GPU_TWIN=$t timeout 300 python bench.py --no-cpu --no-pmc --data clustered --pq-subvectors 96 --steps 5 > $OUT/pq96_twin$t.json 2> $OUT/pq96_twin$t.err
+    python -c "
+import json; d=json.load(open('$OUT/pq96_twin$t.json')); print('pq96 twin=$t', d['value'], d['recall_at_10'], d['ms_per_step'])"
+  done
+}
+
+twinprof() {
+  timeout 300 python scripts/profile_twin.py > $OUT/twin_profile.json 2> $OUT/twin_profile.err; cat $OUT/twin_profile.json; tail -3 $OUT/twin_profile.err
+}
+
+smallidx() {
+  timeout 300 python scripts/profile_small_index.py > $OUT/small_index_profile.json 2> $OUT/small_index.err; python - <<'P'
+import json
+d=json.load(open('gpurun_out/r04/small_index_profile.json'))
+for k,v in d.items():
+    print(k, 'us/launch', round(v['us_per_launch'],1), 'hops', round(v['hops_per_query'],1), 'us/hop', round(v['us_per_hop'],3))
+    for role,sec in v['cycles_per_hop'].items(): print('   ', role, {a:round(b) for a,b in sec.items()})
+P
+  tail -3 $OUT/small_index.err
+}
+
+# 3 + 4 waves (two per SIMD) against 3 + 8 for the lone query and the compact pq index
+waves7() {
+  timeout 300 python -m pytest tests/test_gpu_parity.py -q -x -k "latency_bound or lone_query" > $OUT/w7_tests.log 2>&1; tail -3 $OUT/w7_tests.log
+  for w in 11 7; do
+    LANTERN_GPU_SPEC_WAVES=$w timeout 200 python scripts/bench_single_query.py --no-cpu > $OUT/single_w$w.json 2> $OUT/single_w$w.err
+    python -c "
+import json; d=json.load(open('$OUT/single_w$w.json')); print('waves=$w', d['us_per_query_wall'], d['kernel_only']['latency_bound_shape'], d['identical_to_batch_search'])"
+  done
+  for w in 11 7; do
+    LANTERN_GPU_SPEC_WAVES=$w timeout 300 python bench.py --no-cpu --no-pmc --data clustered --pq-subvectors 96 --steps 5 > $OUT/pq96_w$w.json 2> $OUT/pq96_w$w.err
+    python -c "
+import json; d=json.load(open('$OUT/pq96_w$w.json')); print('pq96 waves=$w', d['value'], d['recall_at_10'], d['ms_per_step'])"
+  done
+}
+
 "$@"

@@ -44,6 +44,8 @@ def measure(ix, queries, nq_per_launch, launches, k=10, ef=64):
             out["us_per_launch_instrumented"] = us
             out["hops_per_query"] = hops / (launches * nq_per_launch)
             out["cycles_per_hop"] = {role: {k2: v / hops for k2, v in sec.items() if k2 not in ("hops", "list_source")} for role, sec in p.items()}
+            out["rounds_per_query"] = hops / (launches * nq_per_launch)
+            out["speculative_nodes_completed_per_round"] = p["list"]["list_source"] / hops  # (the two-nodes-per-round walk: walk_twin.hpp; else 0)
             tot = max(p["visit"]["list_source"] + p["row"]["list_source"] + p["fill"]["list_source"], 1)
             out["neighbour_list_source"] = {"staged_with_previous_hop": p["visit"]["list_source"] / tot, "lds_cache": p["row"]["list_source"] / tot,
                                             "hbm": p["fill"]["list_source"] / tot}

@@ -188,12 +188,16 @@ def test_c5_batched_build_against_the_sequential_reference_build_at_100k_x_1536(
     """north_star "recall@10 within +-0.5 % of the reference" on C5's own row shape: the reference adds one tuple at a time
     (build.c:83-135); the device in batches of up to 8192 (never more than size / 16).  Same 100k seed-7 rows, same seed-8
     queries, both graphs searched on the device against exact truth.  The sequential build is the CPU port on one thread
-    with the reference's summation flags (~100 s: the price of this test)."""
+    with the reference's summation flags (~100-170 s: the price of this test).
+
+    8 000 queries, not C5's 1 000: on i.i.d. Gaussian rows recall@10 is ~0.36 and its standard error over 1 000 queries is
+    ~0.005 -- the bar itself (measured in round 4: the same comparison gave +0.0053 on seeds 1 / 2 and -0.0063 on seeds 7 / 8
+    with 1 000 queries each).  The first 1 000 of the 8 000 ARE the seed-8 queries of SURVEY 8d."""
     from lantern_amd import capi, hip
 
     n = 100_000
     base = np.random.default_rng(7).standard_normal((n, C5_D), dtype=np.float32)
-    queries = np.random.default_rng(8).standard_normal((1000, C5_D), dtype=np.float32)
+    queries = np.random.default_rng(8).standard_normal((8000, C5_D), dtype=np.float32)
     dev, t_dev = build(capi, "l2sq", base, 64)
     truth, _ = dev.exact_search(queries, K)
     r_dev = oracle.recall_at_k(run(hip, dev, queries, 64)[2], truth)

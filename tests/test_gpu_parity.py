@@ -685,7 +685,8 @@ def test_candidate_list_in_registers_or_lds_gives_the_oracle_walk(capi, oracle, 
 # ------------------------------------------------------------------------------------------------
 # the latency-bound walk (walk_spec.hpp): one barrier per hop, speculative row loads behind which the visited filter, the list
 # merge and the list-cache fill run, neighbour lists fetched with the rows.  LANTERN_GPU_SPEC=1: the four-wave batch shape,
-# =2: the lone-query shape (three role waves + eight row waves).  Every lanes-per-row regime (8 / 16 / 32 / 64), list widths
+# =2: the lone-query shape (three role waves + eight row waves), =3: the same shape with two nodes per round, the second one
+# speculative (walk_twin.hpp).  Every lanes-per-row regime (8 / 16 / 32 / 64), list widths
 # with and without the list prefetch (M0 = 10 has no 16-byte pieces at 8 lanes per row), M0 = 64 (two passes per hop), both
 # register-list widths (ef <= 64, <= 128), every storage kind -- against the oracle on the same graph: ids, distance bits, D, E.
 # ------------------------------------------------------------------------------------------------
@@ -694,7 +695,7 @@ SPEC_SHAPES = [("l2sq", 3000, 128, 16, 64, "f32"), ("cos", 2500, 768, 16, 64, "f
                ("l2sq", 1500, 768, 8, 64, "f16"), ("cos", 1500, 256, 16, 48, "i8"), ("l2sq", 700, 2000, 4, 20, "f32"), ("l2sq", 800, 600, 32, 64, "f32")]
 
 
-@pytest.mark.parametrize("spec", ["1", "2"])
+@pytest.mark.parametrize("spec", ["1", "2", "3"])
 @pytest.mark.parametrize("metric,n,d,M,ef,quant", SPEC_SHAPES)
 def test_latency_bound_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef, quant, spec, monkeypatch):
     from lantern_amd import hip
@@ -770,7 +771,7 @@ def test_latency_bound_walk_with_a_spilling_visited_set(capi, oracle, monkeypatc
     assert o_D.max() > 300
     for vis_slots in ("256", "0"):  # 256: spills to the HBM bitmap after ~190 visits; 0: the bitmap only
         monkeypatch.setenv("LANTERN_GPU_VIS_SLOTS", vis_slots)
-        for spec in ("1", "2"):
+        for spec in ("1", "2", "3"):
             monkeypatch.setenv("LANTERN_GPU_SPEC", spec)
             gpu = capi.GpuIndex("l2sq", 64, M=16, ef_construction=64, ef=128, seed=9)
             gpu.import_graph(base, ora.export_graph())

@@ -111,15 +111,16 @@ def test_searches_on_two_streams_share_the_index_safely(capi, monkeypatch):
             assert np.array_equal(o_d[j].download((nq, k), np.float32), want[j & 1][1])
 
 
-def test_two_lanes_of_the_host_buffer_search_run_side_by_side(capi):
-    """lantern_gpu_search_batch_lane: two caller threads, one lane each, many rounds; every answer equals the plain batch search."""
+def test_the_lanes_of_the_host_buffer_search_run_side_by_side(capi):
+    """lantern_gpu_search_batch_lane: four caller threads, one lane each, many rounds; every answer equals the plain batch search."""
     rng = np.random.default_rng(31)
     n, d, k = 20000, 32, 10
     base = rng.standard_normal((n, d), dtype=np.float32)
     ix = capi.GpuIndex("l2sq", d, M=12, ef_construction=48, ef=48, seed=3)
     ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
     ix.flush()
-    qs = [rng.standard_normal((700 + 300 * lane, d), dtype=np.float32) for lane in (0, 1)]
+    LANES = (0, 1, 2, 3)
+    qs = [rng.standard_normal((700 + 300 * lane, d), dtype=np.float32) for lane in LANES]
     want = [ix.search_batch(q, k) for q in qs]
     errs = []
 
@@ -131,12 +132,13 @@ def test_two_lanes_of_the_host_buffer_search_run_side_by_side(capi):
         except Exception as e:  # noqa: BLE001
             errs.append((lane, repr(e)))
 
-    ts = [threading.Thread(target=run, args=(lane,)) for lane in (0, 1)]
+    ts = [threading.Thread(target=run, args=(lane,)) for lane in LANES]
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
-    with pytest.raises(capi.LanternGpuError, match="lane must be 0 or 1"):
-        ix.search_batch_lane(2, qs[0], k)
+    for bad in (4, -1):
+        with pytest.raises(capi.LanternGpuError, match="lane must be in"):
+            ix.search_batch_lane(bad, qs[0], k)
 
 
 def test_inserts_and_searches_on_other_streams_are_ordered(capi, monkeypatch):
