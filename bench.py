@@ -277,8 +277,11 @@ def main():
         pq_truth, _ = ix.exact_search(tq0, a.k)
         ix.pq_compact()
         mem_after = ix.memory_usage()
+        on_the_fly = (a.dim // a.pq_subvectors) % 4 == 0 and os.environ.get("LANTERN_GPU_PQ_ADC", "0") in ("", "0")
         pq_info = {"num_subvectors": a.pq_subvectors, "num_centroids": a.pq_centroids, "row_bytes_decoded_form": mem_before[0], "row_bytes_compact_form": mem_after[0],
-                   "other_index_bytes": mem_after[1], "search": "ADC over the code bytes: per-query table (subvector x centroid) in LDS, lantern_amd/csrc/search_adc_kernel.hip",
+                   "other_index_bytes": mem_after[1],
+                   "search": ("rows decoded on the fly from the L2-resident centroid tables: the expanded index's arithmetic, bit for bit (device_common.hpp PqdRow)" if on_the_fly else
+                              "ADC over the code bytes: per-query table (subvector x centroid) in LDS, lantern_amd/csrc/search_adc_kernel.hip"),
                    "recall_truth": "exact k-NN over the decoded rows"}
 
     # ---- this rank's queries, resident in HBM ----------------------------------------------------
@@ -555,9 +558,11 @@ def roofline(achieved_alg, traffic, dram, traffic_src, launch_s, bytes_per_launc
         r["frac_cold_miss_lower_bound"] = cold / launch_s / 1e9 / HBM_PEAK_GBS
     notes = []
     if adc:
-        r["kernel"] = "k_search_adc"
-        notes.append("a compact pq index: a row is its code bytes (1/32 of the f32 row at 96 subvectors), so the HBM fraction says how far "
-                     "this kernel is from being bandwidth-bound, not how good it is (lantern_amd/csrc/search_adc_kernel.hip)")
+        r["kernel"] = "k_search over rows decoded on the fly (k_search_adc where subvectors are not whole 16-byte chunks, or with LANTERN_GPU_PQ_ADC=1)"
+        notes.append("a compact pq index: HBM holds a row's code bytes only (1/32 of the f32 row at 96 subvectors); every 16-byte chunk of its "
+                     "decoding comes from the per-subvector centroid tables, which stay in L2 (786 KB at 96 x 256 x 8 floats) -- the algorithmic HBM "
+                     "bytes counted here are the code rows and adjacency rows; the walk is bound by L2 gathers of 32-byte centroid pieces, so the HBM "
+                     "fraction says how little of the memory system it needs, not how good it is (lantern_amd/csrc/device_common.hpp PqdRow)")
     if S > 1:
         notes.append(f"{S} launches in flight: rates = all launches' bytes / the timed region; avg_launch_ms is the mean HIP-event "
                      "duration of launches that overlap")

@@ -48,10 +48,17 @@ constexpr int M_ADC = 400;
 constexpr int M_COS_ADC = M_COS + M_ADC;
 constexpr int M_L2SQ_ADC = M_L2SQ + M_ADC;
 constexpr int ADC_LUT_STRIDE = 256;  // table row stride in floats (num_centroids <= 256: external_index.c:283-296)
+// A compact pq index searched by DECODING rows on the fly: a row is its code bytes in HBM, and every 16-byte chunk of its decoding
+// is fetched from the per-subvector centroid tables (786 KB at 96 x 256 x 8 floats: L2-resident) -- PqdRow below.  The arithmetic
+// is the f32 metric's over the decoded row, chunk for chunk: bit-identical to the expanded form of the same index.
+constexpr int M_PQD = 600;
+constexpr int M_COS_PQD = M_COS + M_PQD;
+constexpr int M_L2SQ_PQD = M_L2SQ + M_PQD;
 __host__ __device__ inline bool mcode_is_f16(int m) { return m >= M_F16 && m < M_I8; }
 __host__ __device__ inline bool mcode_is_i8(int m) { return m >= M_I8 && m < M_ADC; }
-__host__ __device__ inline bool mcode_is_adc(int m) { return m >= M_ADC; }
-__host__ __device__ inline int  mcode_base(int m) { return m >= M_ADC ? m - M_ADC : m >= M_I8 ? m - M_I8 : m >= M_F16 ? m - M_F16 : m; }
+__host__ __device__ inline bool mcode_is_adc(int m) { return m >= M_ADC && m < M_PQD; }
+__host__ __device__ inline bool mcode_is_pqd(int m) { return m >= M_PQD; }
+__host__ __device__ inline int  mcode_base(int m) { return m >= M_PQD ? m - M_PQD : m >= M_ADC ? m - M_ADC : m >= M_I8 ? m - M_I8 : m >= M_F16 ? m - M_F16 : m; }
 
 // every kernel's dynamic LDS; the ADC accumulators read their table from its first bytes
 extern __shared__ __attribute__((aligned(16))) unsigned char lgpu_smem[];
@@ -313,7 +320,7 @@ __device__ __forceinline__ void group_dist2(PA a, PB b0, PB b1, int chunks, int 
 // evaluation is then ONE chain (ab), ONE G-lane sum, one multiply and one divide: the bits of
 // 1 - ab / (sqrt(a2) * sqrt(b2)) are those of the one-pass accumulator (usearch metric_cos_gt).  The query's
 // sqrt(a2) is computed once per query the same way.
-template <int METRIC> constexpr bool kCachedNorms = (METRIC == M_COS || METRIC == M_COS_F16 || METRIC == M_COS_ADC);
+template <int METRIC> constexpr bool kCachedNorms = (METRIC == M_COS || METRIC == M_COS_F16 || METRIC == M_COS_ADC || METRIC == M_COS_PQD);
 
 __device__ __forceinline__ float cos_finish(float ab, float a2, float b2)
 {
@@ -430,6 +437,12 @@ template <> struct RowAcc<M_COS_ADC>
     template <int G> __device__ __forceinline__ float finish_n(float ra, float rb) { return cos_finish_rooted(group_sum<G>(s), ra, rb); }
 };
 
+// decode-on-the-fly: the f32 accumulators, fed with decoded chunks
+template <> struct Acc<M_L2SQ_PQD> : Acc<M_L2SQ> {};
+template <> struct Acc<M_COS_PQD> : Acc<M_COS> {};
+template <> struct RowAcc<M_L2SQ_PQD> : RowAcc<M_L2SQ> {};
+template <> struct RowAcc<M_COS_PQD> : RowAcc<M_COS> {};
+
 // group_dist with known (rooted) norms of `a` and `b`; complete in the LAST lane of the group
 template <int METRIC, int G, typename PA, typename PB>
 __device__ __forceinline__ float group_dist_n(PA a, PB b, int chunks, int gl, float a2, float b2)
@@ -498,9 +511,37 @@ struct View
     uint32_t        n;
     uint32_t        entry;
     int32_t         max_level;
+    // decode-on-the-fly metrics (M_*_PQD) only: vec = the CODE rows (pq_row_bytes each), chunks = chunks of a DECODED row
+    const uint4    *pq_centers;   // [S][C][pq_cps] the per-subvector centroid tables, a centroid = pq_cps whole chunks
+    uint32_t        pq_cps;       // chunks per subvector (subvector dimensions / 4)
+    uint32_t        pq_C;         // centroids per subvector
+    uint32_t        pq_inv;       // ceil(2^16 / pq_cps): chunk / pq_cps == (chunk * pq_inv) >> 16 for chunk < 2^11 (host-checked)
+    uint32_t        pq_row_bytes; // bytes of one code row (num_subvectors padded to 16)
 };
 
 __device__ __forceinline__ const uint4 *row_of(const View &v, uint32_t slot) { return v.vec + (size_t)slot * v.chunks; }
+
+// A row of a compact pq index as the walk sees it: indexable by decoded chunk.  Chunk ch lies in subvector ch / cps; its
+// bytes are chunk ch % cps of centroid `code` of that subvector: one byte from the row's codes (HBM: the whole 96-byte row is
+// one or two cache lines), then 16 bytes from the centroid table (L2).  Which subvector and which offset a lane's chunks fall
+// into does not depend on the row: the compiler hoists that arithmetic out of the row loops.
+struct PqdRow
+{
+    const uint8_t *codes;
+    const uint4   *centers;
+    uint32_t       cps, C, inv;
+    __device__ __forceinline__ uint4 operator[](int ch) const
+    {
+        const uint32_t sv = ((uint32_t)ch * inv) >> 16, off = (uint32_t)ch - sv * cps;
+        const uint32_t code = codes[ sv ];
+        return centers[ ((size_t)sv * C + code) * cps + off ];
+    }
+};
+template <int METRIC> __device__ __forceinline__ auto row_of_m(const View &v, uint32_t slot)
+{
+    if constexpr(METRIC >= M_PQD) return PqdRow{ (const uint8_t *)v.vec + (size_t)slot * v.pq_row_bytes, v.pq_centers, v.pq_cps, v.pq_C, v.pq_inv };
+    else return v.vec + (size_t)slot * v.chunks;
+}
 // cached ||row||^2 (cosine metrics); 0 and no memory access for the others
 template <int METRIC> __device__ __forceinline__ float row_norm(const View &v, uint32_t slot)
 {

@@ -87,7 +87,7 @@ void *scratch(Index *ix, int which, size_t bytes)
 
 View Index::view() const
 {
-    View v;
+    View v{};
     v.vec = d_vec;
     v.chunks = chunks;
     v.M = M;
@@ -827,6 +827,16 @@ bool flush_locked(Index *ix)
 // search
 // ---------------------------------------------------------------------------------------------------
 
+// ceil(2^16 / cps) if (chunk * that) >> 16 == chunk / cps for every chunk of a row (checked, not assumed), else 0
+static uint32_t pqd_inverse(uint32_t cps, uint32_t chunks)
+{
+    if(cps == 0 || chunks == 0 || chunks > 4096) return 0;
+    const uint32_t inv = (65536u + cps - 1) / cps;
+    for(uint32_t ch = 0; ch < chunks; ++ch)
+        if(((ch * inv) >> 16) != ch / cps) return 0;
+    return inv;
+}
+
 bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, size_t ef, size_t skip, uint64_t *d_labels,
                        float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D, uint64_t *d_E, hipStream_t stream,
                        int waves, uint32_t *done)
@@ -834,7 +844,13 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     if(nq == 0 || k == 0) return true;
     size_t expansion = ef ? ef : ix->ef;
     if(expansion < k + skip) expansion = k + skip;  // usearch: expansion = max(expansion, wanted)
-    if(ix->pq_compact) {
+    // ---- a compact pq index whose subvectors are whole 16-byte chunks: the f32 walk below over rows DECODED ON THE FLY from the
+    // L2-resident centroid tables (device_common.hpp PqdRow) -- the arithmetic, and so every bit of every answer, of the expanded
+    // form of the same index.  (LANTERN_GPU_PQ_ADC=1, or subvectors of another width: the table walk of search_adc_kernel.hip.)
+    const char *const adc_e = std::getenv("LANTERN_GPU_PQ_ADC");
+    const bool        pq_adc_env = adc_e && std::atoi(adc_e) != 0;
+    const bool pqd = ix->pq_compact && !pq_adc_env && ix->pq_subdim % 4 == 0 && ix->pq_subdim >= 4 && pqd_inverse(ix->pq_subdim / 4, ix->chunks) != 0;
+    if(ix->pq_compact && !pqd) {
         // ---- a compact pq index: ADC over the code rows (search_adc_kernel.hip).  One 8-wave workgroup per query; the per-query
         // table takes num_subvectors16 x 256 floats of LDS (98 KB at 96 subvectors: one workgroup per CU, three at 32).
         const uint32_t code_chunks = ix->pq_S16 / 16;
@@ -968,6 +984,14 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     if(slot < 0) return false;
     SearchArgs a{};
     a.view = ix->view();
+    if(pqd) {
+        a.view.vec = (const uint4 *)ix->d_codes16;
+        a.view.pq_centers = (const uint4 *)ix->d_centers;
+        a.view.pq_cps = ix->pq_subdim / 4;
+        a.view.pq_C = ix->pq_C;
+        a.view.pq_inv = pqd_inverse(ix->pq_subdim / 4, ix->chunks);
+        a.view.pq_row_bytes = ix->pq_S16;
+    }
     a.queries = d_queries;
     a.nq = (uint32_t)nq;
     a.k = (uint32_t)k;
@@ -995,7 +1019,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.spec = spec;
     a.spec_prefetch = spec_prefetch;
     a.spec_cache = spec_cache;
-    HIPCHK(ix, launch_search(ix->mcode, a, waves, grid, stream));
+    HIPCHK(ix, launch_search(pqd ? ix->metric + M_PQD : ix->mcode, a, waves, grid, stream));
     if(done) ix->slot_pending[ slot ] = false;  // the caller waits for the kernel itself: nothing to order later launches against
     else if(!release_search_slot(ix, slot, stream)) return false;
     ix->c_search_queries += nq;

@@ -29,6 +29,8 @@ hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, h
             case M_HAMMING: LGPU_LAUNCH_SEARCH_KPL(M_HAMMING, 64, false, 4); break;
             case M_L2SQ_F16: LGPU_LAUNCH_SEARCH_KPL(M_L2SQ_F16, 64, false, 4); break;
             case M_COS_F16: LGPU_LAUNCH_SEARCH_KPL(M_COS_F16, 64, false, 4); break;
+            case M_L2SQ_PQD: LGPU_LAUNCH_SEARCH_KPL(M_L2SQ_PQD, 64, false, 4); break;
+            case M_COS_PQD: LGPU_LAUNCH_SEARCH_KPL(M_COS_PQD, 64, false, 4); break;
             default: launched = false;  // i8 storage (rows of >= 2033 dims) has no four-row instantiation: the two-row shape below
         }
         if(launched) return hipGetLastError();
@@ -41,6 +43,15 @@ hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, h
         return hipGetLastError();
     }
 #define CALL(MM, GG) LGPU_LAUNCH_SEARCH_KPL(MM, GG, false, 2)
+    if(mcode_is_pqd(metric)) {  // a compact pq index, rows decoded on the fly (device_common.hpp PqdRow); G by the DECODED row
+#define PQD_G(MM)                                                                    \
+    switch(G_) { case 64: CALL(MM, 64); break; case 32: CALL(MM, 32); break; case 16: CALL(MM, 16); break; default: CALL(MM, 8); }
+        if(metric == M_L2SQ_PQD) PQD_G(M_L2SQ_PQD)
+        else if(metric == M_COS_PQD) PQD_G(M_COS_PQD)
+        else return hipErrorInvalidValue;
+#undef PQD_G
+        return hipGetLastError();
+    }
     LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL
     return hipGetLastError();

@@ -48,6 +48,15 @@ __device__ __forceinline__ KernargBytes kernarg_opaque()
         v.entry = LGPU_VIEW_ARG(base, STRUCT, entry); \
         v.max_level = LGPU_VIEW_ARG(base, STRUCT, max_level); \
     }
+// ... and the fields only the decode-on-the-fly metrics read
+#define LGPU_LOAD_VIEW_PQD(v, base, STRUCT)                   \
+    {                                                         \
+        v.pq_centers = LGPU_VIEW_ARG(base, STRUCT, pq_centers); \
+        v.pq_cps = LGPU_VIEW_ARG(base, STRUCT, pq_cps);       \
+        v.pq_C = LGPU_VIEW_ARG(base, STRUCT, pq_C);           \
+        v.pq_inv = LGPU_VIEW_ARG(base, STRUCT, pq_inv);       \
+        v.pq_row_bytes = LGPU_VIEW_ARG(base, STRUCT, pq_row_bytes); \
+    }
 
 // SPEC: the latency-bound walk of walk_spec.hpp -- 1: every wave evaluates rows and waves 0..2 carry the roles on top (the
 // small-batch shape, four waves); 2: three dedicated role waves + row waves (the lone-query shape, 3 + 8 waves); 3: the same
@@ -74,6 +83,7 @@ k_search(SearchArgs)
             const KernargBytes ka = kernarg_opaque();
             View               v;
             LGPU_LOAD_VIEW(v, ka, SearchArgs)
+            if constexpr(METRIC >= M_PQD) LGPU_LOAD_VIEW_PQD(v, ka, SearchArgs)
             const uint32_t chunks = v.chunks, bm_words = LGPU_SEARCH_ARG(ka, bm_words);
             uint32_t      *bitmap = LGPU_SEARCH_ARG(ka, bitmaps) + (size_t)blockIdx.x * bm_words;
             const uint4   *queries = LGPU_SEARCH_ARG(ka, queries);

@@ -47,6 +47,17 @@ hipError_t launch_search_spec(int metric, const SearchArgs &a, int waves, int gr
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
+    if(mcode_is_pqd(metric)) {  // a compact pq index, rows decoded on the fly
+        const int G_ = group_lanes_for(a.view.chunks);
+#define PQD_G(MM)                                                                                                                   \
+    switch(G_) { case 64: LGPU_LAUNCH_SPEC(MM, 64); break; case 32: LGPU_LAUNCH_SPEC(MM, 32); break; case 16: LGPU_LAUNCH_SPEC(MM, 16); break; \
+                 default: LGPU_LAUNCH_SPEC(MM, 8); }
+        if(metric == M_L2SQ_PQD) PQD_G(M_L2SQ_PQD)
+        else if(metric == M_COS_PQD) PQD_G(M_COS_PQD)
+        else return hipErrorInvalidValue;
+#undef PQD_G
+        return hipGetLastError();
+    }
     LGPU_DISPATCH(metric, a.view.chunks, LGPU_LAUNCH_SPEC);
     return hipGetLastError();
 }

@@ -62,7 +62,7 @@ template <bool PROF> __device__ __forceinline__ void mark_touched(const WalkLds 
 // table sits at the start of LDS: device_common.hpp AdcQuery)
 template <int METRIC> __device__ __forceinline__ auto walk_query(const WalkLds &s)
 {
-    if constexpr(METRIC >= M_ADC) return AdcQuery{};
+    if constexpr(METRIC >= M_ADC && METRIC < M_PQD) return AdcQuery{};
     else return (const uint4 *)s.q;
 }
 
@@ -248,7 +248,7 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
     float *newd = (float *)s.newkeys;  // reuse: one f32 per neighbour
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
-        float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) { s.scal[ S_CUR ] = (int)start; s.scal[ S_CURD ] = __float_as_int(d); mark_touched<PROF>(s, start); }
     }
     D += 1;
@@ -274,7 +274,7 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
             const int nn = s.scal[ S_NNEW ];
             for(int i = g; i < nn; i += NG) {
                 const uint32_t id = s.newids[ i ];
-                float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, id), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id));
+                float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, id), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id));
                 if(gl == G - 1) { newd[ i ] = d; mark_touched<PROF>(s, id); }
             }
             D += (uint32_t)nn;
@@ -326,14 +326,14 @@ __device__ __forceinline__ void hop_distances(const View &v, WalkLds &s, int nne
     const int tid = threadIdx.x, T = blockDim.x, g = tid / G, gl = tid % G, NG = T / G;
     if constexpr(ROWS > 2) {
         for(int i = g; i < nnew; i += ROWS * NG) {
-            const uint4 *rows[ ROWS ];
+            decltype(row_of_m<METRIC>(v, 0u)) rows[ ROWS ];
             uint32_t     ids[ ROWS ];
             float        n2[ ROWS ], d[ ROWS ];
 #pragma unroll
             for(int r = 0; r < ROWS; ++r) {
                 const int j = i + r * NG;
                 ids[ r ] = s.newids[ j < nnew ? j : i ];
-                rows[ r ] = row_of(v, ids[ r ]);
+                rows[ r ] = row_of_m<METRIC>(v, ids[ r ]);
                 n2[ r ] = row_norm<METRIC>(v, ids[ r ]);
             }
             group_distR_n<METRIC, G, ROWS>(walk_query<METRIC>(s), rows, (int)v.chunks, gl, qn2, n2, d);
@@ -357,7 +357,7 @@ __device__ __forceinline__ void hop_distances(const View &v, WalkLds &s, int nne
         const uint32_t id0 = s.newids[ i ];
         const uint32_t id1 = j < nnew ? s.newids[ j ] : id0;
         float          d0, d1;
-        group_dist2_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, id0), row_of(v, id1), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id0),
+        group_dist2_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, id0), row_of_m<METRIC>(v, id1), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id0),
                                  row_norm<METRIC>(v, id1), d0, d1);
         if(gl == G - 1) {
             uint64_t k0 = make_key(d0, id0);
@@ -401,7 +401,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
     }
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
-        float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) { s.keys[ 0 ] = make_key(d, start); mark_touched<PROF>(s, start); }
     }
     D += 1;
@@ -576,7 +576,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
     }
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
-        float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) { s.newkeys[ 0 ] = make_key(d, start); mark_touched<PROF>(s, start); }
     }
     D += 1;
@@ -820,7 +820,7 @@ __device__ int refine(const View &v, RefineLds &r, int *scal, int n, int needed,
         const float    cn2 = row_norm<METRIC>(v, cid);
         for(int i = g; i < submitted; i += NG) {
             const uint32_t kid = r.sid[ i ];
-            float inter = group_dist_n<METRIC, G>(row_of(v, cid), row_of(v, kid), (int)v.chunks, gl, cn2, row_norm<METRIC>(v, kid));
+            float inter = group_dist_n<METRIC, G>(row_of_m<METRIC>(v, cid), row_of_m<METRIC>(v, kid), (int)v.chunks, gl, cn2, row_norm<METRIC>(v, kid));
             if(gl == G - 1 && inter < cdist) scal[ S_BAD ] = 1;
         }
         Dr += (uint32_t)submitted;

@@ -135,7 +135,7 @@ __device__ __forceinline__ void spec_issue(const View &v, const SpecLds &c, Spec
             const int ch = gl + u * G;
             if(ch < (int)v.chunks) {
 #pragma unroll
-                for(int r = 0; r < ROWS; ++r) p.y[ r ][ u ] = row_of(v, p.id[ r ])[ ch ];
+                for(int r = 0; r < ROWS; ++r) p.y[ r ][ u ] = row_of_m<METRIC>(v, p.id[ r ])[ ch ];
             }
         }
 #pragma unroll
@@ -167,7 +167,7 @@ __device__ __forceinline__ void spec_consume(const View &v, const WalkLds &s, co
         const uint4 x = walk_query<METRIC>(s)[ ch ];
         uint4       yy[ ROWS ];
 #pragma unroll
-        for(int r = 0; r < ROWS; ++r) yy[ r ] = row_of(v, p.id[ r ])[ ch ];
+        for(int r = 0; r < ROWS; ++r) yy[ r ] = row_of_m<METRIC>(v, p.id[ r ])[ ch ];
 #pragma unroll
         for(int r = 0; r < ROWS; ++r) acc[ r ].add(x, yy[ r ]);
     }
@@ -200,7 +200,7 @@ __device__ uint32_t greedy_descent_spec(const View &v, WalkLds &s, uint32_t star
     float *const  newd = (float *)s.newkeys;  // [2][M] by step parity (cap_max >= 2 M keys of 8 bytes: room for 4 M floats)
     const float   qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(wv == 0 && g == 0) {
-        const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) s.scal[ S_CURD ] = __float_as_int(d);
     }
     D += 1;
@@ -218,7 +218,7 @@ __device__ uint32_t greedy_descent_spec(const View &v, WalkLds &s, uint32_t star
                 const int      i = base + group;
                 const uint32_t id = (uint32_t)__builtin_amdgcn_ds_bpermute((i < nn ? i : 0) << 2, (int)nb);
                 if(i < nn) {
-                    const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, id), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id));
+                    const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, id), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, id));
                     if(gl == G - 1) out[ i ] = d;
                 }
             }
@@ -292,7 +292,7 @@ __device__ int search_level_spec_impl(const View &v, WalkLds &s, const SpecLds &
     const ptrdiff_t kstride = s.sorted - s.newkeys;
     // "hop -1" (parity 1) evaluated one row: the start node
     if(wv == 0 && g == 0) {
-        const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) keys0[ kstride ] = make_key(d, start);
         constexpr int LW = spec_list_words<G>();
         if(c.stage && gl * LW < (int)M0) {

@@ -121,7 +121,7 @@ __device__ int search_level_twin_impl(const View &v, WalkLds &s, const SpecLds &
     uint64_t *const k2b[ 2 ] = { c.keys2, c.keys2 + M0 };      // ... of its speculative node
     // "round -1" (parity 1) evaluated one row: the start node
     if(wv == 0 && g == 0) {
-        const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
+        const float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
         if(gl == G - 1) k1b[ 1 ][ 0 ] = make_key(d, start);
         constexpr int LW = spec_list_words<G>();
         if(c.stage && gl * LW < (int)M0) {

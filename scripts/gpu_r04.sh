@@ -115,4 +115,17 @@ import json; d=json.load(open('$OUT/pq96_w$w.json')); print('pq96 waves=$w', d['
   done
 }
 
+# compact pq indexes: rows decoded on the fly (the default) against the table walk (LANTERN_GPU_PQ_ADC=1)
+pqd() {
+  timeout 600 python -m pytest tests/test_gpu_quantized_indexes.py -q -x > $OUT/pqd_tests.log 2>&1; tail -5 $OUT/pqd_tests.log
+  for sv in 96 32; do for adc in 0 1; do
+    LANTERN_GPU_PQ_ADC=$adc timeout 300 python bench.py --no-cpu --no-pmc --data clustered --pq-subvectors $sv --steps 5 > $OUT/pq${sv}_adc$adc.json 2> $OUT/pq${sv}_adc$adc.err
+    python -c "
+import json; d=json.load(open('$OUT/pq${sv}_adc$adc.json')); print('pq$sv adc=$adc', round(d['value']), d['recall_at_10'], round(d['ms_per_step'],3), d['roofline']['kernel'])" || tail -3 $OUT/pq${sv}_adc$adc.err
+  done; done
+  LANTERN_GPU_PQ_ADC=0 timeout 300 python bench.py --no-cpu --no-pmc --pq-subvectors 96 --steps 5 > $OUT/pq96_gaussian_pqd.json 2> $OUT/pq96_gaussian_pqd.err
+  python -c "
+import json; d=json.load(open('$OUT/pq96_gaussian_pqd.json')); print('pq96 gaussian pqd', round(d['value']), d['recall_at_10'])"
+}
+
 "$@"

@@ -163,8 +163,57 @@ def test_pq_index_is_the_index_of_the_decoded_vectors(capi, oracle, metric, n, d
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# The COMPACT form of a pq index: the decodings leave HBM, searches run ADC over the code bytes (search_adc_kernel.hip).  The
-# summation order of ADC is the device's own definition (the fork's PQ metric is not in the reference tree: PARITY UNPINNED);
+# The COMPACT form of a pq index: the decodings leave HBM.  Subvectors of whole 16-byte chunks (dimensions / num_subvectors a
+# multiple of 4): searches DECODE rows on the fly from the L2-resident centroid tables (device_common.hpp PqdRow) -- the expanded
+# form's arithmetic, so every answer, distance bit and counter equals the expanded form's and the oracle's over the decoded rows.
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric,n,d,S,C,M,ef", [("l2sq", 3000, 128, 32, 256, 8, 40), ("cos", 2000, 768, 96, 64, 16, 64), ("l2sq", 1500, 96, 4, 200, 8, 100),
+                                                  ("cos", 1800, 1536, 96, 256, 16, 48), ("l2sq", 1200, 320, 20, 16, 5, 33)])
+def test_compact_pq_index_decoding_rows_on_the_fly_is_the_expanded_index_bit_for_bit(capi, oracle, metric, n, d, S, C, M, ef, monkeypatch):
+    from lantern_amd import hip
+
+    rng = np.random.default_rng(n + d + S)
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    nq = 300
+    queries = rng.standard_normal((nq, d), dtype=np.float32)
+    cb = make_codebook(rng, base, S, C)
+    ix = capi.GpuIndex(metric, d, M=M, ef_construction=48, ef=ef, seed=5, pq_codebook=cb, num_subvectors=S)
+    ix.set_add_batch(256, 16)
+    ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    g = ix.export_graph(with_vectors=True)
+
+    def device(index, count):
+        dq = hip.Buffer.from_numpy(hip.padded_rows(queries[:count], False))
+        lab, dist, D, E = hip.Buffer(count * 10 * 8), hip.Buffer(count * 10 * 4), hip.Buffer(count * 8), hip.Buffer(count * 8)
+        index.search_batch_device(dq.ptr, count, 10, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr)
+        hip.synchronize()
+        return lab.download((count, 10), np.uint64), dist.download((count, 10), np.float32), D.download(count, np.uint64), E.download(count, np.uint64)
+
+    want = device(ix, nq)  # the expanded form: the f32 walk over the decodings
+    ora = oracle.OracleIndex.from_graph(metric, g["vectors"], g, M, 48, ef, 5, oracle.SUM_WAVE64)
+    o_lab, o_dist, _, o_D, o_E = ora.search_batch(queries, 10, ef, 4)
+    assert np.array_equal(want[0], o_lab) and np.array_equal(want[1].view(np.uint32), o_dist.view(np.uint32))
+    ix.pq_compact()
+    assert ix.memory_usage()[0] == n * ((S + 15) // 16 * 16)
+    for spec in (None, "0", "2"):  # the automatic shape, the bandwidth-bound walk, the latency-bound one
+        if spec is None:
+            monkeypatch.delenv("LANTERN_GPU_SPEC", raising=False)
+        else:
+            monkeypatch.setenv("LANTERN_GPU_SPEC", spec)
+        for count in (nq, 1, 37):
+            got = device(ix, count)
+            assert np.array_equal(got[0], want[0][:count]) and np.array_equal(got[1].view(np.uint32), want[1][:count].view(np.uint32)), (spec, count)
+            assert np.array_equal(got[2], o_D[:count]) and np.array_equal(got[3], o_E[:count]), (spec, count)
+    monkeypatch.delenv("LANTERN_GPU_SPEC", raising=False)
+    l1, d1 = ix.search(queries[0], 10)  # usearch_search_ef, and the host-buffer batch
+    assert np.array_equal(l1, want[0][0]) and np.array_equal(d1, want[1][0])
+    hl, hd, _ = ix.search_batch(queries[:33], 10)
+    assert np.array_equal(hl, want[0][:33]) and np.array_equal(hd, want[1][:33])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Subvectors of any other width (or LANTERN_GPU_PQ_ADC=1): ADC over the code bytes (search_adc_kernel.hip).  The summation order
+# of ADC is the device's own definition (the fork's PQ metric is not in the reference tree: PARITY UNPINNED);
 # the oracle restates it (lo_set_pq_view) and must agree bit for bit; against the decoded-row path distances agree to 1e-5.
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("metric,n,d,S,C,M,ef", [("l2sq", 3000, 128, 32, 256, 8, 40), ("cos", 2000, 768, 96, 64, 16, 64), ("l2sq", 1500, 60, 6, 10, 4, 100),
@@ -172,6 +221,7 @@ def test_pq_index_is_the_index_of_the_decoded_vectors(capi, oracle, metric, n, d
 def test_compact_pq_index_searches_by_adc_over_the_code_bytes(capi, oracle, metric, n, d, S, C, M, ef, monkeypatch):
     from lantern_amd import hip
 
+    monkeypatch.setenv("LANTERN_GPU_PQ_ADC", "1")  # (two of the four shapes would decode on the fly otherwise)
     rng = np.random.default_rng(n + d + S)
     base = rng.standard_normal((n, d), dtype=np.float32)
     nq = 200
