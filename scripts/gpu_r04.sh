@@ -128,4 +128,42 @@ import json; d=json.load(open('$OUT/pq${sv}_adc$adc.json')); print('pq$sv adc=$a
 import json; d=json.load(open('$OUT/pq96_gaussian_pqd.json')); print('pq96 gaussian pqd', round(d['value']), d['recall_at_10'])"
 }
 
+# k_dense_f32: one script, trace-only and counter runs back to back, the shader clock sampled alongside (rocm-smi every 100 ms)
+dense() {
+  D=$OUT/dense; rm -rf $D; mkdir -p $D
+  sample() { while true; do rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk" | tr -s ' \t' ' ' | tr '\n' ';'; echo; sleep 0.1; done; }
+  for mode in plain trace pmc trace2; do
+    sample > $D/clocks_$mode.txt & SP=$!
+    case $mode in
+      plain) timeout 200 python scripts/bench_dense.py > $D/bench_$mode.json 2> $D/$mode.log ;;
+      trace|trace2) timeout 200 rocprofv3 --kernel-trace --stats -d $D/$mode -o t -- python scripts/bench_dense.py > $D/bench_$mode.json 2> $D/$mode.log ;;
+      pmc) timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 -d $D/$mode -o t -- python scripts/bench_dense.py > $D/bench_$mode.json 2> $D/$mode.log ;;
+    esac
+    kill $SP 2>/dev/null; wait $SP 2>/dev/null
+  done
+  python - <<'P'
+import glob, sqlite3, json, re, collections
+D='gpurun_out/r04/dense'
+for mode in ('plain','trace','pmc','trace2'):
+    line=[l for l in open(f'{D}/bench_{mode}.json') if l.startswith('{')]
+    wall=json.loads(line[-1])['seconds_per_call_wall']*1e3 if line else None
+    clk=collections.Counter(re.findall(r'sclk clock level: \S+ \((\d+)Mhz\)', open(f'{D}/clocks_{mode}.txt').read()))
+    print(mode, 'exact k-NN wall ms', wall, 'sclk samples (MHz: count)', dict(clk.most_common(6)))
+    for f in glob.glob(f'{D}/{mode}/**/*.db', recursive=True):
+        cur=sqlite3.connect(f).cursor()
+        try:
+            for r in cur.execute("select name,total_calls,average from top_kernels where name like '%k_dense_f32%'"): print('   ', r[0][:40], r[1], round(r[2],1),'us')
+        except Exception as e: pass
+        try:
+            rows=list(cur.execute("select (end-start) from kernels where name like '%k_dense_f32<1, true>%' order by start"))
+            if rows:
+                d=[r[0]/1e3 for r in rows]; print('    per-launch us: first 8', [round(x) for x in d[:8]], 'last 4', [round(x) for x in d[-4:]], 'median', round(sorted(d)[len(d)//2]))
+        except Exception as e: print('   ', e)
+        try:
+            for r in cur.execute("select counter_name,count(*),avg(value) from counters_collection where kernel_name like '%k_dense_f32<1, true>%' group by counter_name"): print('    ', r)
+        except Exception: pass
+P
+  rm -rf $D/trace $D/pmc $D/trace2
+}
+
 "$@"
