@@ -166,4 +166,10 @@ P
   rm -rf $D/trace $D/pmc $D/trace2
 }
 
+# the whole -m gpu suite + smoke, as the driver runs them at round end
+suite() {
+  ( time timeout 1500 python -m pytest tests/ -q -m gpu --durations=12 ) > $OUT/suite.log 2>&1; tail -25 $OUT/suite.log
+  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+}
+
 "$@"
