@@ -62,6 +62,47 @@ __global__ void __launch_bounds__(256) k_gather_heads(const LinkReq *links, uint
     groups[ g ] = make_uint2(j, e);
 }
 
+// A batch of a handful of insertions (ldb_aminsert's one row: <= 32 requests) does not need three kernels and a library sort:
+// ONE workgroup sorts (key << 11 | position) -- unique, so any sort is the stable sort -- bitonically in LDS and writes the
+// sorted requests and the groups.  Same outputs as the pipeline above (the order of the GROUP LIST is immaterial there too).
+constexpr uint32_t SMALL_N = 2048;
+__global__ void __launch_bounds__(1024) k_group_small(const LinkReq *links, uint32_t n, LinkReq *sorted, uint2 *groups, uint32_t *ngroups)
+{
+    __shared__ uint64_t key[ SMALL_N ];
+    const uint32_t tid = threadIdx.x;
+    if(tid == 0) *ngroups = 0;
+    for(uint32_t i = tid; i < SMALL_N; i += 1024) {
+        uint64_t k = ~0ull;
+        if(i < n) {
+            const LinkReq r = links[ i ];
+            const uint64_t k40 = r.close != EMPTY ? (((uint64_t)r.close << 8) | (uint64_t)(r.level & 0xFFu)) : KEY_NONE;
+            k = (k40 << 11) | (uint64_t)i;
+        }
+        key[ i ] = k;
+    }
+    __syncthreads();
+    for(uint32_t size = 2; size <= SMALL_N; size <<= 1) {
+        for(uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for(uint32_t t = tid; t < SMALL_N / 2; t += 1024) {
+                const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool     up = (lo & size) == 0;
+                const uint64_t a = key[ lo ], b = key[ hi ];
+                if((a > b) == up) { key[ lo ] = b; key[ hi ] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for(uint32_t j = tid; j < n; j += 1024) {
+        const uint64_t k = key[ j ], k40 = k >> 11;
+        if(k40 == KEY_NONE) continue;
+        sorted[ j ] = links[ (uint32_t)(k & 2047u) ];
+        if(j != 0 && (key[ j - 1 ] >> 11) == k40) continue;
+        uint32_t e = j + 1;
+        while(e < n && (key[ e ] >> 11) == k40) ++e;
+        groups[ atomicAdd(ngroups, 1u) ] = make_uint2(j, e);
+    }
+}
+
 // one block: exclusive scan of (level + 1) over the batch
 __global__ void __launch_bounds__(1024) k_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, uint32_t *link_off, uint32_t *item_node)
 {
@@ -205,6 +246,10 @@ hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupSc
                                  int world, int rank, uint32_t *owner_counts, hipStream_t stream)
 {
     if(n == 0) return hipMemsetAsync(ngroups, 0, 4, stream);
+    if(world <= 1 && n <= SMALL_N) {
+        hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, stream, links, n, sorted, groups, ngroups);
+        return hipGetLastError();
+    }
     hipError_t e = hipSuccess;
     if(world > 1 && (e = hipMemsetAsync(owner_counts, 0, (size_t)world * 4, stream)) != hipSuccess) return e;
     const uint32_t blocks = (n + 255) / 256;

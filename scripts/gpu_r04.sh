@@ -172,4 +172,31 @@ suite() {
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 }
 
+# round-end records: build-parity tests (the small-batch grouping kernel is on their path), the kernel trace of the bench command, the
+# secondary lines, one insertion / one query per call
+final() {
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scans_and_inserts.py -q -x > $OUT/final_tests.log 2>&1; tail -3 $OUT/final_tests.log
+  mkdir -p $OUT/ktrace
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ktrace/trace -o trace -- python bench.py --no-cpu --no-pmc --steps 5 --warmup 2 > $OUT/ktrace/bench_trace.json 2> $OUT/ktrace/trace.log
+  python scripts/summarize_prof.py $OUT/ktrace $OUT/r04_bench_1Mx768 > $OUT/ktrace_summary.txt 2>&1; head -12 $OUT/ktrace_summary.txt
+  find $OUT/ktrace -name "*.db" -delete
+  timeout 200 python scripts/bench_single_insert.py > $OUT/r04_single_insert_100kx128.json 2> $OUT/single_insert.err; python -c "
+import json; d=json.load(open('$OUT/r04_single_insert_100kx128.json')); print({k:v for k,v in d.items() if 'us' in k or 'identical' in k})"
+  timeout 200 python scripts/bench_single_query.py > $OUT/r04_single_query_100kx128.json 2> $OUT/single_query.err; python -c "
+import json; d=json.load(open('$OUT/r04_single_query_100kx128.json')); print(d['us_per_query_wall'], d['kernel_only'], d.get('cpu_port_us_per_query_1_thread'))"
+  python bench.py --no-cpu --metric cos --queries 1024 --steps 40 > $OUT/r04_bench_line_cos_q1024.json 2>/dev/null
+  python bench.py --no-cpu --no-pmc --streams 2 > $OUT/r04_bench_line_2streams.json 2>/dev/null
+  python bench.py --no-cpu --quant f16 > $OUT/r04_bench_line_f16.json 2>/dev/null
+  python bench.py --no-cpu --quant i8 --data-scale 0.3 > $OUT/r04_bench_line_i8.json 2>/dev/null
+  python bench.py --no-cpu --quant b1 > $OUT/r04_bench_line_b1.json 2>/dev/null
+  python - <<'P'
+import json
+for f in ('cos_q1024','2streams','f16','i8','b1'):
+    try:
+        d=json.load(open(f'gpurun_out/r04/r04_bench_line_{f}.json')); r=d['roofline']
+        print(f, round(d['value']), round(d['ms_per_step'],3), 'frac', round(r['frac'],3), 'alg', round(r['frac_algorithmic'],3), 'in-run', r['traffic_measured_in_this_run'], 'build', round(d['build_vectors_per_s']))
+    except Exception as e: print(f, e)
+P
+}
+
 "$@"
