@@ -762,10 +762,11 @@ def test_lone_query_and_small_batches_take_the_latency_bound_walk_by_default(cap
     assert len(set(got)) == 30
 
 
-def test_latency_bound_walk_with_a_spilling_visited_set(capi, oracle, monkeypatch):
+@pytest.mark.parametrize("d", [64, 160])  # 8 lanes per row; 16 lanes per row (where LANTERN_GPU_SPEC=3 has a walk of its own)
+def test_latency_bound_walk_with_a_spilling_visited_set(capi, oracle, monkeypatch, d):
     rng = np.random.default_rng(11)
-    base, queries = rng.standard_normal((4000, 64), dtype=np.float32), rng.standard_normal((64, 64), dtype=np.float32)
-    ora = oracle.OracleIndex("l2sq", 64, M=16, ef_construction=64, ef=128, seed=9, sum_mode=oracle.SUM_WAVE64)
+    base, queries = rng.standard_normal((4000, d), dtype=np.float32), rng.standard_normal((64, d), dtype=np.float32)
+    ora = oracle.OracleIndex("l2sq", d, M=16, ef_construction=64, ef=128, seed=9, sum_mode=oracle.SUM_WAVE64)
     ora.add_many(np.arange(4000, dtype=np.uint64) + 1, base)
     o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, 10)
     assert o_D.max() > 300
@@ -773,7 +774,7 @@ def test_latency_bound_walk_with_a_spilling_visited_set(capi, oracle, monkeypatc
         monkeypatch.setenv("LANTERN_GPU_VIS_SLOTS", vis_slots)
         for spec in ("1", "2", "3"):
             monkeypatch.setenv("LANTERN_GPU_SPEC", spec)
-            gpu = capi.GpuIndex("l2sq", 64, M=16, ef_construction=64, ef=128, seed=9)
+            gpu = capi.GpuIndex("l2sq", d, M=16, ef_construction=64, ef=128, seed=9)
             gpu.import_graph(base, ora.export_graph())
             lab, dist, _ = gpu.search_batch(queries, 10)
             assert np.array_equal(lab, o_lab) and np.array_equal(dist, o_dist), (vis_slots, spec)
