@@ -238,7 +238,7 @@ LANTERN_GPU_EXPORT void lantern_gpu_add_with_level(usearch_index_t, usearch_labe
 LANTERN_GPU_EXPORT void lantern_gpu_search_batch(usearch_index_t, const void *queries, size_t nq,
                                                  usearch_scalar_kind_t, size_t k, size_t ef, usearch_label_t *labels,
                                                  float *distances, uint32_t *counts, usearch_error_t *);
-/* The same for a caller that keeps up to FOUR batches in flight (`lane` 0 .. 3, one caller thread per lane): each lane has its
+/* The same for a caller that keeps up to EIGHT batches in flight (`lane` 0 .. 7, one caller thread per lane): each lane has its
  * own stream and staging buffers inside the index, and the wait for the answers does not hold the index's lock, so the lanes'
  * launches overlap on the device (the scan-side service below runs one dispatcher per lane over this). */
 LANTERN_GPU_EXPORT void lantern_gpu_search_batch_lane(usearch_index_t, int lane, const void *queries, size_t nq,

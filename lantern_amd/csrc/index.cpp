@@ -179,6 +179,16 @@ bool pq_decode_rows(Index *ix, size_t first, size_t count)
 // A pq index needs its decodings only to ADD (the walk of a new node, the selection heuristic and the re-prunes evaluate
 // stored row against stored row).  A read-mostly index -- the scan-side mirror of a built index -- drops them: num_subvectors
 // bytes per row stay resident (10M x 768 at 96 subvectors: 0.96 GB instead of 30.7 GB) and searches evaluate rows by ADC.
+// ceil(2^16 / cps) if (chunk * that) >> 16 == chunk / cps for every chunk of a row (checked, not assumed), else 0
+static uint32_t pqd_inverse(uint32_t cps, uint32_t chunks)
+{
+    if(cps == 0 || chunks == 0 || chunks > 4096) return 0;
+    const uint32_t inv = (65536u + cps - 1) / cps;
+    for(uint32_t ch = 0; ch < chunks; ++ch)
+        if(((ch * inv) >> 16) != ch / cps) return 0;
+    return inv;
+}
+
 bool pq_compact_locked(Index *ix)
 {
     if(!ix->pq) { set_err(ix, "lantern_gpu: not a pq index"); return false; }
@@ -195,6 +205,8 @@ bool pq_compact_locked(Index *ix)
     HIPCHK(ix, hipMemset(ix->d_codes16, 0, rows * S16));
     if(ix->n) HIPCHK(ix, hipMemcpy2D(ix->d_codes16, S16, ix->d_codes, ix->pq_S, ix->pq_S, ix->n, hipMemcpyDeviceToDevice));
     ix->pq_S16 = S16;
+    // rows decoded on the fly (device_common.hpp PqdRow) need subvectors of whole 16-byte chunks
+    ix->pqd_inv = ix->pq_subdim % 4 == 0 && ix->pq_subdim >= 4 ? pqd_inverse(ix->pq_subdim / 4, ix->chunks) : 0;
     if(ix->d_vec) { HIPCHK(ix, hipFree(ix->d_vec)); ix->d_vec = nullptr; }
     ix->pq_compact = true;
     return true;
@@ -827,16 +839,6 @@ bool flush_locked(Index *ix)
 // search
 // ---------------------------------------------------------------------------------------------------
 
-// ceil(2^16 / cps) if (chunk * that) >> 16 == chunk / cps for every chunk of a row (checked, not assumed), else 0
-static uint32_t pqd_inverse(uint32_t cps, uint32_t chunks)
-{
-    if(cps == 0 || chunks == 0 || chunks > 4096) return 0;
-    const uint32_t inv = (65536u + cps - 1) / cps;
-    for(uint32_t ch = 0; ch < chunks; ++ch)
-        if(((ch * inv) >> 16) != ch / cps) return 0;
-    return inv;
-}
-
 bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, size_t ef, size_t skip, uint64_t *d_labels,
                        float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D, uint64_t *d_E, hipStream_t stream,
                        int waves, uint32_t *done)
@@ -849,7 +851,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     // form of the same index.  (LANTERN_GPU_PQ_ADC=1, or subvectors of another width: the table walk of search_adc_kernel.hip.)
     const char *const adc_e = std::getenv("LANTERN_GPU_PQ_ADC");
     const bool        pq_adc_env = adc_e && std::atoi(adc_e) != 0;
-    const bool pqd = ix->pq_compact && !pq_adc_env && ix->pq_subdim % 4 == 0 && ix->pq_subdim >= 4 && pqd_inverse(ix->pq_subdim / 4, ix->chunks) != 0;
+    const bool pqd = ix->pq_compact && !pq_adc_env && ix->pqd_inv != 0;
     if(ix->pq_compact && !pqd) {
         // ---- a compact pq index: ADC over the code rows (search_adc_kernel.hip).  One 8-wave workgroup per query; the per-query
         // table takes num_subvectors16 x 256 floats of LDS (98 KB at 96 subvectors: one workgroup per CU, three at 32).
@@ -989,7 +991,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         a.view.pq_centers = (const uint4 *)ix->d_centers;
         a.view.pq_cps = ix->pq_subdim / 4;
         a.view.pq_C = ix->pq_C;
-        a.view.pq_inv = pqd_inverse(ix->pq_subdim / 4, ix->chunks);
+        a.view.pq_inv = ix->pqd_inv;
         a.view.pq_row_bytes = ix->pq_S16;
     }
     a.queries = d_queries;
@@ -1708,7 +1710,7 @@ try {
 }
 LANTERN_ABI_CATCH_VOID(e)
 
-// The same as lantern_gpu_search_batch for a caller that keeps SEVERAL batches in flight (the scan-side service: up to four
+// The same as lantern_gpu_search_batch for a caller that keeps SEVERAL batches in flight (the scan-side service: up to eight
 // dispatchers, each executing a batch while another collects the next): each lane has its own stream and staging buffers, the index mutex is
 // held only while the lane's copies and its launch are queued, and the wait for the answers happens outside it -- so the two
 // lanes' launches overlap on the device (each in its own visited-bitmap slab: acquire_search_slot).
@@ -1718,7 +1720,7 @@ try {
     CLEAR(e);
     Index *ix = H(h, e);
     if(!ix) return;
-    if(lane < 0 || lane >= Index::kLanes) { FAIL(e, "lantern_gpu: lane must be in [0, 4)"); return; }
+    if(lane < 0 || lane >= Index::kLanes) { FAIL(e, "lantern_gpu: lane must be in [0, 8)"); return; }
     if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the queries does not match the index"); return; }
     if(nq == 0 || k == 0) return;
     if(!queries || !labels || !distances) { FAIL(e, "lantern_gpu: null buffer"); return; }

@@ -58,6 +58,7 @@ struct Index
     bool     pq_compact = false;
     uint8_t *d_codes16 = nullptr;        // [n][pq_S16]: the code rows zero padded to whole 16-byte chunks
     uint32_t pq_S16 = 0;
+    uint32_t pqd_inv = 0;                // compact form: the checked multiply-shift inverse of chunks-per-subvector (0: decode-on-the-fly not possible -> the ADC table walk)
 
     // ---- graph state ------------------------------------------------------------------------------
     size_t   n = 0, cap = 0;
@@ -83,7 +84,7 @@ struct Index
     unsigned long long *d_totals = nullptr;  // [0..1] search D,E  [2..4] insert D,E,refine  [5] revlink pairs
 
     // scratch (grown on demand)
-    static const int kLanes = 4;  // lantern_gpu_search_batch_lane: batches one caller each may keep in flight side by side
+    static const int kLanes = 8;  // lantern_gpu_search_batch_lane: batches one caller each may keep in flight side by side
     void  *d_scratch[ 12 + 2 * kLanes ] = {};  // [12 ..]: queries / answers of the lanes of lantern_gpu_search_batch_lane
     size_t scratch_bytes[ 12 + 2 * kLanes ] = {};
     hipStream_t lane_stream[ kLanes ] = {};  // created on first use

@@ -160,7 +160,7 @@ struct IoThread
 
 }  // namespace
 
-constexpr int kMaxLanes = 4;  // = Index::kLanes of the device library (lantern_gpu_search_batch_lane)
+constexpr int kMaxLanes = 8;  // = Index::kLanes of the device library (lantern_gpu_search_batch_lane)
 
 struct lantern_scan_server
 {
@@ -561,7 +561,7 @@ try {
     s->fn = default_backend;
     s->fn_ctx = s;
     // dispatchers = lanes of lantern_gpu_search_batch_lane (up to four batches in flight on the device, each in its own slab of
-    // visited bitmaps).  Default four; LANTERN_SCAN_LANES = 1 .. 4.  Measured with lantern-scan-load on 100k x 128 (round 4,
+    // visited bitmaps).  Default four; LANTERN_SCAN_LANES = 1 .. 8.  Measured with lantern-scan-load on 100k x 128 (round 4,
     // profiles/r04_scan_load_lanes.jsonl; lanes 1 / 2 / 3 / 4): 16 backends p50 201 / 214 / 193 / 173 us, 64: 301 / 243 / 235 / 227 us,
     // 256: 389 k / 560 k / 563 k / 628 k scans/s; 8 backends 157 us whatever the number.
     s->lanes = 4;
@@ -579,7 +579,7 @@ try {
     s->fn = fn;
     s->fn_ctx = ctx;
     s->vec_bytes = vec_bytes;
-    // a caller-supplied backend is called from ONE thread unless LANTERN_SCAN_LANES = 2 .. 4 says it may be entered by that many at a time
+    // a caller-supplied backend is called from ONE thread unless LANTERN_SCAN_LANES = 2 .. 8 says it may be entered by that many at a time
     if(const char *ln = std::getenv("LANTERN_SCAN_LANES")) s->lanes = std::min(kMaxLanes, std::max(1, std::atoi(ln)));
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }

@@ -199,4 +199,23 @@ for f in ('cos_q1024','2streams','f16','i8','b1'):
 P
 }
 
+# more lanes: 4 / 6 / 8 dispatchers at 16 / 64 / 256 connections
+lanes8() {
+  timeout 200 python -m pytest tests/test_gpu_scans_and_inserts.py tests/test_scan_server.py tests/test_gpu_quantized_indexes.py -q -x > $OUT/lanes8_tests.log 2>&1; tail -3 $OUT/lanes8_tests.log
+  rm -f $OUT/r04_scan_load_lanes8.jsonl
+  for l in 4 6 8; do for c in 16 64 256; do
+    echo "{\"lanes\": $l}" >> $OUT/r04_scan_load_lanes8.jsonl
+    LANTERN_SCAN_LANES=$l timeout 60 lantern_amd/lib/lantern-scan-load --connections $c --seconds 3 >> $OUT/r04_scan_load_lanes8.jsonl 2>> $OUT/scanload8.err
+  done; done
+  python - <<'P'
+import json
+lanes=None
+for l in open('gpurun_out/r04/r04_scan_load_lanes8.jsonl'):
+    d=json.loads(l)
+    if len(d)==1: lanes=d['lanes']; continue
+    print(lanes, d['connections'], round(d['queries_per_s']), d['latency_us']['p50'], d['latency_us']['p99'], d['service']['mean_batch'])
+P
+  timeout 600 python bench.py --gpus 2 --dist-backend files --no-cpu --rows 300000 --steps 10 > $OUT/bench_2ranks_one_gpu.json 2> $OUT/bench_2ranks.err; tail -c 700 $OUT/bench_2ranks_one_gpu.json; tail -3 $OUT/bench_2ranks.err
+}
+
 "$@"

@@ -136,7 +136,7 @@ def test_the_lanes_of_the_host_buffer_search_run_side_by_side(capi):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
-    for bad in (4, -1):
+    for bad in (8, -1):
         with pytest.raises(capi.LanternGpuError, match="lane must be in"):
             ix.search_batch_lane(bad, qs[0], k)
 
