@@ -187,6 +187,9 @@ LANTERN_GPU_EXPORT unsigned long level_from_node(char *node);
 LANTERN_GPU_EXPORT void reset_node_label(char *node);
 LANTERN_GPU_EXPORT void *get_node_neighbors_mut(const metadata_t *meta, char *node, uint32_t level, uint32_t *neighbors_count);
 #endif
+/* reloption quant_bits -> scalar kind, as ldb_HnswGetScalarKind (options.c:137-158); *err carries the reference's text for a value the
+ * enum reloption rejects (hnsw_sq.out:30-35) or one it has not implemented (4, 2: options.c:150-153).  unset = no reloption given. */
+LANTERN_GPU_EXPORT usearch_scalar_kind_t lantern_quant_bits_scalar_kind(int quant_bits, bool unset, usearch_error_t *err);
 
 /* ------------------------------------------------------------------------------------------ */
 /* (2) batched / device-resident forms                                                         */

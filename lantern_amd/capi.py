@@ -106,6 +106,7 @@ EXPORTS = [
     "lantern_mirror_invalidate", "lantern_mirror_set_capacity", "lantern_mirror_stats",
     # Lantern's node-tape helpers (usearch_storage.hpp:9-23), host-only
     "UsearchNodeBytes", "usearch_init_node", "node_tuple_size", "label_from_node", "level_from_node", "reset_node_label", "get_node_neighbors_mut",
+    "lantern_quant_bits_scalar_kind",
 ]
 
 # int fn(void *ctx, const void *queries, size_t nq, size_t vec_bytes, size_t k, size_t ef, u64 *labels, f32 *dists, u32 *counts, const char **err)
@@ -246,6 +247,7 @@ def lib() -> C.CDLL:
         "level_from_node": (C.c_ulong, [vp]),
         "reset_node_label": (None, [vp]),
         "get_node_neighbors_mut": (vp, [C.POINTER(Metadata), vp, u32, C.POINTER(u32)]),
+        "lantern_quant_bits_scalar_kind": (i32, [i32, C.c_bool, err]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = the library does not export what the header declares

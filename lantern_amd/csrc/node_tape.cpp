@@ -82,4 +82,27 @@ void *get_node_neighbors_mut(const metadata_t *meta, char *node, uint32_t level,
     return list + sizeof(uint32_t);
 }
 
+// The reloption `quant_bits` -> the scalar kind usearch_init takes (lantern_hnsw/src/hnsw/options.c:137-158), with the reference's
+// error texts: a value that is not one of 1, 2, 4, 8, 16, 32 is rejected by the enum reloption (options.c:37-42,301-309; the text is
+// pinned by test/expected/hnsw_sq.out:30-35), 4 and 2 are "unimplemented quantization" (options.c:150-153).  0 bits = unset = f32
+// only through `unset` (the SQL surface spells an explicit 0 as an error: hnsw_sq.out:33-35).
+usearch_scalar_kind_t lantern_quant_bits_scalar_kind(int quant_bits, bool unset, usearch_error_t *e)
+{
+    if(e) *e = nullptr;
+    if(unset) return usearch_scalar_f32_k;
+    switch(quant_bits) {
+        case 32: return usearch_scalar_f32_k;
+        case 16: return usearch_scalar_f16_k;
+        case 8: return usearch_scalar_i8_k;
+        case 1: return usearch_scalar_b1_k;
+        case 4:
+        case 2:
+            if(e) *e = "unimplemented quantization";
+            return usearch_scalar_unknown_k;
+        default:
+            if(e) *e = "Unsupported quantization bits. Supported values are 1, 2, 4, 8, 16 and 32";
+            return usearch_scalar_unknown_k;
+    }
+}
+
 }  // extern "C"

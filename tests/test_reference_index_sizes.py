@@ -111,6 +111,23 @@ def test_page_packing_rules():
     assert L.label_from_node(tape) == 0 and L.level_from_node(tape) == 2
 
 
+def test_quant_bits_reloption_mapping_and_the_references_error_text(capi):
+    """options.c:137-158 (quant_bits -> scalar kind) and the text test/expected/hnsw_sq.out:30-35 pins for values the enum rejects."""
+    L = capi.lib()
+
+    def kind(bits, unset=False):
+        e = C.c_char_p()
+        k = L.lantern_quant_bits_scalar_kind(bits, unset, C.byref(e))
+        return k, (e.value.decode() if e.value else None)
+
+    assert kind(32) == (capi.SCALAR_F32, None) and kind(16) == (capi.SCALAR_F16, None) and kind(8) == (capi.SCALAR_I8, None) and kind(1) == (capi.SCALAR_B1, None)
+    assert kind(0, unset=True) == (capi.SCALAR_F32, None)
+    for bad in (3, 0):  # hnsw_sq.out:30-35: DETAIL of the error for quant_bits=3 and quant_bits=0
+        assert kind(bad) == (0, "Unsupported quantization bits. Supported values are 1, 2, 4, 8, 16 and 32")
+    for todo in (4, 2):  # options.c:150-153
+        assert kind(todo) == (0, "unimplemented quantization")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,want_kb", [("f32", 680), ("f16", 400), ("i8", 272), ("b1", 160)])
 def test_saved_index_file_packs_into_the_references_page_count(capi, kind, want_kb):
