@@ -218,4 +218,23 @@ P
   timeout 600 python bench.py --gpus 2 --dist-backend files --no-cpu --rows 300000 --steps 10 > $OUT/bench_2ranks_one_gpu.json 2> $OUT/bench_2ranks.err; tail -c 700 $OUT/bench_2ranks_one_gpu.json; tail -3 $OUT/bench_2ranks.err
 }
 
+# the decode-on-the-fly walk by the counters: fabric bytes (the bench's own passes) and the L2 hit rate
+pqdpmc() {
+  timeout 400 python bench.py --no-cpu --data clustered --pq-subvectors 96 --steps 5 > $OUT/r04_bench_line_pq96_compact_clustered.json 2> $OUT/pq96_pmc.err
+  timeout 400 python bench.py --no-cpu --data clustered --pq-subvectors 32 --steps 5 > $OUT/r04_bench_line_pq32_compact_clustered.json 2> $OUT/pq32_pmc.err
+  mkdir -p $OUT/pqd_l2
+  timeout 300 rocprofv3 --kernel-include-regex k_search --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pqd_l2/p -o pmc -- python bench.py --no-cpu --no-pmc --data clustered --pq-subvectors 96 --steps 4 --warmup 1 > /dev/null 2> $OUT/pqd_l2.log
+  timeout 300 rocprofv3 --kernel-include-regex k_search --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -d $OUT/pqd_l2/q -o pmc -- python bench.py --no-cpu --no-pmc --data clustered --pq-subvectors 96 --steps 4 --warmup 1 > /dev/null 2> $OUT/pqd_l1.log
+  python - <<'P'
+import glob, sqlite3, json
+for f in ('96','32'):
+    d=json.load(open(f'gpurun_out/r04/r04_bench_line_pq{f}_compact_clustered.json')); r=d['roofline']
+    print('pq'+f, round(d['value']), 'launch ms', round(r['avg_launch_ms'],3), 'traffic GB', (r['traffic'] or 0)/1e9, 'alg GB', r['algorithmic_bytes_per_launch']/1e9, 'frac', r['frac'], 'in-run', r['traffic_measured_in_this_run'])
+for db in glob.glob('gpurun_out/r04/pqd_l2/**/*.db', recursive=True):
+    cur=sqlite3.connect(db).cursor()
+    for row in cur.execute("select counter_name,count(*),avg(value) from counters_collection where kernel_name like '%k_search%' group by counter_name"): print(db.split('/')[-3], row)
+P
+  rm -rf $OUT/pqd_l2
+}
+
 "$@"
