@@ -486,9 +486,15 @@ LANTERN_GPU_EXPORT void lantern_mirror_stats(uint64_t *hits, uint64_t *misses, u
 typedef struct lantern_index_server lantern_index_server_t;
 /* Bind host:port (port 0 = ephemeral; default of the reference is 0.0.0.0:8998, cli.rs:126-151), start the
  * accept thread.  status_port: HTTP status endpoint {"status":0..3} (server.rs:586-597), -1 = none.
- * One connection is served at a time, as in the reference.  TLS is not offered. */
+ * One connection is served at a time, as in the reference. */
 LANTERN_GPU_EXPORT lantern_index_server_t *lantern_index_server_start(const char *host, int port, int status_port,
                                                                       const char *tmp_dir, usearch_error_t *);
+/* The same over TLS (`start-indexing-server --cert C --key K`: cli.rs:146, server.rs:437-470,548): PEM files; every accepted
+ * connection starts with the handshake (the PostgreSQL side: external_index_socket_ssl.c:6-62, TLS >= 1.2, no certificate
+ * verification).  libssl is bound at run time; NULL, NULL = the plain server.  The router redirect of
+ * external_index_socket.c:411-447 is the ROUTER's half of the protocol (server type 0x2), not this server's. */
+LANTERN_GPU_EXPORT lantern_index_server_t *lantern_index_server_start_tls(const char *host, int port, int status_port, const char *tmp_dir,
+                                                                          const char *cert_pem, const char *key_pem, usearch_error_t *);
 LANTERN_GPU_EXPORT int      lantern_index_server_port(lantern_index_server_t *);
 LANTERN_GPU_EXPORT int      lantern_index_server_status_port(lantern_index_server_t *);
 /* 0 idle, 1 in progress, 2 failed, 3 succeeded (server.rs:44-49) */

@@ -91,7 +91,7 @@ EXPORTS = [
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_export_codes",
     "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_gpu_search_phase_profile", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
-    "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist", "lantern_index_server_start",
+    "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist", "lantern_index_server_start", "lantern_index_server_start_tls",
     "lantern_index_server_port", "lantern_index_server_status_port", "lantern_index_server_status",
     "lantern_index_server_served", "lantern_index_server_stop",
     "lantern_gpu_graph_checksum", "lantern_gpu_comm_unique_id", "lantern_gpu_comm_init_rccl", "lantern_gpu_comm_init_host",
@@ -197,6 +197,7 @@ def lib() -> C.CDLL:
         "lantern_cos_dist": (f32, [vp, i32, vp, i32, err]),
         "lantern_hamming_dist": (C.c_int32, [vp, i32, vp, i32, err]),
         "lantern_index_server_start": (vp, [C.c_char_p, i32, i32, C.c_char_p, err]),
+        "lantern_index_server_start_tls": (vp, [C.c_char_p, i32, i32, C.c_char_p, C.c_char_p, C.c_char_p, err]),
         "lantern_index_server_port": (i32, [vp]),
         "lantern_index_server_status_port": (i32, [vp]),
         "lantern_index_server_status": (i32, [vp]),
@@ -990,8 +991,10 @@ class ScanClient:
 class IndexServer:
     """lantern_index_server_*: the external indexing server (B3) on 127.0.0.1 by default."""
 
-    def __init__(self, host="127.0.0.1", port=0, status_port=0, tmp_dir="/tmp"):
-        self.s = _call("lantern_index_server_start", host.encode(), port, status_port, tmp_dir.encode())
+    def __init__(self, host="127.0.0.1", port=0, status_port=0, tmp_dir="/tmp", cert=None, key=None):
+        """cert / key: PEM files -> the server speaks TLS (lantern_index_server_start_tls)."""
+        self.s = _call("lantern_index_server_start_tls", host.encode(), port, status_port, tmp_dir.encode(),
+                       cert.encode() if cert else None, key.encode() if key else None)
         self.host = host
         self.port = int(lib().lantern_index_server_port(self.s))
         self.status_port = int(lib().lantern_index_server_status_port(self.s))

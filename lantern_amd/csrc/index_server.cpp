@@ -14,6 +14,7 @@
 //   on any error: u32 ERR_MSG 0x37333337, u32 length, message                           server.rs:561-573
 // One connection is served at a time, as in the reference (server.rs:537-583).
 #include <arpa/inet.h>
+#include <dlfcn.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <sys/socket.h>
@@ -62,6 +63,7 @@ struct lantern_index_server
     std::atomic<uint64_t>  served{ 0 };
     std::thread         accept_thread, status_thread;
     std::string         tmp_dir;
+    void               *tls_ctx = nullptr;  // SSL_CTX of a server started with a certificate (server.rs:454-470), else NULL
 };
 
 namespace {
@@ -69,23 +71,98 @@ namespace {
 long long now_ms() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count(); }
 void set_status(lantern_index_server *s, int st) { s->status = st; s->status_updated_at = now_ms(); }
 
-void write_all(int fd, const void *buf, size_t n)
+// ---- TLS (lantern_cli start-indexing-server --cert C --key K: server.rs:437-470,548; the PostgreSQL side connects with OpenSSL and
+// does not verify the certificate: external_index_socket_ssl.c:6-62).  libssl is bound at run time (as RCCL is in comm.cpp): a
+// host without it can still run the plain server.
+struct TlsApi
+{
+    void *lib = nullptr;
+    const void *(*TLS_server_method)() = nullptr;
+    void *(*SSL_CTX_new)(const void *) = nullptr;
+    void (*SSL_CTX_free)(void *) = nullptr;
+    int (*SSL_CTX_use_certificate_chain_file)(void *, const char *) = nullptr;
+    int (*SSL_CTX_use_PrivateKey_file)(void *, const char *, int) = nullptr;
+    int (*SSL_CTX_check_private_key)(const void *) = nullptr;
+    long (*SSL_CTX_ctrl)(void *, int, long, void *) = nullptr;
+    void *(*SSL_new)(void *) = nullptr;
+    void (*SSL_free)(void *) = nullptr;
+    int (*SSL_set_fd)(void *, int) = nullptr;
+    int (*SSL_accept)(void *) = nullptr;
+    int (*SSL_read)(void *, void *, int) = nullptr;
+    int (*SSL_write)(void *, const void *, int) = nullptr;
+    int (*SSL_shutdown)(void *) = nullptr;
+    bool ok = false;
+};
+TlsApi *tls_api()
+{
+    static TlsApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for(const char *name : { "libssl.so.3", "libssl.so", "libssl.so.1.1" }) {
+            api.lib = ::dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if(api.lib) break;
+        }
+        if(!api.lib) return;
+        bool all = true;
+#define TLS_SYM(f) all = ((*(void **)&api.f = ::dlsym(api.lib, #f)) != nullptr) && all
+        TLS_SYM(TLS_server_method); TLS_SYM(SSL_CTX_new); TLS_SYM(SSL_CTX_free); TLS_SYM(SSL_CTX_use_certificate_chain_file);
+        TLS_SYM(SSL_CTX_use_PrivateKey_file); TLS_SYM(SSL_CTX_check_private_key); TLS_SYM(SSL_CTX_ctrl); TLS_SYM(SSL_new); TLS_SYM(SSL_free);
+        TLS_SYM(SSL_set_fd); TLS_SYM(SSL_accept); TLS_SYM(SSL_read); TLS_SYM(SSL_write); TLS_SYM(SSL_shutdown);
+#undef TLS_SYM
+        api.ok = all;
+    });
+    return &api;
+}
+
+// one accepted connection: the socket, and the TLS session over it if the server has a certificate
+struct Wire
+{
+    int   fd = -1;
+    void *ssl = nullptr;
+    ssize_t recv_some(void *buf, size_t n)
+    {
+        if(ssl) return (ssize_t)tls_api()->SSL_read(ssl, buf, (int)std::min<size_t>(n, 1u << 30));
+        return ::recv(fd, buf, n, 0);
+    }
+    ssize_t send_some(const void *buf, size_t n)
+    {
+        if(ssl) return (ssize_t)tls_api()->SSL_write(ssl, buf, (int)std::min<size_t>(n, 1u << 30));
+        return ::send(fd, buf, n, MSG_NOSIGNAL);
+    }
+};
+
+void write_all(Wire &w, const void *buf, size_t n)
 {
     const char *p = (const char *)buf;
     while(n) {
-        ssize_t w = ::send(fd, p, n, MSG_NOSIGNAL);
-        if(w <= 0) throw Fail{ "socket write failed" };
-        p += w;
-        n -= (size_t)w;
+        ssize_t sent = w.send_some(p, n);
+        if(sent <= 0) throw Fail{ "socket write failed" };
+        p += sent;
+        n -= (size_t)sent;
     }
 }
-// gather-write of lantern_gpu_save_stream's spans: sendmsg (writev with MSG_NOSIGNAL), resumed after partial writes
+// gather-write of lantern_gpu_save_stream's spans: sendmsg (writev with MSG_NOSIGNAL), resumed after partial writes; over TLS one
+// record stream, span by span
 static_assert(sizeof(lantern_gpu_span) == sizeof(struct iovec) && offsetof(lantern_gpu_span, data) == offsetof(struct iovec, iov_base) &&
                   offsetof(lantern_gpu_span, size) == offsetof(struct iovec, iov_len),
               "lantern_gpu_span must be layout-compatible with struct iovec");
 int send_spans(void *ctx, const lantern_gpu_span *spans, size_t count)
 {
-    const int    fd = *(const int *)ctx;
+    Wire &wire = *(Wire *)ctx;
+    if(wire.ssl) {
+        for(size_t i = 0; i < count; ++i) {
+            const char *p = (const char *)spans[ i ].data;
+            size_t      n = spans[ i ].size;
+            while(n) {
+                const ssize_t sent = wire.send_some(p, n);
+                if(sent <= 0) return -1;
+                p += sent;
+                n -= (size_t)sent;
+            }
+        }
+        return 0;
+    }
+    const int    fd = wire.fd;
     struct iovec iov[ 1024 ];
     while(count) {
         const size_t m = std::min<size_t>(count, 1024);
@@ -109,11 +186,11 @@ int send_spans(void *ctx, const lantern_gpu_span *spans, size_t count)
     }
     return 0;
 }
-void read_exact(int fd, void *buf, size_t n)
+void read_exact(Wire &w, void *buf, size_t n)
 {
     char *p = (char *)buf;
     while(n) {
-        ssize_t r = ::recv(fd, p, n, 0);
+        ssize_t r = w.recv_some(p, n);
         if(r <= 0) throw Fail{ "failed to fill whole buffer" };
         p += r;
         n -= (size_t)r;
@@ -123,10 +200,10 @@ void read_exact(int fd, void *buf, size_t n)
 enum Frame { FRAME_INIT, FRAME_DATA, FRAME_EXIT };
 
 // read_frame (server.rs:275-309): one read, then fill up to expected_size
-Frame read_frame(int fd, std::vector<uint8_t> &buf, size_t expected_size, bool want_init)
+Frame read_frame(Wire &fd, std::vector<uint8_t> &buf, size_t expected_size, bool want_init)
 {
     buf.assign(expected_size, 0);
-    ssize_t got = ::recv(fd, buf.data(), expected_size, 0);
+    ssize_t got = fd.recv_some(buf.data(), expected_size);
     if(got < 4) throw Fail{ "Invalid frame received" };
     uint32_t hdr;
     std::memcpy(&hdr, buf.data(), 4);
@@ -136,7 +213,7 @@ Frame read_frame(int fd, std::vector<uint8_t> &buf, size_t expected_size, bool w
     return hdr == INIT_MSG ? FRAME_INIT : FRAME_DATA;
 }
 
-void serve(lantern_index_server *srv, int fd)
+void serve(lantern_index_server *srv, Wire &fd)
 {
     usearch_index_t index = nullptr;
     usearch_error_t err = nullptr;
@@ -293,7 +370,7 @@ void serve(lantern_index_server *srv, int fd)
             bool   ended = false;
             while(!ended) {
                 const double  r0 = now_s();
-                const ssize_t got = ::recv(fd, inbuf.data() + have, inbuf.size() - have, 0);
+                const ssize_t got = fd.recv_some(inbuf.data() + have, inbuf.size() - have);
                 const double  r1 = now_s();
                 t_recv += r1 - r0;
                 if(got <= 0) throw Fail{ have ? "failed to fill whole buffer" : "Invalid frame received" };
@@ -356,8 +433,7 @@ void serve(lantern_index_server *srv, int fd)
         length_sent = true;  // from here on the client reads `len64` bytes of index file: a failure may only cut the stream short
         // the file goes out as it is formatted: node prefixes + vector bytes from page-locked row chunks, gathered by sendmsg
         // (r2 built the whole 6.4 GB file in memory first: 5 of the 9 s of a 1M x 1536 build)
-        int sink_fd = fd;
-        lantern_gpu_save_stream(index, send_spans, &sink_fd, &err);
+        lantern_gpu_save_stream(index, send_spans, &fd, &err);
         if(err) throw Fail{ err };
         set_status(srv, SUCCEEDED);
     } catch(const Fail &f) {
@@ -379,8 +455,8 @@ void serve(lantern_index_server *srv, int fd)
         const uint32_t hdr = ERR_MSG, n = (uint32_t)failure.size();
         std::memcpy(out, &hdr, 4);
         std::memcpy(out + 4, &n, 4);
-        (void)::send(fd, out, 8, MSG_NOSIGNAL);
-        (void)::send(fd, failure.data(), failure.size(), MSG_NOSIGNAL);
+        (void)fd.send_some(out, 8);
+        (void)fd.send_some(failure.data(), failure.size());
     }
     if(index) usearch_free(index, &err);
     srv->served++;
@@ -419,8 +495,23 @@ void accept_loop(lantern_index_server *srv)
         ::setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
         int one = 1;
         ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        Wire wire;
+        wire.fd = fd;
+        if(srv->tls_ctx) {  // the handshake first (server.rs:548: a rustls ServerConnection per accepted stream)
+            TlsApi *t = tls_api();
+            wire.ssl = t->SSL_new(srv->tls_ctx);
+            if(!wire.ssl || t->SSL_set_fd(wire.ssl, fd) != 1 || t->SSL_accept(wire.ssl) != 1) {
+                if(wire.ssl) t->SSL_free(wire.ssl);
+                ::close(fd);
+                continue;  // not a TLS client (or it gave up): nothing was served
+            }
+        }
         set_status(srv, IN_PROGRESS);
-        serve(srv, fd);
+        serve(srv, wire);
+        if(wire.ssl) {
+            (void)tls_api()->SSL_shutdown(wire.ssl);
+            tls_api()->SSL_free(wire.ssl);
+        }
         ::shutdown(fd, SHUT_RDWR);
         ::close(fd);
     }
@@ -449,14 +540,33 @@ void status_loop(lantern_index_server *srv)
 
 extern "C" {
 
-lantern_index_server_t *lantern_index_server_start(const char *host, int port, int status_port, const char *tmp_dir, usearch_error_t *e)
+lantern_index_server_t *lantern_index_server_start_tls(const char *host, int port, int status_port, const char *tmp_dir, const char *cert_pem,
+                                                       const char *key_pem, usearch_error_t *e)
 try {
     if(e) *e = nullptr;
+    void *ctx = nullptr;
+    if((cert_pem != nullptr) != (key_pem != nullptr)) { if(e) *e = "lantern_gpu: TLS needs both a certificate and a private key"; return nullptr; }
+    if(cert_pem) {
+        TlsApi *t = tls_api();
+        if(!t->ok) { if(e) *e = "lantern_gpu: libssl could not be loaded: TLS is not available on this host"; return nullptr; }
+        ctx = t->SSL_CTX_new(t->TLS_server_method());
+        if(!ctx) { if(e) *e = "lantern_gpu: could not create the TLS context"; return nullptr; }
+        (void)t->SSL_CTX_ctrl(ctx, 123 /* SSL_CTRL_SET_MIN_PROTO_VERSION */, 0x0303 /* TLS 1.2 */, nullptr);  // external_index_socket_ssl.c:13-21
+        (void)t->SSL_CTX_ctrl(ctx, 33 /* SSL_CTRL_MODE */, 4 /* SSL_MODE_AUTO_RETRY */, nullptr);             // :31
+        if(t->SSL_CTX_use_certificate_chain_file(ctx, cert_pem) != 1 || t->SSL_CTX_use_PrivateKey_file(ctx, key_pem, 1 /* PEM */) != 1 ||
+           t->SSL_CTX_check_private_key(ctx) != 1) {
+            t->SSL_CTX_free(ctx);
+            if(e) *e = "lantern_gpu: cannot load the certificate / private key (PEM files expected)";
+            return nullptr;
+        }
+    }
     lantern_index_server *s = new lantern_index_server();
+    s->tls_ctx = ctx;
     s->tmp_dir = tmp_dir ? tmp_dir : "/tmp";
     s->listen_fd = listen_on(host, port, &s->port);
     if(s->listen_fd < 0) {
         if(e) *e = "lantern_gpu: cannot bind the indexing server socket";
+        if(ctx) tls_api()->SSL_CTX_free(ctx);
         delete s;
         return nullptr;
     }
@@ -469,6 +579,11 @@ try {
     return s;
 }
 LANTERN_ABI_CATCH(e)
+
+lantern_index_server_t *lantern_index_server_start(const char *host, int port, int status_port, const char *tmp_dir, usearch_error_t *e)
+{
+    return lantern_index_server_start_tls(host, port, status_port, tmp_dir, nullptr, nullptr, e);
+}
 
 int lantern_index_server_port(lantern_index_server_t *s) { return s ? s->port : -1; }
 int lantern_index_server_status_port(lantern_index_server_t *s) { return s ? s->status_port : -1; }
@@ -483,6 +598,7 @@ try {
     if(s->status_thread.joinable()) s->status_thread.join();
     if(s->listen_fd >= 0) ::close(s->listen_fd);
     if(s->status_fd >= 0) ::close(s->status_fd);
+    if(s->tls_ctx) tls_api()->SSL_CTX_free(s->tls_ctx);
     delete s;
 }
 LANTERN_ABI_CATCH_VOID(nullptr)

@@ -1,6 +1,6 @@
 // lantern-index-server -- standalone front end of the external indexing server in liblantern_gpu.so.
 // Same flags as `lantern-cli start-indexing-server` (lantern_cli/src/external_index/cli.rs:126-151):
-//   --host 0.0.0.0 --port 8998 --status-port 8999 --tmp-dir /tmp     (--cert/--key: TLS is not offered)
+//   --host 0.0.0.0 --port 8998 --status-port 8999 --tmp-dir /tmp [--cert cert.pem --key key.pem]
 #include <unistd.h>
 
 #include <cstdio>
@@ -12,7 +12,7 @@
 
 int main(int argc, char **argv)
 {
-    std::string host = "0.0.0.0", tmp = "/tmp";
+    std::string host = "0.0.0.0", tmp = "/tmp", cert, key;
     int         port = 8998, status_port = 8999;
     for(int i = 1; i < argc; ++i) {
         auto val = [&](const char *name) -> const char * {
@@ -23,17 +23,17 @@ int main(int argc, char **argv)
         else if(const char *v = val("--port")) port = std::atoi(v);
         else if(const char *v = val("--status-port")) status_port = std::atoi(v);
         else if(const char *v = val("--tmp-dir")) tmp = v;
-        else if(std::strcmp(argv[ i ], "--cert") == 0 || std::strcmp(argv[ i ], "--key") == 0) {
-            std::fprintf(stderr, "TLS is not supported by this server\n");
-            return 2;
-        } else {
-            std::fprintf(stderr, "usage: %s [--host H] [--port P] [--status-port P] [--tmp-dir D]\n", argv[ 0 ]);
+        else if(const char *v = val("--cert")) cert = v;
+        else if(const char *v = val("--key")) key = v;
+        else {
+            std::fprintf(stderr, "usage: %s [--host H] [--port P] [--status-port P] [--tmp-dir D] [--cert cert.pem --key key.pem]\n", argv[ 0 ]);
             return 2;
         }
     }
     if(lantern_gpu_device_count() <= 0) std::fprintf(stderr, "warning: no HIP device visible; every build request will fail\n");
     usearch_error_t         err = nullptr;
-    lantern_index_server_t *s = lantern_index_server_start(host.c_str(), port, status_port, tmp.c_str(), &err);
+    lantern_index_server_t *s = lantern_index_server_start_tls(host.c_str(), port, status_port, tmp.c_str(), cert.empty() ? nullptr : cert.c_str(),
+                                                               key.empty() ? nullptr : key.c_str(), &err);
     if(!s) {
         std::fprintf(stderr, "%s\n", err ? err : "cannot start the server");
         return 1;

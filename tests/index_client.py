@@ -23,8 +23,16 @@ def recv_exact(s, n):
     return bytes(buf)
 
 
-def connect(host, port):
+def connect(host, port, tls=False):
     s = socket.create_connection((host, port), timeout=30)
+    if tls:  # what init_ssl does on the PostgreSQL side (external_index_socket_ssl.c:39-62): TLS >= 1.2, no certificate verification
+        import ssl
+
+        ctx = ssl.SSLContext(ssl.PROTOCOL_TLS_CLIENT)
+        ctx.check_hostname = False
+        ctx.verify_mode = ssl.CERT_NONE
+        ctx.minimum_version = ssl.TLSVersion.TLSv1_2
+        s = ctx.wrap_socket(s)
     version, server_type = struct.unpack("<II", recv_exact(s, 8))
     return s, version, server_type
 
@@ -42,10 +50,10 @@ def init_frame(metric_kind, quantization, dim, m, efc, ef, capacity, element_bit
 
 
 def build_index(host, port, metric_kind, dim, rows, labels, m=16, efc=128, ef=64, element_bits=32, quantization=1, capacity=None,
-                codebook=None, num_subvectors=0):
+                codebook=None, num_subvectors=0, tls=False):
     """Returns (num_added, index_file_bytes).  rows: bytes-like per row.  codebook: [num_centroids][dim] f32 rows (pq = true):
     sent centroid by centroid, then END_MSG (external_index_send_codebook, external_index_socket.c:304-320)."""
-    s, version, server_type = connect(host, port)
+    s, version, server_type = connect(host, port, tls)
     assert (version, server_type) == (PROTOCOL_VERSION, SERVER_TYPE_INDEXER)
     if codebook is None:
         s.sendall(init_frame(metric_kind, quantization, dim, m, efc, ef, capacity if capacity is not None else len(labels), element_bits))

@@ -143,3 +143,72 @@ def _levels_of(blob, n, M, vec_bytes):
         off += 10 + (4 + 2 * M * 6) + lv * (4 + M * 6) + vec_bytes
     assert off == len(blob)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# TLS: `start-indexing-server --cert C --key K` (lantern_cli/src/external_index/cli.rs:146, server.rs:437-470,548); the
+# PostgreSQL side connects with OpenSSL, TLS >= 1.2, and does not verify the certificate (external_index_socket_ssl.c:6-62).
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tls_files(tmp_path_factory):
+    import shutil
+    import subprocess
+
+    if not shutil.which("openssl"):
+        pytest.skip("no openssl binary to make a test certificate with")
+    d = tmp_path_factory.mktemp("tls")
+    cert, key = str(d / "cert.pem"), str(d / "key.pem")
+    subprocess.check_call(["openssl", "req", "-x509", "-newkey", "rsa:2048", "-nodes", "-keyout", key, "-out", cert, "-days", "2", "-subj", "/CN=lantern-index-server"],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return cert, key
+
+
+def test_tls_server_speaks_the_protocol_after_the_handshake(capi, tls_files):
+    cert, key = tls_files
+    srv = capi.IndexServer("127.0.0.1", 0, 0, "/tmp", cert=cert, key=key)
+    try:
+        s, version, server_type = ic.connect(srv.host, srv.port, tls=True)
+        assert (version, server_type) == (1, 1) and s.version() in ("TLSv1.2", "TLSv1.3")
+        s.sendall(bytes([0, 1, 1, 1, 1, 1]))
+        assert ic.read_error(s) == "Invalid message header"  # the error frames travel inside the session too
+        s.close()
+        # a client that does not speak TLS gets no protocol bytes and does not take the server down
+        import socket
+
+        plain = socket.create_connection((srv.host, srv.port), timeout=5)
+        plain.sendall(b"\x00" * 64)
+        plain.settimeout(5)
+        try:
+            assert plain.recv(8) != struct.pack("<II", 1, 1)
+        except (ConnectionResetError, socket.timeout):
+            pass
+        plain.close()
+        s, version, server_type = ic.connect(srv.host, srv.port, tls=True)
+        assert (version, server_type) == (1, 1)
+        s.sendall(ic.init_frame(metric_kind=2, quantization=1, dim=3, m=12, efc=64, ef=32, capacity=4, element_bits=32))
+        assert ic.read_error(s) == "Invalid metric 2"
+        s.close()
+    finally:
+        srv.stop()
+    # a certificate without its key, or files that are not PEM, are refused with a message
+    with pytest.raises(capi.LanternGpuError, match="both a certificate and a private key"):
+        capi.IndexServer("127.0.0.1", 0, 0, "/tmp", cert=cert)
+    with pytest.raises(capi.LanternGpuError, match="cannot load the certificate"):
+        capi.IndexServer("127.0.0.1", 0, 0, "/tmp", cert=key, key=cert)
+
+
+@pytest.mark.gpu
+def test_full_build_round_trip_over_tls(capi, tls_files):
+    cert, key = tls_files
+    rng = np.random.default_rng(4)
+    n, d = 3000, 64
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    srv = capi.IndexServer("127.0.0.1", 0, 0, "/tmp", cert=cert, key=key)
+    try:
+        added, blob = ic.build_index(srv.host, srv.port, 3, d, [r.tobytes() for r in base], np.arange(n) + 1, m=8, efc=40, ef=32, tls=True)
+    finally:
+        srv.stop()
+    assert added == n
+    direct = capi.GpuIndex("l2sq", d, M=8, ef_construction=40, ef=32, seed=42)
+    direct.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    assert direct.save_buffer() == blob  # the same index file as the plain server's and as a local build
