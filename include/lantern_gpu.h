@@ -417,6 +417,22 @@ LANTERN_GPU_EXPORT void lantern_gpu_add_sharded(usearch_index_t, lantern_gpu_com
                                                 const void *vectors_shard, size_t n_shard, usearch_scalar_kind_t,
                                                 usearch_error_t *);
 
+/* Row-SHARDED build (SURVEY.md section 8e as written: "vectors sharded by row; each GPU generates candidates within its shard
+ * for a tile of the rows; all-gather of the candidate lists; merge"): a COLLECTIVE on an EMPTY index.  Rank r passes shard r of
+ * the rows (global slot order = rank order).  Every rank builds an HNSW over ITS rows only (no exchange), then the rows of the
+ * whole set stream past all ranks in tiles of 16384 (one all-gather of the tile's rows: the only time a row crosses the fabric);
+ * each rank searches its own graph for the tile's rows (k = 2M + 1, ef = expansion_add: k_search), the per-rank candidate lists
+ * are all-gathered in HBM (12 bytes per candidate) and merged on the device by (distance, id): a node's level-0 list is its
+ * 2M nearest among the candidates of all shards.  The upper levels (~n / M nodes) are built on rank 0 and broadcast.  Every
+ * rank ends with the same graph and the same rows (search it with lantern_gpu_search_batch on any rank, or query-sharded).
+ * The graph is NOT the one usearch_add builds from the same rows (no insertion order, no reverse-link pruning): it is
+ * compared with it by recall (tests/test_gpu_sharded_build.py), where lantern_gpu_add_sharded above is compared edge for edge.
+ * What it buys: the candidate generation -- the expensive part of a build -- needs no exchange inside it, so it scales with
+ * the number of GPUs where the work-sharded build pays two exchanges per insertion batch. */
+LANTERN_GPU_EXPORT void lantern_gpu_add_row_sharded(usearch_index_t, lantern_gpu_comm_t *, const usearch_label_t *labels_shard,
+                                                    const void *vectors_shard, size_t n_shard, usearch_scalar_kind_t,
+                                                    usearch_error_t *);
+
 /* Row-PARTITIONED search (SURVEY.md section 8e as written: "vectors sharded by row; each GPU produces its best candidates
  * within its shard; all-gather; merge"), for indexes whose vectors do not fit one GPU's HBM: a COLLECTIVE over `comm`.  Every
  * rank holds its OWN index over a disjoint share of the rows -- built independently with usearch_add / lantern_gpu_add_many, no

@@ -97,7 +97,7 @@ EXPORTS = [
     "lantern_gpu_graph_checksum", "lantern_gpu_comm_unique_id", "lantern_gpu_comm_init_rccl", "lantern_gpu_comm_init_host",
     "lantern_gpu_comm_init_local", "lantern_gpu_comm_free", "lantern_gpu_comm_rank", "lantern_gpu_comm_world",
     "lantern_gpu_comm_set_timeout", "lantern_gpu_comm_stats", "lantern_gpu_comm_allgatherv_host",
-    "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded", "lantern_gpu_search_partitioned", "lantern_gpu_search_batch_lane",
+    "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded", "lantern_gpu_add_row_sharded", "lantern_gpu_search_partitioned", "lantern_gpu_search_batch_lane",
     "lantern_gpu_level_for", "lantern_gpu_plan_batch",
     "lantern_scan_server_start", "lantern_scan_server_start_fn", "lantern_scan_server_port", "lantern_scan_server_stats",
     "lantern_scan_server_batch_histogram", "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_search_next",
@@ -217,6 +217,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_comm_allgatherv_device": (None, [vp, vp, C.POINTER(sz), C.POINTER(sz), vp, err]),
         "lantern_gpu_shard_range": (None, [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]),
         "lantern_gpu_add_sharded": (None, [vp, vp, vp, vp, sz, i32, err]),
+        "lantern_gpu_add_row_sharded": (None, [vp, vp, vp, vp, sz, i32, err]),
         "lantern_gpu_search_partitioned": (None, [vp, vp, vp, sz, i32, sz, sz, vp, vp, vp, err]),
         "lantern_gpu_search_batch_lane": (None, [vp, i32, vp, sz, i32, sz, sz, vp, vp, vp, err]),
         "lantern_gpu_level_for": (i32, [u64, u64, u32]),
@@ -429,6 +430,13 @@ class GpuIndex:
         lab = np.ascontiguousarray(labels, dtype=np.uint64)
         assert V.shape[1] == self.dims and lab.size == V.shape[0]
         _call("lantern_gpu_add_sharded", self.h, comm.h, _ptr(lab), _ptr(V), V.shape[0], _kind(self.metric))
+
+    def add_row_sharded(self, comm: "Comm", labels, vecs):
+        """COLLECTIVE on an empty index: the row-sharded build (candidates per shard, merged); see lantern_gpu_add_row_sharded."""
+        V = _rows(vecs, self.metric) if len(labels) else np.zeros((0, self.dims), dtype=np.uint32 if self.metric == METRIC_HAMMING else np.float32)
+        lab = np.ascontiguousarray(labels, dtype=np.uint64)
+        assert V.shape[1] == self.dims and lab.size == V.shape[0]
+        _call("lantern_gpu_add_row_sharded", self.h, comm.h, _ptr(lab), _ptr(V), V.shape[0], _kind(self.metric))
 
     def spec_profile(self, on, read=False):
         """The instrumented latency-bound walk: {wave role: {section: cycles}} accumulated since the last read (read=True)."""

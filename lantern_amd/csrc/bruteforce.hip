@@ -530,6 +530,54 @@ hipError_t launch_merge_parts(const uint64_t *labels, const float *dists, uint32
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Row-sharded build (index.cpp add_row_sharded_locked): the candidate lists the ranks found in THEIR shards for row
+// first_slot + q -- [world][nq][k] (label = slot + 1, distance), unused entries (0, inf) -- become what the insertion walk hands
+// the selection kernel for level 0 of batch member q (item link_off[q] / M): up to `stride` keys (distance, slot) in ascending
+// order.  The members of the batch itself (slots >= first_slot: the shards' graphs hold them already) are left out, as they are
+// invisible to one another in a one-GPU batch -- two of them choosing each other would ask for a link that is there already.
+// One wave per row; ranking by counting, as in k_merge_parts.
+__global__ void __launch_bounds__(256) k_merge_candidates(const uint64_t *labels, const float *dists, uint32_t world, uint32_t nq, uint32_t k,
+                                                          uint32_t first_slot, const uint32_t *link_off, uint32_t M, uint32_t stride, uint64_t *tops,
+                                                          uint32_t *top_count)
+{
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if(q >= nq) return;
+    const uint32_t item = link_off[ q ] / M;
+    const uint32_t total = world * k;
+    const size_t   part = (size_t)nq * k;
+    const uint64_t batch = (uint64_t)first_slot + 1;  // labels from here on are members of this batch (the row itself among them)
+    uint32_t       valid = 0;
+    for(uint32_t i = lane; i < total; i += 64) {
+        const size_t   at = (size_t)(i / k) * part + (size_t)q * k + (i % k);
+        const float    d = dists[ at ];
+        const uint64_t l = labels[ at ];
+        if(l == 0 || l >= batch) continue;
+        valid++;
+        const uint32_t dk = f2ord(d);
+        uint32_t       rank = 0;
+        for(uint32_t j = 0; j < total; ++j) {
+            const size_t   aj = (size_t)(j / k) * part + (size_t)q * k + (j % k);
+            const uint64_t lj = labels[ aj ];
+            if(lj == 0 || lj >= batch) continue;
+            const uint32_t djk = f2ord(dists[ aj ]);
+            rank += (djk < dk || (djk == dk && (lj < l || (lj == l && j < i)))) ? 1u : 0u;
+        }
+        if(rank < stride) tops[ (size_t)item * stride + rank ] = make_key(d, (uint32_t)(l - 1));
+    }
+    for(int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+    if(lane == 0) top_count[ item ] = valid < stride ? valid : stride;
+}
+
+hipError_t launch_merge_candidates(const uint64_t *labels, const float *dists, uint32_t world, uint32_t nq, uint32_t k, uint32_t first_slot,
+                                   const uint32_t *link_off, uint32_t M, uint32_t stride, uint64_t *tops, uint32_t *top_count, hipStream_t stream)
+{
+    if(nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_candidates, dim3((nq + 3) / 4), dim3(256), 0, stream, labels, dists, world, nq, k, first_slot, link_off, M, stride, tops,
+                       top_count);
+    return hipGetLastError();
+}
+
 // f16 rows (8 halves per chunk) -> f32 rows (4 floats per chunk) for the MFMA contraction
 __global__ void __launch_bounds__(256) k_dequant_f16(const uint4 *src, size_t nchunks, uint4 *dst)
 {

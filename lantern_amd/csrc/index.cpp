@@ -465,7 +465,17 @@ void prof_resolve(Index *ix, size_t keep)
     }
 }
 
-static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
+// Row-sharded build (add_row_sharded_locked below): where a batch's level-0 candidates come from
+struct RowShard
+{
+    Index *loc;   // this rank's graph over ITS rows (labels = global slot + 1)
+    Comm  *comm;
+    size_t K;     // candidates a shard answers with per row
+    size_t ef;    // ... found with this expansion (>= K)
+};
+static bool row_shard_candidates(Index *ix, const RowShard &rs, size_t first, size_t b, const uint32_t *d_link_off, uint64_t *d_tops, uint32_t *d_top_count);
+
+static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm, const RowShard *rs = nullptr)
 {
     const size_t first = ix->n;
     const int    W = comm ? comm->world : 1, R = comm ? comm->rank : 0;
@@ -508,7 +518,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     // A handful of insertions -- ldb_aminsert's one row, the first batches of a build -- walk alone on their CUs: level 0 by the
     // lone-query walk (insert_spec_kernel.hip), up to two insertions per CU one after the other (LANTERN_GPU_INSERT_SPEC=0: off).
     static const bool ins_spec_env = !(std::getenv("LANTERN_GPU_INSERT_SPEC") && std::atoi(std::getenv("LANTERN_GPU_INSERT_SPEC")) == 0);
-    const bool ins_spec = ins_spec_env && !comm && b_hi - b_lo <= (size_t)ix->num_cus * 2 && insert_spec_supported(ix->mcode, ix->efc, ix->M0) && !lds_list_env();
+    const bool ins_spec = ins_spec_env && !comm && !rs && b_hi - b_lo <= (size_t)ix->num_cus * 2 && insert_spec_supported(ix->mcode, ix->efc, ix->M0) && !lds_list_env();
     const int  ins_waves = ins_spec ? 11 : ix->insert_waves;
     const int  grid = ins_spec ? (int)std::max<size_t>(1, std::min<size_t>(b_hi - b_lo, (size_t)ix->num_cus)) : search_grid(ix, b_hi - b_lo, ix->insert_waves, 20);
     if(!ensure_bitmaps(ix, (size_t)grid)) return false;
@@ -527,6 +537,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     ia.bitmaps = ix->d_bitmaps;
     ia.bm_words = (uint32_t)ix->bm_words;
     ia.lds_list = lds_list_env();
+    ia.only_upper = rs ? 1u : 0u;
     // LDS visited set for the ef_construction-wide walk (spills to the bitmap when 3/4 full); env override for tuning
     // the largest table that still lets FIVE workgroups share a CU (160 KB / 5, minus the walk's lists): 6400 slots at
     // 768-d / efc 128, enough for the ~3700 nodes such a walk visits at the 3/4 load limit
@@ -546,6 +557,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm)
     if(ins_lds(ivis) > 160 * 1024) { set_err(ix, "lantern_gpu: ef_construction/dimensions exceed the 160 KiB LDS budget"); return false; }
     if(ins_spec) HIPCHK(ix, launch_insert_spec(ix->mcode, ia, ins_waves, grid, ix->stream));
     else HIPCHK(ix, launch_insert(ix->mcode, ia, ix->insert_waves, grid, ix->stream));
+    if(rs && !row_shard_candidates(ix, *rs, first, b, d_link_off, d_tops, d_top_count)) return false;  // level 0: from the shards' graphs
     prof_mark(ix, 1);
 
     ConnectArgs ca;
@@ -818,6 +830,201 @@ bool add_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const voi
     if(!fill_norms(ix, first, total)) return false;  // every rank over all rows: the replicas stay self-contained
     bool ok = true;
     run_batches(ix, all_labels.data(), s, total, comm, &ok);
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row-sharded build (SURVEY.md 8e as written; lantern_gpu_add_row_sharded).  The WORK-sharded build above splits the walks of one graph
+// and pays two exchanges per batch; this is the other partitioning: candidate generation by ROW SHARD.  Every rank keeps a graph over
+// ITS rows only, grown in lock step with the global one; a batch of the global build -- the usual plan (plan_batch), its members drawn
+// from all shards in proportion -- goes
+//   1. every rank inserts its share of the batch into its own graph (the ordinary device build, no exchange);
+//   2. the batch's rows are all-gathered into every rank's HBM (the only time a row crosses the fabric);
+//   3. every rank searches ITS graph for each of the batch's rows (k_search, ef = ef_construction, K answers), the per-rank lists are
+//      all-gathered in HBM (12 bytes per candidate) and merged by (distance, slot) into what the level-0 walk of the insertion would
+//      have handed on (k_merge_candidates); the upper levels (~1/M of the nodes) are walked in the global graph as usual (k_insert
+//      with only_upper: replicated, a few per cent of the walks);
+//   4. k_connect, the grouping pass and k_revlink run on every rank as in a one-GPU batch (deterministic: the replicas agree to the
+//      bit, lantern_gpu_graph_checksum).
+// A row so chooses among the rows inserted before it (and its own batch), as in the sequential algorithm: the early rows' long links
+// and the reverse-link pruning are there.  The slots of the result follow the batches (within a batch rank 0's share first), not the
+// caller's rank order: labels identify rows.  NOT the one-GPU build's graph edge for edge -- the candidates of a row are the union of
+// W approximate searches instead of one -- so parity is a RECALL statement (tests/test_gpu_sharded_build.py).
+// ---------------------------------------------------------------------------------------------------------------------------
+static bool row_shard_candidates(Index *ix, const RowShard &rs, size_t first, size_t b, const uint32_t *d_link_off, uint64_t *d_tops, uint32_t *d_top_count)
+{
+    Index       *loc = rs.loc;
+    Comm        *comm = rs.comm;
+    const int    W = comm->world, R = comm->rank;
+    const size_t K = rs.K, part = b * K, row = (size_t)ix->chunks * 16;
+    char *d_all = (char *)scratch(ix, 10, (size_t)W * part * 12 + 64);  // [W][b][K] labels | [W][b][K] distances
+    if(!d_all) return false;
+    uint64_t *g_lab = (uint64_t *)d_all;
+    float    *g_dist = (float *)(d_all + (size_t)W * part * 8);
+    bool ok = true;
+    if(loc->n == 0) {
+        std::vector<float> inf(part, __builtin_inff());
+        ok = hipMemsetAsync(g_lab + (size_t)R * part, 0, part * 8, ix->stream) == hipSuccess &&
+             hipMemcpyAsync(g_dist + (size_t)R * part, inf.data(), part * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess &&
+             hipStreamSynchronize(ix->stream) == hipSuccess;  // `inf` is a local
+    } else {
+        std::lock_guard<std::mutex> gl(loc->mu);
+        ok = run_search_device(loc, (const uint4 *)((const char *)ix->d_vec + first * row), b, K, rs.ef, 0, g_lab + (size_t)R * part, g_dist + (size_t)R * part,
+                               nullptr, nullptr, nullptr, nullptr, ix->stream, loc->search_waves);
+        if(!ok) set_err(ix, "lantern_gpu: row-sharded build, candidate search: " + loc->err);
+    }
+    if(ok && W > 1) {
+        std::vector<size_t> off((size_t)W), cnt((size_t)W);
+        for(int r = 0; r < W; ++r) { off[ (size_t)r ] = (size_t)r * part * 8; cnt[ (size_t)r ] = part * 8; }
+        ok = comm->allgatherv_device(g_lab, off.data(), cnt.data(), ix->stream);
+        for(int r = 0; r < W; ++r) { off[ (size_t)r ] = (size_t)r * part * 4; cnt[ (size_t)r ] = part * 4; }
+        ok = ok && comm->allgatherv_device(g_dist, off.data(), cnt.data(), ix->stream);
+        if(!ok) set_err(ix, "lantern_gpu: row-sharded build, exchange of the candidate lists: " + comm->err);
+    }
+    ok = ok && launch_merge_candidates(g_lab, g_dist, (uint32_t)W, (uint32_t)b, (uint32_t)K, (uint32_t)first, d_link_off, ix->M, ix->efc, d_tops, d_top_count,
+                                       ix->stream) == hipSuccess;
+    if(!ok && ix->err.empty()) set_err(ix, "lantern_gpu: HIP failure during the row-sharded build");
+    return ok;
+}
+
+bool add_row_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const void *vectors, size_t n_shard, int kind_in)
+{
+    if(ix->n || !ix->pend_labels.empty()) { set_err(ix, "lantern_gpu: the row-sharded build needs an empty index"); return false; }
+    if(ix->pq || ix->b1_from_f32) { set_err(ix, "lantern_gpu: the row-sharded build does not take pq or quant_bits = 1 indexes"); return false; }
+    const int    W = comm->world, R = comm->rank;
+    const size_t row = (size_t)ix->chunks * 16, M0 = ix->M0, efc = ix->efc, in_bytes = input_bytes(ix, kind_in);
+    // ---- shard sizes
+    std::vector<uint64_t> sizes((size_t)W, 0);
+    std::vector<size_t>   off((size_t)W), cnt((size_t)W);
+    sizes[ (size_t)R ] = n_shard;
+    for(int r = 0; r < W; ++r) { off[ (size_t)r ] = (size_t)r * 8; cnt[ (size_t)r ] = 8; }
+    if(!comm->allgatherv_host(sizes.data(), off.data(), cnt.data())) { set_err(ix, comm->err); return false; }
+    std::vector<size_t> lo((size_t)W + 1, 0);
+    for(int r = 0; r < W; ++r) lo[ (size_t)r + 1 ] = lo[ (size_t)r ] + (size_t)sizes[ (size_t)r ];
+    const size_t N = lo[ (size_t)W ];
+    if(N == 0) return true;
+    if(N >= 0x7FFFFFFEull) { set_err(ix, "lantern_gpu: capacity above 2^31-1 slots is not supported"); return false; }
+    // ---- this rank's own graph; a row's label there is its GLOBAL slot + 1
+    usearch_error_t err = nullptr;
+    usearch_init_options_t lo_opts = ix->opts;
+    lo_opts.retriever = lo_opts.retriever_mut = nullptr;
+    lo_opts.retriever_ctx = nullptr;
+    Index *loc = (Index *)usearch_init(&lo_opts, nullptr, &err);
+    if(!loc) { set_err(ix, std::string("lantern_gpu: row-sharded build: ") + (err ? err : "cannot create the shard's index")); return false; }
+    struct Cleanup { Index *a = nullptr; ~Cleanup() { usearch_error_t ig = nullptr; if(a) usearch_free(a, &ig); } } cleanup;
+    cleanup.a = loc;
+    loc->seed = ix->seed;
+    loc->efc = ix->efc;
+    loc->add_batch_max = ix->add_batch_max;
+    loc->add_min_ratio = ix->add_min_ratio;
+    if(n_shard) {
+        usearch_reserve(loc, n_shard, &err);
+        if(err) { set_err(ix, std::string("lantern_gpu: row-sharded build, shard graph: ") + err); return false; }
+    }
+    // ---- levels by the usual draw over the global slots, room for everything, the plan of the whole build
+    StagedMeta s;
+    if(!stage_meta(ix, nullptr, N, s)) return false;
+    struct Batch { size_t first, b; };
+    std::vector<Batch>  plan;
+    std::vector<size_t> share;  // [batch][rank]: how many of the batch's rows come from that rank's shard
+    {
+        std::vector<size_t> rem((size_t)W);
+        for(int r = 0; r < W; ++r) rem[ (size_t)r ] = (size_t)sizes[ (size_t)r ];
+        int    max_level = 0;
+        size_t pi = 0;
+        while(pi < N) {
+            const size_t b = plan_batch(pi, max_level, s.lv.data() + pi, std::min(N - pi, ix->add_batch_max), ix->add_batch_max, ix->add_min_ratio);
+            if(pi == 0 || (b == 1 && s.lv[ pi ] > max_level)) max_level = s.lv[ pi ];
+            // the batch's rows in proportion to what the shards still hold (largest remainders first, ties to the lower rank)
+            const size_t left = N - pi, at = share.size();
+            size_t       given = 0;
+            share.resize(at + (size_t)W);
+            for(int r = 0; r < W; ++r) given += share[ at + (size_t)r ] = (size_t)((unsigned __int128)rem[ (size_t)r ] * b / left);
+            while(given < b) {
+                int best = -1;
+                for(int r = 0; r < W; ++r) {
+                    const size_t spare = rem[ (size_t)r ] - share[ at + (size_t)r ];
+                    if(spare && (best < 0 || spare > rem[ (size_t)best ] - share[ at + (size_t)best ])) best = r;
+                }
+                share[ at + (size_t)best ] += 1;
+                given += 1;
+            }
+            for(int r = 0; r < W; ++r) rem[ (size_t)r ] -= share[ at + (size_t)r ];
+            plan.push_back({ pi, b });
+            pi += b;
+        }
+    }
+    // ---- labels in slot order (every rank knows where every rank's rows go), levels and upper offsets: one upload
+    std::vector<uint64_t> by_rank(N), all_labels(N);
+    if(n_shard) std::memcpy(&by_rank[ lo[ (size_t)R ] ], labels, n_shard * 8);
+    for(int r = 0; r < W; ++r) { off[ (size_t)r ] = lo[ (size_t)r ] * 8; cnt[ (size_t)r ] = (size_t)sizes[ (size_t)r ] * 8; }
+    if(W > 1 && !comm->allgatherv_host(by_rank.data(), off.data(), cnt.data())) { set_err(ix, comm->err); return false; }
+    {
+        std::vector<size_t> cur(lo.begin(), lo.end() - 1);
+        for(size_t t = 0; t < plan.size(); ++t) {
+            size_t at = plan[ t ].first;
+            for(int r = 0; r < W; ++r)
+                for(size_t j = 0; j < share[ t * (size_t)W + (size_t)r ]; ++j) all_labels[ at++ ] = by_rank[ cur[ (size_t)r ]++ ];
+        }
+    }
+    HIPCHK(ix, hipMemcpyAsync(ix->d_labels, all_labels.data(), N * 8, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipMemcpyAsync(ix->d_levels, s.l8.data(), N, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipMemcpyAsync(ix->d_upper_off, s.uo.data(), N * 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipStreamSynchronize(ix->stream));
+    // every shard answers with more than its expected share of a row's ef_construction nearest (2x; all of them for one or two ranks),
+    // found with that expansion; LANTERN_GPU_ROW_SHARD_K / _EF override (tuning)
+    RowShard rs;
+    rs.loc = loc;
+    rs.comm = comm;
+    rs.K = std::min<size_t>(efc, std::max<size_t>(M0 + 1, 2 * efc / (size_t)W));
+    rs.ef = rs.K;  // (measured, 200k x 768, 4 and 8 shards: recall is the same to the fourth digit from ef = ef_construction down to 33)
+    if(const char *ke = std::getenv("LANTERN_GPU_ROW_SHARD_K")) rs.K = std::min<size_t>(efc, std::max<size_t>(1, (size_t)std::atoi(ke)));  // tuning
+    if(const char *ee = std::getenv("LANTERN_GPU_ROW_SHARD_EF")) rs.ef = std::min<size_t>(efc, std::max<size_t>(rs.K, (size_t)std::atoi(ee)));
+    // ---- the batches
+    size_t mine = 0;  // rows of this rank's shard handed out so far
+    bool   ok = true;
+    std::vector<uint64_t> gl;
+    for(size_t t = 0; t < plan.size() && ok; ++t) {
+        const size_t first = plan[ t ].first, b = plan[ t ].b, *sh = &share[ t * (size_t)W ];
+        size_t my_off = 0;
+        for(int r = 0; r < R; ++r) my_off += sh[ r ];
+        const size_t my_n = sh[ R ];
+        // 1. this rank's share joins its own graph
+        if(my_n) {
+            gl.resize(my_n);
+            for(size_t i = 0; i < my_n; ++i) gl[ i ] = (uint64_t)(first + my_off + i) + 1;
+            lantern_gpu_add_many(loc, gl.data(), (const char *)vectors + mine * in_bytes, my_n, (usearch_scalar_kind_t)kind_in, &err);
+            if(!err) lantern_gpu_flush(loc, &err);
+            if(err) { set_err(ix, std::string("lantern_gpu: row-sharded build, shard graph: ") + err); return false; }
+            // 2. ... and the global table (the shard's graph holds the stored form of the rows)
+            HIPCHK(ix, hipMemcpyAsync((char *)ix->d_vec + (first + my_off) * row, (const char *)loc->d_vec + mine * row, my_n * row, hipMemcpyDeviceToDevice, ix->stream));
+            mine += my_n;
+        }
+        if(W > 1) {
+            size_t at = 0;
+            for(int r = 0; r < W; ++r) { off[ (size_t)r ] = at * row; cnt[ (size_t)r ] = sh[ r ] * row; at += sh[ r ]; }
+            if(!comm->allgatherv_device((char *)ix->d_vec + first * row, off.data(), cnt.data(), ix->stream)) { set_err(ix, comm->err); return false; }
+        }
+        if(!fill_norms(ix, first, b)) return false;
+        // 3. + 4.
+        if(ix->n == 0) {  // "Do nothing for the first element": it only becomes the entry point
+            ix->n = 1;
+            ix->entry = 0;
+            ix->max_level = s.lv[ 0 ];
+            ix->c_add_vectors += 1;
+        } else {
+            ok = run_batch(ix, b, s.lv.data() + first, nullptr, &rs);
+        }
+        // the host transport's staging buffers and the candidate scratch are reused by the next batch
+        if(ok && !sync_stream(ix, comm)) ok = false;
+    }
+    if(ix->profiling) prof_resolve(ix, 0);
+    const size_t done = ix->n;
+    ix->labels.assign(all_labels.begin(), all_labels.begin() + (ptrdiff_t)done);
+    ix->levels.assign(s.l8.begin(), s.l8.begin() + (ptrdiff_t)done);
+    ix->upper_off.assign(s.uo.begin(), s.uo.begin() + (ptrdiff_t)done);
+    ix->upper_blocks = 0;
+    for(size_t i = 0; i < done; ++i) ix->upper_blocks += (size_t)s.lv[ i ];
     return ok;
 }
 
@@ -1425,6 +1632,20 @@ try {
     if(!ix) return;
     if(level < 0 || level > 255) { FAIL(e, "lantern_gpu: level out of range"); return; }
     add_common(ix, &label, vector, 1, kind, level, e);
+}
+LANTERN_ABI_CATCH_VOID(e)
+
+void lantern_gpu_add_row_sharded(usearch_index_t h, lantern_gpu_comm_t *comm, const usearch_label_t *labels, const void *vectors,
+                                 size_t n_shard, usearch_scalar_kind_t kind, usearch_error_t *e)
+try {
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    if(!comm) { FAIL(e, "lantern_gpu: null communicator"); return; }
+    if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the vector does not match the index"); return; }
+    if(n_shard && (!vectors || !labels)) { FAIL(e, "lantern_gpu: null vector or label pointer"); return; }
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!add_row_sharded_locked(ix, (Comm *)comm, labels, vectors, n_shard, (int)kind)) FAIL(e, ix->err.c_str());
 }
 LANTERN_ABI_CATCH_VOID(e)
 

@@ -33,8 +33,9 @@ __global__ void __launch_bounds__(512, 6) k_insert(InsertArgs a)
         }
         __syncthreads();
         uint32_t D = 0, E = 0;
-        uint32_t cur = greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, target, D);
-        for(int level = target < a.view.max_level ? target : a.view.max_level; level >= 0; --level) {
+        const int lowest = a.only_upper ? 1 : 0;  // (block-uniform: a node of level 0 has nothing to walk then)
+        uint32_t cur = target >= lowest ? greedy_descent<METRIC, G>(a.view, s, a.view.entry, a.view.max_level, target, D) : 0u;
+        for(int level = target < a.view.max_level ? target : a.view.max_level; level >= lowest; --level) {
             int cnt;
             if constexpr(KPL > 0) cnt = search_level_reg<METRIC, G, KPL>(a.view, s, bitmap, a.bm_words, cur, level, (int)a.efc, D, E);
             else cnt = search_level<METRIC, G>(a.view, s, bitmap, a.bm_words, cur, level, (int)a.efc, D, E);

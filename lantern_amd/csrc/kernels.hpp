@@ -69,6 +69,7 @@ struct InsertArgs
     uint32_t       *ticket;      // as SearchArgs::ticket, over the batch members
     int             lds_list;    // as SearchArgs::lds_list
     uint32_t        spec_prefetch, spec_cache;  // the latency-bound form (insert_spec_kernel.hip): as SearchArgs'
+    uint32_t        only_upper = 0;  // k_insert only: 1 = walk levels >= 1 only (the row-sharded build takes a node's level-0 candidates from the shards)
 };
 
 // neighbour selection of the new nodes: one item per (new node, level)
@@ -157,6 +158,9 @@ hipError_t launch_pq_decode(float *rows, uint32_t row_floats, uint32_t first, ui
 // f32 rows -> the stored rows of an f16 / i8 / b1 index, on the device (the rules of pad_row, element for element)
 hipError_t launch_merge_parts(const uint64_t *labels, const float *dists, uint32_t world, uint32_t nq, uint32_t k, uint64_t *out_labels,
                               float *out_dists, uint32_t *out_counts, hipStream_t stream);
+// row-sharded build: the shards' candidate lists, merged, as the selection kernel's level-0 input
+hipError_t launch_merge_candidates(const uint64_t *labels, const float *dists, uint32_t world, uint32_t nq, uint32_t k, uint32_t first_slot,
+                                   const uint32_t *link_off, uint32_t M, uint32_t stride, uint64_t *tops, uint32_t *top_count, hipStream_t stream);
 hipError_t launch_store_quantised(const float *src, uint32_t dims, uint32_t count, int kind, uint32_t *rows, uint32_t row_words, hipStream_t stream);
 
 // ||row||^2 of rows [first, first + count) into norm2 (cosine metrics only; no-op otherwise)

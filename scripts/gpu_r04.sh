@@ -237,4 +237,28 @@ P
   rm -rf $OUT/pqd_l2
 }
 
+rowshard() {
+  timeout 900 python -m pytest tests/test_gpu_sharded_build.py -q -s -k "row_sharded" > $OUT/rowshard.log 2>&1
+  grep -a "recall@10\|passed\|failed\|Error" $OUT/rowshard.log | tail -40
+}
+
+rowdbg() {
+  LANTERN_GPU_TRACE_ROWSHARD=1 PYTHONPATH=. timeout 120 python scripts/debug_rowshard.py 600 64 > $OUT/rowdbg.log 2>&1
+  grep -a "BAD" $OUT/rowdbg.log | head -30; grep -a -c "mark" $OUT/rowdbg.log
+}
+
+rowsweep() {
+  timeout 900 python scripts/rowshard_sweep.py 200000 768 128 l2sq > $OUT/rowshard_sweep_200k_768.log 2>&1; tail -9 $OUT/rowshard_sweep_200k_768.log
+  timeout 900 python scripts/rowshard_sweep.py 100000 1536 128 cos > $OUT/rowshard_sweep_100k_1536.log 2>&1; tail -9 $OUT/rowshard_sweep_100k_1536.log
+}
+
+rowseeds() {
+  timeout 600 python scripts/rowshard_seeds.py 20000 768 64 l2sq 2 2>&1 | tail -7
+  timeout 600 python scripts/rowshard_seeds.py 20000 768 128 l2sq 3 2>&1 | tail -7
+}
+
+rowsweep2() {
+  timeout 900 python scripts/rowshard_sweep.py 200000 768 128 l2sq 4:0:0,4:64:64,4:48:48,4:33:33,8:0:0,8:33:33 > $OUT/rowshard_sweep_ef_200k_768.log 2>&1; tail -9 $OUT/rowshard_sweep_ef_200k_768.log
+}
+
 "$@"
