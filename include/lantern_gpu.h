@@ -418,17 +418,20 @@ LANTERN_GPU_EXPORT void lantern_gpu_add_sharded(usearch_index_t, lantern_gpu_com
                                                 usearch_error_t *);
 
 /* Row-SHARDED build (SURVEY.md section 8e as written: "vectors sharded by row; each GPU generates candidates within its shard
- * for a tile of the rows; all-gather of the candidate lists; merge"): a COLLECTIVE on an EMPTY index.  Rank r passes shard r of
- * the rows (global slot order = rank order).  Every rank builds an HNSW over ITS rows only (no exchange), then the rows of the
- * whole set stream past all ranks in tiles of 16384 (one all-gather of the tile's rows: the only time a row crosses the fabric);
- * each rank searches its own graph for the tile's rows (k = 2M + 1, ef = expansion_add: k_search), the per-rank candidate lists
- * are all-gathered in HBM (12 bytes per candidate) and merged on the device by (distance, id): a node's level-0 list is its
- * 2M nearest among the candidates of all shards.  The upper levels (~n / M nodes) are built on rank 0 and broadcast.  Every
- * rank ends with the same graph and the same rows (search it with lantern_gpu_search_batch on any rank, or query-sharded).
- * The graph is NOT the one usearch_add builds from the same rows (no insertion order, no reverse-link pruning): it is
- * compared with it by recall (tests/test_gpu_sharded_build.py), where lantern_gpu_add_sharded above is compared edge for edge.
- * What it buys: the candidate generation -- the expensive part of a build -- needs no exchange inside it, so it scales with
- * the number of GPUs where the work-sharded build pays two exchanges per insertion batch. */
+ * for a tile of the rows; all-gather of the candidate lists; merge"): a COLLECTIVE on an EMPTY index (f32 / f16 / i8 / b1 rows,
+ * not pq).  Rank r passes shard r of the rows.  Every rank keeps a graph over ITS rows only, grown in lock step with the global
+ * one.  A batch of the global build (the usual plan, its members drawn from all shards in proportion): every rank inserts its
+ * share into its own graph; the batch's rows are all-gathered (the only time a row crosses the fabric); every rank searches its
+ * own graph for each row of the batch (k_search; K = max(2M + 1, 2 expansion_add / world) answers), the per-rank lists are
+ * all-gathered in HBM (12 bytes per candidate) and merged on the device by (distance, slot) into the input of the neighbour
+ * selection; selection and reverse links then run on every rank as in a one-GPU batch (the upper levels, ~1 / M of the rows, are
+ * walked in the global graph as usual).  Every rank ends with the same graph and the same rows (lantern_gpu_graph_checksum).
+ * The slots follow the batches, not the ranks: labels identify rows.  The graph is NOT the one usearch_add builds edge for edge
+ * (a row's candidates are the union of `world` approximate searches instead of one); it is compared with it by recall
+ * (tests/test_gpu_sharded_build.py, profiles/r04_row_sharded_build.md: on par or better), where lantern_gpu_add_sharded above
+ * is compared edge for edge.  Cost: every rank searches ALL rows and links ALL rows; only the shard-graph insertions fall with
+ * the world size (measured bound: 1.3x at 4-8 ranks) -- lantern_gpu_add_sharded is the build that scales.
+ * LANTERN_GPU_ROW_SHARD_K / LANTERN_GPU_ROW_SHARD_EF override the candidates per shard / the expansion they are found with. */
 LANTERN_GPU_EXPORT void lantern_gpu_add_row_sharded(usearch_index_t, lantern_gpu_comm_t *, const usearch_label_t *labels_shard,
                                                     const void *vectors_shard, size_t n_shard, usearch_scalar_kind_t,
                                                     usearch_error_t *);

@@ -242,10 +242,6 @@ rowshard() {
   grep -a "recall@10\|passed\|failed\|Error" $OUT/rowshard.log | tail -40
 }
 
-rowdbg() {
-  LANTERN_GPU_TRACE_ROWSHARD=1 PYTHONPATH=. timeout 120 python scripts/debug_rowshard.py 600 64 > $OUT/rowdbg.log 2>&1
-  grep -a "BAD" $OUT/rowdbg.log | head -30; grep -a -c "mark" $OUT/rowdbg.log
-}
 
 rowsweep() {
   timeout 900 python scripts/rowshard_sweep.py 200000 768 128 l2sq > $OUT/rowshard_sweep_200k_768.log 2>&1; tail -9 $OUT/rowshard_sweep_200k_768.log
