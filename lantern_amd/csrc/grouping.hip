@@ -66,12 +66,16 @@ __global__ void __launch_bounds__(256) k_gather_heads(const LinkReq *links, uint
 // ONE workgroup sorts (key << 11 | position) -- unique, so any sort is the stable sort -- bitonically in LDS and writes the
 // sorted requests and the groups.  Same outputs as the pipeline above (the order of the GROUP LIST is immaterial there too).
 constexpr uint32_t SMALL_N = 2048;
-__global__ void __launch_bounds__(1024) k_group_small(const LinkReq *links, uint32_t n, LinkReq *sorted, uint2 *groups, uint32_t *ngroups)
+template <uint32_t N, uint32_t THREADS>  // N: keys sorted (a power of two >= n); a lone insertion's <= 64 requests take one wave
+__global__ void __launch_bounds__(THREADS) k_group_small(const LinkReq *links, uint32_t n, LinkReq *sorted, uint2 *groups, uint32_t *ngroups, uint32_t *zero_me)
 {
-    __shared__ uint64_t key[ SMALL_N ];
+    __shared__ uint64_t key[ N ];
     const uint32_t tid = threadIdx.x;
-    if(tid == 0) *ngroups = 0;
-    for(uint32_t i = tid; i < SMALL_N; i += 1024) {
+    if(tid == 0) {
+        *ngroups = 0;
+        if(zero_me) *zero_me = 0;  // (the reverse-link kernels' work counter: saves its own memset node)
+    }
+    for(uint32_t i = tid; i < N; i += THREADS) {
         uint64_t k = ~0ull;
         if(i < n) {
             const LinkReq r = links[ i ];
@@ -81,9 +85,9 @@ __global__ void __launch_bounds__(1024) k_group_small(const LinkReq *links, uint
         key[ i ] = k;
     }
     __syncthreads();
-    for(uint32_t size = 2; size <= SMALL_N; size <<= 1) {
+    for(uint32_t size = 2; size <= N; size <<= 1) {
         for(uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for(uint32_t t = tid; t < SMALL_N / 2; t += 1024) {
+            for(uint32_t t = tid; t < N / 2; t += THREADS) {
                 const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
                 const bool     up = (lo & size) == 0;
                 const uint64_t a = key[ lo ], b = key[ hi ];
@@ -92,7 +96,7 @@ __global__ void __launch_bounds__(1024) k_group_small(const LinkReq *links, uint
             __syncthreads();
         }
     }
-    for(uint32_t j = tid; j < n; j += 1024) {
+    for(uint32_t j = tid; j < n; j += THREADS) {
         const uint64_t k = key[ j ], k40 = k >> 11;
         if(k40 == KEY_NONE) continue;
         sorted[ j ] = links[ (uint32_t)(k & 2047u) ];
@@ -107,13 +111,13 @@ __global__ void __launch_bounds__(1024) k_group_small(const LinkReq *links, uint
 __global__ void __launch_bounds__(1024) k_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, uint32_t *link_off, uint32_t *item_node)
 {
     __shared__ uint32_t part[ 1024 ];
-    const uint32_t tid = threadIdx.x, per = (b + 1023) / 1024;
+    const uint32_t tid = threadIdx.x, T = blockDim.x, per = (b + T - 1) / T;  // (T = 64 for a handful of nodes: one wave, six scan steps)
     const uint32_t lo = tid * per, hi = lo + per < b ? lo + per : b;
     uint32_t       sum = 0;
     for(uint32_t i = lo; i < hi; ++i) sum += (uint32_t)levels[ i ] + 1u;
     part[ tid ] = sum;
     __syncthreads();
-    for(uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    for(uint32_t off = 1; off < T; off <<= 1) {  // Hillis-Steele inclusive scan
         const uint32_t v = tid >= off ? part[ tid - off ] : 0u;
         __syncthreads();
         part[ tid ] += v;
@@ -243,14 +247,20 @@ size_t group_temp_bytes(size_t n)
 }
 
 hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupScratch &gs, LinkReq *sorted, uint2 *groups, uint32_t *ngroups,
-                                 int world, int rank, uint32_t *owner_counts, hipStream_t stream)
+                                 int world, int rank, uint32_t *owner_counts, hipStream_t stream, uint32_t *zero_me)
 {
-    if(n == 0) return hipMemsetAsync(ngroups, 0, 4, stream);
+    if(n == 0) {
+        hipError_t e0 = hipMemsetAsync(ngroups, 0, 4, stream);
+        return e0 != hipSuccess || !zero_me ? e0 : hipMemsetAsync(zero_me, 0, 4, stream);
+    }
     if(world <= 1 && n <= SMALL_N) {
-        hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, stream, links, n, sorted, groups, ngroups);
+        if(n <= 64) hipLaunchKernelGGL((k_group_small<64, 64>), dim3(1), dim3(64), 0, stream, links, n, sorted, groups, ngroups, zero_me);
+        else if(n <= 512) hipLaunchKernelGGL((k_group_small<512, 256>), dim3(1), dim3(256), 0, stream, links, n, sorted, groups, ngroups, zero_me);
+        else hipLaunchKernelGGL((k_group_small<SMALL_N, 1024>), dim3(1), dim3(1024), 0, stream, links, n, sorted, groups, ngroups, zero_me);
         return hipGetLastError();
     }
     hipError_t e = hipSuccess;
+    if(zero_me && (e = hipMemsetAsync(zero_me, 0, 4, stream)) != hipSuccess) return e;
     if(world > 1 && (e = hipMemsetAsync(owner_counts, 0, (size_t)world * 4, stream)) != hipSuccess) return e;
     const uint32_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_link_keys, dim3(blocks), dim3(256), 0, stream, links, n, gs.keys_a, gs.idx_a, ngroups, world, rank, owner_counts);
@@ -265,7 +275,7 @@ hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupSc
 hipError_t launch_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, uint32_t *link_off, uint32_t *item_node, hipStream_t stream)
 {
     if(b == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_batch_layout, dim3(1), dim3(1024), 0, stream, levels, b, M, link_off, item_node);
+    hipLaunchKernelGGL(k_batch_layout, dim3(1), dim3(b <= 64 ? 64 : 1024), 0, stream, levels, b, M, link_off, item_node);
     return hipGetLastError();
 }
 

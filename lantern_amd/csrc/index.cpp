@@ -591,7 +591,8 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm, const RowS
     // reverse links: group by (close, level); within a group apply in new-slot order -- on the device (grouping.hip).
     // In a sharded batch a rank keeps only the groups of the nodes it owns (close % world) and counts the others'
     // (the sizes of the second exchange's segments must be known to every rank's HOST: the one value read back).
-    HIPCHK(ix, launch_group_requests(d_links, (uint32_t)total_links, gs, d_reqs, d_groups, d_ngroups, split ? W : 1, R, d_owner, ix->stream));
+    // (the pass also zeroes the reverse-link kernels' work counter, d_work[0]: one node less on the stream)
+    HIPCHK(ix, launch_group_requests(d_links, (uint32_t)total_links, gs, d_reqs, d_groups, d_ngroups, split ? W : 1, R, d_owner, ix->stream, (uint32_t *)d_work));
     std::vector<uint32_t> owner_reqs((size_t)W, 0);
     if(split) {
         HIPCHK(ix, hipMemcpyAsync(owner_reqs.data(), d_owner, (size_t)W * 4, hipMemcpyDeviceToHost, ix->stream));
@@ -639,7 +640,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm, const RowS
     }
     ra.radius0 = use_state ? ix->d_radius0 : nullptr;
     ra.radius_upper = use_state ? ix->d_radius_upper : nullptr;
-    HIPCHK(ix, launch_revlink(ix->mcode, ra, (char *)d_work + 16, (uint32_t *)d_work, ix->num_cus, ix->stream));
+    HIPCHK(ix, launch_revlink(ix->mcode, ra, (char *)d_work + 16, (uint32_t *)d_work, ix->num_cus, ix->stream, true));
     prof_mark(ix, 4);
     if(split) {
         // exchange 2: the adjacency rows the ranks re-wrote, one record [close, level, list[0..M0)] per group.
@@ -737,6 +738,19 @@ static size_t run_batches(Index *ix, const uint64_t *labels, const StagedMeta &s
     return pi;
 }
 
+static const size_t kStageBytes = 256 * 1024;
+static bool stage_buffer(Index *ix)
+{
+    if(ix->h_stage) return true;
+    if(hipHostMalloc((void **)&ix->h_stage, kStageBytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ix->h_stage = nullptr;
+        return false;  // (the pageable path still works)
+    }
+    ix->h_stage_bytes = kStageBytes;
+    return true;
+}
+
 // Insert `count` vectors whose padded rows start at `rows` (row_words 4-byte words each).  levels[i] < 0
 // means "draw with level_for()".  Returns how many were inserted (== count unless a batch failed).
 // raw_f32: `rows` are the caller's f32 vectors (dimensions floats each) of an index with quantised storage: they are
@@ -753,7 +767,7 @@ static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_i
     // node is unreachable, so its row may sit in the table before its batch runs
     StagedMeta s;
     if(!stage_meta(ix, levels_in, count, s)) return fail();
-    bool up = true;
+    bool up = true, staged = false;
     if(raw_f32) {
         const size_t d = ix->opts.dimensions;
         float *tmp = nullptr;
@@ -763,13 +777,28 @@ static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_i
                                           ix->stream) == hipSuccess;
         up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
         if(tmp) (void)hipFree(tmp);
+    } else if(count * (row_words * 4 + 16) <= kStageBytes && stage_buffer(ix)) {
+        // a handful of rows: through the page-locked block, no wait before the kernels (the block is next written by the next
+        // insertion, which starts after this one's closing synchronisation in run_batches)
+        char *hs = ix->h_stage, *h_rows = hs, *h_lab = h_rows + count * row_words * 4, *h_uo = h_lab + count * 8, *h_lv = h_uo + count * 4;
+        std::memcpy(h_rows, rows, count * row_words * 4);
+        std::memcpy(h_lab, labels, count * 8);
+        std::memcpy(h_uo, s.uo.data(), count * 4);
+        std::memcpy(h_lv, s.l8.data(), count);
+        up = hipMemcpyAsync((char *)ix->d_vec + first * row_words * 4, h_rows, count * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        up = up && hipMemcpyAsync(ix->d_labels + first, h_lab, count * 8, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        up = up && hipMemcpyAsync(ix->d_upper_off + first, h_uo, count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        up = up && hipMemcpyAsync(ix->d_levels + first, h_lv, count, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        staged = true;
     } else {
         up = hipMemcpyAsync((char *)ix->d_vec + first * row_words * 4, rows, count * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     }
-    up = up && hipMemcpyAsync(ix->d_labels + first, labels, count * 8, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-    up = up && hipMemcpyAsync(ix->d_levels + first, s.l8.data(), count, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-    up = up && hipMemcpyAsync(ix->d_upper_off + first, s.uo.data(), count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-    up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
+    if(!staged) {
+        up = up && hipMemcpyAsync(ix->d_labels + first, labels, count * 8, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        up = up && hipMemcpyAsync(ix->d_levels + first, s.l8.data(), count, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        up = up && hipMemcpyAsync(ix->d_upper_off + first, s.uo.data(), count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
+    }
     if(!up) { set_err(ix, "lantern_gpu: HIP failure uploading vectors"); return fail(); }
     if(!pq_encode_rows(ix, first, count)) return fail();  // pq = true: the rows become their decodings, the codes go beside them
     if(!fill_norms(ix, first, count)) return fail();
@@ -984,7 +1013,8 @@ bool add_row_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const
     size_t mine = 0;  // rows of this rank's shard handed out so far
     bool   ok = true;
     std::vector<uint64_t> gl;
-    for(size_t t = 0; t < plan.size() && ok; ++t) {
+    // (a failure leaves the index with the batches that completed: the host mirrors below describe exactly those)
+    auto batch = [&](size_t t) -> bool {
         const size_t first = plan[ t ].first, b = plan[ t ].b, *sh = &share[ t * (size_t)W ];
         size_t my_off = 0;
         for(int r = 0; r < R; ++r) my_off += sh[ r ];
@@ -1012,12 +1042,13 @@ bool add_row_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const
             ix->entry = 0;
             ix->max_level = s.lv[ 0 ];
             ix->c_add_vectors += 1;
-        } else {
-            ok = run_batch(ix, b, s.lv.data() + first, nullptr, &rs);
+        } else if(!run_batch(ix, b, s.lv.data() + first, nullptr, &rs)) {
+            return false;
         }
         // the host transport's staging buffers and the candidate scratch are reused by the next batch
-        if(ok && !sync_stream(ix, comm)) ok = false;
-    }
+        return sync_stream(ix, comm);
+    };
+    for(size_t t = 0; t < plan.size() && ok; ++t) ok = batch(t);
     if(ix->profiling) prof_resolve(ix, 0);
     const size_t done = ix->n;
     ix->labels.assign(all_labels.begin(), all_labels.begin() + (ptrdiff_t)done);
@@ -1500,6 +1531,7 @@ try {
     prof_resolve(ix, 0);
     for(hipEvent_t ev : ix->prof_free) (void)hipEventDestroy(ev);
     if(ix->h_single) (void)hipHostFree(ix->h_single);
+    if(ix->h_stage) (void)hipHostFree(ix->h_stage);
     for(int sl = 0; sl < Index::kSearchSlots; ++sl) {
         if(sl > 0 && ix->slot_bitmaps[ sl ]) (void)hipFree(ix->slot_bitmaps[ sl ]);
         if(ix->slot_done[ sl ]) (void)hipEventDestroy(ix->slot_done[ sl ]);

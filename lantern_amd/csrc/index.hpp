@@ -151,6 +151,10 @@ struct Index
     // launch and one stream synchronisation, no copy commands
     char  *h_single = nullptr, *h_single_dev = nullptr;  // host / device address of the block
     size_t h_single_bytes = 0;
+    // page-locked staging of a SMALL insertion (ldb_aminsert's one row): rows | labels | upper offsets | levels travel from here with
+    // four queued copies and no wait in between (a pageable source costs a staged, synchronous copy each)
+    char  *h_stage = nullptr;
+    size_t h_stage_bytes = 0;
 
     // ---- launches that share per-index scratch are ordered across streams.  The walk kernels use per-workgroup visited
     // bitmaps indexed by blockIdx only, so two launches may overlap only if they use different bitmap slabs.  SEARCH launches

@@ -30,15 +30,16 @@ namespace lgpu {
 // ---------------------------------------------------------------------------------------------------
 // k_connect: connect_new_node_ -- the neighbour-selection heuristic over one walk result, one workgroup of four
 // waves per (new node, level).  It is its own kernel because its best shape differs from the walk's: the kept
-// rows live in REGISTERS (wave w owns kept entries w, w+4, w+8, w+12), every wave loads the candidate row once
-// (the next candidate's row is already in flight) and tests it against its own kept rows with no memory access,
-// so a candidate costs one barrier instead of a round of L2 reads.  Same lane/chunk ownership and reduction
-// tree as group_dist<METRIC, 64>, hence the same bits.  Rows that do not fit this shape (G < 64, more than 256
-// chunks, M > 16) take the generic refine().
+// rows live in REGISTERS (G = 64: wave w owns kept entries w, w+4, w+8, w+12; shorter rows: the 256 / G groups of G lanes own
+// them round robin -- [r4] all row lengths, not only G = 64: a lone insertion at 128 dimensions spent 62 us here), every group
+// loads the candidate row once (the next candidate's row is already in flight) and tests it against its own kept rows with no
+// memory access, so a candidate costs one barrier instead of a round of L2 reads.  Same lane/chunk ownership and reduction
+// tree as group_dist<METRIC, G>, hence the same bits.  Rows that do not fit this shape (more than G x CPLC chunks, M > 16)
+// take the generic refine().
 template <int METRIC, int G, int CPLC = 4>  // CPLC: 16-byte chunks per lane of the register path (rows of up to 64 * CPLC chunks)
 __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
 {
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, T = blockDim.x;
     RefineLds r;
     unsigned char *p = carve_refine(lgpu_smem, r, a.efc);
     int      *scal = (int *)p;                  p += S_SCALARS * 4;
@@ -61,7 +62,10 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
     uint32_t Dr = 0;
     int      keep;
     const int chunks = (int)a.view.chunks;
-    if(G == 64 && chunks <= 64 * CPLC && M <= 16 && T == 256) {
+    // NG groups of G lanes; group g owns kept entries g, g + NG, ... (KPG of them: four per wave at G = 64, one per group at G <= 16)
+    constexpr int NG = 256 / G, KPG = (16 + NG - 1) / NG;
+    const int     grp = tid / G, gl = tid % G;
+    if(chunks <= G * CPLC && M <= 16 && T == 256) {
         // ---- sort by (distance, tie_mix(slot, me)) into sd / sid
         for(int t = tid; t < n; t += T) {
             const uint64_t k = ((uint64_t)f2ord(r.cd[ t ]) << 32) | tie_mix(r.cid[ t ], me);
@@ -80,18 +84,20 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
                 const uint4 *row = row_of(a.view, slot);
 #pragma unroll
                 for(int c = 0; c < CPLC; ++c) {
-                    const int ch = lane + 64 * c;
+                    const int ch = gl + G * c;
                     v[ c ] = ch < chunks ? row[ ch ] : make_uint4(0, 0, 0, 0);
                 }
             };
-            uint4 kept[ 4 ][ CPLC ], cur[ CPLC ], nxt[ CPLC ];
-            float keptn[ 4 ] = { 0.f, 0.f, 0.f, 0.f };  // cached norms of this wave's kept rows (cosine metrics)
+            uint4 kept[ KPG ][ CPLC ], cur[ CPLC ], nxt[ CPLC ];
+            float keptn[ KPG ];  // cached norms of this group's kept rows (cosine metrics)
 #pragma unroll
-            for(int j = 0; j < 4; ++j)
+            for(int j = 0; j < KPG; ++j) {
+                keptn[ j ] = 0.f;
 #pragma unroll
                 for(int c = 0; c < CPLC; ++c) kept[ j ][ c ] = make_uint4(0, 0, 0, 0);
+            }
             load_row(r.sid[ 0 ], cur);
-            if(wave == 0) {
+            if(grp == 0) {
 #pragma unroll
                 for(int c = 0; c < CPLC; ++c) kept[ 0 ][ c ] = cur[ c ];
                 keptn[ 0 ] = row_norm<METRIC>(a.view, r.sid[ 0 ]);
@@ -99,6 +105,10 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
             if(tid == 0) { kid[ 0 ] = r.sid[ 0 ]; kd[ 0 ] = r.sd[ 0 ]; }
             int submitted = 1, consumed = 1;
             if(n > 1) load_row(r.sid[ 1 ], nxt);
+            // (measured and dropped, r4: FOUR candidates per barrier -- every group tests all four against its kept rows, the groups
+            // share out the six pairs among the four, every thread replays the four decisions from flags in LDS.  Same picks, but a
+            // lone insertion's selection at 128 dimensions went from 48.7 to 59.6 us: 2.5x the distance evaluations per group, each a
+            // dependent fma + DPP chain on a SIMD with one wave, cost more than the three barriers saved.)
             while(submitted < (int)M && consumed < n) {
 #pragma unroll
                 for(int c = 0; c < CPLC; ++c) cur[ c ] = nxt[ c ];
@@ -108,25 +118,25 @@ __global__ void __launch_bounds__(256) k_connect(ConnectArgs a)
                 if(consumed + 1 < n) load_row(r.sid[ consumed + 1 ], nxt);  // in flight while this one is tested
                 bool bad = false;
 #pragma unroll
-                for(int j = 0; j < 4; ++j) {
-                    if(wave + 4 * j < submitted) {  // wave-uniform
+                for(int j = 0; j < KPG; ++j) {
+                    if(grp + NG * j < submitted) {  // group-uniform
                         RowAcc<METRIC> acc;
 #pragma unroll
                         for(int c = 0; c < CPLC; ++c) acc.add(cur[ c ], kept[ j ][ c ]);
-                        const float d = acc.template finish_n<64>(cn2, keptn[ j ]);
-                        bad |= d < cdist;  // meaningful in lane 63
+                        const float d = acc.template finish_n<G>(cn2, keptn[ j ]);
+                        bad |= d < cdist;  // meaningful in the group's last lane
                     }
                 }
                 const int slot = consumed % 3;
-                if(lane == 63 && bad) scal[ slot ] = 1;
+                if(gl == G - 1 && bad) scal[ slot ] = 1;
                 if(tid == 0) scal[ (consumed + 1) % 3 ] = 0;
                 Dr += (uint32_t)submitted;
                 __syncthreads();
                 if(scal[ slot ] == 0) {
-                    const int owner = submitted & 3, j = submitted >> 2;
-                    if(wave == owner) {
+                    const int owner = submitted % NG, j = submitted / NG;
+                    if(grp == owner) {
 #pragma unroll
-                        for(int jj = 0; jj < 4; ++jj)
+                        for(int jj = 0; jj < KPG; ++jj)
                             if(jj == j) {
 #pragma unroll
                                 for(int c = 0; c < CPLC; ++c) kept[ jj ][ c ] = cur[ c ];
@@ -962,7 +972,7 @@ hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream)
+hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream, bool work_count_is_zero)
 {
     if(a.max_groups == 0) return hipSuccess;
     // the number of groups is known to the device only (*a.ngroups): every kernel below loops over it with a grid sized
@@ -973,7 +983,7 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
     const bool i8 = mcode_is_i8(metric);  // i8 rows take the LDS-staged / generic kernels (Lantern caps d at 2000: <= 125 chunks)
     if(!i8 && metric != M_COS_B1 && a.view.chunks >= 128 && a.view.chunks <= 512 && a.view.M0 <= 32 && work && work_count) {
         // d = 512..2048 f32 rows, M <= 16: all-pairs re-prune with the rows in registers (k_revlink_pairs)
-        hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
+        hipError_t e = work_count_is_zero ? hipSuccess : hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;
         hipLaunchKernelGGL(k_revlink_append, dim3(append_grid), dim3(256), 0, stream, a, (RevWork *)work, work_count);
         static const bool force4 = std::getenv("LANTERN_GPU_REGS_CPL4") != nullptr;  // tuning: always the four-chunks-per-lane variant
@@ -981,7 +991,9 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
         // chunks per lane: 3 covers d <= 768 f32 at two workgroups per CU; 4 / 6 / 8 (d <= 1024 / 1536 / 2048) run one per CU
         const int    cpl = cpl3 ? 3 : a.view.chunks <= 256 ? 4 : a.view.chunks <= 384 ? 6 : 8;
         const size_t lds = pairs_lds_bytes(cpl);
-        const int    grid = num_cus * (cpl3 ? 2 : 1);
+        // (a work item is a group whose list overflowed: never more than there are groups -- a lone insertion has at most 2M of them,
+        // and a grid of hundreds of idle 512-thread workgroups costs more to dispatch than its re-prunes take)
+        const int    grid = (int)std::min<uint32_t>((uint32_t)(num_cus * (cpl3 ? 2 : 1)), a.max_groups);
 #define PAIRS_ONE(MM, CC)                                                                                                               \
     {                                                                                                                                   \
         (void)hipFuncSetAttribute((const void *)k_revlink_pairs<MM, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
@@ -1006,13 +1018,13 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
     if(staged <= 150 * 1024 && a.view.M0 <= 256 && work && work_count) {
         // as many 8-wave workgroups per CU as the staged rows leave LDS for (short rows: up to four)
         const int staged_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / staged));
-        hipError_t e = hipMemsetAsync(work_count, 0, 4, stream);
+        hipError_t e = work_count_is_zero ? hipSuccess : hipMemsetAsync(work_count, 0, 4, stream);
         if(e != hipSuccess) return e;
         hipLaunchKernelGGL(k_revlink_append, dim3(append_grid), dim3(256), 0, stream, a, (RevWork *)work, work_count);
 #define CALL(MM, GG)                                                                                                    \
     {                                                                                                                   \
         (void)hipFuncSetAttribute((const void *)k_revlink_staged<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged); \
-        hipLaunchKernelGGL((k_revlink_staged<MM, GG>), dim3(num_cus * staged_per_cu), dim3(512), staged, stream, a, (const RevWork *)work, work_count); \
+        hipLaunchKernelGGL((k_revlink_staged<MM, GG>), dim3(std::min<uint32_t>((uint32_t)(num_cus * staged_per_cu), a.max_groups)), dim3(512), staged, stream, a, (const RevWork *)work, work_count); \
     }
         LGPU_DISPATCH(metric, a.view.chunks, CALL);
 #undef CALL

@@ -117,7 +117,8 @@ struct GroupScratch
 };
 size_t     group_temp_bytes(size_t n);
 hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupScratch &gs, LinkReq *sorted, uint2 *groups, uint32_t *ngroups,
-                                 int world, int rank, uint32_t *owner_counts, hipStream_t stream);
+                                 int world, int rank, uint32_t *owner_counts, hipStream_t stream, uint32_t *zero_me = nullptr);
+// (zero_me: a device word the pass sets to 0 on the way -- the reverse-link kernels' work counter; launch_revlink is then told so)
 // link_off[i] = M * sum_{j<i} (level_j + 1), item_node[item] = i for the (level_i + 1) items of node i -- the layout of
 // one batch, from the levels already in HBM (no per-batch host upload)
 hipError_t launch_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, uint32_t *link_off, uint32_t *item_node, hipStream_t stream);
@@ -135,7 +136,8 @@ size_t     insert_spec_lds_bytes(uint32_t chunks, uint32_t efc, uint32_t M0, uin
 hipError_t launch_insert_spec(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream);
 // work: scratch of max_groups x 8 bytes; work_count: one u32 (both device memory)
-hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream);
+hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t *work_count, int num_cus, hipStream_t stream,
+                          bool work_count_is_zero = false);
 // ---- work-sharded build (shard.cpp): the exchange steps either side of the RCCL all-gathers -------------
 // Every rank holds the complete request array after the first all-gather; the own lists of the nodes another
 // rank connected are rebuilt from their requests: list(new_slot, level)[i] = links[link_off[b] + level*M + i].close

@@ -257,4 +257,42 @@ rowsweep2() {
   timeout 900 python scripts/rowshard_sweep.py 200000 768 128 l2sq 4:0:0,4:64:64,4:48:48,4:33:33,8:0:0,8:33:33 > $OUT/rowshard_sweep_ef_200k_768.log 2>&1; tail -9 $OUT/rowshard_sweep_ef_200k_768.log
 }
 
+instrace() {
+  rm -rf $OUT/instrace; mkdir -p $OUT/instrace
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/instrace -o t -- python $GRAFT_REPO_ROOT/scripts/bench_single_insert.py --no-cpu --inserts 200 > $GRAFT_REPO_ROOT/$OUT/instrace/line.json 2> $GRAFT_REPO_ROOT/$OUT/instrace/err.log)
+  python - <<'P'
+import csv, glob, collections
+ks = []
+for f in glob.glob('gpurun_out/r04/instrace/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        ks.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:60]))
+for f in glob.glob('gpurun_out/r04/instrace/**/*memory_copy_trace.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        ks.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r.get('Direction', r.get('Name', ''))[:40]))
+ks.sort()
+# the last 100 inserts: a cycle starts at each k_insert_spec
+idx = [i for i, k in enumerate(ks) if 'k_insert_spec' in k[2]]
+idx = idx[-101:]
+dur = collections.defaultdict(list); gap = collections.defaultdict(list); cyc = []
+for a, b in zip(idx[:-1], idx[1:]):
+    # the cycle's ops: from the first op after the previous cycle's last kernel ... simpler: ops in [a - pre, b - pre) where pre = copies before the walk
+    ops = ks[a:b]
+    cyc.append(ops[-1][1] - ops[0][0])
+    prev_end = None
+    for s0, e0, n in ops:
+        dur[n].append(e0 - s0)
+        if prev_end is not None: gap[n].append(s0 - prev_end)
+        prev_end = e0
+print('ops per insert (from the walk kernel to the next walk kernel), mean over', len(cyc), 'inserts; ns')
+tot = 0
+for n in dur:
+    d = sum(dur[n]) / len(cyc); g = sum(gap[n]) / len(cyc) if gap[n] else 0
+    print(f'{n:62s} x{len(dur[n]) / len(cyc):.1f}  busy {d:9.0f}  gap before {g:9.0f}')
+    tot += d
+print('busy total', tot, 'walk-to-walk period', sum(b0 - a0 for a0, b0 in zip([ks[i][0] for i in idx[:-1]], [ks[i][0] for i in idx[1:]])) / len(cyc))
+P
+  cat $OUT/instrace/line.json | head -c 600
+  rm -rf $OUT/instrace
+}
+
 "$@"
