@@ -209,14 +209,14 @@ def _free_port():
     return p
 
 
-def test_two_gloo_processes_share_one_build(capi, tmp_path):
+def _two_gloo_ranks(tmp_path, *extra):
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=root)
-    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "gloo_build_rank.py"), str(r), "2", str(tmp_path)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "gloo_build_rank.py"), str(r), "2", str(tmp_path), *extra],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = []
     for p in procs:
@@ -227,8 +227,21 @@ def test_two_gloo_processes_share_one_build(capi, tmp_path):
             o, _ = p.communicate()
         outs.append(o.decode(errors="replace"))
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def test_two_gloo_processes_share_one_build(capi, tmp_path):
+    _two_gloo_ranks(tmp_path)
     ref = np.load(tmp_path / "ref.npy")[0]
     assert np.load(tmp_path / "sum0.npy")[0] == ref == np.load(tmp_path / "sum1.npy")[0]
+
+
+def test_two_gloo_processes_share_one_row_sharded_build(capi, tmp_path):
+    """The row-sharded build over the HOST transport, two processes: rows and candidate lists travel through gloo."""
+    _two_gloo_ranks(tmp_path, "rows")
+    assert np.load(tmp_path / "sum0.npy")[0] == np.load(tmp_path / "sum1.npy")[0]
+    for r in range(2):
+        found = np.load(tmp_path / f"self{r}.npy")
+        assert (found == np.arange(found.size, dtype=np.uint64) + 1).mean() >= 0.99, r
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
