@@ -77,6 +77,9 @@ def parse():
                         "low-dimensional clusters (lantern_amd/synth.py): the set on which HNSW reaches the recall the reference asserts (>= 0.9)")
     p.add_argument("--data-scale", type=float, default=1.0, help="multiply the synthetic rows and queries (i8 storage quantises [-1, 1]: use 0.3)")
     p.add_argument("--collective-timeout", type=float, default=180.0, help="deadline of every exchange of the collective build")
+    p.add_argument("--build", choices=["work-sharded", "row-sharded"], default="work-sharded",
+                   help="the collective build of a multi-rank job: lantern_gpu_add_sharded (default; one graph, bit-identical replicas, "
+                        "DESIGN.md 6) or lantern_gpu_add_row_sharded (the survey's 8e partitioning; recall-equivalent, DESIGN.md 4.6d)")
     p.add_argument("--no-pmc", action="store_true", help="skip the counter passes (roofline.traffic then comes from the committed profiles/pmc_traffic.json, if it has this "
                    "configuration): by default, when rocprofv3 is on PATH, the search leg is re-executed under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
                    "(two short passes restricted to k_search) after the timed region and roofline.traffic is THIS run's")
@@ -226,7 +229,10 @@ def main():
         t0 = time.time()
         err = None
         try:
-            ix.add_sharded(comm, labels[lo:hi], base)  # (this rank's shard: generated above, nothing else is on this host)
+            if a.build == "row-sharded":
+                ix.add_row_sharded(comm, labels[lo:hi], base)
+            else:
+                ix.add_sharded(comm, labels[lo:hi], base)  # (this rank's shard: generated above, nothing else is on this host)
             ix.flush()
             hip.synchronize()
         except Exception as e:  # noqa: BLE001 -- every rank fails together: a collective that misses its deadline fails on all
@@ -254,7 +260,7 @@ def main():
         else:
             sums = [x.decode() for x in rdv.allgather(f"{ix.checksum():016x}".encode())]
             stats = comm.stats()
-            collective = {"world": world, "seconds": rdv.max_float(t_build), "transport": transport, "transport_note": note,
+            collective = {"world": world, "build": a.build, "seconds": rdv.max_float(t_build), "transport": transport, "transport_note": note,
                           "replicas_identical": len(set(sums)) == 1, "checksum": sums[0],
                           "bytes_received_per_rank": [int(x) for x in rdv.allgather(str(stats["bytes_received"]).encode())],
                           "collectives": stats["collectives"]}

@@ -295,4 +295,20 @@ P
   rm -rf $OUT/instrace
 }
 
+# bench.py --gpus 2 on the one-GPU box (two ranks share the device, host transport): both collective builds, like for like
+tworanks() {
+  timeout 600 python bench.py --gpus 2 --dist-backend files --no-cpu --no-pmc --rows 500000 --steps 10 > $OUT/r04_bench_line_2ranks_one_gpu_work_sharded.json 2> $OUT/tworanks_work.err
+  timeout 600 python bench.py --gpus 2 --dist-backend files --no-cpu --no-pmc --rows 500000 --steps 10 --build row-sharded > $OUT/r04_bench_line_2ranks_one_gpu_row_sharded.json 2> $OUT/tworanks_rows.err
+  python - <<'P'
+import json
+for k in ('work', 'row'):
+    try:
+        d = json.load(open(f'gpurun_out/r04/r04_bench_line_2ranks_one_gpu_{k}_sharded.json'))
+        c = d['config']; print(k, 'value', round(d['value']), 'recall', d.get('recall_at_k'), 'collective', json.dumps(c.get('collective_build'))[:400])
+    except Exception as e:
+        print(k, 'failed', e)
+P
+  tail -3 $OUT/tworanks_work.err $OUT/tworanks_rows.err
+}
+
 "$@"

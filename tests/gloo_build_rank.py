@@ -45,6 +45,9 @@ def main():
         ref.add_many(labels, base)
         ref.flush()
         np.save(os.path.join(out_dir, "ref.npy"), np.array([ref.checksum()], dtype=np.uint64))
+        if by_rows:
+            found, _, _ = ref.search_batch(base, 1, 64)
+            np.save(os.path.join(out_dir, "self_ref.npy"), found[:, 0])
     dist.barrier()
     dist.destroy_process_group()
 

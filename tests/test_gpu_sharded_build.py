@@ -239,9 +239,10 @@ def test_two_gloo_processes_share_one_row_sharded_build(capi, tmp_path):
     """The row-sharded build over the HOST transport, two processes: rows and candidate lists travel through gloo."""
     _two_gloo_ranks(tmp_path, "rows")
     assert np.load(tmp_path / "sum0.npy")[0] == np.load(tmp_path / "sum1.npy")[0]
+    own = np.arange(2400, dtype=np.uint64) + 1
+    one_gpu = float((np.load(tmp_path / "self_ref.npy") == own).mean())  # (M = 8, ef_construction = 40: ~0.94 on these rows)
     for r in range(2):
-        found = np.load(tmp_path / f"self{r}.npy")
-        assert (found == np.arange(found.size, dtype=np.uint64) + 1).mean() >= 0.99, r
+        assert float((np.load(tmp_path / f"self{r}.npy") == own).mean()) >= one_gpu - 0.02, r
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
