@@ -311,4 +311,22 @@ P
   tail -3 $OUT/tworanks_work.err $OUT/tworanks_rows.err
 }
 
+# the round's closing records: the benchmark line (CPU port beside it, counters in the run), the kernel trace of the bench command
+final2() {
+  ( time python bench.py ) > $OUT/r04_bench_line.json 2> $OUT/bench_line.err; tail -4 $OUT/bench_line.err
+  python - <<'P'
+import json
+for l in open('gpurun_out/r04/r04_bench_line.json'):
+    if l.startswith('{'):
+        d=json.loads(l); r=d['roofline']
+        print(d['value'], d['ms_per_step'], 'build', d['build_vectors_per_s'], {k:r[k] for k in ('achieved','frac','frac_algorithmic','traffic_measured_in_this_run','traffic','unique_rows_per_launch')}, d['cpu_baseline'])
+P
+  mkdir -p $OUT/ktrace
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ktrace/trace -o trace -- python bench.py --no-cpu --no-pmc --steps 5 --warmup 2 > $OUT/ktrace/bench_trace.json 2> $OUT/ktrace/trace.log
+  python scripts/summarize_prof.py $OUT/ktrace $OUT/r04_bench_1Mx768 > $OUT/ktrace_summary.txt 2>&1; head -12 $OUT/ktrace_summary.txt
+  find $OUT/ktrace -name "*.db" -delete
+  timeout 200 python scripts/bench_single_query.py > $OUT/r04_single_query_100kx128.json 2> $OUT/single_query.err; python -c "
+import json; d=json.load(open('$OUT/r04_single_query_100kx128.json')); print(d['us_per_query_wall'], d['kernel_only'], d.get('cpu_port_us_per_query_1_thread'))"
+}
+
 "$@"
