@@ -963,7 +963,8 @@ hipError_t launch_connect(int metric, const ConnectArgs &a, hipStream_t stream)
     // (one wave per SIMD: the 512-entry register file is the workgroup's)
 #define CALL(MM, GG)                                                                                                          \
     {                                                                                                                         \
-        if(GG != 64 || a.view.chunks <= 256) hipLaunchKernelGGL((k_connect<MM, GG, 4>), dim3(a.items), dim3(256), lds, stream, a); \
+        if(GG == 64 && a.view.chunks <= 192) hipLaunchKernelGGL((k_connect<MM, GG == 64 ? 64 : GG, GG == 64 ? 3 : 4>), dim3(a.items), dim3(256), lds, stream, a); \
+        else if(GG != 64 || a.view.chunks <= 256) hipLaunchKernelGGL((k_connect<MM, GG, 4>), dim3(a.items), dim3(256), lds, stream, a); \
         else if(a.view.chunks <= 384) hipLaunchKernelGGL((k_connect<MM, GG == 64 ? 64 : GG, GG == 64 ? 6 : 4>), dim3(a.items), dim3(256), lds, stream, a); \
         else hipLaunchKernelGGL((k_connect<MM, GG == 64 ? 64 : GG, GG == 64 ? 8 : 4>), dim3(a.items), dim3(256), lds, stream, a); \
     }
