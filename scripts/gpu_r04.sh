@@ -329,4 +329,20 @@ P
 import json; d=json.load(open('$OUT/r04_single_query_100kx128.json')); print(d['us_per_query_wall'], d['kernel_only'], d.get('cpu_port_us_per_query_1_thread'))"
 }
 
+# BASELINE configs [3] and [4] again, in the line layout with the counters measured in the run
+at_size2() {
+  timeout 900 python bench.py --dim 1536 --steps 5 --truth-queries 1000 > $OUT/r04_bench_line_1Mx1536.json 2> $OUT/bench_1536.err
+  tail -2 $OUT/bench_1536.err
+  timeout 1500 python bench.py --rows 10000000 --ef 128 --steps 5 --truth-queries 256 --build-quality-rows 0 --pmc-steps 2 > $OUT/r04_bench_line_10Mx768_ef128.json 2> $OUT/bench_10M.err
+  tail -2 $OUT/bench_10M.err
+  python - <<'P'
+import json
+for f in ('1Mx1536','10Mx768_ef128'):
+    try:
+        d=json.load(open(f'gpurun_out/r04/r04_bench_line_{f}.json')); r=d['roofline']
+        print(f, round(d['value']), d['ms_per_step'], 'recall', d['recall_at_10'], 'frac', r['frac'], 'alg', r['frac_algorithmic'], 'in-run', r['traffic_measured_in_this_run'], 'build', round(d['build_vectors_per_s']), 'cpu', d['cpu_baseline'].get('value'))
+    except Exception as e: print(f, 'failed', e)
+P
+}
+
 "$@"
