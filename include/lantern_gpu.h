@@ -427,9 +427,10 @@ LANTERN_GPU_EXPORT void lantern_gpu_add_sharded(usearch_index_t, lantern_gpu_com
  * selection; selection and reverse links then run on every rank as in a one-GPU batch (the upper levels, ~1 / M of the rows, are
  * walked in the global graph as usual).  Every rank ends with the same graph and the same rows (lantern_gpu_graph_checksum).
  * The slots follow the batches, not the ranks: labels identify rows.  The graph is NOT the one usearch_add builds edge for edge
- * (a row's candidates are the union of `world` approximate searches instead of one); it is compared with it by recall
- * (tests/test_gpu_sharded_build.py, profiles/r04_row_sharded_build.md: on par or better), where lantern_gpu_add_sharded above
- * is compared edge for edge.  Cost: every rank searches ALL rows and links ALL rows; only the shard-graph insertions fall with
+ * (a row's candidates are the union of `world` approximate searches instead of one): it equals, edge for edge, the CPU
+ * restatement of THIS collective (oracle.row_sharded_build; tests/test_gpu_sharded_build.py), and is compared with the
+ * one-GPU build by recall (profiles/r04_row_sharded_build.md: on par or better), where lantern_gpu_add_sharded above equals
+ * the one-GPU build itself.  Cost: every rank searches ALL rows and links ALL rows; only the shard-graph insertions fall with
  * the world size (measured bound: 1.3x at 4-8 ranks) -- lantern_gpu_add_sharded is the build that scales.
  * LANTERN_GPU_ROW_SHARD_K / LANTERN_GPU_ROW_SHARD_EF override the candidates per shard / the expansion they are found with. */
 LANTERN_GPU_EXPORT void lantern_gpu_add_row_sharded(usearch_index_t, lantern_gpu_comm_t *, const usearch_label_t *labels_shard,

@@ -878,7 +878,8 @@ bool add_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const voi
 // A row so chooses among the rows inserted before it (and its own batch), as in the sequential algorithm: the early rows' long links
 // and the reverse-link pruning are there.  The slots of the result follow the batches (within a batch rank 0's share first), not the
 // caller's rank order: labels identify rows.  NOT the one-GPU build's graph edge for edge -- the candidates of a row are the union of
-// W approximate searches instead of one -- so parity is a RECALL statement (tests/test_gpu_sharded_build.py).
+// W approximate searches instead of one: parity is edge for edge against the oracle's restatement of THIS procedure
+// (oracle.row_sharded_build) and a recall statement against the one-GPU build (tests/test_gpu_sharded_build.py).
 // ---------------------------------------------------------------------------------------------------------------------------
 static bool row_shard_candidates(Index *ix, const RowShard &rs, size_t first, size_t b, const uint32_t *d_link_off, uint64_t *d_tops, uint32_t *d_top_count)
 {
@@ -957,28 +958,27 @@ bool add_row_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const
     std::vector<Batch>  plan;
     std::vector<size_t> share;  // [batch][rank]: how many of the batch's rows come from that rank's shard
     {
-        std::vector<size_t> rem((size_t)W);
-        for(int r = 0; r < W; ++r) rem[ (size_t)r ] = (size_t)sizes[ (size_t)r ];
+        std::vector<size_t> taken((size_t)W, 0);
         int    max_level = 0;
         size_t pi = 0;
         while(pi < N) {
             const size_t b = plan_batch(pi, max_level, s.lv.data() + pi, std::min(N - pi, ix->add_batch_max), ix->add_batch_max, ix->add_min_ratio);
             if(pi == 0 || (b == 1 && s.lv[ pi ] > max_level)) max_level = s.lv[ pi ];
-            // the batch's rows in proportion to what the shards still hold (largest remainders first, ties to the lower rank)
-            const size_t left = N - pi, at = share.size();
-            size_t       given = 0;
-            share.resize(at + (size_t)W);
-            for(int r = 0; r < W; ++r) given += share[ at + (size_t)r ] = (size_t)((unsigned __int128)rem[ (size_t)r ] * b / left);
-            while(given < b) {
-                int best = -1;
+            // where the batch's rows come from: position p of the global order goes to the shard that is furthest behind its
+            // proportional share n_r (p + 1) / N of the rows handed out so far (ties to the lower rank) -- every prefix of the order
+            // holds every shard's rows in proportion, to within one row, whatever the batch sizes are
+            const size_t at = share.size();
+            share.resize(at + (size_t)W, 0);
+            for(size_t j = 0; j < b; ++j) {
+                int      best = 0;
+                __int128 lead = 0;
                 for(int r = 0; r < W; ++r) {
-                    const size_t spare = rem[ (size_t)r ] - share[ at + (size_t)r ];
-                    if(spare && (best < 0 || spare > rem[ (size_t)best ] - share[ at + (size_t)best ])) best = r;
+                    const __int128 behind = (__int128)sizes[ (size_t)r ] * (__int128)(pi + j + 1) - (__int128)taken[ (size_t)r ] * (__int128)N;
+                    if(r == 0 || behind > lead) { lead = behind; best = r; }
                 }
+                taken[ (size_t)best ] += 1;
                 share[ at + (size_t)best ] += 1;
-                given += 1;
             }
-            for(int r = 0; r < W; ++r) rem[ (size_t)r ] -= share[ at + (size_t)r ];
             plan.push_back({ pi, b });
             pi += b;
         }

@@ -89,6 +89,8 @@ def lib() -> C.CDLL:
     L.lo_add.argtypes = [vp, u64, vp]
     L.lo_add_with_level.argtypes = [vp, u64, vp, i32]
     L.lo_add_batch.argtypes = [vp, vp, vp, sz]
+    L.lo_add_batch_cand.restype = i32
+    L.lo_add_batch_cand.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz]
     L.lo_set_pq_view.restype = i32
     L.lo_set_pq_view.argtypes = [vp, u32, u32, vp, vp]
     L.lo_set_wave_simd.restype = None
@@ -259,6 +261,17 @@ class OracleIndex:
         rc = lib().lo_add_batch(self.h, _ptr(lab), _ptr(V), V.shape[0])
         assert rc == 0, rc
 
+    def add_batch_cand(self, labels, vecs, cand_slot, cand_d, cand_n):
+        """One batch of the row-sharded build: node i's level-0 candidates are cand_slot / cand_d [i][:cand_n[i]] (lo_add_batch_cand)."""
+        V = _rows(vecs, self.metric)
+        lab = np.ascontiguousarray(labels, dtype=np.uint64)
+        cs = np.ascontiguousarray(cand_slot, dtype=np.uint32)
+        cd = np.ascontiguousarray(cand_d, dtype=np.float32)
+        cn = np.ascontiguousarray(cand_n, dtype=np.uint32)
+        assert cs.shape == cd.shape and cs.shape[0] == V.shape[0] == cn.size
+        rc = lib().lo_add_batch_cand(self.h, _ptr(lab), _ptr(V), V.shape[0], _ptr(cs), _ptr(cd), _ptr(cn), cs.shape[1])
+        assert rc == 0, rc
+
     def add_planned(self, labels, vecs, max_batch=4096, min_ratio=16):
         """Insert with the device builder's batch plan (lo_plan_batch)."""
         V = _rows(vecs, self.metric)
@@ -328,6 +341,83 @@ class OracleIndex:
                                   _ptr(levels), _ptr(nbr0), _ptr(upper_off), _ptr(upper_nbr),
                                   int(graph["entry_slot"]), int(graph["max_level"]), 1 if borrow else 0)
         return cls(metric, dims, M, ef_construction, ef, seed, sum_mode, _handle=h, _keep=V if borrow else None)
+
+
+def row_shard_plan(sizes, levels, max_batch, min_ratio):
+    """[(first, b, [rows of the batch that come from shard r, ...]), ...]: the batches of the row-sharded build and where their
+    members come from -- the usual plan over the GLOBAL level draw, position p of the global order goes to the
+    shard that is furthest behind its proportional share of the rows handed out so far, ties to the lower rank (lantern_amd/csrc/index.cpp add_row_sharded_locked)."""
+    W, N = len(sizes), int(sum(sizes))
+    taken, out, pi, max_level = [0] * W, [], 0, 0
+    while pi < N:
+        look = min(N - pi, max_batch)
+        b = plan_batch(pi, max_level, levels[pi:pi + look], max_batch, min_ratio)
+        if pi == 0 or (b == 1 and levels[pi] > max_level):
+            max_level = int(levels[pi])
+        share = [0] * W
+        for j in range(b):
+            behind = [int(sizes[r]) * (pi + j + 1) - taken[r] * N for r in range(W)]
+            best = behind.index(max(behind))
+            taken[best] += 1
+            share[best] += 1
+        out.append((pi, b, share))
+        pi += b
+    return out
+
+
+def row_sharded_build(metric, dims, shards, M=16, ef_construction=128, ef=64, seed=42, max_batch=8192, min_ratio=16, sum_mode=SUM_SEQ,
+                      per_shard=None):
+    """CPU restatement of lantern_gpu_add_row_sharded (lantern_amd/csrc/index.cpp add_row_sharded_locked; SURVEY.md 8e as written).
+    shards = [(labels, rows), ...] in rank order.  Every shard keeps a graph over ITS rows (labels there = global slot + 1), grown
+    batch by batch with the device's plan; a batch's rows are searched in every shard's graph (k = ef = per_shard), the answers are
+    merged by (distance, slot), members of the batch itself left out, the best ef_construction of them are the level-0 candidates
+    of lo_add_batch_cand on the global graph.  Returns (the global index, labels in slot order)."""
+    W = len(shards)
+    sizes = [len(lab) for lab, _ in shards]
+    N = int(sum(sizes))
+    levels = levels_for(seed, 0, N, M)
+    K = per_shard or min(ef_construction, max(2 * M + 1, 2 * ef_construction // W))
+    glob = OracleIndex(metric, dims, M=M, ef_construction=ef_construction, ef=ef, seed=seed, sum_mode=sum_mode)
+    glob.reserve(max(N, 1))
+    locs = [OracleIndex(metric, dims, M=M, ef_construction=ef_construction, ef=ef, seed=seed, sum_mode=sum_mode) for _ in range(W)]
+    for r in range(W):
+        locs[r].reserve(max(sizes[r], 1))
+    cur = [0] * W
+    by_slot = np.zeros(N, dtype=np.uint64)
+    for first, b, share in row_shard_plan(sizes, levels, max_batch, min_ratio):
+        rows = np.zeros((b, np.asarray(shards[0][1]).shape[1]), dtype=np.asarray(shards[0][1]).dtype)
+        labs = np.zeros(b, dtype=np.uint64)
+        at = 0
+        for r in range(W):
+            n_r = share[r]
+            if n_r:
+                lab_r, rows_r = shards[r]
+                seg = slice(cur[r], cur[r] + n_r)
+                locs[r].add_planned(np.arange(first + at, first + at + n_r, dtype=np.uint64) + 1, rows_r[seg], max_batch, min_ratio)
+                rows[at:at + n_r] = rows_r[seg]
+                labs[at:at + n_r] = lab_r[seg]
+                cur[r] += n_r
+                at += n_r
+        cs = np.zeros((b, ef_construction), dtype=np.uint32)
+        cd = np.zeros((b, ef_construction), dtype=np.float32)
+        cn = np.zeros(b, dtype=np.uint32)
+        if first:
+            for i in range(b):
+                L, D = [], []
+                for r in range(W):
+                    if len(locs[r]):
+                        l, d, _ = locs[r].search(rows[i], K, K)
+                        keep = l <= first  # label = slot + 1: the slots before this batch
+                        L.append(l[keep])
+                        D.append(d[keep])
+                La, Da = np.concatenate(L), np.concatenate(D)
+                order = np.lexsort((La, Da))[:ef_construction]
+                cn[i] = order.size
+                cs[i, :order.size] = (La[order] - 1).astype(np.uint32)
+                cd[i, :order.size] = Da[order]
+        glob.add_batch_cand(labs, rows, cs, cd, cn)
+        by_slot[first:first + b] = labs
+    return glob, by_slot
 
 
 def recall_at_k(found_ids, true_ids) -> float:

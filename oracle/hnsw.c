@@ -692,6 +692,78 @@ int lo_add_batch(lo_index *ix, const uint64_t *labels, const void *vecs, size_t 
     return 0;
 }
 
+/* ---- the row-sharded build (lantern_amd/csrc/index.cpp add_row_sharded_locked; SURVEY.md 8e as written) -------------------
+ * One batch of the GLOBAL graph whose level-0 candidates were found elsewhere: in the shards' own graphs, merged by (distance,
+ * slot), the batch's own members left out (oracle/binding.py row_sharded_build does that part with ordinary lo_search calls).
+ * Everything else is lo_add_batch: levels >= 1 are walked in this graph (search_for_one_ + search_to_insert_ per level), the
+ * selection is refine_ at every level, the reverse links are applied grouped by (close, level) in new-slot order.  A batch of
+ * one may raise the top level (the planner isolates such nodes), and then becomes the entry point -- as lo_add_with_level. */
+static size_t insert_search_cand(lo_index *ix, lo_ctx *c, uint32_t new_slot, uint32_t entry, int max_level, link_t *links, const uint32_t *cand_slot,
+                                 const float *cand_d, size_t cand_n)
+{
+    const void *q = lo_vector(ix, new_slot);
+    int         target = ix->levels[ new_slot ];
+    size_t      nl = 0;
+    ctx_fit(c, ix->cap, ix->efc > cand_n ? ix->efc : cand_n);
+    uint32_t closest = target >= 1 ? search_for_one(ix, c, q, entry, max_level, target) : 0; /* a level-0 node walks nothing here */
+    for(int level = target < max_level ? target : max_level; level >= 0; --level) {
+        if(level == 0) {
+            c->top_n = cand_n;
+            for(size_t i = 0; i < cand_n; ++i) c->top[ i ] = (cand_t){ cand_d[ i ], cand_slot[ i ] };
+        } else {
+            search_level(ix, c, q, closest, level, ix->efc);
+        }
+        size_t    keep = refine(ix, c->top, c->top_n, ix->M, new_slot);
+        uint32_t  cap;
+        uint32_t *own = neighbors(ix, new_slot, level, &cap);
+        for(size_t i = 0; i < keep; ++i) {
+            own[ i ] = c->top[ i ].id;
+            links[ nl++ ] = (link_t){ c->top[ i ].id, level, new_slot, c->top[ i ].d };
+        }
+        if(keep) closest = own[ 0 ];
+    }
+    return nl;
+}
+
+int lo_add_batch_cand(lo_index *ix, const uint64_t *labels, const void *vecs, size_t n, const uint32_t *cand_slot, const float *cand_d,
+                      const uint32_t *cand_n, size_t stride)
+{
+    if(n == 0) return 0;
+    if(ix->n == 0) { /* "Do nothing for the first element" */
+        if(n != 1) return -3;
+        int level = lo_level_for(ix->seed, 0, ix->M);
+        node_make(ix, labels[ 0 ], vecs, level);
+        ix->entry = 0;
+        ix->max_level = level;
+        return 0;
+    }
+    uint32_t entry = ix->entry;
+    int      max_level = ix->max_level;
+    size_t   first = ix->n, total_links = 0, cap_links = 0;
+    if(n > 1)
+        for(size_t i = 0; i < n; ++i)
+            if(lo_level_for(ix->seed, first + i, ix->M) > max_level) return -2; /* planner contract violated */
+    int top_level = 0;
+    for(size_t i = 0; i < n; ++i) {
+        int lvl = lo_level_for(ix->seed, ix->n, ix->M);
+        node_make(ix, labels[ i ], (const uint8_t *)vecs + i * ix->vec_bytes, lvl);
+        cap_links += (size_t)ix->M * (size_t)(lvl + 1);
+        top_level = lvl;
+    }
+    link_t *links = (link_t *)malloc(sizeof(link_t) * (cap_links + 1));
+    for(size_t i = 0; i < n; ++i)
+        total_links += insert_search_cand(ix, &ix->ctx, (uint32_t)(first + i), entry, max_level, links + total_links, cand_slot + i * stride,
+                                          cand_d + i * stride, cand_n[ i ]);
+    qsort(links, total_links, sizeof(link_t), link_cmp);
+    for(size_t i = 0; i < total_links; ++i) reverse_link(ix, links[ i ].close, links[ i ].level, links[ i ].new_slot, links[ i ].d);
+    free(links);
+    if(n == 1 && top_level > max_level) {
+        ix->entry = (uint32_t)first;
+        ix->max_level = top_level;
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------------------------------- */
 
 static size_t search_with_ctx(const lo_index *ix, lo_ctx *c, const void *q, size_t k, size_t ef, size_t skip,

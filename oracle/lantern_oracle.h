@@ -106,6 +106,10 @@ int lo_add_with_level(lo_index *, uint64_t label, const void *vec, int level);
  * is the semantics of the device builder (and approximates usearch's concurrent add_raw,
  * lantern_cli/src/external_index/server.rs:333-356). */
 int lo_add_batch(lo_index *, const uint64_t *labels, const void *vecs, size_t n);
+/* the row-sharded build's batch (lantern_amd/csrc/index.cpp add_row_sharded_locked): as lo_add_batch, but node i's level-0
+ * candidates are cand_slot / cand_d [i * stride .. + cand_n[i]) instead of a walk of this graph; n == 1 may raise the top level */
+int lo_add_batch_cand(lo_index *, const uint64_t *labels, const void *vecs, size_t n, const uint32_t *cand_slot, const float *cand_d,
+                      const uint32_t *cand_n, size_t stride);
 /* threads for the two phases of lo_add_batch (walks of a batch are independent; so are its (node, level) groups of
  * reverse links): the graph does not depend on the number -- tests/test_oracle_golden.py builds with 1 and with 4 */
 void lo_set_build_threads(lo_index *, int nthreads);

@@ -373,6 +373,49 @@ def test_row_sharded_build_recall_is_the_single_gpu_builds(capi, metric, n, d, M
         assert r_rows >= r_one - 0.02, (ef, rows_, one_)
 
 
+@pytest.mark.parametrize("metric,n,d,M,efc,plan,cuts", [
+    ("l2sq", 3000, 48, 8, 40, (128, 8), (0, 1500, 3000)),
+    ("l2sq", 2600, 64, 8, 40, (256, 8), (0, 1100, 1100, 2600)),       # three ranks, one without rows
+    ("cos", 2000, 96, 12, 48, (128, 8), (0, 500, 1400, 2000)),
+    ("l2sq", 1500, 768, 16, 64, (256, 8), (0, 700, 1500)),            # 768-d: the register-resident selection, 64-lane groups
+])
+def test_row_sharded_build_is_the_oracles_restatement_edge_for_edge(capi, oracle, metric, n, d, M, efc, plan, cuts):
+    """oracle.row_sharded_build restates the collective on the CPU -- per-shard graphs with the device's batch plan, per-shard
+    lo_search for every row of a batch, merge by (distance, slot) without the batch's own members, lo_add_batch_cand on the global
+    graph -- in the device's summation order: levels, labels (slot order), entry point and every adjacency entry must agree."""
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    labels = np.arange(n, dtype=np.uint64) + LABEL0
+    world = len(cuts) - 1
+    comms = capi.Comm.local_world(world)
+    out, errs = [None] * world, []
+
+    def run(r):
+        try:
+            comms[r].set_timeout(300)
+            ix = capi.GpuIndex(metric, d, M=M, ef_construction=efc, ef=32, seed=21)
+            ix.set_add_batch(*plan)
+            ix.add_row_sharded(comms[r], labels[cuts[r]:cuts[r + 1]], base[cuts[r]:cuts[r + 1]])
+            out[r] = ix
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errs.append((r, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    shards = [(labels[cuts[r]:cuts[r + 1]], base[cuts[r]:cuts[r + 1]]) for r in range(world)]
+    ora, by_slot = oracle.row_sharded_build(metric, d, shards, M=M, ef_construction=efc, ef=32, seed=21, max_batch=plan[0], min_ratio=plan[1],
+                                            sum_mode=oracle.SUM_WAVE64)
+    go = ora.export_graph()
+    assert np.array_equal(go["labels"], by_slot)
+    for ix in out:
+        g = ix.export_graph()
+        assert np.array_equal(g["labels"], go["labels"]), "which row sits in which slot"
+        assert graphs_equal(g, go)
+    [c.free() for c in comms]
+
+
 def test_row_sharded_build_refusals(capi):
     comms = capi.Comm.local_world(1)
     ix = capi.GpuIndex("l2sq", 16, M=8, ef_construction=32, seed=3)
