@@ -436,6 +436,12 @@ LANTERN_GPU_EXPORT void lantern_gpu_add_sharded(usearch_index_t, lantern_gpu_com
 LANTERN_GPU_EXPORT void lantern_gpu_add_row_sharded(usearch_index_t, lantern_gpu_comm_t *, const usearch_label_t *labels_shard,
                                                     const void *vectors_shard, size_t n_shard, usearch_scalar_kind_t,
                                                     usearch_error_t *);
+/* the batches lantern_gpu_add_row_sharded runs for these shard sizes and where their rows come from (host arithmetic only, no
+ * device): first[t] / count[t] = the batch's slots, share[t * world + r] = how many of its rows are shard r's (rank 0's take the
+ * first slots of the batch).  Returns the number of batches; at most `capacity` are written. */
+LANTERN_GPU_EXPORT size_t lantern_gpu_row_shard_plan(const uint64_t *shard_sizes, int world, uint64_t seed, uint32_t connectivity,
+                                                     size_t max_batch, size_t min_ratio, size_t *first, size_t *count, size_t *share,
+                                                     size_t capacity);
 
 /* Row-PARTITIONED search (SURVEY.md section 8e as written: "vectors sharded by row; each GPU produces its best candidates
  * within its shard; all-gather; merge"), for indexes whose vectors do not fit one GPU's HBM: a COLLECTIVE over `comm`.  Every

@@ -98,7 +98,7 @@ EXPORTS = [
     "lantern_gpu_comm_init_local", "lantern_gpu_comm_free", "lantern_gpu_comm_rank", "lantern_gpu_comm_world",
     "lantern_gpu_comm_set_timeout", "lantern_gpu_comm_stats", "lantern_gpu_comm_allgatherv_host",
     "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded", "lantern_gpu_add_row_sharded", "lantern_gpu_search_partitioned", "lantern_gpu_search_batch_lane",
-    "lantern_gpu_level_for", "lantern_gpu_plan_batch",
+    "lantern_gpu_level_for", "lantern_gpu_plan_batch", "lantern_gpu_row_shard_plan",
     "lantern_scan_server_start", "lantern_scan_server_start_fn", "lantern_scan_server_port", "lantern_scan_server_stats",
     "lantern_scan_server_batch_histogram", "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_search_next",
     "lantern_scan_client_close", "lantern_scan_begin_client",
@@ -222,6 +222,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_search_batch_lane": (None, [vp, i32, vp, sz, i32, sz, sz, vp, vp, vp, err]),
         "lantern_gpu_level_for": (i32, [u64, u64, u32]),
         "lantern_gpu_plan_batch": (sz, [sz, i32, vp, sz, sz, sz]),
+        "lantern_gpu_row_shard_plan": (sz, [vp, i32, u64, u32, sz, sz, vp, vp, vp, sz]),
         "lantern_scan_server_start": (vp, [vp, C.c_char_p, i32, sz, C.c_uint, err]),
         "lantern_scan_server_start_fn": (vp, [BATCH_SEARCH_FN, vp, sz, C.c_char_p, i32, sz, C.c_uint, err]),
         "lantern_scan_server_port": (i32, [vp]),
@@ -773,6 +774,17 @@ def level_for(seed: int, slot: int, M: int) -> int:
 def plan_batch(size: int, max_level: int, pending_levels, max_batch: int, min_ratio: int) -> int:
     lv = np.ascontiguousarray(pending_levels, dtype=np.int32)
     return int(lib().lantern_gpu_plan_batch(size, max_level, _ptr(lv), lv.size, max_batch, min_ratio))
+
+
+def row_shard_plan(shard_sizes, seed: int, M: int, max_batch: int, min_ratio: int):
+    """[(first, count, [rows from shard r, ...]), ...]: the batches of lantern_gpu_add_row_sharded (host arithmetic, no device)."""
+    sizes = np.ascontiguousarray(shard_sizes, dtype=np.uint64)
+    world = int(sizes.size)
+    n = int(lib().lantern_gpu_row_shard_plan(_ptr(sizes), world, seed, M, max_batch, min_ratio, None, None, None, 0))
+    first, count = np.zeros(max(n, 1), dtype=np.uintp), np.zeros(max(n, 1), dtype=np.uintp)
+    share = np.zeros((max(n, 1), world), dtype=np.uintp)
+    lib().lantern_gpu_row_shard_plan(_ptr(sizes), world, seed, M, max_batch, min_ratio, _ptr(first), _ptr(count), _ptr(share), n)
+    return [(int(first[t]), int(count[t]), [int(x) for x in share[t]]) for t in range(n)]
 
 
 def shard_range(n: int, world: int, rank: int) -> tuple[int, int]:

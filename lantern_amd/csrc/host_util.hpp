@@ -1,5 +1,7 @@
 // host_util.hpp -- small host-side helpers of the device library (no HIP in here).
 #pragma once
+#include <algorithm>
+#include <vector>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -41,6 +43,38 @@ inline size_t plan_batch(size_t current_size, int max_level, const int *pending_
     for(size_t i = 0; i < b; ++i)
         if(pending_levels[ i ] > max_level) return i == 0 ? 1 : i;
     return b;
+}
+
+// The batches of the row-sharded build (index.cpp add_row_sharded_locked) and where their rows come from: the usual plan over the
+// global level draw; position p of the global order goes to the shard that is furthest behind its proportional share
+// n_r (p + 1) / N of the rows handed out so far (ties to the lower rank), so every prefix of the order holds every shard's rows
+// in proportion, to within one row, whatever the batch sizes are.  first / count: the batches; share[batch * world + r]: how
+// many of a batch's rows come from shard r (within a batch rank 0's rows take the first slots).
+inline void row_shard_plan(const uint64_t *sizes, int world, const int *levels, size_t N, size_t max_batch, size_t min_ratio, std::vector<size_t> &first,
+                           std::vector<size_t> &count, std::vector<size_t> &share)
+{
+    std::vector<size_t> taken((size_t)world, 0);
+    int    max_level = 0;
+    size_t pi = 0;
+    while(pi < N) {
+        const size_t b = plan_batch(pi, max_level, levels + pi, std::min(N - pi, max_batch), max_batch, min_ratio);
+        if(pi == 0 || (b == 1 && levels[ pi ] > max_level)) max_level = levels[ pi ];
+        const size_t at = share.size();
+        share.resize(at + (size_t)world, 0);
+        for(size_t j = 0; j < b; ++j) {
+            int      best = 0;
+            __int128 lead = 0;
+            for(int r = 0; r < world; ++r) {
+                const __int128 behind = (__int128)sizes[ r ] * (__int128)(pi + j + 1) - (__int128)taken[ (size_t)r ] * (__int128)N;
+                if(r == 0 || behind > lead) { lead = behind; best = r; }
+            }
+            taken[ (size_t)best ] += 1;
+            share[ at + (size_t)best ] += 1;
+        }
+        first.push_back(pi);
+        count.push_back(b);
+        pi += b;
+    }
 }
 
 }  // namespace lgpu

@@ -958,30 +958,9 @@ bool add_row_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const
     std::vector<Batch>  plan;
     std::vector<size_t> share;  // [batch][rank]: how many of the batch's rows come from that rank's shard
     {
-        std::vector<size_t> taken((size_t)W, 0);
-        int    max_level = 0;
-        size_t pi = 0;
-        while(pi < N) {
-            const size_t b = plan_batch(pi, max_level, s.lv.data() + pi, std::min(N - pi, ix->add_batch_max), ix->add_batch_max, ix->add_min_ratio);
-            if(pi == 0 || (b == 1 && s.lv[ pi ] > max_level)) max_level = s.lv[ pi ];
-            // where the batch's rows come from: position p of the global order goes to the shard that is furthest behind its
-            // proportional share n_r (p + 1) / N of the rows handed out so far (ties to the lower rank) -- every prefix of the order
-            // holds every shard's rows in proportion, to within one row, whatever the batch sizes are
-            const size_t at = share.size();
-            share.resize(at + (size_t)W, 0);
-            for(size_t j = 0; j < b; ++j) {
-                int      best = 0;
-                __int128 lead = 0;
-                for(int r = 0; r < W; ++r) {
-                    const __int128 behind = (__int128)sizes[ (size_t)r ] * (__int128)(pi + j + 1) - (__int128)taken[ (size_t)r ] * (__int128)N;
-                    if(r == 0 || behind > lead) { lead = behind; best = r; }
-                }
-                taken[ (size_t)best ] += 1;
-                share[ at + (size_t)best ] += 1;
-            }
-            plan.push_back({ pi, b });
-            pi += b;
-        }
+        std::vector<size_t> pf, pc;
+        row_shard_plan(sizes.data(), W, s.lv.data(), N, ix->add_batch_max, ix->add_min_ratio, pf, pc, share);  // (host_util.hpp)
+        for(size_t t = 0; t < pf.size(); ++t) plan.push_back({ pf[ t ], pc[ t ] });
     }
     // ---- labels in slot order (every rank knows where every rank's rows go), levels and upper offsets: one upload
     std::vector<uint64_t> by_rank(N), all_labels(N);
@@ -1780,6 +1759,26 @@ LANTERN_ABI_CATCH(e)
 // the host-side rules a second builder (the test oracle, a CPU fallback on the reference side) must share to
 // reproduce a device build: the stateless level draw and the batch plan (host_util.hpp)
 int lantern_gpu_level_for(uint64_t seed, uint64_t slot, uint32_t connectivity) { return level_for(seed, slot, connectivity < 2 ? 2 : connectivity); }
+
+size_t lantern_gpu_row_shard_plan(const uint64_t *shard_sizes, int world, uint64_t seed, uint32_t connectivity, size_t max_batch, size_t min_ratio,
+                                  size_t *first, size_t *count, size_t *share, size_t capacity)
+try {
+    if(!shard_sizes || world < 1) return 0;
+    size_t N = 0;
+    for(int r = 0; r < world; ++r) N += (size_t)shard_sizes[ r ];
+    std::vector<int> lv(N);
+    for(size_t i = 0; i < N; ++i) lv[ i ] = level_for(seed, i, connectivity < 2 ? 2 : connectivity);
+    std::vector<size_t> pf, pc, ps;
+    row_shard_plan(shard_sizes, world, lv.data(), N, max_batch ? max_batch : 1, min_ratio ? min_ratio : 1, pf, pc, ps);
+    for(size_t t = 0; t < pf.size() && t < capacity; ++t) {
+        if(first) first[ t ] = pf[ t ];
+        if(count) count[ t ] = pc[ t ];
+        if(share)
+            for(int r = 0; r < world; ++r) share[ t * (size_t)world + (size_t)r ] = ps[ t * (size_t)world + (size_t)r ];
+    }
+    return pf.size();
+}
+LANTERN_ABI_CATCH(nullptr)
 
 size_t lantern_gpu_plan_batch(size_t current_size, int max_level, const int *pending_levels, size_t pending, size_t max_batch,
                               size_t min_ratio)

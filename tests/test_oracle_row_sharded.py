@@ -59,3 +59,14 @@ def test_restatement_builds_a_graph_as_good_as_the_one_index_build(oracle):
         lab = ix.search_batch(queries, 10, 64)[0]
         rec.append(np.mean([len(set(lab[i].tolist()) & set((truth[i] + 1).tolist())) / 10 for i in range(len(queries))]))
     assert rec[0] >= rec[1] - 0.02, rec
+
+
+@pytest.mark.parametrize("sizes", [(1000, 1000), (900, 0, 1100), (1, 5, 2000), (7,), (3,) * 8, (0, 0, 5), (12345, 54321, 1)])
+@pytest.mark.parametrize("plan", [(128, 8), (8192, 16), (1, 1)])
+def test_the_librarys_plan_is_the_restatements(oracle, sizes, plan):
+    """lantern_gpu_row_shard_plan (host arithmetic of the collective: no device needed) against oracle.row_shard_plan."""
+    from lantern_amd import capi
+
+    mine = capi.row_shard_plan(sizes, 21, 8, *plan)
+    theirs = oracle.row_shard_plan(sizes, oracle.levels_for(21, 0, sum(sizes), 8), *plan)
+    assert mine == [(f, c, list(s)) for f, c, s in theirs]
