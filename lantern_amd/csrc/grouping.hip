@@ -272,6 +272,29 @@ hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupSc
     return hipGetLastError();
 }
 
+// A handful of new rows (ldb_aminsert's one): rows | labels | upper offsets | levels go from a page-locked, device-mapped block to
+// their places in ONE kernel that reads the host block over the bus -- instead of four queued copies (index.cpp insert_rows).
+__global__ void __launch_bounds__(256) k_stage_small(const uint4 *rows, const uint64_t *labels, const uint32_t *upper_off, const uint8_t *levels,
+                                                     uint32_t chunks, uint4 *d_rows, uint64_t *d_labels, uint32_t *d_upper_off, uint8_t *d_levels)
+{
+    const uint32_t i = blockIdx.x, tid = threadIdx.x;
+    for(uint32_t ch = tid; ch < chunks; ch += 256) d_rows[ (size_t)i * chunks + ch ] = rows[ (size_t)i * chunks + ch ];
+    if(tid == 0) {
+        d_labels[ i ] = labels[ i ];
+        d_upper_off[ i ] = upper_off[ i ];
+        d_levels[ i ] = levels[ i ];
+    }
+}
+
+hipError_t launch_stage_small(const void *rows, const uint64_t *labels, const uint32_t *upper_off, const uint8_t *levels, uint32_t count, uint32_t chunks,
+                              void *d_rows, uint64_t *d_labels, uint32_t *d_upper_off, uint8_t *d_levels, hipStream_t stream)
+{
+    if(count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stage_small, dim3(count), dim3(256), 0, stream, (const uint4 *)rows, labels, upper_off, levels, chunks, (uint4 *)d_rows, d_labels,
+                       d_upper_off, d_levels);
+    return hipGetLastError();
+}
+
 hipError_t launch_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, uint32_t *link_off, uint32_t *item_node, hipStream_t stream)
 {
     if(b == 0) return hipSuccess;

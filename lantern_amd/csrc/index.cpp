@@ -742,9 +742,11 @@ static const size_t kStageBytes = 256 * 1024;
 static bool stage_buffer(Index *ix)
 {
     if(ix->h_stage) return true;
-    if(hipHostMalloc((void **)&ix->h_stage, kStageBytes, hipHostMallocDefault) != hipSuccess) {
+    if(hipHostMalloc((void **)&ix->h_stage, kStageBytes, hipHostMallocMapped) != hipSuccess ||
+       hipHostGetDevicePointer((void **)&ix->h_stage_dev, ix->h_stage, 0) != hipSuccess) {
         (void)hipGetLastError();
-        ix->h_stage = nullptr;
+        if(ix->h_stage) (void)hipHostFree(ix->h_stage);
+        ix->h_stage = ix->h_stage_dev = nullptr;
         return false;  // (the pageable path still works)
     }
     ix->h_stage_bytes = kStageBytes;
@@ -777,18 +779,18 @@ static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_i
                                           ix->stream) == hipSuccess;
         up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
         if(tmp) (void)hipFree(tmp);
-    } else if(count * (row_words * 4 + 16) <= kStageBytes && stage_buffer(ix)) {
-        // a handful of rows: through the page-locked block, no wait before the kernels (the block is next written by the next
-        // insertion, which starts after this one's closing synchronisation in run_batches)
+    } else if(count <= 64 && count * (row_words * 4 + 16) <= kStageBytes && stage_buffer(ix)) {
+        // a handful of rows: one kernel reads them and their metadata from the page-locked, device-mapped block (the block is next
+        // written by the next insertion, which starts after this one's closing synchronisation in run_batches)
         char *hs = ix->h_stage, *h_rows = hs, *h_lab = h_rows + count * row_words * 4, *h_uo = h_lab + count * 8, *h_lv = h_uo + count * 4;
         std::memcpy(h_rows, rows, count * row_words * 4);
         std::memcpy(h_lab, labels, count * 8);
         std::memcpy(h_uo, s.uo.data(), count * 4);
         std::memcpy(h_lv, s.l8.data(), count);
-        up = hipMemcpyAsync((char *)ix->d_vec + first * row_words * 4, h_rows, count * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-        up = up && hipMemcpyAsync(ix->d_labels + first, h_lab, count * 8, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-        up = up && hipMemcpyAsync(ix->d_upper_off + first, h_uo, count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-        up = up && hipMemcpyAsync(ix->d_levels + first, h_lv, count, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        char *dv = ix->h_stage_dev;
+        up = launch_stage_small(dv, (const uint64_t *)(dv + (h_lab - hs)), (const uint32_t *)(dv + (h_uo - hs)), (const uint8_t *)(dv + (h_lv - hs)), (uint32_t)count,
+                                ix->chunks, (char *)ix->d_vec + first * row_words * 4, ix->d_labels + first, ix->d_upper_off + first, ix->d_levels + first,
+                                ix->stream) == hipSuccess;
         staged = true;
     } else {
         up = hipMemcpyAsync((char *)ix->d_vec + first * row_words * 4, rows, count * row_words * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;

@@ -151,9 +151,9 @@ struct Index
     // launch and one stream synchronisation, no copy commands
     char  *h_single = nullptr, *h_single_dev = nullptr;  // host / device address of the block
     size_t h_single_bytes = 0;
-    // page-locked staging of a SMALL insertion (ldb_aminsert's one row): rows | labels | upper offsets | levels travel from here with
-    // four queued copies and no wait in between (a pageable source costs a staged, synchronous copy each)
-    char  *h_stage = nullptr;
+    // page-locked staging of a SMALL insertion (ldb_aminsert's one row): rows | labels | upper offsets | levels are read
+    // from here by ONE kernel over the bus (k_stage_small): no copies, no wait before the batch's kernels
+    char  *h_stage = nullptr, *h_stage_dev = nullptr;  // host / device address of the block
     size_t h_stage_bytes = 0;
 
     // ---- launches that share per-index scratch are ordered across streams.  The walk kernels use per-workgroup visited

@@ -78,7 +78,8 @@ hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, h
     const int    kpl = a.lds_list ? 0 : a.efc <= 64 ? 1 : a.efc <= 128 ? 2 : 0;
 #define LGPU_LAUNCH_INSERT(...)                                                                                        \
     {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void *)k_insert<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        static LdsAttrCache attr_;        \
+        ensure_dynamic_lds((const void *)k_insert<__VA_ARGS__>, lds, attr_);    \
         hipLaunchKernelGGL((k_insert<__VA_ARGS__>), dim3(grid), dim3(64 * waves), lds, stream, a);                     \
     }
 #define CALL(MM, GG)                               \

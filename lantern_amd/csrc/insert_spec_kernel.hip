@@ -87,7 +87,8 @@ hipError_t launch_insert_spec(int metric, const InsertArgs &a, int waves, int gr
     const int    G_ = group_lanes_for(a.view.chunks);
 #define LGPU_INS1(MM, GG, KK)                                                                                                   \
     {                                                                                                                           \
-        (void)hipFuncSetAttribute((const void *)k_insert_spec<MM, GG, KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        static LdsAttrCache attr_;        \
+        ensure_dynamic_lds((const void *)k_insert_spec<MM, GG, KK>, lds, attr_);    \
         hipLaunchKernelGGL((k_insert_spec<MM, GG, KK>), dim3(grid), dim3(64 * waves), lds, stream, a);                          \
     }
 #define LGPU_INS(MM)                                                                  \

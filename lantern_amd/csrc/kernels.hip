@@ -997,7 +997,8 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
         const int    grid = (int)std::min<uint32_t>((uint32_t)(num_cus * (cpl3 ? 2 : 1)), a.max_groups);
 #define PAIRS_ONE(MM, CC)                                                                                                               \
     {                                                                                                                                   \
-        (void)hipFuncSetAttribute((const void *)k_revlink_pairs<MM, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        static LdsAttrCache attr_;        \
+        ensure_dynamic_lds((const void *)k_revlink_pairs<MM, CC>, lds, attr_);    \
         hipLaunchKernelGGL((k_revlink_pairs<MM, CC>), dim3(grid), dim3(512), lds, stream, a, (const RevWork *)work, work_count);        \
     }
 #define PAIRS(MM)                                                                                                                       \
@@ -1024,7 +1025,8 @@ hipError_t launch_revlink(int metric, const RevlinkArgs &a, void *work, uint32_t
         hipLaunchKernelGGL(k_revlink_append, dim3(append_grid), dim3(256), 0, stream, a, (RevWork *)work, work_count);
 #define CALL(MM, GG)                                                                                                    \
     {                                                                                                                   \
-        (void)hipFuncSetAttribute((const void *)k_revlink_staged<MM, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged); \
+        static LdsAttrCache attr_;        \
+        ensure_dynamic_lds((const void *)k_revlink_staged<MM, GG>, staged, attr_);    \
         hipLaunchKernelGGL((k_revlink_staged<MM, GG>), dim3(std::min<uint32_t>((uint32_t)(num_cus * staged_per_cu), a.max_groups)), dim3(512), staged, stream, a, (const RevWork *)work, work_count); \
     }
         LGPU_DISPATCH(metric, a.view.chunks, CALL);

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "device_common.hpp"
+#include <atomic>
 
 namespace lgpu {
 
@@ -122,6 +123,26 @@ hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupSc
 // link_off[i] = M * sum_{j<i} (level_j + 1), item_node[item] = i for the (level_i + 1) items of node i -- the layout of
 // one batch, from the levels already in HBM (no per-batch host upload)
 hipError_t launch_batch_layout(const uint8_t *levels, uint32_t b, uint32_t M, uint32_t *link_off, uint32_t *item_node, hipStream_t stream);
+// a few new rows and their metadata from a device-mapped host block to their places (one kernel instead of four copies)
+hipError_t launch_stage_small(const void *rows, const uint64_t *labels, const uint32_t *upper_off, const uint8_t *levels, uint32_t count, uint32_t chunks,
+                              void *d_rows, uint64_t *d_labels, uint32_t *d_upper_off, uint8_t *d_levels, hipStream_t stream);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device, size reached) instead of on every launch:
+// a driver call of microseconds that a lone query or a one-row insertion would repeat every time.  `cache` is a static of the
+// launcher's expansion for ONE instantiation: zero-initialised, [device ordinal] = the largest size set so far.
+struct LdsAttrCache { std::atomic<size_t> set[ 64 ]; };
+inline void ensure_dynamic_lds(const void *fn, size_t lds, LdsAttrCache &cache)
+{
+    int dev = 0;
+    if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return;
+    }
+    if(cache.set[ dev ].load(std::memory_order_acquire) >= lds && lds > 0) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    size_t seen = cache.set[ dev ].load(std::memory_order_relaxed);
+    while(seen < lds && !cache.set[ dev ].compare_exchange_weak(seen, lds, std::memory_order_release)) {}
+}
 
 // All launchers return hipSuccess or the launch error.  `metric` is a usearch_metric_kind_t value.
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);

@@ -196,7 +196,8 @@ hipError_t launch_search_adc(int metric, const SearchArgs &a, int waves, int gri
     const size_t lds = search_adc_lds_bytes(a.view.chunks, a.adc_qchunks, a.ef, a.view.M0, a.vis_slots) + (a.spec ? spec_lds_bytes(a.view.M0, a.spec_prefetch, a.spec_cache) : 0);
 #define LGPU_ADC1(MM, KK, SS)                                                                                                   \
     {                                                                                                                           \
-        (void)hipFuncSetAttribute((const void *)k_search_adc<MM, KK, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        static LdsAttrCache attr_;        \
+        ensure_dynamic_lds((const void *)k_search_adc<MM, KK, SS>, lds, attr_);    \
         hipLaunchKernelGGL((k_search_adc<MM, KK, SS>), dim3(grid), dim3(64 * waves), lds, stream, a);                           \
     }
 #define LGPU_ADC(MM)                                  \

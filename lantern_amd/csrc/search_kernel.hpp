@@ -177,7 +177,8 @@ k_search(SearchArgs)
 // one instantiation: opt the kernel in to its dynamic LDS size, then launch
 #define LGPU_LAUNCH_SEARCH(...)                                                                                        \
     {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void *)k_search<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        static LdsAttrCache attr_;        \
+        ensure_dynamic_lds((const void *)k_search<__VA_ARGS__>, lds, attr_);    \
         hipLaunchKernelGGL((k_search<__VA_ARGS__>), dim3(grid), dim3(64 * waves), lds, stream, a);                     \
     }
 
