@@ -14,7 +14,10 @@ namespace lgpu {
 // ef_construction-wide search_level whose sorted result (<= efc keys) goes to HBM for k_connect.  The start of
 // the next lower level is connect_new_node_'s first pick: the closest result under (distance, tie_mix).
 template <int METRIC, int G, int KPL = 2>  // KPL: as k_search (keys per lane of wave 0's register list; 0 = LDS list)
-__global__ void __launch_bounds__(512, 6) k_insert(InsertArgs a)
+#ifndef LGPU_INSERT_MIN_BLOCKS
+#define LGPU_INSERT_MIN_BLOCKS 6  // (measured: 5 and 4 -- 81 / 90 registers, no spills -- build at the same speed)
+#endif
+__global__ void __launch_bounds__(512, LGPU_INSERT_MIN_BLOCKS) k_insert(InsertArgs a)
 {
     const int tid = threadIdx.x, T = blockDim.x;
     WalkLds   s;
