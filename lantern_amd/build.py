@@ -19,7 +19,8 @@ OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "liblantern_gpu.so")
 
 SOURCES = ["search_kernel.hip", "search_spec_kernel.hip", "search_adc_kernel.hip", "insert_kernel.hip", "insert_spec_kernel.hip", "kernels.hip", "bruteforce.hip", "grouping.hip", "index.cpp", "comm.cpp", "usearch_file.cpp", "scan_shim.cpp", "index_server.cpp", "scan_server.cpp", "mirror_cache.cpp", "node_tape.cpp"]
-HEADERS = ["device_common.hpp", "walk.hpp", "walk_spec.hpp", "search_kernel.hpp", "dispatch.hpp", "kernels.hpp", "index.hpp", "comm.hpp", "host_util.hpp", "../../include/lantern_gpu.h"]
+# every header under csrc/ is a dependency of every object (globbed, so a new header cannot be forgotten)
+HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith(".hpp")) + ["../../include/lantern_gpu.h"]
 # -ffp-contract=off: every fma in the kernels is explicit, so the reduction tree is exactly the
 # one the oracle models.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",

@@ -174,8 +174,13 @@ def recall_of(capi, hip, oracle, metric, base, graph, queries, truth):
     return oracle.recall_at_k(slot, truth)
 
 
-@pytest.mark.parametrize("name", ["c2_gaussian_100k_x_128", "clustered_100k_x_768"])
-def test_build_quality_matches_the_sequential_reference_build(env, oracle, name):
+_SEQ_GRAPHS = {}  # the sequential reference build of a set is the same for every device plan it is compared with
+
+
+@pytest.mark.parametrize("name,plan", [("c2_gaussian_100k_x_128", (8192, 16)), ("clustered_100k_x_768", (8192, 16)),
+                                       # the larger plan (batches of up to 16 384 rows, full from 65k rows on): the same bar
+                                       ("c2_gaussian_100k_x_128", (16384, 4)), ("clustered_100k_x_768", (16384, 4))])
+def test_build_quality_matches_the_sequential_reference_build(env, oracle, name, plan):
     capi, hip = env
     from lantern_amd import synth
 
@@ -187,16 +192,18 @@ def test_build_quality_matches_the_sequential_reference_build(env, oracle, name)
         base = make(np.random.default_rng(synth.BASE_SEED), 100_000)  # (a sequential CPU build of 768-d rows runs at ~1.7 k vectors/s)
         queries = make(np.random.default_rng(4), 4000)
     t0 = time.time()
-    dev = build(capi, "l2sq", base)  # the default plan: batches of up to 8192, never more than size / 16
+    dev = build(capi, "l2sq", base, plan=plan)  # the default plan: batches of up to 8192, never more than size / 16
     t_dev = time.time() - t0
     truth, _ = dev.exact_search(queries, K)
     r_dev = oracle.recall_at_k(device_batch(hip, dev, queries, K, 64)[2], truth)
     t0 = time.time()
-    seq_graph = sequential_cpu_build(oracle, "l2sq", base)
+    if name not in _SEQ_GRAPHS:
+        _SEQ_GRAPHS[name] = sequential_cpu_build(oracle, "l2sq", base)
+    seq_graph = _SEQ_GRAPHS[name]
     t_seq = time.time() - t0
     r_seq = recall_of(capi, hip, oracle, "l2sq", base, seq_graph, queries, truth)
     # the same sequential build on the device (batch plan (1, 1)) on a prefix: it IS usearch_add, edge for edge
-    print(f"{name}: recall@10 device-batched {r_dev:.4f} (built in {t_dev:.1f} s), sequential reference build {r_seq:.4f} ({t_seq:.1f} s)")
+    print(f"{name} plan {plan}: recall@10 device-batched {r_dev:.4f} (built in {t_dev:.1f} s), sequential reference build {r_seq:.4f} ({t_seq:.1f} s)")
     if name.startswith("clustered"):
         # the regime the reference asserts recall in (scripts/integration_tests.py:249-264: floor 0.7, warn 0.9).  Here the
         # batch-synchronous build comes out BETTER than the sequential one by about a point (0.933 vs 0.922 at 200k rows on
