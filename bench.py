@@ -84,6 +84,8 @@ def parse():
                    "configuration): by default, when rocprofv3 is on PATH, the search leg is re-executed under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
                    "(two short passes restricted to k_search) after the timed region and roofline.traffic is THIS run's")
     p.add_argument("--pmc-steps", type=int, default=4, help="search launches per counter pass")
+    p.add_argument("--no-secondary", action="store_true", help="skip the `secondary` array (bench_secondary.py: BASELINE configs [1] and [2], the clustered set, the "
+                   "host-buffer and scan-service paths at the headline shape)")
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the re-executed search leg: build, launch, print the graph checksum, exit
     return p.parse_args()
 
@@ -434,6 +436,12 @@ def main():
             "collective_build": collective,
             "setup_seconds": {"datagen": t_gen, "build": t_build, "exact_truth": t_truth},
         }
+        if world == 1 and not a.no_secondary and a.quant == "f32" and not a.pq_subvectors and a.metric != "hamming":
+            import bench_secondary
+
+            t0 = time.time()
+            out["secondary"] = bench_secondary.run(a, capi, hip, ix, base, all_queries, qps, recall, None if a.no_pmc else measure_traffic)
+            out["setup_seconds"]["secondary"] = time.time() - t0
     finish(out)
 
 
@@ -544,6 +552,11 @@ def roofline(achieved_alg, traffic, dram, traffic_src, launch_s, bytes_per_launc
     r = {"bound": "hbm",
          "achieved": phys if phys is not None else achieved_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": (phys if phys is not None else achieved_alg) / HBM_PEAK_GBS,
+         # the same rate over what the part can actually deliver: a pure DRAM stream (6.29 TB/s measured) and uniformly random
+         # 3 KiB rows in the walk's own launch shape (6.73 TB/s algorithmic, profiles/r03_gather_ceiling.md).  Values ABOVE 1 say the
+         # bytes cannot all have come from DRAM: the fabric-side counters include what the 256 MiB Infinity Cache served.
+         "frac_of_streaming": (phys if phys is not None else achieved_alg) / HBM_MEASURED_CEILING_GBS,
+         "frac_of_gather_ceiling": (phys if phys is not None else achieved_alg) / GATHER_CEILING_GBS,
          "frac_basis": ("fabric-side counter bytes per launch (roofline.traffic) / HIP-event launch time" if phys is not None else
                         "ALGORITHMIC bytes (no counter pass available for this configuration: rocprofv3 absent and no committed pass) / launch time"),
          "traffic": traffic, "traffic_measured_in_this_run": bool(measured_here), "traffic_source": traffic_src,

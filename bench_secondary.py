@@ -1,0 +1,333 @@
+"""bench_secondary.py -- the `secondary` array of bench.py's ONE JSON line (rank 0, one GPU).
+
+The headline times device-resident 8192-query batches on the prescribed i.i.d. Gaussian set.  These entries put the other
+ways the same hot path is called under the same (driver's) clock:
+
+  c2_one_query_per_call     BASELINE config[1]: 100k x 128 f32 L2sq, M=16 ef=64 k=10, ONE usearch_search_ef per call -- the
+                            reference's actual calling pattern (lantern_hnsw/src/hnsw/scan.c:220-228); wall and kernel time
+  c3_cosine_1024_batches    BASELINE config[2]: 1M x 768 f32 cosine, 1024-query batches, one and two launches in flight
+  clustered_1Mx768_l2sq     the headline shape on the clustered set (lantern_amd/synth.py): the recall >= 0.9 regime the
+                            reference asserts recall in (scripts/integration_tests.py:249-264)
+  headline_host_buffers     the headline index through lantern_gpu_search_batch / _lane: queries and answers in HOST memory
+                            (PCIe both ways inside the timed region) -- what a caller of the C ABI gets
+  headline_scan_service     the headline index behind the scan-side service at 256 connections (one query per request, the
+                            way PostgreSQL backends scan: scan.c:167-338), driven by lantern-scan-load
+
+Every entry: `workload`, `value` + `unit`, `ms_per_step`, `recall_at_10`, `roofline` (algorithmic bytes of SURVEY 8d with D / E
+counted on the device; counter bytes where exactly one launch is in flight and the pass is affordable), `cpu_baseline` (the CPU
+port on ONE thread on the same graph -- a PostgreSQL backend, utils.c:66).  The oracle is used as the baseline only.
+"""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0
+STREAMING_GBS = 6290.0  # MI355X_MICROARCH.md: measured float4 copy
+GATHER_GBS = 6730.0     # profiles/r03_gather_ceiling.md: uniformly random 3 KiB rows in the walk's launch shape
+
+
+def fractions(achieved_gbs: float) -> dict:
+    return {"frac": achieved_gbs / HBM_PEAK_GBS, "frac_of_streaming": achieved_gbs / STREAMING_GBS, "frac_of_gather_ceiling": achieved_gbs / GATHER_GBS}
+
+
+def _recall(found, truth, k):
+    return float(np.mean([len(set(f.tolist()) & set(t.tolist())) / k for f, t in zip(found, truth)]))
+
+
+def _build(capi, hip, metric, base, a):
+    ix = capi.GpuIndex(metric, base.shape[1], M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
+    ix.reserve(base.shape[0])
+    ix.set_add_batch(a.add_batch, 16)
+    hip.synchronize()
+    t0 = time.perf_counter()
+    ix.add_many(np.arange(base.shape[0], dtype=np.uint64) + 1, base)
+    ix.flush()
+    hip.synchronize()
+    return ix, time.perf_counter() - t0
+
+
+def _cpu_one_thread(ix, base, queries, metric, a, seconds=4.0):
+    """The CPU port on ONE thread on the identical graph: queries/s and microseconds per query on a bounded sample."""
+    from oracle import binding as oracle
+
+    native = oracle.build_native() and oracle.use_native(True)
+    ora = oracle.OracleIndex.from_graph(metric, base, ix.export_graph(), a.M, a.efc, a.ef, 42, oracle.SUM_FAST)
+    probe = min(32, queries.shape[0])
+    ora.search_batch(queries[:probe], a.k, a.ef, 1)
+    t0 = time.perf_counter()
+    ora.search_batch(queries[:probe], a.k, a.ef, 1)
+    per_q = (time.perf_counter() - t0) / probe
+    n = int(max(probe, min(queries.shape[0], seconds / max(per_q, 1e-9))))
+    t0 = time.perf_counter()
+    _, _, slots, _, _ = ora.search_batch(queries[:n], a.k, a.ef, 1)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "queries/s", "us_per_query": dt / n * 1e6, "cores": 1, "kind": "port",
+            "sample": f"{n} queries of this workload on 1 thread (a PostgreSQL backend, utils.c:66), same graph",
+            "build": "gcc -O3 -march=native + the reference's -fassociative-math flags" if native else "gcc -O3 -march=x86-64-v3 + the reference's flags"}, slots
+
+
+class _Batches:
+    """B resident query batches with their outputs; step(i) searches batch i mod B on stream i mod S."""
+
+    def __init__(self, hip, ix, queries, nq, a, streams=1):
+        self.hip, self.ix, self.nq, self.a = hip, ix, nq, a
+        self.B = max(1, queries.shape[0] // nq)
+        self.S = streams
+        self.streams = [hip.Stream() for _ in range(streams)]
+        self.lanes = []
+        for i in range(self.B):
+            qi = queries[i * nq:(i + 1) * nq]
+            self.lanes.append({"dq": hip.Buffer.from_numpy(hip.padded_rows(qi, False)), "lab": hip.Buffer(nq * a.k * 8), "dist": hip.Buffer(nq * a.k * 4),
+                               "slot": hip.Buffer(nq * a.k * 4), "D": hip.Buffer(nq * 8), "E": hip.Buffer(nq * 8)})
+
+    def step(self, i):
+        L, a = self.lanes[i % self.B], self.a
+        self.ix.search_batch_device(L["dq"].ptr, self.nq, a.k, a.ef, 0, L["lab"].ptr, L["dist"].ptr, L["slot"].ptr, None, L["D"].ptr, L["E"].ptr,
+                                    self.streams[i % self.S].handle)
+
+    def timed(self, steps, warmup=None):
+        hip = self.hip
+        for i in range(self.B if warmup is None else warmup):
+            self.step(i)
+        hip.synchronize()
+        ev = [(hip.Event(), hip.Event()) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i, (s, e) in enumerate(ev):
+            st = self.streams[i % self.S].handle
+            s.record(st)
+            self.step(i)
+            e.record(st)
+        hip.synchronize()
+        elapsed = time.perf_counter() - t0
+        return elapsed, [s.elapsed_ms(e) for s, e in ev]
+
+    def algorithmic_bytes(self, row_bytes, list_bytes, steps):
+        per = []
+        for L in self.lanes:
+            D = L["D"].download(self.nq, np.uint64).astype(np.float64)
+            E = L["E"].download(self.nq, np.uint64).astype(np.float64)
+            per.append((float((D * row_bytes + E * list_bytes + row_bytes).sum()), float(D.mean()), float(E.mean())))
+        return float(np.mean([per[i % self.B][0] for i in range(steps)])), per[0][1], per[0][2]
+
+
+def c2_one_query_per_call(a, capi, hip):
+    n, d, nq = 100_000, 128, 2000
+    base = np.random.default_rng(1).standard_normal((n, d), dtype=np.float32)  # seeds 1 / 2
+    queries = np.random.default_rng(2).standard_normal((nq, d), dtype=np.float32)
+    ix, t_build = _build(capi, hip, "l2sq", base, a)
+    for q in queries[:50]:
+        ix.search(q, a.k, a.ef)
+    lat, found = [], []
+    t_all = time.perf_counter()
+    for q in queries:
+        t0 = time.perf_counter()
+        lab, _ = ix.search(q, a.k, a.ef)
+        lat.append(time.perf_counter() - t0)
+        found.append(lab.astype(np.int64) - 1)
+    t_all = time.perf_counter() - t_all
+    lat = np.array(lat) * 1e6
+    # the kernel alone: one query per launch, HIP events on the launch stream
+    st = hip.Stream()
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False))
+    d_lab, d_dst, d_D, d_E = hip.Buffer(a.k * 8), hip.Buffer(a.k * 4), hip.Buffer(8), hip.Buffer(8)
+    row_bytes = hip.padded_rows(queries[:1], False).shape[1] * 4
+    kern, Ds, Es = [], [], []
+    for i in range(500):
+        s, e = hip.Event(), hip.Event()
+        s.record(st.handle)
+        ix.search_batch_device(dq.ptr + i * row_bytes, 1, a.k, a.ef, 0, d_lab.ptr, d_dst.ptr, None, None, d_D.ptr, d_E.ptr, st.handle)
+        e.record(st.handle)
+        st.synchronize()
+        kern.append(s.elapsed_ms(e) * 1e3)
+        Ds.append(int(d_D.download(1, np.uint64)[0]))
+        Es.append(int(d_E.download(1, np.uint64)[0]))
+    truth, _ = ix.exact_search(queries[:512], a.k)
+    cpu, _ = _cpu_one_thread(ix, base, queries, "l2sq", a, seconds=1.0)
+    bytes_q = float(np.mean(Ds)) * d * 4 + float(np.mean(Es)) * (2 * a.M * 4) + d * 4
+    gbs = bytes_q / (float(np.mean(kern)) * 1e-6) / 1e9
+    return {"name": "c2_one_query_per_call",
+            "workload": f"BASELINE config[1]: HNSW search {n}x{d} f32 l2sq M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}, {nq} x ONE usearch_search_ef per call (scan.c:220-228)",
+            "value": nq / t_all, "unit": "queries/s", "ms_per_step": float(lat.mean()) / 1e3, "step": "one usearch_search_ef call (host query in, host answer out)",
+            "us_per_call_wall": {"mean": float(lat.mean()), "p50": float(np.median(lat)), "p99": float(np.percentile(lat, 99))},
+            "us_per_call_kernel": {"mean": float(np.mean(kern)), "p50": float(np.median(kern))},
+            "hops_per_query": float(np.mean(Es)), "dist_evals_per_query": float(np.mean(Ds)), "us_per_hop_kernel": float(np.mean(kern) / max(np.mean(Es), 1)),
+            "recall_at_10": _recall(np.array(found[:512]), truth, a.k),
+            "roofline": dict({"bound": "latency (one dependent hop chain; HBM fraction shown for scale)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "algorithmic_bytes_per_launch": bytes_q, "avg_launch_ms": float(np.mean(kern)) / 1e3, "kernel": "k_search_spec (walk_spec.hpp), one query",
+                              "traffic": None}, **fractions(gbs)),
+            "cpu_baseline": cpu, "gpu_over_cpu_1_thread": (nq / t_all) / cpu["value"], "build_vectors_per_s": n / t_build}
+
+
+def c3_cosine_1024_batches(a, capi, hip, base):
+    n, d, nq, B = base.shape[0], base.shape[1], 1024, 8
+    ix, t_build = _build(capi, hip, "cos", base, a)
+    queries = np.random.default_rng(4).standard_normal((nq * B, d), dtype=np.float32)  # base seed 3, queries seed 4
+    out = {"name": "c3_cosine_1024_batches",
+           "workload": f"BASELINE config[2]: HNSW search {n}x{d} f32 cos M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}, {nq}-query batches resident in HBM"}
+    row, lst = d * 4, 2 * a.M * 4
+    one = _Batches(hip, ix, queries, nq, a, streams=1)
+    steps = 24
+    elapsed, kms = one.timed(steps)
+    bytes_l, Dm, Em = one.algorithmic_bytes(row, lst, steps)
+    gbs1 = bytes_l / (float(np.mean(kms)) * 1e-3) / 1e9
+    truth, _ = ix.exact_search(queries[:nq], a.k)
+    found = one.lanes[0]["slot"].download((nq, a.k), np.uint32)
+    two = _Batches(hip, ix, queries, nq, a, streams=2)
+    elapsed2, _ = two.timed(steps)
+    gbs2 = bytes_l * steps / elapsed2 / 1e9
+    cpu, _ = _cpu_one_thread(ix, base, queries[:nq], "cos", a, seconds=3.0)
+    out.update({"value": nq * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "step": "one 1024-query launch, one launch in flight",
+                "two_launches_in_flight": {"value": nq * steps / elapsed2, "ms_per_step": elapsed2 / steps * 1e3,
+                                           "roofline": dict({"achieved": gbs2, "unit": "GB/s", "basis": "all launches' algorithmic bytes / the timed region"}, **fractions(gbs2))},
+                "recall_at_10": _recall(found, truth, a.k), "recall_note": "i.i.d. N(0,1) x 768 under cosine has no neighbourhood structure: the prescribed set, identical on CPU and GPU",
+                "dist_evals_per_query": Dm, "expansions_per_query": Em,
+                "roofline": dict({"bound": "hbm", "achieved": gbs1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": bytes_l,
+                                  "avg_launch_ms": float(np.mean(kms)), "kernel": "k_search", "traffic": None,
+                                  "basis": "ALGORITHMIC bytes (SURVEY 8d; D / E counted on the device) / HIP-event launch time; the counter passes of this shape: profiles/r04_bench_line_cos_q1024.json"},
+                                 **fractions(gbs1)),
+                "cpu_baseline": cpu, "gpu_over_cpu_1_thread": (nq * steps / elapsed) / cpu["value"], "build_vectors_per_s": n / t_build})
+    return out
+
+
+def clustered_headline_shape(a, capi, hip, measure_traffic):
+    from lantern_amd import synth
+
+    n, d, nq, B = a.n, a.dim, a.queries, 4
+    make = synth.query_maker("clustered", d)
+    base = make(np.random.default_rng(synth.BASE_SEED), n)
+    ix, t_build = _build(capi, hip, a.metric, base, a)
+    queries = make(np.random.default_rng(4), nq * B)
+    run = _Batches(hip, ix, queries, nq, a, streams=1)
+    steps = 12
+    elapsed, kms = run.timed(steps)
+    row, lst = d * 4, 2 * a.M * 4
+    bytes_l, Dm, Em = run.algorithmic_bytes(row, lst, steps)
+    launch_s = float(np.mean(kms)) * 1e-3
+    gbs = bytes_l / launch_s / 1e9
+    tq = min(1024, nq)
+    truth, _ = ix.exact_search(queries[:tq], a.k)
+    found = run.lanes[0]["slot"].download((nq, a.k), np.uint32)[:tq]
+    cpu, _ = _cpu_one_thread(ix, base, queries[:nq], a.metric, a, seconds=3.0)
+    traffic = src = None
+    if measure_traffic is not None:
+        import copy
+
+        b = copy.copy(a)
+        b.data, b.query_batches = "clustered", B
+        det = measure_traffic(b, f"{ix.checksum():016x}")
+        if det and det.get("hbm_bytes_per_launch"):
+            traffic, src = det["hbm_bytes_per_launch"], det["source"]
+    roof = dict({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": bytes_l, "avg_launch_ms": launch_s * 1e3,
+                 "kernel": "k_search", "traffic": traffic, "traffic_source": src,
+                 "basis": "ALGORITHMIC bytes (SURVEY 8d; D / E counted on the device) / HIP-event launch time"}, **fractions(gbs))
+    if traffic:
+        roof.update({"achieved_counter": traffic / launch_s / 1e9, "frac_counter": traffic / launch_s / 1e9 / HBM_PEAK_GBS, "traffic_over_algorithmic": traffic / bytes_l})
+    return {"name": "clustered_1Mx768_l2sq",
+            "workload": f"HNSW search {n}x{d} f32 {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}, {nq}-query batches resident in HBM, CLUSTERED set ({synth.CLUSTERED_DOC})",
+            "value": nq * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "step": f"one {nq}-query launch",
+            "recall_at_10": _recall(found, truth, a.k), "recall_queries": tq, "dist_evals_per_query": Dm, "expansions_per_query": Em,
+            "roofline": roof, "cpu_baseline": cpu, "gpu_over_cpu_1_thread": (nq * steps / elapsed) / cpu["value"], "build_vectors_per_s": n / t_build}
+
+
+def headline_host_buffers(a, ix, queries, device_resident_qps, headline_recall):
+    """lantern_gpu_search_batch (one call at a time) and lantern_gpu_search_batch_lane on 2 / 4 lanes (one thread per lane, every
+    thread handing over its own host batches back to back: the copy-in and padding of one batch run over the search of another)."""
+    nq, k = a.queries, a.k
+    B = max(1, queries.shape[0] // nq)
+    batches = [np.ascontiguousarray(queries[i * nq:(i + 1) * nq]) for i in range(B)]
+    ix.search_batch(batches[0], k, a.ef)
+    steps = 8
+    t0 = time.perf_counter()
+    for i in range(steps):
+        lab, _, _ = ix.search_batch(batches[i % B], k, a.ef)
+    one = time.perf_counter() - t0
+    res = {"one_call_at_a_time": {"value": nq * steps / one, "ms_per_step": one / steps * 1e3, "over_device_resident": nq * steps / one / device_resident_qps}}
+    for lanes in (2, 4):
+        per = 6
+        for ln in range(lanes):
+            ix.search_batch_lane(ln, batches[ln % B], k, a.ef)
+        go = threading.Barrier(lanes + 1)
+
+        def worker(ln):
+            go.wait()
+            for i in range(per):
+                ix.search_batch_lane(ln, batches[(ln + i) % B], k, a.ef)
+
+        ts = [threading.Thread(target=worker, args=(ln,)) for ln in range(lanes)]
+        [t.start() for t in ts]
+        go.wait()
+        t0 = time.perf_counter()
+        [t.join() for t in ts]
+        dt = time.perf_counter() - t0
+        res[f"{lanes}_lanes"] = {"value": nq * per * lanes / dt, "ms_per_step": dt / (per * lanes) * 1e3, "over_device_resident": nq * per * lanes / dt / device_resident_qps}
+    best = max(res.values(), key=lambda r: r["value"])
+    bytes_each_way = {"queries_in": nq * a.dim * 4, "answers_out": nq * k * 12 + nq * 4}
+    return {"name": "headline_host_buffers",
+            "workload": f"the headline index ({a.n}x{a.dim} f32 {a.metric}) through lantern_gpu_search_batch[_lane]: {nq}-query batches in HOST memory, answers to HOST memory (PCIe inside the timed region)",
+            "value": best["value"], "unit": "queries/s", "ms_per_step": best["ms_per_step"], "step": f"one {nq}-query host batch (pad + H2D + k_search + D2H + copy-out)",
+            "modes": res, "device_resident_value": device_resident_qps, "over_device_resident": best["over_device_resident"],
+            "pcie_bytes_per_step": bytes_each_way, "recall_at_10": headline_recall, "recall_note": "the headline's queries and graph: the same answers as the device-resident batch",
+            "roofline": None, "cpu_baseline": None}
+
+
+def headline_scan_service(a, capi, ix, device_resident_qps, connections=256, seconds=3.0):
+    tool = os.path.join(ROOT, "lantern_amd", "lib", "lantern-scan-load")
+    if not os.path.exists(tool):
+        return {"name": "headline_scan_service", "error": "lantern-scan-load not built"}
+    srv = capi.ScanServer(index=ix, max_batch=1024, max_wait_us=200)
+    try:
+        runs = {}
+        for mode, extra in (("thread_per_connection", []), ("multiplexed_8_client_threads", ["--client-threads", "8"])):
+            cmd = [tool, "--port", str(srv.port), "--dim", str(a.dim), "--k", str(a.k), "--connections", str(connections), "--seconds", str(seconds),
+                   "--warmup-seconds", "1", "--rows", str(a.n), "--m", str(a.M), "--ef-construction", str(a.efc), "--ef", str(a.ef)] + extra
+            before = srv.stats()
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+            after = srv.stats()
+            line = next((json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")), None)
+            if not line:
+                runs[mode] = {"error": (p.stderr or p.stdout)[-300:]}
+                continue
+            req, bat = after["requests"] - before["requests"], after["batches"] - before["batches"]
+            runs[mode] = {"value": line["queries_per_s"], "latency_us": line["latency_us"], "failures": line["failures"], "connected": line["connected"],
+                          "mean_batch": req / max(bat, 1), "largest_batch": after["largest_batch"]}
+    finally:
+        srv.stop()
+    good = [r for r in runs.values() if "value" in r]
+    if not good:
+        return {"name": "headline_scan_service", "error": runs}
+    best = max(good, key=lambda r: r["value"])
+    return {"name": "headline_scan_service",
+            "workload": f"the headline index ({a.n}x{a.dim} f32 {a.metric}) behind the scan-side service: {connections} connections, one k={a.k} query per request (scan.c:167-338), lantern-scan-load over loopback TCP",
+            "value": best["value"], "unit": "queries/s", "ms_per_step": best["latency_us"]["p50"] / 1e3, "step": "one request on one connection (p50 round trip)",
+            "modes": runs, "device_resident_value": device_resident_qps, "over_device_resident": best["value"] / device_resident_qps,
+            "recall_at_10": None, "recall_note": "answers == the direct batch (tests/test_scan_server.py); queries here are the load generator's own",
+            "roofline": None, "cpu_baseline": None}
+
+
+def run(a, capi, hip, ix, base, queries, device_resident_qps, headline_recall, measure_traffic):
+    """The four (five) entries, each isolated: a failure costs its entry, never the line."""
+    out = []
+
+    def leg(fn, *args, **kw):
+        t0 = time.time()
+        try:
+            e = fn(*args, **kw)
+        except Exception as ex:  # noqa: BLE001
+            e = {"name": fn.__name__, "error": repr(ex)[:400]}
+        e["seconds"] = time.time() - t0
+        out.append(e)
+
+    leg(headline_host_buffers, a, ix, queries, device_resident_qps, headline_recall)
+    leg(headline_scan_service, a, capi, ix, device_resident_qps)
+    leg(c2_one_query_per_call, a, capi, hip)
+    if a.metric == "l2sq" and a.data == "gaussian":
+        leg(c3_cosine_1024_batches, a, capi, hip, base)
+        leg(clustered_headline_shape, a, capi, hip, measure_traffic)
+    return out

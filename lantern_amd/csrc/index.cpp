@@ -801,10 +801,15 @@ static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_i
         up = up && hipMemcpyAsync(ix->d_upper_off + first, s.uo.data(), count * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
         up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
     }
-    if(!up) { set_err(ix, "lantern_gpu: HIP failure uploading vectors"); return fail(); }
-    if(!pq_encode_rows(ix, first, count)) return fail();  // pq = true: the rows become their decodings, the codes go beside them
-    if(!fill_norms(ix, first, count)) return fail();
-    return run_batches(ix, labels, s, count, nullptr, ok_out);
+    // a failure below must not leave k_stage_small queued: it reads the device-mapped block the NEXT insertion overwrites, and
+    // would land the failed rows in slots the host considers free
+    auto fail_staged = [&]() { if(staged) (void)hipStreamSynchronize(ix->stream); return fail(); };
+    if(!up) { set_err(ix, "lantern_gpu: HIP failure uploading vectors"); return fail_staged(); }
+    if(!pq_encode_rows(ix, first, count)) return fail_staged();  // pq = true: the rows become their decodings, the codes go beside them
+    if(!fill_norms(ix, first, count)) return fail_staged();
+    const size_t done = run_batches(ix, labels, s, count, nullptr, ok_out);
+    if(!*ok_out && staged) (void)hipStreamSynchronize(ix->stream);
+    return done;
 }
 
 // lantern_gpu_add_sharded: a COLLECTIVE insert.  Every rank contributes the rows [shard_off, shard_off + n_shard)
@@ -1230,8 +1235,12 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.vis_slots = vis_slots;
     a.totals = ix->d_totals;
     a.ticket = next_ticket(ix, nq, grid, stream);
-    a.phase_cycles = spec ? (ix->spec_profile ? ix->d_totals + 16 : nullptr) : ix->phase_profile ? ix->d_totals + 8 : nullptr;
-    a.touched = (!spec && ix->phase_profile) ? ix->d_touched : nullptr;
+    // (there is no instrumented instantiation of the decoding walk: a compact pq launch ignores phase_profile)
+    const bool prof_walk = ix->phase_profile && !pqd;
+    a.phase_cycles = spec ? (ix->spec_profile ? ix->d_totals + 16 : nullptr) : prof_walk ? ix->d_totals + 8 : nullptr;
+    // the row bitmap only when unique-rows mode asked for it AND it covers every slot the walk can name (a reserve / add since
+    // it was sized would otherwise let mark_touched write past it)
+    a.touched = (!spec && prof_walk && ix->unique_rows_on && ix->d_touched && ix->touched_words * 32 >= ix->cap) ? ix->d_touched : nullptr;
     a.done = done;
     a.lds_list = lds_list_env();
     // small batch (at most four 4-wave workgroups per CU would be resident anyway): four rows in flight per group
@@ -2367,6 +2376,7 @@ try {
         (void)hipMemset(ix->d_totals + 8, 0, 8 * sizeof(unsigned long long));
     }
     ix->phase_profile = on != 0;
+    ix->unique_rows_on = false;  // the row bitmap belongs to lantern_gpu_search_unique_rows alone
 }
 LANTERN_ABI_CATCH_VOID(e)
 
@@ -2388,8 +2398,9 @@ try {
     if(rows) {
         *rows = 0;
         if(ix->d_touched) {
-            std::vector<uint32_t> bits(words);
-            if(hipMemcpy(bits.data(), ix->d_touched, words * 4, hipMemcpyDeviceToHost) != hipSuccess) { FAIL(e, "lantern_gpu: HIP failure reading the row bitmap"); return; }
+            const size_t have = std::min(words, ix->touched_words);  // the index may have grown since the bitmap was sized
+            std::vector<uint32_t> bits(have);
+            if(have && hipMemcpy(bits.data(), ix->d_touched, have * 4, hipMemcpyDeviceToHost) != hipSuccess) { FAIL(e, "lantern_gpu: HIP failure reading the row bitmap"); return; }
             uint64_t n = 0;
             for(uint32_t w : bits) n += (uint64_t)__builtin_popcount(w);
             *rows = n;
@@ -2409,6 +2420,7 @@ try {
         if(hipMemset(ix->d_touched, 0, ix->touched_words * 4) != hipSuccess) { FAIL(e, "lantern_gpu: HIP failure clearing the row bitmap"); return; }
     }
     ix->phase_profile = on != 0;
+    ix->unique_rows_on = on != 0;
 }
 LANTERN_ABI_CATCH_VOID(e)
 

@@ -112,6 +112,7 @@ struct Index
     bool                    spec_profile = false;   // diagnostics: the instrumented latency-bound walk (lantern_gpu_spec_profile)
     uint32_t               *d_touched = nullptr;    // diagnostics: one bit per row evaluated by the instrumented searches (lantern_gpu_search_unique_rows)
     size_t                  touched_words = 0;
+    bool                    unique_rows_on = false; // the bitmap is handed to a launch only in this mode, and only while it covers `cap`
     std::deque<ProfBatch>   prof_pending;
     std::vector<hipEvent_t> prof_free;
     lantern_gpu_build_profile prof{};

@@ -222,6 +222,14 @@ try {
     std::lock_guard<std::mutex> g(c.mu);
     if(m->refs > 0) m->refs--;
     m->last_use = ++c.clock;
+    if(m->refs == 0 && m->index) {
+        // nobody holds the mirror: whatever bindings are left belong to holders that went away without a release (a thread that
+        // exited, a backend that longjmp'ed out of an error) -- their RetrieverCtx is gone and their thread id may be reused.
+        // (The index's lock is free: no holder is inside it, and a new one cannot take a reference before this cache lock drops.)
+        lgpu::Index *ix = (lgpu::Index *)m->index;
+        std::lock_guard<std::mutex> gi(ix->mu);
+        ix->holders.clear();
+    }
     trim(c);
 }
 LANTERN_ABI_CATCH_VOID(nullptr)

@@ -9,6 +9,8 @@
 // --client-threads T (T > 0) drives the same number of connections from T threads instead, each multiplexing its share with
 // epoll and speaking the wire protocol of scan_server.cpp itself: the generator's own scheduling cost (two context switches per
 // query and connection thread, on the cores the server shares with it) leaves the picture, and what remains is the service.
+// --port P [--host H] drives a service that is ALREADY running (another process's index: bench.py's headline index) instead of
+// building one here; the service's own statistics are then the other process's to report.
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -36,6 +38,8 @@ int main(int argc, char **argv)
     size_t   rows = 100000, dim = 128, m = 16, efc = 128, ef = 64, k = 10, connections = 256, max_batch = 1024, pool = 8192, client_threads = 0;
     unsigned wait_us = 200;
     double   seconds = 5.0, warm = 1.0;
+    int      ext_port = 0;
+    std::string ext_host = "127.0.0.1";
     for(int i = 1; i < argc; ++i) {
         auto val = [&](const char *name) -> const char * { return std::strcmp(argv[ i ], name) == 0 && i + 1 < argc ? argv[ ++i ] : nullptr; };
         if(const char *v = val("--rows")) rows = (size_t)std::atoll(v);
@@ -50,9 +54,11 @@ int main(int argc, char **argv)
         else if(const char *v = val("--max-wait-us")) wait_us = (unsigned)std::atoi(v);
         else if(const char *v = val("--seconds")) seconds = std::atof(v);
         else if(const char *v = val("--warmup-seconds")) warm = std::atof(v);
+        else if(const char *v = val("--port")) ext_port = std::atoi(v);
+        else if(const char *v = val("--host")) ext_host = v;
         else {
             std::fprintf(stderr, "usage: %s [--rows N --dim D --m M --ef-construction E --ef E --k K] [--connections C] [--max-batch B] "
-                                 "[--max-wait-us U] [--seconds S] [--warmup-seconds W] [--client-threads T]\n", argv[ 0 ]);
+                                 "[--max-wait-us U] [--seconds S] [--warmup-seconds W] [--client-threads T] [--port P [--host H]]\n", argv[ 0 ]);
             return 2;
         }
     }
@@ -65,9 +71,10 @@ int main(int argc, char **argv)
     o.connectivity = m;
     o.expansion_add = efc;
     o.expansion_search = ef;
-    usearch_index_t ix = usearch_init(&o, nullptr, &err);
+    const bool external = ext_port > 0;
+    usearch_index_t ix = external ? nullptr : usearch_init(&o, nullptr, &err);
     if(err) { std::fprintf(stderr, "%s\n", err); return 1; }
-    std::vector<float> base(rows * dim), queries(pool * dim);
+    std::vector<float> base(external ? 0 : rows * dim), queries(pool * dim);
     {
         std::mt19937_64                 rng(1);
         std::normal_distribution<float> nd(0.f, 1.f);
@@ -75,17 +82,23 @@ int main(int argc, char **argv)
         std::mt19937_64 qr(2);
         for(float &x : queries) x = nd(qr);
     }
-    std::vector<usearch_label_t> labels(rows);
-    for(size_t i = 0; i < rows; ++i) labels[ i ] = i + 1;
-    const auto tb0 = Clock::now();
-    usearch_reserve(ix, rows, &err);
-    lantern_gpu_add_many(ix, labels.data(), base.data(), rows, usearch_scalar_f32_k, &err);
-    if(!err) lantern_gpu_flush(ix, &err);
-    if(err) { std::fprintf(stderr, "%s\n", err); return 1; }
-    const double build_s = std::chrono::duration<double>(Clock::now() - tb0).count();
-    lantern_scan_server_t *srv = lantern_scan_server_start(ix, "127.0.0.1", 0, max_batch, wait_us, &err);
-    if(!srv) { std::fprintf(stderr, "%s\n", err ? err : "cannot start the scan server"); return 1; }
-    const int port = lantern_scan_server_port(srv);
+    double                 build_s = 0;
+    lantern_scan_server_t *srv = nullptr;
+    if(!external) {
+        std::vector<usearch_label_t> labels(rows);
+        for(size_t i = 0; i < rows; ++i) labels[ i ] = i + 1;
+        const auto tb0 = Clock::now();
+        usearch_reserve(ix, rows, &err);
+        lantern_gpu_add_many(ix, labels.data(), base.data(), rows, usearch_scalar_f32_k, &err);
+        if(!err) lantern_gpu_flush(ix, &err);
+        if(err) { std::fprintf(stderr, "%s\n", err); return 1; }
+        build_s = std::chrono::duration<double>(Clock::now() - tb0).count();
+        std::vector<float>().swap(base);
+        srv = lantern_scan_server_start(ix, "127.0.0.1", 0, max_batch, wait_us, &err);
+        if(!srv) { std::fprintf(stderr, "%s\n", err ? err : "cannot start the scan server"); return 1; }
+    }
+    const int   port = external ? ext_port : lantern_scan_server_port(srv);
+    const char *host = ext_host.c_str();
 
     std::atomic<int>      phase{ 0 };  // 0 warm-up, 1 timed, 2 stop
     std::atomic<size_t>   failures{ 0 }, connected{ 0 };
@@ -128,7 +141,7 @@ int main(int argc, char **argv)
                 std::memset(&a, 0, sizeof(a));
                 a.sin_family = AF_INET;
                 a.sin_port = htons((uint16_t)port);
-                ::inet_pton(AF_INET, "127.0.0.1", &a.sin_addr);
+                ::inet_pton(AF_INET, host, &a.sin_addr);
                 if(c.fd < 0 || ::connect(c.fd, (sockaddr *)&a, sizeof(a)) != 0) { failures++; if(c.fd >= 0) ::close(c.fd); c.fd = -1; continue; }
                 int one = 1;
                 ::setsockopt(c.fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
@@ -170,7 +183,7 @@ int main(int argc, char **argv)
     for(size_t c = 0; client_threads == 0 && c < connections; ++c) {
         threads.emplace_back([&, c] {
             usearch_error_t          e = nullptr;
-            lantern_scan_client_t   *cl = lantern_scan_client_connect("127.0.0.1", port, &e);
+            lantern_scan_client_t   *cl = lantern_scan_client_connect(host, port, &e);
             if(!cl) { failures++; return; }
             connected++;
             std::vector<usearch_label_t> lab(k);
@@ -189,18 +202,22 @@ int main(int argc, char **argv)
         });
     }
     std::this_thread::sleep_for(std::chrono::duration<double>(warm));
-    uint64_t r0, b0, l0, big;
-    uint64_t h0[ 16 ], h1[ 16 ];
-    lantern_scan_server_stats(srv, &r0, &b0, &l0, &big);
-    lantern_scan_server_batch_histogram(srv, h0, 16);
+    uint64_t r0 = 0, b0 = 0, l0 = 0, big = 0;
+    uint64_t h0[ 16 ] = {}, h1[ 16 ] = {};
+    if(srv) {
+        lantern_scan_server_stats(srv, &r0, &b0, &l0, &big);
+        lantern_scan_server_batch_histogram(srv, h0, 16);
+    }
     const auto t0 = Clock::now();
     phase = 1;
     std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
     phase = 2;
     const double elapsed = std::chrono::duration<double>(Clock::now() - t0).count();
-    uint64_t r1, b1, l1;
-    lantern_scan_server_stats(srv, &r1, &b1, &l1, &big);
-    lantern_scan_server_batch_histogram(srv, h1, 16);
+    uint64_t r1 = 0, b1 = 0, l1 = 0;
+    if(srv) {
+        lantern_scan_server_stats(srv, &r1, &b1, &l1, &big);
+        lantern_scan_server_batch_histogram(srv, h1, 16);
+    }
     for(auto &t : threads) t.join();
     std::vector<uint32_t> all;
     for(auto &v : lat) all.insert(all.end(), v.begin(), v.end());
@@ -223,7 +240,7 @@ int main(int argc, char **argv)
         first = false;
     }
     std::printf("}}, \"index_build_seconds\": %.2f}\n", build_s);
-    lantern_scan_server_stop(srv);
-    usearch_free(ix, &err);
+    if(srv) lantern_scan_server_stop(srv);
+    if(ix) usearch_free(ix, &err);
     return failures.load() ? 1 : 0;
 }

@@ -179,7 +179,8 @@ _SEQ_GRAPHS = {}  # the sequential reference build of a set is the same for ever
 
 @pytest.mark.parametrize("name,plan", [("c2_gaussian_100k_x_128", (8192, 16)), ("clustered_100k_x_768", (8192, 16)),
                                        # the larger plan (batches of up to 16 384 rows, full from 65k rows on): the same bar
-                                       ("c2_gaussian_100k_x_128", (16384, 4)), ("clustered_100k_x_768", (16384, 4))])
+                                       ("c2_gaussian_100k_x_128", (16384, 4)), ("clustered_100k_x_768", (16384, 4))],
+                         ids=lambda v: v if isinstance(v, str) else f"batch{v[0]}_ratio{v[1]}")
 def test_build_quality_matches_the_sequential_reference_build(env, oracle, name, plan):
     capi, hip = env
     from lantern_amd import synth
