@@ -336,6 +336,9 @@ typedef struct lantern_gpu_counters
      * (k_revlink_pairs), where sequential usearch stops at the first blocker -- they are >= the CPU path's counts and are the
      * right numerators for the device's rooflines, not for a CPU comparison. */
     uint64_t add_walk_evals, add_select_evals, add_revlink_evals, add_reprunes;
+    /* search launches that took the one-wave walk (csrc/walk_solo.hpp): what a lone usearch_search_ef call (scan.c:220-228) runs
+     * on an index it applies to -- tests assert the kernel that was meant is the kernel that ran */
+    uint64_t search_solo_launches;
 } lantern_gpu_counters;
 LANTERN_GPU_EXPORT lantern_gpu_counters lantern_gpu_counters_get(usearch_index_t, usearch_error_t *);
 

@@ -18,7 +18,7 @@ OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "liblantern_gpu.so")
 
-SOURCES = ["search_kernel.hip", "search_spec_kernel.hip", "search_adc_kernel.hip", "insert_kernel.hip", "insert_spec_kernel.hip", "kernels.hip", "bruteforce.hip", "grouping.hip", "index.cpp", "comm.cpp", "usearch_file.cpp", "scan_shim.cpp", "index_server.cpp", "scan_server.cpp", "mirror_cache.cpp", "node_tape.cpp"]
+SOURCES = ["search_kernel.hip", "search_spec_kernel.hip", "search_solo_kernel.hip", "search_adc_kernel.hip", "insert_kernel.hip", "insert_spec_kernel.hip", "kernels.hip", "bruteforce.hip", "grouping.hip", "index.cpp", "comm.cpp", "usearch_file.cpp", "scan_shim.cpp", "index_server.cpp", "scan_server.cpp", "mirror_cache.cpp", "node_tape.cpp"]
 # every header under csrc/ is a dependency of every object (globbed, so a new header cannot be forgotten)
 HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith(".hpp")) + ["../../include/lantern_gpu.h"]
 # -ffp-contract=off: every fma in the kernels is explicit, so the reduction tree is exactly the

@@ -70,7 +70,7 @@ class GraphInfo(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("search_dist_evals", "search_expansions", "search_queries", "add_dist_evals",
                                           "add_expansions", "add_vectors", "add_batches", "add_walk_evals", "add_select_evals",
-                                          "add_revlink_evals", "add_reprunes")]
+                                          "add_revlink_evals", "add_reprunes", "search_solo_launches")]
 
 
 class BuildProfile(C.Structure):

@@ -1170,7 +1170,55 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
             // second query after the first: two workgroups side by side measure the same, 631 vs 627 k at 512 queries)
             if(se) spec = std::atoi(se);
             else if(nq <= (size_t)ix->num_cus * 2) spec = 2;  // (1M x 768 cosine: 384 queries 528 k vs 389 k, 512: 624 k vs 500 k, 768: 658 k vs 691 k)
-            if(spec < 0 || spec > 3) spec = 0;
+            if(spec < 0 || spec > 4) spec = 0;
+            // 4: the ONE-WAVE walk (walk_solo.hpp): no barrier, no hand-over between waves -- f32 l2sq / cos rows of < 64 chunks,
+            // M <= 16, ef <= 64, an index whose visited bitmap fits LDS.  The automatic choice wherever it applies and every query
+            // has a CU to itself (LANTERN_GPU_SOLO=0 keeps the 3 + 8 wave shape); anything else falls back to spec 2.
+            static const bool solo_auto = !(std::getenv("LANTERN_GPU_SOLO") && std::atoi(std::getenv("LANTERN_GPU_SOLO")) == 0);
+            if(spec == 2 && !se && solo_auto && nq <= (size_t)ix->num_cus) spec = 4;
+            if(spec == 4) {
+                const size_t words = ((std::max<size_t>(ix->n, 1) + 31) / 32 + 3) & ~(size_t)3;
+                uint32_t     ne_log2 = 9;
+                while(ne_log2 > 5 && search_solo_lds_bytes(ne_log2, (uint32_t)words) > 160 * 1024) --ne_log2;
+                if(pqd || ix->spec_profile || !search_solo_supported(ix->mcode, ix->chunks, ix->M, ix->M0, (uint32_t)expansion) ||
+                   search_solo_lds_bytes(ne_log2, (uint32_t)words) > 160 * 1024)
+                    spec = 2;
+                else {
+                    const size_t lds = search_solo_lds_bytes(ne_log2, (uint32_t)words);
+                    const size_t per_cu = std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
+                    size_t       gmax = (size_t)ix->num_cus * per_cu;
+                    if(ix->search_max_wg > 0) gmax = (size_t)ix->search_max_wg;
+                    const int grid = (int)std::max<size_t>(1, std::min(gmax, nq));
+                    const int slot = acquire_search_slot(ix, stream, (size_t)grid);
+                    if(slot < 0) return false;
+                    SearchArgs a{};
+                    a.view = ix->view();
+                    a.queries = d_queries;
+                    a.nq = (uint32_t)nq;
+                    a.k = (uint32_t)k;
+                    a.ef = (uint32_t)expansion;
+                    a.skip = (uint32_t)skip;
+                    a.labels = ix->d_labels;
+                    a.out_labels = d_labels;
+                    a.out_dists = d_dists;
+                    a.out_slots = d_slots;
+                    a.out_counts = d_counts;
+                    a.out_D = d_D;
+                    a.out_E = d_E;
+                    a.vis_slots = (uint32_t)words;   // the LDS bitmap (nothing of the slot's HBM slab is touched)
+                    a.spec_cache = ne_log2;
+                    a.totals = ix->d_totals;
+                    a.ticket = next_ticket(ix, nq, grid, stream);
+                    a.done = done;
+                    a.spec = 4;
+                    HIPCHK(ix, launch_search_solo(ix->mcode, a, grid, stream));
+                    ix->c_solo_launches += 1;
+                    if(done) ix->slot_pending[ slot ] = false;
+                    else if(!release_search_slot(ix, slot, stream)) return false;
+                    ix->c_search_queries += nq;
+                    return true;
+                }
+            }
             // (3: two nodes per round, the second speculative -- walk_twin.hpp; on request only: measured slower)
             if(spec == 3 && !(expansion <= 64 && (ix->mcode == M_L2SQ || ix->mcode == M_COS) && (group_lanes_for(ix->chunks) == 64 || (ix->mcode == M_L2SQ && group_lanes_for(ix->chunks) == 16))))
                 spec = 2;
@@ -2357,6 +2405,7 @@ try {
     c.add_select_evals = t[ 4 ];
     c.add_revlink_evals = t[ 5 ];
     c.add_reprunes = t[ 6 ];
+    c.search_solo_launches = ix->c_solo_launches;
     return c;
 }
 LANTERN_ABI_CATCH(e)

@@ -173,7 +173,7 @@ struct Index
     bool        insert_pending = false;
 
     // ---- counters ----------------------------------------------------------------------------------
-    uint64_t c_search_queries = 0, c_add_vectors = 0, c_add_batches = 0;
+    uint64_t c_search_queries = 0, c_add_vectors = 0, c_add_batches = 0, c_solo_launches = 0;
 
     hipStream_t stream = nullptr;
     int         device = 0;

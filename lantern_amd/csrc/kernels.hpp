@@ -148,6 +148,10 @@ inline void ensure_dynamic_lds(const void *fn, size_t lds, LdsAttrCache &cache)
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_search_spec(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);  // a.spec != 0 (search_spec_kernel.hip)
 size_t     search_spec_lds_bytes(uint32_t M0, uint32_t prefetch, uint32_t cache_entries, uint32_t twin = 0);
+// the one-wave walk (search_solo_kernel.hip, walk_solo.hpp): a.spec_cache = log2 of the list-cache entries, a.vis_slots = words of the LDS bitmap
+bool       search_solo_supported(int metric, uint32_t chunks, uint32_t M, uint32_t M0, uint32_t ef);
+size_t     search_solo_lds_bytes(uint32_t ne_log2, uint32_t bm_words);
+hipError_t launch_search_solo(int metric, const SearchArgs &a, int grid, hipStream_t stream);
 hipError_t launch_search_adc(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);  // metric = M_L2SQ_ADC / M_COS_ADC
 size_t     search_adc_lds_bytes(uint32_t code_chunks, uint32_t qchunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots);
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);

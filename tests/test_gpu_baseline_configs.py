@@ -178,15 +178,18 @@ _SEQ_GRAPHS = {}  # the sequential reference build of a set is the same for ever
 
 
 @pytest.mark.parametrize("name,plan", [("c2_gaussian_100k_x_128", (8192, 16)), ("clustered_100k_x_768", (8192, 16)),
-                                       # the larger plan (batches of up to 16 384 rows, full from 65k rows on): the same bar
-                                       ("c2_gaussian_100k_x_128", (16384, 4)), ("clustered_100k_x_768", (16384, 4))],
+                                       # the larger plan DESIGN 8.0 measures as faster: batches of up to 16 384 rows, still never more than
+                                       # size / 16 -- full batches from 262k rows on, so the set has 400k.  (What does NOT hold the bar is a
+                                       # smaller RATIO: plan (16384, 4) on the 100k set builds batches of a quarter of the graph and loses
+                                       # 0.0115 of recall -- 0.4505 against 0.4620, measured in round 5 -- which is why min_ratio stays 16.)
+                                       ("c2_gaussian_400k_x_128", (16384, 16))],
                          ids=lambda v: v if isinstance(v, str) else f"batch{v[0]}_ratio{v[1]}")
 def test_build_quality_matches_the_sequential_reference_build(env, oracle, name, plan):
     capi, hip = env
     from lantern_amd import synth
 
     if name.startswith("c2"):
-        base = np.random.default_rng(1).standard_normal((100_000, 128), dtype=np.float32)
+        base = np.random.default_rng(1).standard_normal((int(name.split("_")[2][:-1]) * 1000, 128), dtype=np.float32)
         queries = np.random.default_rng(2).standard_normal((1000, 128), dtype=np.float32)
     else:
         make = synth.query_maker(name.split("_")[0], 768)

@@ -737,6 +737,50 @@ def test_latency_bound_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef
     assert np.array_equal(lab.download((nq, k), np.uint64), o_lab) and np.array_equal(D.download(nq, np.uint64), o_D)
 
 
+# the ONE-WAVE walk (walk_solo.hpp, LANTERN_GPU_SPEC=4; the automatic shape of a lone query where it applies): f32 l2sq / cos rows of
+# fewer than 64 chunks, M <= 16 (a multiple of 4), ef <= 64.  8 and 16 lanes per row, one to four chunks per lane, rows that end inside
+# a lane's last chunk and rows that do not, full and short neighbour lists, exact duplicates -- ids, distance bits, D, E of the oracle.
+SOLO_SHAPES = [("l2sq", 3000, 128, 16, 64), ("cos", 2500, 128, 16, 64), ("l2sq", 2000, 40, 16, 50), ("cos", 2000, 24, 8, 33), ("l2sq", 1500, 252, 16, 64),
+               ("l2sq", 1500, 192, 4, 20), ("cos", 1800, 100, 12, 40), ("l2sq", 1200, 32, 16, 64), ("l2sq", 1000, 4, 16, 10), ("cos", 1500, 200, 16, 64)]
+
+
+@pytest.mark.parametrize("metric,n,d,M,ef", SOLO_SHAPES)
+def test_one_wave_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef, monkeypatch):
+    from lantern_amd import hip
+
+    rng = np.random.default_rng(n + d + M)
+    base = rand_rows(rng, n, d, metric)
+    nq = 300
+    queries = rand_rows(rng, nq, d, metric)
+    base[n // 2: n // 2 + 100] = base[:100]  # exact duplicates: equal distances, the slot decides
+    gpu = capi.GpuIndex(metric, d, M=M, ef_construction=48, ef=ef, seed=9)
+    gpu.set_add_batch(256, 8)
+    gpu.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    g = gpu.export_graph()
+    ora = oracle.OracleIndex.from_graph(metric, base, g, M, 48, ef, 9, oracle.SUM_WAVE64)
+    k = min(10, ef)
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, k, ef, 4)
+    monkeypatch.setenv("LANTERN_GPU_SPEC", "4")
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False))
+    lab, dist, D, E = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4), hip.Buffer(nq * 8), hip.Buffer(nq * 8)
+    gpu.set_search_shape(0)  # the automatic shape: LANTERN_GPU_SPEC decides
+    before = gpu.counters()["search_solo_launches"]
+    for rows in (nq, 7, 1):  # more queries than workgroups can be resident (tickets), a handful, one
+        gpu.search_batch_device(dq.ptr, rows, k, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr)
+        hip.synchronize()
+        assert np.array_equal(lab.download((nq, k), np.uint64)[:rows], o_lab[:rows])
+        assert np.array_equal(dist.download((nq, k), np.float32)[:rows], o_dist[:rows])
+        assert np.array_equal(D.download(nq, np.uint64)[:rows], o_D[:rows]), "distance-evaluation counts differ"
+        assert np.array_equal(E.download(nq, np.uint64)[:rows], o_E[:rows]), "expansion counts differ"
+    assert gpu.counters()["search_solo_launches"] == before + 3, "the one-wave kernel did not run"
+    # usearch_search_ef, one query per call (the host waits on the kernel's own counter), and the streaming continuation
+    monkeypatch.delenv("LANTERN_GPU_SPEC")
+    for i in range(20):
+        l1, d1 = gpu.search(queries[i], k)
+        assert np.array_equal(l1, o_lab[i]) and np.array_equal(d1, o_dist[i]), i
+    assert gpu.counters()["search_solo_launches"] == before + 23, "a lone query did not take the one-wave kernel by default"
+
+
 def test_lone_query_and_small_batches_take_the_latency_bound_walk_by_default(capi, oracle):
     """usearch_search_ef (one query per call) and batches around the switch points of the automatic shapes (the lone-query shape up
     to two queries per CU -- the second after the first on the same workgroup --, the classic four-wave walk beyond) -- same answers

@@ -70,7 +70,6 @@ def test_device_meets_the_reference_quantised_contract(oracle, metric, bits, n):
 
     dist_fn = capi.l2sq_dist if metric == "l2sq" else capi.cos_dist
     rec = qc.check_contract(col, metric, bits, index_scan, dist_fn)
-    scan.end()
     # the device index is not merely above the floors: on its own graph it IS the oracle (ids and order), so the floors
     # hold for the arithmetic the oracle restates
     rows, conv, m, sm = oracle_view(oracle, col, metric, bits)
@@ -80,4 +79,5 @@ def test_device_meets_the_reference_quantised_contract(oracle, metric, bits, n):
     for qid in qc.QUERY_IDS:
         o_lab = same.search(conv(col[qid - 1]), qc.LIMIT)[0]
         assert [int(x) for x in o_lab] == index_scan(col[qid - 1])
+    scan.end()
     assert min(rec.values()) >= qc.RECALL_FLOOR[bits]
