@@ -104,14 +104,26 @@ def respawn_under_torchrun(a):
     os.execvpe(cmd[0], cmd, env)
 
 
-def bring_up_comm(a, rdv, rank, world, capi):
+def bring_up_comm(a, rdv, rank, world, capi, device_ids):
     """The exchange transport of the collective build.  RCCL first (data stays in HBM, xGMI); every rank reports whether
     its communicator came up AND passed one small all-gather, and only if ALL did is it used -- otherwise every rank
-    switches to the host transport over the rendezvous directory (slower, but a broken fabric never costs the line)."""
+    switches to the host transport over the rendezvous directory (slower, but a broken fabric never costs the line).
+    Returns (comm, transport, note, info): `info` says how many ranks RCCL saw, which device every rank sits on and -- when the
+    host transport was taken -- why.  RCCL is not even attempted when two ranks share a device (it refuses duplicate devices
+    with ncclInvalidUsage, after a rendezvous that can hang): that launch is a debugging configuration, and says so."""
     import threading
 
     note = None
     want_rccl = a.dist_backend in ("rccl", "nccl")
+    per_device = {}
+    for r, d in enumerate(device_ids):
+        per_device.setdefault(d, []).append(r)
+    shared = {d: rs for d, rs in per_device.items() if len(rs) > 1}
+    info = {"requested_backend": a.dist_backend, "devices_by_rank": device_ids, "distinct_devices": len(per_device), "rccl_ranks_seen": 0}
+    if want_rccl and shared:
+        note = ("RCCL not attempted: " + "; ".join(f"ranks {rs} share device {d}" for d, rs in shared.items())
+                + " -- RCCL refuses two ranks on one device; launch one rank per GPU (or pass --dist-backend files for a one-GPU rehearsal)")
+        want_rccl = False
     if want_rccl:
         box = {}
 
@@ -133,13 +145,17 @@ def bring_up_comm(a, rdv, rank, world, capi):
         t.join(150.0)
         ok = "comm" in box
         verdicts = rdv.allgather((b"1" if ok else b"0") + (box.get("err", "timed out") if not ok else "").encode()[:300], timeout=300.0)
+        info["rccl_ranks_seen"] = sum(1 for v in verdicts if v[:1] == b"1")
         if all(v[:1] == b"1" for v in verdicts):
             box["comm"].set_timeout(a.collective_timeout)
-            return box["comm"], "RCCL all-gather-v (grouped ncclBroadcast) on the index stream", None
+            info["transport_used"] = "rccl"
+            return box["comm"], "RCCL all-gather-v (grouped ncclBroadcast) on the index stream", None, info
         note = "RCCL unavailable (" + "; ".join(f"rank {r}: {v[1:].decode(errors='replace')}" for r, v in enumerate(verdicts) if v[:1] != b"1") + ")"
     c = capi.Comm.host(rank, world, rdv.allgatherv)
     c.set_timeout(a.collective_timeout)
-    return c, "host transport over the rendezvous directory (D2H / files / H2D)", note
+    info["transport_used"] = "files"
+    info["fallback_reason"] = note if a.dist_backend in ("rccl", "nccl") else None
+    return c, "host transport over the rendezvous directory (D2H / files / H2D)", note, info
 
 
 def main():
@@ -168,10 +184,18 @@ def main():
         if rdv:
             rdv.finalize()
 
-    if a.dry_run:  # the N>1 plumbing without a device: launch, world check, rendezvous, reductions, line shape
+    if a.dry_run:  # the N>1 plumbing without a device: launch, world check, rendezvous, per-rank shard synthesis, reductions, line shape
+        from lantern_amd import capi as capi_dry, synth as synth_dry
+
+        lo, hi = capi_dry.shard_range(a.n, world, rank)
+        shard = synth_dry.shard_rows(a.data, a.n, a.dim, lo, hi) if world > 1 else synth_dry.base_rows(a.data, a.n, a.dim)
+        mine = json.dumps({"rank": rank, "local_rank": local_rank, "rows": [lo, hi], "host_bytes": int(shard.nbytes),
+                           "device_bytes_replica": int(a.n) * int(a.dim) * 4 + int(a.n) * (2 * a.M * 4 + 16),
+                           "checksum": float(np.float64(shard[:1].sum()))}).encode()
+        shards = [json.loads(x) for x in rdv.allgather(mine)] if rdv else [json.loads(mine)]
         elapsed = rdv.max_float(0.001 * (rank + 1)) if rdv else 0.001
         ranks = [int(x) for x in rdv.allgather(str(rank).encode())] if rdv else [0]
-        return finish({"metric": f"QPS (recall@{a.k} alongside), {a.n}x{a.dim} f32 {a.metric} ef={a.ef} k={a.k}", "value": None, "unit": "queries/s",
+        return finish({"dry_run_shards": shards, "rows_covered": sum(s_["rows"][1] - s_["rows"][0] for s_ in shards),"metric": f"QPS (recall@{a.k} alongside), {a.n}x{a.dim} f32 {a.metric} ef={a.ef} k={a.k}", "value": None, "unit": "queries/s",
                        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed * 1e3, "higher_is_better": True,
                        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True, "ranks_seen": ranks,
                        "config": {"workload": f"HNSW search {a.n}x{a.dim} {a.quant} {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}",
@@ -181,8 +205,11 @@ def main():
     from lantern_amd import capi, hip
 
     assert capi.device_count() > 0, "no HIP device: bench.py measures the HIP path only"
+    # one rank per GPU: hipSetDevice(local_rank).  More ranks than devices (a one-GPU rehearsal of the N-rank job) wrap around -- the
+    # ranks then share a device, RCCL is not attempted (bring_up_comm) and the line says so.
     dev_index = (local_rank % capi.device_count()) if world > 1 else 0
     hip.set_device(dev_index)
+    device_ids = [x.decode() for x in rdv.allgather(hip.device_bus_id(dev_index).encode())] if rdv else [hip.device_bus_id(dev_index)]
 
     # ---- synthetic data (numpy default_rng, standard normal f32, seeds 3 / 4) -------
     from lantern_amd import synth
@@ -224,7 +251,7 @@ def main():
     ix.set_profiling(True)
     collective = None
     if world > 1:
-        comm, transport, note = bring_up_comm(a, rdv, rank, world, capi)
+        comm, transport, note, comm_info = bring_up_comm(a, rdv, rank, world, capi, device_ids)
         lo, hi = capi.shard_range(a.n, world, rank)
         rdv.barrier()
         hip.synchronize()
@@ -258,11 +285,12 @@ def main():
             ix.flush()
             hip.synchronize()
             t_build = time.time() - t0
-            collective = {"error": next(e for e in errs if e), "fallback": "every rank built its own replica", "transport": transport, "transport_note": note}
+            collective = dict({"error": next(e for e in errs if e), "fallback": "every rank built its own replica", "transport": transport, "transport_note": note},
+                              **comm_info)
         else:
             sums = [x.decode() for x in rdv.allgather(f"{ix.checksum():016x}".encode())]
             stats = comm.stats()
-            collective = {"world": world, "build": a.build, "seconds": rdv.max_float(t_build), "transport": transport, "transport_note": note,
+            collective = {**comm_info, "world": world, "build": a.build, "seconds": rdv.max_float(t_build), "transport": transport, "transport_note": note,
                           "replicas_identical": len(set(sums)) == 1, "checksum": sums[0],
                           "bytes_received_per_rank": [int(x) for x in rdv.allgather(str(stats["bytes_received"]).encode())],
                           "collectives": stats["collectives"]}

@@ -47,6 +47,36 @@ __global__ void __launch_bounds__(256) k_link_keys(const LinkReq *links, uint32_
     idx[ i ] = i;
 }
 
+// A rank of a work-sharded build (world > 1) sorts ONLY the requests it owns (close % world == rank): the append position is the
+// value the owner count's atomicAdd returns, and the key carries the request's position in its low 24 bits -- keys are unique,
+// so the order inside a group is the new-slot order whatever order the appends landed in.  1 / world of the sort and of the
+// gather per rank instead of a replicated pass over every rank's requests.
+constexpr uint32_t POS_BITS = 24;
+__global__ void __launch_bounds__(256) k_link_keys_owned(const LinkReq *links, uint32_t n, uint64_t *keys, uint32_t *ngroups, int world, int rank,
+                                                         uint32_t *owner_counts)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i == 0) *ngroups = 0;
+    if(i >= n) return;
+    const LinkReq r = links[ i ];
+    if(r.close == EMPTY) return;
+    const uint32_t o = r.close % (uint32_t)world;
+    const uint32_t at = atomicAdd(&owner_counts[ o ], 1u);
+    if((int)o == rank) keys[ at ] = (((uint64_t)r.close << 8 | (uint64_t)(r.level & 0xFFu)) << POS_BITS) | (uint64_t)i;
+}
+__global__ void __launch_bounds__(256) k_gather_heads_owned(const LinkReq *links, uint32_t m, const uint64_t *keys, LinkReq *sorted, uint2 *groups,
+                                                            uint32_t *ngroups)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if(j >= m) return;
+    const uint64_t k = keys[ j ], k40 = k >> POS_BITS;
+    sorted[ j ] = links[ (uint32_t)(k & ((1u << POS_BITS) - 1u)) ];
+    if(j != 0 && (keys[ j - 1 ] >> POS_BITS) == k40) return;
+    uint32_t e = j + 1;
+    while(e < m && (keys[ e ] >> POS_BITS) == k40) ++e;
+    groups[ atomicAdd(ngroups, 1u) ] = make_uint2(j, e);
+}
+
 __global__ void __launch_bounds__(256) k_gather_heads(const LinkReq *links, uint32_t n, const uint64_t *keys, const uint32_t *idx, LinkReq *sorted,
                                                       uint2 *groups, uint32_t *ngroups)
 {
@@ -243,7 +273,9 @@ size_t group_temp_bytes(size_t n)
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                     n ? n : 1, 0u, 40u, (hipStream_t) nullptr);
-    return bytes;
+    size_t owned = 0;  // (the keys-only sort of a sharded batch's owned requests: launch_group_sort_owned)
+    (void)rocprim::radix_sort_keys(nullptr, owned, (const uint64_t *)nullptr, (uint64_t *)nullptr, n ? n : 1, 0u, 63u, (hipStream_t) nullptr);
+    return bytes > owned ? bytes : owned;
 }
 
 hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupScratch &gs, LinkReq *sorted, uint2 *groups, uint32_t *ngroups,
@@ -269,6 +301,30 @@ hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupSc
     if(e != hipSuccess) return e;
     hipLaunchKernelGGL(k_gather_heads, dim3(blocks), dim3(256), 0, stream, links, n, (const uint64_t *)gs.keys_b, (const uint32_t *)gs.idx_b, sorted, groups,
                        ngroups);
+    return hipGetLastError();
+}
+
+// The same for a rank of a work-sharded build, in two steps either side of the one host wait a sharded batch has anyway (the owner
+// counts size the second exchange): keys of the OWNED requests, appended; then -- `m` = owner_counts[rank], now known to the host --
+// the sort of those m keys (unique: 39 key bits + 24 position bits) and the gather.  n < 2^24 (the caller checks).
+hipError_t launch_group_keys_owned(const LinkReq *links, uint32_t n, const GroupScratch &gs, uint32_t *ngroups, int world, int rank, uint32_t *owner_counts,
+                                   hipStream_t stream, uint32_t *zero_me)
+{
+    hipError_t e = hipSuccess;
+    if(zero_me && (e = hipMemsetAsync(zero_me, 0, 4, stream)) != hipSuccess) return e;
+    if((e = hipMemsetAsync(owner_counts, 0, (size_t)world * 4, stream)) != hipSuccess) return e;
+    if(n == 0) return hipMemsetAsync(ngroups, 0, 4, stream);
+    hipLaunchKernelGGL(k_link_keys_owned, dim3((n + 255) / 256), dim3(256), 0, stream, links, n, gs.keys_a, ngroups, world, rank, owner_counts);
+    return hipGetLastError();
+}
+hipError_t launch_group_sort_owned(const LinkReq *links, uint32_t m, const GroupScratch &gs, LinkReq *sorted, uint2 *groups, uint32_t *ngroups,
+                                   hipStream_t stream)
+{
+    if(m == 0) return hipSuccess;
+    size_t     temp = gs.temp_bytes;
+    hipError_t e = rocprim::radix_sort_keys(gs.temp, temp, (const uint64_t *)gs.keys_a, gs.keys_b, (size_t)m, 0u, 39u + POS_BITS, stream);
+    if(e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gather_heads_owned, dim3((m + 255) / 256), dim3(256), 0, stream, links, m, (const uint64_t *)gs.keys_b, sorted, groups, ngroups);
     return hipGetLastError();
 }
 

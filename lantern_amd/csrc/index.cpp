@@ -592,11 +592,18 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm, const RowS
     // In a sharded batch a rank keeps only the groups of the nodes it owns (close % world) and counts the others'
     // (the sizes of the second exchange's segments must be known to every rank's HOST: the one value read back).
     // (the pass also zeroes the reverse-link kernels' work counter, d_work[0]: one node less on the stream)
-    HIPCHK(ix, launch_group_requests(d_links, (uint32_t)total_links, gs, d_reqs, d_groups, d_ngroups, split ? W : 1, R, d_owner, ix->stream, (uint32_t *)d_work));
     std::vector<uint32_t> owner_reqs((size_t)W, 0);
+    // A sharded batch sorts and gathers only the requests THIS rank owns (1 / W of them: DESIGN.md 6): their keys are appended while
+    // the owners are counted, the counts come back in the batch's one host wait, and the sort runs on owner_reqs[R] keys.
+    // (LANTERN_GPU_GROUP_ALL=1: the replicated pass over every request, kept for A/B runs; positions need 24 bits.)
+    static const bool group_all = std::getenv("LANTERN_GPU_GROUP_ALL") && std::atoi(std::getenv("LANTERN_GPU_GROUP_ALL")) != 0;
+    const bool        owned_only = split && !group_all && total_links < (1u << 24);
+    if(owned_only) HIPCHK(ix, launch_group_keys_owned(d_links, (uint32_t)total_links, gs, d_ngroups, W, R, d_owner, ix->stream, (uint32_t *)d_work));
+    else HIPCHK(ix, launch_group_requests(d_links, (uint32_t)total_links, gs, d_reqs, d_groups, d_ngroups, split ? W : 1, R, d_owner, ix->stream, (uint32_t *)d_work));
     if(split) {
         HIPCHK(ix, hipMemcpyAsync(owner_reqs.data(), d_owner, (size_t)W * 4, hipMemcpyDeviceToHost, ix->stream));
         if(!sync_stream(ix, comm)) return false;
+        if(owned_only) HIPCHK(ix, launch_group_sort_owned(d_links, owner_reqs[ (size_t)R ], gs, d_reqs, d_groups, d_ngroups, ix->stream));
     }
     prof_mark(ix, 3);
     if(std::getenv("LANTERN_GPU_DEBUG_GROUPS")) {  // debugging aid: the size distribution of this batch's groups
@@ -1172,9 +1179,11 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
             else if(nq <= (size_t)ix->num_cus * 2) spec = 2;  // (1M x 768 cosine: 384 queries 528 k vs 389 k, 512: 624 k vs 500 k, 768: 658 k vs 691 k)
             if(spec < 0 || spec > 4) spec = 0;
             // 4: the ONE-WAVE walk (walk_solo.hpp): no barrier, no hand-over between waves -- f32 l2sq / cos rows of < 64 chunks,
-            // M <= 16, ef <= 64, an index whose visited bitmap fits LDS.  The automatic choice wherever it applies and every query
-            // has a CU to itself (LANTERN_GPU_SOLO=0 keeps the 3 + 8 wave shape); anything else falls back to spec 2.
-            static const bool solo_auto = !(std::getenv("LANTERN_GPU_SOLO") && std::atoi(std::getenv("LANTERN_GPU_SOLO")) == 0);
+            // M <= 16, ef <= 64, an index whose visited bitmap fits LDS.  ON REQUEST ONLY (LANTERN_GPU_SPEC=4, or LANTERN_GPU_SOLO=1 for
+            // every launch it applies to): measured in round 5 on the lone 100k x 128 query it is SLOWER than the 3 + 8 wave shape --
+            // 152.6 us against 106.0 us per call, 2.20 against 1.53 us per hop -- because one wave has to issue all ~540 instructions
+            // of a hop itself; parity-green in every regime it takes.  Anything it does not take falls back to spec 2.
+            static const bool solo_auto = std::getenv("LANTERN_GPU_SOLO") && std::atoi(std::getenv("LANTERN_GPU_SOLO")) != 0;
             if(spec == 2 && !se && solo_auto && nq <= (size_t)ix->num_cus) spec = 4;
             if(spec == 4) {
                 const size_t words = ((std::max<size_t>(ix->n, 1) + 31) / 32 + 3) & ~(size_t)3;

@@ -119,6 +119,10 @@ struct GroupScratch
 size_t     group_temp_bytes(size_t n);
 hipError_t launch_group_requests(const LinkReq *links, uint32_t n, const GroupScratch &gs, LinkReq *sorted, uint2 *groups, uint32_t *ngroups,
                                  int world, int rank, uint32_t *owner_counts, hipStream_t stream, uint32_t *zero_me = nullptr);
+hipError_t launch_group_keys_owned(const LinkReq *links, uint32_t n, const GroupScratch &gs, uint32_t *ngroups, int world, int rank, uint32_t *owner_counts,
+                                   hipStream_t stream, uint32_t *zero_me = nullptr);
+hipError_t launch_group_sort_owned(const LinkReq *links, uint32_t m, const GroupScratch &gs, LinkReq *sorted, uint2 *groups, uint32_t *ngroups,
+                                   hipStream_t stream);
 // (zero_me: a device word the pass sets to 0 on the way -- the reverse-link kernels' work counter; launch_revlink is then told so)
 // link_off[i] = M * sum_{j<i} (level_j + 1), item_node[item] = i for the (level_i + 1) items of node i -- the layout of
 // one batch, from the levels already in HBM (no per-batch host upload)

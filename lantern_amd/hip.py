@@ -48,6 +48,13 @@ def set_device(i: int):
     check(rt().hipSetDevice(C.c_int(i)), "hipSetDevice")
 
 
+def device_bus_id(i: int) -> str:
+    """PCI bus id of device `i` ("0000:05:00.0"): what tells two ranks apart that were handed the same GPU."""
+    buf = C.create_string_buffer(64)
+    check(rt().hipDeviceGetPCIBusId(buf, C.c_int(64), C.c_int(i)), "hipDeviceGetPCIBusId")
+    return buf.value.decode()
+
+
 def synchronize():
     check(rt().hipDeviceSynchronize(), "hipDeviceSynchronize")
 

@@ -72,3 +72,24 @@ def test_file_rendezvous_collectives(tmp_path):
     lone = FileRendezvous(0, 2, path=str(tmp_path / "lonely"), timeout=0.3)
     with pytest.raises(RendezvousTimeout):
         lone.barrier()
+
+
+def test_eight_ranks_rendezvous_shard_the_rows_and_print_one_line():
+    """The first 8-GPU run should be boring: eight ranks find each other, every rank synthesises only ITS shard (the shards tile
+    the row range, host memory per rank is an eighth of the set), the timing reduction is the max over ranks, and rank 0 prints
+    ONE line with n_gpus = 8.  (No device is touched: --dry-run.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--dry-run", "--rows", "80000", "--dim", "64", "--no-cpu", "--dist-backend", "files"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == list(range(8))
+    shards = d["dry_run_shards"]
+    assert [s["rank"] for s in shards] == list(range(8)) and [s["local_rank"] for s in shards] == list(range(8))
+    assert shards[0]["rows"][0] == 0 and shards[-1]["rows"][1] == 80000 and d["rows_covered"] == 80000
+    assert all(a["rows"][1] == b["rows"][0] for a, b in zip(shards, shards[1:]))  # the shards tile the range
+    assert all(s["host_bytes"] == (s["rows"][1] - s["rows"][0]) * 64 * 4 for s in shards)  # a rank holds its shard only
+    assert len({s["checksum"] for s in shards}) == 8  # ... and draws it from its own stream
+    assert abs(d["ms_per_step"] - 8.0) < 1e-6 and d["config"]["global_queries_per_step"] == 8 * d["config"]["queries_per_step_per_gpu"]

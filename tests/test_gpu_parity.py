@@ -737,7 +737,7 @@ def test_latency_bound_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef
     assert np.array_equal(lab.download((nq, k), np.uint64), o_lab) and np.array_equal(D.download(nq, np.uint64), o_D)
 
 
-# the ONE-WAVE walk (walk_solo.hpp, LANTERN_GPU_SPEC=4; the automatic shape of a lone query where it applies): f32 l2sq / cos rows of
+# the ONE-WAVE walk (walk_solo.hpp, LANTERN_GPU_SPEC=4; on request only -- measured slower than the 3 + 8 wave shape): f32 l2sq / cos rows of
 # fewer than 64 chunks, M <= 16 (a multiple of 4), ef <= 64.  8 and 16 lanes per row, one to four chunks per lane, rows that end inside
 # a lane's last chunk and rows that do not, full and short neighbour lists, exact duplicates -- ids, distance bits, D, E of the oracle.
 SOLO_SHAPES = [("l2sq", 3000, 128, 16, 64), ("cos", 2500, 128, 16, 64), ("l2sq", 2000, 40, 16, 50), ("cos", 2000, 24, 8, 33), ("l2sq", 1500, 252, 16, 64),
@@ -773,12 +773,15 @@ def test_one_wave_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef, mon
         assert np.array_equal(D.download(nq, np.uint64)[:rows], o_D[:rows]), "distance-evaluation counts differ"
         assert np.array_equal(E.download(nq, np.uint64)[:rows], o_E[:rows]), "expansion counts differ"
     assert gpu.counters()["search_solo_launches"] == before + 3, "the one-wave kernel did not run"
-    # usearch_search_ef, one query per call (the host waits on the kernel's own counter), and the streaming continuation
-    monkeypatch.delenv("LANTERN_GPU_SPEC")
+    # usearch_search_ef, one query per call: the host waits on the kernel's own completion counter
     for i in range(20):
         l1, d1 = gpu.search(queries[i], k)
         assert np.array_equal(l1, o_lab[i]) and np.array_equal(d1, o_dist[i]), i
-    assert gpu.counters()["search_solo_launches"] == before + 23, "a lone query did not take the one-wave kernel by default"
+    assert gpu.counters()["search_solo_launches"] == before + 23
+    # ... and without the request a lone query keeps the 3 + 8 wave shape (the faster one: DESIGN.md 4.3c)
+    monkeypatch.delenv("LANTERN_GPU_SPEC")
+    l1, d1 = gpu.search(queries[0], k)
+    assert np.array_equal(l1, o_lab[0]) and gpu.counters()["search_solo_launches"] == before + 23
 
 
 def test_lone_query_and_small_batches_take_the_latency_bound_walk_by_default(capi, oracle):
