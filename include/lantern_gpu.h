@@ -247,6 +247,15 @@ LANTERN_GPU_EXPORT void lantern_gpu_search_batch(usearch_index_t, const void *qu
 LANTERN_GPU_EXPORT void lantern_gpu_search_batch_lane(usearch_index_t, int lane, const void *queries, size_t nq,
                                                       usearch_scalar_kind_t, size_t k, size_t ef, usearch_label_t *labels,
                                                       float *distances, uint32_t *counts, usearch_error_t *);
+/* The same with every answer handed on AS ITS OWN WALK ENDS: `done(ctx, which, count)` is called from the calling thread for the
+ * `count` queries (indices in `which`) that finished since the last call -- their rows of labels / distances / counts are filled in by
+ * then -- until every query has been handed on; the function returns after the last call.  The walks of a launch differ in length by
+ * 2x and more; a service that answers each client when ITS walk is over does not make it wait for the longest one of its batch. */
+typedef void (*lantern_gpu_queries_done_fn)(void *ctx, const uint32_t *which, size_t count);
+LANTERN_GPU_EXPORT void lantern_gpu_search_batch_lane_notify(usearch_index_t, int lane, const void *queries, size_t nq,
+                                                             usearch_scalar_kind_t, size_t k, size_t ef, usearch_label_t *labels,
+                                                             float *distances, uint32_t *counts, lantern_gpu_queries_done_fn done, void *done_ctx,
+                                                             usearch_error_t *);
 /* Same, every buffer already in device memory, asynchronous on `stream` (a hipStream_t; NULL =
  * the default stream).  slots (u32 internal ids), counts, dist_evals (D) and expansions (E) may
  * be NULL.  `skip` drops that many leading results per query (streaming continuation).

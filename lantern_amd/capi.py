@@ -97,7 +97,7 @@ EXPORTS = [
     "lantern_gpu_graph_checksum", "lantern_gpu_comm_unique_id", "lantern_gpu_comm_init_rccl", "lantern_gpu_comm_init_host",
     "lantern_gpu_comm_init_local", "lantern_gpu_comm_free", "lantern_gpu_comm_rank", "lantern_gpu_comm_world",
     "lantern_gpu_comm_set_timeout", "lantern_gpu_comm_stats", "lantern_gpu_comm_allgatherv_host",
-    "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded", "lantern_gpu_add_row_sharded", "lantern_gpu_search_partitioned", "lantern_gpu_search_batch_lane",
+    "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded", "lantern_gpu_add_row_sharded", "lantern_gpu_search_partitioned", "lantern_gpu_search_batch_lane", "lantern_gpu_search_batch_lane_notify",
     "lantern_gpu_level_for", "lantern_gpu_plan_batch", "lantern_gpu_row_shard_plan",
     "lantern_scan_server_start", "lantern_scan_server_start_fn", "lantern_scan_server_port", "lantern_scan_server_stats",
     "lantern_scan_server_batch_histogram", "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_search_next",
@@ -114,6 +114,7 @@ BATCH_SEARCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_s
                               C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_char_p))
 
 # int fn(void *ctx, void *host_buf, const size_t *offsets, const size_t *counts, int world, int rank)
+QUERIES_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t)  # lantern_gpu_queries_done_fn
 ALLGATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int, C.c_int)
 COMM_ID_BYTES = 128
 
@@ -220,6 +221,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_add_row_sharded": (None, [vp, vp, vp, vp, sz, i32, err]),
         "lantern_gpu_search_partitioned": (None, [vp, vp, vp, sz, i32, sz, sz, vp, vp, vp, err]),
         "lantern_gpu_search_batch_lane": (None, [vp, i32, vp, sz, i32, sz, sz, vp, vp, vp, err]),
+        "lantern_gpu_search_batch_lane_notify": (None, [vp, i32, vp, sz, i32, sz, sz, vp, vp, vp, vp, vp, err]),
         "lantern_gpu_level_for": (i32, [u64, u64, u32]),
         "lantern_gpu_plan_batch": (sz, [sz, i32, vp, sz, sz, sz]),
         "lantern_gpu_row_shard_plan": (sz, [vp, i32, u64, u32, sz, sz, vp, vp, vp, sz]),
@@ -514,6 +516,28 @@ class GpuIndex:
         counts = np.zeros(nq, dtype=np.uint32)
         _call("lantern_gpu_search_batch_lane", self.h, lane, _ptr(Q), nq, _kind(self.metric), k, ef, _ptr(labels), _ptr(dists), _ptr(counts))
         return labels, dists, counts
+
+    def search_batch_lane_notify(self, lane, queries, k, ef=0):
+        """lantern_gpu_search_batch_lane_notify: the answers plus the ORDER in which the queries were handed on (a list of index lists,
+        one per callback)."""
+        Q = _rows(queries, self.metric)
+        nq = Q.shape[0]
+        labels = np.zeros((nq, k), dtype=np.uint64)
+        dists = np.zeros((nq, k), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        calls = []
+        snapshots = {}
+
+        def on_done(ctx, which, count):
+            idx = [int(which[i]) for i in range(count)]
+            calls.append(idx)
+            for j in idx:  # the rows are filled in when the callback runs
+                snapshots[j] = (labels[j].copy(), dists[j].copy(), int(counts[j]))
+
+        cb = QUERIES_DONE_FN(on_done)
+        _call("lantern_gpu_search_batch_lane_notify", self.h, lane, _ptr(Q), nq, _kind(self.metric), k, ef, _ptr(labels), _ptr(dists), _ptr(counts),
+              C.cast(cb, C.c_void_p), None)
+        return labels, dists, counts, calls, snapshots
 
     def search_partitioned(self, comm: "Comm", queries, k, ef=0):
         """COLLECTIVE: this rank's index holds one share of the rows; every rank passes the same queries and gets the same

@@ -1072,7 +1072,7 @@ bool flush_locked(Index *ix)
 
 bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, size_t ef, size_t skip, uint64_t *d_labels,
                        float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D, uint64_t *d_E, hipStream_t stream,
-                       int waves, uint32_t *done)
+                       int waves, uint32_t *done, uint32_t *done_flags)
 {
     if(nq == 0 || k == 0) return true;
     size_t expansion = ef ? ef : ix->ef;
@@ -1144,6 +1144,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         a.totals = ix->d_totals;
         a.ticket = next_ticket(ix, nq, grid, stream);
         a.done = done;
+    a.done_flags = done_flags;
         a.lds_list = lds_list_env();
         a.adc_centers = ix->d_centers;
         a.adc_S = ix->pq_S;
@@ -1189,7 +1190,9 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
                 const size_t words = ((std::max<size_t>(ix->n, 1) + 31) / 32 + 3) & ~(size_t)3;
                 uint32_t     ne_log2 = 9;
                 while(ne_log2 > 5 && search_solo_lds_bytes(ne_log2, (uint32_t)words) > 160 * 1024) --ne_log2;
-                if(pqd || ix->spec_profile || !search_solo_supported(ix->mcode, ix->chunks, ix->M, ix->M0, (uint32_t)expansion) ||
+                // (the instrumented instantiation -- lantern_gpu_spec_profile -- exists for f32 l2sq rows of exactly 32 chunks)
+                const bool prof_ok = !ix->spec_profile || (ix->mcode == M_L2SQ && ix->chunks == 32);
+                if(pqd || !prof_ok || !search_solo_supported(ix->mcode, ix->chunks, ix->M, ix->M0, (uint32_t)expansion) ||
                    search_solo_lds_bytes(ne_log2, (uint32_t)words) > 160 * 1024)
                     spec = 2;
                 else {
@@ -1219,7 +1222,9 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
                     a.totals = ix->d_totals;
                     a.ticket = next_ticket(ix, nq, grid, stream);
                     a.done = done;
+    a.done_flags = done_flags;
                     a.spec = 4;
+                    a.phase_cycles = ix->spec_profile ? ix->d_totals + 16 : nullptr;
                     HIPCHK(ix, launch_search_solo(ix->mcode, a, grid, stream));
                     ix->c_solo_launches += 1;
                     if(done) ix->slot_pending[ slot ] = false;
@@ -1299,6 +1304,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     // it was sized would otherwise let mark_touched write past it)
     a.touched = (!spec && prof_walk && ix->unique_rows_on && ix->d_touched && ix->touched_words * 32 >= ix->cap) ? ix->d_touched : nullptr;
     a.done = done;
+    a.done_flags = done_flags;
     a.lds_list = lds_list_env();
     // small batch (at most four 4-wave workgroups per CU would be resident anyway): four rows in flight per group
     static const int wide_env = std::getenv("LANTERN_GPU_WIDE_ROWS") ? std::atoi(std::getenv("LANTERN_GPU_WIDE_ROWS")) : -1;
@@ -1981,7 +1987,7 @@ try {
         ix->lane_host[ which ] = nullptr;
         ix->lane_host_bytes[ which ] = 0;
         const size_t grow = need + need / 2;
-        if(hipHostMalloc((void **)&ix->lane_host[ which ], grow, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if(hipHostMalloc((void **)&ix->lane_host[ which ], grow, hipHostMallocMapped) != hipSuccess) return nullptr;  // (mapped: lane_notify's kernels write into it)
         ix->lane_host_bytes[ which ] = grow;
     }
     return ix->lane_host[ which ];
@@ -2087,6 +2093,104 @@ try {
     std::memcpy(labels, h_out, nq * k * 8);
     std::memcpy(distances, h_out + nq * k * 8, nq * k * 4);
     if(counts) std::memcpy(counts, h_out + nq * k * 12, nq * 4);
+}
+LANTERN_ABI_CATCH_VOID(e)
+
+// lantern_gpu_search_batch_lane with the answers handed on ONE QUERY AT A TIME: the kernel writes labels | distances | counts straight
+// into the lane's page-locked, device-mapped block and raises a per-query word there as each walk ends (SearchArgs::done_flags);
+// the calling thread polls those words and calls `done(ctx, which, count)` for the queries that finished since its last look --
+// their rows are in the caller's arrays by then.  A launch's walks differ in length by 2x and more (140 hops where the mean is
+// 78): a caller that answers each client when ITS walk is over, instead of when the longest one is, halves what a client of a
+// small batch waits (the scan-side service: scan_server.cpp).  Returns when every query has been handed on.
+void lantern_gpu_search_batch_lane_notify(usearch_index_t h, int lane, const void *queries, size_t nq, usearch_scalar_kind_t kind, size_t k, size_t ef,
+                                          usearch_label_t *labels, float *distances, uint32_t *counts, lantern_gpu_queries_done_fn done, void *done_ctx,
+                                          usearch_error_t *e)
+try {
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    if(lane < 0 || lane >= Index::kLanes) { FAIL(e, "lantern_gpu: lane must be in [0, 8)"); return; }
+    if(!kind_accepted(ix, (int)kind)) { FAIL(e, "lantern_gpu: scalar kind of the queries does not match the index"); return; }
+    if(nq == 0 || k == 0) return;
+    if(!queries || !labels || !distances || !done) { FAIL(e, "lantern_gpu: null buffer or callback"); return; }
+    const size_t row_words = (size_t)ix->chunks * 4;
+    const size_t in_bytes = input_bytes(ix, (int)kind);
+    const size_t q_bytes = nq * row_words * 4, out_bytes = nq * k * 12 + nq * 4, flag_bytes = nq * 4;
+    const size_t out_at = (q_bytes + 63) & ~(size_t)63, flag_at = (out_at + out_bytes + 63) & ~(size_t)63, need = flag_at + flag_bytes + 64;
+    char *const  hs = host_stage(ix, lane, need);
+    if(!hs) { FAIL(e, "lantern_gpu: cannot allocate the lane's page-locked staging block"); return; }
+    char *hs_dev = nullptr;  // the same block as the device names it
+    if(hipHostGetDevicePointer((void **)&hs_dev, hs, 0) != hipSuccess || !hs_dev) {
+        (void)hipGetLastError();
+        FAIL(e, "lantern_gpu: the lane's staging block is not device-mapped");
+        return;
+    }
+    uint32_t *const padded = (uint32_t *)hs;
+    char *const     h_out = hs + out_at;
+    uint32_t *const flags = (uint32_t *)(hs + flag_at);
+    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
+    std::memset(flags, 0, flag_bytes);
+    hipStream_t st = nullptr;
+    bool        ok = true;
+    static thread_local std::string msg;
+    msg.clear();
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        if(!flush_locked(ix)) { msg = ix->err; FAIL(e, msg.c_str()); return; }
+        if(!ix->lane_stream[ lane ] && hipStreamCreateWithFlags(&ix->lane_stream[ lane ], hipStreamNonBlocking) != hipSuccess) {
+            FAIL(e, "lantern_gpu: cannot create the lane's stream");
+            return;
+        }
+        st = ix->lane_stream[ lane ];
+        char *dq = (char *)scratch(ix, 12 + 2 * lane, nq * row_words * 4);
+        if(!dq) { msg = ix->err; FAIL(e, msg.c_str()); return; }
+        char *const d_out = hs_dev + out_at;
+        ok = hipMemcpyAsync(dq, padded, q_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = ok && run_search_device(ix, (const uint4 *)dq, nq, k, ef, 0, (uint64_t *)d_out, (float *)(d_out + nq * k * 8), nullptr, (uint32_t *)(d_out + nq * k * 12),
+                                     nullptr, nullptr, st, ix->search_waves, nullptr, (uint32_t *)(hs_dev + flag_at));
+        if(!ok) msg = ix->err.empty() ? "lantern_gpu: HIP failure during batched search" : ix->err;
+    }
+    if(!ok) { (void)hipStreamSynchronize(st); FAIL(e, msg.c_str()); return; }
+    // hand the answers on as their flags come up (outside the mutex: the other lanes queue their batches meanwhile)
+    std::vector<uint32_t> pending(nq), ready;
+    for(size_t i = 0; i < nq; ++i) pending[ i ] = (uint32_t)i;
+    ready.reserve(nq);
+    unsigned idle = 0;
+    bool     drained = false;  // the stream has finished: whatever is still pending is complete as well
+    while(!pending.empty()) {
+        ready.clear();
+        for(size_t i = 0; i < pending.size();) {
+            const uint32_t j = pending[ i ];
+            if(drained || __atomic_load_n(&flags[ j ], __ATOMIC_ACQUIRE) != 0) {
+                ready.push_back(j);
+                pending[ i ] = pending.back();
+                pending.pop_back();
+            } else {
+                ++i;
+            }
+        }
+        if(!ready.empty()) {
+            for(uint32_t j : ready) {
+                std::memcpy(labels + (size_t)j * k, h_out + (size_t)j * k * 8, k * 8);
+                std::memcpy(distances + (size_t)j * k, h_out + nq * k * 8 + (size_t)j * k * 4, k * 4);
+                if(counts) std::memcpy(counts + j, h_out + nq * k * 12 + (size_t)j * 4, 4);
+            }
+            done(done_ctx, ready.data(), ready.size());
+            idle = 0;
+            continue;
+        }
+        if(++idle < 64) {
+            __builtin_ia32_pause();
+        } else {
+            idle = 0;
+            const hipError_t q = hipStreamQuery(st);
+            if(q == hipSuccess) { (void)hipStreamSynchronize(st); drained = true; }
+            else if(q != hipErrorNotReady) { (void)hipGetLastError(); ok = false; break; }
+            else std::this_thread::yield();
+        }
+    }
+    if(hipStreamSynchronize(st) != hipSuccess) ok = false;
+    if(!ok) { msg = "lantern_gpu: HIP failure during batched search"; FAIL(e, msg.c_str()); }
 }
 LANTERN_ABI_CATCH_VOID(e)
 

@@ -201,7 +201,8 @@ int         search_grid(const Index *ix, size_t nq, int waves, int waves_per_cu)
 // stream) and no completion event is queued behind the launch
 bool        run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, size_t ef, size_t skip,
                               uint64_t *d_labels, float *d_dists, uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_D,
-                              uint64_t *d_E, hipStream_t stream, int waves, uint32_t *done = nullptr);
+                              uint64_t *d_E, hipStream_t stream, int waves, uint32_t *done = nullptr,
+                       uint32_t *done_flags = nullptr);
 
 // one usearch_search_ef on behalf of `cur` (the caller holds ix->mu); returns the number of results
 size_t      search_one_locked(Index *ix, Cursor *cur, const void *query, int kind, size_t k, size_t ef, bool streaming,

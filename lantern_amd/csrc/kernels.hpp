@@ -40,6 +40,9 @@ struct SearchArgs
     uint32_t        adc_qchunks;    // 16-byte chunks of a (raw f32) query row
     unsigned long long *phase_cycles;  // diagnostics (lantern_gpu_search_phase_profile): [8] shader-clock cycles summed over the
     uint32_t       *done;        // NULL, or a counter in host-visible memory: +1 (system scope) per finished query, after its answers
+    uint32_t       *done_flags;  // NULL, or [nq] words in host-visible memory: done_flags[q] = 1 (system scope, release) once query q's answers
+                                 // are written -- a host that keeps the answers in device-mapped memory hands each one on as ITS walk ends
+                                 // instead of when the launch's longest walk does (lantern_gpu_search_batch_lane_notify)
     uint32_t       *touched;     // diagnostics (lantern_gpu_search_unique_rows; the instrumented instantiations only): [ceil(n / 32)] one
                                  // bit per row, set when any query of the launch evaluates the row; NULL = off
 };                               // launch's queries by phase: pop | list + visited | distances | merge | descent | whole query

@@ -174,6 +174,7 @@ struct lantern_scan_server
     std::atomic<bool>       stop{ false };
     std::thread             accept_thread, dispatch_thread[ kMaxLanes ];
     int                     lanes = 1;   // dispatchers: one collects the next batch while the other's batch is on the device
+    bool                    notify = false;  // the device index: answers go back one by one as their walks end (lantern_gpu_search_batch_lane_notify)
     std::vector<std::unique_ptr<IoThread>> io;
     std::mutex              collect_mu;  // held by the dispatcher that is collecting (one batch is formed at a time)
     std::mutex              mu;          // the queue and the two counts below
@@ -396,6 +397,10 @@ void dispatch_loop(lantern_scan_server *s, int lane)
         std::map<std::pair<uint32_t, uint32_t>, std::vector<size_t>> groups;
         for(size_t i = 0; i < batch.size(); ++i) groups[ { batch[ i ]->k, batch[ i ]->ef } ].push_back(i);
         touched.assign(s->io.size(), 0);
+        // A handful of answers the dispatcher writes itself (a disarmed connection has one holder at a time, and this is it):
+        // one thread hand-off less on the path of a lone backend.  Larger batches go back to the I/O threads, whose sends
+        // run side by side.
+        const bool direct = batch.size() <= 8;
         for(auto &kv : groups) {
             const size_t k = kv.first.first, ef = kv.first.second, nq = kv.second.size();
             qbuf.resize(nq * s->vec_bytes);
@@ -403,42 +408,70 @@ void dispatch_loop(lantern_scan_server *s, int lane)
             labels.assign(nq * k, 0);
             dists.assign(nq * k, 0.f);
             counts.assign(nq, 0);
+            // answers `which[0 .. count)` of this group back to their connections (rc != 0: the error frame `msg`), then one wake-up per
+            // I/O thread that got any, and the requests leave the in-flight count
+            std::string       msg;
+            int               rc = 0;
+            std::vector<char> delivered(nq, 0);
+            auto deliver = [&](const uint32_t *which, size_t count) {
+                for(size_t w = 0; w < count; ++w) {
+                    const size_t j = which[ w ];
+                    delivered[ j ] = 1;
+                    Done         d;
+                    d.c = batch[ kv.second[ j ] ];
+                    if(direct) {
+                        const bool sent = rc != 0 ? reply_error(d.c->fd, msg)
+                                                  : reply_rows(d.c, &labels[ j * k ], &dists[ j * k ], std::min<size_t>(counts[ j ], k));
+                        if(sent && arm(s->io[ (size_t)d.c->io ].get(), d.c, EPOLL_CTL_MOD)) continue;
+                        d.gone = true;  // its I/O thread takes it down
+                    }
+                    if(d.gone) {
+                    } else if(rc != 0) {
+                        d.error = msg;
+                    } else {
+                        const size_t cn = std::min<size_t>(counts[ j ], k);
+                        d.labels.assign(labels.begin() + (ptrdiff_t)(j * k), labels.begin() + (ptrdiff_t)(j * k + cn));
+                        d.dists.assign(dists.begin() + (ptrdiff_t)(j * k), dists.begin() + (ptrdiff_t)(j * k + cn));
+                    }
+                    IoThread *t = s->io[ (size_t)d.c->io ].get();
+                    touched[ (size_t)d.c->io ] = 1;
+                    std::lock_guard<std::mutex> g(t->mu);
+                    t->done.push_back(std::move(d));
+                }
+                const uint64_t one = 1;
+                for(size_t i = 0; i < s->io.size(); ++i)
+                    if(touched[ i ]) {
+                        (void)!::write(s->io[ i ]->evfd, &one, 8);
+                        touched[ i ] = 0;
+                    }
+                std::lock_guard<std::mutex> g(s->mu);
+                s->in_flight -= count;
+            };
             const char *err = nullptr;
-            const int   rc = s->fn(s->fn_ctx, qbuf.data(), nq, s->vec_bytes, k, ef, labels.data(), dists.data(), counts.data(), &err);
-            s->n_launches += 1;
-            const std::string msg = rc != 0 ? std::string(err ? err : "lantern_scan_server: the batch search failed") : std::string();
-            // A handful of answers the dispatcher writes itself (a disarmed connection has one holder at a time, and this is it):
-            // one thread hand-off less on the path of a lone backend.  Larger batches go back to the I/O threads, whose sends
-            // run side by side.
-            const bool direct = batch.size() <= 8;
-            for(size_t j = 0; j < nq; ++j) {  // every answer back to the I/O thread of its connection
-                Done d;
-                d.c = batch[ kv.second[ j ] ];
-                if(direct) {
-                    const bool sent = rc != 0 ? reply_error(d.c->fd, msg)
-                                              : reply_rows(d.c, &labels[ j * k ], &dists[ j * k ], std::min<size_t>(counts[ j ], k));
-                    if(sent && arm(s->io[ (size_t)d.c->io ].get(), d.c, EPOLL_CTL_MOD)) continue;
-                    d.gone = true;  // its I/O thread takes it down
-                }
-                if(d.gone) {
-                } else if(rc != 0) {
-                    d.error = msg;
-                } else {
-                    const size_t cn = std::min<size_t>(counts[ j ], k);
-                    d.labels.assign(labels.begin() + (ptrdiff_t)(j * k), labels.begin() + (ptrdiff_t)(j * k + cn));
-                    d.dists.assign(dists.begin() + (ptrdiff_t)(j * k), dists.begin() + (ptrdiff_t)(j * k + cn));
-                }
-                IoThread *t = s->io[ (size_t)d.c->io ].get();
-                touched[ (size_t)d.c->io ] = 1;
-                std::lock_guard<std::mutex> g(t->mu);
-                t->done.push_back(std::move(d));
+            if(s->notify) {
+                // the device index: every answer goes back when ITS walk ends, not when the batch's longest one does
+                // (lantern_gpu_search_batch_lane_notify; the callback runs on this thread)
+                struct Ctx { decltype(deliver) *fn; } cx{ &deliver };
+                usearch_error_t ue = nullptr;
+                lantern_gpu_search_batch_lane_notify(s->index, tl_lane, qbuf.data(), nq, s->kind, k, ef, labels.data(), dists.data(), counts.data(),
+                                                     [](void *c, const uint32_t *which, size_t count) {
+                                                         Ctx *x = (Ctx *)c;
+                                                         (*x->fn)(which, count);
+                                                     },
+                                                     &cx, &ue);
+                if(ue) { rc = 1; err = ue; }
+            } else {
+                rc = s->fn(s->fn_ctx, qbuf.data(), nq, s->vec_bytes, k, ef, labels.data(), dists.data(), counts.data(), &err);
             }
+            s->n_launches += 1;
+            if(rc != 0) msg = std::string(err ? err : "lantern_scan_server: the batch search failed");
+            // everything (the plain back end) -- or what a failed launch never handed on: those get the error frame.  (A connection
+            // whose answer went out has been re-armed and may already carry its next request: it is never answered twice.)
+            std::vector<uint32_t> rest;
+            for(size_t j = 0; j < nq; ++j)
+                if(!delivered[ j ]) rest.push_back((uint32_t)j);
+            if(!rest.empty()) deliver(rest.data(), rest.size());
         }
-        const uint64_t one = 1;
-        for(size_t i = 0; i < s->io.size(); ++i)
-            if(touched[ i ]) (void)!::write(s->io[ i ]->evfd, &one, 8);
-        std::lock_guard<std::mutex> g(s->mu);
-        s->in_flight -= batch.size();
     }
 }
 
@@ -566,6 +599,8 @@ try {
     // 256: 389 k / 560 k / 563 k / 628 k scans/s; 8 backends 157 us whatever the number.
     s->lanes = 4;
     if(const char *ln = std::getenv("LANTERN_SCAN_LANES")) s->lanes = std::min(kMaxLanes, std::max(1, std::atoi(ln)));
+    // answers one by one as their walks end (LANTERN_SCAN_NOTIFY=0: the whole batch's answers when its launch ends, as before round 5)
+    s->notify = !(std::getenv("LANTERN_SCAN_NOTIFY") && std::atoi(std::getenv("LANTERN_SCAN_NOTIFY")) == 0);
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }
 LANTERN_ABI_CATCH(e)

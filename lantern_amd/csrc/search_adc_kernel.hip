@@ -174,9 +174,11 @@ __global__ void __launch_bounds__(SPEC ? 704 : 512, SPEC ? 1 : 2) k_search_adc(S
             s.scal[ S_POS ] = ticket ? (int)(gridDim.x + atomicAdd(ticket, 1u)) : (int)(q + gridDim.x);
         }
         __syncthreads();
-        if(tid == 0 && done) {
+        uint32_t *const done_flags = LGPU_SEARCH_ARG(kb, done_flags);
+        if(tid == 0 && (done || done_flags)) {
             __threadfence_system();
-            __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if(done) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if(done_flags) __hip_atomic_store(&done_flags[ q ], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         q = (uint32_t)s.scal[ S_POS ];
         __syncthreads();

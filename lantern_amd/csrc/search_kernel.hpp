@@ -163,11 +163,10 @@ k_search(SearchArgs)
         if(tid == 0) {
             // a host that waits on this counter instead of on the stream (the lone-query path: index.cpp search_one_locked)
             // sees this query's answers first: they were written before the barrier above, and the fence orders them
-            uint32_t *const done = LGPU_SEARCH_ARG(kb, done);
-            if(done) {
-                __threadfence_system();
-                __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            uint32_t *const done = LGPU_SEARCH_ARG(kb, done), *const done_flags = LGPU_SEARCH_ARG(kb, done_flags);
+            if(done || done_flags) __threadfence_system();
+            if(done) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if(done_flags) __hip_atomic_store(&done_flags[ q ], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         q = (uint32_t)s.scal[ S_POS ];
         __syncthreads();

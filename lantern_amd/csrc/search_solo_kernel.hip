@@ -5,7 +5,7 @@
 
 namespace lgpu {
 
-template <int METRIC, int G, int CPL, bool RAGGED>
+template <int METRIC, int G, int CPL, bool RAGGED, bool PROF = false>
 __global__ void __launch_bounds__(64, 1) k_search_solo(SearchArgs a)
 {
     const int lane = (int)(threadIdx.x & 63);
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(64, 1) k_search_solo(SearchArgs a)
             w.load_query(a.queries + (size_t)q * a.view.chunks);
             float          d0;
             const uint32_t start = w.descend(D, d0);
-            cnt = w.level0(start, d0, (int)a.ef, D, E, hop_ctr);
+            cnt = w.template level0<PROF>(start, d0, (int)a.ef, D, E, hop_ctr, PROF ? a.phase_cycles : nullptr);
         }
         __builtin_amdgcn_wave_barrier();
         int got = cnt - (int)a.skip;
@@ -52,14 +52,15 @@ __global__ void __launch_bounds__(64, 1) k_search_solo(SearchArgs a)
             if(a.ticket) next = gridDim.x + atomicAdd(a.ticket, 1u);
         }
         next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-        if(a.done) {
-            // a host that waits on this counter instead of on the stream sees this query's answers first: every lane's stores are
-            // complete (vmcnt) before lane 0 releases the counter at system scope
+        if(a.done || a.done_flags) {
+            // a host that waits on this counter (or on the query's flag) instead of on the stream sees this query's answers first:
+            // every lane's stores are complete (vmcnt) before lane 0 releases at system scope
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_wave_barrier();
             if(lane == 0) {
                 __threadfence_system();
-                __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if(a.done) __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if(a.done_flags) __hip_atomic_store(&a.done_flags[ q ], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         q = next;
@@ -100,6 +101,13 @@ hipError_t launch_search_solo(int metric, const SearchArgs &a, int grid, hipStre
     if(lds > 160 * 1024 || (size_t)a.vis_slots * 32 < a.view.n) return hipErrorInvalidValue;
     const int  G_ = group_lanes_for(a.view.chunks), cpl = ((int)a.view.chunks + G_ - 1) / G_;
     const bool ragged = (int)a.view.chunks % G_ != 0;
+    if(a.phase_cycles) {  // the diagnostic instantiation (lantern_gpu_spec_profile): f32 l2sq, 32-chunk rows (128-d)
+        if(metric != M_L2SQ || G_ != 16 || cpl != 2 || ragged) return hipErrorInvalidValue;
+        static LdsAttrCache attr_;
+        ensure_dynamic_lds((const void *)k_search_solo<M_L2SQ, 16, 2, false, true>, lds, attr_);
+        hipLaunchKernelGGL((k_search_solo<M_L2SQ, 16, 2, false, true>), dim3(grid), dim3(64), lds, stream, a);
+        return hipGetLastError();
+    }
     if(metric == M_L2SQ) {
         if(G_ == 16) LGPU_SOLO_CPL(M_L2SQ, 16)
         else LGPU_SOLO_CPL(M_L2SQ, 8)

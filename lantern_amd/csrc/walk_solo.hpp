@@ -181,34 +181,47 @@ template <int METRIC, int G, int CPL, bool RAGGED> struct SoloWalk
         if(gl >= RPG) r.mine = EMPTY;
     }
 
-    // the RPG rows of this lane's group against the query: raw G-lane sums (l2sq: the distance; cos: the ab chain), complete in
-    // every lane of the group -- each lane keeps the sum of ITS neighbour (gl & (RPG - 1)) and of the neighbour whose list it helps
-    // to cache (gl >> 1), picked as the sums are formed (values, never an array: an indexed array would live in scratch memory).
-    // EMPTY ids read row 0 and are ignored by the caller.
-    __device__ __forceinline__ void eval(const Ids &id, float &sum_mine, float &sum_pair) const
+    // the RPG rows of this lane's group against the query, in two steps so that the caller can put work between the requests and
+    // their use: rows_issue asks for every chunk; rows_reduce forms the raw G-lane sums (l2sq: the distance; cos: the ab chain),
+    // complete in every lane of the group -- each lane keeps the sum of ITS neighbour (gl & (RPG - 1)) and of the neighbour whose
+    // list it helps to cache (gl >> 1), picked as the sums are formed (values, never an array: an indexed array would live in
+    // scratch memory).  EMPTY ids read row 0 and are ignored by the caller.
+    struct Rows
     {
-        uint4 R[ RPG ][ CPL ];
+        uint4 r[ RPG ][ CPL ];
+    };
+    __device__ __forceinline__ void rows_issue(const Ids &id, Rows &R) const
+    {
 #pragma unroll
         for(int p = 0; p < RPG; ++p) {
             const uint32_t at = (id.row[ p ] == EMPTY ? 0u : id.row[ p ]) * row_bytes;
 #pragma unroll
-            for(int c = 0; c + 1 < CPL; ++c) R[ p ][ c ] = ld16(v.vec, at + lane_off + (uint32_t)(c * G * 16));
-            R[ p ][ CPL - 1 ] = ld16(v.vec, at + last_off + (RAGGED ? 0u : 0u));
+            for(int c = 0; c + 1 < CPL; ++c) R.r[ p ][ c ] = ld16(v.vec, at + lane_off + (uint32_t)(c * G * 16));
+            R.r[ p ][ CPL - 1 ] = ld16(v.vec, at + last_off);
         }
+    }
+    __device__ __forceinline__ void rows_reduce(const Rows &R, float &sum_mine, float &sum_pair) const
+    {
         uint32_t bm = 0u, bp = 0u;
 #pragma unroll
         for(int p = 0; p < RPG; ++p) {
             RowAcc<METRIC> a;
 #pragma unroll
-            for(int c = 0; c + 1 < CPL; ++c) a.add(Q[ c ], R[ p ][ c ]);
-            if constexpr(RAGGED) a.add(Q[ CPL - 1 ], sel4(last_ok, R[ p ][ CPL - 1 ], make_uint4(0, 0, 0, 0)));  // (Q is zero there too)
-            else a.add(Q[ CPL - 1 ], R[ p ][ CPL - 1 ]);
+            for(int c = 0; c + 1 < CPL; ++c) a.add(Q[ c ], R.r[ p ][ c ]);
+            if constexpr(RAGGED) a.add(Q[ CPL - 1 ], sel4(last_ok, R.r[ p ][ CPL - 1 ], make_uint4(0, 0, 0, 0)));  // (Q is zero there too)
+            else a.add(Q[ CPL - 1 ], R.r[ p ][ CPL - 1 ]);
             const uint32_t sp = __float_as_uint(group_sum<G>(a.s));
             bm |= sp & pick_mine.is[ p ];
             bp |= sp & pick_pair.is[ p ];
         }
         sum_mine = __uint_as_float(bm);
         sum_pair = __uint_as_float(bp);
+    }
+    __device__ __forceinline__ void eval(const Ids &id, float &sum_mine, float &sum_pair) const
+    {
+        Rows R;
+        rows_issue(id, R);
+        rows_reduce(R, sum_mine, sum_pair);
     }
     __device__ __forceinline__ float finish(float sum, float row_norm_rooted) const
     {
@@ -265,8 +278,21 @@ template <int METRIC, int G, int CPL, bool RAGGED> struct SoloWalk
 
     // ---- search_to_find_in_base_: the ef-bounded walk over level 0 from `start` (whose distance the descent just took: the
     // oracle evaluates it once more here -- counted in D, not re-read).  Leaves the list in s.keys, returns its length.
-    __device__ int level0(uint32_t start, float start_d, int ef, uint32_t &D, uint32_t &E, uint32_t &hop_ctr)
+    // PROF (the diagnostic instantiation): shader-clock cycles per section of a hop, summed over the query, into prof[0..8):
+    // [0] list look-up (LDS cache / HBM)  [1] issuing the row, list and norm loads  [2] merge of the previous hop's keys (in the
+    // loads' shadow)  [3] visited filter + cache claims  [4] waiting for the rows + the distances  [5] cache writes
+    // [6] choosing the next node  [7] hops  [8] hops whose list was not in the LDS cache.  Every stamp costs an s_memtime + wait (~40 cycles).
+    template <bool PROF = false>
+    __device__ int level0(uint32_t start, float start_d, int ef, uint32_t &D, uint32_t &E, uint32_t &hop_ctr, unsigned long long *prof = nullptr)
     {
+        unsigned long long tl = 0, pacc[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }, misses = 0;
+#define LGPU_SOLO_MARK(i)                                                   \
+    if constexpr(PROF) {                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
+        const unsigned long long t_ = (unsigned long long)clock64();        \
+        pacc[ i ] += t_ - tl;                                               \
+        tl = t_;                                                            \
+    }
         const unsigned long long live = ef >= 64 ? ~0ull : (1ull << ef) - 1ull;
         const uint32_t           M0 = v.M0, list_bytes = M0 * 4u;
         const uint32_t           half = (uint32_t)(gl & 1);
@@ -278,6 +304,7 @@ template <int METRIC, int G, int CPL, bool RAGGED> struct SoloWalk
         uint32_t node = start;
         D += 1;
         if(lane == 0) s.bitmap[ start >> 5 ] = 1u << (start & 31);
+        if constexpr(PROF) tl = (unsigned long long)clock64();
         while(node != EMPTY) {
             E += 1;
             ++hop_ctr;
@@ -285,8 +312,13 @@ template <int METRIC, int G, int CPL, bool RAGGED> struct SoloWalk
             const uint32_t e = solo_hash(node, s.ne_log2);
             const uint32_t tag = s.tags[ e ];
             Ids            id = ids_lds(e);
-            if((uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != node) id = ids_hbm(v.nbr0, node * list_bytes, M0);
+            if((uint32_t)__builtin_amdgcn_readfirstlane((int)tag) != node) {
+                id = ids_hbm(v.nbr0, node * list_bytes, M0);
+                if constexpr(PROF) misses += 1;
+            }
             hide_keys(id);
+            if constexpr(PROF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a list that came from HBM is charged to the look-up)
+            LGPU_SOLO_MARK(0)
             // ---- [2] every neighbour's row, its own list (two lanes per list, 64 bytes each) and norm: all requested now
             uint4 L[ 4 ];
             {
@@ -299,8 +331,9 @@ template <int METRIC, int G, int CPL, bool RAGGED> struct SoloWalk
                 }
             }
             const float nrm_mine = norm_of(id.mine), nrm_pair = norm_of(id.pair);
-            float       sum_mine, sum_pair;
-            eval(id, sum_mine, sum_pair);
+            Rows        R;
+            rows_issue(id, R);
+            LGPU_SOLO_MARK(1)
             // ---- [3] in the shadow of the loads: merge the previous hop's keys, mark `node` expanded
             {
                 const uint64_t     worst = cnt == ef ? readlane64(K, ef - 1) : ~0ull;
@@ -318,6 +351,7 @@ template <int METRIC, int G, int CPL, bool RAGGED> struct SoloWalk
                 }
                 if(K != ~0ull && key_slot(K) == node) K |= 1ull;
             }
+            LGPU_SOLO_MARK(2)
             // ---- [4] visited filter (one LDS atomic per neighbour) and the cache claims
             bool isnew = false;
             if(id.mine != EMPTY) {
@@ -330,9 +364,14 @@ template <int METRIC, int G, int CPL, bool RAGGED> struct SoloWalk
                 won = __hip_atomic_exchange(s.stamps + ep, hop_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != hop_ctr;
             won = dpp_take<0xA0, 0xF>(won);  // quad_perm [0,0,2,2]: the pair's even lane decides for both
             D += (uint32_t)__popcll(__ballot(isnew));
+            LGPU_SOLO_MARK(3)
             // ---- [5] distances -> this hop's new keys
+            float sum_mine, sum_pair;
+            rows_reduce(R, sum_mine, sum_pair);
             const float d_mine = finish(sum_mine, nrm_mine);
             N = isnew ? make_key(d_mine, id.mine) : ~0ull;
+            if constexpr(PROF) asm volatile("" ::"v"(d_mine));
+            LGPU_SOLO_MARK(4)
             // ---- [6] lists of keys inside the radius -> cache
             {
                 const float    d_pair = finish(sum_pair, nrm_pair);
@@ -344,6 +383,7 @@ template <int METRIC, int G, int CPL, bool RAGGED> struct SoloWalk
                     if(half == 0) s.tags[ ep ] = id.pair;
                 }
             }
+            LGPU_SOLO_MARK(5)
             // ---- [7] the next node: min(first unexpanded entry of the list, smallest new key inside the radius)
             {
                 const unsigned long long m = __ballot(!key_expanded(K)) & live;
@@ -352,6 +392,15 @@ template <int METRIC, int G, int CPL, bool RAGGED> struct SoloWalk
                 bool                     got = f != ~0ull;
                 const uint64_t           t = wave_min_below(N, got ? f : w, got);
                 node = got ? key_slot(t) : EMPTY;
+            }
+            LGPU_SOLO_MARK(6)
+        }
+#undef LGPU_SOLO_MARK
+        if constexpr(PROF) {
+            if(lane == 0 && prof) {
+                for(int i = 0; i < 7; ++i) atomicAdd(&prof[ i ], pacc[ i ]);
+                atomicAdd(&prof[ 7 ], (unsigned long long)E);
+                atomicAdd(&prof[ 8 ], misses);  // hops whose list came from HBM (not in the LDS cache)
             }
         }
         if(lane < cnt) s.keys[ lane ] = K;

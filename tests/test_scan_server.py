@@ -410,7 +410,9 @@ def test_server_on_an_index_needs_a_device(capi):
 
 
 @pytest.mark.gpu
-def test_concurrent_backends_get_exactly_the_direct_search_results(capi):
+@pytest.mark.parametrize("notify", ["1", "0"])  # answers one by one as their walks end (the default) / all of a batch's when its launch ends
+def test_concurrent_backends_get_exactly_the_direct_search_results(capi, monkeypatch, notify):
+    monkeypatch.setenv("LANTERN_SCAN_NOTIFY", notify)
     n, d, k = 20000, 64, 10
     rng = np.random.default_rng(5)
     base = rng.standard_normal((n, d), dtype=np.float32)
@@ -441,6 +443,34 @@ def test_concurrent_backends_get_exactly_the_direct_search_results(capi):
     for qi in range(queries.shape[0]):
         assert np.array_equal(got[qi][0], want_lab[qi]) and np.array_equal(got[qi][1], want_dst[qi])
     assert st["requests"] == 320 and st["batches"] < 320 and st["largest_batch"] > 1, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,n,d,nq", [("l2sq", 20000, 128, 300), ("cos", 8000, 768, 64), ("l2sq", 5000, 64, 1), ("hamming", 6000, 8, 700)])
+def test_lane_notify_hands_on_every_query_once_with_its_final_rows(capi, metric, n, d, nq):
+    """lantern_gpu_search_batch_lane_notify: the kernels raise one host-visible word per query as its walk ends and the caller is told
+    batch by batch of finished queries.  Every query is handed on exactly once, its rows are the final ones at that moment, and the
+    answers are lantern_gpu_search_batch's -- in the latency-bound shapes (<= two queries per CU) and in the classic one."""
+    rng = np.random.default_rng(n + nq)
+    if metric == "hamming":
+        base = rng.integers(0, 2**32, size=(n, d), dtype=np.uint32)
+        queries = rng.integers(0, 2**32, size=(nq, d), dtype=np.uint32)
+    else:
+        base = rng.standard_normal((n, d), dtype=np.float32)
+        queries = rng.standard_normal((nq, d), dtype=np.float32)
+    ix = capi.GpuIndex(metric, d, M=16, ef_construction=64, ef=48, seed=3)
+    ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    ix.flush()
+    want_lab, want_dst, want_cnt = ix.search_batch(queries, 10)
+    for lane in (0, 3):
+        lab, dst, cnt, calls, snap = ix.search_batch_lane_notify(lane, queries, 10)
+        assert np.array_equal(lab, want_lab) and np.array_equal(dst, want_dst) and np.array_equal(cnt, want_cnt)
+        handed = [j for c in calls for j in c]
+        assert sorted(handed) == list(range(nq)), "every query exactly once"
+        for j, (l, dd, c) in snap.items():
+            assert np.array_equal(l, want_lab[j]) and np.array_equal(dd, want_dst[j]) and c == want_cnt[j], "rows were final when handed on"
+    if nq >= 300:
+        assert len(calls) > 1, "a batch whose walks differ in length is handed on in more than one piece"
 
 
 def test_standalone_binary_fails_loudly_without_a_device_or_arguments(capi):
