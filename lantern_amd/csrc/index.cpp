@@ -931,6 +931,36 @@ static bool row_shard_candidates(Index *ix, const RowShard &rs, size_t first, si
     return ok;
 }
 
+// `count` caller rows (scalar kind `kind_in`) into the vector table at slots [at, at + count) in their STORED form -- nothing is linked:
+// a row that no list names is unreachable.  Queued on the index stream.
+static bool stage_rows_at(Index *ix, size_t at, const void *vectors, size_t count, int kind_in)
+{
+    if(count == 0) return true;
+    const size_t row_words = (size_t)ix->chunks * 4, row = row_words * 4, in_bytes = input_bytes(ix, kind_in);
+    char *const  dst = (char *)ix->d_vec + at * row;
+    if(kind_in == ix->scalar && in_bytes == row) {
+        HIPCHK(ix, hipMemcpyAsync(dst, vectors, count * row, hipMemcpyHostToDevice, ix->stream));
+        HIPCHK(ix, hipStreamSynchronize(ix->stream));  // (the caller's buffer is pageable and borrowed)
+        return true;
+    }
+    if(kind_in == usearch_scalar_f32_k && (ix->scalar == usearch_scalar_f16_k || ix->scalar == usearch_scalar_i8_k || ix->b1_from_f32)) {
+        const size_t d = ix->opts.dimensions;
+        float       *tmp = nullptr;
+        bool         up = hipMalloc((void **)&tmp, count * d * 4) == hipSuccess;
+        up = up && hipMemcpyAsync(tmp, vectors, count * d * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+        up = up && launch_store_quantised(tmp, (uint32_t)d, (uint32_t)count, ix->scalar, (uint32_t *)dst, (uint32_t)row_words, ix->stream) == hipSuccess;
+        up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
+        if(tmp) (void)hipFree(tmp);
+        if(!up) { (void)hipGetLastError(); set_err(ix, "lantern_gpu: HIP failure uploading vectors"); }
+        return up;
+    }
+    std::vector<uint32_t> padded(count * row_words);
+    for(size_t i = 0; i < count; ++i) pad_row(ix, (const char *)vectors + i * in_bytes, kind_in, &padded[ i * row_words ]);
+    HIPCHK(ix, hipMemcpyAsync(dst, padded.data(), count * row, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(ix, hipStreamSynchronize(ix->stream));  // (`padded` is a local)
+    return true;
+}
+
 bool add_row_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const void *vectors, size_t n_shard, int kind_in)
 {
     if(ix->n || !ix->pend_labels.empty()) { set_err(ix, "lantern_gpu: the row-sharded build needs an empty index"); return false; }
@@ -1012,24 +1042,16 @@ bool add_row_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const
         size_t my_off = 0;
         for(int r = 0; r < R; ++r) my_off += sh[ r ];
         const size_t my_n = sh[ R ];
-        // 1. this rank's share joins its own graph
-        if(my_n) {
-            gl.resize(my_n);
-            for(size_t i = 0; i < my_n; ++i) gl[ i ] = (uint64_t)(first + my_off + i) + 1;
-            lantern_gpu_add_many(loc, gl.data(), (const char *)vectors + mine * in_bytes, my_n, (usearch_scalar_kind_t)kind_in, &err);
-            if(!err) lantern_gpu_flush(loc, &err);
-            if(err) { set_err(ix, std::string("lantern_gpu: row-sharded build, shard graph: ") + err); return false; }
-            // 2. ... and the global table (the shard's graph holds the stored form of the rows)
-            HIPCHK(ix, hipMemcpyAsync((char *)ix->d_vec + (first + my_off) * row, (const char *)loc->d_vec + mine * row, my_n * row, hipMemcpyDeviceToDevice, ix->stream));
-            mine += my_n;
-        }
+        // 1. this rank's share goes into the GLOBAL table (stored form); the shards' shares follow by all-gather
+        if(my_n && !stage_rows_at(ix, first + my_off, (const char *)vectors + mine * in_bytes, my_n, kind_in)) return false;
         if(W > 1) {
             size_t at = 0;
             for(int r = 0; r < W; ++r) { off[ (size_t)r ] = at * row; cnt[ (size_t)r ] = sh[ r ] * row; at += sh[ r ]; }
             if(!comm->allgatherv_device((char *)ix->d_vec + first * row, off.data(), cnt.data(), ix->stream)) { set_err(ix, comm->err); return false; }
         }
         if(!fill_norms(ix, first, b)) return false;
-        // 3. + 4.
+        // 2. + 3. candidates from every shard's graph AS IT STOOD BEFORE THIS BATCH (a batch's members are invisible to each other, as
+        // in a one-GPU batch: every one of a shard's K answers is usable), selection, reverse links
         if(ix->n == 0) {  // "Do nothing for the first element": it only becomes the entry point
             ix->n = 1;
             ix->entry = 0;
@@ -1037,6 +1059,16 @@ bool add_row_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const
             ix->c_add_vectors += 1;
         } else if(!run_batch(ix, b, s.lv.data() + first, nullptr, &rs)) {
             return false;
+        }
+        // 4. only now this rank's share joins its own graph (until round 4 it joined first: in-batch rows then used up part of the K
+        // answers per shard and were discarded by the merge -- a row could be left with far fewer than ef_construction candidates)
+        if(my_n) {
+            gl.resize(my_n);
+            for(size_t i = 0; i < my_n; ++i) gl[ i ] = (uint64_t)(first + my_off + i) + 1;
+            lantern_gpu_add_many(loc, gl.data(), (const char *)vectors + mine * in_bytes, my_n, (usearch_scalar_kind_t)kind_in, &err);
+            if(!err) lantern_gpu_flush(loc, &err);
+            if(err) { set_err(ix, std::string("lantern_gpu: row-sharded build, shard graph: ") + err); return false; }
+            mine += my_n;
         }
         // the host transport's staging buffers and the candidate scratch are reused by the next batch
         return sync_stream(ix, comm);
@@ -2179,14 +2211,18 @@ try {
             idle = 0;
             continue;
         }
-        if(++idle < 64) {
-            __builtin_ia32_pause();
-        } else {
-            idle = 0;
+        // nothing new: spin on the flags (they change in host memory; a look costs a cache miss when one does).  The runtime is asked
+        // only now and then -- hipStreamQuery takes its lock, which the other lanes' launches need -- to notice a launch that ended
+        // without raising its flags (it cannot, short of a fault) or failed.
+        ++idle;
+        if((idle & 0x3FFFu) == 0) {
             const hipError_t q = hipStreamQuery(st);
             if(q == hipSuccess) { (void)hipStreamSynchronize(st); drained = true; }
             else if(q != hipErrorNotReady) { (void)hipGetLastError(); ok = false; break; }
-            else std::this_thread::yield();
+        } else if((idle & 0xFFu) == 0) {
+            std::this_thread::yield();
+        } else {
+            __builtin_ia32_pause();
         }
     }
     if(hipStreamSynchronize(st) != hipSuccess) ok = false;

@@ -174,6 +174,7 @@ struct lantern_scan_server
     std::atomic<bool>       stop{ false };
     std::thread             accept_thread, dispatch_thread[ kMaxLanes ];
     int                     lanes = 1;   // dispatchers: one collects the next batch while the other's batch is on the device
+    bool                    window = false;  // notify mode: keep the batching window anyway (LANTERN_SCAN_WINDOW=1)
     bool                    notify = false;  // the device index: answers go back one by one as their walks end (lantern_gpu_search_batch_lane_notify)
     std::vector<std::unique_ptr<IoThread>> io;
     std::mutex              collect_mu;  // held by the dispatcher that is collecting (one batch is formed at a time)
@@ -375,9 +376,13 @@ void dispatch_loop(lantern_scan_server *s, int lane)
             const auto   deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(s->max_wait_us);
             const size_t lanes = (size_t)s->lanes;
             auto         share = [&] { return std::min(s->max_batch, std::max<size_t>(1, (s->open_conns + lanes - 1) / lanes)); };
-            s->cv.wait_until(lk, deadline, [&] { return s->stop.load() || s->queue.size() >= share() || s->queue.size() + s->in_flight >= s->open_conns; });
+            // Answers that go back one by one (notify) need no window at all: a request that waits for company only waits -- its walk
+            // is not made faster by the walks beside it while there are idle CUs, and a dispatcher that is free takes what is there
+            // (LANTERN_SCAN_WINDOW=1 keeps the window; measured, 1M x 768, 256 backends: see DESIGN.md 4.6b).
+            if(!s->notify || s->window)
+                s->cv.wait_until(lk, deadline, [&] { return s->stop.load() || s->queue.size() >= share() || s->queue.size() + s->in_flight >= s->open_conns; });
             if(s->stop) return;
-            const size_t take = share();
+            const size_t take = (s->notify && !s->window) ? s->max_batch : share();
             while(!s->queue.empty() && batch.size() < take) {
                 batch.push_back(s->queue.front());
                 s->queue.pop_front();
@@ -601,6 +606,7 @@ try {
     if(const char *ln = std::getenv("LANTERN_SCAN_LANES")) s->lanes = std::min(kMaxLanes, std::max(1, std::atoi(ln)));
     // answers one by one as their walks end (LANTERN_SCAN_NOTIFY=0: the whole batch's answers when its launch ends, as before round 5)
     s->notify = !(std::getenv("LANTERN_SCAN_NOTIFY") && std::atoi(std::getenv("LANTERN_SCAN_NOTIFY")) == 0);
+    s->window = std::getenv("LANTERN_SCAN_WINDOW") && std::atoi(std::getenv("LANTERN_SCAN_WINDOW")) != 0;
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }
 LANTERN_ABI_CATCH(e)

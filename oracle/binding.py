@@ -369,8 +369,9 @@ def row_sharded_build(metric, dims, shards, M=16, ef_construction=128, ef=64, se
                       per_shard=None):
     """CPU restatement of lantern_gpu_add_row_sharded (lantern_amd/csrc/index.cpp add_row_sharded_locked; SURVEY.md 8e as written).
     shards = [(labels, rows), ...] in rank order.  Every shard keeps a graph over ITS rows (labels there = global slot + 1), grown
-    batch by batch with the device's plan; a batch's rows are searched in every shard's graph (k = ef = per_shard), the answers are
-    merged by (distance, slot), members of the batch itself left out, the best ef_construction of them are the level-0 candidates
+    batch by batch with the device's plan; a batch's rows are searched in every shard's graph AS IT STOOD BEFORE THE BATCH (k = ef =
+    per_shard; the batch's members join their shards afterwards), the answers are merged by (distance, slot), the best
+    ef_construction of them are the level-0 candidates
     of lo_add_batch_cand on the global graph.  Returns (the global index, labels in slot order)."""
     W = len(shards)
     sizes = [len(lab) for lab, _ in shards]
@@ -388,12 +389,13 @@ def row_sharded_build(metric, dims, shards, M=16, ef_construction=128, ef=64, se
         rows = np.zeros((b, np.asarray(shards[0][1]).shape[1]), dtype=np.asarray(shards[0][1]).dtype)
         labs = np.zeros(b, dtype=np.uint64)
         at = 0
+        joins = []  # (shard, global slots + 1, rows): the batch's members join their shards' graphs AFTER the batch's candidate searches
         for r in range(W):
             n_r = share[r]
             if n_r:
                 lab_r, rows_r = shards[r]
                 seg = slice(cur[r], cur[r] + n_r)
-                locs[r].add_planned(np.arange(first + at, first + at + n_r, dtype=np.uint64) + 1, rows_r[seg], max_batch, min_ratio)
+                joins.append((r, np.arange(first + at, first + at + n_r, dtype=np.uint64) + 1, rows_r[seg]))
                 rows[at:at + n_r] = rows_r[seg]
                 labs[at:at + n_r] = lab_r[seg]
                 cur[r] += n_r
@@ -407,14 +409,17 @@ def row_sharded_build(metric, dims, shards, M=16, ef_construction=128, ef=64, se
                 for r in range(W):
                     if len(locs[r]):
                         l, d, _ = locs[r].search(rows[i], K, K)
-                        keep = l <= first  # label = slot + 1: the slots before this batch
+                        keep = l <= first  # label = slot + 1: the slots before this batch (all of them: the shards hold nothing newer)
                         L.append(l[keep])
                         D.append(d[keep])
-                La, Da = np.concatenate(L), np.concatenate(D)
+                La = np.concatenate(L) if L else np.zeros(0, dtype=np.uint64)
+                Da = np.concatenate(D) if D else np.zeros(0, dtype=np.float32)
                 order = np.lexsort((La, Da))[:ef_construction]
                 cn[i] = order.size
                 cs[i, :order.size] = (La[order] - 1).astype(np.uint32)
                 cd[i, :order.size] = Da[order]
+        for r, slots1, rws in joins:
+            locs[r].add_planned(slots1, rws, max_batch, min_ratio)
         glob.add_batch_cand(labs, rows, cs, cd, cn)
         by_slot[first:first + b] = labs
     return glob, by_slot
