@@ -212,13 +212,58 @@ __global__ void __launch_bounds__(256, 2) k_dense_f32(const float *Q, uint32_t n
             mfma4(fa[ set ][ 0 ].w, fa[ set ][ 1 ].w, fb[ set ][ 0 ].w, fb[ set ][ 1 ].w);
         }
     };
+    // plain-output variant: the finished tile's distances on their way out (see the epilogue), its origin, and how many of its
+    // eight parts (row block x column block x half of the 16 registers) have left
+    floatx16 stash[ 2 ][ 2 ];
+    uint32_t st_q0 = 0, st_c0 = 0;
+    int      st_done = 8;
+    auto     flush_part = [&](auto part_c) {
+        // only INTERIOR tiles take this way out (every row below nq, every column below nb): plain stores, no bounds, no branch
+        constexpr int part = decltype(part_c)::value, i = part >> 2, jj = (part >> 1) & 1, h = part & 1;
+        const uint32_t c = st_c0 + (uint32_t)(wn * 64 + jj * 32 + (lane & 31));
+#pragma unroll
+        for(int r = 8 * h; r < 8 * h + 8; ++r) {
+            const uint32_t q = st_q0 + (uint32_t)(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+            out[ (size_t)q * ldo + c ] = stash[ i ][ jj ][ r ];
+        }
+    };
+    // (st_done only ever holds uniform values; it goes through readfirstlane so that the compiler KNOWS, and keeps the branches -- and
+    // everything live across them, the buffer descriptors of the load side above all -- scalar)
+    auto flush_range = [&](int from, int to) {  // parts [from, to) that have not left yet
+        const int d = __builtin_amdgcn_readfirstlane(st_done);
+        if(d <= 0 && 0 >= from && 0 < to) flush_part(std::integral_constant<int, 0>{});
+        if(d <= 1 && 1 >= from && 1 < to) flush_part(std::integral_constant<int, 1>{});
+        if(d <= 2 && 2 >= from && 2 < to) flush_part(std::integral_constant<int, 2>{});
+        if(d <= 3 && 3 >= from && 3 < to) flush_part(std::integral_constant<int, 3>{});
+        if(d <= 4 && 4 >= from && 4 < to) flush_part(std::integral_constant<int, 4>{});
+        if(d <= 5 && 5 >= from && 5 < to) flush_part(std::integral_constant<int, 5>{});
+        if(d <= 6 && 6 >= from && 6 < to) flush_part(std::integral_constant<int, 6>{});
+        if(d <= 7 && 7 >= from && 7 < to) flush_part(std::integral_constant<int, 7>{});
+    };
+    auto flush_next = [&]() {
+        const int d = __builtin_amdgcn_readfirstlane(st_done);
+        if(d >= 8) return;
+        flush_range(d, d + 1);
+        st_done = d + 1;
+    };
+    auto flush_rest = [&]() {
+        flush_range(0, 8);
+        st_done = 8;
+    };
     auto epilogue = [&](uint32_t ti) {
         // ---- the tile's epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
         // Its norms and radii are in Ns[ti & 1] since the barrier of its first step; the next tile's first step is already in
         // the other LDS buffer and its fragments in registers, so the MFMAs resume right after.
         uint32_t q0, c0;
         tile_origin(ti, q0, c0);
+        if constexpr(!FUSED) {
+            flush_rest();  // (a tile of fewer than eight K steps: the previous one's parts have not all left yet)
+            st_q0 = q0;
+            st_c0 = c0;
+        }
         const float *Nq = Ns[ ti & 1 ], *Nb = Ns[ ti & 1 ] + 128, *Nr = Ns[ ti & 1 ] + 256;
+        const bool   interior = q0 + (uint32_t)BM <= nq && c0 + (uint32_t)BN <= nb;  // (uniform)
+        if constexpr(!FUSED) st_done = interior ? 0 : 8;
 #pragma unroll
         for(int i = 0; i < 2; ++i)
 #pragma unroll
@@ -262,11 +307,22 @@ __global__ void __launch_bounds__(256, 2) k_dense_f32(const float *Q, uint32_t n
                         if(p < tk.cap) tk.cand[ (size_t)q * tk.cap + p ] = ((uint64_t)f2ord(d) << 32) | (uint64_t)(tk.c_base + c);
                     }
                 } else {
+                    // The plain-output variant does not store an interior tile here: 64 stores per lane issued at once sit in the SAME
+                    // in-order counter as the LDS-direct loads of the next tile's first steps, whose `s_waitcnt vmcnt(0)` then waits for
+                    // the writes to reach memory -- once per tile the matrix pipe stood still for a write latency (0.80 of the peak where
+                    // the fused variant runs at 0.905).  The distances go to a register stash and leave eight at a time, one part per K
+                    // step of the NEXT tile, right behind that step's barrier (flush_part above): a part has a whole step to drain.  A
+                    // tile on the matrix's edge (rows past nq or columns past nb) stores at once, under its bounds checks, as before.
+                    if(interior) {
 #pragma unroll
-                    for(int r = 0; r < 16; ++r) {
-                        const uint32_t q = q0 + (uint32_t)(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                        const float    d = dist_of(r, acc[ i ][ jj ][ r ]);
-                        if(q < nq && c < nb) out[ (size_t)q * ldo + c ] = d;
+                        for(int r = 0; r < 16; ++r) stash[ i ][ jj ][ r ] = dist_of(r, acc[ i ][ jj ][ r ]);
+                    } else {
+#pragma unroll
+                        for(int r = 0; r < 16; ++r) {
+                            const uint32_t q = q0 + (uint32_t)(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                            const float    d = dist_of(r, acc[ i ][ jj ][ r ]);
+                            if(q < nq && c < nb) out[ (size_t)q * ldo + c ] = d;
+                        }
                     }
                 }
             }
@@ -309,6 +365,7 @@ __global__ void __launch_bounds__(256, 2) k_dense_f32(const float *Q, uint32_t n
         LGPU_FENCE;                                                                 \
         dma_wait();                                                                 \
         __syncthreads();                                                            \
+        if constexpr(!FUSED) flush_next(); /* one part of the previous tile's distances: a whole step to drain */ \
         if(ks == 0) { /* (behind the wait for the loads: the norms' own load is long done) */ \
             store_norms(ti & 1);                                                    \
             if(ti + 1 < my_n) load_norms(ti + 1);                                   \
@@ -339,6 +396,7 @@ __global__ void __launch_bounds__(256, 2) k_dense_f32(const float *Q, uint32_t n
         LGPU_DENSE_STEP(0)
         LGPU_DENSE_STEP(1)
     }
+    if constexpr(!FUSED) flush_rest();  // the workgroup's last tile
 #undef LGPU_DENSE_STEP
 #undef LGPU_FENCE
 }

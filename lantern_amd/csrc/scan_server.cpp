@@ -174,7 +174,7 @@ struct lantern_scan_server
     std::atomic<bool>       stop{ false };
     std::thread             accept_thread, dispatch_thread[ kMaxLanes ];
     int                     lanes = 1;   // dispatchers: one collects the next batch while the other's batch is on the device
-    bool                    window = false;  // notify mode: keep the batching window anyway (LANTERN_SCAN_WINDOW=1)
+    bool                    window = true;   // notify mode: LANTERN_SCAN_WINDOW=0 drops the batching window (measured slower)
     bool                    notify = false;  // the device index: answers go back one by one as their walks end (lantern_gpu_search_batch_lane_notify)
     std::vector<std::unique_ptr<IoThread>> io;
     std::mutex              collect_mu;  // held by the dispatcher that is collecting (one batch is formed at a time)
@@ -376,9 +376,10 @@ void dispatch_loop(lantern_scan_server *s, int lane)
             const auto   deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(s->max_wait_us);
             const size_t lanes = (size_t)s->lanes;
             auto         share = [&] { return std::min(s->max_batch, std::max<size_t>(1, (s->open_conns + lanes - 1) / lanes)); };
-            // Answers that go back one by one (notify) need no window at all: a request that waits for company only waits -- its walk
-            // is not made faster by the walks beside it while there are idle CUs, and a dispatcher that is free takes what is there
-            // (LANTERN_SCAN_WINDOW=1 keeps the window; measured, 1M x 768, 256 backends: see DESIGN.md 4.6b).
+            // (Answers that go back one by one -- notify -- still gain from the window: measured in round 5 at 1M x 768, a dispatcher
+            // that takes whatever is queued the moment it is free forms batches of 44 instead of 62 at 256 backends and of 75 instead of
+            // 150 - 180 at 1024, and serves 452 k against 501 k and 583 k against 715 k scans/s: every launch costs the host a padding
+            // pass, a copy and a launch under the runtime's lock.  LANTERN_SCAN_WINDOW=0 selects that policy.)
             if(!s->notify || s->window)
                 s->cv.wait_until(lk, deadline, [&] { return s->stop.load() || s->queue.size() >= share() || s->queue.size() + s->in_flight >= s->open_conns; });
             if(s->stop) return;
@@ -606,7 +607,7 @@ try {
     if(const char *ln = std::getenv("LANTERN_SCAN_LANES")) s->lanes = std::min(kMaxLanes, std::max(1, std::atoi(ln)));
     // answers one by one as their walks end (LANTERN_SCAN_NOTIFY=0: the whole batch's answers when its launch ends, as before round 5)
     s->notify = !(std::getenv("LANTERN_SCAN_NOTIFY") && std::atoi(std::getenv("LANTERN_SCAN_NOTIFY")) == 0);
-    s->window = std::getenv("LANTERN_SCAN_WINDOW") && std::atoi(std::getenv("LANTERN_SCAN_WINDOW")) != 0;
+    s->window = !(std::getenv("LANTERN_SCAN_WINDOW") && std::atoi(std::getenv("LANTERN_SCAN_WINDOW")) == 0);
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }
 LANTERN_ABI_CATCH(e)
