@@ -571,6 +571,9 @@ LANTERN_GPU_EXPORT int  lantern_scan_server_port(lantern_scan_server_t *);
 LANTERN_GPU_EXPORT void lantern_scan_server_stats(lantern_scan_server_t *, uint64_t *requests, uint64_t *batches,
                                                   uint64_t *launches, uint64_t *largest_batch);
 /* batches formed so far by size: bins[b] counts batches of 2^b .. 2^(b+1) - 1 requests (b < 16); returns the bins written */
+/* mean microseconds of a request on the server by leg -- out4[0] read -> its batch closes, [1] batch closed -> its answer is known,
+ * [2] answer known -> written to the socket -- and out4[3] the number of requests the means are over (cumulative since start) */
+LANTERN_GPU_EXPORT void lantern_scan_server_timing(lantern_scan_server_t *, double *out4);
 LANTERN_GPU_EXPORT size_t lantern_scan_server_batch_histogram(lantern_scan_server_t *, uint64_t *bins, size_t nbins);
 LANTERN_GPU_EXPORT void lantern_scan_server_stop(lantern_scan_server_t *);
 /* client: one connection per backend, one query at a time; returns the number of results (<= k), ascending */

@@ -100,7 +100,7 @@ EXPORTS = [
     "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded", "lantern_gpu_add_row_sharded", "lantern_gpu_search_partitioned", "lantern_gpu_search_batch_lane", "lantern_gpu_search_batch_lane_notify",
     "lantern_gpu_level_for", "lantern_gpu_plan_batch", "lantern_gpu_row_shard_plan",
     "lantern_scan_server_start", "lantern_scan_server_start_fn", "lantern_scan_server_port", "lantern_scan_server_stats",
-    "lantern_scan_server_batch_histogram", "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_search_next",
+    "lantern_scan_server_batch_histogram", "lantern_scan_server_timing", "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_search_next",
     "lantern_scan_client_close", "lantern_scan_begin_client",
     "lantern_mirror_acquire", "lantern_mirror_index", "lantern_mirror_version", "lantern_mirror_rebind", "lantern_mirror_advance", "lantern_mirror_release",
     "lantern_mirror_invalidate", "lantern_mirror_set_capacity", "lantern_mirror_stats",
@@ -230,6 +230,7 @@ def lib() -> C.CDLL:
         "lantern_scan_server_port": (i32, [vp]),
         "lantern_scan_server_stats": (None, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
         "lantern_scan_server_batch_histogram": (sz, [vp, C.POINTER(u64), sz]),
+        "lantern_scan_server_timing": (None, [vp, C.POINTER(C.c_double)]),
         "lantern_scan_server_stop": (None, [vp]),
         "lantern_scan_client_connect": (vp, [C.c_char_p, i32, err]),
         "lantern_scan_client_search": (sz, [vp, vp, sz, sz, sz, vp, vp, err]),
@@ -986,6 +987,12 @@ class ScanServer:
         v = [C.c_uint64() for _ in range(4)]
         lib().lantern_scan_server_stats(self.s, *[C.byref(x) for x in v])
         return dict(zip(("requests", "batches", "launches", "largest_batch"), (int(x.value) for x in v)))
+
+    def timing(self):
+        """Mean microseconds of a request on the server by leg (cumulative since start) and the number of requests."""
+        v = (C.c_double * 4)()
+        lib().lantern_scan_server_timing(self.s, v)
+        return {"wait_for_batch_us": v[0], "batch_closed_to_answer_us": v[1], "answer_to_socket_us": v[2], "requests": int(v[3])}
 
     def stop(self):
         if self.s:

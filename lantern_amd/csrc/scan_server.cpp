@@ -133,6 +133,7 @@ struct Conn
     bool                 cont = false;
     uint32_t             want = 0, k = 0, ef = 0;  // rows the client asked for; rows the search is asked for (handed out + want)
     std::vector<uint8_t> vec;
+    uint64_t             t_read = 0, t_closed = 0;  // ns: its request was read / its batch closed (lantern_scan_server_timing)
     // this connection's scan: labels handed out since its last fresh request, and how many label-0 rows among them
     std::unordered_set<uint64_t> seen;
     size_t                       seen_zero = 0;
@@ -143,6 +144,7 @@ struct Done
 {
     Conn                 *c = nullptr;
     bool                  gone = false;  // the dispatcher answered it itself and the write failed: only the connection's end is left to do
+    uint64_t              t_known = 0;  // ns: when the dispatcher learnt the answer
     std::string           error;  // non-empty: an error frame
     std::vector<uint64_t> labels;
     std::vector<float>    dists;
@@ -184,9 +186,15 @@ struct lantern_scan_server
     size_t                  open_conns = 0, in_flight = 0;  // connections being served; requests in a closed batch, not answered yet
     std::atomic<uint64_t>   n_requests{ 0 }, n_batches{ 0 }, n_launches{ 0 }, max_batch_seen{ 0 };
     std::atomic<uint64_t>   batch_hist[ 16 ] = {};  // batches by size: bin b counts sizes in [2^b, 2^(b+1))
+    // where a request's time on the server goes, summed in ns over all answered requests: read -> its batch closes (the window and
+    // the wait for a free dispatcher) | batch closed -> its answer is known (padding, copy, launch, ITS walk -- or, without notify,
+    // the batch's longest) | answer known -> written to the socket
+    std::atomic<uint64_t>   t_wait_ns{ 0 }, t_search_ns{ 0 }, t_reply_ns{ 0 }, t_count{ 0 };
 };
 
 namespace {
+
+inline uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 thread_local int tl_lane = 0;  // which dispatcher this thread is (the default backend's lane)
 
@@ -317,6 +325,7 @@ void io_loop(lantern_scan_server *s, IoThread *t)
                 else if(got == 0) { if(!arm(t, c, EPOLL_CTL_MOD)) drop(s, t, c); }
                 else {
                     s->n_requests += 1;
+                    c->t_read = now_ns();
                     std::lock_guard<std::mutex> g(s->mu);
                     s->queue.push_back(c);
                     ++queued;
@@ -340,6 +349,7 @@ void io_loop(lantern_scan_server *s, IoThread *t)
             fresh.clear();
             for(Done &d : done) {
                 const bool sent = !d.gone && (d.error.empty() ? reply_rows(d.c, d.labels.data(), d.dists.data(), d.labels.size()) : reply_error(d.c->fd, d.error));
+                if(d.t_known) s->t_reply_ns += now_ns() - d.t_known;
                 if(!sent || !arm(t, d.c, EPOLL_CTL_MOD)) drop(s, t, d.c);  // answered: the connection may speak again
             }
             done.clear();
@@ -391,6 +401,10 @@ void dispatch_loop(lantern_scan_server *s, int lane)
             s->in_flight += batch.size();
         }
         if(batch.empty()) continue;
+        {
+            const uint64_t t = now_ns();
+            for(Conn *c : batch) c->t_closed = t;
+        }
         s->n_batches += 1;
         {
             int bin = 0;
@@ -420,14 +434,20 @@ void dispatch_loop(lantern_scan_server *s, int lane)
             int               rc = 0;
             std::vector<char> delivered(nq, 0);
             auto deliver = [&](const uint32_t *which, size_t count) {
+                const uint64_t t_known = now_ns();
                 for(size_t w = 0; w < count; ++w) {
                     const size_t j = which[ w ];
                     delivered[ j ] = 1;
                     Done         d;
                     d.c = batch[ kv.second[ j ] ];
+                    d.t_known = t_known;
+                    s->t_wait_ns += d.c->t_closed - d.c->t_read;
+                    s->t_search_ns += t_known - d.c->t_closed;
+                    s->t_count += 1;
                     if(direct) {
                         const bool sent = rc != 0 ? reply_error(d.c->fd, msg)
                                                   : reply_rows(d.c, &labels[ j * k ], &dists[ j * k ], std::min<size_t>(counts[ j ], k));
+                        s->t_reply_ns += now_ns() - t_known;
                         if(sent && arm(s->io[ (size_t)d.c->io ].get(), d.c, EPOLL_CTL_MOD)) continue;
                         d.gone = true;  // its I/O thread takes it down
                     }
@@ -637,6 +657,18 @@ try {
     if(largest_batch) *largest_batch = s ? s->max_batch_seen.load() : 0;
 }
 LANTERN_ABI_CATCH_VOID(nullptr)
+
+// mean microseconds a request spends on the server, by leg: read -> batch closed | batch closed -> answer known | answer known ->
+// written; out[3] = requests the means are over.  Counters are cumulative since start.
+void lantern_scan_server_timing(lantern_scan_server_t *s, double *out4)
+{
+    if(!s || !out4) return;
+    const double n = (double)std::max<uint64_t>(s->t_count.load(), 1);
+    out4[ 0 ] = (double)s->t_wait_ns.load() / n / 1e3;
+    out4[ 1 ] = (double)s->t_search_ns.load() / n / 1e3;
+    out4[ 2 ] = (double)s->t_reply_ns.load() / n / 1e3;
+    out4[ 3 ] = (double)s->t_count.load();
+}
 
 size_t lantern_scan_server_batch_histogram(lantern_scan_server_t *s, uint64_t *bins, size_t nbins)
 try {

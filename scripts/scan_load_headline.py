@@ -107,13 +107,15 @@ def main():
     srv = capi.ScanServer(index=ix, max_batch=a.max_batch, max_wait_us=a.max_wait_us)
     for c in [int(x) for x in a.connections.split(",")]:
         for extra in ([], ["--client-threads", "8"]) if c >= 64 else ([],):
-            before = srv.stats()
+            before, tb = srv.stats(), srv.timing()
             pr = subprocess.run([tool, "--port", str(srv.port), "--dim", str(a.dim), "--rows", str(a.rows), "--connections", str(c), "--seconds", str(a.seconds),
                                  "--warmup-seconds", "1"] + extra, capture_output=True, text=True, timeout=300)
-            after = srv.stats()
+            after, ta = srv.stats(), srv.timing()
             line = next((json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")), {"error": (pr.stderr or pr.stdout)[-300:]})
             req, bat = after["requests"] - before["requests"], after["batches"] - before["batches"]
             line.pop("service", None)
+            dn = max(ta["requests"] - tb["requests"], 1)
+            line["server_side_us"] = {k2: (ta[k2] * ta["requests"] - tb[k2] * tb["requests"]) / dn for k2 in ("wait_for_batch_us", "batch_closed_to_answer_us", "answer_to_socket_us")}
             line.update({"leg": "scan service", "mean_batch": req / max(bat, 1), "over_device_resident": line.get("queries_per_s", 0) / resident,
                          "max_batch": a.max_batch, "max_wait_us": a.max_wait_us})
             print(json.dumps(line), flush=True)
