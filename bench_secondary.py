@@ -315,7 +315,11 @@ def run(a, capi, hip, ix, base, queries, device_resident_qps, headline_recall, m
     """The four (five) entries, each isolated: a failure costs its entry, never the line."""
     out = []
 
+    only = [x for x in os.environ.get("LANTERN_BENCH_SECONDARY", "").split(",") if x]  # debugging: run the named legs only
+
     def leg(fn, *args, **kw):
+        if only and fn.__name__ not in only:
+            return
         t0 = time.time()
         try:
             e = fn(*args, **kw)

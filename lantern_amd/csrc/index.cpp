@@ -2174,10 +2174,14 @@ try {
             return;
         }
         st = ix->lane_stream[ lane ];
-        char *dq = (char *)scratch(ix, 12 + 2 * lane, nq * row_words * 4);
+        // A service-sized batch's queries are read by the walks straight out of the page-locked block (each workgroup fetches its 3 KB
+        // row over the host link once, as a lone usearch_search_ef does): no copy command in front of the kernel -- a DMA command costs
+        // tens of microseconds of queueing, as much as a tenth of a walk.  Large batches are copied into HBM first, at the link's rate.
+        const bool  direct_queries = q_bytes <= (size_t)1 << 20;
+        char       *dq = direct_queries ? hs_dev : (char *)scratch(ix, 12 + 2 * lane, nq * row_words * 4);
         if(!dq) { msg = ix->err; FAIL(e, msg.c_str()); return; }
         char *const d_out = hs_dev + out_at;
-        ok = hipMemcpyAsync(dq, padded, q_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = direct_queries || hipMemcpyAsync(dq, padded, q_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
         ok = ok && run_search_device(ix, (const uint4 *)dq, nq, k, ef, 0, (uint64_t *)d_out, (float *)(d_out + nq * k * 8), nullptr, (uint32_t *)(d_out + nq * k * 12),
                                      nullptr, nullptr, st, ix->search_waves, nullptr, (uint32_t *)(hs_dev + flag_at));
         if(!ok) msg = ix->err.empty() ? "lantern_gpu: HIP failure during batched search" : ix->err;
