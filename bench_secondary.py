@@ -287,16 +287,19 @@ def headline_scan_service(a, capi, ix, device_resident_qps, connections=256, sec
         for mode, extra in (("thread_per_connection", []), ("multiplexed_8_client_threads", ["--client-threads", "8"])):
             cmd = [tool, "--port", str(srv.port), "--dim", str(a.dim), "--k", str(a.k), "--connections", str(connections), "--seconds", str(seconds),
                    "--warmup-seconds", "1", "--rows", str(a.n), "--m", str(a.M), "--ef-construction", str(a.efc), "--ef", str(a.ef)] + extra
-            before = srv.stats()
+            before, tb = srv.stats(), srv.timing()
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
-            after = srv.stats()
+            after, ta = srv.stats(), srv.timing()
             line = next((json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")), None)
             if not line:
                 runs[mode] = {"error": (p.stderr or p.stdout)[-300:]}
                 continue
             req, bat = after["requests"] - before["requests"], after["batches"] - before["batches"]
+            dn = max(ta["requests"] - tb["requests"], 1)
             runs[mode] = {"value": line["queries_per_s"], "latency_us": line["latency_us"], "failures": line["failures"], "connected": line["connected"],
-                          "mean_batch": req / max(bat, 1), "largest_batch": after["largest_batch"]}
+                          "mean_batch": req / max(bat, 1), "largest_batch": after["largest_batch"],
+                          "server_side_us": {k2: (ta[k2] * ta["requests"] - tb[k2] * tb["requests"]) / dn
+                                             for k2 in ("wait_for_batch_us", "batch_closed_to_answer_us", "answer_to_socket_us")}}
     finally:
         srv.stop()
     good = [r for r in runs.values() if "value" in r]

@@ -21,6 +21,19 @@
 static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
                              uint32_t *d_slots, float *d_dists, hipStream_t st);
 
+// The HIP runtime multiplexes a process's streams onto FOUR hardware queues by default (GPU_MAX_HW_QUEUES); streams that share a queue
+// run their kernels one after the other.  This library keeps up to eight search launches in flight on streams of their own (the lanes of
+// lantern_gpu_search_batch_lane: the scan-side service's dispatchers) beside the index's stream and whatever the caller made: with
+// four queues two lanes end up behind one another -- measured in round 5 at 1M x 768, 256 backends: a batch's answers 100 us later,
+// 443 k instead of 551 - 589 k scans/s, and which lanes collide depends on how many streams the process happened to create first.  The
+// flag is read when the runtime initialises (its first call), so it is set here, when the library is loaded; an explicit setting wins.
+namespace {
+struct HwQueues
+{
+    HwQueues() { (void)::setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} hw_queues_at_load;
+}  // namespace
+
 namespace lgpu {
 
 // LANTERN_GPU_LDS_LIST=1: walks keep their candidate list in LDS even when it fits wave 0's registers (walk.hpp search_level vs
