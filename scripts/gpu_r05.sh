@@ -176,4 +176,15 @@ step_k() {
   echo "rc $?" >> $OUT/bench_8ranks.err
 }
 
-"step_${1:?usage: gpu_r05.sh <a..k>}"
+# l: the records round 4 did not re-measure: B3 end to end at 1M x 1536, one insertion per call, BASELINE configs [3] and [4] on one GPU
+step_l() {
+  cd "$GRAFT_REPO_ROOT" || exit 1
+  OUT=gpurun_out/r05l; mkdir -p $OUT
+  export TMPDIR=/tmp
+  timeout 300 lantern_amd/lib/lantern-index-load --rows 1000000 --dim 1536 > $OUT/index_load_1Mx1536.json 2> $OUT/indexload.err
+  timeout 200 python scripts/bench_single_insert.py > $OUT/single_insert_100kx128.json 2> $OUT/single_insert.err
+  timeout 900 python bench.py --rows 10000000 --ef 128 --steps 5 --truth-queries 256 --build-quality-rows 0 --no-secondary > $OUT/bench_line_10Mx768_ef128.json 2> $OUT/bench_10M.err
+  timeout 900 python bench.py --dim 1536 --steps 5 --truth-queries 1000 --no-secondary > $OUT/bench_line_1Mx1536.json 2> $OUT/bench_1536.err
+}
+
+"step_${1:?usage: gpu_r05.sh <a..l>}"
