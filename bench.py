@@ -510,6 +510,9 @@ def measure_traffic(a, checksum):
             line = next((json.loads(l) for l in p.stdout.splitlines() if l.startswith("{") and "pmc_child" in l), None)
             if p.returncode != 0 or not line:
                 out["passes"].append({"counter": ctr, "error": f"rc {p.returncode}: {(p.stderr or p.stdout)[-300:]}"})
+                if os.environ.get("LANTERN_BENCH_PMC_LOG"):  # debugging: the failed pass's whole output
+                    with open(os.path.join(os.environ["LANTERN_BENCH_PMC_LOG"], f"pmc_{ctr}.log"), "w") as f:
+                        f.write(p.stdout + "\n==== stderr\n" + p.stderr)
                 continue
             if line["checksum"] != checksum:
                 out["passes"].append({"counter": ctr, "error": "the child built a different graph"})

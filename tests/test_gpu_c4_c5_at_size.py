@@ -58,7 +58,11 @@ def run(hip, ix, queries, ef, waves=0):
             cnt.download(nq, np.uint32), Dv.download(nq, np.uint64), Ev.download(nq, np.uint64))
 
 
-def build(capi, metric, base, ef, plan=(8192, 16)):
+def build(capi, metric, base, ef, plan=None):
+    # (8192, 16) unless LANTERN_TEST_ADD_BATCH says otherwise: bench.py builds with 16384-row batches since round 5, and the at-size
+    # parity below has been run once with that plan too (profiles/r05_c4_at_size_plan16384.txt)
+    if plan is None:
+        plan = (int(os.environ.get("LANTERN_TEST_ADD_BATCH", "8192")), 16)
     ix = capi.GpuIndex(metric, base.shape[1], M=M, ef_construction=EFC, ef=ef, seed=42)
     ix.reserve(base.shape[0])
     ix.set_add_batch(*plan)
