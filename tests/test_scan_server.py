@@ -55,9 +55,14 @@ def test_many_clients_are_batched_and_answers_routed(capi):
     [t.start() for t in ts]
     [t.join() for t in ts]
     st = srv.stats()
+    legs = srv.timing()
     srv.stop()
     assert not errs, errs
     assert len(got) == nthreads * per
+    # the per-leg clock (lantern_scan_server_timing): every answered request was timed once, and every leg took some time
+    assert legs["requests"] == nthreads * per
+    assert legs["wait_for_batch_us"] >= 0 and legs["batch_closed_to_answer_us"] > 0 and legs["answer_to_socket_us"] > 0
+    assert legs["wait_for_batch_us"] < 25_000 * 2  # never longer than the window allows (20 ms here)
     for ident, (lab, dst, k) in got.items():  # every client got ITS answer, in order, for ITS k and ef
         assert lab.tolist() == [ident * 1000 + j for j in range(k)]
         assert np.allclose(dst, np.arange(k) + (0.04 if k == 5 else 0.0))
