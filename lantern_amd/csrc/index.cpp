@@ -317,6 +317,30 @@ bool pad_row(const Index *ix, const void *vec, int kind_in, uint32_t *dst)
     return true;
 }
 
+// `count` caller rows into their padded, stored form (pad_row each).  A batch in the thousands is the host's largest share of a
+// lantern_gpu_search_batch call -- 8192 x 768-d rows are 25 MB through one core: 2.5 ms beside a 6.6 ms search -- so large batches are
+// split over a few short-lived threads (rows are independent; measured in round 5: one call at a time 0.77 -> see DESIGN.md 4.6b).
+static void pad_rows(const Index *ix, const void *rows, int kind, size_t count, uint32_t *padded)
+{
+    const size_t row_words = (size_t)ix->chunks * 4, in_bytes = input_bytes(ix, kind);
+    auto span = [&](size_t lo, size_t hi) {
+        for(size_t i = lo; i < hi; ++i) pad_row(ix, (const char *)rows + i * in_bytes, kind, &padded[ i * row_words ]);
+    };
+    const size_t bytes = count * row_words * 4;
+    size_t       T = bytes >= ((size_t)4 << 20) ? std::min<size_t>(4, count / 512) : 1;
+    if(T <= 1) { span(0, count); return; }
+    std::vector<std::thread> th;
+    size_t                   made = 0;  // threads 1 .. made exist; the calling thread takes share 0 and whatever got no thread
+    try {
+        th.reserve(T);
+        for(size_t t = 1; t < T; ++t, ++made) th.emplace_back(span, count * t / T, count * (t + 1) / T);
+    } catch(...) {
+    }
+    span(0, count / T);
+    if(made + 1 < T) span(count * (made + 1) / T, count);
+    for(auto &x : th) x.join();
+}
+
 // a zeroed work ticket for one launch on `stream` (ring: concurrent launches on different streams get different slots)
 static const uint32_t kTicketRing = 64;
 static uint32_t *next_ticket(Index *ix, size_t work, int grid, hipStream_t stream)
@@ -1812,9 +1836,8 @@ try {
     const int    W = comm->world, R = comm->rank;
     const size_t part = nq * k;
     const size_t row_words = (size_t)ix->chunks * 4;
-    const size_t in_bytes = input_bytes(ix, (int)kind);
     std::vector<uint32_t> padded(nq * row_words);
-    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
+    pad_rows(ix, queries, (int)kind, nq, padded.data());
     char *dq = (char *)scratch(ix, 5, nq * row_words * 4);
     // [W][nq][k] labels | [W][nq][k] distances | merged labels | merged distances | merged counts
     char *dall = (char *)scratch(ix, 6, (size_t)W * part * 12 + part * 12 + nq * 4 + 64);
@@ -2050,7 +2073,6 @@ try {
     std::lock_guard<std::mutex> g(ix->mu);
     if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
     const size_t row_words = (size_t)ix->chunks * 4;
-    const size_t in_bytes = input_bytes(ix, (int)kind);
     // queries and answers pass through one page-locked block: one copy up, one down (labels | distances | counts as they lie),
     // at the link's rate instead of through the runtime's staging of pageable memory
     const size_t q_bytes = nq * row_words * 4, out_bytes = nq * k * 12 + nq * 4;
@@ -2058,7 +2080,7 @@ try {
     if(!hs) { FAIL(e, "lantern_gpu: cannot allocate the page-locked staging block"); return; }
     uint32_t *const padded = (uint32_t *)hs;
     char *const     h_out = hs + ((q_bytes + 63) & ~(size_t)63);
-    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
+    pad_rows(ix, queries, (int)kind, nq, padded);
     char *dq = (char *)scratch(ix, 5, q_bytes);
     char *dout = (char *)scratch(ix, 6, out_bytes + 64);
     if(!dq || !dout) { FAIL(e, ix->err.c_str()); return; }
@@ -2096,7 +2118,6 @@ try {
     if(nq == 0 || k == 0) return;
     if(!queries || !labels || !distances) { FAIL(e, "lantern_gpu: null buffer"); return; }
     const size_t row_words = (size_t)ix->chunks * 4;
-    const size_t in_bytes = input_bytes(ix, (int)kind);
     // Queries and answers pass through ONE page-locked block per lane (a lane has one caller at a time): the padded queries go up
     // in one copy, labels + distances + counts come back in one, both at the link's rate and without the runtime's staging of
     // pageable memory (four copies of it before: ~40 us of a small batch's ~150).
@@ -2105,7 +2126,7 @@ try {
     if(!hs) { FAIL(e, "lantern_gpu: cannot allocate the lane's page-locked staging block"); return; }
     uint32_t *const padded = (uint32_t *)hs;  // (chunks and the scalar kind are fixed at init: no lock needed yet)
     char *const     h_out = hs + ((q_bytes + 63) & ~(size_t)63);
-    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
+    pad_rows(ix, queries, (int)kind, nq, padded);
     hipStream_t st = nullptr;
     bool        ok = true;
     // A lane's error text belongs to the calling thread: ix->err is shared by both lanes (and by every other entry point) and
@@ -2159,7 +2180,6 @@ try {
     if(nq == 0 || k == 0) return;
     if(!queries || !labels || !distances || !done) { FAIL(e, "lantern_gpu: null buffer or callback"); return; }
     const size_t row_words = (size_t)ix->chunks * 4;
-    const size_t in_bytes = input_bytes(ix, (int)kind);
     const size_t q_bytes = nq * row_words * 4, out_bytes = nq * k * 12 + nq * 4, flag_bytes = nq * 4;
     const size_t out_at = (q_bytes + 63) & ~(size_t)63, flag_at = (out_at + out_bytes + 63) & ~(size_t)63, need = flag_at + flag_bytes + 64;
     char *const  hs = host_stage(ix, lane, need);
@@ -2173,7 +2193,7 @@ try {
     uint32_t *const padded = (uint32_t *)hs;
     char *const     h_out = hs + out_at;
     uint32_t *const flags = (uint32_t *)(hs + flag_at);
-    for(size_t i = 0; i < nq; ++i) pad_row(ix, (const char *)queries + i * in_bytes, (int)kind, &padded[ i * row_words ]);
+    pad_rows(ix, queries, (int)kind, nq, padded);
     std::memset(flags, 0, flag_bytes);
     hipStream_t st = nullptr;
     bool        ok = true;

@@ -187,4 +187,14 @@ step_l() {
   timeout 900 python bench.py --dim 1536 --steps 5 --truth-queries 1000 --no-secondary > $OUT/bench_line_1Mx1536.json 2> $OUT/bench_1536.err
 }
 
-"step_${1:?usage: gpu_r05.sh <a..l>}"
+# m: host batches padded on a few threads: lantern_gpu_search_batch[_lane] at the headline shape, the tests that go through them
+step_m() {
+  cd "$GRAFT_REPO_ROOT" || exit 1
+  OUT=gpurun_out/r05p; mkdir -p $OUT
+  export TMPDIR=/tmp
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_scan_server.py tests/test_gpu_partitioned_search.py -m gpu -x -q -p no:cacheprovider > $OUT/tests.log 2>&1; echo "rc $?" >> $OUT/tests.log
+  timeout 600 python scripts/scan_load_headline.py --connections 256 > $OUT/scan_load.jsonl 2> $OUT/scan_load.err
+  LANTERN_BENCH_SECONDARY=headline_host_buffers timeout 600 python bench.py --no-pmc --no-cpu --build-quality-rows 0 --steps 5 > $OUT/bench_host_buffers.json 2> $OUT/bench.err
+}
+
+"step_${1:?usage: gpu_r05.sh <a..m>}"
