@@ -478,6 +478,39 @@ def test_lane_notify_hands_on_every_query_once_with_its_final_rows(capi, metric,
         assert len(calls) > 1, "a batch whose walks differ in length is handed on in more than one piece"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["one_wave_walk", "adc_table_walk"])
+def test_lane_notify_through_the_other_search_kernels(capi, monkeypatch, which):
+    """The per-query completion words are raised by every search kernel's tail: here the one-wave walk (k_search_solo,
+    LANTERN_GPU_SPEC=4) and the table walk over PQ code bytes (k_search_adc, a compact pq index with LANTERN_GPU_PQ_ADC=1)."""
+    rng = np.random.default_rng(77)
+    n, d, nq = 6000, 128, 200
+    base = rng.standard_normal((n, d), dtype=np.float32)
+    queries = rng.standard_normal((nq, d), dtype=np.float32)
+    if which == "one_wave_walk":
+        monkeypatch.setenv("LANTERN_GPU_SPEC", "4")
+        ix = capi.GpuIndex("l2sq", d, M=16, ef_construction=64, ef=48, seed=3)
+        ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+        ix.flush()
+    else:
+        monkeypatch.setenv("LANTERN_GPU_PQ_ADC", "1")
+        cb = np.zeros((64, d), dtype=np.float32)
+        for s in range(16):
+            cb[:, s * 8:(s + 1) * 8] = base[rng.choice(n, size=64, replace=False), s * 8:(s + 1) * 8]
+        ix = capi.GpuIndex("l2sq", d, M=16, ef_construction=64, ef=48, seed=3, pq_codebook=cb, num_subvectors=16)
+        ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+        ix.flush()
+        ix.pq_compact()
+    want_lab, want_dst, want_cnt = ix.search_batch(queries, 10)
+    before = ix.counters()["search_solo_launches"]
+    lab, dst, cnt, calls, snap = ix.search_batch_lane_notify(1, queries, 10)
+    assert np.array_equal(lab, want_lab) and np.array_equal(dst, want_dst) and np.array_equal(cnt, want_cnt)
+    assert sorted(j for c in calls for j in c) == list(range(nq))
+    assert all(np.array_equal(l, want_lab[j]) for j, (l, _, _) in snap.items())
+    if which == "one_wave_walk":
+        assert ix.counters()["search_solo_launches"] == before + 1
+
+
 def test_standalone_binary_fails_loudly_without_a_device_or_arguments(capi):
     import os
     import subprocess
