@@ -1251,8 +1251,9 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
             // 4: the ONE-WAVE walk (walk_solo.hpp): no barrier, no hand-over between waves -- f32 l2sq / cos rows of < 64 chunks,
             // M <= 16, ef <= 64, an index whose visited bitmap fits LDS.  ON REQUEST ONLY (LANTERN_GPU_SPEC=4, or LANTERN_GPU_SOLO=1 for
             // every launch it applies to): measured in round 5 on the lone 100k x 128 query it is SLOWER than the 3 + 8 wave shape --
-            // 152.6 us against 106.0 us per call, 2.20 against 1.53 us per hop -- because one wave has to issue all ~540 instructions
-            // of a hop itself; parity-green in every regime it takes.  Anything it does not take falls back to spec 2.
+            // 117.7 us against 102.0 us per query on one box (its first form: 152.6 against 106.0), 1.70 against 1.47 us per hop -- because
+            // one wave has to issue all ~540 instructions of a hop itself; parity-green in every regime it takes.
+            // Anything it does not take falls back to spec 2.
             static const bool solo_auto = std::getenv("LANTERN_GPU_SOLO") && std::atoi(std::getenv("LANTERN_GPU_SOLO")) != 0;
             if(spec == 2 && !se && solo_auto && nq <= (size_t)ix->num_cus) spec = 4;
             if(spec == 4) {

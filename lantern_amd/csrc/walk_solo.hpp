@@ -16,7 +16,9 @@
 //   * the merge of a hop's keys into the list happens in the shadow of the NEXT hop's row loads: the next node is
 //     min(first unexpanded list entry, smallest new key inside the radius), which needs no merged list.
 // Which node is expanded when, what the visited set holds at every filter and the order keys enter the list are the oracle's:
-// ids, distance bits, D and E are those of every other launch shape (tests/test_gpu_parity.py::test_latency_bound_walk_is_the_oracle_walk).
+// ids, distance bits, D and E are those of every other launch shape (tests/test_gpu_parity.py::test_one_wave_walk_is_the_oracle_walk).
+// MEASURED SLOWER than the 3 + 8 wave shape it was meant to beat (117.7 against 102.0 us per lone 100k x 128 query): one wave has to
+// issue a hop's ~540 instructions itself.  On request only (LANTERN_GPU_SPEC=4); DESIGN.md 4.3c has the section profile.
 #pragma once
 #include "device_common.hpp"
 #include "walk.hpp"
