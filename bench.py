@@ -335,7 +335,7 @@ def main():
     lanes = []  # one per query batch: its rows and outputs
     for i in range(B):
         qi = all_queries[i * nq:(i + 1) * nq]
-        lanes.append({"dq": hip.Buffer.from_numpy(hip.padded_rows(qi, False, a.quant == "f16", a.quant == "i8", a.quant == "b1")),
+        lanes.append({"dq": hip.Buffer.from_numpy(hip.padded_rows(qi, False, a.quant == "f16", a.quant == "i8", a.quant == "b1", row_bytes=ix.row_bytes())),
                       "lab": hip.Buffer(nq * a.k * 8), "dist": hip.Buffer(nq * a.k * 4), "slot": hip.Buffer(nq * a.k * 4),
                       "D": hip.Buffer(nq * 8), "E": hip.Buffer(nq * 8)})
     d_slot = lanes[0]["slot"]

@@ -328,6 +328,10 @@ LANTERN_GPU_EXPORT void lantern_gpu_export_codes(usearch_index_t, uint8_t *codes
 LANTERN_GPU_EXPORT void lantern_gpu_pq_compact(usearch_index_t, usearch_error_t *);
 LANTERN_GPU_EXPORT void lantern_gpu_pq_expand(usearch_index_t, usearch_error_t *);
 /* HBM held by the index: the vector block (the code rows of a compact pq index) | adjacency, labels, levels, norms, codes */
+/* bytes of one stored row in device memory = the row stride of `d_queries` in lantern_gpu_search_batch_device: the vector zero padded
+ * to whole 16-byte chunks, and bit rows of 65 .. 127 bytes (768 bits: quant_bits = 1 at 768 dimensions, hamming over integer[24]) to 128 --
+ * one cache line per row instead of a line and a piece of the next (usearch_storage.cpp:29-31 sizes the ON-TAPE vector; this is HBM only) */
+LANTERN_GPU_EXPORT size_t lantern_gpu_row_bytes(usearch_index_t, usearch_error_t *);
 LANTERN_GPU_EXPORT void lantern_gpu_memory_usage(usearch_index_t, size_t *row_bytes, size_t *other_bytes, usearch_error_t *);
 LANTERN_GPU_EXPORT void lantern_gpu_import_graph(usearch_index_t, size_t size, const void *vectors,
                                                  const uint64_t *labels, const uint8_t *levels, const uint32_t *nbr0,

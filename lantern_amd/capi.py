@@ -97,7 +97,7 @@ EXPORTS = [
     "lantern_gpu_graph_checksum", "lantern_gpu_comm_unique_id", "lantern_gpu_comm_init_rccl", "lantern_gpu_comm_init_host",
     "lantern_gpu_comm_init_local", "lantern_gpu_comm_free", "lantern_gpu_comm_rank", "lantern_gpu_comm_world",
     "lantern_gpu_comm_set_timeout", "lantern_gpu_comm_stats", "lantern_gpu_comm_allgatherv_host",
-    "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded", "lantern_gpu_add_row_sharded", "lantern_gpu_search_partitioned", "lantern_gpu_search_batch_lane", "lantern_gpu_search_batch_lane_notify",
+    "lantern_gpu_comm_allgatherv_device", "lantern_gpu_shard_range", "lantern_gpu_add_sharded", "lantern_gpu_add_row_sharded", "lantern_gpu_search_partitioned", "lantern_gpu_search_batch_lane", "lantern_gpu_search_batch_lane_notify", "lantern_gpu_row_bytes",
     "lantern_gpu_level_for", "lantern_gpu_plan_batch", "lantern_gpu_row_shard_plan",
     "lantern_scan_server_start", "lantern_scan_server_start_fn", "lantern_scan_server_port", "lantern_scan_server_stats",
     "lantern_scan_server_batch_histogram", "lantern_scan_server_timing", "lantern_scan_server_stop", "lantern_scan_client_connect", "lantern_scan_client_search", "lantern_scan_client_search_next",
@@ -220,6 +220,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_add_sharded": (None, [vp, vp, vp, vp, sz, i32, err]),
         "lantern_gpu_add_row_sharded": (None, [vp, vp, vp, vp, sz, i32, err]),
         "lantern_gpu_search_partitioned": (None, [vp, vp, vp, sz, i32, sz, sz, vp, vp, vp, err]),
+        "lantern_gpu_row_bytes": (sz, [vp, err]),
         "lantern_gpu_search_batch_lane": (None, [vp, i32, vp, sz, i32, sz, sz, vp, vp, vp, err]),
         "lantern_gpu_search_batch_lane_notify": (None, [vp, i32, vp, sz, i32, sz, sz, vp, vp, vp, vp, vp, err]),
         "lantern_gpu_level_for": (i32, [u64, u64, u32]),
@@ -464,6 +465,10 @@ class GpuIndex:
 
     def pq_expand(self):
         _call("lantern_gpu_pq_expand", self.h)
+
+    def row_bytes(self) -> int:
+        """Bytes of one stored row in device memory: the stride of device-resident queries (hip.padded_rows(..., row_bytes=))."""
+        return int(_call("lantern_gpu_row_bytes", self.h))
 
     def memory_usage(self):
         """(bytes of the vector block or of a compact pq index's code rows, bytes of everything else that grows with the nodes)"""

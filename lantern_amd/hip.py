@@ -129,7 +129,16 @@ class Event:
         return float(ms.value)
 
 
-def padded_rows(x: np.ndarray, metric_is_hamming: bool, f16: bool = False, i8: bool = False, b1: bool = False) -> np.ndarray:
+def padded_rows(x: np.ndarray, metric_is_hamming: bool, f16: bool = False, i8: bool = False, b1: bool = False, row_bytes: int | None = None) -> np.ndarray:
+    out = _padded_rows(x, metric_is_hamming, f16, i8, b1)
+    if row_bytes is not None and out.shape[1] * out.itemsize < row_bytes:  # the index stores its rows at a wider stride (GpuIndex.row_bytes())
+        wide = np.zeros((out.shape[0], row_bytes // out.itemsize), dtype=out.dtype)
+        wide[:, : out.shape[1]] = out
+        out = wide
+    return out
+
+
+def _padded_rows(x: np.ndarray, metric_is_hamming: bool, f16: bool = False, i8: bool = False, b1: bool = False) -> np.ndarray:
     """Rows in STORAGE format, zero-padded to whole 16-byte chunks: the layout the device entry points expect
     (u32 words for hamming, f32, halves for an f16 index: the cast is round-to-nearest-even, or bytes for an i8
     index: trunc(clamp(x * 100, -100, 100)), the library's own rule for f32 input)."""

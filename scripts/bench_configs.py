@@ -31,7 +31,7 @@ def build(metric, base, M=16, efc=128, ef=64):
 
 def batch_qps(ix, queries, k, ef, steps=10, waves=4, ham=False):
     nq = queries.shape[0]
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, ham))
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, ham, row_bytes=ix.row_bytes()))
     lab, dist, slot = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4), hip.Buffer(nq * k * 4)
     Dv, Ev = hip.Buffer(nq * 8), hip.Buffer(nq * 8)
     st = hip.Stream()

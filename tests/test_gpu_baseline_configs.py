@@ -31,7 +31,7 @@ def env():
 
 def device_batch(hip, ix, queries, k, ef, ham=False, waves=4):
     nq = queries.shape[0]
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, ham))
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, ham, row_bytes=ix.row_bytes()))
     lab, dist, slot = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4), hip.Buffer(nq * k * 4)
     cnt, Dv, Ev = hip.Buffer(nq * 4), hip.Buffer(nq * 8), hip.Buffer(nq * 8)
     ix.set_search_shape(waves)

@@ -101,7 +101,7 @@ def test_search_matches_oracle_on_same_graph(capi, oracle, metric, n, d, M, efc,
     o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, k)
     from lantern_amd import hip
 
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, metric == "hamming"))
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, metric == "hamming", row_bytes=gpu.row_bytes()))
     lab, dist, slot = hip.Buffer(64 * k * 8), hip.Buffer(64 * k * 4), hip.Buffer(64 * k * 4)
     cnt, D, E = hip.Buffer(64 * 4), hip.Buffer(64 * 8), hip.Buffer(64 * 8)
     for waves in (1, 4, 8):
@@ -721,7 +721,7 @@ def test_latency_bound_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef
     k = min(10, ef)
     o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(oq, k, ef, 4)
     monkeypatch.setenv("LANTERN_GPU_SPEC", spec)
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, metric == "hamming", quant == "f16", quant == "i8"))
+    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, metric == "hamming", quant == "f16", quant == "i8", row_bytes=gpu.row_bytes()))
     lab, dist, D, E = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4), hip.Buffer(nq * 8), hip.Buffer(nq * 8)
     gpu.set_search_shape(0)  # the automatic shape: LANTERN_GPU_SPEC decides
     gpu.search_batch_device(dq.ptr, nq, k, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr)
