@@ -114,3 +114,23 @@ def test_level_draw_and_batch_plan_agree_with_the_oracle(capi):
         got = capi.plan_batch(size, max_level, pending, mb, mr)
         assert got == oracle.plan_batch(size, max_level, pending, mb, mr)
         assert 1 <= got <= min(len(pending), mb)
+
+
+def test_padded_rows_take_the_index_stride():
+    """hip.padded_rows(..., row_bytes=GpuIndex.row_bytes()): device-resident queries of an index whose bit rows sit at a 128-byte
+    stride (768 bits = 96 bytes of data) are zero padded to it; rows that already fill their stride are left alone."""
+    import numpy as np
+
+    from lantern_amd import hip
+
+    bits = np.arange(5 * 24, dtype=np.uint32).reshape(5, 24)
+    plain = hip.padded_rows(bits, True)
+    wide = hip.padded_rows(bits, True, row_bytes=128)
+    assert plain.shape == (5, 24) and wide.shape == (5, 32) and wide.dtype == np.uint32
+    assert np.array_equal(wide[:, :24], bits) and not wide[:, 24:].any()
+    f = np.ones((3, 768), dtype=np.float32)
+    assert hip.padded_rows(f, False, row_bytes=3072).shape == (3, 768)
+    x = np.ones((2, 768), dtype=np.float32)
+    x[0, ::2] = -1.0
+    b = hip.padded_rows(x, False, b1=True, row_bytes=128)
+    assert b.shape == (2, 128) and b.dtype == np.uint8 and b[0, 0] == 0b01010101 and b[1, 95] == 255 and not b[:, 96:].any()
