@@ -15,7 +15,7 @@ namespace lgpu {
 // the next lower level is connect_new_node_'s first pick: the closest result under (distance, tie_mix).
 template <int METRIC, int G, int KPL = 2>  // KPL: as k_search (keys per lane of wave 0's register list; 0 = LDS list)
 #ifndef LGPU_INSERT_MIN_BLOCKS
-#define LGPU_INSERT_MIN_BLOCKS 6  // (measured: 5 and 4 -- 81 / 90 registers, no spills -- build at the same speed)
+#define LGPU_INSERT_MIN_BLOCKS 6  // (measured: 5 and 4 -- 81 / 90 registers, no spills -- build at the same speed; DESIGN_HISTORY.md H.2 item 1)
 #endif
 __global__ void __launch_bounds__(512, LGPU_INSERT_MIN_BLOCKS) k_insert(InsertArgs a)
 {

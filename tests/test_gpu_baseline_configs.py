@@ -178,7 +178,7 @@ _SEQ_GRAPHS = {}  # the sequential reference build of a set is the same for ever
 
 
 @pytest.mark.parametrize("name,plan", [("c2_gaussian_100k_x_128", (8192, 16)), ("clustered_100k_x_768", (8192, 16)),
-                                       # the larger plan DESIGN 8.0 measures as faster: batches of up to 16 384 rows, still never more than
+                                       # the larger plan DESIGN_HISTORY H.2 item 0 measures as faster: batches of up to 16 384 rows, still never more than
                                        # size / 16 -- full batches from 262k rows on, so the set has 400k.  (What does NOT hold the bar is a
                                        # smaller RATIO: plan (16384, 4) on the 100k set builds batches of a quarter of the graph and loses
                                        # 0.0115 of recall -- 0.4505 against 0.4620, measured in round 5 -- which is why min_ratio stays 16.)

@@ -62,7 +62,7 @@ CASES = {
     "gaussian_60k_x_768_cos": ("cos", 3, 60_000, 768, (8192, 8)),
     "c5_gaussian_64k_x_1536_l2sq": ("l2sq", 7, 65_536, 1536, (8192, 4)),           # SURVEY 8d C5 rows (seed 7), 6 KiB rows: k_connect's widest register path,
                                                                                    # k_revlink_pairs at 384 chunks; full 8192-row batches from 32k rows on
-    # the larger plans DESIGN 8.0 measures as faster (564 / 575 k vectors/s): tested options, not only measured ones
+    # the larger plans DESIGN_HISTORY H.2 item 0 measures as faster (564 / 575 k vectors/s): tested options, not only measured ones
     "gaussian_160k_x_768_l2sq_plan16384": ("l2sq", 3, 160_000, 768, (16384, 16)),  # batches keep growing past 8192 (to size / 16 = 10 000)
     "gaussian_160k_x_768_l2sq_plan16384_ratio4": ("l2sq", 3, 160_000, 768, (16384, 4)),  # full 16 384-row batches from 65k rows on
 }
