@@ -692,30 +692,14 @@ def build_quality(a):
             "device_build_seconds": t_dev, "sequential_cpu_build_seconds": t_seq, "sequential_cpu_build_vectors_per_s": n / t_seq}
 
 
-def usable_cores() -> int:
-    """Threads this process may really use: the affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, int(q / p + 0.5)))
-        except Exception:
-            pass
-    return n
-
-
 def cpu_baseline(a, ix, base, queries, gpu_found):
     """The oracle (CPU port of the usearch path) on the identical graph, on this host's cores."""
     from oracle import binding as oracle
 
+    import bench_cpu
+
     native = oracle.build_native() and oracle.use_native(True)  # best CPU code for the baseline: -march=native on this host
-    cores = usable_cores()
+    cores = bench_cpu.usable_cores()
     g = ix.export_graph()
     mode = oracle.SUM_FAST
     if a.quant == "f16":  # the CPU port works on the rounded values (f32 arithmetic, no conversion cost: favours the CPU)
@@ -733,31 +717,8 @@ def cpu_baseline(a, ix, base, queries, gpu_found):
         base, queries, metric = pack(base), pack(queries), "hamming"
         dim = base.shape[1]
     ora = oracle.OracleIndex.from_graph(metric, base, g, a.M, a.efc, a.ef, 42, mode)
-    # size the samples from a short probe so the whole leg stays near the budget (about 30 % of it
-    # for the 1-thread leg, 70 % for the all-cores leg).  The all-cores sample cycles through the
-    # step's query set: 256 threads need >10^5 queries to reach steady state (each thread first
-    # faults in its own visited-set array), far more than one GPU step holds.
-    probe = min(64, queries.shape[0])
-    t0 = time.perf_counter()
-    ora.search_batch(queries[:probe], a.k, a.ef, 1)
-    per_q_1t = (time.perf_counter() - t0) / probe
-    n1 = int(max(16, min(queries.shape[0], (a.cpu_seconds * 0.3) / per_q_1t)))
-    t0 = time.perf_counter()
-    ora.search_batch(queries[:n1], a.k, a.ef, 1)
-    qps_1t = n1 / (time.perf_counter() - t0)
-    # a short all-cores probe sizes the timed all-cores sample (parallel efficiency is host-dependent)
-    pq = np.ascontiguousarray(np.tile(queries, (max(1, (cores * 32) // queries.shape[0] + 1), 1))[: cores * 32])
-    t0 = time.perf_counter()
-    ora.search_batch(pq, a.k, a.ef, cores)
-    qps_probe = pq.shape[0] / (time.perf_counter() - t0)
-    want = int(a.cpu_seconds * 0.6 * qps_probe)
-    reps = int(max(1, min(64, -(-want // queries.shape[0]))))
-    tiled = np.ascontiguousarray(np.tile(queries, (reps, 1)))
-    nall = tiled.shape[0]
-    t0 = time.perf_counter()
-    _, _, slots, _, _ = ora.search_batch(tiled, a.k, a.ef, cores)
-    qps_all = nall / (time.perf_counter() - t0)
-    del tiled
+    # 1 thread and all cores, three timed repetitions each, median reported (bench_cpu.py)
+    rates, slots = bench_cpu.search_rates(ora, queries, a.k, a.ef, a.cpu_seconds, cores)
     # index build on the CPU: the port's sequential usearch_add (a PostgreSQL backend builds with one thread,
     # utils.c:66) on a bounded prefix of the same rows.  The rate falls as the graph grows, so this flatters the CPU.
     nb = int(min(base.shape[0], 4096))
@@ -766,15 +727,13 @@ def cpu_baseline(a, ix, base, queries, gpu_found):
     cb.add_many(np.arange(nb, dtype=np.uint64) + 1, base[:nb])
     cpu_build = nb / (time.perf_counter() - t0)
     del cb
-    m = min(nall, gpu_found.shape[0], queries.shape[0])
+    m = min(slots.shape[0], gpu_found.shape[0], queries.shape[0])
     agree = float(np.mean([len(set(x.tolist()) & set(y.tolist())) / a.k for x, y in zip(slots[:m], gpu_found[:m])]))
-    return {"value": qps_all, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{nall} queries (the step's {queries.shape[0]} cycled x{reps}) on {cores} threads, one query per thread "
-                      f"(server.rs:317-359 model); {n1} queries on 1 thread (a PostgreSQL backend, utils.c:66)",
-            "value_1_thread": qps_1t, "topk_overlap_with_gpu": agree,
-            "build_vectors_per_s_1_thread": cpu_build, "build_sample": f"first {nb} rows, sequential usearch_add",
-            "build": "gcc -O3 -march=native + the reference's -fassociative-math flags" if native else "gcc -O3 -march=x86-64-v3 + the reference's -fassociative-math flags",
-            "note": "oracle/hnsw.c restates the usearch algorithm; the reference binary itself cannot be built here"}
+    rates.update({"topk_overlap_with_gpu": agree,
+                  "build_vectors_per_s_1_thread": cpu_build, "build_sample": f"first {nb} rows, sequential usearch_add",
+                  "build": bench_cpu.port_build_note(native),
+                  "note": "oracle/hnsw.c restates the usearch algorithm; the reference binary itself cannot be built here"})
+    return rates
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ ways the same hot path is called under the same (driver's) clock:
 
 Every entry: `workload`, `value` + `unit`, `ms_per_step`, `recall_at_10`, `roofline` (algorithmic bytes of SURVEY 8d with D / E
 counted on the device; counter bytes where exactly one launch is in flight and the pass is affordable), `cpu_baseline` (the CPU
-port on ONE thread on the same graph -- a PostgreSQL backend, utils.c:66).  The oracle is used as the baseline only.
+port on the same graph, on ONE thread -- a PostgreSQL backend, utils.c:66 -- and on all cores; median of three repetitions each).  The oracle is used as the baseline only.
 """
 from __future__ import annotations
 
@@ -53,24 +53,20 @@ def _build(capi, hip, metric, base, a):
     return ix, time.perf_counter() - t0
 
 
-def _cpu_one_thread(ix, base, queries, metric, a, seconds=4.0):
-    """The CPU port on ONE thread on the identical graph: queries/s and microseconds per query on a bounded sample."""
+def _cpu_port(ix, base, queries, metric, a, seconds=4.0):
+    """The CPU port on the identical graph, 1 thread and all cores: three timed repetitions each, median reported (bench_cpu.py)."""
+    import bench_cpu
     from oracle import binding as oracle
 
     native = oracle.build_native() and oracle.use_native(True)
     ora = oracle.OracleIndex.from_graph(metric, base, ix.export_graph(), a.M, a.efc, a.ef, 42, oracle.SUM_FAST)
-    probe = min(32, queries.shape[0])
-    ora.search_batch(queries[:probe], a.k, a.ef, 1)
-    t0 = time.perf_counter()
-    ora.search_batch(queries[:probe], a.k, a.ef, 1)
-    per_q = (time.perf_counter() - t0) / probe
-    n = int(max(probe, min(queries.shape[0], seconds / max(per_q, 1e-9))))
-    t0 = time.perf_counter()
-    _, _, slots, _, _ = ora.search_batch(queries[:n], a.k, a.ef, 1)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "queries/s", "us_per_query": dt / n * 1e6, "cores": 1, "kind": "port",
-            "sample": f"{n} queries of this workload on 1 thread (a PostgreSQL backend, utils.c:66), same graph",
-            "build": "gcc -O3 -march=native + the reference's -fassociative-math flags" if native else "gcc -O3 -march=x86-64-v3 + the reference's flags"}, slots
+    rates, slots = bench_cpu.search_rates(ora, queries, a.k, a.ef, seconds)
+    rates["build"] = bench_cpu.port_build_note(native)
+    return rates, slots
+
+
+def _over_cpu(value, cpu):
+    return {"gpu_over_cpu_1_thread": value / cpu["value_1_thread"], "gpu_over_cpu_all_cores": value / cpu["value"]}
 
 
 class _Batches:
@@ -149,7 +145,7 @@ def c2_one_query_per_call(a, capi, hip):
         Ds.append(int(d_D.download(1, np.uint64)[0]))
         Es.append(int(d_E.download(1, np.uint64)[0]))
     truth, _ = ix.exact_search(queries[:512], a.k)
-    cpu, _ = _cpu_one_thread(ix, base, queries, "l2sq", a, seconds=1.0)
+    cpu, _ = _cpu_port(ix, base, queries, "l2sq", a, seconds=3.0)
     bytes_q = float(np.mean(Ds)) * d * 4 + float(np.mean(Es)) * (2 * a.M * 4) + d * 4
     gbs = bytes_q / (float(np.mean(kern)) * 1e-6) / 1e9
     return {"name": "c2_one_query_per_call",
@@ -162,7 +158,7 @@ def c2_one_query_per_call(a, capi, hip):
             "roofline": dict({"bound": "latency (one dependent hop chain; HBM fraction shown for scale)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "algorithmic_bytes_per_launch": bytes_q, "avg_launch_ms": float(np.mean(kern)) / 1e3, "kernel": "k_search_spec (walk_spec.hpp), one query",
                               "traffic": None}, **fractions(gbs)),
-            "cpu_baseline": cpu, "gpu_over_cpu_1_thread": (nq / t_all) / cpu["value"], "build_vectors_per_s": n / t_build}
+            "cpu_baseline": cpu, **_over_cpu(nq / t_all, cpu), "build_vectors_per_s": n / t_build}
 
 
 def c3_cosine_1024_batches(a, capi, hip, base):
@@ -182,7 +178,7 @@ def c3_cosine_1024_batches(a, capi, hip, base):
     two = _Batches(hip, ix, queries, nq, a, streams=2)
     elapsed2, _ = two.timed(steps)
     gbs2 = bytes_l * steps / elapsed2 / 1e9
-    cpu, _ = _cpu_one_thread(ix, base, queries[:nq], "cos", a, seconds=3.0)
+    cpu, _ = _cpu_port(ix, base, queries[:nq], "cos", a, seconds=5.0)
     out.update({"value": nq * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "step": "one 1024-query launch, one launch in flight",
                 "two_launches_in_flight": {"value": nq * steps / elapsed2, "ms_per_step": elapsed2 / steps * 1e3,
                                            "roofline": dict({"achieved": gbs2, "unit": "GB/s", "basis": "all launches' algorithmic bytes / the timed region"}, **fractions(gbs2))},
@@ -192,7 +188,7 @@ def c3_cosine_1024_batches(a, capi, hip, base):
                                   "avg_launch_ms": float(np.mean(kms)), "kernel": "k_search", "traffic": None,
                                   "basis": "ALGORITHMIC bytes (SURVEY 8d; D / E counted on the device) / HIP-event launch time; the counter passes of this shape: profiles/r04_bench_line_cos_q1024.json"},
                                  **fractions(gbs1)),
-                "cpu_baseline": cpu, "gpu_over_cpu_1_thread": (nq * steps / elapsed) / cpu["value"], "build_vectors_per_s": n / t_build})
+                "cpu_baseline": cpu, **_over_cpu(nq * steps / elapsed, cpu), "build_vectors_per_s": n / t_build})
     return out
 
 
@@ -214,7 +210,7 @@ def clustered_headline_shape(a, capi, hip, measure_traffic):
     tq = min(1024, nq)
     truth, _ = ix.exact_search(queries[:tq], a.k)
     found = run.lanes[0]["slot"].download((nq, a.k), np.uint32)[:tq]
-    cpu, _ = _cpu_one_thread(ix, base, queries[:nq], a.metric, a, seconds=3.0)
+    cpu, _ = _cpu_port(ix, base, queries[:nq], a.metric, a, seconds=9.0)
     traffic = src = None
     if measure_traffic is not None:
         import copy
@@ -233,7 +229,7 @@ def clustered_headline_shape(a, capi, hip, measure_traffic):
             "workload": f"HNSW search {n}x{d} f32 {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}, {nq}-query batches resident in HBM, CLUSTERED set ({synth.CLUSTERED_DOC})",
             "value": nq * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "step": f"one {nq}-query launch",
             "recall_at_10": _recall(found, truth, a.k), "recall_queries": tq, "dist_evals_per_query": Dm, "expansions_per_query": Em,
-            "roofline": roof, "cpu_baseline": cpu, "gpu_over_cpu_1_thread": (nq * steps / elapsed) / cpu["value"], "build_vectors_per_s": n / t_build}
+            "roofline": roof, "cpu_baseline": cpu, **_over_cpu(nq * steps / elapsed, cpu), "build_vectors_per_s": n / t_build}
 
 
 def headline_host_buffers(a, ix, queries, device_resident_qps, headline_recall):

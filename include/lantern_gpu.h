@@ -488,6 +488,10 @@ LANTERN_GPU_EXPORT void lantern_scan_rescan(lantern_scan_t *, const void *query,
 /* ldb_amgettuple: true and *label set while tuples remain.  Skips label 0 (deleted, scan.c:296-300),
  * doubles k through the streaming continuation (scan.c:240-292), stops at 1000 rows (:249-252). */
 LANTERN_GPU_EXPORT bool lantern_scan_gettuple(lantern_scan_t *, usearch_label_t *label, usearch_error_t *);
+/* The k of every usearch_search_ef the scan has issued since its last rescan, in order -- the sequence the reference logs as
+ * "LANTERN querying index for %d elements" (scan.c:219, :272; pinned by test/expected/hnsw_select.out:76-140: 10 | 4, 8, 8).
+ * Writes min(n, cap) values to ks (may be NULL), returns n. */
+LANTERN_GPU_EXPORT size_t lantern_scan_trace(lantern_scan_t *, int *ks, size_t cap);
 LANTERN_GPU_EXPORT void lantern_scan_end(lantern_scan_t *);
 
 /* ------------------------------------------------------------------------------------------ */

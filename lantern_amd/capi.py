@@ -90,7 +90,7 @@ EXPORTS = [
     "lantern_gpu_host_alloc", "lantern_gpu_host_free", "lantern_gpu_save_stream", "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile", "lantern_gpu_search_unique_rows",
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_export_codes",
-    "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_gpu_search_phase_profile", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_end",
+    "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_gpu_search_phase_profile", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_trace", "lantern_scan_end",
     "lantern_l2sq_dist", "lantern_cos_dist", "lantern_hamming_dist", "lantern_index_server_start", "lantern_index_server_start_tls",
     "lantern_index_server_port", "lantern_index_server_status_port", "lantern_index_server_status",
     "lantern_index_server_served", "lantern_index_server_stop",
@@ -193,6 +193,7 @@ def lib() -> C.CDLL:
         "lantern_scan_begin": (vp, [vp, i32, i32, err]),
         "lantern_scan_rescan": (None, [vp, vp, i32, err]),
         "lantern_scan_gettuple": (C.c_bool, [vp, C.POINTER(u64), err]),
+        "lantern_scan_trace": (sz, [vp, vp, sz]),
         "lantern_scan_end": (None, [vp]),
         "lantern_l2sq_dist": (f32, [vp, i32, vp, i32, err]),
         "lantern_cos_dist": (f32, [vp, i32, vp, i32, err]),
@@ -937,6 +938,13 @@ class Scan:
         ok = lib().lantern_scan_gettuple(self.s, C.byref(label), C.byref(err))
         _check(err)
         return int(label.value) if ok else None
+
+    def trace(self):
+        """The k of every usearch_search_ef issued since the last rescan ("querying index for %d elements", scan.c:219, :272)."""
+        n = lib().lantern_scan_trace(self.s, None, 0)
+        ks = (C.c_int * max(n, 1))()
+        lib().lantern_scan_trace(self.s, ks, n)
+        return [int(ks[i]) for i in range(n)]
 
     def fetch(self, limit):
         out = []

@@ -33,6 +33,8 @@ struct lantern_scan
     std::vector<float>     distances;         // HnswScanState.distances
     std::vector<usearch_label_t> labels;      // HnswScanState.labels
     int                    count = 0, current = 0;  // HnswScanState.count / .current
+    std::vector<int>       k_trace;           // the k of every usearch_search_ef this scan issued since its last rescan: what the
+                                              // reference logs as "querying index for %d elements" (scan.c:219, :272)
 };
 
 static const usearch_label_t INVALID_ELEMENT_LABEL = 0;  // lantern_hnsw/src/hnsw.h:40
@@ -42,6 +44,7 @@ static size_t scan_search(lantern_scan *s, size_t k, bool streaming, usearch_err
 {
     s->distances.resize(k);
     s->labels.resize(k);
+    s->k_trace.push_back((int)k);
     if(s->client)
         return streaming ? lantern_scan_client_search_next(s->client, s->query.data(), s->query.size(), k, (size_t)s->ef, s->labels.data(),
                                                            s->distances.data(), err)
@@ -97,6 +100,7 @@ try {
     s->first = true;  // ldb_amrescan: scanstate->first = true (scan.c:150)
     s->armed = true;
     s->count = s->current = 0;
+    s->k_trace.clear();
 }
 LANTERN_ABI_CATCH_VOID(e)
 
@@ -135,6 +139,14 @@ try {
     return false;
 }
 LANTERN_ABI_CATCH(e)
+
+size_t lantern_scan_trace(lantern_scan_t *s, int *ks, size_t cap)
+try {
+    if(!s) return 0;
+    for(size_t i = 0; i < s->k_trace.size() && i < cap && ks; i++) ks[ i ] = s->k_trace[ i ];
+    return s->k_trace.size();
+}
+LANTERN_ABI_CATCH(nullptr)
 
 void lantern_scan_end(lantern_scan_t *s)
 try {

@@ -16,8 +16,10 @@ class Scan:
         self.first = True
         self.labels, self.count, self.current = [], 0, 0
         self.seen = set()
+        self.k_trace = []  # "LANTERN querying index for %d elements" (scan.c:219, :272)
 
     def _next_batch(self, k, streaming):
+        self.k_trace.append(k)
         if not streaming:
             self.seen.clear()
         want = min(len(self.seen) + k, self.index_size)
@@ -56,11 +58,14 @@ class Scan:
         return None
 
 
-def scan(search, index_size, limit, init_k=10):
+def scan(search, index_size, limit, init_k=10, trace=None):
+    """`limit` rows the way the executor pulls them; `trace` (a list) receives the k of every search the scan issued."""
     s, out = Scan(search, index_size, init_k), []
     while len(out) < limit:
         label = s.gettuple()
         if label is None:
             break
         out.append(label)
+    if trace is not None:
+        trace.extend(s.k_trace)
     return out

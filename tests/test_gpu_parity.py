@@ -221,6 +221,34 @@ def test_golden_streaming_and_pagination_on_device(capi, golden):
     assert len(got) == p["limit"] and len(set(got)) == len(got)
 
 
+def test_golden_scan_k_trace_expression_index_and_unlogged_insert_on_device(capi, golden):
+    """The reference's own trace of usearch_search_ef calls per scan (hnsw_select.out:76-140: 10 | 10 | 4 | 4, 8, 8 and the counts
+    3 / 8) asserted on the C++ shim (csrc/scan_shim.cpp vs scan.c:167-338); hnsw_create_expr.out:90-94; hnsw_insert_unlogged.out:62-92."""
+    g, sw = golden["scan_k_trace"], golden["small_world"]
+    ix = gpu_build(capi, "l2sq", sw["v"], M=g["index"]["M"], efc=g["index"]["ef_construction"], ef=g["index"]["ef"])
+    for c in g["cases"]:
+        s = capi.Scan(ix, init_k=c["init_k"])
+        s.rescan(g["query"])
+        got = s.fetch(c["limit"])
+        assert len(got) == c["count"] and len(set(got)) == len(got), c
+        assert s.trace() == c["k_trace"], c
+        s.rescan(g["query"])  # ldb_amrescan starts a new trace
+        assert s.trace() == []
+        s.end()
+    e = golden["create_expr"]
+    ix = capi.GpuIndex("l2sq", 3, M=e["M"], seed=7)
+    ix.add_many([i + LABEL0 for i in e["ids"]], np.asarray(e["v"], dtype=np.float32))
+    assert [l - LABEL0 for l in ordered(capi, ix, e["query"], e["limit"])] == e["expect_ids"]
+    u = golden["insert_unlogged"]
+    ix = gpu_build(capi, "l2sq", sw["v"])
+    ix.add(100, u["inserted"])
+    with pytest.raises(capi.LanternGpuError, match=u["wrong_dim_error"]):
+        ix.add(101, u["wrong_dim_row"])
+    rows = sw["v"] + [u["inserted"]]
+    order = ordered(capi, ix, u["query"], 20)
+    assert [round(capi.l2sq_dist(rows[8 if l == 100 else l - LABEL0], u["query"]), 2) for l in order] == u["sorted_2dp"]
+
+
 def test_golden_insert_dimension_errors_and_misc(capi, golden):
     sw = golden["small_world"]
     ix = gpu_build(capi, "l2sq", sw["v"])

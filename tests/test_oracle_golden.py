@@ -128,6 +128,36 @@ def test_streaming_continuation_counts(oracle, golden):
     assert len(got) == g["limit_15_count"] and len(set(got)) == len(got)
 
 
+def test_scan_issues_the_reference_sequence_of_searches(oracle, golden):
+    """hnsw_select.out:76-140: the reference logs every usearch_search_ef of a scan ("querying index for %d elements"): one search
+    of init_k = 10 for LIMIT 3 and for LIMIT 15 (8 rows: index_size == current ends the scan, scan.c:254-256); with init_k = 4,
+    LIMIT 15 takes 4, then 8 (the 4 remaining rows), then 8 again (returns nothing: scan ends) -- and the counts 3 / 8."""
+    g, sw = golden["scan_k_trace"], golden["small_world"]
+    ix = build(oracle, "l2sq", sw["v"], M=g["index"]["M"], efc=g["index"]["ef_construction"], ef=g["index"]["ef"])
+    for c in g["cases"]:
+        trace = []
+        got = scan(lambda k: ix.search(g["query"], k), len(ix), c["limit"], init_k=c["init_k"], trace=trace)
+        assert len(got) == c["count"] and len(set(got)) == len(got), c
+        assert trace == c["k_trace"], c
+
+
+def test_index_on_an_expression(oracle, golden):
+    g = golden["create_expr"]  # hnsw_create_expr.out:90-94
+    ix = oracle.OracleIndex("l2sq", 3, M=g["M"], seed=7)
+    ix.add_many(np.asarray(g["ids"], dtype=np.uint64) + LABEL0, np.asarray(g["v"], dtype=np.float32))
+    got = scan(lambda k: ix.search(g["query"], k), len(ix), g["limit"])
+    assert [l - LABEL0 for l in got] == g["expect_ids"]
+
+
+def test_insert_into_unlogged_index(oracle, golden):
+    g, sw = golden["insert_unlogged"], golden["small_world"]  # hnsw_insert_unlogged.out:62-92
+    ix = build(oracle, "l2sq", sw["v"])
+    ix.add(100, g["inserted"])
+    rows = sw["v"] + [g["inserted"]]
+    order = ordered(oracle, ix, g["query"], 20)
+    assert [round(oracle.distance(rows[8 if l == 100 else l - LABEL0], g["query"], "l2sq"), 2) for l in order] == g["sorted_2dp"]
+
+
 def test_insert_then_search(oracle, golden):
     g, sw = golden["insert_then_search"], golden["small_world"]
     ix = build(oracle, "l2sq", sw["v"])
