@@ -35,6 +35,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# This process is the launcher of the scan-service leg (bench_secondary.headline_scan_service: four dispatcher lanes, a stream each):
+# give the HIP runtime a hardware queue per lane before it initialises (lantern_amd/csrc/index.cpp)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_CEILING_GBS = 6290.0  # same guide: "6.29 TB/s measured (float4 copy, 79 %)" -- what a pure DRAM stream reaches
@@ -335,14 +338,17 @@ def main():
     lanes = []  # one per query batch: its rows and outputs
     for i in range(B):
         qi = all_queries[i * nq:(i + 1) * nq]
-        lanes.append({"dq": hip.Buffer.from_numpy(hip.padded_rows(qi, False, a.quant == "f16", a.quant == "i8", a.quant == "b1", row_bytes=ix.row_bytes())),
+        rows_i = ix.device_query_rows(qi)  # the index's own storage format and row stride
+        q_stride = rows_i.strides[0]
+        lanes.append({"dq": hip.Buffer.from_numpy(rows_i),
                       "lab": hip.Buffer(nq * a.k * 8), "dist": hip.Buffer(nq * a.k * 4), "slot": hip.Buffer(nq * a.k * 4),
                       "D": hip.Buffer(nq * 8), "E": hip.Buffer(nq * 8)})
     d_slot = lanes[0]["slot"]
 
     def step(i=0):
         L = lanes[i % B]
-        ix.search_batch_device(L["dq"].ptr, nq, a.k, a.ef, 0, L["lab"].ptr, L["dist"].ptr, L["slot"].ptr, None, L["D"].ptr, L["E"].ptr, streams[i % S].handle)
+        ix.search_batch_device(L["dq"].ptr, nq, a.k, a.ef, 0, L["lab"].ptr, L["dist"].ptr, L["slot"].ptr, None, L["D"].ptr, L["E"].ptr, streams[i % S].handle,
+                               query_stride=q_stride)
 
     def barrier():
         hip.synchronize()

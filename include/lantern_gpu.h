@@ -267,6 +267,16 @@ LANTERN_GPU_EXPORT void lantern_gpu_search_batch_device(usearch_index_t, const v
                                                         size_t ef, size_t skip, uint64_t *d_labels, float *d_distances,
                                                         uint32_t *d_slots, uint32_t *d_counts, uint64_t *d_dist_evals,
                                                         uint64_t *d_expansions, void *stream, usearch_error_t *);
+/* The same with the caller's query row stride stated: query i is read at d_queries + i * query_stride_bytes, which must equal
+ * lantern_gpu_row_bytes() -- anything else is refused ("the query row stride does not match ...") instead of being read at
+ * the wrong offsets and past the end of the caller's buffer.  lantern_gpu_search_batch_device (no stride argument) is accepted
+ * only for indexes whose stored stride is the vector's own length rounded up to 16 bytes; for an index that widens its rows
+ * (bit rows of 65 .. 127 bytes are stored at 128) it fails and names this entry point. */
+LANTERN_GPU_EXPORT void lantern_gpu_search_batch_device_strided(usearch_index_t, const void *d_queries, size_t query_stride_bytes,
+                                                                size_t nq, size_t k, size_t ef, size_t skip, uint64_t *d_labels,
+                                                                float *d_distances, uint32_t *d_slots, uint32_t *d_counts,
+                                                                uint64_t *d_dist_evals, uint64_t *d_expansions, void *stream,
+                                                                usearch_error_t *);
 /* kernel shape of the search launch: waves per query (1..8; 0 = automatic: 4 when the batch fills the chip, up to 8 for
  * smaller batches) and resident workgroups (0 = auto) */
 LANTERN_GPU_EXPORT void lantern_gpu_set_search_shape(usearch_index_t, int waves_per_query, int max_workgroups,
@@ -277,6 +287,21 @@ LANTERN_GPU_EXPORT void lantern_gpu_set_search_shape(usearch_index_t, int waves_
  * (distance, slot). */
 LANTERN_GPU_EXPORT void lantern_gpu_exact_search(usearch_index_t, const void *queries, size_t nq, size_t k,
                                                  uint32_t *slots, float *distances, usearch_error_t *);
+
+/* Diagnostic for the measurement harness: HIP events around every launch of the fp32-MFMA contraction (k_dense_f32) inside
+ * lantern_gpu_exact_search / _assign_to_clusters / _distance_matrix.  on != 0 starts recording; on == 0 stops and writes up to
+ * `cap` records -- ms[i], rows[i] x cols[i] (queries x base rows of the launch), fused[i] (1: the launch with the fused top-k
+ * epilogue) -- and returns how many launches were recorded.  Process-wide; any pointer may be NULL. */
+LANTERN_GPU_EXPORT size_t lantern_gpu_dense_profile(int on, float *ms, uint32_t *rows, uint32_t *cols, uint32_t *fused, size_t cap);
+
+/* Diagnostic for the measurement harness: the memory objects every query of a launch asks for, in order (rows evaluated, adjacency
+ * lists read) -- the input of the cache model behind bench.py's roofline.frac_dram_model (lantern_amd/tools/cache_model.c).
+ * on = 1: allocate nq x per_query_cap entries and trace the following launches of at most nq queries (the instrumented walk:
+ * f32 l2sq / cos, as lantern_gpu_search_unique_rows; same answers, D and E).  on = 0: copy the LAST traced launch's trace
+ * (nq x per_query_cap u32) and counts (nq u32; above per_query_cap: the tail was dropped) out, free the buffers, switch it off.
+ * Entry = slot (a row evaluation) | 0x80000000 (level-0 list of that node read) | 0xC0000000 (an upper-level list). */
+LANTERN_GPU_EXPORT void lantern_gpu_search_row_trace(usearch_index_t, int on, size_t nq, size_t per_query_cap, uint32_t *trace,
+                                                     uint32_t *counts, usearch_error_t *);
 
 /* Gathered distances: out[i] = metric(query, row(slots[i])) -- the kernel the graph walk is
  * made of, exposed for tests and profiling.  Host buffers. */

@@ -18,13 +18,26 @@ OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "liblantern_gpu.so")
 
-SOURCES = ["search_kernel.hip", "search_spec_kernel.hip", "search_solo_kernel.hip", "search_adc_kernel.hip", "insert_kernel.hip", "insert_spec_kernel.hip", "kernels.hip", "bruteforce.hip", "grouping.hip", "index.cpp", "comm.cpp", "usearch_file.cpp", "scan_shim.cpp", "index_server.cpp", "scan_server.cpp", "mirror_cache.cpp", "node_tape.cpp"]
+SOURCES = ["search_kernel.hip", "search_spec_kernel.hip", "search_adc_kernel.hip", "insert_kernel.hip", "insert_spec_kernel.hip", "kernels.hip", "bruteforce.hip", "grouping.hip", "index.cpp", "comm.cpp", "usearch_file.cpp", "scan_shim.cpp", "index_server.cpp", "scan_server.cpp", "mirror_cache.cpp", "node_tape.cpp"]
 # every header under csrc/ is a dependency of every object (globbed, so a new header cannot be forgotten)
-HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith(".hpp")) + ["../../include/lantern_gpu.h"]
+HEADERS = (sorted(h for h in os.listdir(CSRC) if h.endswith(".hpp")) + sorted("experimental/" + h for h in os.listdir(os.path.join(CSRC, "experimental")) if h.endswith(".hpp"))
+           + ["../../include/lantern_gpu.h"])
 # -ffp-contract=off: every fma in the kernels is explicit, so the reduction tree is exactly the
 # one the oracle models.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+# LANTERN_BUILD_EXPERIMENTAL=1: also build the walk variants that lost their A/B (csrc/experimental/: the two-nodes-per-round walk
+# and the one-wave walk, LANTERN_GPU_SPEC=3 / 4).  The default library -- what bench.py, the driver's tests and a deployment run --
+# does not contain them.  Objects of the two builds live in separate directories; the library on disk is whichever was built last,
+# and lantern_gpu_version() says which ("... +experimental").
+EXPERIMENTAL = os.environ.get("LANTERN_BUILD_EXPERIMENTAL", "0") not in ("", "0")
+EXPERIMENTAL_SOURCES = ["experimental/search_solo_kernel.hip"]
+if EXPERIMENTAL:
+    SOURCES = SOURCES + EXPERIMENTAL_SOURCES
+    FLAGS = FLAGS + ["-DLGPU_EXPERIMENTAL=1"]
+    OBJ_DIR = os.path.join(OUT_DIR, "obj_experimental")
 
 
 def _hipcc() -> str:
@@ -48,10 +61,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
 
     def compile_one(src: str) -> str:
-        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
         path = os.path.join(CSRC, src)
         if force or _stale(obj, [path] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+            cmd = [hipcc] + FLAGS + ["-I" + CSRC, "-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -59,8 +72,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, srcs))
-    if force or _stale(LIB, objs):
+    marker = os.path.join(OUT_DIR, ".built_experimental")  # which of the two builds the library on disk is
+    if force or _stale(LIB, objs) or os.path.exists(marker) != EXPERIMENTAL:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        if EXPERIMENTAL:
+            open(marker, "w").close()
+        elif os.path.exists(marker):
+            os.remove(marker)
+    # the cache model of bench.py's roofline.frac_dram_model (tools/cache_model.c: plain C, host only)
+    cm_src, cm_lib = os.path.join(HERE, "tools", "cache_model.c"), os.path.join(OUT_DIR, "libcache_model.so")
+    if os.path.exists(cm_src) and (force or _stale(cm_lib, [cm_src])):
+        cmd = ["gcc", "-O2", "-Wall", "-shared", "-fPIC", "-o", cm_lib, cm_src]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -85,9 +85,9 @@ EXPORTS = [
     "usearch_header_get_entry_slot", "usearch_header_set_entry_slot", "usearch_view_mem_lazy", "usearch_update_header",
     "lantern_gpu_version", "lantern_gpu_device_count",
     "lantern_gpu_set_seed", "lantern_gpu_set_add_batch", "lantern_gpu_add_many", "lantern_gpu_flush",
-    "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device",
-    "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_distance_gather",
-    "lantern_gpu_host_alloc", "lantern_gpu_host_free", "lantern_gpu_save_stream", "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile", "lantern_gpu_search_unique_rows",
+    "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device", "lantern_gpu_search_batch_device_strided",
+    "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_dense_profile", "lantern_gpu_distance_gather",
+    "lantern_gpu_host_alloc", "lantern_gpu_host_free", "lantern_gpu_save_stream", "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile", "lantern_gpu_search_unique_rows", "lantern_gpu_search_row_trace",
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_export_codes",
     "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_gpu_search_phase_profile", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_trace", "lantern_scan_end",
@@ -171,11 +171,14 @@ def lib() -> C.CDLL:
         "lantern_gpu_add_with_level": (None, [vp, u64, vp, i32, i32, err]),
         "lantern_gpu_search_batch": (None, [vp, vp, sz, i32, sz, sz, vp, vp, vp, err]),
         "lantern_gpu_search_batch_device": (None, [vp, vp, sz, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp, err]),
+        "lantern_gpu_search_batch_device_strided": (None, [vp, vp, sz, sz, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp, err]),
         "lantern_gpu_set_search_shape": (None, [vp, i32, i32, err]),
         "lantern_gpu_exact_search": (None, [vp, vp, sz, sz, vp, vp, err]),
+        "lantern_gpu_dense_profile": (sz, [i32, vp, vp, vp, vp, sz]),
         "lantern_gpu_distance_gather": (None, [vp, vp, vp, sz, vp, err]),
         "lantern_gpu_spec_profile": (None, [vp, i32, vp, err]),
         "lantern_gpu_search_unique_rows": (None, [vp, i32, C.POINTER(u64), err]),
+        "lantern_gpu_search_row_trace": (None, [vp, i32, sz, sz, vp, vp, err]),
         "lantern_gpu_save_stream": (None, [vp, vp, vp, err]),
         "lantern_gpu_pq_compact": (None, [vp, err]),
         "lantern_gpu_pq_expand": (None, [vp, err]),
@@ -329,6 +332,27 @@ def assign_to_clusters(dataset, centers, metric, subvector_start=0, subvector_di
     return idx, dist
 
 
+def version() -> str:
+    return lib().lantern_gpu_version().decode()
+
+
+def experimental_build() -> bool:
+    """True when the loaded library contains the walk variants of csrc/experimental/ (LANTERN_BUILD_EXPERIMENTAL=1 at build time)."""
+    return "+experimental" in version()
+
+
+def dense_profile(on: bool):
+    """on=True: record HIP events around every fp32-MFMA contraction launch of the exact k-NN.  on=False: stop and return the records
+    as a list of dicts {ms, rows, cols, fused} (lantern_gpu_dense_profile)."""
+    if on:
+        lib().lantern_gpu_dense_profile(1, None, None, None, None, 0)
+        return None
+    cap = 4096
+    ms, rows, cols, fused = np.zeros(cap, np.float32), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    n = min(int(lib().lantern_gpu_dense_profile(0, _ptr(ms), _ptr(rows), _ptr(cols), _ptr(fused), cap)), cap)
+    return [{"ms": float(ms[i]), "rows": int(rows[i]), "cols": int(cols[i]), "fused": bool(fused[i])} for i in range(n)]
+
+
 def l2sq_dist(a, b) -> float:
     """SQL l2sq_dist(real[], real[]) (hnsw.c:354-360)."""
     A, B = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
@@ -460,6 +484,20 @@ class GpuIndex:
         _call("lantern_gpu_search_unique_rows", self.h, 1 if on else 0, C.byref(out) if read else None)
         return int(out.value) if read else None
 
+    def row_trace_begin(self, nq, per_query_cap):
+        """lantern_gpu_search_row_trace(on=1): the following launches of at most nq queries record, per query, the memory objects the
+        walk asks for (rows evaluated, adjacency lists read) in order."""
+        self._trace_shape = (int(nq), int(per_query_cap))
+        _call("lantern_gpu_search_row_trace", self.h, 1, int(nq), int(per_query_cap), None, None)
+
+    def row_trace_end(self):
+        """-> (trace [nq][cap] u32, counts [nq] u32) of the last traced launch; switches the tracing off."""
+        nq, cap = self._trace_shape
+        trace = np.zeros((nq, cap), dtype=np.uint32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        _call("lantern_gpu_search_row_trace", self.h, 0, nq, cap, _ptr(trace), _ptr(counts))
+        return trace, counts
+
     def pq_compact(self):
         """pq = true: drop the decoded rows from HBM; searches run ADC over the code bytes."""
         _call("lantern_gpu_pq_compact", self.h)
@@ -468,7 +506,7 @@ class GpuIndex:
         _call("lantern_gpu_pq_expand", self.h)
 
     def row_bytes(self) -> int:
-        """Bytes of one stored row in device memory: the stride of device-resident queries (hip.padded_rows(..., row_bytes=))."""
+        """Bytes of one stored row in device memory: the stride of device-resident queries (device_query_rows())."""
         return int(_call("lantern_gpu_row_bytes", self.h))
 
     def memory_usage(self):
@@ -558,10 +596,24 @@ class GpuIndex:
         return labels, dists, counts
 
     def search_batch_device(self, d_queries, nq, k, ef=0, skip=0, d_labels=None, d_dists=None, d_slots=None, d_counts=None,
-                            d_D=None, d_E=None, stream=None):
-        """All pointers are raw device addresses (ints), e.g. torch.Tensor.data_ptr()."""
-        _call("lantern_gpu_search_batch_device", self.h, _ptr(d_queries), nq, k, ef, skip, _ptr(d_labels), _ptr(d_dists),
-              _ptr(d_slots), _ptr(d_counts), _ptr(d_D), _ptr(d_E), _ptr(stream))
+                            d_D=None, d_E=None, stream=None, query_stride=None):
+        """All pointers are raw device addresses (ints), e.g. torch.Tensor.data_ptr().  `query_stride` = bytes between consecutive
+        query rows (device_query_rows(...).strides[0]): checked against the index's stored stride by the library.  Without it the
+        call is accepted only for indexes whose stride is unambiguous (no widened rows) -- lantern_gpu.h."""
+        if query_stride is None:
+            _call("lantern_gpu_search_batch_device", self.h, _ptr(d_queries), nq, k, ef, skip, _ptr(d_labels), _ptr(d_dists),
+                  _ptr(d_slots), _ptr(d_counts), _ptr(d_D), _ptr(d_E), _ptr(stream))
+        else:
+            _call("lantern_gpu_search_batch_device_strided", self.h, _ptr(d_queries), int(query_stride), nq, k, ef, skip, _ptr(d_labels),
+                  _ptr(d_dists), _ptr(d_slots), _ptr(d_counts), _ptr(d_D), _ptr(d_E), _ptr(stream))
+
+    def device_query_rows(self, queries) -> np.ndarray:
+        """Host rows in the index's STORAGE format at the index's OWN row stride (zero padded): upload them and pass
+        `query_stride=rows.strides[0]` to search_batch_device.  Takes the format and the stride from the index itself, so neither
+        can be forgotten (bit rows of 65 .. 127 bytes sit at a 128-byte stride)."""
+        from . import hip
+
+        return hip.padded_rows(queries, self.metric == METRIC_HAMMING, self.f16, self.i8, self.b1, row_bytes=self.row_bytes())
 
     def exact_search(self, queries, k):
         Q = _rows(queries, self.metric)

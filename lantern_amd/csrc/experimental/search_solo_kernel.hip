@@ -1,6 +1,6 @@
 // search_solo_kernel.hip -- k_search_solo: usearch_search_ef (lantern_hnsw/src/hnsw/scan.c:220-228) for a lone query or a handful,
 // ONE WAVE per query, no workgroup barrier (walk_solo.hpp).  f32 l2sq / cos rows of fewer than 64 chunks, M <= 16, ef <= 64.
-#include "kernels.hpp"
+#include "../kernels.hpp"
 #include "walk_solo.hpp"
 
 namespace lgpu {

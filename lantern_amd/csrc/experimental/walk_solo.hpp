@@ -20,8 +20,8 @@
 // MEASURED SLOWER than the 3 + 8 wave shape it was meant to beat (117.7 against 102.0 us per lone 100k x 128 query): one wave has to
 // issue a hop's ~540 instructions itself.  On request only (LANTERN_GPU_SPEC=4); DESIGN.md 4.3c has the section profile.
 #pragma once
-#include "device_common.hpp"
-#include "walk.hpp"
+#include "../device_common.hpp"
+#include "../walk.hpp"
 
 namespace lgpu {
 

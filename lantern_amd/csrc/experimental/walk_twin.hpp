@@ -21,7 +21,7 @@
 // distance bits, D and E equal the oracle's (tests/test_gpu_parity.py runs this form beside the others).
 // Dedicated role waves only (the lone-query shape: visit | list | fill | row waves); requires what search_level_spec requires.
 #pragma once
-#include "walk_spec.hpp"
+#include "../walk_spec.hpp"
 
 namespace lgpu {
 

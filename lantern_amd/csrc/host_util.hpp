@@ -8,6 +8,18 @@
 
 namespace lgpu {
 
+// one turn of a spin-wait loop, on whatever the host is
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    __asm__ __volatile__("yield" ::: "memory");
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
+
 // Level draw: floor(-ln(U) / ln(M)) -- usearch choose_random_level_, Lantern's copy at
 // lantern_hnsw/src/hnsw/insert.c:32-46.  U is a stateless hash of (seed, slot) so that every
 // builder (this library on any batch plan, the test oracle) draws the same level for a slot.

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <new>
 
+#include <time.h>
+
 #include "comm.hpp"
 #include "host_util.hpp"
 
@@ -25,14 +27,11 @@ static bool exact_knn_device(int mcode, uint32_t chunks, const uint4 *d_base, si
 // run their kernels one after the other.  This library keeps up to eight search launches in flight on streams of their own (the lanes of
 // lantern_gpu_search_batch_lane: the scan-side service's dispatchers) beside the index's stream and whatever the caller made: with
 // four queues two lanes end up behind one another -- measured in round 5 at 1M x 768, 256 backends: a batch's answers 100 us later,
-// 443 k instead of 551 - 589 k scans/s, and which lanes collide depends on how many streams the process happened to create first.  The
-// flag is read when the runtime initialises (its first call), so it is set here, when the library is loaded; an explicit setting wins.
-namespace {
-struct HwQueues
-{
-    HwQueues() { (void)::setenv("GPU_MAX_HW_QUEUES", "16", 0); }
-} hw_queues_at_load;
-}  // namespace
+// 443 k instead of 551 - 589 k scans/s, and which lanes collide depends on how many streams the process happened to create first.
+// The flag is read when the runtime initialises, so it belongs to whoever STARTS the process: lantern-scan-server's main() sets it,
+// bench.py and the tests set it before the library is loaded, INTEGRATION.md section 7 tells a host that embeds the service to.
+// The library itself never touches the environment of the process it is loaded into (a PostgreSQL backend, a Python process with
+// other HIP users in it); lantern_scan_server_start warns on stderr when it runs more lanes than the setting gives queues.
 
 namespace lgpu {
 
@@ -797,6 +796,22 @@ static bool stage_buffer(Index *ix)
     return true;
 }
 
+// `count` f32 vectors of the caller (dimensions floats each) into `dst` in the index's STORED form (f16 / i8 / sign bits): uploaded as
+// they are and converted on the device (a million 768-d rows cost seconds on the host).  Returns after the stream has drained: the
+// caller's buffer is pageable and borrowed.  Shared by insert_rows and the row-sharded build's stage_rows_at.
+static bool upload_f32_as_stored(Index *ix, const void *f32_rows, size_t count, uint32_t *dst)
+{
+    const size_t d = ix->opts.dimensions;
+    float       *tmp = nullptr;
+    bool         up = hipMalloc((void **)&tmp, count * d * 4) == hipSuccess;
+    up = up && hipMemcpyAsync(tmp, f32_rows, count * d * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    up = up && launch_store_quantised(tmp, (uint32_t)d, (uint32_t)count, ix->scalar, dst, (uint32_t)ix->chunks * 4, ix->stream) == hipSuccess;
+    up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
+    if(tmp) (void)hipFree(tmp);
+    if(!up) (void)hipGetLastError();
+    return up;
+}
+
 // Insert `count` vectors whose padded rows start at `rows` (row_words 4-byte words each).  levels[i] < 0
 // means "draw with level_for()".  Returns how many were inserted (== count unless a batch failed).
 // raw_f32: `rows` are the caller's f32 vectors (dimensions floats each) of an index with quantised storage: they are
@@ -815,14 +830,7 @@ static size_t insert_rows(Index *ix, const uint64_t *labels, const int *levels_i
     if(!stage_meta(ix, levels_in, count, s)) return fail();
     bool up = true, staged = false;
     if(raw_f32) {
-        const size_t d = ix->opts.dimensions;
-        float *tmp = nullptr;
-        up = hipMalloc((void **)&tmp, count * d * 4) == hipSuccess;
-        up = up && hipMemcpyAsync(tmp, rows, count * d * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-        up = up && launch_store_quantised(tmp, (uint32_t)d, (uint32_t)count, ix->scalar, (uint32_t *)ix->d_vec + first * row_words, (uint32_t)row_words,
-                                          ix->stream) == hipSuccess;
-        up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
-        if(tmp) (void)hipFree(tmp);
+        up = upload_f32_as_stored(ix, rows, count, (uint32_t *)ix->d_vec + first * row_words);
     } else if(count <= 64 && count * (row_words * 4 + 16) <= kStageBytes && stage_buffer(ix)) {
         // a handful of rows: one kernel reads them and their metadata from the page-locked, device-mapped block (the block is next
         // written by the next insertion, which starts after this one's closing synchronisation in run_batches)
@@ -918,15 +926,21 @@ bool add_sharded_locked(Index *ix, Comm *comm, const uint64_t *labels, const voi
 // and pays two exchanges per batch; this is the other partitioning: candidate generation by ROW SHARD.  Every rank keeps a graph over
 // ITS rows only, grown in lock step with the global one; a batch of the global build -- the usual plan (plan_batch), its members drawn
 // from all shards in proportion -- goes
-//   1. every rank inserts its share of the batch into its own graph (the ordinary device build, no exchange);
-//   2. the batch's rows are all-gathered into every rank's HBM (the only time a row crosses the fabric);
-//   3. every rank searches ITS graph for each of the batch's rows (k_search, ef = ef_construction, K answers), the per-rank lists are
-//      all-gathered in HBM (12 bytes per candidate) and merged by (distance, slot) into what the level-0 walk of the insertion would
-//      have handed on (k_merge_candidates); the upper levels (~1/M of the nodes) are walked in the global graph as usual (k_insert
-//      with only_upper: replicated, a few per cent of the walks);
-//   4. k_connect, the grouping pass and k_revlink run on every rank as in a one-GPU batch (deterministic: the replicas agree to the
-//      bit, lantern_gpu_graph_checksum).
-// A row so chooses among the rows inserted before it (and its own batch), as in the sequential algorithm: the early rows' long links
+//   1. every rank writes its share of the batch's rows into the global vector table and the shares are all-gathered into every rank's
+//      HBM (the only time a row crosses the fabric); nothing is linked yet;
+//   2. every rank searches ITS graph -- as it stood BEFORE this batch: a batch's members are invisible to each other, as in a one-GPU
+//      batch -- for each of the batch's rows (k_search, ef = K answers), the per-rank lists are all-gathered in HBM (12 bytes per
+//      candidate) and merged by (distance, slot) into what the level-0 walk of the insertion would have handed on
+//      (k_merge_candidates); the upper levels (~1/M of the nodes) are walked in the global graph as usual (k_insert with only_upper:
+//      replicated, a few per cent of the walks);
+//   3. k_connect, the grouping pass and k_revlink run on every rank as in a one-GPU batch (deterministic: the replicas agree to the
+//      bit, lantern_gpu_graph_checksum);
+//   4. only then every rank inserts its share of the batch into its own graph (the ordinary device build, no exchange).  (Until round 4
+//      the share joined first: in-batch rows then used up part of the K answers per shard and were discarded by the merge.)
+//      If this step fails after step 3 committed the batch globally, the build stops with the error; the global index holds the
+//      batches that completed and is consistent (searchable, saveable), the shard graph is one batch behind it and is discarded
+//      with the call -- the build cannot be resumed, as with any failed collective build.
+// A row so chooses among the rows inserted before its batch, as in the batch-synchronous one-GPU build: the early rows' long links
 // and the reverse-link pruning are there.  The slots of the result follow the batches (within a batch rank 0's share first), not the
 // caller's rank order: labels identify rows.  NOT the one-GPU build's graph edge for edge -- the candidates of a row are the union of
 // W approximate searches instead of one: parity is edge for edge against the oracle's restatement of THIS procedure
@@ -980,15 +994,9 @@ static bool stage_rows_at(Index *ix, size_t at, const void *vectors, size_t coun
         HIPCHK(ix, hipStreamSynchronize(ix->stream));  // (the caller's buffer is pageable and borrowed)
         return true;
     }
-    if(kind_in == usearch_scalar_f32_k && (ix->scalar == usearch_scalar_f16_k || ix->scalar == usearch_scalar_i8_k || ix->b1_from_f32)) {
-        const size_t d = ix->opts.dimensions;
-        float       *tmp = nullptr;
-        bool         up = hipMalloc((void **)&tmp, count * d * 4) == hipSuccess;
-        up = up && hipMemcpyAsync(tmp, vectors, count * d * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
-        up = up && launch_store_quantised(tmp, (uint32_t)d, (uint32_t)count, ix->scalar, (uint32_t *)dst, (uint32_t)row_words, ix->stream) == hipSuccess;
-        up = up && hipStreamSynchronize(ix->stream) == hipSuccess;
-        if(tmp) (void)hipFree(tmp);
-        if(!up) { (void)hipGetLastError(); set_err(ix, "lantern_gpu: HIP failure uploading vectors"); }
+    if(kind_in == usearch_scalar_f32_k && (ix->scalar == usearch_scalar_f16_k || ix->scalar == usearch_scalar_i8_k)) {  // (quant_bits = 1 is refused above)
+        const bool up = upload_f32_as_stored(ix, vectors, count, (uint32_t *)dst);
+        if(!up) set_err(ix, "lantern_gpu: HIP failure uploading vectors");
         return up;
     }
     std::vector<uint32_t> padded(count * row_words);
@@ -1213,7 +1221,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         a.totals = ix->d_totals;
         a.ticket = next_ticket(ix, nq, grid, stream);
         a.done = done;
-    a.done_flags = done_flags;
+        a.done_flags = done_flags;
         a.lds_list = lds_list_env();
         a.adc_centers = ix->d_centers;
         a.adc_S = ix->pq_S;
@@ -1248,6 +1256,9 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
             if(se) spec = std::atoi(se);
             else if(nq <= (size_t)ix->num_cus * 2) spec = 2;  // (1M x 768 cosine: 384 queries 528 k vs 389 k, 512: 624 k vs 500 k, 768: 658 k vs 691 k)
             if(spec < 0 || spec > 4) spec = 0;
+#if !LGPU_EXPERIMENTAL
+            if(spec >= 3) spec = 2;  // the variants behind 3 / 4 are not in this library (LANTERN_BUILD_EXPERIMENTAL=1 builds them)
+#else
             // 4: the ONE-WAVE walk (walk_solo.hpp): no barrier, no hand-over between waves -- f32 l2sq / cos rows of < 64 chunks,
             // M <= 16, ef <= 64, an index whose visited bitmap fits LDS.  ON REQUEST ONLY (LANTERN_GPU_SPEC=4, or LANTERN_GPU_SOLO=1 for
             // every launch it applies to): measured in round 5 on the lone 100k x 128 query it is SLOWER than the 3 + 8 wave shape --
@@ -1292,7 +1303,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
                     a.totals = ix->d_totals;
                     a.ticket = next_ticket(ix, nq, grid, stream);
                     a.done = done;
-    a.done_flags = done_flags;
+                    a.done_flags = done_flags;
                     a.spec = 4;
                     a.phase_cycles = ix->spec_profile ? ix->d_totals + 16 : nullptr;
                     HIPCHK(ix, launch_search_solo(ix->mcode, a, grid, stream));
@@ -1306,6 +1317,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
             // (3: two nodes per round, the second speculative -- walk_twin.hpp; on request only: measured slower)
             if(spec == 3 && !(expansion <= 64 && (ix->mcode == M_L2SQ || ix->mcode == M_COS) && (group_lanes_for(ix->chunks) == 64 || (ix->mcode == M_L2SQ && group_lanes_for(ix->chunks) == 16))))
                 spec = 2;
+#endif
         }
         // (measured, classic kernel, 1M x 768 cosine, 1024 queries: 4 waves 693 k QPS, 6 waves 525 k, 8 waves 594 k -- more waves
         // only make its serial phases costlier; so four waves per query whatever the batch size)
@@ -1373,6 +1385,12 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     // the row bitmap only when unique-rows mode asked for it AND it covers every slot the walk can name (a reserve / add since
     // it was sized would otherwise let mark_touched write past it)
     a.touched = (!spec && prof_walk && ix->unique_rows_on && ix->d_touched && ix->touched_words * 32 >= ix->cap) ? ix->d_touched : nullptr;
+    if(!spec && prof_walk && ix->trace_on && ix->d_trace && nq <= ix->trace_nq) {  // (lantern_gpu_search_row_trace: the launch's own counts start at zero)
+        HIPCHK(ix, hipMemsetAsync(ix->d_trace_count, 0, nq * 4, stream));
+        a.trace = ix->d_trace;
+        a.trace_count = ix->d_trace_count;
+        a.trace_cap = (uint32_t)ix->trace_cap;
+    }
     a.done = done;
     a.done_flags = done_flags;
     a.lds_list = lds_list_env();
@@ -1434,11 +1452,7 @@ size_t search_one_locked(Index *ix, Cursor *cur, const void *query, int kind, si
                                 ix->search_waves > 0 ? 8 : -8, (uint32_t *)(dev + flag_off));
     if(ok) {
         for(unsigned spins = 0; *h_done == 0; ++spins) {
-#if defined(__x86_64__) || defined(__i386__)
-            __builtin_ia32_pause();
-#else
-            __asm__ __volatile__("" ::: "memory");
-#endif
+            cpu_relax();
             if((spins & 0x3FFF) == 0x3FFF) {  // every ~100 us: is the kernel still there?
                 const hipError_t st = hipStreamQuery(ix->stream);
                 if(st == hipErrorNotReady) continue;
@@ -1536,7 +1550,7 @@ static Index *H(usearch_index_t h, usearch_error_t *e)
 
 extern "C" {
 
-const char *lantern_gpu_version(void) { return "lantern_gpu 0.1 (gfx950)"; }
+const char *lantern_gpu_version(void) { return LGPU_EXPERIMENTAL ? "lantern_gpu 0.1 (gfx950) +experimental" : "lantern_gpu 0.1 (gfx950)"; }
 
 int lantern_gpu_device_count(void)
 try {
@@ -1591,7 +1605,7 @@ try {
                 : f16 ? (uint32_t)((o->dimensions + 1) / 2)
                 : i8 ? (uint32_t)((o->dimensions + 3) / 4)
                      : (uint32_t)o->dimensions;
-    ix->chunks = (ix->words + 3) / 4;
+    ix->chunks = ix->natural_chunks = (ix->words + 3) / 4;
     // Bit rows of 65 .. 127 bytes (768 bits = 96 bytes: quant_bits = 1 on 768-d, hamming over 24 words) are stored at a 128-BYTE STRIDE,
     // zero padded: the fabric fetches 128-byte lines, and a 96-byte row at a 96-byte stride straddles two of them three times in four.
     // Measured in round 5 (1M rows, 8192-query launches): 3.23 GB of fabric traffic per launch for 96-byte rows against 2.22 GB for
@@ -1653,7 +1667,7 @@ try {
     if(!ix) return;
     void *ptrs[] = { ix->d_vec, ix->d_norm2, ix->d_labels, ix->d_levels, ix->d_nbr0, ix->d_upper_off, ix->d_upper_nbr, ix->d_bitmaps, ix->d_totals, ix->d_tickets,
                      ix->d_radius0, ix->d_radius_upper,
-                     ix->d_codebook, ix->d_centers, ix->d_codes, ix->d_codes16, ix->d_touched };
+                     ix->d_codebook, ix->d_centers, ix->d_codes, ix->d_codes16, ix->d_touched, ix->d_trace, ix->d_trace_count };
     for(void *p : ptrs)
         if(p) (void)hipFree(p);
     for(void *p : ix->d_scratch)
@@ -2040,6 +2054,31 @@ size_t lantern_gpu_cursor_seen(lantern_gpu_cursor_t *c) { return c ? c->cur.seen
 
 void lantern_gpu_cursor_close(lantern_gpu_cursor_t *c) { delete c; }
 
+// Device-resident queries come with their row stride: the kernel reads query i at d_queries + i * (stored row stride), and a caller
+// that laid its rows out at any other stride would get wrong answers and a read past the end of its buffer with no error.  The
+// stride is therefore part of the call (`_strided`) and a mismatch is refused; the form without it is accepted only where the
+// stride is unambiguous -- the index stores rows at the vector's own length rounded up to 16 bytes.
+static const char *kStrideMismatch = "lantern_gpu: the query row stride does not match the index's stored row stride (lantern_gpu_row_bytes)";
+static const char *kStrideAmbiguous =
+    "lantern_gpu: this index stores rows at a stride wider than the vector's own length (lantern_gpu_row_bytes): device-resident "
+    "queries must be handed over with their stride, through lantern_gpu_search_batch_device_strided";
+
+void lantern_gpu_search_batch_device_strided(usearch_index_t h, const void *d_queries, size_t query_stride_bytes, size_t nq, size_t k, size_t ef,
+                                             size_t skip, uint64_t *d_labels, float *d_distances, uint32_t *d_slots, uint32_t *d_counts,
+                                             uint64_t *d_D, uint64_t *d_E, void *stream, usearch_error_t *e)
+try {
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(query_stride_bytes != (size_t)ix->chunks * 16) { FAIL(e, kStrideMismatch); return; }
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    if(!run_search_device(ix, (const uint4 *)d_queries, nq, k, ef, skip, d_labels, d_distances, d_slots, d_counts, d_D, d_E,
+                          (hipStream_t)stream, ix->search_waves))
+        FAIL(e, ix->err.c_str());
+}
+LANTERN_ABI_CATCH_VOID(e)
+
 void lantern_gpu_search_batch_device(usearch_index_t h, const void *d_queries, size_t nq, size_t k, size_t ef, size_t skip,
                                      uint64_t *d_labels, float *d_distances, uint32_t *d_slots, uint32_t *d_counts,
                                      uint64_t *d_D, uint64_t *d_E, void *stream, usearch_error_t *e)
@@ -2048,6 +2087,7 @@ try {
     Index *ix = H(h, e);
     if(!ix) return;
     std::lock_guard<std::mutex> g(ix->mu);
+    if(ix->chunks != ix->natural_chunks) { FAIL(e, kStrideAmbiguous); return; }
     if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
     if(!run_search_device(ix, (const uint4 *)d_queries, nq, k, ef, skip, d_labels, d_distances, d_slots, d_counts, d_D, d_E,
                           (hipStream_t)stream, ix->search_waves))
@@ -2232,7 +2272,23 @@ try {
     std::vector<uint32_t> pending(nq), ready;
     for(size_t i = 0; i < nq; ++i) pending[ i ] = (uint32_t)i;
     ready.reserve(nq);
+    // Waiting: the flags change in host memory, so a look is a load (a cache miss when one changed).  The lane SPINS only for a
+    // bounded time after the last answer came up -- LANTERN_GPU_NOTIFY_SPIN_US, default 100: about the spacing of walks ending in a
+    // service-sized batch -- and then backs off to sleeping 10 .. 100 us at a time, so a lane waiting out a long launch does not
+    // hold one of the database host's cores at 100 % against the backends it serves.  The runtime is asked only now and then --
+    // hipStreamQuery takes its lock, which the other lanes' launches need -- to notice a launch that ended without raising its
+    // flags (it cannot, short of a fault) or failed.
+    static const long spin_ns = [] {
+        const char *v = std::getenv("LANTERN_GPU_NOTIFY_SPIN_US");
+        return (long)(v ? std::max(0, std::atoi(v)) : 100) * 1000L;
+    }();
+    auto now_ns = [] {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (long)ts.tv_sec * 1000000000L + ts.tv_nsec;
+    };
     unsigned idle = 0;
+    long     quiet_since = now_ns(), nap_ns = 10000;
     bool     drained = false;  // the stream has finished: whatever is still pending is complete as well
     while(!pending.empty()) {
         ready.clear();
@@ -2254,20 +2310,25 @@ try {
             }
             done(done_ctx, ready.data(), ready.size());
             idle = 0;
+            quiet_since = now_ns();
+            nap_ns = 10000;
             continue;
         }
-        // nothing new: spin on the flags (they change in host memory; a look costs a cache miss when one does).  The runtime is asked
-        // only now and then -- hipStreamQuery takes its lock, which the other lanes' launches need -- to notice a launch that ended
-        // without raising its flags (it cannot, short of a fault) or failed.
         ++idle;
-        if((idle & 0x3FFFu) == 0) {
+        const bool napping = (idle & 0x3Fu) == 0 && now_ns() - quiet_since > spin_ns;
+        if((idle & 0x3FFFu) == 0 || (napping && (idle & 0x3FFu) == 0)) {
             const hipError_t q = hipStreamQuery(st);
             if(q == hipSuccess) { (void)hipStreamSynchronize(st); drained = true; }
             else if(q != hipErrorNotReady) { (void)hipGetLastError(); ok = false; break; }
+        } else if(napping) {
+            timespec nap{0, nap_ns};
+            nanosleep(&nap, nullptr);
+            nap_ns = std::min(nap_ns * 2, 100000L);
+            idle |= 0x3Fu;  // look at the flags, then nap again (one look per nap until something comes up)
         } else if((idle & 0xFFu) == 0) {
             std::this_thread::yield();
         } else {
-            __builtin_ia32_pause();
+            cpu_relax();
         }
     }
     if(hipStreamSynchronize(st) != hipSuccess) ok = false;
@@ -2363,6 +2424,39 @@ LANTERN_ABI_CATCH_VOID(e)
 // query a radius the ordinary way.  *overflowed: a candidate list ran out of room (adversarially ordered rows): the caller repeats
 // the search unfused.
 static const size_t kSeedCols = 4096, kCandCap = 4096;
+// lantern_gpu_dense_profile: HIP events around every launch of the fp32-MFMA contraction inside the exact k-NN (bench.py's
+// c3_dense_exact_knn leg: the duration of steady full-chunk launches apart from the cold first ones and the partial last chunk).
+// Off unless asked for; a process-wide diagnostic, not part of any index's state.
+namespace {
+struct DenseLaunch { hipEvent_t a = nullptr, b = nullptr; uint32_t rows = 0, cols = 0, fused = 0; };
+struct DenseProfile
+{
+    std::mutex               mu;
+    bool                     on = false;
+    std::vector<DenseLaunch> launches;
+} g_dense_profile;
+struct DenseTimer  // records event `a` now and `b` on destruction, on the launch stream
+{
+    DenseLaunch l;
+    hipStream_t st;
+    bool        armed = false;
+    DenseTimer(hipStream_t s, uint32_t rows, uint32_t cols, bool fused) : st(s)
+    {
+        if(!g_dense_profile.on) return;
+        if(hipEventCreate(&l.a) != hipSuccess || hipEventCreate(&l.b) != hipSuccess) { (void)hipGetLastError(); return; }
+        l.rows = rows; l.cols = cols; l.fused = fused;
+        armed = hipEventRecord(l.a, st) == hipSuccess;
+    }
+    ~DenseTimer()
+    {
+        if(!armed) return;
+        (void)hipEventRecord(l.b, st);
+        std::lock_guard<std::mutex> g(g_dense_profile.mu);
+        g_dense_profile.launches.push_back(l);
+    }
+};
+}  // namespace
+
 static bool exact_knn_device_impl(int mcode, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
                                   uint32_t *d_slots, float *d_dists, hipStream_t st, bool fused, bool *overflowed)
 try {
@@ -2417,12 +2511,18 @@ try {
             for(size_t q0 = 0; ok && q0 < nq; q0 += QT) {
                 const size_t nqt = std::min(QT, nq - q0);
                 if(plain) {
-                    ok = ok && launch_dense(base_metric, qv + q0 * fchunks, (uint32_t)nqt, bv, (uint32_t)plain, fchunks, qn + q0, bn + c0, dd, ldd, st) == hipSuccess;
+                    {
+                        DenseTimer t(st, (uint32_t)nqt, (uint32_t)plain, false);
+                        ok = ok && launch_dense(base_metric, qv + q0 * fchunks, (uint32_t)nqt, bv, (uint32_t)plain, fchunks, qn + q0, bn + c0, dd, ldd, st) == hipSuccess;
+                    }
                     ok = ok && launch_select(dd, ldd, (uint32_t)nqt, (uint32_t)plain, (uint32_t)c0, best + q0 * kk, kk, st) == hipSuccess;
                 }
                 if(plain < nc) {
-                    ok = ok && launch_dense_topk(base_metric, qv + q0 * fchunks, (uint32_t)nqt, bv + plain * fchunks, (uint32_t)(nc - plain), fchunks, qn + q0,
-                                                 bn + c0 + plain, best + q0 * kk, kk, cand, ccnt, (uint32_t)kCandCap, (uint32_t)(c0 + plain), st) == hipSuccess;
+                    {
+                        DenseTimer t(st, (uint32_t)nqt, (uint32_t)(nc - plain), true);
+                        ok = ok && launch_dense_topk(base_metric, qv + q0 * fchunks, (uint32_t)nqt, bv + plain * fchunks, (uint32_t)(nc - plain), fchunks, qn + q0,
+                                                     bn + c0 + plain, best + q0 * kk, kk, cand, ccnt, (uint32_t)kCandCap, (uint32_t)(c0 + plain), st) == hipSuccess;
+                    }
                     ok = ok && launch_select_candidates((uint32_t)nqt, best + q0 * kk, kk, cand, ccnt, (uint32_t)kCandCap, cover, st) == hipSuccess;
                 }
             }
@@ -2485,6 +2585,39 @@ try {
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in exact_search");
 }
 LANTERN_ABI_CATCH_VOID(e)
+
+// on != 0: start recording (forgets earlier records).  on == 0: stop, wait for the recorded launches and write up to `cap` of them:
+// ms[i] = duration of launch i (HIP events on its stream), rows[i] x cols[i] = its queries x base rows, fused[i] = 1 for the
+// launch with the fused top-k epilogue.  Returns the number of recorded launches.
+size_t lantern_gpu_dense_profile(int on, float *ms, uint32_t *rows, uint32_t *cols, uint32_t *fused, size_t cap)
+try {
+    std::vector<DenseLaunch> got;
+    {
+        std::lock_guard<std::mutex> g(g_dense_profile.mu);
+        if(on) {
+            for(auto &l : g_dense_profile.launches) { (void)hipEventDestroy(l.a); (void)hipEventDestroy(l.b); }
+            g_dense_profile.launches.clear();
+            g_dense_profile.on = true;
+            return 0;
+        }
+        g_dense_profile.on = false;
+        got.swap(g_dense_profile.launches);
+    }
+    for(size_t i = 0; i < got.size(); ++i) {
+        float t = 0.0f;
+        if(hipEventSynchronize(got[ i ].b) != hipSuccess || hipEventElapsedTime(&t, got[ i ].a, got[ i ].b) != hipSuccess) { (void)hipGetLastError(); t = -1.0f; }
+        if(i < cap) {
+            if(ms) ms[ i ] = t;
+            if(rows) rows[ i ] = got[ i ].rows;
+            if(cols) cols[ i ] = got[ i ].cols;
+            if(fused) fused[ i ] = got[ i ].fused;
+        }
+        (void)hipEventDestroy(got[ i ].a);
+        (void)hipEventDestroy(got[ i ].b);
+    }
+    return got.size();
+}
+LANTERN_ABI_CATCH(nullptr)
 
 // PQ k-means assignment (product_quantization.c:80-124 assign_to_clusters): the one dense N x k contraction in
 // Lantern's C code -- N x k usearch_distance calls there, one fp32-MFMA pass + exact re-rank here.
@@ -2664,6 +2797,64 @@ try {
     }
     ix->phase_profile = on != 0;
     ix->unique_rows_on = on != 0;
+}
+LANTERN_ABI_CATCH_VOID(e)
+
+// The memory objects every query of a launch asks for, in order: the input of the cache model behind bench.py's frac_dram_model
+// (lantern_amd/tools/cache_model.c).  Runs the instrumented instantiation of the walk (as lantern_gpu_search_unique_rows); same walk,
+// same D and E.
+//   on = 1: allocate [nq][per_query_cap] entries and switch the instrumented, tracing kernel on for launches of <= nq queries;
+//   on = 0: wait for the device, copy the LAST traced launch's trace (nq x per_query_cap u32, row-major) and counts (nq u32; a
+//           count above per_query_cap means the tail of that query's trace was dropped) to the host buffers (either may be NULL),
+//           free the device buffers and switch the instrumented kernel off.
+// An entry is a row's slot (a distance evaluation), slot | 0x80000000 (the node's level-0 adjacency list was read) or
+// slot | 0xC0000000 (an upper-level list); indexes of at most 2^30 slots.
+void lantern_gpu_search_row_trace(usearch_index_t h, int on, size_t nq, size_t per_query_cap, uint32_t *trace, uint32_t *counts, usearch_error_t *e)
+try {
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if(!flush_locked(ix)) { FAIL(e, ix->err.c_str()); return; }
+    (void)hipDeviceSynchronize();
+    if(on) {
+        const int G_ = group_lanes_for(ix->chunks);
+        if(!((ix->mcode == M_L2SQ && (G_ == 64 || G_ == 16)) || (ix->mcode == M_COS && G_ == 64))) {
+            FAIL(e, "lantern_gpu: the instrumented walk exists for f32 l2sq (rows of >= 128 or 32..63 chunks) and f32 cos (>= 128 chunks) only");
+            return;
+        }
+        if(ix->cap > ((size_t)1 << 30) || nq == 0 || per_query_cap == 0) { FAIL(e, "lantern_gpu: row trace: bad arguments, or an index above 2^30 slots"); return; }
+        if(ix->d_trace) { (void)hipFree(ix->d_trace); ix->d_trace = nullptr; }
+        if(ix->d_trace_count) { (void)hipFree(ix->d_trace_count); ix->d_trace_count = nullptr; }
+        if(hipMalloc((void **)&ix->d_trace, nq * per_query_cap * 4) != hipSuccess || hipMalloc((void **)&ix->d_trace_count, nq * 4) != hipSuccess ||
+           hipMemset(ix->d_trace_count, 0, nq * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            if(ix->d_trace) (void)hipFree(ix->d_trace);
+            if(ix->d_trace_count) (void)hipFree(ix->d_trace_count);
+            ix->d_trace = ix->d_trace_count = nullptr;
+            FAIL(e, "lantern_gpu: out of device memory (row trace)");
+            return;
+        }
+        ix->trace_nq = nq;
+        ix->trace_cap = per_query_cap;
+        ix->trace_on = true;
+        ix->phase_profile = true;
+        return;
+    }
+    bool ok = true;
+    if(ix->d_trace && ix->d_trace_count) {
+        const size_t m = std::min(nq, ix->trace_nq);
+        if(counts && m) ok = hipMemcpy(counts, ix->d_trace_count, m * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        if(ok && trace && m && per_query_cap == ix->trace_cap) ok = hipMemcpy(trace, ix->d_trace, m * ix->trace_cap * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        else if(trace && m && per_query_cap != ix->trace_cap) ok = false;
+    }
+    if(ix->d_trace) (void)hipFree(ix->d_trace);
+    if(ix->d_trace_count) (void)hipFree(ix->d_trace_count);
+    ix->d_trace = ix->d_trace_count = nullptr;
+    ix->trace_nq = ix->trace_cap = 0;
+    ix->trace_on = false;
+    ix->phase_profile = ix->unique_rows_on;
+    if(!ok) FAIL(e, "lantern_gpu: HIP failure reading the row trace (or per_query_cap differs from the one the trace was started with)");
 }
 LANTERN_ABI_CATCH_VOID(e)
 

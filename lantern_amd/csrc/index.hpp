@@ -33,6 +33,7 @@ struct Index
     int      scalar = 0;         // STORAGE kind: usearch_scalar_f32_k, _f16_k (quant_bits=16) or _b1_k
     uint32_t words = 0;          // 4-byte words per vector as the caller supplies it
     uint32_t chunks = 0;         // 16-byte chunks per stored row (zero padded)
+    uint32_t natural_chunks = 0; // the vector's own length in 16-byte chunks; < chunks where rows are stored at a widened stride (bit rows of 65 .. 127 bytes)
     uint32_t M = 16, M0 = 32, efc = 128, ef = 64;
     uint64_t seed = 42;
     size_t   add_batch_max = 8192, add_min_ratio = 16;
@@ -113,6 +114,9 @@ struct Index
     uint32_t               *d_touched = nullptr;    // diagnostics: one bit per row evaluated by the instrumented searches (lantern_gpu_search_unique_rows)
     size_t                  touched_words = 0;
     bool                    unique_rows_on = false; // the bitmap is handed to a launch only in this mode, and only while it covers `cap`
+    uint32_t               *d_trace = nullptr, *d_trace_count = nullptr;  // diagnostics: [trace_nq][trace_cap] + [trace_nq] (lantern_gpu_search_row_trace)
+    size_t                  trace_nq = 0, trace_cap = 0;
+    bool                    trace_on = false;
     std::deque<ProfBatch>   prof_pending;
     std::vector<hipEvent_t> prof_free;
     lantern_gpu_build_profile prof{};

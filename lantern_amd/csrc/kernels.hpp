@@ -7,6 +7,14 @@
 #include "device_common.hpp"
 #include <atomic>
 
+// LANTERN_BUILD_EXPERIMENTAL=1 (lantern_amd/build.py -> -DLGPU_EXPERIMENTAL=1) adds the walk variants that lost their A/B to the
+// library: two nodes per round (experimental/walk_twin.hpp, LANTERN_GPU_SPEC=3) and the one-wave walk (experimental/walk_solo.hpp +
+// experimental/search_solo_kernel.hip, LANTERN_GPU_SPEC=4 / LANTERN_GPU_SOLO=1).  The default library does not contain them: the
+// switches then select the default latency-bound walk.  lantern_gpu_version() names the build.
+#ifndef LGPU_EXPERIMENTAL
+#define LGPU_EXPERIMENTAL 0
+#endif
+
 namespace lgpu {
 
 struct SearchArgs
@@ -45,6 +53,9 @@ struct SearchArgs
                                  // instead of when the launch's longest walk does (lantern_gpu_search_batch_lane_notify)
     uint32_t       *touched;     // diagnostics (lantern_gpu_search_unique_rows; the instrumented instantiations only): [ceil(n / 32)] one
                                  // bit per row, set when any query of the launch evaluates the row; NULL = off
+    uint32_t       *trace;       // diagnostics (lantern_gpu_search_row_trace; the instrumented instantiations only): [nq][trace_cap] the
+    uint32_t       *trace_count; // memory objects every query asks for, in order (walk.hpp trace_append), and [nq] how many; NULL = off
+    uint32_t        trace_cap;
 };                               // launch's queries by phase: pop | list + visited | distances | merge | descent | whole query
 
 // one reverse-link request produced by the insert pass: add `new_slot` to `close`'s list at `level`
@@ -155,10 +166,13 @@ inline void ensure_dynamic_lds(const void *fn, size_t lds, LdsAttrCache &cache)
 hipError_t launch_search(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);
 hipError_t launch_search_spec(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);  // a.spec != 0 (search_spec_kernel.hip)
 size_t     search_spec_lds_bytes(uint32_t M0, uint32_t prefetch, uint32_t cache_entries, uint32_t twin = 0);
-// the one-wave walk (search_solo_kernel.hip, walk_solo.hpp): a.spec_cache = log2 of the list-cache entries, a.vis_slots = words of the LDS bitmap
+#if LGPU_EXPERIMENTAL
+// the one-wave walk (experimental/search_solo_kernel.hip, experimental/walk_solo.hpp): a.spec_cache = log2 of the list-cache entries,
+// a.vis_slots = words of the LDS bitmap
 bool       search_solo_supported(int metric, uint32_t chunks, uint32_t M, uint32_t M0, uint32_t ef);
 size_t     search_solo_lds_bytes(uint32_t ne_log2, uint32_t bm_words);
 hipError_t launch_search_solo(int metric, const SearchArgs &a, int grid, hipStream_t stream);
+#endif
 hipError_t launch_search_adc(int metric, const SearchArgs &a, int waves, int grid, hipStream_t stream);  // metric = M_L2SQ_ADC / M_COS_ADC
 size_t     search_adc_lds_bytes(uint32_t code_chunks, uint32_t qchunks, uint32_t ef_cap, uint32_t M0, uint32_t vis_slots);
 hipError_t launch_insert(int metric, const InsertArgs &a, int waves, int grid, hipStream_t stream);

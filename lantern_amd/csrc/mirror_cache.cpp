@@ -223,12 +223,16 @@ try {
     if(m->refs > 0) m->refs--;
     m->last_use = ++c.clock;
     if(m->refs == 0 && m->index) {
-        // nobody holds the mirror: whatever bindings are left belong to holders that went away without a release (a thread that
-        // exited, a backend that longjmp'ed out of an error) -- their RetrieverCtx is gone and their thread id may be reused.
-        // (The index's lock is free: no holder is inside it, and a new one cannot take a reference before this cache lock drops.)
+        // nobody holds the mirror: whatever bindings are left belong to holders that went away without a release of THIS handle
+        // (a thread that exited while another handle of the mirror was still out) -- their RetrieverCtx is gone and their thread id
+        // may be reused.  The index's lock is only TRIED: the invariant of rebind_retriever stands -- the cache lock never WAITS
+        // for an index lock, so a long operation on one mirror (a service lane or an indexing thread working on the handle it
+        // was given earlier) cannot stall acquire / release of every other relation.  A busy index keeps its stale bindings until
+        // the next release that finds it idle; they are never dereferenced meanwhile (a binding is looked up by the CALLING
+        // thread's id, and a caller without a live one gets an error message: index.hpp binding()).
         lgpu::Index *ix = (lgpu::Index *)m->index;
-        std::lock_guard<std::mutex> gi(ix->mu);
-        ix->holders.clear();
+        std::unique_lock<std::mutex> gi(ix->mu, std::try_to_lock);
+        if(gi.owns_lock()) ix->holders.clear();
     }
     trim(c);
 }

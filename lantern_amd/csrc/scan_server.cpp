@@ -632,6 +632,22 @@ try {
     // answers one by one as their walks end (LANTERN_SCAN_NOTIFY=0: the whole batch's answers when its launch ends, as before round 5)
     s->notify = !(std::getenv("LANTERN_SCAN_NOTIFY") && std::atoi(std::getenv("LANTERN_SCAN_NOTIFY")) == 0);
     s->window = !(std::getenv("LANTERN_SCAN_WINDOW") && std::atoi(std::getenv("LANTERN_SCAN_WINDOW")) == 0);
+    // every lane launches on a stream of its own; the HIP runtime gives a process GPU_MAX_HW_QUEUES hardware queues (4 unless the
+    // process was started with more) and streams that share one run their kernels one after the other.  The setting is read when
+    // the runtime initialises, i.e. it belongs to whoever starts the process (lantern-scan-server's main() sets 16): say so, once,
+    // rather than lose a fifth of the service's throughput silently.
+    {
+        const char *hq = std::getenv("GPU_MAX_HW_QUEUES");
+        const int   queues = hq ? std::atoi(hq) : 4;
+        static bool warned = false;
+        if(s->lanes + 1 > queues && !warned) {
+            warned = true;
+            std::fprintf(stderr,
+                         "lantern_gpu: the scan service runs %d lanes but GPU_MAX_HW_QUEUES=%s gives the process %d hardware queues: lanes that share a queue "
+                         "run one behind the other.  Start the process with GPU_MAX_HW_QUEUES=16 in its environment (INTEGRATION.md section 7).\n",
+                         s->lanes, hq ? hq : "(unset)", queues);
+        }
+    }
     return start_common(s, host, port, max_batch, max_wait_us, e);
 }
 LANTERN_ABI_CATCH(e)

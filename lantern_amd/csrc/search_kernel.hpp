@@ -10,7 +10,15 @@
 #include "kernels.hpp"
 #include "walk.hpp"
 #include "walk_spec.hpp"
-#include "walk_twin.hpp"
+// LGPU_EXPERIMENTAL (build.py, LANTERN_BUILD_EXPERIMENTAL=1): the walk variants that lost their A/B -- two nodes per round
+// (experimental/walk_twin.hpp, SPEC 3) and the one-wave walk (experimental/walk_solo.hpp) -- are kept with their records and
+// parity tests but are NOT in the default library.
+#ifndef LGPU_EXPERIMENTAL
+#define LGPU_EXPERIMENTAL 0
+#endif
+#if LGPU_EXPERIMENTAL
+#include "experimental/walk_twin.hpp"
+#endif
 #include "dispatch.hpp"
 
 namespace lgpu {
@@ -100,6 +108,10 @@ k_search(SearchArgs)
             if constexpr(PROF) {
                 t_q = (unsigned long long)clock64();
                 s.touched = LGPU_SEARCH_ARG(ka, touched);
+                s.trace_cap = LGPU_SEARCH_ARG(ka, trace_cap);
+                uint32_t *const tr = LGPU_SEARCH_ARG(ka, trace);
+                s.trace = tr ? tr + (size_t)q * s.trace_cap : nullptr;
+                s.trace_count = tr ? LGPU_SEARCH_ARG(ka, trace_count) + q : nullptr;
             }
             if(v.n != 0) {
                 uint32_t start;
@@ -107,10 +119,13 @@ k_search(SearchArgs)
                 else start = greedy_descent<METRIC, G, PROF>(v, s, v.entry, v.max_level, 0, D);
                 if constexpr(PROF) pc[ 6 ] = (unsigned long long)clock64() - t_q;
                 // KPL keys per lane of wave 0 hold the candidate list (ef <= 64 KPL); KPL = 0: the list lives in LDS
+#if LGPU_EXPERIMENTAL
                 if constexpr(SPEC == 3)
                     cnt = search_level_twin<METRIC, G, KPL, ROWS, (G == 64 ? 3 : 2), PROF>(v, s, sc, bitmap, bm_words, start, ef, D, E,
                                                                                            PROF ? LGPU_SEARCH_ARG(ka, phase_cycles) : nullptr);
-                else if constexpr(SPEC != 0)
+                else
+#endif
+                if constexpr(SPEC != 0)
                     cnt = search_level_spec<METRIC, G, KPL, ROWS, (G == 64 && SPEC == 2 ? 3 : 2), SPEC == 2, PROF>(v, s, sc, bitmap, bm_words, start, ef, D, E,
                                                                                                                      PROF ? LGPU_SEARCH_ARG(ka, phase_cycles) : nullptr);
                 else if constexpr(KPL > 0) cnt = search_level_reg<METRIC, G, KPL, PROF, ROWS>(v, s, bitmap, bm_words, start, 0, ef, D, E, pc);

@@ -26,7 +26,11 @@ hipError_t launch_search_spec(int metric, const SearchArgs &a, int waves, int gr
     const int    kpl = a.ef <= 64 ? 1 : 2;
     if(a.phase_cycles) {  // diagnostic instantiations (lantern_gpu_spec_profile): f32 l2sq / cos rows of 32..63 and of >= 128 chunks, ef <= 64
         const int G_ = group_lanes_for(a.view.chunks);
+#if LGPU_EXPERIMENTAL
 #define LGPU_PROF_SPEC(MM, GG, RR) { if(a.spec == 3) LGPU_LAUNCH_SEARCH(MM, GG, true, RR, 1, 3) else if(a.spec == 2) LGPU_LAUNCH_SEARCH(MM, GG, true, RR, 1, 2) else LGPU_LAUNCH_SEARCH(MM, GG, true, RR, 1, 1) }
+#else
+#define LGPU_PROF_SPEC(MM, GG, RR) { if(a.spec == 2) LGPU_LAUNCH_SEARCH(MM, GG, true, RR, 1, 2) else LGPU_LAUNCH_SEARCH(MM, GG, true, RR, 1, 1) }
+#endif
         if(kpl == 1 && metric == M_L2SQ && G_ == 16) LGPU_PROF_SPEC(M_L2SQ, 16, 1)
         else if(kpl == 1 && metric == M_L2SQ && G_ == 64) LGPU_PROF_SPEC(M_L2SQ, 64, 4)
         else if(kpl == 1 && metric == M_COS && G_ == 64) LGPU_PROF_SPEC(M_COS, 64, 4)
@@ -34,6 +38,9 @@ hipError_t launch_search_spec(int metric, const SearchArgs &a, int waves, int gr
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
+#if !LGPU_EXPERIMENTAL
+    if(a.spec >= 3) return hipErrorInvalidValue;  // (index.cpp never asks: without the experimental unit LANTERN_GPU_SPEC=3 / 4 mean 2)
+#else
     if(a.spec == 3) {
         // Two nodes per round, the second one speculative (walk_twin.hpp).  Measured and NOT adopted: parity-green,
         // 51 rounds instead of 69 hops for the lone 100k x 128 query, but a round costs 1.9 hops -- the walk is bound by the
@@ -47,6 +54,7 @@ hipError_t launch_search_spec(int metric, const SearchArgs &a, int waves, int gr
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
+#endif
     if(mcode_is_pqd(metric)) {  // a compact pq index, rows decoded on the fly
         const int G_ = group_lanes_for(a.view.chunks);
 #define PQD_G(MM)                                                                                                                   \

@@ -44,7 +44,27 @@ struct WalkLds
     uint32_t  vis_slots;
     uint32_t *touched;  // diagnostic instantiations only (PROF): one bit per row of the index, set when ANY query of the launch
                         // evaluates the row (lantern_gpu_search_unique_rows); never read, and never set, elsewhere
+    // diagnostic instantiations only (PROF; lantern_gpu_search_row_trace): THIS query's memory-object trace, in the order the walk
+    // asks for them -- a row evaluation is the row's slot, an adjacency list read is the node's slot | TRACE_LIST0 (level 0) or
+    // | TRACE_LISTU (an upper level).  trace_count is bumped atomically (the lanes of a hop append side by side); entries beyond
+    // trace_cap are counted, not stored.  The input of the cache model behind bench.py's frac_dram_model.
+    uint32_t *trace, *trace_count;
+    uint32_t  trace_cap;
 };
+constexpr uint32_t TRACE_LIST0 = 0x80000000u, TRACE_LISTU = 0xC0000000u;
+
+template <bool PROF> __device__ __forceinline__ void trace_append(const WalkLds &s, uint32_t entry)
+{
+    if constexpr(PROF) {
+        if(s.trace) {
+            const uint32_t p = atomicAdd(s.trace_count, 1u);
+            if(p < s.trace_cap) s.trace[ p ] = entry;
+        }
+    } else {
+        (void)s;
+        (void)entry;
+    }
+}
 
 // PROF: record that row `id` was evaluated by this launch (the union over the launch's queries = the rows the launch needs at
 // least once from HBM: the cold-miss lower bound of its DRAM traffic)
@@ -52,6 +72,7 @@ template <bool PROF> __device__ __forceinline__ void mark_touched(const WalkLds 
 {
     if constexpr(PROF) {
         if(s.touched) atomicOr(&s.touched[ id >> 5 ], 1u << (id & 31));
+        trace_append<PROF>(s, id);
     } else {
         (void)s;
         (void)id;
@@ -261,6 +282,7 @@ __device__ uint32_t greedy_descent(const View &v, WalkLds &s, uint32_t start, in
             // gather the (EMPTY-terminated, hole-free) list: wave 0, one ballot per 64 slots (an LDS atomicMax here is
             // serialised by the compiler into a scalar loop over the lanes)
             if(tid < 64) {
+                if(tid == 0) trace_append<PROF>(s, cur | (level > 0 ? TRACE_LISTU : TRACE_LIST0));
                 int count = 0;
                 for(uint32_t off = 0; off < cap; off += 64) {
                     const uint32_t i = off + (uint32_t)(tid & 63);
@@ -453,6 +475,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                 }
                 uint32_t        cap;
                 const uint32_t *list = neighbors_of(v, node, level, cap);
+                if(lane == 0) trace_append<PROF>(s, node | (level > 0 ? TRACE_LISTU : TRACE_LIST0));
                 int nb_new = 0;
                 for(uint32_t off = 0; off < cap; off += 64) {
                     const uint32_t i = off + (uint32_t)lane;
@@ -724,6 +747,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                 }
                 uint32_t        cap;
                 const uint32_t *list = neighbors_of(v, node, level, cap);
+                if(lane == 0) trace_append<PROF>(s, node | (level > 0 ? TRACE_LISTU : TRACE_LIST0));
                 int nb_new = 0;
                 for(uint32_t off = 0; off < cap; off += 64) {
                     const uint32_t i = off + (uint32_t)lane;

@@ -15,6 +15,9 @@
 
 int main(int argc, char **argv)
 {
+    // one hardware queue per dispatcher lane (the HIP runtime's default of four makes lanes queue behind one another: index.cpp);
+    // read when the runtime initialises, so it is set here, before the first call into the library; an explicit setting wins
+    (void)::setenv("GPU_MAX_HW_QUEUES", "16", 0);
     std::string host = "127.0.0.1", index_path, metric = "l2sq";
     int         port = 8997, quant_bits = 32;
     size_t      dim = 0, m = 16, ef = 64, efc = 128, max_batch = 256;

@@ -31,12 +31,13 @@ def build(metric, base, M=16, efc=128, ef=64):
 
 def batch_qps(ix, queries, k, ef, steps=10, waves=4, ham=False):
     nq = queries.shape[0]
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, ham, row_bytes=ix.row_bytes()))
+    rows = ix.device_query_rows(queries)
+    dq = hip.Buffer.from_numpy(rows)
     lab, dist, slot = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4), hip.Buffer(nq * k * 4)
     Dv, Ev = hip.Buffer(nq * 8), hip.Buffer(nq * 8)
     st = hip.Stream()
     ix.set_search_shape(waves)
-    go = lambda: ix.search_batch_device(dq.ptr, nq, k, ef, 0, lab.ptr, dist.ptr, slot.ptr, None, Dv.ptr, Ev.ptr, st.handle)
+    go = lambda: ix.search_batch_device(dq.ptr, nq, k, ef, 0, lab.ptr, dist.ptr, slot.ptr, None, Dv.ptr, Ev.ptr, st.handle, query_stride=rows.strides[0])
     for _ in range(2):
         go()
     hip.synchronize()

@@ -6,6 +6,8 @@ one-at-a-time rate of usearch_search_ef on the same index for comparison.  The c
 released while a request is in flight), so the client side, not the device, bounds the rate reported here."""
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # the launcher gives the runtime a hardware queue per service lane (INTEGRATION.md section 7)
 import sys
 import threading
 import time

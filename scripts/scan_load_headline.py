@@ -8,6 +8,8 @@ lanes, and one backend's usearch_search_ef latency beside the CPU port's on the 
 import argparse
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # the launcher gives the runtime a hardware queue per service lane
 import subprocess
 import sys
 import threading

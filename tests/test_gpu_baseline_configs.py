@@ -31,11 +31,12 @@ def env():
 
 def device_batch(hip, ix, queries, k, ef, ham=False, waves=4):
     nq = queries.shape[0]
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, ham, row_bytes=ix.row_bytes()))
+    rows = ix.device_query_rows(queries)
+    dq = hip.Buffer.from_numpy(rows)
     lab, dist, slot = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4), hip.Buffer(nq * k * 4)
     cnt, Dv, Ev = hip.Buffer(nq * 4), hip.Buffer(nq * 8), hip.Buffer(nq * 8)
     ix.set_search_shape(waves)
-    ix.search_batch_device(dq.ptr, nq, k, ef, 0, lab.ptr, dist.ptr, slot.ptr, cnt.ptr, Dv.ptr, Ev.ptr)
+    ix.search_batch_device(dq.ptr, nq, k, ef, 0, lab.ptr, dist.ptr, slot.ptr, cnt.ptr, Dv.ptr, Ev.ptr, query_stride=rows.strides[0])
     hip.synchronize()
     ix.set_search_shape(0)
     return (lab.download((nq, k), np.uint64), dist.download((nq, k), np.float32), slot.download((nq, k), np.uint32),

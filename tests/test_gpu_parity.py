@@ -7,6 +7,7 @@ identical top-k id lists, identical distance-evaluation and expansion counts on 
 import numpy as np
 import pytest
 
+from tests.conftest import needs_experimental
 from tests.scan_driver import scan as oracle_scan
 
 pytestmark = pytest.mark.gpu
@@ -101,12 +102,13 @@ def test_search_matches_oracle_on_same_graph(capi, oracle, metric, n, d, M, efc,
     o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, k)
     from lantern_amd import hip
 
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, metric == "hamming", row_bytes=gpu.row_bytes()))
+    rows = gpu.device_query_rows(queries)
+    dq = hip.Buffer.from_numpy(rows)
     lab, dist, slot = hip.Buffer(64 * k * 8), hip.Buffer(64 * k * 4), hip.Buffer(64 * k * 4)
     cnt, D, E = hip.Buffer(64 * 4), hip.Buffer(64 * 8), hip.Buffer(64 * 8)
     for waves in (1, 4, 8):
         gpu.set_search_shape(waves)
-        gpu.search_batch_device(dq.ptr, 64, k, 0, 0, lab.ptr, dist.ptr, slot.ptr, cnt.ptr, D.ptr, E.ptr)
+        gpu.search_batch_device(dq.ptr, 64, k, 0, 0, lab.ptr, dist.ptr, slot.ptr, cnt.ptr, D.ptr, E.ptr, query_stride=rows.strides[0])
         hip.synchronize()
         assert np.array_equal(slot.download((64, k), np.uint32), o_slot), f"top-k slots differ (waves={waves})"
         assert np.array_equal(lab.download((64, k), np.uint64), o_lab)
@@ -247,6 +249,48 @@ def test_golden_scan_k_trace_expression_index_and_unlogged_insert_on_device(capi
     rows = sw["v"] + [u["inserted"]]
     order = ordered(capi, ix, u["query"], 20)
     assert [round(capi.l2sq_dist(rows[8 if l == 100 else l - LABEL0], u["query"]), 2) for l in order] == u["sorted_2dp"]
+
+
+def test_device_resident_queries_state_their_stride(capi):
+    """Bit rows of 96 bytes are stored at a 128-byte stride: device-resident queries laid out at 96 would be read at the wrong
+    offsets and past the end of the caller's buffer.  The stride is part of the call and a mismatch is refused; the entry point
+    without a stride argument refuses such an index outright (include/lantern_gpu.h)."""
+    from lantern_amd import hip
+
+    rng = np.random.default_rng(3)
+    n, words, nq, k = 3000, 24, 32, 10
+    base = rng.integers(0, 2**32, size=(n, words), dtype=np.uint32)
+    queries = rng.integers(0, 2**32, size=(nq, words), dtype=np.uint32)
+    ix = capi.GpuIndex("hamming", words, M=8, ef_construction=32, ef=32, seed=2)
+    ix.set_add_batch(256, 16)
+    ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+    assert ix.row_bytes() == 128
+    want_lab, want_dist, _ = ix.search_batch(queries, k)
+    rows = ix.device_query_rows(queries)
+    assert rows.strides[0] == 128 and not rows[:, words:].any()
+    dq = hip.Buffer.from_numpy(rows)
+    lab, dist = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4)
+    ix.search_batch_device(dq.ptr, nq, k, 0, 0, lab.ptr, dist.ptr, query_stride=rows.strides[0])
+    hip.synchronize()
+    assert np.array_equal(lab.download((nq, k), np.uint64), want_lab) and np.array_equal(dist.download((nq, k), np.float32), want_dist)
+    with pytest.raises(capi.LanternGpuError, match="query row stride does not match"):
+        ix.search_batch_device(dq.ptr, nq, k, 0, 0, lab.ptr, dist.ptr, query_stride=96)
+    with pytest.raises(capi.LanternGpuError, match="lantern_gpu_search_batch_device_strided"):
+        ix.search_batch_device(dq.ptr, nq, k, 0, 0, lab.ptr, dist.ptr)
+    # an index whose rows sit at their own length accepts both forms, and still checks a stated stride
+    f = capi.GpuIndex("l2sq", 20, M=8, ef_construction=32, ef=32, seed=2)
+    fb = rng.standard_normal((500, 20), dtype=np.float32)
+    f.add_many(np.arange(500, dtype=np.uint64) + 1, fb)
+    fr = f.device_query_rows(fb[:8])
+    assert fr.strides[0] == f.row_bytes() == 80
+    fq = hip.Buffer.from_numpy(fr)
+    l1, l2 = hip.Buffer(8 * k * 8), hip.Buffer(8 * k * 8)
+    f.search_batch_device(fq.ptr, 8, k, 0, 0, l1.ptr)
+    f.search_batch_device(fq.ptr, 8, k, 0, 0, l2.ptr, query_stride=80)
+    hip.synchronize()
+    assert np.array_equal(l1.download((8, k), np.uint64), l2.download((8, k), np.uint64))
+    with pytest.raises(capi.LanternGpuError, match="query row stride does not match"):
+        f.search_batch_device(fq.ptr, 8, k, 0, 0, l2.ptr, query_stride=96)
 
 
 def test_golden_insert_dimension_errors_and_misc(capi, golden):
@@ -723,7 +767,7 @@ SPEC_SHAPES = [("l2sq", 3000, 128, 16, 64, "f32"), ("cos", 2500, 768, 16, 64, "f
                ("l2sq", 1500, 768, 8, 64, "f16"), ("cos", 1500, 256, 16, 48, "i8"), ("l2sq", 700, 2000, 4, 20, "f32"), ("l2sq", 800, 600, 32, 64, "f32")]
 
 
-@pytest.mark.parametrize("spec", ["1", "2", "3"])
+@pytest.mark.parametrize("spec", ["1", "2", pytest.param("3", marks=needs_experimental)])
 @pytest.mark.parametrize("metric,n,d,M,ef,quant", SPEC_SHAPES)
 def test_latency_bound_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef, quant, spec, monkeypatch):
     from lantern_amd import hip
@@ -749,10 +793,11 @@ def test_latency_bound_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef
     k = min(10, ef)
     o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(oq, k, ef, 4)
     monkeypatch.setenv("LANTERN_GPU_SPEC", spec)
-    dq = hip.Buffer.from_numpy(hip.padded_rows(queries, metric == "hamming", quant == "f16", quant == "i8", row_bytes=gpu.row_bytes()))
+    rows = gpu.device_query_rows(queries)
+    dq = hip.Buffer.from_numpy(rows)
     lab, dist, D, E = hip.Buffer(nq * k * 8), hip.Buffer(nq * k * 4), hip.Buffer(nq * 8), hip.Buffer(nq * 8)
     gpu.set_search_shape(0)  # the automatic shape: LANTERN_GPU_SPEC decides
-    gpu.search_batch_device(dq.ptr, nq, k, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr)
+    gpu.search_batch_device(dq.ptr, nq, k, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr, query_stride=rows.strides[0])
     hip.synchronize()
     assert np.array_equal(lab.download((nq, k), np.uint64), o_lab)
     assert np.array_equal(dist.download((nq, k), np.float32), o_dist)
@@ -760,7 +805,7 @@ def test_latency_bound_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef
     assert np.array_equal(E.download(nq, np.uint64), o_E), "expansion counts differ"
     # the classic kernel on the same index agrees (LANTERN_GPU_SPEC=0)
     monkeypatch.setenv("LANTERN_GPU_SPEC", "0")
-    gpu.search_batch_device(dq.ptr, nq, k, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr)
+    gpu.search_batch_device(dq.ptr, nq, k, 0, 0, lab.ptr, dist.ptr, None, None, D.ptr, E.ptr, query_stride=rows.strides[0])
     hip.synchronize()
     assert np.array_equal(lab.download((nq, k), np.uint64), o_lab) and np.array_equal(D.download(nq, np.uint64), o_D)
 
@@ -772,6 +817,7 @@ SOLO_SHAPES = [("l2sq", 3000, 128, 16, 64), ("cos", 2500, 128, 16, 64), ("l2sq",
                ("l2sq", 1500, 192, 4, 20), ("cos", 1800, 100, 12, 40), ("l2sq", 1200, 32, 16, 64), ("l2sq", 1000, 4, 16, 10), ("cos", 1500, 200, 16, 64)]
 
 
+@needs_experimental
 @pytest.mark.parametrize("metric,n,d,M,ef", SOLO_SHAPES)
 def test_one_wave_walk_is_the_oracle_walk(capi, oracle, metric, n, d, M, ef, monkeypatch):
     from lantern_amd import hip
@@ -847,7 +893,7 @@ def test_latency_bound_walk_with_a_spilling_visited_set(capi, oracle, monkeypatc
     assert o_D.max() > 300
     for vis_slots in ("256", "0"):  # 256: spills to the HBM bitmap after ~190 visits; 0: the bitmap only
         monkeypatch.setenv("LANTERN_GPU_VIS_SLOTS", vis_slots)
-        for spec in ("1", "2", "3"):
+        for spec in ("1", "2", "3"):  # ("3" is "2" in a library without csrc/experimental/)
             monkeypatch.setenv("LANTERN_GPU_SPEC", spec)
             gpu = capi.GpuIndex("l2sq", d, M=16, ef_construction=64, ef=128, seed=9)
             gpu.import_graph(base, ora.export_graph())

@@ -8,6 +8,8 @@ import time
 import numpy as np
 import pytest
 
+from tests.conftest import needs_experimental
+
 
 @pytest.fixture(scope="module")
 def capi():
@@ -479,7 +481,7 @@ def test_lane_notify_hands_on_every_query_once_with_its_final_rows(capi, metric,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["one_wave_walk", "adc_table_walk"])
+@pytest.mark.parametrize("which", [pytest.param("one_wave_walk", marks=needs_experimental), "adc_table_walk"])
 def test_lane_notify_through_the_other_search_kernels(capi, monkeypatch, which):
     """The per-query completion words are raised by every search kernel's tail: here the one-wave walk (k_search_solo,
     LANTERN_GPU_SPEC=4) and the table walk over PQ code bytes (k_search_adc, a compact pq index with LANTERN_GPU_PQ_ADC=1)."""
