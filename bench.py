@@ -89,9 +89,13 @@ def parse():
                    "configuration): by default, when rocprofv3 is on PATH, the search leg is re-executed under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
                    "(two short passes restricted to k_search) after the timed region and roofline.traffic is THIS run's")
     p.add_argument("--pmc-steps", type=int, default=4, help="search launches per counter pass")
+    p.add_argument("--no-dram-model", action="store_true", help="skip roofline.dram_bytes_model (two traced launches + the LRU replay of their traces)")
     p.add_argument("--no-secondary", action="store_true", help="skip the `secondary` array (bench_secondary.py: BASELINE configs [1] and [2], the clustered set, the "
                    "host-buffer and scan-service paths at the headline shape)")
+    p.add_argument("--base-seed", type=int, default=3, help="numpy default_rng seed of the indexed rows (SURVEY 8d: C3 = 3, C2 = 1)")
+    p.add_argument("--query-seed", type=int, default=4, help="seed of the queries (C3 = 4, C2 = 2)")
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the re-executed search leg: build, launch, print the graph checksum, exit
+    p.add_argument("--dense-child", action="store_true", help=argparse.SUPPRESS)  # the re-executed exact k-NN of bench_secondary.c3_dense_exact_knn (counter pass)
     return p.parse_args()
 
 
@@ -210,6 +214,10 @@ def main():
     from lantern_amd import capi, hip
 
     assert capi.device_count() > 0, "no HIP device: bench.py measures the HIP path only"
+    if a.dense_child:
+        import bench_secondary
+
+        return bench_secondary.dense_child(a, capi, hip)
     # one rank per GPU: hipSetDevice(local_rank).  More ranks than devices (a one-GPU rehearsal of the N-rank job) wrap around -- the
     # ranks then share a device, RCCL is not attempted (bring_up_comm) and the line says so.
     dev_index = (local_rank % capi.device_count()) if world > 1 else 0
@@ -225,7 +233,7 @@ def main():
         shard_lo, shard_hi = capi.shard_range(a.n, world, rank)
         base = synth.shard_rows(a.data, a.n, a.dim, shard_lo, shard_hi)
     else:
-        base = synth.base_rows(a.data, a.n, a.dim)
+        base = synth.base_rows(a.data, a.n, a.dim, a.base_seed)
     if a.data_scale != 1.0:
         raw_queries = make_queries
         make_queries = lambda r, n: raw_queries(r, n) * np.float32(a.data_scale)
@@ -314,7 +322,7 @@ def main():
     if a.pq_subvectors:
         # recall truth = exact k-NN over the DECODED rows (what a PQ index's distances are distances to), taken before the rows go
         mem_before = ix.memory_usage()
-        tq0 = make_queries(np.random.default_rng(4 + 1000 * rank), a.queries * max(a.streams, a.query_batches, 1))[:min(a.truth_queries, a.queries)]  # = queries[:tq] below
+        tq0 = make_queries(np.random.default_rng(a.query_seed + 1000 * rank), a.queries * max(a.streams, a.query_batches, 1))[:min(a.truth_queries, a.queries)]  # = queries[:tq] below
         pq_truth, _ = ix.exact_search(tq0, a.k)
         ix.pq_compact()
         mem_after = ix.memory_usage()
@@ -328,7 +336,7 @@ def main():
     # ---- this rank's queries, resident in HBM ----------------------------------------------------
     # B distinct batches (>= 4 by default), step i searches batch i mod B on stream i mod S: consecutive steps never replay
     # the same queries, so a launch does not find the rows of its own previous run in L2 / the 256 MiB Infinity Cache.
-    qrng = np.random.default_rng(4 + 1000 * rank)
+    qrng = np.random.default_rng(a.query_seed + 1000 * rank)
     nq = a.queries
     S = max(1, a.streams)
     B = max(S, a.query_batches, 1)
@@ -407,13 +415,17 @@ def main():
 
         cpu = None
         quality = None
+        co_headline = (world == 1 and not a.no_secondary and a.quant == "f32" and not a.pq_subvectors and a.metric == "l2sq" and a.data == "gaussian"
+                       and S == 1)  # the clustered set beside the prescribed one (clustered_coheadline)
+        qualities = {}
         if world == 1 and not a.no_cpu and a.cpu_seconds > 0 and not a.pq_subvectors:
             cpu = cpu_baseline(a, ix, base, queries, found)
             if a.build_quality_rows > 0 and a.quant == "f32" and a.metric != "hamming":
-                quality = build_quality(a)
+                qualities = build_quality(a, [a.data] + (["clustered"] if co_headline else []))
+                quality = qualities.get(a.data)
 
         # ---- HBM-side bytes per launch: counter passes of THIS run (measure_traffic), else the committed passes of this command line
-        traffic = traffic_src = dram = None
+        traffic = traffic_src = None
         measured_here = False
         pmc_detail = None
         key = (f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves or 4}" + ("" if a.quant == "f32" else "_" + a.quant)
@@ -428,12 +440,15 @@ def main():
             try:
                 hit = json.load(open(prof)).get(key, {})
                 traffic = hit.get("hbm_bytes_per_launch")
-                dram = hit.get("dram_bytes_per_launch")
                 traffic_src = hit.get("source")
             except Exception:
                 traffic = None
         # ---- distinct rows a launch evaluates (device bitmap, instrumented walk): the cold-miss lower bound of its DRAM bytes
         unique = unique_rows_per_launch(a, ix, step, B, hip) if world == 1 and not a.pq_subvectors else None
+        # ---- what of those bytes reaches DRAM: the cache model over the launch's own trace (f32 l2sq / cos, one launch in flight)
+        model = None
+        if world == 1 and not a.pq_subvectors and a.quant == "f32" and a.metric in ("l2sq", "cos") and S == 1 and not a.no_dram_model:
+            model = dram_model(ix, hip, lanes, nq, a.k, a.ef, q_stride, row_bytes, 2 * a.M * 4, avg_kernel_s, traffic)
         qps = world * nq * a.steps / elapsed
         out = {
             "metric": f"QPS (recall@{a.k} alongside), {a.n}x{a.dim} f32 {a.metric} ef={a.ef} k={a.k}",
@@ -463,15 +478,32 @@ def main():
             "build_roofline": build_roofline(a, build_counters, build_profile, t_build, world),
             "dist_evals_per_query": float(D.mean()),
             "expansions_per_query": float(E.mean()),
-            "roofline": roofline(achieved, traffic, dram, traffic_src, avg_kernel_s if S == 1 else elapsed / a.steps, bytes_per_launch, avg_kernel_s, S, B,
+            "roofline": roofline(achieved, traffic, traffic_src, avg_kernel_s if S == 1 else elapsed / a.steps, bytes_per_launch, avg_kernel_s, S, B,
                                  adc=bool(a.pq_subvectors), measured_here=measured_here, pmc_detail=pmc_detail, unique=unique, row_bytes=row_bytes,
-                                 list_bytes=2 * a.M * 4, expansions_per_launch=float(np.mean([per_lane[i % B][1].sum() for i in range(a.steps)]))),
+                                 list_bytes=2 * a.M * 4, expansions_per_launch=float(np.mean([per_lane[i % B][1].sum() for i in range(a.steps)])), model=model),
             "cpu_baseline": cpu,
             "pq": pq_info,
             "build_quality": quality,
             "collective_build": collective,
             "setup_seconds": {"datagen": t_gen, "build": t_build, "exact_truth": t_truth},
         }
+        if co_headline:
+            # ---- the co-headline: the same shape, index parameters and procedure on the CLUSTERED set -- the set on which recall (>= the
+            # reference's 0.7 / 0.9 floors, scripts/integration_tests.py:249-257) and the roofline fractions (< 1) both mean something
+            t0 = time.time()
+            try:
+                out["clustered"] = clustered_coheadline(a, capi, hip, qualities.get("clustered"))
+            except Exception as ex:  # noqa: BLE001 -- the co-headline never costs the line
+                out["clustered"] = {"error": repr(ex)[:400]}
+            out["setup_seconds"]["clustered"] = time.time() - t0
+            c = out["clustered"]
+            out["sets"] = {"gaussian": {"data": "i.i.d. N(0,1) (SURVEY 8d's prescribed set; no neighbourhood structure in 768 dimensions)", "value": qps,
+                                        f"recall_at_{a.k}": recall, "frac_algorithmic": out["roofline"]["frac_algorithmic"], "frac_fabric": out["roofline"]["frac_fabric"],
+                                        "frac_dram_model": out["roofline"]["frac_dram_model"], "cpu_all_cores": cpu["value"] if cpu else None},
+                           "clustered": {"data": "clustered: " + synth.CLUSTERED_DOC, "value": c.get("value"), f"recall_at_{a.k}": c.get(f"recall_at_{a.k}"),
+                                         "frac_algorithmic": (c.get("roofline") or {}).get("frac_algorithmic"), "frac_fabric": (c.get("roofline") or {}).get("frac_fabric"),
+                                         "frac_dram_model": (c.get("roofline") or {}).get("frac_dram_model"),
+                                         "cpu_all_cores": (c.get("cpu_baseline") or {}).get("value")}}
         if world == 1 and not a.no_secondary and a.quant == "f32" and not a.pq_subvectors and a.metric != "hamming":
             import bench_secondary
 
@@ -484,68 +516,103 @@ def main():
 GATHER_CEILING_GBS = 6730.0  # profiles/r03_gather_ceiling.md: uniformly random 3 KiB rows in the walk's own launch shape (k_gather_walkshape), algorithmic bytes
 
 
-def measure_traffic(a, checksum):
+def measure_traffic(a, checksum, counters=("FETCH_SIZE", "WRITE_SIZE"), kernel="k_search"):
     """roofline.traffic of THIS run: the search leg re-executed under rocprofv3, one pass per counter (FETCH_SIZE takes three of
     the four TCC slots, WRITE_SIZE two: MI355X_MICROARCH.md "rocprofv3 PMC slots"; gpurun refuses counter passes combined with
-    trace domains), restricted to the search kernel.  The child builds the same index from the same seeds (checked: graph
-    checksum), runs max(warmup, batches) + --pmc-steps launches over the same rotating query batches and exits; the mean
-    counter value per launch is converted as the guide's HBM section prescribes: FETCH_SIZE is KiB and on gfx950 reports
-    exactly 1/2 of the bytes of wide coalesced reads -> x 1024 x 2; WRITE_SIZE KiB x 1024 (uncalibrated there; < 0.01 % here).
-    Returns None when rocprofv3 is not on PATH or a pass fails (the committed profiles/pmc_traffic.json is used then)."""
-    import glob
-    import shutil
-    import sqlite3
-    import subprocess
-    import tempfile
+    trace domains), restricted to the search kernel (bench_pmc.run_pass).  The child builds the same index from the same seeds
+    (checked: graph checksum), runs max(warmup, batches) + --pmc-steps launches over the same rotating query batches and exits; the
+    mean counter value per launch is converted as the guide's HBM section prescribes: FETCH_SIZE is KiB and on gfx950 reports
+    exactly 1/2 of the bytes of wide coalesced reads -> x 1024 x 2; WRITE_SIZE KiB x 1024 (uncalibrated there; < 0.01 % here, so the
+    secondary legs pass counters=("FETCH_SIZE",) and say so).
+    Returns None when rocprofv3 is not on PATH (the committed profiles/pmc_traffic.json is used then)."""
+    import bench_pmc
 
-    exe = shutil.which("rocprofv3")
-    if not exe:
+    if not bench_pmc.rocprof():
         return None
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--no-pmc", "--no-cpu", "--truth-queries", "0", "--build-quality-rows", "0",
              "--steps", str(max(1, a.pmc_steps)), "--warmup", "1", "--rows", str(a.n), "--dim", str(a.dim), "--metric", a.metric, "--M", str(a.M),
              "--efc", str(a.efc), "--ef", str(a.ef), "--k", str(a.k), "--queries", str(a.queries), "--query-batches", str(a.query_batches),
              "--waves", str(a.waves), "--max-wg", str(a.max_wg), "--add-batch", str(a.add_batch), "--quant", a.quant, "--data", a.data,
-             "--data-scale", str(a.data_scale), "--pq-subvectors", str(a.pq_subvectors), "--pq-centroids", str(a.pq_centroids)]
+             "--data-scale", str(a.data_scale), "--pq-subvectors", str(a.pq_subvectors), "--pq-centroids", str(a.pq_centroids),
+             "--base-seed", str(a.base_seed), "--query-seed", str(a.query_seed)]
     out = {"counters": {}, "passes": []}
     t0 = time.time()
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        tmp = tempfile.mkdtemp(prefix="lantern_pmc_", dir="/tmp")
-        cmd = [exe, "--kernel-include-regex", "k_search", "--pmc", ctr, "-d", tmp, "-o", "pmc", "--"] + child
-        try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
-            line = next((json.loads(l) for l in p.stdout.splitlines() if l.startswith("{") and "pmc_child" in l), None)
-            if p.returncode != 0 or not line:
-                out["passes"].append({"counter": ctr, "error": f"rc {p.returncode}: {(p.stderr or p.stdout)[-300:]}"})
-                if os.environ.get("LANTERN_BENCH_PMC_LOG"):  # debugging: the failed pass's whole output
-                    with open(os.path.join(os.environ["LANTERN_BENCH_PMC_LOG"], f"pmc_{ctr}.log"), "w") as f:
-                        f.write(p.stdout + "\n==== stderr\n" + p.stderr)
-                continue
-            if line["checksum"] != checksum:
-                out["passes"].append({"counter": ctr, "error": "the child built a different graph"})
-                continue
-            vals = []
-            for db in glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True):
-                cur = sqlite3.connect(db).cursor()
-                vals += [float(v) for (v,) in cur.execute("select value from counters_collection where kernel_name like '%k_search%' and counter_name = ?", (ctr,))]
-            if not vals:
-                out["passes"].append({"counter": ctr, "error": "no counter rows for k_search in the rocprofv3 output"})
-                continue
-            out["counters"][ctr] = {"launches": len(vals), "mean_per_launch": float(np.mean(vals)), "min": float(np.min(vals)), "max": float(np.max(vals))}
-            out["passes"].append({"counter": ctr, "launches": len(vals), "command": "rocprofv3 --kernel-include-regex k_search --pmc " + ctr + " -- python bench.py --pmc-child ..."})
-        except Exception as e:  # noqa: BLE001
-            out["passes"].append({"counter": ctr, "error": repr(e)[:300]})
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
+    for ctr in counters:
+        r = bench_pmc.run_pass(child, kernel, kernel, [ctr], "pmc_child")
+        if "error" in r:
+            out["passes"].append({"counter": ctr, "error": r["error"]})
+            continue
+        if r["child"]["checksum"] != checksum:
+            out["passes"].append({"counter": ctr, "error": "the child built a different graph"})
+            continue
+        vals = r["values"][ctr]
+        if not vals:
+            out["passes"].append({"counter": ctr, "error": f"no counter rows for {kernel} in the rocprofv3 output"})
+            continue
+        out["counters"][ctr] = {"launches": len(vals), "mean_per_launch": float(np.mean(vals)), "min": float(np.min(vals)), "max": float(np.max(vals))}
+        out["passes"].append({"counter": ctr, "launches": len(vals), "command": f"rocprofv3 --kernel-include-regex {kernel} --pmc {ctr} -- python bench.py --pmc-child ..."})
     out["seconds"] = time.time() - t0
     if "FETCH_SIZE" not in out["counters"]:
         out["hbm_bytes_per_launch"] = None
         return out
     rd = out["counters"]["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
     wr = out["counters"].get("WRITE_SIZE", {}).get("mean_per_launch", 0.0) * 1024
-    out.update(read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
-               source="this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes restricted to k_search, over a re-execution of the search leg "
+    out.update(read_bytes_per_launch=rd, write_bytes_per_launch=wr if "WRITE_SIZE" in out["counters"] else None, hbm_bytes_per_launch=rd + wr,
+               source="this run: rocprofv3 " + " / ".join("--pmc " + c for c in counters) + (", separate passes" if len(counters) > 1 else "")
+                      + f" restricted to {kernel}, over a re-execution of the search leg "
                       "(same seeds, same graph checksum, same rotating query batches); FETCH_SIZE KiB x 1024 x 2 (gfx950: the counter reports half the "
-                      "bytes of wide coalesced reads), WRITE_SIZE KiB x 1024 -- /opt/skills/guides/MI355X_MICROARCH.md, HBM")
+                      "bytes of wide coalesced reads)" + (", WRITE_SIZE KiB x 1024" if "WRITE_SIZE" in counters else "; writes not counted (< 0.01 % of the reads in the headline's passes)")
+                      + " -- /opt/skills/guides/MI355X_MICROARCH.md, HBM")
+    return out
+
+
+def dram_model(ix, hip, lanes, nq, k, ef, q_stride, row_bytes, list_bytes, launch_s, traffic):
+    """roofline.dram_bytes_model: what the 256 MiB Infinity Cache MISSES during one launch, by replaying the launch's own memory-object
+    trace through an LRU model of the part's caches (lantern_amd/tools/cache_model.c: eight 4 MiB L2s by XCD in front of the shared
+    Infinity Cache; objects = rows and adjacency lists; the walks of the launch advance one hop at a time on as many walkers as the
+    launch has workgroups).  The part has no counter that separates DRAM from Infinity-Cache service (profiles/r03_counter_notes.md),
+    so this is a MODEL and is labelled so; it is checked on every run by its OTHER output -- the bytes the L2s miss -- against the
+    fabric-side counter bytes of the same launch shape (roofline.traffic), and offline on traces with known answers
+    (tests/test_cache_model.py).  Two launches over different query batches are traced (the instrumented walk records every row a
+    query evaluates and every list it reads, in order: lantern_gpu_search_row_trace; same answers, D and E) and replayed back to back:
+    the figures are those of the SECOND launch, which finds the caches as the first left them -- the steady state of the timed loop."""
+    import bench_cache_model as cm
+
+    cap = 8192
+    t0 = time.time()
+    traces, counts = [], []
+    try:
+        for i in range(2):
+            L = lanes[i % len(lanes)]
+            ix.row_trace_begin(nq, cap)
+            ix.search_batch_device(L["dq"].ptr, nq, k, ef, 0, L["lab"].ptr, L["dist"].ptr, None, None, None, None, None, query_stride=q_stride)
+            hip.synchronize()
+            walkers = ix.last_search_grid()
+            t, c = ix.row_trace_end()
+            traces.append(t)
+            counts.append(c)
+    except Exception as e:  # noqa: BLE001 -- a diagnostic: the line stands without it
+        try:
+            ix.row_trace_end()
+        except Exception:  # noqa: BLE001
+            pass
+        return {"error": repr(e)[:300]}
+    listu = list_bytes // 2
+    res = cm.replay(traces, counts, walkers, int(row_bytes), int(list_bytes), int(listu))
+    cold, steady = res
+    out = {"model": "LRU replay of the launch's own row / adjacency-list trace: 8 x 4 MiB L2 (by XCD) -> 256 MiB Infinity Cache, fully associative, object "
+                    "granularity, walks advance one hop per turn on `walkers` workgroups (lantern_amd/tools/cache_model.c; tests/test_cache_model.py)",
+           "walkers": walkers, "trace_entries_per_launch": steady["accesses"], "dropped_entries": steady["dropped_entries"],
+           "trace_bytes_per_launch": steady["access_bytes"],
+           "dram_bytes_model": steady["dram_bytes"], "fabric_bytes_model": steady["fabric_bytes"],
+           "dram_bytes_model_cold_caches": cold["dram_bytes"], "fabric_bytes_model_cold_caches": cold["fabric_bytes"],
+           "distinct_bytes_per_launch": cm.distinct_bytes(traces[1], counts[1], row_bytes, list_bytes, listu),
+           "frac_dram_model": steady["dram_bytes"] / launch_s / 1e9 / HBM_PEAK_GBS,
+           "frac_fabric_model": steady["fabric_bytes"] / launch_s / 1e9 / HBM_PEAK_GBS,
+           "fabric_model_over_counters": (steady["fabric_bytes"] / traffic) if traffic else None,
+           "check": "fabric_model_over_counters near 1 says the model's L2 level reproduces what rocprofv3 counted at the fabric for this launch shape; "
+                    "the DRAM level is the same replay one cache further out",
+           "seconds": time.time() - t0}
     return out
 
 
@@ -571,40 +638,43 @@ def unique_rows_per_launch(a, ix, step, B, hip):
     return float(np.mean(counts)) if counts else None
 
 
-def roofline(achieved_alg, traffic, dram, traffic_src, launch_s, bytes_per_launch, avg_kernel_s, S, B, adc=False, measured_here=False, pmc_detail=None,
-             unique=None, row_bytes=0.0, list_bytes=0.0, expansions_per_launch=0.0):
-    """The search kernel against the HBM roofline (8 TB/s spec peak).
+def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg_kernel_s, S, B, adc=False, measured_here=False, pmc_detail=None,
+             unique=None, row_bytes=0.0, list_bytes=0.0, expansions_per_launch=0.0, model=None):
+    """The search kernel against the HBM roofline (8 TB/s spec peak).  FOUR fractions, each named for what it is a fraction OF:
 
-    `frac` / `achieved` are PHYSICAL: the bytes the L2 requested from the fabric during a launch (rocprofv3 counters, `traffic`,
-    measured in this run when rocprofv3 is present) / the launch's HIP-event duration.  They can not exceed the peak by
-    construction of the hardware, and they still include what the 256 MiB Infinity Cache served (the part exposes no counter
-    that separates DRAM from it: profiles/r03_counter_notes.md) -- an upper bound of the DRAM rate.
-    `frac_algorithmic` / `achieved_algorithmic` are SURVEY 8d's bytes -- one row per distance evaluation, one adjacency row per
-    expansion, D and E counted on the device and equal to the oracle's -- over the same time: what the walk ASKS for.  Rows that
-    several queries of a launch evaluate (upper levels, hub rows of un-normalised Gaussian data under L2sq) are counted once
-    per evaluation there but come from L2 / Infinity Cache, so this figure may exceed 1; counter bytes BELOW algorithmic bytes
-    mean no wasted re-reads.
-    `frac_cold_miss_lower_bound`: distinct rows of a launch x row bytes (+ its adjacency rows) / time / peak -- what DRAM must
-    deliver even with perfect caches.  The true DRAM fraction lies between this and `frac`."""
+    `frac` = `frac_algorithmic` (the contract's definition): one row per distance evaluation, one adjacency row per
+        expansion, D and E counted on the device and equal to the oracle's, / the HIP-event launch time / 8 TB/s.  What the walk ASKS
+        the memory system for.  Rows that several queries of a launch evaluate (upper levels, hub rows of un-normalised Gaussian data
+        under L2sq: each touched row ~54 times per 8192-query launch) are counted once per evaluation but come from L2 / Infinity
+        Cache, so on such a set this figure EXCEEDS 1 and is not a fraction of what HBM delivered.
+    `frac_fabric`: the bytes the L2s requested from the fabric during a launch (rocprofv3 FETCH_SIZE / WRITE_SIZE, `traffic`,
+        measured in this run) / the same time / 8 TB/s.  Physical, but it still INCLUDES what the 256 MiB Infinity Cache served (the
+        part has no counter that separates the two: profiles/r03_counter_notes.md) -- an upper bound of the DRAM rate.
+    `frac_dram_model`: Infinity-Cache MISSES of an LRU replay of the launch's own trace (dram_model(); lantern_amd/tools/cache_model.c)
+        / time / 8 TB/s.  A model, validated by its fabric-side output against the counters (`dram_model.fabric_model_over_counters`).
+    `frac_cold_miss_lower_bound`: distinct rows of a launch x row bytes (+ their adjacency rows) / time / 8 TB/s -- what DRAM must
+        deliver even with perfect caches.  The true DRAM fraction lies between this and `frac_fabric`; `frac_dram_model` estimates it."""
     alg_frac = achieved_alg / HBM_PEAK_GBS
-    phys = (traffic / launch_s / 1e9) if traffic else None
+    fabric = (traffic / launch_s / 1e9) if traffic else None
     r = {"bound": "hbm",
-         "achieved": phys if phys is not None else achieved_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": (phys if phys is not None else achieved_alg) / HBM_PEAK_GBS,
-         # the same rate over what the part can actually deliver: a pure DRAM stream (6.29 TB/s measured) and uniformly random
-         # 3 KiB rows in the walk's own launch shape (6.73 TB/s algorithmic, profiles/r03_gather_ceiling.md).  Values ABOVE 1 say the
-         # bytes cannot all have come from DRAM: the fabric-side counters include what the 256 MiB Infinity Cache served.
-         "frac_of_streaming": (phys if phys is not None else achieved_alg) / HBM_MEASURED_CEILING_GBS,
-         "frac_of_gather_ceiling": (phys if phys is not None else achieved_alg) / GATHER_CEILING_GBS,
-         "frac_basis": ("fabric-side counter bytes per launch (roofline.traffic) / HIP-event launch time" if phys is not None else
-                        "ALGORITHMIC bytes (no counter pass available for this configuration: rocprofv3 absent and no committed pass) / launch time"),
+         "achieved": achieved_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_frac,
+         "frac_is": "frac_algorithmic -- SURVEY 8d algorithmic bytes / HIP-event launch time / 8 TB/s (the bench contract's definition).  Above ~0.84 "
+                    "(the measured random-row gather ceiling) it is NOT a physical HBM fraction: rows shared by the queries of a launch are counted once per "
+                    "evaluation and served by L2 / Infinity Cache.  The physical figures are frac_fabric (counters; includes Infinity-Cache hits) and "
+                    "frac_dram_model (cache-model estimate of DRAM bytes), bounded below by frac_cold_miss_lower_bound",
          "traffic": traffic, "traffic_measured_in_this_run": bool(measured_here), "traffic_source": traffic_src,
-         "achieved_algorithmic": achieved_alg, "frac_algorithmic": alg_frac,
          "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
+         "achieved_algorithmic": achieved_alg, "frac_algorithmic": alg_frac,
+         "achieved_fabric": fabric, "frac_fabric": (fabric / HBM_PEAK_GBS) if fabric else None,
+         "frac_fabric_of_streaming_ceiling": (fabric / HBM_MEASURED_CEILING_GBS) if fabric else None,
+         "dram_bytes_model": model.get("dram_bytes_model") if model else None,
+         "frac_dram_model": model.get("frac_dram_model") if model else None,
+         "frac_dram_model_of_streaming_ceiling": (model["frac_dram_model"] * HBM_PEAK_GBS / HBM_MEASURED_CEILING_GBS) if model and model.get("frac_dram_model") else None,
+         "dram_model": model,
          "unique_rows_per_launch": unique,
          "cold_miss_bytes_per_launch": None, "frac_cold_miss_lower_bound": None,
-         "dram_bytes_per_launch": dram, "frac_dram": (dram / launch_s / 1e9 / HBM_PEAK_GBS) if dram else None,
-         "gather_ceiling": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r03_gather_ceiling.md (uniformly random 3 KiB rows in the walk's launch shape, algorithmic bytes)",
+         "dram_bytes_per_launch": None, "frac_dram": None,  # (no DRAM-side counter on this part; see dram_bytes_model)
+         "gather_ceiling": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r03_gather_ceiling.md (uniformly random 3 KiB rows in the walk's launch shape, algorithmic bytes = counter bytes)",
          "algorithmic_over_gather_ceiling": achieved_alg / GATHER_CEILING_GBS,
          "streaming_ceiling": HBM_MEASURED_CEILING_GBS,
          "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_kernel_s * 1e3,
@@ -625,8 +695,8 @@ def roofline(achieved_alg, traffic, dram, traffic_src, launch_s, bytes_per_launc
         notes.append(f"{S} launches in flight: rates = all launches' bytes / the timed region; avg_launch_ms is the mean HIP-event "
                      "duration of launches that overlap")
     if alg_frac > 1.0 or achieved_alg > GATHER_CEILING_GBS:
-        notes.append("frac_algorithmic exceeds " + ("1" if alg_frac > 1.0 else "the random-row gather ceiling") + ": rows shared by the queries of a launch "
-                     "(upper levels, hub rows) are counted once per evaluation but served by L2 / Infinity Cache; `frac` (counter bytes) is the physical figure")
+        notes.append("frac (algorithmic) exceeds " + ("1" if alg_frac > 1.0 else "the random-row gather ceiling") + ": rows shared by the queries of a launch "
+                     "(upper levels, hub rows) are counted once per evaluation but served by L2 / Infinity Cache; frac_fabric and frac_dram_model are the physical figures")
     r["note"] = "; ".join(notes) or None
     return r
 
@@ -655,47 +725,173 @@ def build_roofline(a, c, prof, t_build, world):
     return out
 
 
-def build_quality(a):
+def build_quality(a, kinds):
     """north_star: "recall@10 within +-0.5 % of the reference".  The reference builds with one usearch_add per tuple
     (build.c:83-135); the device builds batch-synchronously (batches of up to --add-batch, never more than size / 16).  On
-    --build-quality-rows rows of the bench's OWN shape (--dim, --metric, --data; seeds 1 / 2) both builds are made from the
-    same rows -- the sequential one by the CPU port, usearch's own summation flags -- and searched ON THE DEVICE with the same
-    queries against exact truth.  (tests/test_gpu_fullsize.py asserts the same on the full 1M x 768 headline set,
-    tests/test_gpu_baseline_configs.py on the C2 set, a low-rank and a clustered set.)"""
-    from lantern_amd import capi
+    --build-quality-rows rows of the bench's OWN shape (--dim, --metric; seeds 1 / 2), for every data kind in `kinds`, both builds
+    are made from the same rows -- the sequential one by the CPU port, usearch's own summation flags -- and searched ON THE DEVICE
+    with the same queries against exact truth.  The sequential CPU builds (~55 s each at 100k x 768) run side by side on a thread each.
+    (tests/test_gpu_fullsize.py asserts the same on the full 1M x 768 headline set, tests/test_gpu_baseline_configs.py on the C2
+    set, a low-rank and a clustered set.)  -> {kind: result}"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from lantern_amd import capi, synth
     from oracle import binding as oracle
+
+    n, d, metric = a.build_quality_rows, a.dim, a.metric
+    sets = {}
+    for kind in dict.fromkeys(kinds):
+        make = synth.query_maker(kind, d)
+        sets[kind] = (make(np.random.default_rng(1), n), make(np.random.default_rng(2), 1000))
+    labels = np.arange(n, dtype=np.uint64) + 1
+
+    def sequential(kind):  # (ctypes releases the GIL: the builds of the sets overlap)
+        seq = oracle.OracleIndex(metric, d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, sum_mode=oracle.SUM_FAST)
+        seq.reserve(n)
+        t0 = time.perf_counter()
+        seq.add_many(labels, sets[kind][0])
+        return seq.export_graph(), time.perf_counter() - t0
+
+    with ThreadPoolExecutor(max_workers=max(1, len(sets))) as ex:
+        futures = {kind: ex.submit(sequential, kind) for kind in sets}
+        dev_side = {}
+        for kind, (base, queries) in sets.items():  # the device builds meanwhile
+            dev = capi.GpuIndex(metric, d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
+            dev.reserve(n)
+            dev.set_add_batch(a.add_batch, 16)
+            t0 = time.perf_counter()
+            dev.add_many(labels, base)
+            dev.flush()
+            t_dev = time.perf_counter() - t0
+            truth, _ = dev.exact_search(queries, a.k)
+            lab, _, _ = dev.search_batch(queries, a.k, a.ef)
+            dev_side[kind] = (oracle.recall_at_k(lab.astype(np.int64) - 1, truth), t_dev, truth)
+        graphs = {kind: f.result() for kind, f in futures.items()}
+    out = {}
+    for kind, (base, queries) in sets.items():
+        r_dev, t_dev, truth = dev_side[kind]
+        graph, t_seq = graphs[kind]
+        ref = capi.GpuIndex(metric, d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
+        ref.import_graph(base, graph)
+        lab2, _, _ = ref.search_batch(queries, a.k, a.ef)
+        r_seq = oracle.recall_at_k(lab2.astype(np.int64) - 1, truth)
+        out[kind] = {"set": f"{n}x{d} f32 {metric} {kind}, seeds 1 / 2 (the bench's own --dim / --metric), 1000 queries, ef={a.ef}",
+                     "recall_device_batched_build": r_dev, "recall_sequential_build": r_seq, "abs_diff": abs(r_dev - r_seq), "device_minus_sequential": r_dev - r_seq,
+                     "bar": 0.005,
+                     "device_build_seconds": t_dev, "sequential_cpu_build_seconds": t_seq, "sequential_cpu_build_vectors_per_s": n / t_seq,
+                     "sequential_builds_side_by_side": len(sets)}
+    return out
+
+
+def clustered_coheadline(a, capi, hip, quality):
+    """The headline's shape, index parameters and measuring procedure on the clustered set (lantern_amd/synth.py): value, recall,
+    the roofline with counters of THIS run and the DRAM model, the CPU port on all cores and on one (median of three), the build
+    quality leg, and BASELINE config[2]'s form (cosine, 1024-query batches) on the same rows."""
+    import copy
 
     from lantern_amd import synth
 
-    n, d = a.build_quality_rows, a.dim
-    make = synth.query_maker(a.data, d)
-    base = make(np.random.default_rng(1), n)
-    queries = make(np.random.default_rng(2), 1000)
-    labels = np.arange(n, dtype=np.uint64) + 1
-    metric = a.metric
-    dev = capi.GpuIndex(metric, d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
-    dev.reserve(n)
-    dev.set_add_batch(a.add_batch, 16)
-    t0 = time.perf_counter()
-    dev.add_many(labels, base)
-    dev.flush()
-    t_dev = time.perf_counter() - t0
-    truth, _ = dev.exact_search(queries, a.k)
-    lab, _, _ = dev.search_batch(queries, a.k, a.ef)
-    r_dev = oracle.recall_at_k(lab.astype(np.int64) - 1, truth)
-    seq = oracle.OracleIndex(metric, d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42, sum_mode=oracle.SUM_FAST)
-    seq.reserve(n)
-    t0 = time.perf_counter()
-    seq.add_many(labels, base)
-    t_seq = time.perf_counter() - t0
-    ref = capi.GpuIndex(metric, d, M=a.M, ef_construction=a.efc, ef=a.ef, seed=42)
-    ref.import_graph(base, seq.export_graph())
-    lab2, _, _ = ref.search_batch(queries, a.k, a.ef)
-    r_seq = oracle.recall_at_k(lab2.astype(np.int64) - 1, truth)
-    return {"set": f"{n}x{d} f32 {metric} {a.data}, seeds 1 / 2 (the bench's own --dim / --metric / --data), 1000 queries, ef={a.ef}",
-            "recall_device_batched_build": r_dev, "recall_sequential_build": r_seq, "abs_diff": abs(r_dev - r_seq), "device_minus_sequential": r_dev - r_seq,
-            "bar": 0.005,
-            "device_build_seconds": t_dev, "sequential_cpu_build_seconds": t_seq, "sequential_cpu_build_vectors_per_s": n / t_seq}
+    b = copy.copy(a)
+    b.data, b.query_batches = "clustered", 4
+    n, d, nq, B = b.n, b.dim, b.queries, 4
+    t0 = time.time()
+    base = synth.base_rows("clustered", n, d, b.base_seed)
+    make = synth.query_maker("clustered", d)
+    all_queries = make(np.random.default_rng(b.query_seed), nq * B)
+    t_gen = time.time() - t0
+
+    def build(metric):
+        ix = capi.GpuIndex(metric, d, M=b.M, ef_construction=b.efc, ef=b.ef, seed=42)
+        ix.reserve(n)
+        ix.set_add_batch(b.add_batch, 16)
+        ix.set_profiling(True)
+        hip.synchronize()
+        t0 = time.time()
+        ix.add_many(np.arange(n, dtype=np.uint64) + 1, base)
+        ix.flush()
+        hip.synchronize()
+        return ix, time.time() - t0
+
+    def resident(ix, queries, per):
+        out = []
+        for i in range(queries.shape[0] // per):
+            rows = ix.device_query_rows(queries[i * per:(i + 1) * per])
+            out.append({"dq": hip.Buffer.from_numpy(rows), "stride": rows.strides[0], "lab": hip.Buffer(per * b.k * 8), "dist": hip.Buffer(per * b.k * 4),
+                        "slot": hip.Buffer(per * b.k * 4), "D": hip.Buffer(per * 8), "E": hip.Buffer(per * 8)})
+        return out
+
+    def timed(ix, lanes, per, steps, stream):
+        def step(i):
+            L = lanes[i % len(lanes)]
+            ix.search_batch_device(L["dq"].ptr, per, b.k, b.ef, 0, L["lab"].ptr, L["dist"].ptr, L["slot"].ptr, None, L["D"].ptr, L["E"].ptr, stream.handle,
+                                   query_stride=L["stride"])
+        for i in range(max(b.warmup, len(lanes))):
+            step(i)
+        hip.synchronize()
+        ev = [(hip.Event(), hip.Event()) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i, (s_, e_) in enumerate(ev):
+            s_.record(stream.handle)
+            step(i)
+            e_.record(stream.handle)
+        hip.synchronize()
+        elapsed = time.perf_counter() - t0
+        per_lane = []
+        for L in lanes:
+            Dl = L["D"].download(per, np.uint64).astype(np.float64)
+            El = L["E"].download(per, np.uint64).astype(np.float64)
+            per_lane.append((Dl, El, float((Dl * d * 4 + El * (2 * b.M * 4) + d * 4).sum())))
+        bytes_l = float(np.mean([per_lane[i % len(lanes)][2] for i in range(steps)]))
+        exp_l = float(np.mean([per_lane[i % len(lanes)][1].sum() for i in range(steps)]))
+        return step, elapsed, float(np.mean([s_.elapsed_ms(e_) for s_, e_ in ev])) / 1e3, bytes_l, exp_l, per_lane
+
+    st = hip.Stream()
+    ix, t_build = build(b.metric)
+    counters, profile = ix.counters(), ix.build_profile()
+    lanes = resident(ix, all_queries, nq)
+    steps = max(8, min(b.steps, 12))
+    step, elapsed, launch_s, bytes_l, exp_l, per_lane = timed(ix, lanes, nq, steps, st)
+    tq = min(b.truth_queries, nq)
+    truth = ix.exact_search(all_queries[:tq], b.k)[0]
+    found = lanes[0]["slot"].download((nq, b.k), np.uint32)
+    recall = float(np.mean([len(set(f.tolist()) & set(t.tolist())) / b.k for f, t in zip(found[:tq], truth)]))
+    cpu = cpu_baseline(b, ix, base, all_queries[:nq], found[:tq]) if not b.no_cpu and b.cpu_seconds > 0 else None
+    traffic = src = pmc = None
+    if not b.no_pmc:
+        pmc = measure_traffic(b, f"{ix.checksum():016x}")
+        if pmc and pmc.get("hbm_bytes_per_launch"):
+            traffic, src = pmc["hbm_bytes_per_launch"], pmc["source"]
+    unique = unique_rows_per_launch(b, ix, step, B, hip)
+    model = None if b.no_dram_model else dram_model(ix, hip, lanes, nq, b.k, b.ef, lanes[0]["stride"], d * 4, 2 * b.M * 4, launch_s, traffic)
+    qps = nq * steps / elapsed
+    out = {"workload": f"HNSW search {n}x{d} f32 {b.metric} M={b.M} ef_construction={b.efc} ef={b.ef} k={b.k}, {nq}-query batches resident in HBM",
+           "data": "synthetic (clustered: " + synth.CLUSTERED_DOC + ")", "value": qps, "unit": "queries/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+           f"recall_at_{b.k}": recall, "recall_queries": tq, "dist_evals_per_query": float(per_lane[0][0].mean()), "expansions_per_query": float(per_lane[0][1].mean()),
+           "roofline": roofline(bytes_l / launch_s / 1e9, traffic, src, launch_s, bytes_l, launch_s, 1, B, measured_here=traffic is not None, pmc_detail=pmc, unique=unique,
+                                row_bytes=d * 4, list_bytes=2 * b.M * 4, expansions_per_launch=exp_l, model=model),
+           "cpu_baseline": cpu, "gpu_over_cpu_all_cores": (qps / cpu["value"]) if cpu else None, "gpu_over_cpu_1_thread": (qps / cpu["value_1_thread"]) if cpu else None,
+           "build_vectors_per_s": n / t_build, "build_seconds": t_build, "build_roofline": build_roofline(b, counters, profile, t_build, 1),
+           "build_quality": quality, "setup_seconds": {"datagen": t_gen}}
+    # ---- BASELINE config[2]'s form on the same rows: cosine, 1024-query batches, one and two launches in flight
+    try:
+        cix, t_cbuild = build("cos")
+        cq = 1024
+        cl = resident(cix, all_queries[:cq * 8], cq)
+        csteps = 24
+        _, c_el, c_launch, c_bytes, _, c_lane = timed(cix, cl, cq, csteps, st)
+        ctruth = cix.exact_search(all_queries[:cq], b.k)[0]
+        cfound = cl[0]["slot"].download((cq, b.k), np.uint32)
+        c_alg = c_bytes / c_launch / 1e9
+        out["cosine_1024_query_batches"] = {
+            "workload": f"BASELINE config[2]'s form on the clustered rows: HNSW search {n}x{d} f32 cos M={b.M} ef_construction={b.efc} ef={b.ef} k={b.k}, {cq}-query batches resident in HBM",
+            "value": cq * csteps / c_el, "unit": "queries/s", "ms_per_step": c_el / csteps * 1e3,
+            f"recall_at_{b.k}": float(np.mean([len(set(f.tolist()) & set(t.tolist())) / b.k for f, t in zip(cfound, ctruth)])),
+            "dist_evals_per_query": float(c_lane[0][0].mean()), "build_vectors_per_s": n / t_cbuild,
+            "roofline": {"bound": "hbm", "achieved": c_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c_alg / HBM_PEAK_GBS, "frac_is": "frac_algorithmic (SURVEY 8d bytes / HIP-event launch time)",
+                         "frac_of_gather_ceiling": c_alg / GATHER_CEILING_GBS, "algorithmic_bytes_per_launch": c_bytes, "avg_launch_ms": c_launch * 1e3, "kernel": "k_search", "traffic": None}}
+    except Exception as ex:  # noqa: BLE001
+        out["cosine_1024_query_batches"] = {"error": repr(ex)[:300]}
+    return out
 
 
 def cpu_baseline(a, ix, base, queries, gpu_found):

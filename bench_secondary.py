@@ -6,8 +6,10 @@ ways the same hot path is called under the same (driver's) clock:
   c2_one_query_per_call     BASELINE config[1]: 100k x 128 f32 L2sq, M=16 ef=64 k=10, ONE usearch_search_ef per call -- the
                             reference's actual calling pattern (lantern_hnsw/src/hnsw/scan.c:220-228); wall and kernel time
   c3_cosine_1024_batches    BASELINE config[2]: 1M x 768 f32 cosine, 1024-query batches, one and two launches in flight
-  clustered_1Mx768_l2sq     the headline shape on the clustered set (lantern_amd/synth.py): the recall >= 0.9 regime the
-                            reference asserts recall in (scripts/integration_tests.py:249-264)
+  c3_dense_exact_knn        BASELINE config[2]'s dense contraction: the exact k-NN of 1024 queries x 1M x 768 cosine through k_dense_f32
+                            (fp32 MFMA): TFLOP/s of steady full-chunk launches and of the whole call against the 157.3 TFLOP/s
+                            fp32-matrix peak, and the matrix pipe's busy fraction from an in-run rocprofv3 counter pass
+  (the clustered set is no longer a secondary entry: it is the line's co-headline, bench.py clustered_coheadline)
   headline_host_buffers     the headline index through lantern_gpu_search_batch / _lane: queries and answers in HOST memory
                             (PCIe both ways inside the timed region) -- what a caller of the C ABI gets
   headline_scan_service     the headline index behind the scan-side service at 256 connections (one query per request, the
@@ -22,6 +24,7 @@ from __future__ import annotations
 import json
 import os
 import subprocess
+import sys
 import threading
 import time
 
@@ -69,6 +72,130 @@ def _over_cpu(value, cpu):
     return {"gpu_over_cpu_1_thread": value / cpu["value_1_thread"], "gpu_over_cpu_all_cores": value / cpu["value"]}
 
 
+def _traffic_of(a, measure_traffic, ix, **shape):
+    """Fabric-side bytes per launch of a secondary leg's own launch shape: ONE in-run rocprofv3 --pmc FETCH_SIZE pass over a re-execution
+    of that shape (bench.py --pmc-child; same seeds, graph checksum checked).  Writes are not counted here (< 0.01 % of the reads in
+    the headline's two-pass measurement).  (None, None) when rocprofv3 is absent or --no-pmc."""
+    if measure_traffic is None:
+        return None, None
+    import copy
+
+    b = copy.copy(a)
+    b.n, b.dim, b.metric = shape["rows"], shape["dim"], shape["metric"]
+    b.queries, b.query_batches, b.base_seed, b.query_seed, b.pmc_steps = shape["queries"], shape["query_batches"], shape["base_seed"], shape["query_seed"], shape["pmc_steps"]
+    b.data, b.quant, b.pq_subvectors, b.data_scale = "gaussian", "f32", 0, 1.0
+    det = measure_traffic(b, f"{ix.checksum():016x}", counters=("FETCH_SIZE",))
+    if det and det.get("hbm_bytes_per_launch"):
+        return det["hbm_bytes_per_launch"], det["source"]
+    return None, (det or {}).get("passes")
+
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md / SURVEY 8d: dense fp32 matrix (v_mfma_f32_32x32x2_f32: 256 CUs x 256 flop/cycle x 2.4 GHz)
+DENSE_CHUNK = 65536             # columns of a full launch of the exact k-NN (index.cpp exact_knn_device_impl)
+
+
+def _graphless_index(capi, metric, base):
+    """Rows in HBM without a graph: all the exact k-NN needs."""
+    n = base.shape[0]
+    ix = capi.GpuIndex(metric, base.shape[1], M=4, ef_construction=8)
+    g = {"levels": np.zeros(n, np.uint8), "nbr0": np.full((n, 8), 0xFFFFFFFF, np.uint32), "upper_off": np.full(n, 0xFFFFFFFF, np.uint32),
+         "upper_nbr": np.zeros((0, 4), np.uint32), "labels": None, "entry_slot": 0, "max_level": 0}
+    ix.import_graph(base, g)
+    return ix
+
+
+def dense_child(a, capi, hip):
+    """`bench.py --dense-child`: the exact k-NN leg alone, for a rocprofv3 counter pass over k_dense_f32 (c3_dense_exact_knn)."""
+    base = np.random.default_rng(3).standard_normal((a.n, a.dim), dtype=np.float32)
+    queries = np.random.default_rng(4).standard_normal((1024, a.dim), dtype=np.float32)
+    ix = _graphless_index(capi, "cos", base)
+    for _ in range(3):
+        slots, _ = ix.exact_search(queries, a.k)
+    hip.synchronize()
+    print(json.dumps({"dense_child": True, "calls": 3, "slot_checksum": int(slots.astype(np.uint64).sum())}), flush=True)
+
+
+def c3_dense_exact_knn(a, capi, hip, base, keep=None):
+    """BASELINE config[2] / north_star: "batched IP as MFMA GEMM, rocprof MFMA util".  The one dense contraction on the path: exact k-NN
+    of 1024 queries x N x d (cosine) = k_dense_f32 (fp32 MFMA, csrc/bruteforce.hip) + fused top-k + exact re-rank; the reference's
+    own dense site is the PQ k-means assignment (product_quantization.c:80-124), which runs on the same kernel.
+    Algorithmic flops = 2 d per REQUIRED (query, row) pair (padding earns nothing)."""
+    import bench_pmc
+
+    n, d, nq, k = base.shape[0], base.shape[1], 1024, a.k
+    queries = np.random.default_rng(4).standard_normal((nq, d), dtype=np.float32)  # C3: base seed 3, queries seed 4
+    ix = (keep or {}).get("cos_index") or _graphless_index(capi, "cos", base)
+    ix.exact_search(queries, k)  # first call: first touch of the row block, clock ramp (its launches are the "cold" ones)
+    hip.synchronize()
+    calls = 6
+    capi.dense_profile(True)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        slots, dists = ix.exact_search(queries, k)
+    hip.synchronize()
+    wall = (time.perf_counter() - t0) / calls
+    recs = capi.dense_profile(False)
+    full = [r["ms"] for r in recs if r["rows"] == nq and r["cols"] == DENSE_CHUNK and r["ms"] > 0]
+    other = [r for r in recs if not (r["rows"] == nq and r["cols"] == DENSE_CHUNK)]
+    flops_call = 2.0 * nq * n * d
+    flops_full = 2.0 * nq * DENSE_CHUNK * d
+    full_ms = float(np.mean(full)) if full else None
+    steady = flops_full / (full_ms * 1e-3) / 1e12 if full_ms else None
+    kernel_ms_per_call = float(sum(r["ms"] for r in recs if r["ms"] > 0)) / calls
+    # the same calls on the CPU port's brute force (one thread and all cores are both memory-bound f32 dot products)
+    from oracle import binding as oracle
+
+    import bench_cpu
+
+    cores = bench_cpu.usable_cores()
+    oracle.build_native() and oracle.use_native(True)
+    sample = max(8, min(2 * cores, 64))
+    t0 = time.perf_counter()
+    truth, _ = oracle.bruteforce(base, queries[:sample], k, "cos", oracle.SUM_FAST, cores)
+    cpu_s = (time.perf_counter() - t0) / sample
+    agree = float(np.mean([len(set(x.tolist()) & set(y.tolist())) / k for x, y in zip(slots[:sample], truth)]))
+    roof = {"bound": "mfma_fp32", "algorithmic_flops_per_call": flops_call, "algorithmic_flops_per_full_launch": flops_full,
+            "avg_launch_ms": full_ms, "avg_launch_ms_basis": f"HIP events around the {len(full)} steady full-chunk launches (1024 x {DENSE_CHUNK} x {d}) of {calls} calls after a warm-up call",
+            "achieved": steady, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (steady / FP32_MATRIX_PEAK_TFLOPS) if steady else None,
+            "launches_per_call": len(recs) / calls, "other_launches_ms": sorted({(r["cols"], round(r["ms"], 3)) for r in other})[:6],
+            "contraction_ms_per_call": kernel_ms_per_call, "achieved_contraction_per_call": flops_call / (kernel_ms_per_call * 1e-3) / 1e12 if kernel_ms_per_call else None,
+            "call_level": {"seconds_per_call_wall": wall, "achieved": flops_call / wall / 1e12, "frac": flops_call / wall / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+                           "includes": "host query padding + H2D, row norms, the partial last chunk, fused top-k selection, exact re-rank, D2H of the answers"},
+            "kernel": "k_dense_f32<cos, fused top-k> (csrc/bruteforce.hip: v_mfma_f32_32x32x2_f32, buffer_load ... lds, persistent, software-pipelined)",
+            "traffic": None, "mfma_busy": None}
+    if a.no_pmc or not bench_pmc.rocprof():
+        roof["mfma_busy_note"] = "no counter pass (--no-pmc or rocprofv3 absent); the last committed one: profiles/r04_dense_mfma.md (0.892)"
+    else:
+        child = [sys.executable, os.path.join(ROOT, "bench.py"), "--dense-child", "--rows", str(n), "--dim", str(d), "--k", str(k)]
+        r = bench_pmc.run_pass(child, "k_dense_f32", "k_dense_f32", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], "dense_child")
+        if "error" in r:
+            roof["mfma_busy_note"] = "counter pass failed: " + r["error"]
+        else:
+            v = r["values"]
+            m, sq, gui = (np.array(v[c], dtype=np.float64) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))
+            if len(m) and len(m) == len(gui) == len(sq):
+                big = gui >= 0.8 * gui.max()  # the full-chunk launches (a partial chunk is a third of one)
+                simds, xcds, ses = 1024.0, 8.0, 32.0  # the counters are sums over 256 CUs x 4 SIMDs | 8 XCDs | 32 shader engines (profiles/r03_dense_mfma.md)
+                busy_gui = (m[big] / simds) / (gui[big] / xcds)
+                busy_sq = (m[big] / simds) / (sq[big] / ses)
+                roof["mfma_busy"] = float(np.median(busy_gui))
+                roof["mfma_busy_detail"] = {"definition": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs, median over the full-chunk launches of the pass",
+                                            "over_sq_busy_cycles": float(np.median(busy_sq)), "launches_counted": int(big.sum()), "launches_in_pass": int(len(m)),
+                                            "mean_per_full_launch": {"SQ_VALU_MFMA_BUSY_CYCLES": float(m[big].mean()), "SQ_BUSY_CYCLES": float(sq[big].mean()), "GRBM_GUI_ACTIVE": float(gui[big].mean())},
+                                            "effective_clock_GHz": float(np.median(gui[big] / xcds) / (full_ms * 1e-3) / 1e9) if full_ms else None,
+                                            "command": r["command"], "seconds": r["seconds"]}
+            else:
+                roof["mfma_busy_note"] = f"counter rows do not line up ({len(m)} / {len(sq)} / {len(gui)})"
+    return {"name": "c3_dense_exact_knn",
+            "workload": f"BASELINE config[2]'s dense contraction: exact k-NN of {nq} queries x {n} x {d} f32 cos (k={k}) through k_dense_f32 (fp32 MFMA) + fused top-k + exact re-rank",
+            "value": nq / wall, "unit": "queries/s", "ms_per_step": wall * 1e3, "step": f"one exact k-NN call of {nq} queries (host buffers)",
+            "recall_at_10": 1.0, "recall_note": f"exact by construction; top-{k} overlap with the CPU port's brute force on {sample} queries: {agree}",
+            "roofline": roof,
+            "cpu_baseline": {"value": 1.0 / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
+                             "sample": f"{sample} queries of this workload on {cores} threads (one query per thread), the CPU port's brute force over the same {n} rows"},
+            "gpu_over_cpu": (nq / wall) * cpu_s}
+
+
 class _Batches:
     """B resident query batches with their outputs; step(i) searches batch i mod B on stream i mod S."""
 
@@ -113,7 +240,7 @@ class _Batches:
         return float(np.mean([per[i % self.B][0] for i in range(steps)])), per[0][1], per[0][2]
 
 
-def c2_one_query_per_call(a, capi, hip):
+def c2_one_query_per_call(a, capi, hip, measure_traffic=None):
     n, d, nq = 100_000, 128, 2000
     base = np.random.default_rng(1).standard_normal((n, d), dtype=np.float32)  # seeds 1 / 2
     queries = np.random.default_rng(2).standard_normal((nq, d), dtype=np.float32)
@@ -148,6 +275,7 @@ def c2_one_query_per_call(a, capi, hip):
     cpu, _ = _cpu_port(ix, base, queries, "l2sq", a, seconds=3.0)
     bytes_q = float(np.mean(Ds)) * d * 4 + float(np.mean(Es)) * (2 * a.M * 4) + d * 4
     gbs = bytes_q / (float(np.mean(kern)) * 1e-6) / 1e9
+    traffic, src = _traffic_of(a, measure_traffic, ix, rows=n, dim=d, metric="l2sq", queries=1, query_batches=64, base_seed=1, query_seed=2, pmc_steps=64)
     return {"name": "c2_one_query_per_call",
             "workload": f"BASELINE config[1]: HNSW search {n}x{d} f32 l2sq M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}, {nq} x ONE usearch_search_ef per call (scan.c:220-228)",
             "value": nq / t_all, "unit": "queries/s", "ms_per_step": float(lat.mean()) / 1e3, "step": "one usearch_search_ef call (host query in, host answer out)",
@@ -157,11 +285,12 @@ def c2_one_query_per_call(a, capi, hip):
             "recall_at_10": _recall(np.array(found[:512]), truth, a.k),
             "roofline": dict({"bound": "latency (one dependent hop chain; HBM fraction shown for scale)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "algorithmic_bytes_per_launch": bytes_q, "avg_launch_ms": float(np.mean(kern)) / 1e3, "kernel": "k_search_spec (walk_spec.hpp), one query",
-                              "traffic": None}, **fractions(gbs)),
+                              "traffic": traffic, "traffic_source": src, "traffic_over_algorithmic": (traffic / bytes_q) if traffic else None,
+                              "frac_is": "frac_algorithmic (SURVEY 8d bytes / HIP-event launch time / 8 TB/s)"}, **fractions(gbs)),
             "cpu_baseline": cpu, **_over_cpu(nq / t_all, cpu), "build_vectors_per_s": n / t_build}
 
 
-def c3_cosine_1024_batches(a, capi, hip, base):
+def c3_cosine_1024_batches(a, capi, hip, base, measure_traffic=None, keep=None):
     n, d, nq, B = base.shape[0], base.shape[1], 1024, 8
     ix, t_build = _build(capi, hip, "cos", base, a)
     queries = np.random.default_rng(4).standard_normal((nq * B, d), dtype=np.float32)  # base seed 3, queries seed 4
@@ -179,57 +308,23 @@ def c3_cosine_1024_batches(a, capi, hip, base):
     elapsed2, _ = two.timed(steps)
     gbs2 = bytes_l * steps / elapsed2 / 1e9
     cpu, _ = _cpu_port(ix, base, queries[:nq], "cos", a, seconds=5.0)
+    traffic, src = _traffic_of(a, measure_traffic, ix, rows=n, dim=d, metric="cos", queries=nq, query_batches=B, base_seed=3, query_seed=4, pmc_steps=8)
+    if keep is not None:
+        keep["cos_index"] = ix  # the dense leg computes over the same rows
     out.update({"value": nq * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "step": "one 1024-query launch, one launch in flight",
                 "two_launches_in_flight": {"value": nq * steps / elapsed2, "ms_per_step": elapsed2 / steps * 1e3,
                                            "roofline": dict({"achieved": gbs2, "unit": "GB/s", "basis": "all launches' algorithmic bytes / the timed region"}, **fractions(gbs2))},
                 "recall_at_10": _recall(found, truth, a.k), "recall_note": "i.i.d. N(0,1) x 768 under cosine has no neighbourhood structure: the prescribed set, identical on CPU and GPU",
                 "dist_evals_per_query": Dm, "expansions_per_query": Em,
                 "roofline": dict({"bound": "hbm", "achieved": gbs1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": bytes_l,
-                                  "avg_launch_ms": float(np.mean(kms)), "kernel": "k_search", "traffic": None,
-                                  "basis": "ALGORITHMIC bytes (SURVEY 8d; D / E counted on the device) / HIP-event launch time; the counter passes of this shape: profiles/r04_bench_line_cos_q1024.json"},
+                                  "avg_launch_ms": float(np.mean(kms)), "kernel": "k_search", "traffic": traffic, "traffic_source": src,
+                                  "traffic_over_algorithmic": (traffic / bytes_l) if traffic else None,
+                                  "achieved_fabric": (traffic / (float(np.mean(kms)) * 1e-3) / 1e9) if traffic else None,
+                                  "frac_fabric": (traffic / (float(np.mean(kms)) * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                                  "frac_is": "frac_algorithmic (SURVEY 8d bytes; D / E counted on the device) / HIP-event launch time / 8 TB/s; frac_fabric = this run's counter bytes"},
                                  **fractions(gbs1)),
                 "cpu_baseline": cpu, **_over_cpu(nq * steps / elapsed, cpu), "build_vectors_per_s": n / t_build})
     return out
-
-
-def clustered_headline_shape(a, capi, hip, measure_traffic):
-    from lantern_amd import synth
-
-    n, d, nq, B = a.n, a.dim, a.queries, 4
-    make = synth.query_maker("clustered", d)
-    base = make(np.random.default_rng(synth.BASE_SEED), n)
-    ix, t_build = _build(capi, hip, a.metric, base, a)
-    queries = make(np.random.default_rng(4), nq * B)
-    run = _Batches(hip, ix, queries, nq, a, streams=1)
-    steps = 12
-    elapsed, kms = run.timed(steps)
-    row, lst = d * 4, 2 * a.M * 4
-    bytes_l, Dm, Em = run.algorithmic_bytes(row, lst, steps)
-    launch_s = float(np.mean(kms)) * 1e-3
-    gbs = bytes_l / launch_s / 1e9
-    tq = min(1024, nq)
-    truth, _ = ix.exact_search(queries[:tq], a.k)
-    found = run.lanes[0]["slot"].download((nq, a.k), np.uint32)[:tq]
-    cpu, _ = _cpu_port(ix, base, queries[:nq], a.metric, a, seconds=9.0)
-    traffic = src = None
-    if measure_traffic is not None:
-        import copy
-
-        b = copy.copy(a)
-        b.data, b.query_batches = "clustered", B
-        det = measure_traffic(b, f"{ix.checksum():016x}")
-        if det and det.get("hbm_bytes_per_launch"):
-            traffic, src = det["hbm_bytes_per_launch"], det["source"]
-    roof = dict({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": bytes_l, "avg_launch_ms": launch_s * 1e3,
-                 "kernel": "k_search", "traffic": traffic, "traffic_source": src,
-                 "basis": "ALGORITHMIC bytes (SURVEY 8d; D / E counted on the device) / HIP-event launch time"}, **fractions(gbs))
-    if traffic:
-        roof.update({"achieved_counter": traffic / launch_s / 1e9, "frac_counter": traffic / launch_s / 1e9 / HBM_PEAK_GBS, "traffic_over_algorithmic": traffic / bytes_l})
-    return {"name": "clustered_1Mx768_l2sq",
-            "workload": f"HNSW search {n}x{d} f32 {a.metric} M={a.M} ef_construction={a.efc} ef={a.ef} k={a.k}, {nq}-query batches resident in HBM, CLUSTERED set ({synth.CLUSTERED_DOC})",
-            "value": nq * steps / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "step": f"one {nq}-query launch",
-            "recall_at_10": _recall(found, truth, a.k), "recall_queries": tq, "dist_evals_per_query": Dm, "expansions_per_query": Em,
-            "roofline": roof, "cpu_baseline": cpu, **_over_cpu(nq * steps / elapsed, cpu), "build_vectors_per_s": n / t_build}
 
 
 def headline_host_buffers(a, ix, queries, device_resident_qps, headline_recall):
@@ -329,8 +424,9 @@ def run(a, capi, hip, ix, base, queries, device_resident_qps, headline_recall, m
 
     leg(headline_host_buffers, a, ix, queries, device_resident_qps, headline_recall)
     leg(headline_scan_service, a, capi, ix, device_resident_qps)
-    leg(c2_one_query_per_call, a, capi, hip)
+    leg(c2_one_query_per_call, a, capi, hip, measure_traffic)
     if a.metric == "l2sq" and a.data == "gaussian":
-        leg(c3_cosine_1024_batches, a, capi, hip, base)
-        leg(clustered_headline_shape, a, capi, hip, measure_traffic)
+        keep = {}
+        leg(c3_cosine_1024_batches, a, capi, hip, base, measure_traffic, keep)
+        leg(c3_dense_exact_knn, a, capi, hip, base, keep)
     return out

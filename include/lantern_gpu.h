@@ -303,6 +303,9 @@ LANTERN_GPU_EXPORT size_t lantern_gpu_dense_profile(int on, float *ms, uint32_t 
 LANTERN_GPU_EXPORT void lantern_gpu_search_row_trace(usearch_index_t, int on, size_t nq, size_t per_query_cap, uint32_t *trace,
                                                      uint32_t *counts, usearch_error_t *);
 
+/* workgroups of the last search launch = walks resident on the device at a time (the cache model's `walkers`) */
+LANTERN_GPU_EXPORT int lantern_gpu_last_search_grid(usearch_index_t, usearch_error_t *);
+
 /* Gathered distances: out[i] = metric(query, row(slots[i])) -- the kernel the graph walk is
  * made of, exposed for tests and profiling.  Host buffers. */
 LANTERN_GPU_EXPORT void lantern_gpu_distance_gather(usearch_index_t, const void *query, const uint32_t *slots,

@@ -87,7 +87,7 @@ EXPORTS = [
     "lantern_gpu_set_seed", "lantern_gpu_set_add_batch", "lantern_gpu_add_many", "lantern_gpu_flush",
     "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device", "lantern_gpu_search_batch_device_strided",
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_dense_profile", "lantern_gpu_distance_gather",
-    "lantern_gpu_host_alloc", "lantern_gpu_host_free", "lantern_gpu_save_stream", "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile", "lantern_gpu_search_unique_rows", "lantern_gpu_search_row_trace",
+    "lantern_gpu_host_alloc", "lantern_gpu_host_free", "lantern_gpu_save_stream", "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile", "lantern_gpu_search_unique_rows", "lantern_gpu_search_row_trace", "lantern_gpu_last_search_grid",
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_export_codes",
     "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_gpu_search_phase_profile", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_trace", "lantern_scan_end",
@@ -179,6 +179,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_spec_profile": (None, [vp, i32, vp, err]),
         "lantern_gpu_search_unique_rows": (None, [vp, i32, C.POINTER(u64), err]),
         "lantern_gpu_search_row_trace": (None, [vp, i32, sz, sz, vp, vp, err]),
+        "lantern_gpu_last_search_grid": (i32, [vp, err]),
         "lantern_gpu_save_stream": (None, [vp, vp, vp, err]),
         "lantern_gpu_pq_compact": (None, [vp, err]),
         "lantern_gpu_pq_expand": (None, [vp, err]),
@@ -484,18 +485,21 @@ class GpuIndex:
         _call("lantern_gpu_search_unique_rows", self.h, 1 if on else 0, C.byref(out) if read else None)
         return int(out.value) if read else None
 
+    def last_search_grid(self) -> int:
+        return int(_call("lantern_gpu_last_search_grid", self.h))
+
     def row_trace_begin(self, nq, per_query_cap):
         """lantern_gpu_search_row_trace(on=1): the following launches of at most nq queries record, per query, the memory objects the
         walk asks for (rows evaluated, adjacency lists read) in order."""
         self._trace_shape = (int(nq), int(per_query_cap))
-        _call("lantern_gpu_search_row_trace", self.h, 1, int(nq), int(per_query_cap), None, None)
+        _call("lantern_gpu_search_row_trace", "lantern_gpu_last_search_grid", self.h, 1, int(nq), int(per_query_cap), None, None)
 
     def row_trace_end(self):
         """-> (trace [nq][cap] u32, counts [nq] u32) of the last traced launch; switches the tracing off."""
         nq, cap = self._trace_shape
         trace = np.zeros((nq, cap), dtype=np.uint32)
         counts = np.zeros(nq, dtype=np.uint32)
-        _call("lantern_gpu_search_row_trace", self.h, 0, nq, cap, _ptr(trace), _ptr(counts))
+        _call("lantern_gpu_search_row_trace", "lantern_gpu_last_search_grid", self.h, 0, nq, cap, _ptr(trace), _ptr(counts))
         return trace, counts
 
     def pq_compact(self):

@@ -1350,6 +1350,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         return false;
     }
     const int grid = search_grid(ix, nq, waves, spec >= 2 ? waves : spec == 1 ? 16 : 24);
+    ix->last_search_grid = grid;
     const int slot = acquire_search_slot(ix, stream, (size_t)grid);
     if(slot < 0) return false;
     SearchArgs a{};
@@ -2857,6 +2858,17 @@ try {
     if(!ok) FAIL(e, "lantern_gpu: HIP failure reading the row trace (or per_query_cap differs from the one the trace was started with)");
 }
 LANTERN_ABI_CATCH_VOID(e)
+
+// workgroups of the last search launch (k_search / k_search_spec): the number of walks resident at a time -- the cache model's `walkers`
+int lantern_gpu_last_search_grid(usearch_index_t h, usearch_error_t *e)
+try {
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return 0;
+    std::lock_guard<std::mutex> g(ix->mu);
+    return ix->last_search_grid;
+}
+LANTERN_ABI_CATCH(e)
 
 // the instrumented latency-bound walk (walk_spec.hpp PROF): out32[8 * wave + i], waves 0..3 = visit | list | fill | a row wave;
 // i: 0 decision, 1 neighbour list, 2 issue, 3 role section, 4 loads + distances, 5 barrier wait, 6 hops, 7 list source count

@@ -59,8 +59,8 @@ def query_maker(kind: str, dim: int):
     raise ValueError(f"unknown data kind {kind!r}")
 
 
-def base_rows(kind: str, n: int, dim: int) -> np.ndarray:
-    return query_maker(kind, dim)(np.random.default_rng(BASE_SEED), n)
+def base_rows(kind: str, n: int, dim: int, seed: int = BASE_SEED) -> np.ndarray:
+    return query_maker(kind, dim)(np.random.default_rng(seed), n)
 
 
 def shard_rows(kind: str, n: int, dim: int, lo: int, hi: int) -> np.ndarray:
