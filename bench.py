@@ -43,6 +43,14 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 HBM_MEASURED_CEILING_GBS = 6290.0  # same guide: "6.29 TB/s measured (float4 copy, 79 %)" -- what a pure DRAM stream reaches
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line is the only thing on stdout): which leg is running, seconds since start."""
+    print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -315,6 +323,7 @@ def main():
         ix.flush()
         hip.synchronize()
         t_build = time.time() - t0
+    log(f"index built: {a.n} rows in {t_build:.2f}s")
     build_counters = ix.counters()
     build_profile = ix.build_profile()
     pq_info = None
@@ -380,6 +389,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [s.elapsed_ms(e) for s, e in ev]  # HIP events on the launch stream: one search launch each
+    log(f"timed region done: {a.steps} steps in {elapsed:.3f}s")
     if rdv:
         elapsed = rdv.max_float(elapsed)
     if a.pmc_child:  # a counter pass of measure_traffic(): the launches above are what rocprofv3 counted
@@ -419,7 +429,9 @@ def main():
                        and S == 1)  # the clustered set beside the prescribed one (clustered_coheadline)
         qualities = {}
         if world == 1 and not a.no_cpu and a.cpu_seconds > 0 and not a.pq_subvectors:
+            log("cpu_baseline ...")
             cpu = cpu_baseline(a, ix, base, queries, found)
+            log("build_quality ...")
             if a.build_quality_rows > 0 and a.quant == "f32" and a.metric != "hamming":
                 qualities = build_quality(a, [a.data] + (["clustered"] if co_headline else []))
                 quality = qualities.get(a.data)
@@ -431,7 +443,9 @@ def main():
         key = (f"{a.n}x{a.dim}_{a.metric}_ef{a.ef}_q{nq}_w{a.waves or 4}" + ("" if a.quant == "f32" else "_" + a.quant)
                + ("" if a.data == "gaussian" else "_" + a.data) + (f"_b{B}" if B > 1 else "") + (f"_pq{a.pq_subvectors}" if a.pq_subvectors else ""))
         if world == 1 and not a.no_pmc and S == 1:
+            log("counter passes (headline) ...")
             pmc_detail = measure_traffic(a, f"{ix.checksum():016x}")
+            log(f"counter passes done: {[p_.get('error', 'ok') for p_ in (pmc_detail or {}).get('passes', [])]}")
             if pmc_detail and pmc_detail.get("hbm_bytes_per_launch"):
                 traffic, measured_here = pmc_detail["hbm_bytes_per_launch"], True
                 traffic_src = pmc_detail["source"]
@@ -448,7 +462,9 @@ def main():
         # ---- what of those bytes reaches DRAM: the cache model over the launch's own trace (f32 l2sq / cos, one launch in flight)
         model = None
         if world == 1 and not a.pq_subvectors and a.quant == "f32" and a.metric in ("l2sq", "cos") and S == 1 and not a.no_dram_model:
+            log("dram model (traced launches + replay) ...")
             model = dram_model(ix, hip, lanes, nq, a.k, a.ef, q_stride, row_bytes, 2 * a.M * 4, avg_kernel_s, traffic)
+            log(f"dram model done: {model.get('error') or model.get('seconds')}")
         qps = world * nq * a.steps / elapsed
         out = {
             "metric": f"QPS (recall@{a.k} alongside), {a.n}x{a.dim} f32 {a.metric} ef={a.ef} k={a.k}",
@@ -491,6 +507,7 @@ def main():
             # ---- the co-headline: the same shape, index parameters and procedure on the CLUSTERED set -- the set on which recall (>= the
             # reference's 0.7 / 0.9 floors, scripts/integration_tests.py:249-257) and the roofline fractions (< 1) both mean something
             t0 = time.time()
+            log("clustered co-headline ...")
             try:
                 out["clustered"] = clustered_coheadline(a, capi, hip, qualities.get("clustered"))
             except Exception as ex:  # noqa: BLE001 -- the co-headline never costs the line
@@ -508,6 +525,7 @@ def main():
             import bench_secondary
 
             t0 = time.time()
+            log("secondary legs ...")
             out["secondary"] = bench_secondary.run(a, capi, hip, ix, base, all_queries, qps, recall, None if a.no_pmc else measure_traffic)
             out["setup_seconds"]["secondary"] = time.time() - t0
     finish(out)

@@ -22,7 +22,7 @@ def rocprof():
     return shutil.which("rocprofv3")
 
 
-def run_pass(child_argv, kernel_like, kernel_regex, counters, marker, timeout=900):
+def run_pass(child_argv, kernel_like, kernel_regex, counters, marker, timeout=300):
     """-> {"child": the child's JSON line, "values": {counter: [per-dispatch values, dispatch order]}, "seconds", "command"} or {"error": ...}"""
     exe = rocprof()
     if not exe:

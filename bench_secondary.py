@@ -415,6 +415,7 @@ def run(a, capi, hip, ix, base, queries, device_resident_qps, headline_recall, m
         if only and fn.__name__ not in only:
             return
         t0 = time.time()
+        print(f"[bench secondary] {fn.__name__} ...", file=sys.stderr, flush=True)
         try:
             e = fn(*args, **kw)
         except Exception as ex:  # noqa: BLE001

@@ -492,14 +492,14 @@ class GpuIndex:
         """lantern_gpu_search_row_trace(on=1): the following launches of at most nq queries record, per query, the memory objects the
         walk asks for (rows evaluated, adjacency lists read) in order."""
         self._trace_shape = (int(nq), int(per_query_cap))
-        _call("lantern_gpu_search_row_trace", "lantern_gpu_last_search_grid", self.h, 1, int(nq), int(per_query_cap), None, None)
+        _call("lantern_gpu_search_row_trace", self.h, 1, int(nq), int(per_query_cap), None, None)
 
     def row_trace_end(self):
         """-> (trace [nq][cap] u32, counts [nq] u32) of the last traced launch; switches the tracing off."""
         nq, cap = self._trace_shape
         trace = np.zeros((nq, cap), dtype=np.uint32)
         counts = np.zeros(nq, dtype=np.uint32)
-        _call("lantern_gpu_search_row_trace", "lantern_gpu_last_search_grid", self.h, 0, nq, cap, _ptr(trace), _ptr(counts))
+        _call("lantern_gpu_search_row_trace", self.h, 0, nq, cap, _ptr(trace), _ptr(counts))
         return trace, counts
 
     def pq_compact(self):

@@ -1543,6 +1543,7 @@ using namespace lgpu;
 static Index *H(usearch_index_t h, usearch_error_t *e)
 {
     if(!h) { FAIL(e, "lantern_gpu: null index handle"); return nullptr; }
+    if(((const Index *)h)->magic != kIndexMagic) { FAIL(e, "lantern_gpu: not an index handle (stale, freed or foreign pointer)"); return nullptr; }
     // HIP's current device is per host thread: an index lives on the device it was created on, whichever thread calls
     // (one thread per GPU is how a single process drives a node: lantern_gpu_comm_init_local)
     (void)hipSetDevice(((Index *)h)->device);
@@ -1686,6 +1687,7 @@ try {
         if(ls) (void)hipStreamDestroy(ls);
     for(char *lh : ix->lane_host)
         if(lh) (void)hipHostFree(lh);
+    ix->magic = 0;  // a use after free is refused by H() for as long as the allocator leaves the word alone
     delete ix;
 }
 LANTERN_ABI_CATCH_VOID(e)

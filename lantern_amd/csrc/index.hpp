@@ -24,8 +24,12 @@ struct Cursor
     std::unordered_set<uint32_t> seen;
 };
 
+constexpr uint64_t kIndexMagic = 0x4C414E5445524E31ull;  // "LANTERN1": the first word of every live index handle
+
 struct Index
 {
+    uint64_t magic = kIndexMagic;  // checked by every entry point (index.cpp H()): a stale, freed or foreign pointer handed over as a
+                                   // usearch_index_t is refused with an error string instead of being dereferenced as an index
     // ---- configuration (usearch_init_options_t as Lantern fills it) -------------------------------
     usearch_init_options_t opts{};
     int      metric = 0;         // usearch_metric_kind_t

@@ -10,7 +10,7 @@ case "$JOB" in
   tests-new)    # a named subset: bash scripts/gpu.sh tests-new "expr for -k"
     timeout 900 python -m pytest tests -m gpu -x -q -k "$1" 2>&1 | tail -40 | tee "$OUT/pytest.log" ;;
   bench)        # the driver's command; extra flags pass through
-    LANTERN_BENCH_PMC_LOG="$OUT" timeout 1500 python bench.py "$@" > "$OUT/line.json" 2> "$OUT/stderr.log"; echo "rc=$?"; tail -5 "$OUT/stderr.log"; head -c 600 "$OUT/line.json" ;;
+    LANTERN_BENCH_PMC_LOG="$OUT" timeout ${BENCH_TIMEOUT:-1200} python bench.py "$@" > "$OUT/line.json" 2> "$OUT/stderr.log"; echo "rc=$?"; tail -5 "$OUT/stderr.log"; head -c 600 "$OUT/line.json" ;;
   bench-trace)  # rocprofv3 --kernel-trace --stats of the search leg only (no counters, no secondary legs)
     timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python bench.py --no-pmc --no-secondary --no-cpu --no-dram-model --build-quality-rows 0 "$@" > "$OUT/line.json" 2> "$OUT/trace.log"
     python scripts/prof_dump.py "$OUT/trace" > "$OUT/kernel_stats.md"; head -30 "$OUT/kernel_stats.md" ;;

@@ -134,3 +134,12 @@ def test_padded_rows_take_the_index_stride():
     x[0, ::2] = -1.0
     b = hip.padded_rows(x, False, b1=True, row_bytes=128)
     assert b.shape == (2, 128) and b.dtype == np.uint8 and b[0, 0] == 0b01010101 and b[1, 95] == 255 and not b[:, 96:].any()
+
+
+def test_a_foreign_pointer_is_not_an_index_handle(capi):
+    """Every entry point checks the handle's first word before dereferencing it as an index: a stale or foreign pointer gets an
+    error string, not a walk through garbage (a mutex locked out of a string's bytes hangs the caller)."""
+    junk = C.create_string_buffer(8192)
+    err = C.c_char_p()
+    assert capi.lib().usearch_size(C.cast(junk, C.c_void_p), C.byref(err)) == 0
+    assert err.value and b"not an index handle" in err.value
