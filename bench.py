@@ -795,7 +795,7 @@ def build_quality(a, kinds):
         r_seq = oracle.recall_at_k(lab2.astype(np.int64) - 1, truth)
         out[kind] = {"set": f"{n}x{d} f32 {metric} {kind}, seeds 1 / 2 (the bench's own --dim / --metric), 1000 queries, ef={a.ef}",
                      "recall_device_batched_build": r_dev, "recall_sequential_build": r_seq, "abs_diff": abs(r_dev - r_seq), "device_minus_sequential": r_dev - r_seq,
-                     "bar": 0.005,
+                     "bar": 0.005, "device_not_worse_than_sequential_by_more_than_bar": bool(r_dev >= r_seq - 0.005),
                      "device_build_seconds": t_dev, "sequential_cpu_build_seconds": t_seq, "sequential_cpu_build_vectors_per_s": n / t_seq,
                      "sequential_builds_side_by_side": len(sets)}
     return out

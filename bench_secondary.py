@@ -140,6 +140,12 @@ def c3_dense_exact_knn(a, capi, hip, base, keep=None):
     flops_call = 2.0 * nq * n * d
     flops_full = 2.0 * nq * DENSE_CHUNK * d
     full_ms = float(np.mean(full)) if full else None
+    per_pos = {}  # mean duration by position of the launch within its call (the first launches of a call follow the norms / memset kernels)
+    pos = 0
+    for r in recs:
+        pos = 0 if (r["cols"] < DENSE_CHUNK and not r["fused"]) else pos + 1
+        if r["rows"] == nq and r["cols"] == DENSE_CHUNK and r["ms"] > 0:
+            per_pos.setdefault(pos, []).append(r["ms"])
     steady = flops_full / (full_ms * 1e-3) / 1e12 if full_ms else None
     kernel_ms_per_call = float(sum(r["ms"] for r in recs if r["ms"] > 0)) / calls
     # the same calls on the CPU port's brute force (one thread and all cores are both memory-bound f32 dot products)
@@ -157,6 +163,8 @@ def c3_dense_exact_knn(a, capi, hip, base, keep=None):
     roof = {"bound": "mfma_fp32", "algorithmic_flops_per_call": flops_call, "algorithmic_flops_per_full_launch": flops_full,
             "avg_launch_ms": full_ms, "avg_launch_ms_basis": f"HIP events around the {len(full)} steady full-chunk launches (1024 x {DENSE_CHUNK} x {d}) of {calls} calls after a warm-up call",
             "achieved": steady, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (steady / FP32_MATRIX_PEAK_TFLOPS) if steady else None,
+            "full_launch_ms": {"mean": full_ms, "median": float(np.median(full)) if full else None, "min": float(np.min(full)) if full else None,
+                               "max": float(np.max(full)) if full else None, "by_position_in_call": {str(k_): round(float(np.mean(v)), 4) for k_, v in sorted(per_pos.items())}},
             "launches_per_call": len(recs) / calls, "other_launches_ms": sorted({(r["cols"], round(r["ms"], 3)) for r in other})[:6],
             "contraction_ms_per_call": kernel_ms_per_call, "achieved_contraction_per_call": flops_call / (kernel_ms_per_call * 1e-3) / 1e12 if kernel_ms_per_call else None,
             "call_level": {"seconds_per_call_wall": wall, "achieved": flops_call / wall / 1e12, "frac": flops_call / wall / 1e12 / FP32_MATRIX_PEAK_TFLOPS,

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -37,11 +38,21 @@ RcclApi *rccl_api()
     static std::mutex mu;
     std::lock_guard<std::mutex> g(mu);
     if(api.so || !api.why.empty()) return &api;
-    // a host that already mapped RCCL (PyTorch bundles librccl.so.1 under the same SONAME) gets that copy
+    // LANTERN_GPU_RCCL_LIB names the library to bind instead (a site's own RCCL build; the test double of tests/fake_rccl/, which
+    // runs this transport with several in-process ranks on one device).  Otherwise: a host that already mapped RCCL (PyTorch
+    // bundles librccl.so.1 under the same SONAME) gets that copy.
+    const char *override_path = std::getenv("LANTERN_GPU_RCCL_LIB");
+    if(override_path && *override_path) {
+        api.so = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+        if(!api.so) {
+            api.why = std::string("lantern_gpu: cannot load LANTERN_GPU_RCCL_LIB=") + override_path + ": " + (dlerror() ? dlerror() : "unknown error");
+            return &api;
+        }
+    }
     const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
     for(const char *n : names) {
-        api.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if(api.so) break;
+        api.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     }
     if(!api.so) {
         api.why = std::string("lantern_gpu: cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "unknown error");
