@@ -399,7 +399,7 @@ def main():
     # ---- algorithmic bytes of one launch --------------------------------------------
     row_bytes = a.dim * {"f32": 4, "f16": 2, "i8": 1, "b1": 0.125}[a.quant]
     if a.pq_subvectors:
-        row_bytes = (a.pq_subvectors + 15) // 16 * 16  # a compact pq index evaluates a row from its code bytes
+        row_bytes = ix.memory_usage()[0] // max(len(ix), 1)  # a compact pq index evaluates a row from its code bytes (their stride in HBM)
     per_lane = []
     for L in lanes:
         Dl = L["D"].download(nq, np.uint64).astype(np.float64)
@@ -465,6 +465,10 @@ def main():
             log("dram model (traced launches + replay) ...")
             model = dram_model(ix, hip, lanes, nq, a.k, a.ef, q_stride, row_bytes, 2 * a.M * 4, avg_kernel_s, traffic)
             log(f"dram model done: {model.get('error') or model.get('seconds')}")
+        build_traffic = None
+        if world == 1 and not a.no_pmc and not a.pq_subvectors:
+            log("counter pass (build kernels) ...")
+            build_traffic = measure_build_traffic(a, f"{ix.checksum():016x}")
         qps = world * nq * a.steps / elapsed
         out = {
             "metric": f"QPS (recall@{a.k} alongside), {a.n}x{a.dim} f32 {a.metric} ef={a.ef} k={a.k}",
@@ -491,7 +495,7 @@ def main():
             "build_batches": build_counters["add_batches"],
             "build_counters_per_vector": {k: build_counters[k] / a.n for k in ("add_walk_evals", "add_select_evals", "add_revlink_evals",
                                                                                  "add_reprunes", "add_expansions")},
-            "build_roofline": build_roofline(a, build_counters, build_profile, t_build, world),
+            "build_roofline": build_roofline(a, build_counters, build_profile, t_build, world, build_traffic),
             "dist_evals_per_query": float(D.mean()),
             "expansions_per_query": float(E.mean()),
             "roofline": roofline(achieved, traffic, traffic_src, avg_kernel_s if S == 1 else elapsed / a.steps, bytes_per_launch, avg_kernel_s, S, B,
@@ -581,6 +585,32 @@ def measure_traffic(a, checksum, counters=("FETCH_SIZE", "WRITE_SIZE"), kernel="
                       "(same seeds, same graph checksum, same rotating query batches); FETCH_SIZE KiB x 1024 x 2 (gfx950: the counter reports half the "
                       "bytes of wide coalesced reads)" + (", WRITE_SIZE KiB x 1024" if "WRITE_SIZE" in counters else "; writes not counted (< 0.01 % of the reads in the headline's passes)")
                       + " -- /opt/skills/guides/MI355X_MICROARCH.md, HBM")
+    return out
+
+
+def measure_build_traffic(a, checksum):
+    """build_roofline.*.traffic of THIS run: one rocprofv3 --pmc FETCH_SIZE pass over a re-execution of the BUILD (the --pmc-child builds
+    the same index from the same seeds: graph checksum checked), restricted to the build's kernels; bytes = KiB x 1024 x 2 as for the
+    search kernel (measure_traffic).  -> {short kernel name: {"launches", "fetch_bytes"}} or {"error": ...} / None without rocprofv3."""
+    import bench_pmc
+
+    if not bench_pmc.rocprof():
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--no-pmc", "--no-cpu", "--truth-queries", "0", "--build-quality-rows", "0",
+             "--steps", "1", "--warmup", "1", "--rows", str(a.n), "--dim", str(a.dim), "--metric", a.metric, "--M", str(a.M),
+             "--efc", str(a.efc), "--ef", str(a.ef), "--k", str(a.k), "--queries", "64", "--query-batches", "1",
+             "--add-batch", str(a.add_batch), "--quant", a.quant, "--data", a.data, "--data-scale", str(a.data_scale),
+             "--base-seed", str(a.base_seed), "--query-seed", str(a.query_seed)]
+    regex = "k_insert|k_connect|k_revlink|k_group|k_link|k_merge"
+    r = bench_pmc.run_pass(child, "", regex, ["FETCH_SIZE"], "pmc_child", timeout=420, by_kernel=True)
+    if "error" in r:
+        return {"error": r["error"]}
+    if r["child"]["checksum"] != checksum:
+        return {"error": "the child built a different graph"}
+    out = {k: {"launches": len(v["FETCH_SIZE"]), "fetch_bytes": float(np.sum(v["FETCH_SIZE"])) * 1024 * 2} for k, v in r["values"].items()}
+    out["_source"] = (f"this run: rocprofv3 --kernel-include-regex '{regex}' --pmc FETCH_SIZE over a re-execution of the build (same seeds, same graph checksum); "
+                      "FETCH_SIZE KiB x 1024 x 2 (gfx950) -- /opt/skills/guides/MI355X_MICROARCH.md, HBM")
+    out["_seconds"] = r["seconds"]
     return out
 
 
@@ -719,7 +749,7 @@ def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg
     return r
 
 
-def build_roofline(a, c, prof, t_build, world):
+def build_roofline(a, c, prof, t_build, world, traffic=None):
     """Per-phase time of the build (HIP events recorded inside the library around each phase of every batch) against
     the algorithmic traffic of that phase (SURVEY.md 8d "Build unit of work"): the walk reads one row per distance
     evaluation and one adjacency row per expansion; a re-prune needs the cap+1 candidate rows and `close`'s once."""
@@ -734,7 +764,17 @@ def build_roofline(a, c, prof, t_build, world):
            "host_and_idle_ms": max(0.0, t_build * 1e3 - sum(prof[k] for k in ("walk_ms", "connect_ms", "group_ms", "revlink_ms", "exchange_ms")))}
     gbs = walk_bytes / max(prof["walk_ms"], 1e-9) / 1e6
     out["walk"] = {"bound": "hbm", "algorithmic_bytes": float(walk_bytes), "ms": prof["walk_ms"], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": gbs / HBM_PEAK_GBS}
+                   "frac": gbs / HBM_PEAK_GBS, "frac_is": "frac_algorithmic (one row per distance evaluation of the insertion walks, one adjacency row per expansion)",
+                   "traffic": None, "traffic_over_algorithmic": None, "frac_fabric": None}
+    if traffic and "error" not in traffic:
+        walk_t = sum(v["fetch_bytes"] for k, v in traffic.items() if k.startswith("k_insert"))
+        if walk_t:
+            out["walk"].update({"traffic": walk_t, "traffic_over_algorithmic": walk_t / max(walk_bytes, 1.0),
+                                "frac_fabric": walk_t / max(prof["walk_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS,
+                                "traffic_source": traffic.get("_source")})
+        out["traffic_by_kernel"] = {k: v for k, v in traffic.items() if not k.startswith("_")}
+    elif traffic:
+        out["traffic_error"] = traffic["error"]
     # the re-prune phase is bound by the latency of its dependent chains, not by bytes: the device cuts most requests to a full
     # list from the list's recorded radius without reading a row, so no byte roofline is claimed for it -- counts only
     out["reprune"] = {"bound": "latency (dependent chains per list)", "ms": prof["revlink_ms"], "requests_to_full_lists": c["add_reprunes"],

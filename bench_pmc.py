@@ -22,8 +22,15 @@ def rocprof():
     return shutil.which("rocprofv3")
 
 
-def run_pass(child_argv, kernel_like, kernel_regex, counters, marker, timeout=300):
-    """-> {"child": the child's JSON line, "values": {counter: [per-dispatch values, dispatch order]}, "seconds", "command"} or {"error": ...}"""
+def short_kernel_name(name: str) -> str:
+    """`void lgpu::k_insert<3, 64, ...>(lgpu::InsertArgs)` -> `k_insert`"""
+    head = name.split("(")[0].split("<")[0]
+    return head.split("::")[-1].split(" ")[-1]
+
+
+def run_pass(child_argv, kernel_like, kernel_regex, counters, marker, timeout=300, by_kernel=False):
+    """-> {"child": the child's JSON line, "values": {counter: [per-dispatch values, dispatch order]}, "seconds", "command"} or {"error": ...}.
+    by_kernel: "values" becomes {short kernel name: {counter: [values]}} over every kernel the regex admits (kernel_like is ignored)."""
     exe = rocprof()
     if not exe:
         return {"error": "rocprofv3 is not on PATH"}
@@ -39,17 +46,21 @@ def run_pass(child_argv, kernel_like, kernel_regex, counters, marker, timeout=30
                 f.write(p.stdout + "\n==== stderr\n" + p.stderr)
         if p.returncode != 0 or not line:
             return {"error": f"rc {p.returncode}: {(p.stderr or p.stdout)[-300:]}"}
-        values = {c: [] for c in counters}
+        values = {} if by_kernel else {c: [] for c in counters}
         for db in glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True):
             cur = sqlite3.connect(db).cursor()
             cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
             order = "dispatch_id" if "dispatch_id" in cols else ("id" if "id" in cols else None)
-            q = "select counter_name, value from counters_collection where kernel_name like ?" + (f" order by {order}" if order else "")
-            for name, v in cur.execute(q, (f"%{kernel_like}%",)):
-                if name in values:
+            q = "select kernel_name, counter_name, value from counters_collection where kernel_name like ?" + (f" order by {order}" if order else "")
+            for kname, name, v in cur.execute(q, ("%" if by_kernel else f"%{kernel_like}%",)):
+                if name not in counters:
+                    continue
+                if by_kernel:
+                    values.setdefault(short_kernel_name(kname), {c: [] for c in counters})[name].append(float(v))
+                else:
                     values[name].append(float(v))
-        if not any(values.values()):
-            return {"error": f"no counter rows for {kernel_like} in the rocprofv3 output"}
+        if not values or not any(values.values()):
+            return {"error": f"no counter rows for {kernel_regex} in the rocprofv3 output"}
         return {"child": line, "values": values, "seconds": time.time() - t0,
                 "command": f"rocprofv3 --kernel-include-regex {kernel_regex} --pmc {' '.join(counters)} -- python bench.py {child_argv[2] if len(child_argv) > 2 else ''} ..."}
     except Exception as e:  # noqa: BLE001

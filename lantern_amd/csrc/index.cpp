@@ -206,7 +206,12 @@ bool pq_compact_locked(Index *ix)
     if(!ix->pq) { set_err(ix, "lantern_gpu: not a pq index"); return false; }
     if(ix->pq_compact) return true;
     if(!flush_locked(ix)) return false;
-    const uint32_t S16 = (ix->pq_S + 15) / 16 * 16;
+    uint32_t S16 = (ix->pq_S + 15) / 16 * 16;
+    // Code rows of 65 .. 127 bytes (96 subvectors: Lantern's usual 768 / 8) are stored at a 128-BYTE STRIDE, zero padded, for the reason
+    // bit rows are (usearch_init): the fabric fetches 128-byte lines, and a 96-byte row at a 96-byte stride straddles two of them three
+    // times in four.  Code bytes are addressed by subvector, so the decoding walk never looks at the padding; the table walk adds the
+    // padding's all-zero table rows at the end of its chains (x + 0.0f: the same bits).  HBM only: files and the ABI keep num_subvectors bytes.
+    if(S16 > 64 && S16 < 128) S16 = 128;
     if(S16 > 128 || ix->pq_C > (uint32_t)ADC_LUT_STRIDE) { set_err(ix, "lantern_gpu: the compact form takes up to 128 subvectors and 256 centroids"); return false; }
     HIPCHK(ix, hipStreamSynchronize(ix->stream));
     for(int l = 0; l < Index::kLanes; ++l)

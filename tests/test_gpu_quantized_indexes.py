@@ -81,6 +81,13 @@ def test_quant_bits_1_on_real_input_is_the_hamming_index_of_the_sign_bits(capi, 
     assert again.checksum() == ix.checksum() and np.array_equal(again.search_batch(queries, 10)[0], lab)
 
 
+def code_row_stride(S):
+    """Bytes between the code rows of a compact pq index in HBM: num_subvectors rounded up to 16, and 65 .. 127 widened to 128 (one
+    cache line per row: index.cpp pq_compact_locked)."""
+    s16 = (S + 15) // 16 * 16
+    return 128 if 64 < s16 < 128 else s16
+
+
 def make_codebook(rng, base, S, C):
     """A codebook in the layout Lantern hands to usearch_init (pqtable.c:194-240): [C][d], row c = centroid c of every
     subvector, concatenated.  Centroids are sampled data points per subvector (what k-means++ starts from)."""
@@ -194,7 +201,7 @@ def test_compact_pq_index_decoding_rows_on_the_fly_is_the_expanded_index_bit_for
     o_lab, o_dist, _, o_D, o_E = ora.search_batch(queries, 10, ef, 4)
     assert np.array_equal(want[0], o_lab) and np.array_equal(want[1].view(np.uint32), o_dist.view(np.uint32))
     ix.pq_compact()
-    assert ix.memory_usage()[0] == n * ((S + 15) // 16 * 16)
+    assert ix.memory_usage()[0] == n * code_row_stride(S)
     for spec in (None, "0", "2"):  # the automatic shape, the bandwidth-bound walk, the latency-bound one
         if spec is None:
             monkeypatch.delenv("LANTERN_GPU_SPEC", raising=False)
@@ -240,7 +247,7 @@ def test_compact_pq_index_searches_by_adc_over_the_code_bytes(capi, oracle, metr
     # ---- compact: num_subvectors bytes per row (padded to 16) instead of 4 * d
     ix.pq_compact()
     rows_after, other_after = ix.memory_usage()
-    S16 = (S + 15) // 16 * 16
+    S16 = code_row_stride(S)
     assert rows_after == (n - 50) * S16 and rows_before >= (n - 50) * d * 4 and other_after == other
     dq = hip.Buffer.from_numpy(hip.padded_rows(queries, False))
     lab, dist, slot = hip.Buffer(nq * 10 * 8), hip.Buffer(nq * 10 * 4), hip.Buffer(nq * 10 * 4)
