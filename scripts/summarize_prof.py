@@ -1,5 +1,5 @@
 """Condense rocprofv3 output (rocpd sqlite: kernel-trace --stats + separate --pmc passes) into small
-text/JSON summaries.  Run on the box by scripts/profile_bench.sh, or locally on the pulled .db files:
+text/JSON summaries.  Run on the box by scripts/history/profile_bench.sh, or locally on the pulled .db files:
 
     python scripts/summarize_prof.py gpurun_out/prof [profiles/r01]
 """
