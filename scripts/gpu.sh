@@ -5,8 +5,8 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 JOB="${1:-help}"; shift || true
 OUT="gpurun_out/$JOB"; mkdir -p "$OUT"
 case "$JOB" in
-  tests)        # the whole -m gpu suite
-    timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 2>&1 | tail -60 > "$OUT/pytest.log"; tail -40 "$OUT/pytest.log" ;;
+  tests)        # the default -m gpu suite (what the driver runs)
+    timeout 1500 python -m pytest tests -m gpu -x -q --durations=40 2>&1 | tail -60 > "$OUT/pytest.log"; tail -40 "$OUT/pytest.log" ;;
   tests-new)    # a named subset: bash scripts/gpu.sh tests-new "expr for -k"
     timeout 900 python -m pytest tests -m gpu -x -q -k "$1" 2>&1 | tail -40 | tee "$OUT/pytest.log" ;;
   bench)        # the driver's command; extra flags pass through
@@ -14,5 +14,14 @@ case "$JOB" in
   bench-trace)  # rocprofv3 --kernel-trace --stats of the search leg only (no counters, no secondary legs)
     timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python bench.py --no-pmc --no-secondary --no-cpu --no-dram-model --build-quality-rows 0 "$@" > "$OUT/line.json" 2> "$OUT/trace.log"
     python scripts/prof_dump.py "$OUT/trace" > "$OUT/kernel_stats.md"; head -30 "$OUT/kernel_stats.md" ;;
-  *) echo "jobs: tests | tests-new EXPR | bench [flags] | bench-trace [flags]" ;;
+  tests-slow)   # the at-size comparisons marked slow (10M x 768, sequential-build comparisons)
+    LANTERN_TEST_SLOW=1 timeout 1700 python -m pytest tests -m "gpu and slow" -x -q --durations=15 2>&1 | tail -40 > "$OUT/pytest.log"; tail -30 "$OUT/pytest.log" ;;
+  rccl-double)  # the RCCL transport at worlds 2 / 3 / 8 through tests/fake_rccl (one JSON line per world)
+    hipcc -O2 -shared -fPIC -o tests/fake_rccl/librccl_fake.so tests/fake_rccl/fake_rccl.cpp
+    for w in 2 3 8; do LANTERN_GPU_RCCL_LIB="$PWD/tests/fake_rccl/librccl_fake.so" timeout 300 python tests/fake_rccl/run_world.py $w; done > "$OUT/worlds.jsonl" 2> "$OUT/stderr.log"
+    cut -c1-400 "$OUT/worlds.jsonl" ;;
+  bench-10m)    # BASELINE config[3] on one GPU with this run's counters (8192-row batches: rocprofv3 --pmc survives them at 10M rows)
+    LANTERN_BENCH_PMC_LOG="$OUT" timeout 1500 python bench.py --rows 10000000 --ef 128 --steps 5 --truth-queries 256 --no-secondary --build-quality-rows 0 --add-batch 8192 "$@" > "$OUT/line.json" 2> "$OUT/stderr.log"
+    echo "rc=$?"; tail -12 "$OUT/stderr.log"; head -c 400 "$OUT/line.json" ;;
+  *) echo "jobs: tests | tests-slow | tests-new EXPR | bench [flags] | bench-trace [flags] | bench-10m | rccl-double" ;;
 esac

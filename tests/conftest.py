@@ -19,6 +19,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: at-size comparisons that take minutes of host time (the sequential CPU reference builds); skipped unless "
+                                       "LANTERN_TEST_SLOW=1 -- `bash scripts/gpu.sh tests-slow`; each has a fast representative in the default run")
+
+
+# The comparisons whose cost is a sequential CPU build of 10^5 .. 4 x 10^5 rows (110 - 150 s each on the GPU box's host) are kept out of the
+# default `-m gpu` run, which the driver gives 1200 s: mark them `slow_gpu`.  Their fast representatives stay in the default run.
+slow_gpu = [pytest.mark.slow, pytest.mark.skipif(os.environ.get("LANTERN_TEST_SLOW", "0") in ("", "0"),
+                                                  reason="slow at-size comparison: LANTERN_TEST_SLOW=1 (bash scripts/gpu.sh tests-slow)")]
 
 
 def _experimental_build() -> bool:

@@ -15,6 +15,8 @@ import time
 import numpy as np
 import pytest
 
+from tests.conftest import slow_gpu
+
 pytestmark = pytest.mark.gpu
 
 M, EFC, K = 16, 128, 10
@@ -183,7 +185,7 @@ _SEQ_GRAPHS = {}  # the sequential reference build of a set is the same for ever
                                        # size / 16 -- full batches from 262k rows on, so the set has 400k.  (What does NOT hold the bar is a
                                        # smaller RATIO: plan (16384, 4) on the 100k set builds batches of a quarter of the graph and loses
                                        # 0.0115 of recall -- 0.4505 against 0.4620, measured in round 5 -- which is why min_ratio stays 16.)
-                                       ("c2_gaussian_400k_x_128", (16384, 16))],
+                                       pytest.param("c2_gaussian_400k_x_128", (16384, 16), marks=slow_gpu)],  # (110 s: the sequential CPU build of 400k rows)
                          ids=lambda v: v if isinstance(v, str) else f"batch{v[0]}_ratio{v[1]}")
 def test_build_quality_matches_the_sequential_reference_build(env, oracle, name, plan):
     capi, hip = env
