@@ -24,7 +24,7 @@ def rocprof():
 
 def short_kernel_name(name: str) -> str:
     """`void lgpu::k_insert<3, 64, ...>(lgpu::InsertArgs)` -> `k_insert`"""
-    head = name.split("(")[0].split("<")[0]
+    head = name.replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
     return head.split("::")[-1].split(" ")[-1]
 
 

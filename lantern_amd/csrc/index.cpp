@@ -2465,9 +2465,56 @@ struct DenseTimer  // records event `a` now and `b` on destruction, on the launc
 };
 }  // namespace
 
+// The exact k-NN's device temporaries (norms + best lists, the seed-column matrix, the candidate lists) come from a small grow-only pool
+// per device instead of hipMalloc / hipFree per call -- a free synchronises the device, and a 1024 x 1M x 768 call made five of them:
+// about a millisecond of a 13.6 ms call.  Blocks above 64 MB (the whole-chunk matrix of the unfused path, the f32 copies of quantised
+// rows) are still allocated per call.  One exact k-NN at a time per device holds the pool (the calls are bandwidth- or MFMA-bound on
+// the whole chip: nothing is lost by not overlapping them).
+namespace {
+struct KnnPool
+{
+    std::mutex mu;
+    void      *p[ 3 ] = { nullptr, nullptr, nullptr };
+    size_t     bytes[ 3 ] = { 0, 0, 0 };
+};
+KnnPool g_knn_pool[ 16 ];
+constexpr size_t kKnnPoolMax = (size_t)64 << 20;
+
+struct KnnBlock  // pooled if small, allocated for the call otherwise; released by the destructor
+{
+    void *ptr = nullptr;
+    bool  own = false;
+    bool get(KnnPool *pool, int which, size_t need)
+    {
+        if(need == 0) need = 16;
+        if(pool && need <= kKnnPoolMax) {
+            if(pool->bytes[ which ] < need) {
+                if(pool->p[ which ]) (void)hipFree(pool->p[ which ]);
+                pool->p[ which ] = nullptr;
+                pool->bytes[ which ] = 0;
+                if(hipMalloc(&pool->p[ which ], need) != hipSuccess) { (void)hipGetLastError(); return false; }
+                pool->bytes[ which ] = need;
+            }
+            ptr = pool->p[ which ];
+            return true;
+        }
+        own = hipMalloc(&ptr, need) == hipSuccess;
+        if(!own) { (void)hipGetLastError(); ptr = nullptr; }
+        return own;
+    }
+    ~KnnBlock() { if(own && ptr) (void)hipFree(ptr); }
+};
+}  // namespace
+
 static bool exact_knn_device_impl(int mcode, uint32_t chunks, const uint4 *d_base, size_t nb, const uint4 *d_q, size_t nq, size_t k,
                                   uint32_t *d_slots, float *d_dists, hipStream_t st, bool fused, bool *overflowed)
 try {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    KnnPool *const               pool = (dev >= 0 && dev < 16) ? &g_knn_pool[ dev ] : nullptr;
+    std::unique_lock<std::mutex> pool_lock;
+    if(pool) pool_lock = std::unique_lock<std::mutex>(pool->mu);
+    KnnBlock b_aux, b_dd, b_cand;
     // kk = k plus a margin: the MFMA distances (|q|^2 + |b|^2 - 2 q.b) differ from the exact-order ones in the
     // last bits, so the survivors are re-ranked exactly and only then cut to k
     const uint32_t kk = (uint32_t)k + 16;
@@ -2488,10 +2535,12 @@ try {
     uint64_t *cand = nullptr;            // fused: [min(nq, QT)][kCandCap] keys, then the counters and the overflow flag
     const size_t nqt_max = std::min(nq, QT);
     // the distance matrix of the unfused launches: a whole chunk, or only the seed columns
-    bool ok = hipMalloc((void **)&aux, (nq + nb) * 4 + 8 + nq * kk * 8) == hipSuccess &&
-              hipMalloc((void **)&dd, nqt_max * (fused ? kSeedCols : CH) * 4) == hipSuccess;
+    bool ok = b_aux.get(pool, 0, (nq + nb) * 4 + 8 + nq * kk * 8) && b_dd.get(pool, 1, nqt_max * (fused ? kSeedCols : CH) * 4);
+    aux = (char *)b_aux.ptr;
+    dd = (float *)b_dd.ptr;
     if(ok && fused) {
-        ok = hipMalloc((void **)&cand, nqt_max * kCandCap * 8 + nqt_max * 4 + 16) == hipSuccess;
+        ok = b_cand.get(pool, 2, nqt_max * kCandCap * 8 + nqt_max * 4 + 16);
+        cand = (uint64_t *)b_cand.ptr;
         ok = ok && hipMemsetAsync((char *)cand + nqt_max * kCandCap * 8, 0, nqt_max * 4 + 16, st) == hipSuccess;
     }
     uint32_t *ccnt = cand ? (uint32_t *)((char *)cand + nqt_max * kCandCap * 8) : nullptr, *cover = ccnt ? ccnt + nqt_max : nullptr;
@@ -2541,9 +2590,7 @@ try {
         ok = ok && hipStreamSynchronize(st) == hipSuccess;
         if(overflowed) *overflowed = over != 0;
     }
-    if(aux) (void)hipFree(aux);
-    if(dd) (void)hipFree(dd);
-    if(cand) (void)hipFree(cand);
+    if(!ok) (void)hipStreamSynchronize(st);  // nothing queued may still name the pooled blocks when the pool's lock is released
     if(fq) (void)hipFree(fq);
     if(fb) (void)hipFree(fb);
     return ok;

@@ -23,5 +23,24 @@ case "$JOB" in
   bench-10m)    # BASELINE config[3] on one GPU with this run's counters (8192-row batches: rocprofv3 --pmc survives them at 10M rows)
     LANTERN_BENCH_PMC_LOG="$OUT" timeout 1500 python bench.py --rows 10000000 --ef 128 --steps 5 --truth-queries 256 --no-secondary --build-quality-rows 0 --add-batch 8192 "$@" > "$OUT/line.json" 2> "$OUT/stderr.log"
     echo "rc=$?"; tail -12 "$OUT/stderr.log"; head -c 400 "$OUT/line.json" ;;
+  calibrate)    # the cache model against the counters on launches with known traffic (a stream, a uniformly random gather)
+    for pass in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
+      d="$OUT/$(echo $pass | tr ' ' '_')"; rm -rf "$d"
+      timeout 400 rocprofv3 --kernel-include-regex k_gather --pmc $pass -d "$d" -o pmc -- python scripts/calibrate_cache_model.py > "$OUT/model.json" 2> "$OUT/stderr.log"
+    done
+    cat "$OUT/model.json"
+    python - <<'PY'
+import glob, sqlite3, json
+out = {}
+for db in glob.glob("gpurun_out/calibrate/**/*.db", recursive=True):
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    order = "dispatch_id" if "dispatch_id" in cols else None
+    for name, v in cur.execute("select counter_name, value from counters_collection where kernel_name like '%k_gather%'" + (f" order by {order}" if order else "")):
+        out.setdefault(name, []).append(v)
+print(json.dumps(out))
+open("gpurun_out/calibrate/counters.json", "w").write(json.dumps(out))
+PY
+    ;;
   *) echo "jobs: tests | tests-slow | tests-new EXPR | bench [flags] | bench-trace [flags] | bench-10m | rccl-double" ;;
 esac

@@ -60,3 +60,4 @@ def test_short_kernel_names():
     assert pmc.short_kernel_name("void lgpu::k_insert<3, 64, false>(lgpu::InsertArgs)") == "k_insert"
     assert pmc.short_kernel_name("lgpu::k_revlink_pairs(lgpu::RevlinkArgs) [clone .kd]") == "k_revlink_pairs"
     assert pmc.short_kernel_name("void lgpu::k_search<3, 64, false, 2, 1, 0>(lgpu::SearchArgs)") == "k_search"
+    assert pmc.short_kernel_name("lgpu::(anonymous namespace)::k_gather_heads(lgpu::LinkReq const*, unsigned int)") == "k_gather_heads"
