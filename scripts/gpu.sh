@@ -28,10 +28,19 @@ case "$JOB" in
       d="$OUT/$(echo $pass | tr ' ' '_')"; rm -rf "$d"
       timeout 400 rocprofv3 --kernel-include-regex k_gather --pmc $pass -d "$d" -o pmc -- python scripts/calibrate_cache_model.py > "$OUT/model.json" 2> "$OUT/stderr.log"
     done
+    timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python scripts/calibrate_cache_model.py > /dev/null 2>> "$OUT/stderr.log"
+    python scripts/prof_dump.py "$OUT/trace" > "$OUT/kernel_stats.md"; head -8 "$OUT/kernel_stats.md"
     cat "$OUT/model.json"
     python - <<'PY'
 import glob, sqlite3, json
 out = {}
+for db in glob.glob("gpurun_out/calibrate/trace/**/*.db", recursive=True):
+    cur = sqlite3.connect(db).cursor()
+    try:
+        rows = [r for r in cur.execute("select name, start, end from kernels where name like '%k_gather%' order by start")]
+        out["k_gather_durations_us"] = [(e - s) / 1e3 for _, s, e in rows]
+    except Exception as ex:
+        out["k_gather_durations_error"] = repr(ex)
 for db in glob.glob("gpurun_out/calibrate/**/*.db", recursive=True):
     cur = sqlite3.connect(db).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
