@@ -293,6 +293,23 @@ def test_device_resident_queries_state_their_stride(capi):
         f.search_batch_device(fq.ptr, 8, k, 0, 0, l2.ptr, query_stride=96)
 
 
+def test_golden_exact_order_with_ef_construction_below_m_on_device(capi, golden):
+    """hnsw_logged_unlogged.out:35-275 on the device: ef_construction = 2 < M = 14, ids in the pinned order after a build over 8 / 9 / 10
+    rows and after every later insert (usearch_add one at a time, as aminsert does)."""
+    g = golden["logged_unlogged"]
+    ids = g["ids"] + [e["id"] for e in g["inserted"]]
+    rows = g["v"] + [e["v"] for e in g["inserted"]]
+    for built in (8, 9, 10):
+        for total in range(built, 11):
+            ix = capi.GpuIndex("l2sq", 4, M=g["index"]["M"], ef_construction=g["index"]["ef_construction"], ef=g["index"]["ef"], seed=7)
+            ix.set_add_batch(1, 1)  # CREATE INDEX adds one tuple at a time (build.c:83-135)
+            ix.add_many(np.arange(built, dtype=np.uint64) + LABEL0, np.asarray(rows[:built], dtype=np.float32))
+            for i in range(built, total):
+                ix.add(i + LABEL0, rows[i])
+            got = ordered(capi, ix, g["query"], g["limit"])
+            assert [[ids[l - LABEL0], int(capi.l2sq_dist(rows[l - LABEL0], g["query"]))] for l in got] == g[f"order_{total}"], (built, total)
+
+
 def test_golden_insert_dimension_errors_and_misc(capi, golden):
     sw = golden["small_world"]
     ix = gpu_build(capi, "l2sq", sw["v"])

@@ -158,6 +158,28 @@ def test_insert_into_unlogged_index(oracle, golden):
     assert [round(oracle.distance(rows[8 if l == 100 else l - LABEL0], g["query"], "l2sq"), 2) for l in order] == g["sorted_2dp"]
 
 
+def _logged_unlogged_cases(g):
+    """(rows the index is BUILT over, rows inserted one by one afterwards, expected [(id, distance)]) for every index the test creates."""
+    ids = g["ids"] + [e["id"] for e in g["inserted"]]
+    rows = g["v"] + [e["v"] for e in g["inserted"]]
+    for built in (8, 9, 10):          # small_world_idx / _idx2 / _idx3 are created over 8, 9 and 10 rows ...
+        for total in range(max(built, 8), 11):   # ... and each is queried after every later insert
+            yield ids, rows, built, total, g[f"order_{total}"]
+
+
+def test_exact_order_with_ef_construction_below_m_and_inserts(oracle, golden):
+    """hnsw_logged_unlogged.out: unique distances pin the ORDER of ids; ef_construction = 2 (< M = 14) still links every row; rows that
+    arrive through aminsert land where the expected output has them, on indexes built over 8, 9 and 10 rows."""
+    g = golden["logged_unlogged"]
+    for ids, rows, built, total, want in _logged_unlogged_cases(g):
+        ix = oracle.OracleIndex("l2sq", 4, M=g["index"]["M"], ef_construction=g["index"]["ef_construction"], ef=g["index"]["ef"], seed=7)
+        ix.add_many(np.arange(built, dtype=np.uint64) + LABEL0, np.asarray(rows[:built], dtype=np.float32))
+        for i in range(built, total):
+            ix.add(i + LABEL0, rows[i])
+        got = scan(lambda k: ix.search(g["query"], k), len(ix), g["limit"])
+        assert [[ids[l - LABEL0], int(oracle.distance(rows[l - LABEL0], g["query"], "l2sq"))] for l in got] == want, (built, total)
+
+
 def test_insert_then_search(oracle, golden):
     g, sw = golden["insert_then_search"], golden["small_world"]
     ix = build(oracle, "l2sq", sw["v"])
