@@ -535,7 +535,11 @@ def main():
     finish(out)
 
 
-GATHER_CEILING_GBS = 6730.0  # profiles/r03_gather_ceiling.md: uniformly random 3 KiB rows in the walk's own launch shape (k_gather_walkshape), algorithmic bytes
+# profiles/r06_cache_model_calibration.md: 17.56 M uniformly random 3 KiB rows in the walk's own launch shape (k_gather_walkshape) take 9.56 ms:
+# 5.64 TB/s in algorithmic bytes, 5.78 TB/s at the fabric (counters), 5.15 TB/s from DRAM by the cache model.  (Round 3 measured 6.73 TB/s
+# algorithmic for the same kernel with 15 % fewer fabric bytes; rounds 3 - 5 quoted that figure.)
+GATHER_CEILING_GBS = 5640.0
+GATHER_DRAM_CEILING_GBS = 5150.0
 
 
 def measure_traffic(a, checksum, counters=("FETCH_SIZE", "WRITE_SIZE"), kernel="k_search"):
@@ -722,8 +726,11 @@ def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg
          "unique_rows_per_launch": unique,
          "cold_miss_bytes_per_launch": None, "frac_cold_miss_lower_bound": None,
          "dram_bytes_per_launch": None, "frac_dram": None,  # (no DRAM-side counter on this part; see dram_bytes_model)
-         "gather_ceiling": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r03_gather_ceiling.md (uniformly random 3 KiB rows in the walk's launch shape, algorithmic bytes = counter bytes)",
+         "gather_ceiling": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r06_cache_model_calibration.md (uniformly random 3 KiB rows in the walk's launch shape: 5.64 TB/s algorithmic, "
+                                                                         "5.15 TB/s from DRAM by the cache model -- a walk with reuse may exceed the first, not the second)",
          "algorithmic_over_gather_ceiling": achieved_alg / GATHER_CEILING_GBS,
+         "gather_dram_ceiling": GATHER_DRAM_CEILING_GBS,
+         "dram_model_over_gather_dram_ceiling": (model["dram_bytes_model"] / launch_s / 1e9 / GATHER_DRAM_CEILING_GBS) if model and model.get("dram_bytes_model") else None,
          "streaming_ceiling": HBM_MEASURED_CEILING_GBS,
          "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_kernel_s * 1e3,
          "query_batches_rotated": B, "pmc": pmc_detail, "note": None}

@@ -33,7 +33,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0
 STREAMING_GBS = 6290.0  # MI355X_MICROARCH.md: measured float4 copy
-GATHER_GBS = 6730.0     # profiles/r03_gather_ceiling.md: uniformly random 3 KiB rows in the walk's launch shape
+GATHER_GBS = 5640.0     # profiles/r06_cache_model_calibration.md: uniformly random 3 KiB rows in the walk's launch shape, algorithmic bytes (r03 - r05: 6730)
 
 
 def fractions(achieved_gbs: float) -> dict:
