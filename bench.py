@@ -536,8 +536,8 @@ def main():
 
 
 # profiles/r06_cache_model_calibration.md: 17.56 M uniformly random 3 KiB rows in the walk's own launch shape (k_gather_walkshape) take 9.56 ms:
-# 5.64 TB/s in algorithmic bytes, 5.78 TB/s at the fabric (counters), 5.15 TB/s from DRAM by the cache model.  (Round 3 measured 6.73 TB/s
-# algorithmic for the same kernel with 15 % fewer fabric bytes; rounds 3 - 5 quoted that figure.)
+# 5.64 TB/s in algorithmic bytes, 5.78 TB/s at the fabric (counters), 5.15 TB/s from DRAM by the cache model.  (Rounds 3 - 5 quoted 6.73 TB/s:
+# an average over six launches one of which was the measuring script's 1000-row self-check -- the calibration file has the correction.)
 GATHER_CEILING_GBS = 5640.0
 GATHER_DRAM_CEILING_GBS = 5150.0
 

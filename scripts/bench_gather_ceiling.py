@@ -5,6 +5,11 @@ no list maintenance, no visited set, no dependent hops.  Run under rocprofv3 (ke
 miss passes) it gives the fabric traffic and the time of a pure random-row stream to set beside k_search's.
 
     python scripts/bench_gather_ceiling.py [--rows 1000000 --dim 768 --evals 17563648]
+
+CAUTION when reading a rocprofv3 table of this command: the FIRST k_gather launch is the 1000-row self-check below, so "average per launch"
+over all 6 launches is 5/6 of a full launch's figure.  profiles/r03_gather_ceiling.md was read that way (8.02 ms, 46 GB, "6.73 TB/s"); per
+FULL launch it is 9.58 ms and 55.3 GB = 5.64 TB/s algorithmic (profiles/r06_cache_model_calibration.md; scripts/calibrate_cache_model.py
+reads the launches one by one).
 """
 import argparse
 import json

@@ -1,7 +1,7 @@
 """The cache model behind bench.py's roofline.frac_dram_model (lantern_amd/tools/cache_model.c, bench_cache_model.py), on traces whose
 answer is known: (1) it IS an LRU (cross-checked against a 20-line reference); (2) a gather with no reuse over a table far larger than
-the caches costs its algorithmic bytes at both levels (the k_gather_walkshape calibration: profiles/r03_gather_ceiling.md measured
-traffic == algorithmic there); (3) an index that fits the Infinity Cache costs ~0 DRAM bytes once warm, and one that fits an L2 ~0
+the caches costs its algorithmic bytes at both levels (the k_gather_walkshape calibration: profiles/r06_cache_model_calibration.md --
+the counters read 1.024 x the algorithmic bytes there, the model 0.9986 x); (3) an index that fits the Infinity Cache costs ~0 DRAM bytes once warm, and one that fits an L2 ~0
 fabric bytes (scripts/profile_small_index.py); (4) hub rows shared by every query are served by the caches while the cold tail is not."""
 import collections
 
@@ -87,7 +87,7 @@ def test_it_is_an_lru(cm):
 
 def test_gather_without_reuse_costs_its_algorithmic_bytes(cm):
     """Uniformly random rows of a 3 GB table through 32 MiB of L2 and a 256 MiB Infinity Cache: (nearly) every access misses
-    everywhere -- model == algorithmic, as the counters said of the real gather (traffic / algorithmic 1.00: r03_gather_ceiling.md)."""
+    everywhere -- model == algorithmic, as the counters say of the real gather (traffic / algorithmic 1.02: r06_cache_model_calibration.md)."""
     rng = np.random.default_rng(2)
     n_rows, nq, per = 1_000_000, 1024, 300
     tr = rng.integers(0, n_rows, size=(nq, per), dtype=np.uint32)
