@@ -185,7 +185,10 @@ _SEQ_GRAPHS = {}  # the sequential reference build of a set is the same for ever
                                        # size / 16 -- full batches from 262k rows on, so the set has 400k.  (What does NOT hold the bar is a
                                        # smaller RATIO: plan (16384, 4) on the 100k set builds batches of a quarter of the graph and loses
                                        # 0.0115 of recall -- 0.4505 against 0.4620, measured in round 5 -- which is why min_ratio stays 16.)
-                                       pytest.param("c2_gaussian_400k_x_128", (16384, 16), marks=slow_gpu)],  # (110 s: the sequential CPU build of 400k rows)
+                                       pytest.param("c2_gaussian_400k_x_128", (16384, 16), marks=slow_gpu),  # (110 s: the sequential CPU build of 400k rows)
+                                       # [r6] the next plan up, (32768, 16): full 32 768-row batches from 524k rows on, so the set has 600k (the sequential
+                                       # CPU build of 600k x 128 rows: ~3 min)
+                                       pytest.param("c2_gaussian_600k_x_128", (32768, 16), marks=slow_gpu)],
                          ids=lambda v: v if isinstance(v, str) else f"batch{v[0]}_ratio{v[1]}")
 def test_build_quality_matches_the_sequential_reference_build(env, oracle, name, plan):
     capi, hip = env

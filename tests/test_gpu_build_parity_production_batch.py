@@ -65,6 +65,10 @@ CASES = {
     # the larger plans DESIGN_HISTORY H.2 item 0 measures as faster (564 / 575 k vectors/s): tested options, not only measured ones
     "gaussian_160k_x_768_l2sq_plan16384": ("l2sq", 3, 160_000, 768, (16384, 16)),  # batches keep growing past 8192 (to size / 16 = 10 000)
     "gaussian_160k_x_768_l2sq_plan16384_ratio4": ("l2sq", 3, 160_000, 768, (16384, 4)),  # full 16 384-row batches from 65k rows on
+    # [r6] 32 768-row batches: the plan (32768, 16) only reaches its cap at 524k rows, where an edge-for-edge oracle build is
+    # minutes of host time; ratio 4 reaches full 32 768-row batches from 131k rows on and drives the same device machinery (scratch sizes, the
+    # grouping pass's 24-bit positions, chains of ~1000 requests per hub list) at an affordable size.  The RATIO that holds recall stays 16.
+    "gaussian_160k_x_768_l2sq_plan32768_ratio4": ("l2sq", 3, 160_000, 768, (32768, 4)),
 }
 
 
