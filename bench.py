@@ -70,9 +70,10 @@ def parse():
                    "no step replays the queries of the step before it, so no launch finds its own rows in L2 / Infinity Cache")
     p.add_argument("--waves", type=int, default=0, help="wavefronts per query (0 = the library's automatic shape)")
     p.add_argument("--max-wg", type=int, default=0)
-    p.add_argument("--add-batch", type=int, default=16384, help="largest insertion batch (never more than a sixteenth of the graph): 16384 since round 5 -- the plan is "
-                   "pinned edge for edge against the oracle (tests/test_gpu_build_parity_production_batch.py: plan16384 cases) and within 0.005 of the "
-                   "sequential reference build's recall (tests/test_gpu_baseline_configs.py, 400k rows); 8192 was the plan of rounds 1-4")
+    p.add_argument("--add-batch", type=int, default=32768, help="largest insertion batch (never more than a sixteenth of the graph): 32768 since round 6 -- 32 768-row "
+                   "batches are pinned edge for edge against the oracle (tests/test_gpu_build_parity_production_batch.py: plan32768 case) and the plan (32768, 16) is "
+                   "within 0.005 of the sequential reference build's recall at 600k rows (tests/test_gpu_baseline_configs.py, slow: 0.2546 vs 0.2571); "
+                   "16384 was the plan of round 5, 8192 of rounds 1 - 4")
     p.add_argument("--truth-queries", type=int, default=1024, help="queries used for recall@k")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     p.add_argument("--no-cpu", action="store_true")
