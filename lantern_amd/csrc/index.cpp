@@ -2281,11 +2281,13 @@ try {
     for(size_t i = 0; i < nq; ++i) pending[ i ] = (uint32_t)i;
     ready.reserve(nq);
     // Waiting: the flags change in host memory, so a look is a load (a cache miss when one changed).  The lane SPINS only for a
-    // bounded time after the last answer came up -- LANTERN_GPU_NOTIFY_SPIN_US, default 400: longer than a service-sized launch takes to its first answers (measured, 1M x 768, 256 backends: 524 k / 555 k / 568 k scans/s at 100 / 400 / never sleeping -- within the run-to-run spread) and than the spacing of walks ending in a
-    // service-sized batch -- and then backs off to sleeping 10 .. 100 us at a time, so a lane waiting out a long launch does not
-    // hold one of the database host's cores at 100 % against the backends it serves.  The runtime is asked only now and then --
-    // hipStreamQuery takes its lock, which the other lanes' launches need -- to notice a launch that ended without raising its
-    // flags (it cannot, short of a fault) or failed.
+    // bounded time after the last answer came up -- LANTERN_GPU_NOTIFY_SPIN_US, default 400: longer than a service-sized launch takes
+    // to its first answers and than the spacing of walks ending in a service-sized batch (measured, 1M x 768, 256 backends:
+    // 524 k / 555 k / 568 k scans/s at 100 / 400 / never sleeping -- within the run-to-run spread:
+    // profiles/r06_scan_notify_spin_sweep.txt) -- and then backs off to sleeping 10 .. 100 us at a time, so a lane waiting out a
+    // long launch does not hold one of the database host's cores at 100 % against the backends it serves.  The runtime is asked
+    // only now and then -- hipStreamQuery takes its lock, which the other lanes' launches need -- to notice a launch that ended
+    // without raising its flags (it cannot, short of a fault) or failed.
     static const long spin_ns = [] {
         const char *v = std::getenv("LANTERN_GPU_NOTIFY_SPIN_US");
         return (long)(v ? std::max(0, std::atoi(v)) : 400) * 1000L;
