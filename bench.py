@@ -138,7 +138,9 @@ def bring_up_comm(a, rdv, rank, world, capi, device_ids):
         per_device.setdefault(d, []).append(r)
     shared = {d: rs for d, rs in per_device.items() if len(rs) > 1}
     info = {"requested_backend": a.dist_backend, "devices_by_rank": device_ids, "distinct_devices": len(per_device), "rccl_ranks_seen": 0}
-    if want_rccl and shared:
+    # (LANTERN_BENCH_RCCL_ON_SHARED_DEVICE=1: only with the test double of tests/fake_rccl/ bound through LANTERN_GPU_RCCL_LIB, which -- unlike
+    # RCCL -- takes several ranks on one device: the bring-up below then runs end to end on a one-GPU box, tests/test_gpu_fake_rccl.py)
+    if want_rccl and shared and os.environ.get("LANTERN_BENCH_RCCL_ON_SHARED_DEVICE", "0") in ("", "0"):
         note = ("RCCL not attempted: " + "; ".join(f"ranks {rs} share device {d}" for d, rs in shared.items())
                 + " -- RCCL refuses two ranks on one device; launch one rank per GPU (or pass --dist-backend files for a one-GPU rehearsal)")
         want_rccl = False
