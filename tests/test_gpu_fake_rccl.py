@@ -50,18 +50,19 @@ def test_sharded_builds_through_the_rccl_transport(fake_lib, world):
         assert line["shards"][1] == 0, "the empty shard"
 
 
-def test_bench_ranks_bring_up_and_build_through_the_rccl_path(fake_lib):
-    """`bench.py --gpus 2` as the driver launches it, with the double in its multi-process mode: the unique id travels over the
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_ranks_bring_up_and_build_through_the_rccl_path(fake_lib, ranks):
+    """`bench.py --gpus N` as the driver launches it (N = 2 and the full node's 8), with the double in its multi-process mode: the unique id travels over the
     rendezvous, every rank's ncclCommInitRank runs under its deadline thread, the probe all-gather and the verdict exchange pass, the
     collective build runs through the RCCL transport (grouped broadcasts on the index stream) and leaves identical replicas.  On a
-    one-GPU box the two ranks share the device, which real RCCL refuses -- hence the explicit override for the double."""
+    one-GPU box the ranks share the device, which real RCCL refuses -- hence the explicit override for the double."""
     env = dict(os.environ, LANTERN_GPU_RCCL_LIB=fake_lib, FAKE_RCCL_MULTIPROCESS="1", LANTERN_BENCH_RCCL_ON_SHARED_DEVICE="1")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "120000", "--dim", "128", "--steps", "3", "--queries", "2048",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--rows", "120000", "--dim", "128", "--steps", "3", "--queries", "2048",
            "--no-cpu", "--no-pmc", "--no-secondary", "--build-quality-rows", "0", "--truth-queries", "256"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     line = next((json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")), None)
     assert p.returncode == 0 and line, (p.stdout[-2000:], p.stderr[-3000:])
     cb = line["collective_build"]
-    assert line["n_gpus"] == 2 and cb["transport_used"] == "rccl" and cb["rccl_ranks_seen"] == 2, cb
+    assert line["n_gpus"] == ranks and cb["transport_used"] == "rccl" and cb["rccl_ranks_seen"] == ranks, cb
     assert cb["replicas_identical"] and cb["collectives"] > 4 and all(b > 0 for b in cb["bytes_received_per_rank"]), cb
     assert line["value"] > 0 and line["recall_at_10"] > 0.3
