@@ -2,7 +2,9 @@
 tests/fake_rccl/fake_rccl.cpp implements the nine ncclXxx entry points comm.cpp binds across the threads of one process, and
 LANTERN_GPU_RCCL_LIB points the library at it.  Real RCCL refuses two ranks on one device, so until a multi-GPU box runs
 `bench.py --gpus N` this is the only execution the multi-rank RCCL code path gets: communicator bring-up per rank, the metadata
-all-gather through the device path, the grouped in-place broadcasts with ragged (and empty) segments on the index streams."""
+all-gather through the device path, the grouped in-place broadcasts with ragged (and empty) segments on the index streams -- with the
+ranks as threads of one process (run_world.py), and with the ranks as the PROCESSES `bench.py --gpus N` launches (the double's
+shared-memory mode), i.e. the driver's own multi-GPU command end to end through the RCCL path."""
 import json
 import os
 import subprocess
