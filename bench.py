@@ -466,7 +466,8 @@ def main():
         model = None
         if world == 1 and not a.pq_subvectors and a.quant == "f32" and a.metric in ("l2sq", "cos") and S == 1 and not a.no_dram_model:
             log("dram model (traced launches + replay) ...")
-            model = dram_model(ix, hip, lanes, nq, a.k, a.ef, q_stride, row_bytes, 2 * a.M * 4, avg_kernel_s, traffic)
+            model = dram_model(ix, hip, lanes, nq, a.k, a.ef, q_stride, row_bytes, 2 * a.M * 4, avg_kernel_s, traffic,
+                               (pmc_detail or {}).get("read_bytes_per_launch") if measured_here else None)
             log(f"dram model done: {model.get('error') or model.get('seconds')}")
         build_traffic = None
         if world == 1 and not a.no_pmc and not a.pq_subvectors:
@@ -621,7 +622,7 @@ def measure_build_traffic(a, checksum):
     return out
 
 
-def dram_model(ix, hip, lanes, nq, k, ef, q_stride, row_bytes, list_bytes, launch_s, traffic):
+def dram_model(ix, hip, lanes, nq, k, ef, q_stride, row_bytes, list_bytes, launch_s, traffic, read_traffic=None):
     """roofline.dram_bytes_model: what the 256 MiB Infinity Cache MISSES during one launch, by replaying the launch's own memory-object
     trace through an LRU model of the part's caches (lantern_amd/tools/cache_model.c: eight 4 MiB L2s by XCD in front of the shared
     Infinity Cache; objects = rows and adjacency lists; the walks of the launch advance one hop at a time on as many walkers as the
@@ -665,8 +666,11 @@ def dram_model(ix, hip, lanes, nq, k, ef, q_stride, row_bytes, list_bytes, launc
            "frac_dram_model": steady["dram_bytes"] / launch_s / 1e9 / HBM_PEAK_GBS,
            "frac_fabric_model": steady["fabric_bytes"] / launch_s / 1e9 / HBM_PEAK_GBS,
            "fabric_model_over_counters": (steady["fabric_bytes"] / traffic) if traffic else None,
-           "check": "fabric_model_over_counters near 1 says the model's L2 level reproduces what rocprofv3 counted at the fabric for this launch shape; "
-                    "the DRAM level is the same replay one cache further out",
+           # the model replays READS (rows and lists); the counters' writes are the walk's own stores -- answers, and the clears of a
+           # workgroup's HBM visited bitmap when the LDS set spills (10M rows at ef = 128: 7 % of the traffic; 1M rows at ef = 64: 0.01 %)
+           "fabric_model_over_counter_reads": (steady["fabric_bytes"] / read_traffic) if read_traffic else None,
+           "check": "fabric_model_over_counter_reads near 1 says the model's L2 level reproduces what rocprofv3 counted as fabric READS (FETCH_SIZE) for this "
+                    "launch shape; the DRAM level is the same replay one cache further out",
            "seconds": time.time() - t0}
     return out
 
@@ -930,7 +934,8 @@ def clustered_coheadline(a, capi, hip, quality):
         if pmc and pmc.get("hbm_bytes_per_launch"):
             traffic, src = pmc["hbm_bytes_per_launch"], pmc["source"]
     unique = unique_rows_per_launch(b, ix, step, B, hip)
-    model = None if b.no_dram_model else dram_model(ix, hip, lanes, nq, b.k, b.ef, lanes[0]["stride"], d * 4, 2 * b.M * 4, launch_s, traffic)
+    model = None if b.no_dram_model else dram_model(ix, hip, lanes, nq, b.k, b.ef, lanes[0]["stride"], d * 4, 2 * b.M * 4, launch_s, traffic,
+                                                    (pmc or {}).get("read_bytes_per_launch") if traffic else None)
     qps = nq * steps / elapsed
     out = {"workload": f"HNSW search {n}x{d} f32 {b.metric} M={b.M} ef_construction={b.efc} ef={b.ef} k={b.k}, {nq}-query batches resident in HBM",
            "data": "synthetic (clustered: " + synth.CLUSTERED_DOC + ")", "value": qps, "unit": "queries/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,

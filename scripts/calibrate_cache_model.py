@@ -19,7 +19,7 @@ from lantern_amd import capi  # noqa: E402
 
 
 def main():
-    rows, dim, per, nq = 1_000_000, 768, 2144, 8192
+    rows, dim, per, nq = int(os.environ.get("CAL_ROWS", "1000000")), 768, 2144, 8192  # CAL_ROWS=10000000: a 30.7 GB table (does translation traffic grow?)
     rng = np.random.default_rng(3)
     base = rng.standard_normal((rows, dim), dtype=np.float32)
     ix = capi.GpuIndex("l2sq", dim, M=4, ef_construction=8, seed=1)
