@@ -47,6 +47,9 @@ constexpr int M_L2SQ_I8 = M_L2SQ + M_I8;
 constexpr int M_ADC = 400;
 constexpr int M_COS_ADC = M_COS + M_ADC;
 constexpr int M_L2SQ_ADC = M_L2SQ + M_ADC;
+// entries of the undo log behind every workgroup's HBM visited bitmap (walk.hpp VisUndo): a walk that records more ids than this in the
+// bitmap clears the whole bitmap at its end instead.  A walk at ef = 128 evaluates ~4 000 rows, most of them after its LDS set spilled.
+constexpr uint32_t kVisUndoWords = 8192;
 constexpr int ADC_LUT_STRIDE = 256;  // table row stride in floats (num_centroids <= 256: external_index.c:283-296)
 // A compact pq index searched by DECODING rows on the fly: a row is its code bytes in HBM, and every 16-byte chunk of its decoding
 // is fetched from the per-subvector centroid tables (786 KB at 96 x 256 x 8 floats: L2-resident) -- PqdRow below.  The arithmetic

@@ -109,12 +109,7 @@ __device__ int search_level_twin_impl(const View &v, WalkLds &s, const SpecLds &
     const int     ngroups = (NW - 3) * GPW;    // G-lane groups that evaluate rows
     const int     group = (wv - 3) * GPW + g;  // this lane's group among them
     const uint32_t M0 = v.M0;
-    if(s.vis_slots) {
-        for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
-    } else {
-        uint4 *b4 = (uint4 *)bitmap;
-        for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
-    }
+    for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;  // (the HBM bitmap is all-zero between walks: walk.hpp VisUndo)
     for(uint32_t i = tid; i < c.cache_entries; i += T) c.ctag[ i ] = EMPTY;
     const float     qn2 = __int_as_float(s.scal[ S_QN2 ]);
     uint64_t *const k1b[ 2 ] = { s.newkeys, s.sorted };        // the keys of a round's certain node, by round parity
@@ -137,14 +132,16 @@ __device__ int search_level_twin_impl(const View &v, WalkLds &s, const SpecLds &
         c.tw[ TW_W ] = ~0ull;                                              // no radius
     }
     __syncthreads();
-    // visit wave's private state: how many slots the LDS set holds, and whether it has spilled to the bitmap
+    // visit wave's private state: how many slots the LDS set holds, whether it has spilled to the bitmap, the bitmap's undo log
     uint32_t viscnt = 0;
     bool     spilled = false;
+    VisUndo  undo;
     if(tid == 0) {
         (void)visit_test_and_set(s, bitmap, start, false);
         viscnt = s.vis_slots ? 1u : 0u;
     }
     viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);
+    if(visit_wave && !s.vis_slots) undo_record(s, undo, lane == 0, start, 1ull, lane);  // bitmap-only mode: the start node's bit
     // list wave's private state (walk.hpp search_level_reg): lane l of register r holds the (64 r + l)-th smallest key
     uint64_t           K[ KPL ];
     unsigned long long live[ KPL ];
@@ -241,19 +238,18 @@ __device__ int search_level_twin_impl(const View &v, WalkLds &s, const SpecLds &
         // ---- in the shadow of the loads: the three role sections
         if(visit_wave) {
             // the LDS set must keep room for the lists of this round (a completed y's and x's); otherwise spill to the bitmap
-            if(s.vis_slots && !spilled && viscnt + 2 * M0 > s.vis_slots / 4 * 3) {
-                uint4 *b4 = (uint4 *)bitmap;
-                for(uint32_t i = (uint32_t)lane; i < bm_words / 4; i += 64) b4[ i ] = make_uint4(0, 0, 0, 0);
-                spilled = true;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            }
+            if(s.vis_slots && !spilled && viscnt + 2 * M0 > s.vis_slots / 4 * 3) spilled = true;  // (the bitmap is all-zero: VisUndo)
+            const bool to_bitmap = spilled || !s.vis_slots;
             if(hit) {  // the node just completed: its neighbours that tested new last round are visited from now on
-                if((pm2 >> lane) & 1ull) (void)visit_test_and_set(s, bitmap, nby_prev, spilled);
+                bool rec = false;
+                if((pm2 >> lane) & 1ull) rec = !visit_test_and_set(s, bitmap, nby_prev, spilled);
+                if(to_bitmap) undo_record(s, undo, rec, nby_prev, __ballot(rec), lane);
                 if(s.vis_slots && !spilled) viscnt += (uint32_t)__popcll(pm2);
             }
             const bool               isnew = hop_is_new(s, bitmap, nbx, spilled);
             const unsigned long long nm = __ballot(isnew);
             if(s.vis_slots && !spilled) viscnt += (uint32_t)__popcll(nm);
+            if(to_bitmap) undo_record(s, undo, isnew, nbx, nm, lane);
             unsigned long long nm2 = 0ull;
             if(county) nm2 = __ballot(nby != EMPTY && !visit_test(s, bitmap, nby, spilled));
             if(lane == 0) {
@@ -388,6 +384,7 @@ __device__ int search_level_twin_impl(const View &v, WalkLds &s, const SpecLds &
             for(int i = 0; i < 8; ++i) atomicAdd(&prof[ 8 * wv + i ], pacc[ i ]);
         }
     }
+    if(visit_wave) undo_apply(s, bitmap, bm_words, undo, lane);  // the workgroup's HBM bitmap goes back to all-zero
     // the result goes where the callers read it: s.keys, ascending
     if(list_wave) {
 #pragma unroll

@@ -259,10 +259,25 @@ bool ensure_bitmaps(Index *ix, size_t slots)
     if(ix->d_bitmaps && ix->bitmap_slots >= slots && ix->bm_words == words) return true;
     if(ix->d_bitmaps) { (void)hipFree(ix->d_bitmaps); ix->d_bitmaps = nullptr; }
     slots = std::max(slots, ix->bitmap_slots);
-    HIPCHK(ix, hipMalloc((void **)&ix->d_bitmaps, slots * words * 4));
+    // a workgroup's region: its bitmap + the undo log that lets every walk leave the bitmap ALL-ZERO (walk.hpp VisUndo) -- zeroed here, once
+    const size_t bytes = slots * (words + kVisUndoWords) * 4;
+    HIPCHK(ix, hipMalloc((void **)&ix->d_bitmaps, bytes));
+    HIPCHK(ix, hipMemset(ix->d_bitmaps, 0, bytes));
+    HIPCHK(ix, hipDeviceSynchronize());  // (launches on non-blocking streams do not wait for the null stream's memset)
     ix->bitmap_slots = slots;
     ix->bm_words = words;
     return true;
+}
+
+// entries of the bitmaps' undo logs a walk may use: all of them, or LANTERN_GPU_VIS_UNDO (tests of the overflow path: a walk that
+// records more ids than that clears its whole bitmap when it ends)
+static uint32_t vis_undo_cap()
+{
+    static const uint32_t cap = [] {
+        const char *e = std::getenv("LANTERN_GPU_VIS_UNDO");
+        return e ? (uint32_t)std::min<long>(std::max<long>(std::atol(e), 0), (long)kVisUndoWords) : kVisUndoWords;
+    }();
+    return cap;
 }
 
 // bytes of one caller-side vector of scalar kind `kind_in`
@@ -403,7 +418,13 @@ int acquire_search_slot(Index *ix, hipStream_t stream, size_t grid)
             if(ix->slot_bitmaps[ pick ]) (void)hipFree(ix->slot_bitmaps[ pick ]);  // (hipFree waits for the device)
             ix->slot_bitmaps[ pick ] = nullptr;
             const size_t rows = std::max(grid, ix->slot_rows[ pick ]);
-            if(hipMalloc((void **)&ix->slot_bitmaps[ pick ], rows * words * 4) != hipSuccess) { set_err(ix, "lantern_gpu: out of device memory (visited bitmaps)"); return -1; }
+            const size_t bytes = rows * (words + kVisUndoWords) * 4;  // (bitmap + undo log per workgroup, all-zero: ensure_bitmaps)
+            if(hipMalloc((void **)&ix->slot_bitmaps[ pick ], bytes) != hipSuccess || hipMemset(ix->slot_bitmaps[ pick ], 0, bytes) != hipSuccess ||
+               hipDeviceSynchronize() != hipSuccess) {
+                (void)hipGetLastError();
+                set_err(ix, "lantern_gpu: out of device memory (visited bitmaps)");
+                return -1;
+            }
             ix->slot_rows[ pick ] = rows;
             ix->slot_words[ pick ] = words;
         }
@@ -577,6 +598,7 @@ static bool run_batch(Index *ix, size_t b, const int *lv, Comm *comm, const RowS
     ia.top_count = d_top_count;
     ia.bitmaps = ix->d_bitmaps;
     ia.bm_words = (uint32_t)ix->bm_words;
+    ia.undo_cap = vis_undo_cap();
     ia.lds_list = lds_list_env();
     ia.only_upper = rs ? 1u : 0u;
     // LDS visited set for the ef_construction-wide walk (spills to the bitmap when 3/4 full); env override for tuning
@@ -1222,6 +1244,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
         a.out_E = d_E;
         a.bitmaps = ix->slot_bitmaps[ slot ];
         a.bm_words = (uint32_t)ix->slot_words[ slot ];
+        a.undo_cap = vis_undo_cap();
         a.vis_slots = vis_slots;
         a.totals = ix->d_totals;
         a.ticket = next_ticket(ix, nq, grid, stream);
@@ -1382,6 +1405,7 @@ bool run_search_device(Index *ix, const uint4 *d_queries, size_t nq, size_t k, s
     a.out_E = d_E;
     a.bitmaps = ix->slot_bitmaps[ slot ];
     a.bm_words = (uint32_t)ix->slot_words[ slot ];
+    a.undo_cap = vis_undo_cap();
     a.vis_slots = vis_slots;
     a.totals = ix->d_totals;
     a.ticket = next_ticket(ix, nq, grid, stream);

@@ -22,7 +22,9 @@ __global__ void __launch_bounds__(512, LGPU_INSERT_MIN_BLOCKS) k_insert(InsertAr
     const int tid = threadIdx.x, T = blockDim.x;
     WalkLds   s;
     carve_walk(lgpu_smem, s, a.view.chunks, a.efc, a.view.M0, a.vis_slots);
-    uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
+    uint32_t *bitmap = a.bitmaps + (size_t)blockIdx.x * (a.bm_words + kVisUndoWords);
+    s.undo = bitmap + a.bm_words;
+    s.undo_cap = a.undo_cap;
     const uint32_t chunks = a.view.chunks, M = a.view.M;
     for(uint32_t b = a.b_begin + blockIdx.x; b < a.count;) {
         const uint32_t me = a.first_slot + b;

@@ -22,7 +22,9 @@ __global__ void __launch_bounds__(704, 1) k_insert_spec(InsertArgs a)
         unsigned char *end = carve_walk(lgpu_smem, s, a.view.chunks, a.efc, a.view.M0, a.vis_slots);
         carve_spec(end, sc, a.view.M0, a.spec_prefetch, a.spec_cache);
     }
-    uint32_t      *bitmap = a.bitmaps + (size_t)blockIdx.x * a.bm_words;
+    uint32_t      *bitmap = a.bitmaps + (size_t)blockIdx.x * (a.bm_words + kVisUndoWords);
+    s.undo = bitmap + a.bm_words;
+    s.undo_cap = a.undo_cap;
     const uint32_t chunks = a.view.chunks, M = a.view.M;
     for(uint32_t b = a.b_begin + blockIdx.x; b < a.count;) {
         const uint32_t me = a.first_slot + b;

@@ -29,8 +29,9 @@ struct SearchArgs
     uint32_t       *out_counts;  // [nq] or NULL
     uint64_t       *out_D;       // [nq] or NULL
     uint64_t       *out_E;       // [nq] or NULL
-    uint32_t       *bitmaps;     // [grid][bm_words]
+    uint32_t       *bitmaps;     // [grid][bm_words + kVisUndoWords]: a workgroup's visited bitmap (all-zero between walks) + its undo log
     uint32_t        bm_words;    // multiple of 4
+    uint32_t        undo_cap;    // entries of the undo log a walk may use (<= kVisUndoWords; LANTERN_GPU_VIS_UNDO for tests of the overflow path)
     uint32_t        vis_slots;   // LDS visited-set slots (a multiple of 4; 0 = HBM bitmap only)
     unsigned long long *totals;  // [2] cumulative D, E (atomicAdd) or NULL
     uint32_t       *ticket;      // zeroed before the launch: queries beyond the first gridDim.x are handed out dynamically
@@ -77,8 +78,9 @@ struct InsertArgs
     const uint32_t *link_off;   // [batch] first LinkReq of each new node (M*(level+1) entries each); /M = first item
     uint64_t       *tops;       // [items][efc] walk results, ascending (distance, slot) keys
     uint32_t       *top_count;  // [items]
-    uint32_t       *bitmaps;
+    uint32_t       *bitmaps;     // as SearchArgs
     uint32_t        bm_words;
+    uint32_t        undo_cap;
     uint32_t        vis_slots;   // LDS visited-set slots (0 = HBM bitmap only)
     unsigned long long *totals;  // [2] cumulative D, E
     uint32_t       *ticket;      // as SearchArgs::ticket, over the batch members

@@ -125,7 +125,9 @@ __global__ void __launch_bounds__(SPEC ? 704 : 512, SPEC ? 1 : 2) k_search_adc(S
             View               v;
             LGPU_LOAD_VIEW(v, ka, SearchArgs)
             const uint32_t bm_words = LGPU_SEARCH_ARG(ka, bm_words);
-            uint32_t      *bitmap = LGPU_SEARCH_ARG(ka, bitmaps) + (size_t)blockIdx.x * bm_words;
+            uint32_t      *bitmap = LGPU_SEARCH_ARG(ka, bitmaps) + (size_t)blockIdx.x * (bm_words + kVisUndoWords);
+            s.undo = bitmap + bm_words;
+            s.undo_cap = LGPU_SEARCH_ARG(ka, undo_cap);
             const int      ef = (int)LGPU_SEARCH_ARG(ka, ef);
             if(v.n != 0) {
                 if constexpr(SPEC != 0) {

@@ -93,7 +93,9 @@ k_search(SearchArgs)
             LGPU_LOAD_VIEW(v, ka, SearchArgs)
             if constexpr(METRIC >= M_PQD) LGPU_LOAD_VIEW_PQD(v, ka, SearchArgs)
             const uint32_t chunks = v.chunks, bm_words = LGPU_SEARCH_ARG(ka, bm_words);
-            uint32_t      *bitmap = LGPU_SEARCH_ARG(ka, bitmaps) + (size_t)blockIdx.x * bm_words;
+            uint32_t      *bitmap = LGPU_SEARCH_ARG(ka, bitmaps) + (size_t)blockIdx.x * (bm_words + kVisUndoWords);
+            s.undo = bitmap + bm_words;
+            s.undo_cap = LGPU_SEARCH_ARG(ka, undo_cap);
             const uint4   *queries = LGPU_SEARCH_ARG(ka, queries);
             const int      ef = (int)LGPU_SEARCH_ARG(ka, ef);
             for(uint32_t i = tid; i < chunks; i += T) s.q[ i ] = queries[ (size_t)q * chunks + i ];

@@ -50,6 +50,9 @@ struct WalkLds
     // trace_cap are counted, not stored.  The input of the cache model behind bench.py's frac_dram_model.
     uint32_t *trace, *trace_count;
     uint32_t  trace_cap;
+    // the UNDO LOG of the workgroup's HBM visited bitmap (VisUndo below): undo_cap entries behind the bitmap's words
+    uint32_t *undo;
+    uint32_t  undo_cap;
 };
 constexpr uint32_t TRACE_LIST0 = 0x80000000u, TRACE_LISTU = 0xC0000000u;
 
@@ -113,7 +116,7 @@ __host__ inline size_t walk_lds_bytes(uint32_t chunks, uint32_t ef_cap, uint32_t
 // ---- visited set ------------------------------------------------------------------------------------------
 // usearch keeps a growing hash set of visited slots per search.  Here: an open-addressing hash set in LDS
 // (no HBM round trip per hop, nothing to clear in HBM per query) that SPILLS to the workgroup's HBM bitmap once it
-// is three quarters full: from then on new slots are recorded in the bitmap (cleared at that moment) and a
+// is three quarters full: from then on new slots are recorded in the bitmap (all-zero whenever a walk starts: VisUndo below) and a
 // lookup consults both.  With vis_slots == 0 only the bitmap is used.
 // multiply-shift onto [0, slots): any table size, so the set can be sized to the LDS a given occupancy leaves
 __device__ __forceinline__ uint32_t vis_hash(uint32_t x, uint32_t buckets) { return __umulhi(x * 0x9E3779B1u, buckets); }
@@ -140,6 +143,46 @@ __device__ __forceinline__ VisProbe vis_look(const WalkLds &s, uint32_t bucket, 
         if(v[ j ] == EMPTY) r.e = j;
     }
     return r;
+}
+
+// ---- the HBM bitmap is kept ALL-ZERO between walks, by undoing instead of clearing [r6] ------------------------------------
+// Until round 5 a walk whose LDS set filled up CLEARED its workgroup's whole bitmap before the first bit went in: cap / 8 bytes of
+// writes per spilling walk -- 1.25 MB at 10M rows, where at ef = 128 most walks spill: 7.8 GB of writes per 8192-query launch, 7 % of
+// the launch's fabric traffic (profiles/r06_bench_line_10Mx768_ef128.json), and 10 % of a 10M-row build's.  Now the bitmap is zero when
+// a walk starts (zeroed when it is allocated; every walk leaves it as it found it): the ids a walk records in it are also appended
+// to an undo log behind the bitmap, and when the walk ends the visit wave zeroes the words the log names (a word's other bits are
+// the same walk's).  A walk that overflows the log clears the whole bitmap at its end, as a spilling walk used to at its spill.
+struct VisUndo
+{
+    uint32_t cnt = 0;      // entries in the log (wave-uniform in the visit wave)
+    bool     over = false; // more ids were recorded than the log holds: clear everything at the end
+};
+// after a filter pass that recorded ids in the BITMAP: `mine` = this lane recorded `id`; newmask = __ballot(mine).  Visit wave only.
+__device__ __forceinline__ void undo_record(const WalkLds &s, VisUndo &u, bool mine, uint32_t id, unsigned long long newmask, int lane)
+{
+    const uint32_t n = (uint32_t)__popcll(newmask);
+    if(n == 0 || u.over) return;
+    if(u.cnt + n <= s.undo_cap) {
+        if(mine) __hip_atomic_store(&s.undo[ u.cnt + (uint32_t)__popcll(newmask & ((1ull << lane) - 1ull)) ], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u.cnt += n;
+    } else {
+        u.over = true;
+    }
+}
+// at the end of a walk, by the visit wave: the bitmap goes back to all-zero
+__device__ __forceinline__ void undo_apply(const WalkLds &s, uint32_t *bitmap, uint32_t bm_words, const VisUndo &u, int lane)
+{
+    if(u.over) {
+        uint4 *b4 = (uint4 *)bitmap;
+        for(uint32_t i = (uint32_t)lane; i < bm_words / 4; i += 64) b4[ i ] = make_uint4(0, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the clears reach L2 before the next walk's atomics on these words
+    } else if(u.cnt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the log's own stores have left
+        for(uint32_t i = (uint32_t)lane; i < u.cnt; i += 64) {
+            const uint32_t id = __hip_atomic_load(&s.undo[ i ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)atomicAnd(&bitmap[ id >> 5 ], 0u);  // (an atomic, like the atomicOr's that set the bits: same path to L2, in order)
+        }
+    }
 }
 
 // true if `x` was already visited; otherwise records it.  Called by the lanes of wave 0 only.
@@ -414,13 +457,8 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
             tl = t_;                                                  \
         }                                                             \
     }
-    // visits.clear()
-    if(s.vis_slots) {
-        for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
-    } else {
-        uint4 *b4 = (uint4 *)bitmap;
-        for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
-    }
+    // visits.clear(): the LDS set; the HBM bitmap is all-zero between walks (VisUndo)
+    for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
         float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
@@ -428,14 +466,16 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
     }
     D += 1;
     __syncthreads();
-    // wave 0's private walk state: how many slots the LDS set holds, and whether it has spilled to the bitmap
+    // wave 0's private walk state: how many slots the LDS set holds, whether it has spilled to the bitmap, the bitmap's undo log
     uint32_t viscnt = 0;
     bool     spilled = false;
+    VisUndo  undo;
     if(tid == 0) {
         (void)visit_test_and_set(s, bitmap, start, false);
         viscnt = s.vis_slots ? 1u : 0u;
     }
     viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);  // uniform in wave 0 (tid 0 is its first lane); unused elsewhere
+    if(wave0 && !s.vis_slots) undo_record(s, undo, lane == 0, start, 1ull, lane);  // bitmap-only mode: the start node's bit
     int      cnt = 1;
     for(int hop = 0;; ++hop) {
         int *const nnew_slot = &s.scal[ (hop & 1) ? S_NNEW1 : S_NNEW0 ];
@@ -465,14 +505,9 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
             } else {
                 E += 1;
                 LGPU_MARK(4)
-                // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (rare: the set
-                // holds 3/4 * vis_slots slots, a search visits D of them).  Wave 0 clears the bitmap on its own.
-                if(s.vis_slots && !spilled && viscnt + v.M0 > s.vis_slots / 4 * 3) {
-                    uint4 *b4 = (uint4 *)bitmap;
-                    for(uint32_t i = (uint32_t)lane; i < bm_words / 4; i += 64) b4[ i ] = make_uint4(0, 0, 0, 0);
-                    spilled = true;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the clears are ordered before this wave's atomicOr's
-                }
+                // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (the set holds
+                // 3/4 * vis_slots slots, a search visits D of them).  The bitmap is all-zero (VisUndo): nothing to clear.
+                if(s.vis_slots && !spilled && viscnt + v.M0 > s.vis_slots / 4 * 3) spilled = true;
                 uint32_t        cap;
                 const uint32_t *list = neighbors_of(v, node, level, cap);
                 if(lane == 0) trace_append<PROF>(s, node | (level > 0 ? TRACE_LISTU : TRACE_LIST0));
@@ -490,6 +525,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
                         s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
                         mark_touched<PROF>(s, nb);
                     }
+                    if(spilled || !s.vis_slots) undo_record(s, undo, isnew, nb, m, lane);  // these ids went into the HBM bitmap
                     nb_new += __popcll(m);
                 }
                 if(s.vis_slots && !spilled) viscnt += (uint32_t)nb_new;
@@ -536,6 +572,7 @@ __device__ int search_level(const View &v, WalkLds &s, uint32_t *bitmap, uint32_
         LGPU_MARK(3)
     }
 #undef LGPU_MARK
+    if(wave0) undo_apply(s, bitmap, bm_words, undo, lane);  // the workgroup's HBM bitmap goes back to all-zero
     return cnt;
 }
 
@@ -591,12 +628,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
     const bool visit_wave = wv == 0, list_wave = split ? wv == 1 : wv == 0;  // (which second wave makes no difference: measured)
     unsigned long long tl = 0;
     if constexpr(PROF) tl = (unsigned long long)clock64();
-    if(s.vis_slots) {
-        for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
-    } else {
-        uint4 *b4 = (uint4 *)bitmap;
-        for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
-    }
+    for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;  // (the HBM bitmap is all-zero between walks: VisUndo)
     const float qn2 = __int_as_float(s.scal[ S_QN2 ]);
     if(g == 0) {
         float d = group_dist_n<METRIC, G>(walk_query<METRIC>(s), row_of_m<METRIC>(v, start), (int)v.chunks, gl, qn2, row_norm<METRIC>(v, start));
@@ -606,14 +638,16 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
     __syncthreads();
     uint64_t *const front_pub = (uint64_t *)&s.scal[ S_FRONT ];  // [2] by hop parity
     uint64_t *const worst_pub = (uint64_t *)&s.scal[ S_WORST ];  // [2]
-    // visit wave's private state: how many slots the LDS set holds, and whether it has spilled to the bitmap
+    // visit wave's private state: how many slots the LDS set holds, whether it has spilled to the bitmap, the bitmap's undo log
     uint32_t viscnt = 0;
     bool     spilled = false;
+    VisUndo  undo;
     if(tid == 0) {
         (void)visit_test_and_set(s, bitmap, start, false);
         viscnt = s.vis_slots ? 1u : 0u;
     }
     viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);
+    if(visit_wave && !s.vis_slots) undo_record(s, undo, lane == 0, start, 1ull, lane);  // bitmap-only mode: the start node's bit
     // list wave's private state
     uint64_t           K[ KPL ];     // the list; lanes past position ef - 1 hold leftovers of the shifts and are masked out by
     unsigned long long live[ KPL ];  // `live`: the lanes of register r whose position 64 r + lane is below ef
@@ -737,14 +771,9 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
             } else {
                 E += 1;
                 if(!split) LGPU_MARK(4)
-                // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (rare: the set
-                // holds 3/4 * vis_slots slots, a search visits D of them).  The visit wave clears the bitmap on its own.
-                if(s.vis_slots && !spilled && viscnt + v.M0 > s.vis_slots / 4 * 3) {
-                    uint4 *b4 = (uint4 *)bitmap;
-                    for(uint32_t i = (uint32_t)lane; i < bm_words / 4; i += 64) b4[ i ] = make_uint4(0, 0, 0, 0);
-                    spilled = true;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the clears are ordered before this wave's atomicOr's
-                }
+                // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (the set holds
+                // 3/4 * vis_slots slots, a search visits D of them).  The bitmap is all-zero (VisUndo): nothing to clear.
+                if(s.vis_slots && !spilled && viscnt + v.M0 > s.vis_slots / 4 * 3) spilled = true;
                 uint32_t        cap;
                 const uint32_t *list = neighbors_of(v, node, level, cap);
                 if(lane == 0) trace_append<PROF>(s, node | (level > 0 ? TRACE_LISTU : TRACE_LIST0));
@@ -762,6 +791,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                         s.newids[ nb_new + __popcll(m & ((1ull << lane) - 1ull)) ] = nb;
                         mark_touched<PROF>(s, nb);
                     }
+                    if(spilled || !s.vis_slots) undo_record(s, undo, isnew, nb, m, lane);  // these ids went into the HBM bitmap
                     nb_new += __popcll(m);
                 }
                 if(s.vis_slots && !spilled) viscnt += (uint32_t)nb_new;
@@ -780,6 +810,7 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
         __syncthreads();
         LGPU_MARK(2)
     }
+    if(visit_wave) undo_apply(s, bitmap, bm_words, undo, lane);  // the workgroup's HBM bitmap goes back to all-zero
     // the result goes where the callers read it: s.keys, ascending
     if(list_wave) {
 #pragma unroll

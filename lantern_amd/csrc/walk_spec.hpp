@@ -274,12 +274,7 @@ __device__ int search_level_spec_impl(const View &v, WalkLds &s, const SpecLds &
     const int     ngroups = (DED ? NW - 3 : NW) * GPW;                  // G-lane groups that evaluate rows
     const int     group = ((DED ? wv - 3 : wv) * GPW) + g;              // this lane's group among them
     const uint32_t M0 = v.M0;
-    if(s.vis_slots) {
-        for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;
-    } else {
-        uint4 *b4 = (uint4 *)bitmap;
-        for(uint32_t i = tid; i < bm_words / 4; i += T) b4[ i ] = make_uint4(0, 0, 0, 0);
-    }
+    for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;  // (the HBM bitmap is all-zero between walks: walk.hpp VisUndo)
     for(uint32_t i = tid; i < c.cache_entries; i += T) c.ctag[ i ] = EMPTY;
     const float     qn2 = __int_as_float(s.scal[ S_QN2 ]);
     uint64_t *const front_pub = (uint64_t *)&s.scal[ S_FRONT ];  // [2] by hop parity: first unexpanded key of the list the hop starts from
@@ -307,14 +302,16 @@ __device__ int search_level_spec_impl(const View &v, WalkLds &s, const SpecLds &
         worst_pub[ 0 ] = ~0ull;  // no front, no radius
     }
     __syncthreads();
-    // visit wave's private state: how many slots the LDS set holds, and whether it has spilled to the bitmap
+    // visit wave's private state: how many slots the LDS set holds, whether it has spilled to the bitmap, the bitmap's undo log
     uint32_t viscnt = 0;
     bool     spilled = false;
+    VisUndo  undo;
     if(tid == 0) {
         (void)visit_test_and_set(s, bitmap, start, false);
         viscnt = s.vis_slots ? 1u : 0u;
     }
     viscnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)viscnt);
+    if(visit_wave && !s.vis_slots) undo_record(s, undo, lane == 0, start, 1ull, lane);  // bitmap-only mode: the start node's bit
     // list wave's private state (walk.hpp search_level_reg): lane l of register r holds the (64 r + l)-th smallest key
     uint64_t           K[ KPL ];
     unsigned long long live[ KPL ];
@@ -398,15 +395,11 @@ __device__ int search_level_spec_impl(const View &v, WalkLds &s, const SpecLds &
         // ---- in the shadow of the loads: the three role sections
         if(visit_wave) {
             // the LDS set must keep room for one full neighbour list; otherwise spill to the HBM bitmap (walk.hpp)
-            if(s.vis_slots && !spilled && viscnt + M0 > s.vis_slots / 4 * 3) {
-                uint4 *b4 = (uint4 *)bitmap;
-                for(uint32_t i = (uint32_t)lane; i < bm_words / 4; i += 64) b4[ i ] = make_uint4(0, 0, 0, 0);
-                spilled = true;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            }
+            if(s.vis_slots && !spilled && viscnt + M0 > s.vis_slots / 4 * 3) spilled = true;  // (the bitmap is all-zero: VisUndo)
             const bool               isnew = hop_is_new(s, bitmap, nb, spilled);
             const unsigned long long nm = __ballot(isnew);
             if(s.vis_slots && !spilled) viscnt += (uint32_t)__popcll(nm);
+            if(spilled || !s.vis_slots) undo_record(s, undo, isnew, nb, nm, lane);  // these ids went into the HBM bitmap
             if(lane == 0) mask_pub[ par ] = nm;
         }
         if(list_wave) {
@@ -512,6 +505,7 @@ __device__ int search_level_spec_impl(const View &v, WalkLds &s, const SpecLds &
             for(int i = 0; i < 8; ++i) atomicAdd(&prof[ 8 * wv + i ], pacc[ i ]);
         }
     }
+    if(visit_wave) undo_apply(s, bitmap, bm_words, undo, lane);  // the workgroup's HBM bitmap goes back to all-zero
     // the result goes where the callers read it: s.keys, ascending
     if(list_wave) {
 #pragma unroll
