@@ -16,6 +16,16 @@
 namespace lgpu {
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+// steps of a row pair's chunk loop whose loads are issued together (group_dist2_n); 0 = one step at a time (the form of rounds 1 - 5)
+#ifndef LGPU_ROW_BLOCK
+#define LGPU_ROW_BLOCK 3
+#endif
+#ifndef LGPU_ROW_BLOCK_COS
+#define LGPU_ROW_BLOCK_COS 2
+#endif
+#ifndef LGPU_ROW_BLOCK1
+#define LGPU_ROW_BLOCK1 4
+#endif
 
 // values follow usearch_metric_kind_t (include/lantern_gpu.h)
 constexpr int M_COS = 1;
@@ -451,18 +461,56 @@ template <int METRIC, int G, typename PA, typename PB>
 __device__ __forceinline__ float group_dist_n(PA a, PB b, int chunks, int gl, float a2, float b2)
 {
     RowAcc<METRIC> acc;
+#if LGPU_ROW_BLOCK1 > 0
+    // one row: both operands' loads of a block of four steps are in flight together (either may be a row in HBM)
+    constexpr int B = LGPU_ROW_BLOCK1;
+    for(int base = gl; base < chunks; base += B * G) {
+        uint4 x[ B ], y[ B ];
+#pragma unroll
+        for(int c = 0; c < B; ++c)
+            if(base + c * G < chunks) {
+                x[ c ] = a[ base + c * G ];
+                y[ c ] = b[ base + c * G ];
+            }
+#pragma unroll
+        for(int c = 0; c < B; ++c)
+            if(base + c * G < chunks) acc.add(x[ c ], y[ c ]);
+    }
+#else
 #pragma unroll 4
     for(int ch = gl; ch < chunks; ch += G) {
         uint4 x = a[ ch ];
         uint4 y = b[ ch ];
         acc.add(x, y);
     }
+#endif
     return acc.template finish_n<G>(a2, b2);
 }
 template <int METRIC, int G, typename PA, typename PB>
 __device__ __forceinline__ void group_dist2_n(PA a, PB b0, PB b1, int chunks, int gl, float a2, float b2_0, float b2_1, float &d0, float &d1)
 {
     RowAcc<METRIC> acc0, acc1;
+#if LGPU_ROW_BLOCK > 0
+    // All loads of a block of LGPU_ROW_BLOCK steps are issued before the first is consumed (2 x LGPU_ROW_BLOCK x 16 bytes per lane in
+    // flight instead of 2 x 16: a 768-d row pair is ONE memory round trip, not three).  The additions keep their order: same bits.
+    constexpr int B = (METRIC % 100 == M_COS) ? LGPU_ROW_BLOCK_COS : LGPU_ROW_BLOCK;
+    for(int base = gl; base < chunks; base += B * G) {
+        uint4 y0[ B ], y1[ B ];
+#pragma unroll
+        for(int c = 0; c < B; ++c)
+            if(base + c * G < chunks) {
+                y0[ c ] = b0[ base + c * G ];
+                y1[ c ] = b1[ base + c * G ];
+            }
+#pragma unroll
+        for(int c = 0; c < B; ++c)
+            if(base + c * G < chunks) {
+                uint4 x = a[ base + c * G ];
+                acc0.add(x, y0[ c ]);
+                acc1.add(x, y1[ c ]);
+            }
+    }
+#else
 #pragma unroll 4
     for(int ch = gl; ch < chunks; ch += G) {
         uint4 x = a[ ch ];
@@ -471,6 +519,7 @@ __device__ __forceinline__ void group_dist2_n(PA a, PB b0, PB b1, int chunks, in
         acc0.add(x, y0);
         acc1.add(x, y1);
     }
+#endif
     d0 = acc0.template finish_n<G>(a2, b2_0);
     d1 = acc1.template finish_n<G>(a2, b2_1);
 }
@@ -481,6 +530,25 @@ template <int METRIC, int G, int R, typename PA, typename PB>
 __device__ __forceinline__ void group_distR_n(PA a, const PB (&b)[ R ], int chunks, int gl, float a2, const float (&b2)[ R ], float (&d)[ R ])
 {
     RowAcc<METRIC> acc[ R ];
+#if LGPU_ROW_BLOCK > 0
+    constexpr int B = R <= 2 ? 3 : 2;  // R x B x 16 bytes per lane in flight
+    for(int base = gl; base < chunks; base += B * G) {
+        uint4 y[ B ][ R ];
+#pragma unroll
+        for(int c = 0; c < B; ++c)
+            if(base + c * G < chunks) {
+#pragma unroll
+                for(int r = 0; r < R; ++r) y[ c ][ r ] = b[ r ][ base + c * G ];
+            }
+#pragma unroll
+        for(int c = 0; c < B; ++c)
+            if(base + c * G < chunks) {
+                uint4 x = a[ base + c * G ];
+#pragma unroll
+                for(int r = 0; r < R; ++r) acc[ r ].add(x, y[ c ][ r ]);
+            }
+    }
+#else
 #pragma unroll 2
     for(int ch = gl; ch < chunks; ch += G) {
         uint4 x = a[ ch ];
@@ -490,6 +558,7 @@ __device__ __forceinline__ void group_distR_n(PA a, const PB (&b)[ R ], int chun
 #pragma unroll
         for(int r = 0; r < R; ++r) acc[ r ].add(x, y[ r ]);
     }
+#endif
 #pragma unroll
     for(int r = 0; r < R; ++r) d[ r ] = acc[ r ].template finish_n<G>(a2, b2[ r ]);
 }
