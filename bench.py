@@ -98,6 +98,7 @@ def parse():
                    "configuration): by default, when rocprofv3 is on PATH, the search leg is re-executed under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
                    "(two short passes restricted to k_search) after the timed region and roofline.traffic is THIS run's")
     p.add_argument("--pmc-steps", type=int, default=4, help="search launches per counter pass")
+    p.add_argument("--no-gather-ceiling", action="store_true", help="skip roofline.gather (the random-row fetch rate of this box, three launches of k_gather_walkshape)")
     p.add_argument("--no-dram-model", action="store_true", help="skip roofline.dram_bytes_model (two traced launches + the LRU replay of their traces)")
     p.add_argument("--no-secondary", action="store_true", help="skip the `secondary` array (bench_secondary.py: BASELINE configs [1] and [2], the clustered set, the "
                    "host-buffer and scan-service paths at the headline shape)")
@@ -473,6 +474,10 @@ def main():
         if world == 1 and not a.no_pmc and not a.pq_subvectors:
             log("counter pass (build kernels) ...")
             build_traffic = measure_build_traffic(a, f"{ix.checksum():016x}")
+        gather = None
+        if world == 1 and not a.pq_subvectors and not a.no_gather_ceiling:
+            log("gather ceiling of this box ...")
+            gather = gather_ceiling(ix, a.n, int(row_bytes), int(min(max(float(D.mean()) * nq, 2e6), 2e7)))
         qps = world * nq * a.steps / elapsed
         out = {
             "metric": f"QPS (recall@{a.k} alongside), {a.n}x{a.dim} f32 {a.metric} ef={a.ef} k={a.k}",
@@ -504,7 +509,8 @@ def main():
             "expansions_per_query": float(E.mean()),
             "roofline": roofline(achieved, traffic, traffic_src, avg_kernel_s if S == 1 else elapsed / a.steps, bytes_per_launch, avg_kernel_s, S, B,
                                  adc=bool(a.pq_subvectors), measured_here=measured_here, pmc_detail=pmc_detail, unique=unique, row_bytes=row_bytes,
-                                 list_bytes=2 * a.M * 4, expansions_per_launch=float(np.mean([per_lane[i % B][1].sum() for i in range(a.steps)])), model=model),
+                                 list_bytes=2 * a.M * 4, expansions_per_launch=float(np.mean([per_lane[i % B][1].sum() for i in range(a.steps)])), model=model,
+                                 gather=gather),
             "cpu_baseline": cpu,
             "pq": pq_info,
             "build_quality": quality,
@@ -532,6 +538,9 @@ def main():
         if world == 1 and not a.no_secondary and a.quant == "f32" and not a.pq_subvectors and a.metric != "hamming":
             import bench_secondary
 
+            if gather and gather.get("algorithmic_gbs"):
+                bench_secondary.GATHER_GBS = gather["algorithmic_gbs"]  # the secondary legs' frac_of_gather_ceiling: this box's, this run's
+
             t0 = time.time()
             log("secondary legs ...")
             out["secondary"] = bench_secondary.run(a, capi, hip, ix, base, all_queries, qps, recall, None if a.no_pmc else measure_traffic)
@@ -542,8 +551,8 @@ def main():
 # profiles/r06_cache_model_calibration.md: 17.56 M uniformly random 3 KiB rows in the walk's own launch shape (k_gather_walkshape) take 9.56 ms:
 # 5.64 TB/s in algorithmic bytes, 5.78 TB/s at the fabric (counters), 5.15 TB/s from DRAM by the cache model.  (Rounds 3 - 5 quoted 6.73 TB/s:
 # an average over six launches one of which was the measuring script's 1000-row self-check -- the calibration file has the correction.)
-GATHER_CEILING_GBS = 5640.0
-GATHER_DRAM_CEILING_GBS = 5150.0
+GATHER_CEILING_GBS = 5640.0       # fallback only (--no-gather-ceiling): profiles/r06_cache_model_calibration.md, another box, before the blocked row loads;
+GATHER_DRAM_CEILING_GBS = 5150.0  # a run measures its own box's figure (gather_ceiling(), roofline.gather)
 
 
 def measure_traffic(a, checksum, counters=("FETCH_SIZE", "WRITE_SIZE"), kernel="k_search"):
@@ -697,8 +706,48 @@ def unique_rows_per_launch(a, ix, step, B, hip):
     return float(np.mean(counts)) if counts else None
 
 
+def gather_ceiling(ix, rows, row_bytes, evaluations, launches=3):
+    """The random-row fetch rate of THIS box, measured in this run: the distance phase of a hop alone, in the walk's launch shape
+    (k_gather_walkshape: four-wave workgroups, six per CU, two rows per 64-lane group in flight, the same blocked loads), over
+    `evaluations` uniformly random rows of the index (no reuse beyond chance, no list, no visited set, no dependent hops).  Boxes of
+    this pool differ by up to 10 % on this figure, so the walk is set against the ceiling of the box it ran on, not a constant.
+    DRAM share: a uniformly random gather over T bytes through an LRU hierarchy of C bytes hits C / T of the time (the cache model
+    reproduces exactly that on this trace: profiles/r06_cache_model_calibration.md), C = the 256 MiB Infinity Cache."""
+    from bench_cache_model import MALL_BYTES
+
+    try:
+        rng = np.random.default_rng(99)
+        q = rng.standard_normal(ix.dims, dtype=np.float32) if ix.metric != capi_mod().METRIC_HAMMING else rng.integers(0, 2**32, ix.dims, dtype=np.uint32)
+        old = os.environ.get("LANTERN_GPU_GATHER_WALKSHAPE")
+        os.environ["LANTERN_GPU_GATHER_WALKSHAPE"] = "1"
+        ms = []
+        try:
+            for i in range(launches):
+                slots = rng.integers(0, rows, size=evaluations, dtype=np.uint32)
+                ix.distance_gather(q, slots)
+                ms.append(ix.last_gather_ms())
+        finally:
+            if old is None:
+                os.environ.pop("LANTERN_GPU_GATHER_WALKSHAPE", None)
+            else:
+                os.environ["LANTERN_GPU_GATHER_WALKSHAPE"] = old
+        steady = ms[1:] or ms
+        alg = evaluations * row_bytes / (float(np.mean(steady)) * 1e-3) / 1e9
+        dram_share = 1.0 - min(1.0, MALL_BYTES / float(rows * row_bytes))
+        return {"kernel": "k_gather_walkshape", "evaluations_per_launch": evaluations, "row_bytes": row_bytes, "launch_ms": ms, "algorithmic_gbs": alg,
+                "dram_share": dram_share, "dram_gbs": alg * dram_share, "measured_in_this_run": True}
+    except Exception as ex:  # noqa: BLE001 -- the ceiling never costs the line
+        return {"error": repr(ex)[:300]}
+
+
+def capi_mod():
+    from lantern_amd import capi
+
+    return capi
+
+
 def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg_kernel_s, S, B, adc=False, measured_here=False, pmc_detail=None,
-             unique=None, row_bytes=0.0, list_bytes=0.0, expansions_per_launch=0.0, model=None):
+             unique=None, row_bytes=0.0, list_bytes=0.0, expansions_per_launch=0.0, model=None, gather=None):
     """The search kernel against the HBM roofline (8 TB/s spec peak).  FOUR fractions, each named for what it is a fraction OF:
 
     `frac` = `frac_algorithmic` (the contract's definition): one row per distance evaluation, one adjacency row per
@@ -715,10 +764,18 @@ def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg
         deliver even with perfect caches.  The true DRAM fraction lies between this and `frac_fabric`; `frac_dram_model` estimates it."""
     alg_frac = achieved_alg / HBM_PEAK_GBS
     fabric = (traffic / launch_s / 1e9) if traffic else None
+    if gather and gather.get("algorithmic_gbs"):
+        g_alg, g_dram = gather["algorithmic_gbs"], gather["dram_gbs"]
+        g_src = ("measured in THIS run on this box (roofline.gather: uniformly random rows of this index through k_gather_walkshape, the distance phase of a hop "
+                 "in the walk's launch shape) -- a walk with reuse may exceed the algorithmic figure, not the DRAM one")
+    else:
+        g_alg, g_dram = GATHER_CEILING_GBS, GATHER_DRAM_CEILING_GBS
+        g_src = ("profiles/r06_cache_model_calibration.md (another box, before the blocked row loads: uniformly random 3 KiB rows in the walk's launch shape: "
+                 "5.64 TB/s algorithmic, 5.15 TB/s from DRAM by the cache model)")
     r = {"bound": "hbm",
          "achieved": achieved_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_frac,
-         "frac_is": "frac_algorithmic -- SURVEY 8d algorithmic bytes / HIP-event launch time / 8 TB/s (the bench contract's definition).  Above ~0.84 "
-                    "(the measured random-row gather ceiling) it is NOT a physical HBM fraction: rows shared by the queries of a launch are counted once per "
+         "frac_is": f"frac_algorithmic -- SURVEY 8d algorithmic bytes / HIP-event launch time / 8 TB/s (the bench contract's definition).  Above ~{g_alg / HBM_PEAK_GBS:.2f} "
+                    "(the random-row gather ceiling, roofline.gather) it is NOT a physical HBM fraction: rows shared by the queries of a launch are counted once per "
                     "evaluation and served by L2 / Infinity Cache.  The physical figures are frac_fabric (counters; includes Infinity-Cache hits) and "
                     "frac_dram_model (cache-model estimate of DRAM bytes), bounded below by frac_cold_miss_lower_bound",
          "traffic": traffic, "traffic_measured_in_this_run": bool(measured_here), "traffic_source": traffic_src,
@@ -733,11 +790,10 @@ def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg
          "unique_rows_per_launch": unique,
          "cold_miss_bytes_per_launch": None, "frac_cold_miss_lower_bound": None,
          "dram_bytes_per_launch": None, "frac_dram": None,  # (no DRAM-side counter on this part; see dram_bytes_model)
-         "gather_ceiling": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r06_cache_model_calibration.md (uniformly random 3 KiB rows in the walk's launch shape: 5.64 TB/s algorithmic, "
-                                                                         "5.15 TB/s from DRAM by the cache model -- a walk with reuse may exceed the first, not the second)",
-         "algorithmic_over_gather_ceiling": achieved_alg / GATHER_CEILING_GBS,
-         "gather_dram_ceiling": GATHER_DRAM_CEILING_GBS,
-         "dram_model_over_gather_dram_ceiling": (model["dram_bytes_model"] / launch_s / 1e9 / GATHER_DRAM_CEILING_GBS) if model and model.get("dram_bytes_model") else None,
+         "gather_ceiling": g_alg, "gather_ceiling_source": g_src,
+         "algorithmic_over_gather_ceiling": achieved_alg / g_alg,
+         "gather_dram_ceiling": g_dram, "gather": gather,
+         "dram_model_over_gather_dram_ceiling": (model["dram_bytes_model"] / launch_s / 1e9 / g_dram) if model and model.get("dram_bytes_model") else None,
          "streaming_ceiling": HBM_MEASURED_CEILING_GBS,
          "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_kernel_s * 1e3,
          "query_batches_rotated": B, "pmc": pmc_detail, "note": None}
@@ -756,7 +812,7 @@ def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg
     if S > 1:
         notes.append(f"{S} launches in flight: rates = all launches' bytes / the timed region; avg_launch_ms is the mean HIP-event "
                      "duration of launches that overlap")
-    if alg_frac > 1.0 or achieved_alg > GATHER_CEILING_GBS:
+    if alg_frac > 1.0 or achieved_alg > g_alg:
         notes.append("frac (algorithmic) exceeds " + ("1" if alg_frac > 1.0 else "the random-row gather ceiling") + ": rows shared by the queries of a launch "
                      "(upper levels, hub rows) are counted once per evaluation but served by L2 / Infinity Cache; frac_fabric and frac_dram_model are the physical figures")
     r["note"] = "; ".join(notes) or None
@@ -941,7 +997,8 @@ def clustered_coheadline(a, capi, hip, quality):
            "data": "synthetic (clustered: " + synth.CLUSTERED_DOC + ")", "value": qps, "unit": "queries/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
            f"recall_at_{b.k}": recall, "recall_queries": tq, "dist_evals_per_query": float(per_lane[0][0].mean()), "expansions_per_query": float(per_lane[0][1].mean()),
            "roofline": roofline(bytes_l / launch_s / 1e9, traffic, src, launch_s, bytes_l, launch_s, 1, B, measured_here=traffic is not None, pmc_detail=pmc, unique=unique,
-                                row_bytes=d * 4, list_bytes=2 * b.M * 4, expansions_per_launch=exp_l, model=model),
+                                row_bytes=d * 4, list_bytes=2 * b.M * 4, expansions_per_launch=exp_l, model=model,
+                                gather=None if b.no_gather_ceiling else gather_ceiling(ix, n, d * 4, int(min(max(float(per_lane[0][0].mean()) * nq, 2e6), 2e7)))),
            "cpu_baseline": cpu, "gpu_over_cpu_all_cores": (qps / cpu["value"]) if cpu else None, "gpu_over_cpu_1_thread": (qps / cpu["value_1_thread"]) if cpu else None,
            "build_vectors_per_s": n / t_build, "build_seconds": t_build, "build_roofline": build_roofline(b, counters, profile, t_build, 1),
            "build_quality": quality, "setup_seconds": {"datagen": t_gen}}
@@ -961,7 +1018,7 @@ def clustered_coheadline(a, capi, hip, quality):
             f"recall_at_{b.k}": float(np.mean([len(set(f.tolist()) & set(t.tolist())) / b.k for f, t in zip(cfound, ctruth)])),
             "dist_evals_per_query": float(c_lane[0][0].mean()), "build_vectors_per_s": n / t_cbuild,
             "roofline": {"bound": "hbm", "achieved": c_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c_alg / HBM_PEAK_GBS, "frac_is": "frac_algorithmic (SURVEY 8d bytes / HIP-event launch time)",
-                         "frac_of_gather_ceiling": c_alg / GATHER_CEILING_GBS, "algorithmic_bytes_per_launch": c_bytes, "avg_launch_ms": c_launch * 1e3, "kernel": "k_search", "traffic": None}}
+                         "frac_of_gather_ceiling": c_alg / (((out.get("roofline") or {}).get("gather") or {}).get("algorithmic_gbs") or GATHER_CEILING_GBS), "algorithmic_bytes_per_launch": c_bytes, "avg_launch_ms": c_launch * 1e3, "kernel": "k_search", "traffic": None}}
     except Exception as ex:  # noqa: BLE001
         out["cosine_1024_query_batches"] = {"error": repr(ex)[:300]}
     return out

@@ -310,6 +310,8 @@ LANTERN_GPU_EXPORT int lantern_gpu_last_search_grid(usearch_index_t, usearch_err
  * made of, exposed for tests and profiling.  Host buffers. */
 LANTERN_GPU_EXPORT void lantern_gpu_distance_gather(usearch_index_t, const void *query, const uint32_t *slots,
                                                     size_t n, float *out, usearch_error_t *);
+/* kernel time (ms, HIP events on the index stream) of the last lantern_gpu_distance_gather launch of this index */
+LANTERN_GPU_EXPORT float lantern_gpu_last_gather_ms(usearch_index_t, usearch_error_t *);
 /* Dense na x nb distance matrix between two host matrices (f32 rows of `dims` scalars, or u32
  * words for hamming with dims = bits).  `exact_order` != 0 uses the per-pair reduction order of
  * the graph walk (bit-identical to usearch_distance); 0 uses the fp32-MFMA contraction. */

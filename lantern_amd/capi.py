@@ -87,7 +87,7 @@ EXPORTS = [
     "lantern_gpu_set_seed", "lantern_gpu_set_add_batch", "lantern_gpu_add_many", "lantern_gpu_flush",
     "lantern_gpu_add_with_level", "lantern_gpu_search_batch", "lantern_gpu_search_batch_device", "lantern_gpu_search_batch_device_strided",
     "lantern_gpu_set_search_shape", "lantern_gpu_exact_search", "lantern_gpu_dense_profile", "lantern_gpu_distance_gather",
-    "lantern_gpu_host_alloc", "lantern_gpu_host_free", "lantern_gpu_save_stream", "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile", "lantern_gpu_search_unique_rows", "lantern_gpu_search_row_trace", "lantern_gpu_last_search_grid",
+    "lantern_gpu_host_alloc", "lantern_gpu_host_free", "lantern_gpu_save_stream", "lantern_gpu_pq_compact", "lantern_gpu_pq_expand", "lantern_gpu_memory_usage", "lantern_gpu_spec_profile", "lantern_gpu_search_unique_rows", "lantern_gpu_search_row_trace", "lantern_gpu_last_search_grid", "lantern_gpu_last_gather_ms",
     "lantern_gpu_distance_matrix", "lantern_gpu_assign_to_clusters", "lantern_gpu_graph_info_get", "lantern_gpu_export_graph", "lantern_gpu_import_graph",
     "lantern_gpu_export_codes",
     "lantern_gpu_counters_get", "lantern_gpu_set_profiling", "lantern_gpu_build_profile_get", "lantern_gpu_search_phase_profile", "lantern_scan_begin", "lantern_scan_rescan", "lantern_scan_gettuple", "lantern_scan_trace", "lantern_scan_end",
@@ -180,6 +180,7 @@ def lib() -> C.CDLL:
         "lantern_gpu_search_unique_rows": (None, [vp, i32, C.POINTER(u64), err]),
         "lantern_gpu_search_row_trace": (None, [vp, i32, sz, sz, vp, vp, err]),
         "lantern_gpu_last_search_grid": (i32, [vp, err]),
+        "lantern_gpu_last_gather_ms": (f32, [vp, err]),
         "lantern_gpu_save_stream": (None, [vp, vp, vp, err]),
         "lantern_gpu_pq_compact": (None, [vp, err]),
         "lantern_gpu_pq_expand": (None, [vp, err]),
@@ -484,6 +485,10 @@ class GpuIndex:
         out = C.c_uint64(0)
         _call("lantern_gpu_search_unique_rows", self.h, 1 if on else 0, C.byref(out) if read else None)
         return int(out.value) if read else None
+
+    def last_gather_ms(self) -> float:
+        """kernel time of the last distance_gather launch (HIP events on the index stream)"""
+        return float(_call("lantern_gpu_last_gather_ms", self.h))
 
     def last_search_grid(self) -> int:
         return int(_call("lantern_gpu_last_search_grid", self.h))

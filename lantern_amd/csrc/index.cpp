@@ -2443,9 +2443,17 @@ try {
     float    *d_out = (float *)(buf + row + n * 4);
     bool      ok = hipMemcpyAsync(buf, padded.data(), row, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(d_slots, slots, n * 4, hipMemcpyHostToDevice, ix->stream) == hipSuccess;
+    hipEvent_t t0 = nullptr, t1 = nullptr;  // the kernel alone (lantern_gpu_last_gather_ms: bench.py's in-run gather ceiling)
+    ok = ok && hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess;
+    ok = ok && hipEventRecord(t0, ix->stream) == hipSuccess;
     ok = ok && launch_gather(ix->mcode, ix->view(), (const uint4 *)buf, d_slots, (uint32_t)n, d_out, ix->stream) == hipSuccess;
+    ok = ok && hipEventRecord(t1, ix->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ix->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(ix->stream) == hipSuccess;
+    ix->last_gather_ms = 0.f;
+    if(ok) (void)hipEventElapsedTime(&ix->last_gather_ms, t0, t1);
+    if(t0) (void)hipEventDestroy(t0);
+    if(t1) (void)hipEventDestroy(t1);
     if(!ok) FAIL(e, "lantern_gpu: HIP failure in distance_gather");
 }
 LANTERN_ABI_CATCH_VOID(e)
@@ -2938,6 +2946,16 @@ try {
     if(!ok) FAIL(e, "lantern_gpu: HIP failure reading the row trace (or per_query_cap differs from the one the trace was started with)");
 }
 LANTERN_ABI_CATCH_VOID(e)
+
+float lantern_gpu_last_gather_ms(usearch_index_t h, usearch_error_t *e)
+try {
+    CLEAR(e);
+    Index *ix = H(h, e);
+    if(!ix) return 0.f;
+    std::lock_guard<std::mutex> g(ix->mu);
+    return ix->last_gather_ms;
+}
+LANTERN_ABI_CATCH(e)
 
 // workgroups of the last search launch (k_search / k_search_spec): the number of walks resident at a time -- the cache model's `walkers`
 int lantern_gpu_last_search_grid(usearch_index_t h, usearch_error_t *e)

@@ -121,6 +121,7 @@ struct Index
     uint32_t               *d_trace = nullptr, *d_trace_count = nullptr;  // diagnostics: [trace_nq][trace_cap] + [trace_nq] (lantern_gpu_search_row_trace)
     size_t                  trace_nq = 0, trace_cap = 0;
     bool                    trace_on = false;
+    float                   last_gather_ms = 0.f;   // kernel time of the last lantern_gpu_distance_gather launch (HIP events on the index stream)
     int                     last_search_grid = 0;   // workgroups of the last bandwidth-bound search launch (lantern_gpu_last_search_grid)
     std::deque<ProfBatch>   prof_pending;
     std::vector<hipEvent_t> prof_free;
