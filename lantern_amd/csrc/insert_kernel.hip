@@ -3,6 +3,9 @@
 #include <algorithm>
 #include <cstdlib>
 
+#ifdef LGPU_INSERT_ROW_BLOCK_COS  // this translation unit's own block for the cosine row pairs (device_common.hpp LGPU_ROW_BLOCK_COS)
+#define LGPU_ROW_BLOCK_COS LGPU_INSERT_ROW_BLOCK_COS
+#endif
 #include "kernels.hpp"
 #include "walk.hpp"
 #include "dispatch.hpp"
@@ -17,7 +20,10 @@ template <int METRIC, int G, int KPL = 2>  // KPL: as k_search (keys per lane of
 #ifndef LGPU_INSERT_MIN_BLOCKS
 #define LGPU_INSERT_MIN_BLOCKS 6  // (measured: 5 and 4 -- 81 / 90 registers, no spills -- build at the same speed; DESIGN_HISTORY.md H.2 item 1)
 #endif
-__global__ void __launch_bounds__(512, LGPU_INSERT_MIN_BLOCKS) k_insert(InsertArgs a)
+// [r6] the cosine walks are compiled for the FIVE workgroups per CU that k_insert's LDS lets run anyway (<= 96 VGPRs): with the blocked row
+// loads they spill at 80 (48 bytes of scratch, reloads inside a hop) -- same-box A/B at 1M x 768: walk 742 -> 691 ms, 949 -> 993 k vectors/s;
+// the other metrics measure the same or slower at five (profiles/r06_row_block_ab.jsonl, second table)
+__global__ void __launch_bounds__(512, (METRIC % 100 == M_COS) ? 5 : LGPU_INSERT_MIN_BLOCKS) k_insert(InsertArgs a)
 {
     const int tid = threadIdx.x, T = blockDim.x;
     WalkLds   s;

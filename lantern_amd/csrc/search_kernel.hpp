@@ -70,7 +70,10 @@ __device__ __forceinline__ KernargBytes kernarg_opaque()
 // small-batch shape, four waves); 2: three dedicated role waves + row waves (the lone-query shape, 3 + 8 waves); 3: the same
 // shape with two nodes per round, the second one speculative (walk_twin.hpp).
 template <int METRIC, int G, bool PROF = false, int ROWS = 2, int KPL = 1, int SPEC = 0>
-__global__ void __launch_bounds__(SPEC >= 2 ? 704 : 512, SPEC >= 2 ? 3 : (SPEC == 1 || ROWS != 2) ? 4 : 6)  // SPEC 0, ROWS 2: <= 80 VGPRs, six 4-wave workgroups per CU
+#ifndef LGPU_SEARCH_MIN_BLOCKS_COS
+#define LGPU_SEARCH_MIN_BLOCKS_COS 6
+#endif
+__global__ void __launch_bounds__(SPEC >= 2 ? 704 : 512, SPEC >= 2 ? 3 : (SPEC == 1 || ROWS != 2) ? 4 : (METRIC % 100 == M_COS) ? LGPU_SEARCH_MIN_BLOCKS_COS : 6)  // SPEC 0, ROWS 2: <= 80 VGPRs, six 4-wave workgroups per CU
 k_search(SearchArgs)
 {
     const int tid = threadIdx.x, T = blockDim.x;
