@@ -734,8 +734,27 @@ def gather_ceiling(ix, rows, row_bytes, evaluations, launches=3):
         steady = ms[1:] or ms
         alg = evaluations * row_bytes / (float(np.mean(steady)) * 1e-3) / 1e9
         dram_share = 1.0 - min(1.0, MALL_BYTES / float(rows * row_bytes))
-        return {"kernel": "k_gather_walkshape", "evaluations_per_launch": evaluations, "row_bytes": row_bytes, "launch_ms": ms, "algorithmic_gbs": alg,
-                "dram_share": dram_share, "dram_gbs": alg * dram_share, "measured_in_this_run": True}
+        out = {"kernel": "k_gather_walkshape", "evaluations_per_launch": evaluations, "row_bytes": row_bytes, "launch_ms": ms, "algorithmic_gbs": alg,
+               "dram_share": dram_share, "dram_gbs": alg * dram_share, "measured_in_this_run": True}
+        # the same gather over a part of the table that FITS the Infinity Cache (0.7 of its 256 MiB; far more than the eight 4 MiB L2s hold):
+        # what the fabric between the L2s and the Infinity Cache delivers to this access pattern -- the ceiling of a walk whose rows are
+        # shared by the queries of a launch (the Gaussian set: nine tenths of its fabric bytes are Infinity-Cache hits)
+        cache_rows = int(0.7 * MALL_BYTES / row_bytes)
+        if cache_rows < rows:
+            os.environ["LANTERN_GPU_GATHER_WALKSHAPE"] = "1"
+            cms = []
+            try:
+                for i in range(launches):
+                    ix.distance_gather(q, rng.integers(0, cache_rows, size=evaluations, dtype=np.uint32))
+                    cms.append(ix.last_gather_ms())
+            finally:
+                if old is None:
+                    os.environ.pop("LANTERN_GPU_GATHER_WALKSHAPE", None)
+                else:
+                    os.environ["LANTERN_GPU_GATHER_WALKSHAPE"] = old
+            out["infinity_cache"] = {"rows": cache_rows, "table_bytes": cache_rows * row_bytes, "launch_ms": cms,
+                                     "algorithmic_gbs": evaluations * row_bytes / (float(np.mean(cms[1:] or cms)) * 1e-3) / 1e9}
+        return out
     except Exception as ex:  # noqa: BLE001 -- the ceiling never costs the line
         return {"error": repr(ex)[:300]}
 
@@ -772,6 +791,7 @@ def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg
         g_alg, g_dram = GATHER_CEILING_GBS, GATHER_DRAM_CEILING_GBS
         g_src = ("profiles/r06_cache_model_calibration.md (another box, before the blocked row loads: uniformly random 3 KiB rows in the walk's launch shape: "
                  "5.64 TB/s algorithmic, 5.15 TB/s from DRAM by the cache model)")
+    g_mall = ((gather or {}).get("infinity_cache") or {}).get("algorithmic_gbs")
     r = {"bound": "hbm",
          "achieved": achieved_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_frac,
          "frac_is": f"frac_algorithmic -- SURVEY 8d algorithmic bytes / HIP-event launch time / 8 TB/s (the bench contract's definition).  Above ~{g_alg / HBM_PEAK_GBS:.2f} "
@@ -793,6 +813,8 @@ def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg
          "gather_ceiling": g_alg, "gather_ceiling_source": g_src,
          "algorithmic_over_gather_ceiling": achieved_alg / g_alg,
          "gather_dram_ceiling": g_dram, "gather": gather,
+         "gather_infinity_cache_ceiling": g_mall,
+         "fabric_over_infinity_cache_gather": (fabric / g_mall) if fabric and g_mall else None,
          "dram_model_over_gather_dram_ceiling": (model["dram_bytes_model"] / launch_s / 1e9 / g_dram) if model and model.get("dram_bytes_model") else None,
          "streaming_ceiling": HBM_MEASURED_CEILING_GBS,
          "kernel": "k_search", "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_kernel_s * 1e3,

@@ -81,9 +81,10 @@ static void run(const uint4 *table, uint32_t *ids, std::vector<uint32_t> &h, uin
     first = false;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const uint32_t rows = 1000000, evals = 17600000;
+    // rows: 1000000 (3 GB: DRAM) by default; 60000 (184 MB: inside the 256 MiB Infinity Cache); 8000 (24.6 MB: inside the eight 4 MiB L2s)
+    const uint32_t rows = argc > 1 ? (uint32_t)std::atoi(argv[ 1 ]) : 1000000, evals = 17600000;
     uint4 *table;
     CHECK(hipMalloc(&table, (size_t)rows * 3072));
     CHECK(hipMemset(table, 0x3c, (size_t)rows * 3072));

@@ -34,10 +34,13 @@ def test_roofline_names_its_fractions():
     assert "exceeds 1" in r["note"]
     # the random-row ceiling is this run's own (roofline.gather) when it was measured, the committed calibration's otherwise -- and says which
     assert r["gather_ceiling"] == bench.GATHER_CEILING_GBS and "another box" in r["gather_ceiling_source"]
-    g = {"algorithmic_gbs": 5950.0, "dram_gbs": 5430.0, "measured_in_this_run": True}
+    g = {"algorithmic_gbs": 5950.0, "dram_gbs": 5430.0, "measured_in_this_run": True, "infinity_cache": {"algorithmic_gbs": 7100.0}}
     rg = bench.roofline(alg_bytes / launch_s / 1e9, 48.9e9, "counters", launch_s, alg_bytes, launch_s, 1, 4, measured_here=True, model=model, gather=g)
     assert rg["gather_ceiling"] == 5950.0 and rg["gather_dram_ceiling"] == 5430.0 and "THIS run" in rg["gather_ceiling_source"] and rg["gather"] is g
     assert abs(rg["dram_model_over_gather_dram_ceiling"] - 5.3e9 / launch_s / 1e9 / 5430.0) < 1e-12
+    # ... and the cache-served counterpart: the fabric rate of the walk against a gather over a table that fits the Infinity Cache
+    assert rg["gather_infinity_cache_ceiling"] == 7100.0 and abs(rg["fabric_over_infinity_cache_gather"] - rg["achieved_fabric"] / 7100.0) < 1e-12
+    assert r["gather_infinity_cache_ceiling"] is None and r["fabric_over_infinity_cache_gather"] is None
     assert bench.roofline(1.0, None, None, 1.0, 1.0, 1.0, 1, 1, gather={"error": "x"})["gather_ceiling"] == bench.GATHER_CEILING_GBS
     # without counters or a model the physical fields are null, never silently the algorithmic figure
     r2 = bench.roofline(6500.0, None, None, launch_s, 6500.0e9 * launch_s, launch_s, 1, 4)
