@@ -530,11 +530,15 @@ def main():
             c = out["clustered"]
             out["sets"] = {"gaussian": {"data": "i.i.d. N(0,1) (SURVEY 8d's prescribed set; no neighbourhood structure in 768 dimensions)", "value": qps,
                                         f"recall_at_{a.k}": recall, "frac_algorithmic": out["roofline"]["frac_algorithmic"], "frac_fabric": out["roofline"]["frac_fabric"],
-                                        "frac_dram_model": out["roofline"]["frac_dram_model"], "cpu_all_cores": cpu["value"] if cpu else None},
+                                        "frac_dram_model": out["roofline"]["frac_dram_model"], "cpu_all_cores": cpu["value"] if cpu else None,
+                                        "fabric_over_infinity_cache_gather": out["roofline"].get("fabric_over_infinity_cache_gather"),
+                                        "dram_model_over_gather_dram_ceiling": out["roofline"].get("dram_model_over_gather_dram_ceiling")},
                            "clustered": {"data": "clustered: " + synth.CLUSTERED_DOC, "value": c.get("value"), f"recall_at_{a.k}": c.get(f"recall_at_{a.k}"),
                                          "frac_algorithmic": (c.get("roofline") or {}).get("frac_algorithmic"), "frac_fabric": (c.get("roofline") or {}).get("frac_fabric"),
                                          "frac_dram_model": (c.get("roofline") or {}).get("frac_dram_model"),
-                                         "cpu_all_cores": (c.get("cpu_baseline") or {}).get("value")}}
+                                         "cpu_all_cores": (c.get("cpu_baseline") or {}).get("value"),
+                                         "fabric_over_infinity_cache_gather": (c.get("roofline") or {}).get("fabric_over_infinity_cache_gather"),
+                                         "dram_model_over_gather_dram_ceiling": (c.get("roofline") or {}).get("dram_model_over_gather_dram_ceiling")}}
         if world == 1 and not a.no_secondary and a.quant == "f32" and not a.pq_subvectors and a.metric != "hamming":
             import bench_secondary
 
@@ -780,7 +784,10 @@ def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg
     `frac_dram_model`: Infinity-Cache MISSES of an LRU replay of the launch's own trace (dram_model(); lantern_amd/tools/cache_model.c)
         / time / 8 TB/s.  A model, validated by its fabric-side output against the counters (`dram_model.fabric_model_over_counters`).
     `frac_cold_miss_lower_bound`: distinct rows of a launch x row bytes (+ their adjacency rows) / time / 8 TB/s -- what DRAM must
-        deliver even with perfect caches.  The true DRAM fraction lies between this and `frac_fabric`; `frac_dram_model` estimates it."""
+        deliver even with perfect caches.  The true DRAM fraction lies between this and `frac_fabric`; `frac_dram_model` estimates it.
+    Beside the fractions of the spec peak, the two ceilings of the access pattern measured in the same run on the same box (`gather`,
+    gather_ceiling()): `dram_model_over_gather_dram_ceiling` (the walk's DRAM rate / a uniformly random gather's over the whole table) and
+    `fabric_over_infinity_cache_gather` (the walk's fabric rate / the same gather's over a part of the table that fits the Infinity Cache)."""
     alg_frac = achieved_alg / HBM_PEAK_GBS
     fabric = (traffic / launch_s / 1e9) if traffic else None
     if gather and gather.get("algorithmic_gbs"):
