@@ -609,8 +609,9 @@ def test_i8_storage_matches_oracle(capi, oracle, metric, n, d, M, efc):
 
 @pytest.mark.parametrize("metric,d", [("l2sq", 768), ("cos", 768), ("l2sq", 128), ("hamming", 24), ("cos", 100)])
 def test_gather_in_the_walks_launch_shape_has_the_same_bits(capi, metric, d, monkeypatch):
-    """scripts/bench_gather_ceiling.py calibrates the random-row fetch rate with the distance phase of a hop on its own
-    (persistent four-wave workgroups, two rows in flight per group): same chains and trees as the plain gather."""
+    """bench.py gather_ceiling() measures the random-row fetch rate of the box with the distance phase of a hop on its own
+    (persistent four-wave workgroups, two rows in flight per group, the blocked row loads): same chains and trees as the plain
+    gather, and lantern_gpu_last_gather_ms reports that launch's kernel time."""
     rng = np.random.default_rng(d)
     base = rand_rows(rng, 3000, d, metric)
     ix = capi.GpuIndex(metric, d, M=4, ef_construction=16, ef=16, seed=1)
@@ -619,7 +620,9 @@ def test_gather_in_the_walks_launch_shape_has_the_same_bits(capi, metric, d, mon
     slots = rng.integers(0, 3000, 20_001).astype(np.uint32)
     plain = ix.distance_gather(q, slots)
     monkeypatch.setenv("LANTERN_GPU_GATHER_WALKSHAPE", "1")
+    assert ix.last_gather_ms() > 0.0
     assert np.array_equal(ix.distance_gather(q, slots), plain)
+    assert 0.0 < ix.last_gather_ms() < 50.0
 
 
 @pytest.mark.parametrize("metric", ["l2sq", "cos"])
