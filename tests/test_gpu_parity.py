@@ -982,3 +982,78 @@ def test_device_reproduces_the_committed_fixture(capi):
         assert [[f"{int(x):08x}" for x in row] for row in dist.view(np.uint32)] == exp["dist_bits"], name
         ran += 1
     assert ran == 6
+
+
+# ------------------------------------------------------------------------------------------------
+# The row loads of a distance go out in blocks of steps (device_common.hpp LGPU_ROW_BLOCK: three steps for L2sq, two for cosine,
+# four for the single-row form), each step predicated on the lane's own chunk count.  Row widths on both sides of every block
+# boundary, for every group width G (64 lanes from 128 chunks, 32 from 64, 16 from 32, else 8): chunks = steps x G - 1, steps x G,
+# steps x G + 1 -- builds edge for edge, searches bit for bit (ids, distance bits, D, E), a lone query through the latency-bound walk.
+# ------------------------------------------------------------------------------------------------
+BLOCK_BOUNDARY_CHUNKS = [1, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31,            # G = 8:  1 .. 4 steps
+                         32, 33, 47, 48, 49, 63,                            # G = 16: 2 .. 4 steps
+                         64, 65, 95, 96, 97, 127,                           # G = 32: 2 .. 4 steps
+                         128, 129, 191, 192, 193, 255, 256, 257, 383, 385]  # G = 64: 2 .. 7 steps
+
+
+@pytest.mark.parametrize("metric", ["l2sq", "cos"])
+@pytest.mark.parametrize("chunks", BLOCK_BOUNDARY_CHUNKS)
+def test_row_widths_around_every_load_block_boundary(capi, oracle, metric, chunks):
+    rng = np.random.default_rng(chunks)
+    d = chunks * 4 - int(rng.integers(0, 4))  # the last chunk full or ragged
+    n = 500
+    base, queries = rand_rows(rng, n, d, metric), rand_rows(rng, 40, d, metric)
+    labels = np.arange(n, dtype=np.uint64) + LABEL0
+    ora = oracle.OracleIndex(metric, d, M=8, ef_construction=32, ef=24, seed=13, sum_mode=oracle.SUM_WAVE64)
+    ora.add_planned(labels, base, max_batch=128, min_ratio=4)
+    gpu = capi.GpuIndex(metric, d, M=8, ef_construction=32, ef=24, seed=13)
+    gpu.set_add_batch(128, 4)
+    gpu.add_many(labels, base)
+    go, gg = ora.export_graph(), gpu.export_graph()
+    assert np.array_equal(gg["nbr0"], go["nbr0"]) and np.array_equal(gg["upper_nbr"], go["upper_nbr"]) and np.array_equal(gg["levels"], go["levels"])
+    o_lab, o_dist, o_slot, o_D, o_E = ora.search_batch(queries, 5)
+    from lantern_amd import hip
+
+    rows = gpu.device_query_rows(queries)
+    dq = hip.Buffer.from_numpy(rows)
+    slot, dist, D, E = hip.Buffer(40 * 5 * 4), hip.Buffer(40 * 5 * 4), hip.Buffer(40 * 8), hip.Buffer(40 * 8)
+    for waves in (0, 4):  # the automatic shape (40 queries: the latency-bound walk) and the classic kernel
+        gpu.set_search_shape(waves)
+        gpu.search_batch_device(dq.ptr, 40, 5, 0, 0, None, dist.ptr, slot.ptr, None, D.ptr, E.ptr, query_stride=rows.strides[0])
+        hip.synchronize()
+        assert np.array_equal(slot.download((40, 5), np.uint32), o_slot), f"slots differ (waves={waves})"
+        assert np.array_equal(dist.download((40, 5), np.float32).view(np.uint32), o_dist.view(np.uint32))
+        assert np.array_equal(D.download(40, np.uint64), o_D) and np.array_equal(E.download(40, np.uint64), o_E)
+    gpu.set_search_shape(0)
+    l1, d1 = gpu.search(queries[0], 5)
+    assert np.array_equal(l1, o_lab[0][: len(l1)]) and np.array_equal(d1, o_dist[0][: len(d1)])
+    # the gathered distance (single-row form, both launch shapes)
+    picks = rng.integers(0, n, 64).astype(np.uint32)
+    ref = np.array([oracle.distance(queries[1], base[s], metric, oracle.SUM_WAVE64) for s in picks], dtype=np.float32)
+    assert np.array_equal(gpu.distance_gather(queries[1], picks).view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", ["f16", "i8"])
+@pytest.mark.parametrize("metric", ["l2sq", "cos"])
+@pytest.mark.parametrize("chunks", [15, 16, 17, 47, 48, 49, 95, 96, 97, 125])  # (Lantern caps d at 2000: an i8 row has at most 125 chunks)
+def test_quantised_row_widths_around_the_load_block_boundaries(capi, oracle, kind, metric, chunks):
+    per_chunk = 8 if kind == "f16" else 16
+    rng = np.random.default_rng(chunks + per_chunk)
+    d = min(2000, chunks * per_chunk - int(rng.integers(0, per_chunk)))
+    n = 400
+    base = (rng.standard_normal((n, d), dtype=np.float32) * np.float32(0.4)).astype(np.float32)
+    queries = (rng.standard_normal((32, d), dtype=np.float32) * np.float32(0.4)).astype(np.float32)
+    stored, mode = (oracle.round_f16, oracle.SUM_WAVE64_F16) if kind == "f16" else (oracle.quantize_i8, oracle.SUM_I8)
+    labels = np.arange(n, dtype=np.uint64) + LABEL0
+    ora = oracle.OracleIndex(metric, d, M=8, ef_construction=32, ef=24, seed=13, sum_mode=mode)
+    ora.add_planned(labels, stored(base), max_batch=128, min_ratio=4)
+    gpu = capi.GpuIndex(metric, d, M=8, ef_construction=32, ef=24, seed=13, quantization=kind)
+    gpu.set_add_batch(128, 4)
+    gpu.add_many(labels, base)
+    go, gg = ora.export_graph(), gpu.export_graph()
+    assert np.array_equal(gg["nbr0"], go["nbr0"]) and np.array_equal(gg["upper_nbr"], go["upper_nbr"])
+    o_lab, o_dist, _, _, _ = ora.search_batch(stored(queries), 5)
+    for waves in (0, 4):
+        gpu.set_search_shape(waves)
+        lab, dist, _ = gpu.search_batch(queries, 5)
+        assert np.array_equal(lab, o_lab) and np.array_equal(dist.view(np.uint32), o_dist.view(np.uint32)), f"waves={waves}"
