@@ -996,7 +996,7 @@ BLOCK_BOUNDARY_CHUNKS = [1, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31,            # G 
                          128, 129, 191, 192, 193, 255, 256, 257, 383, 385]  # G = 64: 2 .. 7 steps
 
 
-@pytest.mark.parametrize("metric", ["l2sq", "cos"])
+@pytest.mark.parametrize("metric", ["l2sq", "cos", "hamming"])
 @pytest.mark.parametrize("chunks", BLOCK_BOUNDARY_CHUNKS)
 def test_row_widths_around_every_load_block_boundary(capi, oracle, metric, chunks):
     rng = np.random.default_rng(chunks)
