@@ -23,6 +23,9 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 #ifndef LGPU_ROW_BLOCK_COS
 #define LGPU_ROW_BLOCK_COS 2
 #endif
+#ifndef LGPU_LIST_PREFETCH  // speculative fetch of the front's neighbour list (walk.hpp search_level_reg): 0 off, 1 rows of < 128 chunks, 2 all
+#define LGPU_LIST_PREFETCH 1
+#endif
 #ifndef LGPU_ROW_BLOCK1
 #define LGPU_ROW_BLOCK1 4
 #endif

@@ -5,6 +5,9 @@
 // above it (one node in sixteen has any) keep walk.hpp's walk.  Same candidates in the same order as k_insert: the graph does
 // not depend on which of the two ran (tests/: the build parity tests start from an empty index and pass through this kernel).
 // f32 rows under l2sq / cos only; other storage kinds keep k_insert.
+#ifndef LGPU_LIST_PREFETCH  // as insert_kernel.hip
+#define LGPU_LIST_PREFETCH 0
+#endif
 #include "kernels.hpp"
 #include "walk.hpp"
 #include "walk_spec.hpp"

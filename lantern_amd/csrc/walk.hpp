@@ -626,6 +626,15 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
     const int  wv = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const bool split = T >= 128;
     const bool visit_wave = wv == 0, list_wave = split ? wv == 1 : wv == 0;  // (which second wave makes no difference: measured)
+    // [r6] Speculative fetch of the FRONT's neighbour list.  The node a hop expands is min(front, best new key of the previous hop); the
+    // front is published before the previous hop's distances are even requested, and it IS the next node in 88 % of the hops on
+    // clustered data (49 % on i.i.d. Gaussian: scripts/experiments/front_hit_rate.py).  So the visit wave requests the front's list
+    // (one 128-byte line at M = 16) right before the distance phase and finds it in a register one hop later; a wrong guess costs the
+    // line.  Level 0 only (an upper list's address needs a load of its own), lists of at most 64 entries, never in the instrumented
+    // walk (its trace is the logical access sequence).  LGPU_LIST_PREFETCH: 0 off, 1 rows of fewer than 128 chunks (G < 64), 2 all.
+    constexpr bool PF = !PROF && (LGPU_LIST_PREFETCH >= 2 || (LGPU_LIST_PREFETCH == 1 && G < 64));
+    const bool     pf_on = PF && split && level == 0 && v.M0 <= 64;
+    uint32_t       pf_node = EMPTY, pf_nb = EMPTY;
     unsigned long long tl = 0;
     if constexpr(PROF) tl = (unsigned long long)clock64();
     for(uint32_t i = tid; i < s.vis_slots; i += T) s.vis[ i ] = EMPTY;  // (the HBM bitmap is all-zero between walks: VisUndo)
@@ -777,10 +786,13 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
                 uint32_t        cap;
                 const uint32_t *list = neighbors_of(v, node, level, cap);
                 if(lane == 0) trace_append<PROF>(s, node | (level > 0 ? TRACE_LISTU : TRACE_LIST0));
+                const bool have_list = pf_on && node == pf_node;  // (uniform) the speculative fetch of the previous hop was this node's list
                 int nb_new = 0;
                 for(uint32_t off = 0; off < cap; off += 64) {
                     const uint32_t i = off + (uint32_t)lane;
-                    const uint32_t nb = i < cap ? list[ i ] : EMPTY;
+                    uint32_t       nb;
+                    if(have_list) nb = pf_nb;  // (cap <= 64: one pass)
+                    else nb = i < cap ? list[ i ] : EMPTY;
                     if constexpr(PROF) {  // make the list's arrival visible to the phase clock
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         LGPU_MARK(5)
@@ -804,6 +816,11 @@ __device__ int search_level_reg(const View &v, WalkLds &s, uint32_t *bitmap, uin
         LGPU_MARK(1)
         if(nnew < 0) break;
         pend = nnew;
+        if(pf_on && visit_wave) {  // the next hop's front (the list wave published it before the barrier): request its list now
+            const uint64_t nf = front_pub[ par ^ 1 ];
+            pf_node = nf != ~0ull ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)nf >> 1)) : EMPTY;
+            if(pf_node != EMPTY) pf_nb = (uint32_t)lane < v.M0 ? v.nbr0[ (size_t)pf_node * v.M0 + (uint32_t)lane ] : EMPTY;
+        }
         if(nnew == 0) continue;
         hop_distances<METRIC, G, ROWS, false>(v, s, nnew, qn2, ~0ull, nullptr);
         D += (uint32_t)nnew;
