@@ -718,10 +718,11 @@ def gather_ceiling(ix, rows, row_bytes, evaluations, launches=3):
     DRAM share: a uniformly random gather over T bytes through an LRU hierarchy of C bytes hits C / T of the time (the cache model
     reproduces exactly that on this trace: profiles/r06_cache_model_calibration.md), C = the 256 MiB Infinity Cache."""
     from bench_cache_model import MALL_BYTES
+    from lantern_amd import capi
 
     try:
         rng = np.random.default_rng(99)
-        q = rng.standard_normal(ix.dims, dtype=np.float32) if ix.metric != capi_mod().METRIC_HAMMING else rng.integers(0, 2**32, ix.dims, dtype=np.uint32)
+        q = rng.standard_normal(ix.dims, dtype=np.float32) if ix.metric != capi.METRIC_HAMMING else rng.integers(0, 2**32, ix.dims, dtype=np.uint32)
         old = os.environ.get("LANTERN_GPU_GATHER_WALKSHAPE")
         os.environ["LANTERN_GPU_GATHER_WALKSHAPE"] = "1"
         ms = []
@@ -761,12 +762,6 @@ def gather_ceiling(ix, rows, row_bytes, evaluations, launches=3):
         return out
     except Exception as ex:  # noqa: BLE001 -- the ceiling never costs the line
         return {"error": repr(ex)[:300]}
-
-
-def capi_mod():
-    from lantern_amd import capi
-
-    return capi
 
 
 def roofline(achieved_alg, traffic, traffic_src, launch_s, bytes_per_launch, avg_kernel_s, S, B, adc=False, measured_here=False, pmc_detail=None,
