@@ -98,6 +98,7 @@ def parse():
                    "configuration): by default, when rocprofv3 is on PATH, the search leg is re-executed under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
                    "(two short passes restricted to k_search) after the timed region and roofline.traffic is THIS run's")
     p.add_argument("--pmc-steps", type=int, default=4, help="search launches per counter pass")
+    p.add_argument("--no-two-in-flight", action="store_true", help="skip two_launches_in_flight (the same steps alternating over two streams)")
     p.add_argument("--no-gather-ceiling", action="store_true", help="skip roofline.gather (the random-row fetch rate of this box, three launches of k_gather_walkshape)")
     p.add_argument("--no-dram-model", action="store_true", help="skip roofline.dram_bytes_model (two traced launches + the LRU replay of their traces)")
     p.add_argument("--no-secondary", action="store_true", help="skip the `secondary` array (bench_secondary.py: BASELINE configs [1] and [2], the clustered set, the "
@@ -396,6 +397,27 @@ def main():
     log(f"timed region done: {a.steps} steps in {elapsed:.3f}s")
     if rdv:
         elapsed = rdv.max_float(elapsed)
+    # ---- the same steps with TWO launches in flight (independent batches on two streams: the tail of one launch, where the last walks
+    # finish on a half-empty device, is filled by the next one).  Reported beside `value`, never as `value`: the contract's roofline is
+    # defined per launch, and launches that share the device stretch each other's durations.
+    two_in_flight = None
+    if world == 1 and S == 1 and B >= 2 and not a.pmc_child and not a.no_two_in_flight:
+        st2 = [streams[0], hip.Stream()]
+
+        def step2(i):
+            L = lanes[i % B]
+            ix.search_batch_device(L["dq"].ptr, nq, a.k, a.ef, 0, L["lab"].ptr, L["dist"].ptr, L["slot"].ptr, None, L["D"].ptr, L["E"].ptr, st2[i % 2].handle,
+                                   query_stride=q_stride)
+        for i in range(2):  # (the second launch slot's visited bitmaps are allocated on first use)
+            step2(i)
+        barrier()
+        t2 = time.perf_counter()
+        for i in range(a.steps):
+            step2(i)
+        barrier()
+        el2 = time.perf_counter() - t2
+        two_in_flight = {"value": nq * a.steps / el2, "unit": "queries/s", "ms_per_step": el2 / a.steps * 1e3, "over_one_in_flight": elapsed / el2,
+                         "note": "the same K steps alternating over two streams (two launches in flight, independent batches); per-launch durations overlap, so no per-launch roofline"}
     if a.pmc_child:  # a counter pass of measure_traffic(): the launches above are what rocprofv3 counted
         print(json.dumps({"pmc_child": True, "checksum": f"{ix.checksum():016x}", "launches": max(a.warmup, B) + a.steps, "queries_per_launch": nq}), flush=True)
         return
@@ -513,6 +535,7 @@ def main():
                                  gather=gather),
             "cpu_baseline": cpu,
             "pq": pq_info,
+            "two_launches_in_flight": two_in_flight,
             "build_quality": quality,
             "collective_build": collective,
             "setup_seconds": {"datagen": t_gen, "build": t_build, "exact_truth": t_truth},
@@ -1003,6 +1026,23 @@ def clustered_coheadline(a, capi, hip, quality):
     lanes = resident(ix, all_queries, nq)
     steps = max(8, min(b.steps, 12))
     step, elapsed, launch_s, bytes_l, exp_l, per_lane = timed(ix, lanes, nq, steps, st)
+    two_in_flight = None
+    if not b.no_two_in_flight:  # the same steps alternating over two streams (bench main: two_launches_in_flight)
+        st2 = [st, hip.Stream()]
+
+        def step2(i):
+            L = lanes[i % len(lanes)]
+            ix.search_batch_device(L["dq"].ptr, nq, b.k, b.ef, 0, L["lab"].ptr, L["dist"].ptr, L["slot"].ptr, None, L["D"].ptr, L["E"].ptr, st2[i % 2].handle,
+                                   query_stride=L["stride"])
+        for i in range(2):
+            step2(i)
+        hip.synchronize()
+        t2 = time.perf_counter()
+        for i in range(steps):
+            step2(i)
+        hip.synchronize()
+        el2 = time.perf_counter() - t2
+        two_in_flight = {"value": nq * steps / el2, "unit": "queries/s", "ms_per_step": el2 / steps * 1e3, "over_one_in_flight": elapsed / el2}
     tq = min(b.truth_queries, nq)
     truth = ix.exact_search(all_queries[:tq], b.k)[0]
     found = lanes[0]["slot"].download((nq, b.k), np.uint32)
@@ -1019,6 +1059,7 @@ def clustered_coheadline(a, capi, hip, quality):
     qps = nq * steps / elapsed
     out = {"workload": f"HNSW search {n}x{d} f32 {b.metric} M={b.M} ef_construction={b.efc} ef={b.ef} k={b.k}, {nq}-query batches resident in HBM",
            "data": "synthetic (clustered: " + synth.CLUSTERED_DOC + ")", "value": qps, "unit": "queries/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+           "two_launches_in_flight": two_in_flight,
            f"recall_at_{b.k}": recall, "recall_queries": tq, "dist_evals_per_query": float(per_lane[0][0].mean()), "expansions_per_query": float(per_lane[0][1].mean()),
            "roofline": roofline(bytes_l / launch_s / 1e9, traffic, src, launch_s, bytes_l, launch_s, 1, B, measured_here=traffic is not None, pmc_detail=pmc, unique=unique,
                                 row_bytes=d * 4, list_bytes=2 * b.M * 4, expansions_per_launch=exp_l, model=model,
