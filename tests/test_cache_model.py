@@ -141,3 +141,18 @@ def test_dropped_entries_are_reported(cm):
     ct = np.array([4, 9, 2], dtype=np.uint32)
     got = cm.replay([tr], [ct], walkers=2, row_bytes=ROW, list0_bytes=LIST0, listu_bytes=LISTU)[0]
     assert got["dropped_entries"] == 5 and got["accesses"] == 4 + 4 + 2
+
+
+def test_uniformly_random_gather_misses_the_infinity_cache_one_minus_c_over_t_of_the_time(cm):
+    """bench.py gather_ceiling() takes the DRAM share of its whole-table gather as 1 - C / T (C: the Infinity Cache, T: the table)
+    instead of replaying the 17 M-entry trace in every run: the model gives that figure on a scaled-down case (and gave 0.9126 on the
+    full one: profiles/r06_cache_model_calibration.md)."""
+    rng = np.random.default_rng(5)
+    rows, walkers, per_walker = 20_000, 64, 6_000   # T = 61.4 MB of 3 KiB rows
+    mall, l2 = 16 << 20, 256 << 10                   # C = 16 MiB behind eight small L2s
+    launches = [as_launch([rng.integers(0, rows, per_walker).astype(np.uint32) for _ in range(walkers)]) for _ in range(2)]
+    res = cm.replay([t for t, _ in launches], [c for _, c in launches], walkers, ROW, LIST0, LISTU, l2_bytes_per_xcd=l2, mall_bytes=mall)
+    warm = res[1]  # the second launch finds the caches as the first left them
+    share = warm["dram_bytes"] / warm["access_bytes"]
+    assert abs(share - (1.0 - mall / (rows * ROW))) < 0.02, share
+    assert warm["fabric_bytes"] / warm["access_bytes"] > 0.95  # the L2s (2 MiB in all) catch next to nothing of it
